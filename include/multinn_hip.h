@@ -1,0 +1,186 @@
+/* libmultinn_hip -- C ABI of the MI355X-native LSTM-NADE / LSTM-RBM hot path of ilya16/MultINN.
+ *
+ * Conventions:
+ *   - every function returns 0 (MNN_OK) or a negative error code; mnn_last_error() gives a
+ *     thread-local message for the last failure on the calling thread;
+ *   - every pointer is a CALLER-OWNED DEVICE pointer (e.g. a torch allocation); the library
+ *     never allocates or frees user tensors; scratch is a caller-provided workspace whose size
+ *     comes from the matching *_workspace_bytes() query;
+ *   - every call takes a hipStream_t (as void*) and is asynchronous on that stream;
+ *   - no global mutable state; RNG is passed as (seed, row0, sub) -- never global;
+ *   - dtypes are explicit enums; "T" operands are bf16 or f32 (mnn_dtype).
+ *
+ * Each entry cites the reference interface it replaces as file:line under
+ * /root/reference/multinn (ilya16/MultINN).
+ */
+#ifndef MULTINN_HIP_H
+#define MULTINN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNN_OK 0
+#define MNN_ERR_INVALID (-1)
+#define MNN_ERR_HIP (-2)
+
+typedef void* mnn_stream_t; /* hipStream_t */
+
+typedef enum { MNN_F32 = 0, MNN_BF16 = 1, MNN_U8 = 2 } mnn_dtype;
+
+/* RNG streams of the build's Philox4x32-10 contract (DESIGN.md "RNG contract") */
+enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_STREAM_RBM_V = 3,
+       MNN_STREAM_DBN_ENC = 4, MNN_STREAM_DBN_DEC = 5 };
+
+int mnn_version(void);
+const char* mnn_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense contractions on MFMA.   C[M,N] (op)= A[M,K] . B[N,K]^T (+ bias[N])
+ * Both operands are K-contiguous ("TN" GEMM): A row-major [M,K] (lda), B row-major [N,K] (ldb).
+ * dtype = MNN_BF16 (v_mfma_f32_32x32x16_bf16) or MNN_F32 (v_mfma_f32_32x32x2_f32, exact f32 fma
+ * chain).  C is f32 unless c_dtype says bf16.  K, lda, ldb must be multiples of 8 (bf16) / 4 (f32).
+ * flags: bit0 accumulate into C (C += ...), bit1 atomic accumulate (split-K, split>1).
+ * Replaces: tf.matmul / tf.layers.Dense / LSTMBlockCell GEMMs -- rnn.py:124, rnn_nade.py:54-57,
+ *           rnn_rbm.py:252-253, and their autodiff (generator.py:176-205).
+ * ------------------------------------------------------------------------------------------ */
+#define MNN_GEMM_ACCUMULATE 1
+#define MNN_GEMM_ATOMIC 2
+int mnn_gemm_tn(mnn_stream_t s, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                void* C, int ldc, int c_dtype, const float* bias, int flags, int split_k);
+
+/* out[C,R] = in[R,C]^T with dtype conversion (in_dtype -> out_dtype in {f32,bf16,u8->f32/bf16});
+ * used to build K-contiguous operands for weight-gradient GEMMs and transposed weight copies. */
+int mnn_transpose(mnn_stream_t s, const void* in, int in_dtype, int R, int C, int ld_in, void* out, int out_dtype, int ld_out);
+
+/* dst[r, c] = convert(src[r, c]) (2-D strided copy/convert; f32<->bf16, u8->f32/bf16) */
+int mnn_convert2d(mnn_stream_t s, const void* src, int src_dtype, int ld_src, void* dst, int dst_dtype, int ld_dst, int R, int C);
+
+/* ------------------------------------------------------------------------------------------
+ * Piano-roll plumbing.
+ * mnn_pianoroll_shift_timemajor: x u8 [B,T,D] (joint view of [B,T,P,M], feature p*M+m)
+ *   -> inputs  T-dtype [T,B,ld_in]   inputs[t,b,:]  = x[b,t-1,:] (zeros at t=0, zero pad to ld_in)
+ *   -> targets u8      [T,B,D]       targets[t,b,:] = x[b,t,:]
+ *   -> row_weight f32  [T*B]         1/sum(lengths) if t<lengths[b] else 0   (lengths may be NULL)
+ * Replaces: multinn_joint.py:83-89,132-139 (zero pad + inputs/targets slicing) and the row
+ *           selection of utils/sequences.py:6-37 (as a weight mask; row order is time-major).
+ * n_valid_total: sum of lengths over ALL ranks (data parallel); 0 -> computed from this batch.
+ * ------------------------------------------------------------------------------------------ */
+int mnn_pianoroll_shift_timemajor(mnn_stream_t s, const uint8_t* x, int B, int T, int D, const int32_t* lengths,
+                                  void* inputs, int in_dtype, int ld_in, uint8_t* targets, float* row_weight,
+                                  long n_valid_total);
+
+/* per-track variant: targets_tracks u8 [M,T,B,P] from x u8 [B,T,P,M]  (multi_encoder_nn.py:66-76) */
+int mnn_pianoroll_split_tracks(mnn_stream_t s, const uint8_t* x, int B, int T, int P, int M, uint8_t* targets_tracks);
+
+/* ------------------------------------------------------------------------------------------
+ * LSTM (tf.contrib.cudnn_rnn.CudnnCompatibleLSTMCell == LSTMBlockCell, gate order i,ci,f,o,
+ * forget_bias 0; rnn.py:104-145).  Internal pre-activation layout is gate-interleaved:
+ * column (unit/32)*128 + gate*32 + unit%32; units must be a multiple of 32.
+ *
+ * mnn_lstm_pack_weights: natural TF kernel W[(in+u),4u] f32 + bias[4u] ->
+ *   wx_t  T [4u, ld_in]   (permuted rows, K-contiguous; input-projection B operand)
+ *   wh_t  T [4u, u]       (permuted rows; recurrent B operand)
+ *   wh_p  T [u, 4u]       (permuted columns; recurrent dgrad B operand)
+ *   wx_p  T [in, 4u]      (permuted columns; input dgrad B operand)  (may be NULL)
+ *   bias_p f32 [4u]       (permuted)
+ * ------------------------------------------------------------------------------------------ */
+int mnn_lstm_pack_weights(mnn_stream_t s, const float* W, const float* bias, int n_in, int units, int dtype, int ld_in,
+                          void* wx_t, void* wh_t, void* wh_p, void* wx_p, float* bias_p);
+
+/* scatter-add the gate-interleaved gradient (dWx_t[4u,ld_in] f32, dWh_t[4u,u] f32, db_p[4u]) back
+ * into the natural TF layout dW[(in+u),4u], db[4u] (accumulating). */
+int mnn_lstm_unpack_grads(mnn_stream_t s, const float* dwx_t, const float* dwh_t, const float* db_p, int n_in, int units,
+                          int ld_in, float* dW, float* db);
+
+/* One layer over a whole sequence, time-major.  xproj f32 [T,B,4u] = inputs . Wx + b (already
+ * computed with mnn_gemm_tn).  Runs T fused {recurrent GEMM + gate pointwise} kernels.
+ *   h0,c0 may be NULL (zero state, rnn.py:155-176).
+ *   gates f32 [T,B,4u] (post-activation i,g,f,o; saved for backward; may be NULL for inference)
+ *   c f32 [T,B,u], h T [T,B,u]
+ * Replaces: dynamic_decode/dynamic_rnn over the cell -- rnn_nade.py:204-218, rnn_rbm.py:217-223. */
+int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int units, const float* xproj, const void* wh_t,
+                     const void* h0, const float* c0, float* gates, float* c, void* h);
+
+/* BPTT for one layer.  dh_ext f32 [T,B,u] (gradient arriving at h_t from above),
+ * dz f32 [T,B,4u] out (gate-interleaved pre-activation gradient), dh0/dc0 f32 [B,u] out (may be NULL).
+ * workspace: mnn_lstm_seq_bwd_workspace_bytes(B, units). */
+size_t mnn_lstm_seq_bwd_workspace_bytes(int B, int units);
+int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int units, const float* dh_ext, const void* wh_p,
+                     const float* gates, const float* c, const float* c0, float* dz, void* dz_T /* T copy of dz or NULL */,
+                     float* dh0, float* dc0, void* workspace);
+
+/* Output dropout of DropoutWrapper (rnn.py:132): y = h/kp * floor(kp+u), u = Philox(stream 0,
+ * row = row0+b, sub = (t<<8)|layer, elem = unit).  h,y T [T,B,u].  kp>=1 -> copy. */
+int mnn_dropout_fwd(mnn_stream_t s, int dtype, const void* h, void* y, int T, int B, int units, float keep_prob,
+                    uint64_t seed, uint32_t row0, int layer);
+/* dh[t,b,j] (+)= dy[t,b,j]/kp*keep  (f32 in/out, mask recomputed) */
+int mnn_dropout_bwd(mnn_stream_t s, const float* dy, float* dh, int T, int B, int units, float keep_prob, uint64_t seed,
+                    uint32_t row0, int layer, int accumulate);
+
+/* ------------------------------------------------------------------------------------------
+ * NADE (models/common/nade.py).  Weights w_enc,w_dec f32 [tracks,D,Hn].  Rows: v u8
+ * [tracks][N][D] (track stride v_track_stride, row stride D); biases come from one Dense output
+ * matrix `bias` f32 [N, ld_bias]: b_enc of track m at column m*Hn, b_dec at tracks*Hn + m*D
+ * (rnn_nade.py:245; rnn_multinade.py:242-249).  Hn <= 256.
+ *
+ * mnn_nade_logprob_fwd (nade.py:155-229): nll f32 [tracks,N], cond_p f32 [tracks,N,D];
+ *   if row_weight != NULL also dl f32 [N, ld_bias] columns tracks*Hn.. := d(sum_n w[n]*nll)/d b_dec.
+ * mnn_nade_logprob_bwd: reverse scan -> d_bias[:, m*Hn..] (= d b_enc), d_w_enc, d_w_dec f32
+ *   [tracks,D,Hn] (ACCUMULATED with atomics: zero them first).
+ * mnn_nade_sample (nade.py:231-308): deterministic-order kernel, Bernoulli u < sigmoid(l/T);
+ *   u = Philox(stream 1, row = row0+n, sub, elem = m*D+i); temperature <= 0 -> threshold 0.5.
+ * ------------------------------------------------------------------------------------------ */
+int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
+                         const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* row_weight,
+                         float* nll, float* cond_p, float* d_bias);
+int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
+                         const float* bias, int ld_bias, const float* w_enc, const float* w_dec, float* d_bias,
+                         float* d_w_enc, float* d_w_dec);
+int mnn_nade_sample(mnn_stream_t s, int tracks, int N, int D, int Hn, const float* bias, int ld_bias, const float* w_enc,
+                    const float* w_dec, float temperature, uint64_t seed, uint32_t row0, uint32_t sub, uint8_t* samples,
+                    long s_track_stride, int s_row_stride, int s_elem_stride, float* nll);
+
+/* ------------------------------------------------------------------------------------------
+ * RBM (models/common/rbm.py).  W f32 [D,Hn]; bh f32 [N or 1, Hn] (ld_bh = 0 broadcasts one row);
+ * bv likewise.  Deterministic summation order (ascending index) for bit-exact sampling.
+ * mnn_rbm_gibbs (rbm.py:192-231): k steps from v0 u8 [N,D]; p_v f32 [N,D], v_out u8 [N,D];
+ *   uniforms Philox(stream 2/3, row = row_ids ? row_ids[n] : row0+n, sub = sub0+it, elem = j / d).
+ * mnn_rbm_hidden (rbm.py:148-167,337-353): p_h f32 [N,Hn]; h u8 [N,Hn] sampled with `stream`
+ *   (either may be NULL).  mnn_rbm_visible (rbm.py:169-190,355-373) likewise.
+ * mnn_rbm_free_energy (rbm.py:256-258, per-row, R4): F f32 [N].
+ * workspace for gibbs/visible: mnn_rbm_workspace_bytes(D,Hn) (transposed W copy).
+ * ------------------------------------------------------------------------------------------ */
+size_t mnn_rbm_workspace_bytes(int D, int Hn);
+int mnn_rbm_gibbs(mnn_stream_t s, int N, int D, int Hn, int k, const uint8_t* v0, const float* W, const float* bh, int ld_bh,
+                  const float* bv, int ld_bv, uint64_t seed, uint32_t row0, const uint32_t* row_ids, uint32_t sub0,
+                  float* p_v, uint8_t* v_out, void* workspace);
+int mnn_rbm_hidden(mnn_stream_t s, int N, int D, int Hn, const void* v, int v_dtype, const float* W, const float* bh,
+                   int ld_bh, int stream_id, uint64_t seed, uint32_t row0, uint32_t sub, float* p_h, uint8_t* h);
+int mnn_rbm_visible(mnn_stream_t s, int N, int D, int Hn, const void* h, int h_dtype, const float* W, const float* bv,
+                    int ld_bv, int stream_id, uint64_t seed, uint32_t row0, uint32_t sub, float* p_v, uint8_t* v,
+                    void* workspace);
+int mnn_rbm_free_energy(mnn_stream_t s, int N, int D, int Hn, const uint8_t* v, const float* W, const float* bh, int ld_bh,
+                        const float* bv, int ld_bv, float* F);
+
+/* ------------------------------------------------------------------------------------------
+ * Reductions / optimiser on the flat parameter buffer.
+ * mnn_sumsq: out[0] += sum(x^2) (f32 atomic; zero first).  mnn_weighted_sum: out[0] += sum w*x.
+ * mnn_clip_adam_step (utils/training.py:163-175 + train.py:64): scale = clip*min(1/gn,1/clip) with
+ *   gn = sqrt(*sumsq) read ON DEVICE; TF Adam with epsilon outside the bias correction;
+ *   `step` is the 1-based step count.  sgd != 0 -> plain SGD (train.py:61-62).
+ * ------------------------------------------------------------------------------------------ */
+int mnn_sumsq(mnn_stream_t s, const float* x, long n, float* out);
+int mnn_weighted_sum(mnn_stream_t s, const float* x, const float* w, long n, float* out);
+int mnn_clip_adam_step(mnn_stream_t s, float* theta, const float* grad, float* m, float* v, long n, const float* sumsq,
+                       float clip_norm, float lr, float beta1, float beta2, float eps, int step, int sgd);
+int mnn_bias_grad(mnn_stream_t s, const float* dY, int rows, int cols, int ld, float* db, int accumulate);
+int mnn_fill_f32(mnn_stream_t s, float* x, long n, float value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MULTINN_HIP_H */

@@ -1,0 +1,81 @@
+"""ctypes loader for the C-ABI library (include/multinn_hip.h).
+
+The product path has NO CPU fallback: if ``libmultinn_hip.so`` is missing or a call fails,
+a ``RuntimeError`` is raised.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmultinn_hip.so")
+
+F32, BF16, U8 = 0, 1, 2
+GEMM_ACCUMULATE, GEMM_ATOMIC = 1, 2
+
+_p, _i, _l, _f, _u64, _u32, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_uint32, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/multinn_hip.h one to one
+SIGNATURES = {
+    "mnn_version": (_i, []),
+    "mnn_last_error": (C.c_char_p, []),
+    "mnn_gemm_tn": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _i]),
+    "mnn_transpose": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _i]),
+    "mnn_convert2d": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i]),
+    "mnn_pianoroll_shift_timemajor": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _l]),
+    "mnn_pianoroll_split_tracks": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "mnn_lstm_pack_weights": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "mnn_lstm_unpack_grads": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "mnn_lstm_seq_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "mnn_lstm_seq_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "mnn_lstm_seq_bwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "mnn_dropout_fwd": (_i, [_p, _i, _p, _p, _i, _i, _i, _f, _u64, _u32, _i]),
+    "mnn_dropout_bwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _u64, _u32, _i, _i]),
+    "mnn_nade_logprob_fwd": (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "mnn_nade_logprob_bwd": (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p]),
+    "mnn_nade_sample": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _f, _u64, _u32, _u32, _p, _l, _i, _i, _p]),
+    "mnn_rbm_workspace_bytes": (_sz, [_i, _i]),
+    "mnn_rbm_gibbs": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _u64, _u32, _p, _u32, _p, _p, _p]),
+    "mnn_rbm_hidden": (_i, [_p, _i, _i, _i, _p, _i, _p, _p, _i, _i, _u64, _u32, _u32, _p, _p]),
+    "mnn_rbm_visible": (_i, [_p, _i, _i, _i, _p, _i, _p, _p, _i, _i, _u64, _u32, _u32, _p, _p, _p]),
+    "mnn_rbm_free_energy": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p]),
+    "mnn_sumsq": (_i, [_p, _p, _l, _p]),
+    "mnn_weighted_sum": (_i, [_p, _p, _p, _l, _p]),
+    "mnn_clip_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _f, _i, _i]),
+    "mnn_bias_grad": (_i, [_p, _p, _i, _i, _i, _p, _i]),
+    "mnn_fill_f32": (_i, [_p, _p, _l, _f]),
+}
+
+_lib = None
+
+
+class MnnError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmultinn_hip.so and bind every symbol of include/multinn_hip.h.  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MnnError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(multinn_amd has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise MnnError(f"{what} failed ({rc}): {load().mnn_last_error().decode()}")
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise MnnError on a non-zero code."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise MnnError(f"{name} failed ({rc}): {lib.mnn_last_error().decode()}")

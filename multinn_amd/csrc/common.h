@@ -1,0 +1,124 @@
+// Shared device/host helpers for libmultinn_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/multinn_hip.h"
+
+// ----------------------------------------------------------------------------------------------
+// error handling: every C-ABI entry returns 0 or <0 and records a thread-local message
+// ----------------------------------------------------------------------------------------------
+void mnn_set_error(const char* fmt, ...);
+
+#define MNN_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            mnn_set_error(__VA_ARGS__);        \
+            return MNN_ERR_INVALID;            \
+        }                                      \
+    } while (0)
+
+#define MNN_HIP(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            mnn_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return MNN_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+#define MNN_LAUNCH_CHECK() MNN_HIP(hipGetLastError())
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ----------------------------------------------------------------------------------------------
+// bf16 <-> f32 (round-to-nearest-even via the hardware cast; NaN stays NaN)
+// ----------------------------------------------------------------------------------------------
+typedef uint16_t bf16_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
+}
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+    __device__ static __forceinline__ float load(float x) { return x; }
+    __device__ static __forceinline__ float store(float x) { return x; }
+};
+template <> struct Cvt<bf16_t> {
+    __device__ static __forceinline__ float load(bf16_t x) { return bf16_to_f32(x); }
+    __device__ static __forceinline__ bf16_t store(float x) { return f32_to_bf16(x); }
+};
+
+// ----------------------------------------------------------------------------------------------
+// fast math (throughput paths; tolerance-checked against the oracle)
+// ----------------------------------------------------------------------------------------------
+#define MNN_LOG2E 1.4426950408889634f
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + fast_exp2(-MNN_LOG2E * x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * fast_rcp(1.0f + fast_exp2(-2.0f * MNN_LOG2E * x)) - 1.0f; }
+
+// ----------------------------------------------------------------------------------------------
+// deterministic math (sampling paths; bit-identical to oracle/det_ref.c, which restates the same
+// specification with IEEE fma/mul/add/div only).  DESIGN.md "Deterministic sigmoid".
+// ----------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ float det_exp(float x) {
+    // exp(x) for x in [-87, 87]: n = floor(x*log2e + 0.5); r = x - n*ln2 (two-term); degree-6 Horner; scale by 2^n.
+    x = x < -87.0f ? -87.0f : (x > 87.0f ? 87.0f : x);
+    const float n = floorf(fmaf(x, 1.4426950408889634f, 0.5f));
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.3888889225e-3f;                 // 1/720
+    p = fmaf(p, r, 8.3333337680e-3f);           // 1/120
+    p = fmaf(p, r, 4.1666667908e-2f);           // 1/24
+    p = fmaf(p, r, 1.6666667163e-1f);           // 1/6
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    const int e = (int)n + 127;                 // 40..213 -> normal
+    union { uint32_t u; float f; } s;
+    s.u = ((uint32_t)e) << 23;
+    return p * s.f;
+}
+__host__ __device__ __forceinline__ float det_sigmoid(float x) { return 1.0f / (1.0f + det_exp(-x)); }
+
+// ----------------------------------------------------------------------------------------------
+// Philox4x32-10 (RNG contract: DESIGN.md; oracle/philox.py)
+// ----------------------------------------------------------------------------------------------
+struct Philox4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ float bits_to_uniform(uint32_t x) { return __uint_as_float((x & 0x7FFFFFu) | 0x3F800000u) - 1.0f; }
+
+// four uniforms for elements 4q..4q+3 of (row, sub) on `stream`
+__device__ __forceinline__ void philox_uniform4(uint64_t seed, uint32_t stream, uint32_t row, uint32_t sub, uint32_t q, float u[4]) {
+    const Philox4 r = philox4x32_10(q, row, sub, stream, (uint32_t)seed, (uint32_t)(seed >> 32));
+    u[0] = bits_to_uniform(r.x); u[1] = bits_to_uniform(r.y); u[2] = bits_to_uniform(r.z); u[3] = bits_to_uniform(r.w);
+}
+__device__ __forceinline__ float philox_uniform1(uint64_t seed, uint32_t stream, uint32_t row, uint32_t sub, uint32_t elem) {
+    const Philox4 r = philox4x32_10(elem >> 2, row, sub, stream, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t w = elem & 3u;
+    return bits_to_uniform(w == 0 ? r.x : (w == 1 ? r.y : (w == 2 ? r.z : r.w)));
+}
+
+// gate-interleaved column index of the LSTM pre-activation space (DESIGN.md "LSTM layout"):
+// natural TF column g*u + unit  ->  (unit/32)*128 + g*32 + unit%32
+__host__ __device__ __forceinline__ int gate_perm_col(int g, int unit) { return (unit >> 5) * 128 + g * 32 + (unit & 31); }

@@ -1,0 +1,405 @@
+// HBM-bound plumbing kernels: layout changes, dropout, reductions, optimiser.
+#include <stdarg.h>
+
+#include "common.h"
+
+// ----------------------------------------------------------------------------------------------
+// housekeeping
+// ----------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void mnn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* mnn_last_error(void) { return g_err; }
+extern "C" int mnn_version(void) { return 100; }
+
+template <typename T> __device__ __forceinline__ float ld_as_f32(const T* p, size_t i);
+template <> __device__ __forceinline__ float ld_as_f32<float>(const float* p, size_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ld_as_f32<bf16_t>(const bf16_t* p, size_t i) { return bf16_to_f32(p[i]); }
+template <> __device__ __forceinline__ float ld_as_f32<uint8_t>(const uint8_t* p, size_t i) { return (float)p[i]; }
+template <typename T> __device__ __forceinline__ void st_from_f32(T* p, size_t i, float v);
+template <> __device__ __forceinline__ void st_from_f32<float>(float* p, size_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void st_from_f32<bf16_t>(bf16_t* p, size_t i, float v) { p[i] = f32_to_bf16(v); }
+
+// ----------------------------------------------------------------------------------------------
+// transpose with conversion: out[c, r] = in[r, c]; 32x32 tiles through LDS (+1 pad)
+// ----------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) transpose_kernel(const TI* __restrict__ in, int R, int C, int ld_in, TO* __restrict__ out, int ld_out) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + k * 8, c = c0 + tx;
+        tile[ty + k * 8][tx] = (r < R && c < C) ? ld_as_f32<TI>(in, (size_t)r * ld_in + c) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + k * 8, r = r0 + tx;
+        if (c < C && r < R) st_from_f32<TO>(out, (size_t)c * ld_out + r, tile[tx][ty + k * 8]);
+    }
+}
+
+template <typename TI, typename TO>
+static int launch_transpose(hipStream_t st, const void* in, int R, int C, int ld_in, void* out, int ld_out) {
+    dim3 grid(cdiv(C, 32), cdiv(R, 32));
+    hipLaunchKernelGGL((transpose_kernel<TI, TO>), grid, dim3(256), 0, st, (const TI*)in, R, C, ld_in, (TO*)out, ld_out);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+extern "C" int mnn_transpose(mnn_stream_t s, const void* in, int in_dtype, int R, int C, int ld_in, void* out, int out_dtype, int ld_out) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(in && out && R > 0 && C > 0 && ld_in >= C && ld_out >= R, "mnn_transpose: bad arguments R=%d C=%d ld_in=%d ld_out=%d", R, C,
+                ld_in, ld_out);
+    MNN_REQUIRE(out_dtype == MNN_F32 || out_dtype == MNN_BF16, "mnn_transpose: out dtype must be f32/bf16");
+#define TR(TI) (out_dtype == MNN_F32 ? launch_transpose<TI, float>(st, in, R, C, ld_in, out, ld_out) \
+                                      : launch_transpose<TI, bf16_t>(st, in, R, C, ld_in, out, ld_out))
+    if (in_dtype == MNN_F32) return TR(float);
+    if (in_dtype == MNN_BF16) return TR(bf16_t);
+    if (in_dtype == MNN_U8) return TR(uint8_t);
+#undef TR
+    mnn_set_error("mnn_transpose: unknown in dtype %d", in_dtype);
+    return MNN_ERR_INVALID;
+}
+
+template <typename TI, typename TO>
+__global__ void convert2d_kernel(const TI* __restrict__ src, int ld_src, TO* __restrict__ dst, int ld_dst, int R, int C) {
+    const long n = (long)R * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / C), c = (int)(i % C);
+        st_from_f32<TO>(dst, (size_t)r * ld_dst + c, ld_as_f32<TI>(src, (size_t)r * ld_src + c));
+    }
+}
+
+extern "C" int mnn_convert2d(mnn_stream_t s, const void* src, int src_dtype, int ld_src, void* dst, int dst_dtype, int ld_dst, int R, int C) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(src && dst && R > 0 && C > 0 && ld_src >= C && ld_dst >= C, "mnn_convert2d: bad arguments");
+    MNN_REQUIRE(dst_dtype == MNN_F32 || dst_dtype == MNN_BF16, "mnn_convert2d: dst dtype must be f32/bf16");
+    const int blocks = (int)min((long)2048, ((long)R * C + 255) / 256);
+#define CV(TI)                                                                                                              \
+    do {                                                                                                                    \
+        if (dst_dtype == MNN_F32)                                                                                           \
+            hipLaunchKernelGGL((convert2d_kernel<TI, float>), dim3(blocks), dim3(256), 0, st, (const TI*)src, ld_src, (float*)dst, ld_dst, R, C); \
+        else                                                                                                                \
+            hipLaunchKernelGGL((convert2d_kernel<TI, bf16_t>), dim3(blocks), dim3(256), 0, st, (const TI*)src, ld_src, (bf16_t*)dst, ld_dst, R, C); \
+    } while (0)
+    if (src_dtype == MNN_F32) CV(float);
+    else if (src_dtype == MNN_BF16) CV(bf16_t);
+    else if (src_dtype == MNN_U8) CV(uint8_t);
+    else { mnn_set_error("mnn_convert2d: unknown src dtype %d", src_dtype); return MNN_ERR_INVALID; }
+#undef CV
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// piano-roll plumbing (multinn_joint.py:83-89,132-139)
+// one block per (t, b) row; threads sweep the D features
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(128) pianoroll_shift_kernel(const uint8_t* __restrict__ x, int B, int Tn, int D,
+                                                             const int32_t* __restrict__ lengths, T* __restrict__ inputs, int ld_in,
+                                                             uint8_t* __restrict__ targets, float* __restrict__ row_weight,
+                                                             float inv_n) {
+    const int t = blockIdx.x / B, b = blockIdx.x % B;
+    const uint8_t* cur = x + ((size_t)b * Tn + t) * D;
+    const uint8_t* prev = t > 0 ? cur - D : nullptr;
+    T* in = inputs + (size_t)blockIdx.x * ld_in;
+    uint8_t* tg = targets ? targets + (size_t)blockIdx.x * D : nullptr;
+    for (int i = threadIdx.x; i < ld_in; i += blockDim.x) {
+        const float pv = (prev != nullptr && i < D) ? (float)prev[i] : 0.f;
+        st_from_f32<T>(in, i, pv);
+        if (tg != nullptr && i < D) tg[i] = cur[i];
+    }
+    if (threadIdx.x == 0 && row_weight != nullptr) row_weight[blockIdx.x] = (lengths == nullptr || t < lengths[b]) ? inv_n : 0.f;
+}
+
+extern "C" int mnn_pianoroll_shift_timemajor(mnn_stream_t s, const uint8_t* x, int B, int T, int D, const int32_t* lengths, void* inputs,
+                                             int in_dtype, int ld_in, uint8_t* targets, float* row_weight, long n_valid_total) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(x && inputs && B > 0 && T > 0 && D > 0 && ld_in >= D, "mnn_pianoroll_shift_timemajor: bad arguments");
+    MNN_REQUIRE(in_dtype == MNN_F32 || in_dtype == MNN_BF16, "mnn_pianoroll_shift_timemajor: inputs dtype must be f32/bf16");
+    MNN_REQUIRE(lengths == nullptr || n_valid_total > 0, "mnn_pianoroll_shift_timemajor: n_valid_total required with lengths");
+    const float inv_n = 1.0f / (float)(n_valid_total > 0 ? n_valid_total : (long)B * T);
+    if (in_dtype == MNN_F32)
+        hipLaunchKernelGGL(pianoroll_shift_kernel<float>, dim3(B * T), dim3(128), 0, st, x, B, T, D, lengths, (float*)inputs, ld_in, targets,
+                           row_weight, inv_n);
+    else
+        hipLaunchKernelGGL(pianoroll_shift_kernel<bf16_t>, dim3(B * T), dim3(128), 0, st, x, B, T, D, lengths, (bf16_t*)inputs, ld_in, targets,
+                           row_weight, inv_n);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+__global__ void __launch_bounds__(128) split_tracks_kernel(const uint8_t* __restrict__ x, int B, int Tn, int P, int M, uint8_t* __restrict__ out) {
+    const int t = blockIdx.x / B, b = blockIdx.x % B;
+    const uint8_t* src = x + ((size_t)b * Tn + t) * P * M;
+    for (int i = threadIdx.x; i < P * M; i += blockDim.x) {
+        const int p = i / M, m = i % M;
+        out[((size_t)m * Tn * B + blockIdx.x) * P + p] = src[i];
+    }
+}
+
+extern "C" int mnn_pianoroll_split_tracks(mnn_stream_t s, const uint8_t* x, int B, int T, int P, int M, uint8_t* targets_tracks) {
+    MNN_REQUIRE(x && targets_tracks && B > 0 && T > 0 && P > 0 && M > 0, "mnn_pianoroll_split_tracks: bad arguments");
+    hipLaunchKernelGGL(split_tracks_kernel, dim3(B * T), dim3(128), 0, (hipStream_t)s, x, B, T, P, M, targets_tracks);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// LSTM weight packing: natural TF kernel W[(in+u), 4u] -> gate-interleaved K-contiguous copies
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void lstm_pack_kernel(const float* __restrict__ W, const float* __restrict__ bias, int n_in, int U, int ld_in,
+                                 T* __restrict__ wx_t, T* __restrict__ wh_t, T* __restrict__ wh_p, T* __restrict__ wx_p,
+                                 float* __restrict__ bias_p) {
+    const int N4 = 4 * U;
+    const long total = (long)(n_in + U) * N4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i / N4), nat = (int)(i % N4);
+        const int g = nat / U, unit = nat % U;
+        const int pc = gate_perm_col(g, unit);
+        const float w = W[i];
+        if (k < n_in) {
+            st_from_f32<T>(wx_t, (size_t)pc * ld_in + k, w);
+            if (wx_p != nullptr) st_from_f32<T>(wx_p, (size_t)k * N4 + pc, w);
+        } else {
+            const int kk = k - n_in;
+            st_from_f32<T>(wh_t, (size_t)pc * U + kk, w);
+            st_from_f32<T>(wh_p, (size_t)kk * N4 + pc, w);
+        }
+        if (k == 0) bias_p[pc] = bias[nat];
+    }
+    // zero the K padding of wx_t
+    const long padtotal = (long)N4 * (ld_in - n_in);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < padtotal; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / (ld_in - n_in)), c = n_in + (int)(i % (ld_in - n_in));
+        st_from_f32<T>(wx_t, (size_t)r * ld_in + c, 0.f);
+    }
+}
+
+extern "C" int mnn_lstm_pack_weights(mnn_stream_t s, const float* W, const float* bias, int n_in, int units, int dtype, int ld_in,
+                                     void* wx_t, void* wh_t, void* wh_p, void* wx_p, float* bias_p) {
+    MNN_REQUIRE(W && bias && wx_t && wh_t && wh_p && bias_p, "mnn_lstm_pack_weights: null pointer");
+    MNN_REQUIRE(units > 0 && units % 32 == 0 && n_in > 0 && ld_in >= n_in, "mnn_lstm_pack_weights: units %% 32 != 0 or bad n_in/ld_in");
+    MNN_REQUIRE(dtype == MNN_F32 || dtype == MNN_BF16, "mnn_lstm_pack_weights: dtype must be f32/bf16");
+    const int blocks = (int)min((long)1024, ((long)(n_in + units) * 4 * units + 255) / 256);
+    if (dtype == MNN_F32)
+        hipLaunchKernelGGL(lstm_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, W, bias, n_in, units, ld_in, (float*)wx_t,
+                           (float*)wh_t, (float*)wh_p, (float*)wx_p, bias_p);
+    else
+        hipLaunchKernelGGL(lstm_pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, W, bias, n_in, units, ld_in, (bf16_t*)wx_t,
+                           (bf16_t*)wh_t, (bf16_t*)wh_p, (bf16_t*)wx_p, bias_p);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+__global__ void lstm_unpack_grads_kernel(const float* __restrict__ dwx_t, const float* __restrict__ dwh_t, const float* __restrict__ db_p,
+                                         int n_in, int U, int ld_in, float* __restrict__ dW, float* __restrict__ db) {
+    const int N4 = 4 * U;
+    const long total = (long)(n_in + U) * N4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i / N4), nat = (int)(i % N4);
+        const int pc = gate_perm_col(nat / U, nat % U);
+        const float g = k < n_in ? dwx_t[(size_t)pc * ld_in + k] : dwh_t[(size_t)pc * U + (k - n_in)];
+        dW[i] += g;
+        if (k == 0) db[nat] += db_p[pc];
+    }
+}
+
+extern "C" int mnn_lstm_unpack_grads(mnn_stream_t s, const float* dwx_t, const float* dwh_t, const float* db_p, int n_in, int units,
+                                     int ld_in, float* dW, float* db) {
+    MNN_REQUIRE(dwx_t && dwh_t && db_p && dW && db && units % 32 == 0 && ld_in >= n_in, "mnn_lstm_unpack_grads: bad arguments");
+    const int blocks = (int)min((long)1024, ((long)(n_in + units) * 4 * units + 255) / 256);
+    hipLaunchKernelGGL(lstm_unpack_grads_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, dwx_t, dwh_t, db_p, n_in, units, ld_in, dW, db);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// dropout (rnn.py:132 DropoutWrapper, output only): one Philox call per 4 consecutive units
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void dropout_fwd_kernel(const T* __restrict__ h, T* __restrict__ y, int Tn, int B, int U, float kp, uint64_t seed,
+                                   uint32_t row0, int layer) {
+    const int U4 = U >> 2;
+    const long total = (long)Tn * B * U4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % U4);
+        const long tb = i / U4;
+        const int b = (int)(tb % B), t = (int)(tb / B);
+        float u[4];
+        philox_uniform4(seed, MNN_STREAM_DROPOUT, row0 + (uint32_t)b, ((uint32_t)t << 8) | (uint32_t)layer, (uint32_t)q, u);
+        const size_t o = (size_t)tb * U + q * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float keep = floorf(kp + u[k]);
+            st_from_f32<T>(y, o + k, ld_as_f32<T>(h, o + k) / kp * keep);
+        }
+    }
+}
+
+extern "C" int mnn_dropout_fwd(mnn_stream_t s, int dtype, const void* h, void* y, int T, int B, int units, float keep_prob, uint64_t seed,
+                               uint32_t row0, int layer) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(h && y && T > 0 && B > 0 && units > 0 && units % 4 == 0, "mnn_dropout_fwd: bad arguments");
+    MNN_REQUIRE(dtype == MNN_F32 || dtype == MNN_BF16, "mnn_dropout_fwd: dtype must be f32/bf16");
+    MNN_REQUIRE(keep_prob > 0.f, "mnn_dropout_fwd: keep_prob must be > 0");
+    const size_t bytes = (size_t)T * B * units * (dtype == MNN_BF16 ? 2 : 4);
+    if (keep_prob >= 1.0f) {
+        if (h != y) MNN_HIP(hipMemcpyAsync(y, h, bytes, hipMemcpyDeviceToDevice, st));
+        return MNN_OK;
+    }
+    const int blocks = (int)min((long)4096, ((long)T * B * units / 4 + 255) / 256);
+    if (dtype == MNN_F32)
+        hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)h, (float*)y, T, B, units, keep_prob, seed,
+                           row0, layer);
+    else
+        hipLaunchKernelGGL(dropout_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)h, (bf16_t*)y, T, B, units, keep_prob,
+                           seed, row0, layer);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+__global__ void dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dh, int Tn, int B, int U, float kp, uint64_t seed,
+                                   uint32_t row0, int layer, int accumulate) {
+    const int U4 = U >> 2;
+    const long total = (long)Tn * B * U4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % U4);
+        const long tb = i / U4;
+        const int b = (int)(tb % B), t = (int)(tb / B);
+        float u[4] = {1.f, 1.f, 1.f, 1.f};
+        if (kp < 1.0f) philox_uniform4(seed, MNN_STREAM_DROPOUT, row0 + (uint32_t)b, ((uint32_t)t << 8) | (uint32_t)layer, (uint32_t)q, u);
+        const size_t o = (size_t)tb * U + q * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float g = kp < 1.0f ? dy[o + k] / kp * floorf(kp + u[k]) : dy[o + k];
+            dh[o + k] = accumulate ? dh[o + k] + g : g;
+        }
+    }
+}
+
+extern "C" int mnn_dropout_bwd(mnn_stream_t s, const float* dy, float* dh, int T, int B, int units, float keep_prob, uint64_t seed,
+                               uint32_t row0, int layer, int accumulate) {
+    MNN_REQUIRE(dy && dh && T > 0 && B > 0 && units > 0 && units % 4 == 0 && keep_prob > 0.f, "mnn_dropout_bwd: bad arguments");
+    const int blocks = (int)min((long)4096, ((long)T * B * units / 4 + 255) / 256);
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, dy, dh, T, B, units, keep_prob, seed, row0, layer,
+                       accumulate);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// reductions + optimiser (utils/training.py:163-175, train.py:61-64)
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float block_sum_256(float v) {
+    __shared__ float part[4];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    float acc = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc = fmaf(x[i], x[i], acc);
+    acc = block_sum_256(acc);
+    if (threadIdx.x == 0) atomicAdd(out, acc);
+}
+__global__ void __launch_bounds__(256) wsum_kernel(const float* __restrict__ x, const float* __restrict__ w, long n, float* __restrict__ out) {
+    float acc = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc = fmaf(x[i], w ? w[i] : 1.f, acc);
+    acc = block_sum_256(acc);
+    if (threadIdx.x == 0) atomicAdd(out, acc);
+}
+
+extern "C" int mnn_sumsq(mnn_stream_t s, const float* x, long n, float* out) {
+    MNN_REQUIRE(x && out && n > 0, "mnn_sumsq: bad arguments");
+    hipLaunchKernelGGL(sumsq_kernel, dim3((int)min(1024L, (n + 255) / 256)), dim3(256), 0, (hipStream_t)s, x, n, out);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+extern "C" int mnn_weighted_sum(mnn_stream_t s, const float* x, const float* w, long n, float* out) {
+    MNN_REQUIRE(x && out && n > 0, "mnn_weighted_sum: bad arguments");
+    hipLaunchKernelGGL(wsum_kernel, dim3((int)min(1024L, (n + 255) / 256)), dim3(256), 0, (hipStream_t)s, x, w, n, out);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+__global__ void clip_adam_kernel(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
+                                 long n, const float* __restrict__ sumsq, float clip, float lr_t, float lr, float b1, float b2, float eps,
+                                 int sgd) {
+    float scale = 1.f;
+    if (clip > 0.f && sumsq != nullptr) {
+        const float gn = sqrtf(sumsq[0]);
+        scale = gn > 0.f ? clip * fminf(1.0f / gn, 1.0f / clip) : 1.f;   // tf.clip_by_global_norm
+    }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float g = grad[i] * scale;
+        if (sgd) {
+            theta[i] -= lr * g;
+        } else {
+            const float mi = b1 * m[i] + (1.f - b1) * g;
+            const float vi = b2 * v[i] + (1.f - b2) * g * g;
+            m[i] = mi;
+            v[i] = vi;
+            theta[i] -= lr_t * mi / (sqrtf(vi) + eps);
+        }
+    }
+}
+
+extern "C" int mnn_clip_adam_step(mnn_stream_t s, float* theta, const float* grad, float* m, float* v, long n, const float* sumsq,
+                                  float clip_norm, float lr, float beta1, float beta2, float eps, int step, int sgd) {
+    MNN_REQUIRE(theta && grad && n > 0 && (sgd || (m && v)) && step >= 1, "mnn_clip_adam_step: bad arguments");
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+    hipLaunchKernelGGL(clip_adam_kernel, dim3((int)min(2048L, (n + 255) / 256)), dim3(256), 0, (hipStream_t)s, theta, grad, m, v, n, sumsq,
+                       clip_norm, (float)lr_t, lr, beta1, beta2, eps, sgd);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+// db[c] (+)= sum_r dY[r, c]; grid over column blocks of 64 x row slabs, atomics across slabs
+__global__ void __launch_bounds__(256) bias_grad_kernel(const float* __restrict__ dY, int rows, int cols, int ld, float* __restrict__ db) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < cols)
+        for (int r = blockIdx.y * 4 + w; r < rows; r += gridDim.y * 4) acc += dY[(size_t)r * ld + c];
+    part[w][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (w == 0 && c < cols) atomicAdd(db + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+extern "C" int mnn_bias_grad(mnn_stream_t s, const float* dY, int rows, int cols, int ld, float* db, int accumulate) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(dY && db && rows > 0 && cols > 0 && ld >= cols, "mnn_bias_grad: bad arguments");
+    if (!accumulate) MNN_HIP(hipMemsetAsync(db, 0, (size_t)cols * 4, st));
+    dim3 grid(cdiv(cols, 64), min(256, cdiv(rows, 64)));
+    hipLaunchKernelGGL(bias_grad_kernel, grid, dim3(256), 0, st, dY, rows, cols, ld, db);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+__global__ void fill_kernel(float* __restrict__ x, long n, float v) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = v;
+}
+extern "C" int mnn_fill_f32(mnn_stream_t s, float* x, long n, float value) {
+    MNN_REQUIRE(x && n > 0, "mnn_fill_f32: bad arguments");
+    hipLaunchKernelGGL(fill_kernel, dim3((int)min(2048L, (n + 255) / 256)), dim3(256), 0, (hipStream_t)s, x, n, value);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}

@@ -1,0 +1,399 @@
+// MFMA GEMM core for gfx950 + the fused LSTM step kernels built on it.
+//
+//   C[M,N] (op)= A[M,K] . B[N,K]^T        both operands K-contiguous
+//
+// T = bf16 -> v_mfma_f32_32x32x16_bf16 ; T = f32 -> v_mfma_f32_32x32x2_f32 (exact f32 fma chain).
+// Tiles are staged global -> registers -> LDS (double buffered); an LDS row holds one 64-byte
+// K-chunk (32 bf16 / 16 f32) padded to 80 bytes so that the 16 rows a ds_read_b128 lane group
+// touches fall on 16 distinct 16-byte slots (conflict-free, MI355X_MICROARCH "LDS").
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+#define LDS_ROW 80   // bytes per LDS tile row: 64 B of K + 16 B pad
+#define CHUNK_B 64   // bytes of K per row per stage
+
+template <typename T> struct Elem;
+template <> struct Elem<bf16_t> { static constexpr int PER16 = 8; static constexpr int PER_CHUNK = 32; };
+template <> struct Elem<float>  { static constexpr int PER16 = 4; static constexpr int PER_CHUNK = 16; };
+
+template <typename T, int BM, int BN, int WM, int WN>
+struct GemmCore {
+    static constexpr int NT = WM * WN * 64;
+    static constexpr int TM = BM / WM / 32;
+    static constexpr int TN = BN / WN / 32;
+    static constexpr int A_CHUNKS = BM * 4 / NT;   // 16-byte pieces per thread per stage
+    static constexpr int B_CHUNKS = BN * 4 / NT;
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * LDS_ROW;
+    static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile/wave mismatch");
+    static_assert((BM * 4) % NT == 0 && (BN * 4) % NT == 0, "staging mismatch");
+
+    uint4 ra[A_CHUNKS], rb[B_CHUNKS];
+
+    __device__ __forceinline__ void gload(const T* __restrict__ A, int lda, int M, int m0, const T* __restrict__ B, int ldb,
+                                          int N, int n0, int K, int k0, int tid) {
+#pragma unroll
+        for (int s = 0; s < A_CHUNKS; ++s) {
+            const int idx = tid + s * NT, row = idx >> 2, c = idx & 3;
+            const int gr = m0 + row, gk = k0 + c * Elem<T>::PER16;
+            ra[s] = (gr < M && gk < K) ? *reinterpret_cast<const uint4*>(A + (size_t)gr * lda + gk) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < B_CHUNKS; ++s) {
+            const int idx = tid + s * NT, row = idx >> 2, c = idx & 3;
+            const int gr = n0 + row, gk = k0 + c * Elem<T>::PER16;
+            rb[s] = (gr < N && gk < K) ? *reinterpret_cast<const uint4*>(B + (size_t)gr * ldb + gk) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void lstore(char* sA, char* sB, int tid) {
+#pragma unroll
+        for (int s = 0; s < A_CHUNKS; ++s) {
+            const int idx = tid + s * NT, row = idx >> 2, c = idx & 3;
+            *reinterpret_cast<uint4*>(sA + row * LDS_ROW + c * 16) = ra[s];
+        }
+#pragma unroll
+        for (int s = 0; s < B_CHUNKS; ++s) {
+            const int idx = tid + s * NT, row = idx >> 2, c = idx & 3;
+            *reinterpret_cast<uint4*>(sB + row * LDS_ROW + c * 16) = rb[s];
+        }
+    }
+    // one 64-byte K-chunk of MFMAs for this wave
+    __device__ __forceinline__ void compute(const char* sA, const char* sB, int wm, int wn, int lane, f32x16_t (&acc)[TM][TN]) {
+        const int r = lane & 31, h = lane >> 5;
+        const char* pa = sA + (wm * (BM / WM) + r) * LDS_ROW;
+        const char* pb = sB + (wn * (BN / WN) + r) * LDS_ROW;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(pa + i * 32 * LDS_ROW + ks * 32 + h * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(pb + j * 32 * LDS_ROW + ks * 32 + h * 16);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // K order inside the chunk is permuted (lane half h owns k = 8h..8h+7) so each lane reads
+            // 32 contiguous bytes; A and B use the same permutation, so the product is unchanged.
+            f32x4_t a[TM][2], b[TN][2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                a[i][0] = *reinterpret_cast<const f32x4_t*>(pa + i * 32 * LDS_ROW + h * 32);
+                a[i][1] = *reinterpret_cast<const f32x4_t*>(pa + i * 32 * LDS_ROW + h * 32 + 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                b[j][0] = *reinterpret_cast<const f32x4_t*>(pb + j * 32 * LDS_ROW + h * 32);
+                b[j][1] = *reinterpret_cast<const f32x4_t*>(pb + j * 32 * LDS_ROW + h * 32 + 16);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][ks >> 2][ks & 3], b[j][ks >> 2][ks & 3], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // full K loop [kc0, kc1) in chunk units; acc must be initialised by the caller
+    __device__ __forceinline__ void run(const T* __restrict__ A, int lda, int M, int m0, const T* __restrict__ B, int ldb, int N,
+                                        int n0, int K, int kc0, int kc1, char* smem, f32x16_t (&acc)[TM][TN]) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+        char* sA[2] = {smem, smem + (BM + BN) * LDS_ROW};
+        char* sB[2] = {smem + BM * LDS_ROW, smem + (BM + BN) * LDS_ROW + BM * LDS_ROW};
+        if (kc0 >= kc1) return;
+        gload(A, lda, M, m0, B, ldb, N, n0, K, kc0 * Elem<T>::PER_CHUNK, tid);
+        lstore(sA[0], sB[0], tid);
+        __syncthreads();
+        int cur = 0;
+        for (int kc = kc0; kc < kc1; ++kc) {
+            const bool more = kc + 1 < kc1;
+            if (more) gload(A, lda, M, m0, B, ldb, N, n0, K, (kc + 1) * Elem<T>::PER_CHUNK, tid);
+            compute(sA[cur], sB[cur], wm, wn, lane, acc);
+            if (more) lstore(sA[cur ^ 1], sB[cur ^ 1], tid);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+};
+
+// C/D fragment coordinates of a 32x32 MFMA tile: reg r of lane l -> (row, col)
+__device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ----------------------------------------------------------------------------------------------
+// plain GEMM
+// ----------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(WM * WN * 64)
+gemm_tn_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c_bf16,
+               const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
+    using Core = GemmCore<T, BM, BN, WM, WN>;
+    __shared__ __attribute__((aligned(16))) char smem[Core::LDS_BYTES];
+    // XCD-aware tile order: blocks b and b+8 share an XCD (speed only); give each XCD one m-panel
+    // for all n-tiles so the A panel stays in that XCD's L2.
+    const int bid = blockIdx.x;
+    const int grp = bid / (8 * ntn), within = bid % (8 * ntn);
+    const int mt = grp * 8 + (within & 7), nt = within >> 3;
+    if (mt >= ntm) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int nchunks = (K + Elem<T>::PER_CHUNK - 1) / Elem<T>::PER_CHUNK;
+    const int z = blockIdx.y;
+    const int per = (nchunks + split_k - 1) / split_k;
+    const int kc0 = z * per, kc1 = min(nchunks, kc0 + per);
+    f32x16_t acc[Core::TM][Core::TN];
+#pragma unroll
+    for (int i = 0; i < Core::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Core::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    Core core;
+    core.run(A, lda, M, m0, B, ldb, N, n0, K, kc0, kc1, smem, acc);
+    if (kc0 >= kc1 && z > 0) return;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    float* Cf = reinterpret_cast<float*>(Cv);
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv);
+#pragma unroll
+    for (int i = 0; i < Core::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Core::TN; ++j) {
+            const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+            if (col >= N) continue;
+            const float bv = (bias != nullptr && z == 0) ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / WM) + i * 32 + frag_row(r, lane);
+                if (row >= M) continue;
+                const float val = acc[i][j][r] + bv;
+                const size_t o = (size_t)row * ldc + col;
+                if (c_bf16) {
+                    Cb[o] = f32_to_bf16(val);
+                } else if (flags & MNN_GEMM_ATOMIC) {
+                    atomicAdd(Cf + o, val);
+                } else if (flags & MNN_GEMM_ACCUMULATE) {
+                    Cf[o] += val;
+                } else {
+                    Cf[o] = val;
+                }
+            }
+        }
+}
+
+template <typename T>
+static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                       int c_bf16, const float* bias, int flags, int split_k) {
+    constexpr int BM = 128, BN = 128;
+    const int ntm = cdiv(M, BM), ntn = cdiv(N, BN);
+    const int ngrp = cdiv(ntm, 8);
+    dim3 grid(ngrp * 8 * ntn, split_k);
+    hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, 2, 2>), grid, dim3(256), 0, st, (const T*)A, lda, (const T*)B, ldb, C, ldc,
+                       c_bf16, bias, M, N, K, flags, split_k, ntm, ntn);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+extern "C" int mnn_gemm_tn(mnn_stream_t s, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                           int ldc, int c_dtype, const float* bias, int flags, int split_k) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F32, "mnn_gemm_tn: dtype must be bf16 or f32 (got %d)", dtype);
+    MNN_REQUIRE(c_dtype == MNN_F32 || c_dtype == MNN_BF16, "mnn_gemm_tn: c_dtype must be f32 or bf16");
+    MNN_REQUIRE(M > 0 && N > 0 && K > 0, "mnn_gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
+    const int al = dtype == MNN_BF16 ? 8 : 4;
+    MNN_REQUIRE(K % al == 0 && lda % al == 0 && ldb % al == 0, "mnn_gemm_tn: K/lda/ldb must be multiples of %d (K=%d lda=%d ldb=%d)",
+                al, K, lda, ldb);
+    MNN_REQUIRE(lda >= K && ldb >= K && ldc >= N, "mnn_gemm_tn: leading dimension too small");
+    MNN_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "mnn_gemm_tn: operands must be 16-byte aligned");
+    if (split_k < 1) split_k = 1;
+    if (split_k > 1) {
+        MNN_REQUIRE(c_dtype == MNN_F32, "mnn_gemm_tn: split-K needs an f32 C");
+        if (!(flags & MNN_GEMM_ACCUMULATE)) {
+            MNN_HIP(hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, st));
+        }
+        flags |= MNN_GEMM_ATOMIC | MNN_GEMM_ACCUMULATE;
+    }
+    MNN_REQUIRE(!(c_dtype == MNN_BF16 && (flags & (MNN_GEMM_ACCUMULATE | MNN_GEMM_ATOMIC))), "mnn_gemm_tn: bf16 C cannot accumulate");
+    if (dtype == MNN_BF16) return launch_gemm<bf16_t>(st, M, N, K, A, lda, B, ldb, C, ldc, c_dtype == MNN_BF16, bias, flags, split_k);
+    return launch_gemm<float>(st, M, N, K, A, lda, B, ldb, C, ldc, c_dtype == MNN_BF16, bias, flags, split_k);
+}
+
+// ----------------------------------------------------------------------------------------------
+// LSTM forward step: z = xproj[t] + h_{t-1} . Wh ; gates ; c,h           (rnn.py:124, LSTMBlockCell)
+// block = 64 rows x 128 pre-activation columns = 32 units x 4 gates (gate-interleaved layout),
+// 2 waves, each 32 rows x 128 cols -> every lane owns all four gates of its (row, unit) elements.
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(128)
+lstm_fwd_step_kernel(const T* __restrict__ h_prev, const T* __restrict__ wh_t, const float* __restrict__ xproj,
+                     const float* __restrict__ c_prev, float* __restrict__ gates, float* __restrict__ c_out, T* __restrict__ h_out,
+                     int B, int U) {
+    using Core = GemmCore<T, 64, 128, 2, 1>;
+    __shared__ __attribute__((aligned(16))) char smem[Core::LDS_BYTES];
+    const int nt = blockIdx.x, m0 = blockIdx.y * 64, n0 = nt * 128;
+    const int N4 = 4 * U;
+    f32x16_t acc[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+    if (h_prev != nullptr) {
+        Core core;
+        const int nchunks = (U + Elem<T>::PER_CHUNK - 1) / Elem<T>::PER_CHUNK;
+        core.run(h_prev, U, B, m0, wh_t, U, N4, n0, U, 0, nchunks, smem, acc);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, unit = nt * 32 + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wave * 32 + frag_row(r, lane);
+        if (row >= B) continue;
+        const size_t zo = (size_t)row * N4 + n0 + col;
+        const float zi = acc[0][0][r] + xproj[zo];
+        const float zg = acc[0][1][r] + xproj[zo + 32];
+        const float zf = acc[0][2][r] + xproj[zo + 64];
+        const float zq = acc[0][3][r] + xproj[zo + 96];
+        const float gi = fast_sigmoid(zi), gg = fast_tanh(zg), gf = fast_sigmoid(zf), go = fast_sigmoid(zq);
+        const size_t uo = (size_t)row * U + unit;
+        const float cp = c_prev != nullptr ? c_prev[uo] : 0.f;
+        const float c = gg * gi + cp * gf;
+        const float h = fast_tanh(c) * go;
+        if (gates != nullptr) {
+            gates[zo] = gi; gates[zo + 32] = gg; gates[zo + 64] = gf; gates[zo + 96] = go;
+        }
+        c_out[uo] = c;
+        h_out[uo] = Cvt<T>::store(h);
+    }
+}
+
+extern "C" int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int units, const float* xproj, const void* wh_t,
+                                const void* h0, const float* c0, float* gates, float* c, void* h) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F32, "mnn_lstm_seq_fwd: dtype must be bf16 or f32");
+    MNN_REQUIRE(T > 0 && B > 0 && units > 0 && units % 32 == 0, "mnn_lstm_seq_fwd: units must be a positive multiple of 32 (T=%d B=%d u=%d)",
+                T, B, units);
+    MNN_REQUIRE(xproj && wh_t && c && h, "mnn_lstm_seq_fwd: null pointer");
+    const size_t esz = dtype == MNN_BF16 ? 2 : 4;
+    dim3 grid(units / 32, cdiv(B, 64));
+    for (int t = 0; t < T; ++t) {
+        const float* xp = xproj + (size_t)t * B * 4 * units;
+        float* gt = gates ? gates + (size_t)t * B * 4 * units : nullptr;
+        float* ct = c + (size_t)t * B * units;
+        const float* cp = t == 0 ? c0 : c + (size_t)(t - 1) * B * units;
+        char* ht = (char*)h + (size_t)t * B * units * esz;
+        const char* hp = t == 0 ? (const char*)h0 : (const char*)h + (size_t)(t - 1) * B * units * esz;
+        if (dtype == MNN_BF16)
+            hipLaunchKernelGGL(lstm_fwd_step_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)hp, (const bf16_t*)wh_t, xp, cp, gt, ct,
+                               (bf16_t*)ht, B, units);
+        else
+            hipLaunchKernelGGL(lstm_fwd_step_kernel<float>, grid, dim3(128), 0, st, (const float*)hp, (const float*)wh_t, xp, cp, gt, ct,
+                               (float*)ht, B, units);
+    }
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// LSTM backward step: dh = dh_ext[t] + dz[t+1] . Wh^T ; pointwise -> dz[t], dc (in place)
+// block = 64 rows x 64 units, 2 waves, each 32 rows x 64 units.
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(128)
+lstm_bwd_step_kernel(const T* __restrict__ dz_next, const T* __restrict__ wh_p, const float* __restrict__ dh_ext,
+                     const float* __restrict__ gates, const float* __restrict__ c_t, const float* __restrict__ c_prev,
+                     float* __restrict__ dc, float* __restrict__ dz, T* __restrict__ dzT, float* __restrict__ dh_out, int B, int U,
+                     int first) {
+    using Core = GemmCore<T, 64, 64, 2, 1>;
+    __shared__ __attribute__((aligned(16))) char smem[Core::LDS_BYTES];
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int N4 = 4 * U;
+    f32x16_t acc[1][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+    if (dz_next != nullptr) {
+        Core core;
+        const int nchunks = (N4 + Elem<T>::PER_CHUNK - 1) / Elem<T>::PER_CHUNK;
+        core.run(dz_next, N4, B, m0, wh_p, N4, U, n0, N4, 0, nchunks, smem, acc);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int unit = n0 + j * 32 + (lane & 31);
+        if (unit >= U) continue;
+        const int pc = gate_perm_col(0, unit);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wave * 32 + frag_row(r, lane);
+            if (row >= B) continue;
+            const size_t uo = (size_t)row * U + unit;
+            const size_t zo = (size_t)row * N4 + pc;
+            if (dh_out != nullptr) {          // pseudo-step "t = -1": only the recurrent gradient into h0
+                dh_out[uo] = acc[0][j][r];
+                continue;
+            }
+            const float dh = dh_ext[uo] + acc[0][j][r];
+            const float gi = gates[zo], gg = gates[zo + 32], gf = gates[zo + 64], go = gates[zo + 96];
+            const float c = c_t[uo];
+            const float cp = c_prev != nullptr ? c_prev[uo] : 0.f;
+            const float tc = fast_tanh(c);
+            const float dcn = first ? 0.f : dc[uo];
+            const float d_o = dh * tc;
+            const float d_c = dh * go * (1.f - tc * tc) + dcn;
+            const float dzi = d_c * gg * gi * (1.f - gi);
+            const float dzg = d_c * gi * (1.f - gg * gg);
+            const float dzf = d_c * cp * gf * (1.f - gf);
+            const float dzo = d_o * go * (1.f - go);
+            dc[uo] = d_c * gf;
+            if (dz != nullptr) { dz[zo] = dzi; dz[zo + 32] = dzg; dz[zo + 64] = dzf; dz[zo + 96] = dzo; }
+            if ((void*)dzT != (void*)dz) {
+                dzT[zo] = Cvt<T>::store(dzi); dzT[zo + 32] = Cvt<T>::store(dzg);
+                dzT[zo + 64] = Cvt<T>::store(dzf); dzT[zo + 96] = Cvt<T>::store(dzo);
+            }
+        }
+    }
+}
+
+extern "C" size_t mnn_lstm_seq_bwd_workspace_bytes(int B, int units) { return (size_t)B * units * sizeof(float); }
+
+extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int units, const float* dh_ext, const void* wh_p,
+                                const float* gates, const float* c, const float* c0, float* dz, void* dz_T, float* dh0, float* dc0,
+                                void* workspace) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F32, "mnn_lstm_seq_bwd: dtype must be bf16 or f32");
+    MNN_REQUIRE(T > 0 && B > 0 && units > 0 && units % 32 == 0, "mnn_lstm_seq_bwd: units must be a positive multiple of 32");
+    MNN_REQUIRE(dh_ext && wh_p && gates && c && workspace, "mnn_lstm_seq_bwd: null pointer");
+    MNN_REQUIRE(dtype == MNN_F32 ? (dz != nullptr) : (dz_T != nullptr), "mnn_lstm_seq_bwd: dz (f32) / dz_T (bf16) output required");
+    if (dtype == MNN_F32) dz_T = dz;
+    const size_t esz = dtype == MNN_BF16 ? 2 : 4;
+    float* dc = dc0 ? dc0 : (float*)workspace;
+    dim3 grid(cdiv(units, 64), cdiv(B, 64));
+    const size_t zs = (size_t)B * 4 * units, us = (size_t)B * units;
+    for (int t = T - 1; t >= -1; --t) {
+        if (t < 0 && dh0 == nullptr) break;
+        const char* dzn = t == T - 1 ? nullptr : (const char*)dz_T + (size_t)(t + 1) * zs * esz;
+        const int tt = t < 0 ? 0 : t;
+        const float* cp = t <= 0 ? c0 : c + (size_t)(t - 1) * us;
+        float* dzt = dz ? dz + (size_t)tt * zs : nullptr;
+        char* dzTt = (char*)dz_T + (size_t)tt * zs * esz;
+        float* dho = t < 0 ? dh0 : nullptr;
+        if (dtype == MNN_BF16)
+            hipLaunchKernelGGL(lstm_bwd_step_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)dzn, (const bf16_t*)wh_p,
+                               dh_ext + (size_t)tt * us, gates + (size_t)tt * zs, c + (size_t)tt * us, cp, dc, dzt, (bf16_t*)dzTt, dho, B,
+                               units, t == T - 1 ? 1 : 0);
+        else
+            hipLaunchKernelGGL(lstm_bwd_step_kernel<float>, grid, dim3(128), 0, st, (const float*)dzn, (const float*)wh_p,
+                               dh_ext + (size_t)tt * us, gates + (size_t)tt * zs, c + (size_t)tt * us, cp, dc, dzt, (float*)dzTt, dho, B,
+                               units, t == T - 1 ? 1 : 0);
+    }
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}

@@ -1,0 +1,314 @@
+"""Torch-tensor front end of the C ABI (include/multinn_hip.h).
+
+Every function validates shapes/dtypes/devices on the host (a mis-sized operand must never reach
+a kernel), extracts raw device pointers and the current HIP stream, and calls the library.
+There is no CPU path: tensors must be on a ROCm device.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import F32, BF16, U8, GEMM_ACCUMULATE, call
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.uint8: U8}
+
+
+def dtype_code(t):
+    return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+
+
+def _stream():
+    if not torch.cuda.is_available():
+        raise _lib.MnnError("multinn_amd has no CPU path: no ROCm device is available")
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.MnnError("multinn_amd has no CPU path: tensor is on %s" % t.device)
+    return C.c_void_p(t.data_ptr())
+
+
+def _req(cond, msg):
+    if not cond:
+        raise ValueError(msg)
+
+
+def _rowmajor(t, what):
+    _req(t.dim() == 2 and t.stride(1) == 1, f"{what}: need a 2-D tensor with unit inner stride, got {tuple(t.shape)} {t.stride()}")
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------
+def gemm_tn(A, B, C_out, bias=None, accumulate=False, split_k=1):
+    """C[M,N] (+)= A[M,K] . B[N,K]^T (+bias).  A,B same dtype (f32/bf16), K-contiguous views."""
+    _rowmajor(A, "gemm A"); _rowmajor(B, "gemm B"); _rowmajor(C_out, "gemm C")
+    _req(A.dtype == B.dtype and A.dtype in (torch.float32, torch.bfloat16), "gemm: A/B must both be f32 or bf16")
+    M, K = A.shape
+    N, K2 = B.shape
+    _req(K == K2 and C_out.shape == (M, N), f"gemm: shape mismatch A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(C_out.shape)}")
+    _req(C_out.dtype in (torch.float32, torch.bfloat16), "gemm: C must be f32/bf16")
+    if bias is not None:
+        _req(bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous(), "gemm: bias must be f32[N]")
+    call("mnn_gemm_tn", _stream(), dtype_code(A), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C_out), C_out.stride(0),
+         dtype_code(C_out), _ptr(bias), GEMM_ACCUMULATE if accumulate else 0, split_k)
+    return C_out
+
+
+def transpose(src, out):
+    """out[C,R] = src[R,C]^T with conversion."""
+    _rowmajor(src, "transpose src"); _rowmajor(out, "transpose out")
+    R, Cc = src.shape
+    _req(out.shape[0] == Cc and out.shape[1] >= R, "transpose: out must be [C, >=R]")
+    call("mnn_transpose", _stream(), _ptr(src), dtype_code(src), R, Cc, src.stride(0), _ptr(out), dtype_code(out), out.stride(0))
+    return out
+
+
+def convert2d(src, dst):
+    _rowmajor(src, "convert src"); _rowmajor(dst, "convert dst")
+    _req(src.shape == dst.shape, "convert2d: shape mismatch")
+    call("mnn_convert2d", _stream(), _ptr(src), dtype_code(src), src.stride(0), _ptr(dst), dtype_code(dst), dst.stride(0), src.shape[0], src.shape[1])
+    return dst
+
+
+def pianoroll_shift_timemajor(x, lengths, inputs, targets, row_weight, n_valid_total=0):
+    """x u8 [B,T,D] -> inputs [T,B,ld] (shifted, zero first step), targets u8 [T,B,D], row_weight f32 [T*B]."""
+    _req(x.dtype == torch.uint8 and x.dim() == 3 and x.is_contiguous(), "pianoroll: x must be contiguous u8 [B,T,D]")
+    B, T, D = x.shape
+    _req(inputs.dim() == 3 and inputs.shape[0] == T and inputs.shape[1] == B and inputs.shape[2] >= D and inputs.is_contiguous(),
+         "pianoroll: inputs must be contiguous [T,B,>=D]")
+    if targets is not None:
+        _req(targets.dtype == torch.uint8 and targets.shape == (T, B, D) and targets.is_contiguous(), "pianoroll: targets u8 [T,B,D]")
+    if row_weight is not None:
+        _req(row_weight.dtype == torch.float32 and row_weight.numel() == T * B, "pianoroll: row_weight f32 [T*B]")
+    if lengths is not None:
+        _req(lengths.dtype == torch.int32 and lengths.numel() == B, "pianoroll: lengths int32 [B]")
+        _req(n_valid_total > 0, "pianoroll: n_valid_total required with lengths")
+    call("mnn_pianoroll_shift_timemajor", _stream(), _ptr(x), B, T, D, _ptr(lengths), _ptr(inputs), dtype_code(inputs), inputs.shape[2],
+         _ptr(targets), _ptr(row_weight), int(n_valid_total))
+
+
+def pianoroll_split_tracks(x, out):
+    _req(x.dtype == torch.uint8 and x.dim() == 4 and x.is_contiguous(), "split_tracks: x must be contiguous u8 [B,T,P,M]")
+    B, T, P, M = x.shape
+    _req(out.dtype == torch.uint8 and out.shape == (M, T, B, P) and out.is_contiguous(), "split_tracks: out u8 [M,T,B,P]")
+    call("mnn_pianoroll_split_tracks", _stream(), _ptr(x), B, T, P, M, _ptr(out))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def lstm_pack_weights(W, b, n_in, units, wx_t, wh_t, wh_p, wx_p, bias_p):
+    _req(W.dtype == torch.float32 and W.shape == (n_in + units, 4 * units) and W.is_contiguous(), "pack: W f32 [(in+u),4u]")
+    _req(b.dtype == torch.float32 and b.numel() == 4 * units, "pack: b f32 [4u]")
+    ld_in = wx_t.shape[1]
+    _req(wx_t.shape == (4 * units, ld_in) and ld_in >= n_in and wx_t.is_contiguous(), "pack: wx_t [4u, ld_in]")
+    _req(wh_t.shape == (4 * units, units) and wh_t.is_contiguous(), "pack: wh_t [4u,u]")
+    _req(wh_p.shape == (units, 4 * units) and wh_p.is_contiguous(), "pack: wh_p [u,4u]")
+    if wx_p is not None:
+        _req(wx_p.shape == (n_in, 4 * units) and wx_p.is_contiguous() and wx_p.dtype == wx_t.dtype, "pack: wx_p [in,4u]")
+    _req(wx_t.dtype == wh_t.dtype == wh_p.dtype, "pack: dtype mismatch")
+    _req(bias_p.dtype == torch.float32 and bias_p.numel() == 4 * units, "pack: bias_p f32 [4u]")
+    call("mnn_lstm_pack_weights", _stream(), _ptr(W), _ptr(b), n_in, units, dtype_code(wx_t), ld_in, _ptr(wx_t), _ptr(wh_t), _ptr(wh_p),
+         _ptr(wx_p), _ptr(bias_p))
+
+
+def lstm_unpack_grads(dwx_t, dwh_t, db_p, n_in, units, dW, db):
+    ld_in = dwx_t.shape[1]
+    _req(dwx_t.dtype == torch.float32 and dwx_t.shape == (4 * units, ld_in) and dwx_t.is_contiguous(), "unpack: dwx_t f32 [4u,ld]")
+    _req(dwh_t.dtype == torch.float32 and dwh_t.shape == (4 * units, units) and dwh_t.is_contiguous(), "unpack: dwh_t f32 [4u,u]")
+    _req(dW.dtype == torch.float32 and dW.shape == (n_in + units, 4 * units) and dW.is_contiguous(), "unpack: dW f32 [(in+u),4u]")
+    _req(db.numel() == 4 * units and db_p.numel() == 4 * units, "unpack: bias sizes")
+    call("mnn_lstm_unpack_grads", _stream(), _ptr(dwx_t), _ptr(dwh_t), _ptr(db_p), n_in, units, ld_in, _ptr(dW), _ptr(db))
+
+
+def lstm_seq_fwd(xproj, wh_t, h0, c0, gates, c, h):
+    T, B, N4 = xproj.shape
+    units = N4 // 4
+    _req(xproj.dtype == torch.float32 and xproj.is_contiguous() and units % 32 == 0, "lstm_fwd: xproj f32 [T,B,4u], u%32==0")
+    _req(wh_t.shape == (N4, units) and wh_t.is_contiguous() and wh_t.dtype == h.dtype, "lstm_fwd: wh_t [4u,u] in the compute dtype")
+    _req(c.dtype == torch.float32 and c.shape == (T, B, units) and c.is_contiguous(), "lstm_fwd: c f32 [T,B,u]")
+    _req(h.shape == (T, B, units) and h.is_contiguous(), "lstm_fwd: h [T,B,u]")
+    if gates is not None:
+        _req(gates.dtype == torch.float32 and gates.shape == (T, B, N4) and gates.is_contiguous(), "lstm_fwd: gates f32 [T,B,4u]")
+    if h0 is not None:
+        _req(h0.shape == (B, units) and h0.dtype == h.dtype and h0.is_contiguous(), "lstm_fwd: h0")
+    if c0 is not None:
+        _req(c0.shape == (B, units) and c0.dtype == torch.float32 and c0.is_contiguous(), "lstm_fwd: c0")
+    call("mnn_lstm_seq_fwd", _stream(), dtype_code(h), T, B, units, _ptr(xproj), _ptr(wh_t), _ptr(h0), _ptr(c0), _ptr(gates), _ptr(c), _ptr(h))
+
+
+def lstm_seq_bwd(dh_ext, wh_p, gates, c, c0, dz, dz_T, dh0=None, dc0=None):
+    T, B, units = dh_ext.shape
+    N4 = 4 * units
+    _req(dh_ext.dtype == torch.float32 and dh_ext.is_contiguous(), "lstm_bwd: dh_ext f32 [T,B,u]")
+    _req(wh_p.shape == (units, N4) and wh_p.is_contiguous(), "lstm_bwd: wh_p [u,4u]")
+    _req(gates.shape == (T, B, N4) and gates.dtype == torch.float32 and gates.is_contiguous(), "lstm_bwd: gates")
+    _req(c.shape == (T, B, units) and c.dtype == torch.float32 and c.is_contiguous(), "lstm_bwd: c")
+    if dz is not None:
+        _req(dz.shape == (T, B, N4) and dz.dtype == torch.float32 and dz.is_contiguous(), "lstm_bwd: dz f32 [T,B,4u]")
+    if dz_T is not None:
+        _req(dz_T.shape == (T, B, N4) and dz_T.dtype == wh_p.dtype and dz_T.is_contiguous(), "lstm_bwd: dz_T")
+    ws = torch.empty(_lib.load().mnn_lstm_seq_bwd_workspace_bytes(B, units), dtype=torch.uint8, device=dh_ext.device)
+    call("mnn_lstm_seq_bwd", _stream(), dtype_code(wh_p), T, B, units, _ptr(dh_ext), _ptr(wh_p), _ptr(gates), _ptr(c), _ptr(c0), _ptr(dz),
+         _ptr(dz_T), _ptr(dh0), _ptr(dc0), _ptr(ws))
+
+
+def dropout_fwd(h, y, keep_prob, seed, row0, layer):
+    T, B, u = h.shape
+    _req(h.is_contiguous() and y.is_contiguous() and h.shape == y.shape and h.dtype == y.dtype and u % 4 == 0, "dropout_fwd: shapes")
+    call("mnn_dropout_fwd", _stream(), dtype_code(h), _ptr(h), _ptr(y), T, B, u, float(keep_prob), int(seed), int(row0), int(layer))
+
+
+def dropout_bwd(dy, dh, keep_prob, seed, row0, layer, accumulate=False):
+    T, B, u = dy.shape
+    _req(dy.dtype == torch.float32 and dh.dtype == torch.float32 and dy.is_contiguous() and dh.is_contiguous() and dy.shape == dh.shape,
+         "dropout_bwd: f32 [T,B,u]")
+    call("mnn_dropout_bwd", _stream(), _ptr(dy), _ptr(dh), T, B, u, float(keep_prob), int(seed), int(row0), int(layer), int(accumulate))
+
+
+# ------------------------------------------------------------------------------------------------
+def _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec):
+    _req(v.dtype == torch.uint8 and v.is_contiguous() and v.numel() == tracks * N * D, "nade: v must be contiguous u8 [tracks,N,D]")
+    _req(bias.dtype == torch.float32 and bias.dim() == 2 and bias.shape[0] == N and bias.stride(1) == 1
+         and bias.shape[1] >= tracks * (Hn + D), "nade: bias f32 [N, >=tracks*(Hn+D)]")
+    for w in (w_enc, w_dec):
+        _req(w.dtype == torch.float32 and w.is_contiguous() and w.numel() == tracks * D * Hn, "nade: weights f32 [tracks,D,Hn]")
+    _req(0 < Hn <= 256, "nade: Hn must be in 1..256")
+
+
+def nade_logprob_fwd(v, bias, w_enc, w_dec, tracks, D, Hn, row_weight=None, nll=None, cond_p=None, d_bias=None):
+    N = bias.shape[0]
+    _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)
+    if nll is not None:
+        _req(nll.dtype == torch.float32 and nll.numel() == tracks * N and nll.is_contiguous(), "nade: nll f32 [tracks,N]")
+    if cond_p is not None:
+        _req(cond_p.dtype == torch.float32 and cond_p.numel() == tracks * N * D and cond_p.is_contiguous(), "nade: cond_p f32 [tracks,N,D]")
+    if d_bias is not None:
+        _req(row_weight is not None and d_bias.shape == bias.shape and d_bias.stride() == bias.stride() and d_bias.dtype == torch.float32,
+             "nade: d_bias must mirror bias and needs row_weight")
+    if row_weight is not None:
+        _req(row_weight.dtype == torch.float32 and row_weight.numel() == N, "nade: row_weight f32 [N]")
+    call("mnn_nade_logprob_fwd", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
+         _ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias))
+
+
+def nade_logprob_bwd(v, bias, w_enc, w_dec, tracks, D, Hn, d_bias, d_w_enc, d_w_dec):
+    N = bias.shape[0]
+    _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)
+    _req(d_bias.shape == bias.shape and d_bias.stride() == bias.stride() and d_bias.dtype == torch.float32, "nade bwd: d_bias")
+    for w in (d_w_enc, d_w_dec):
+        _req(w.dtype == torch.float32 and w.is_contiguous() and w.numel() == tracks * D * Hn, "nade bwd: grad weights f32 [tracks,D,Hn]")
+    call("mnn_nade_logprob_bwd", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
+         _ptr(d_bias), _ptr(d_w_enc), _ptr(d_w_dec))
+
+
+def nade_sample(bias, w_enc, w_dec, tracks, D, Hn, temperature, seed, row0, sub, samples, track_minor=False, nll=None):
+    """samples u8 [N, tracks*D]; feature index m*D+i (track_minor False) or i*tracks+m (True, rnn_multinade.py:313-314)."""
+    N = bias.shape[0]
+    _req(bias.dtype == torch.float32 and bias.dim() == 2 and bias.stride(1) == 1 and bias.shape[1] >= tracks * (Hn + D), "sample: bias")
+    _req(samples.dtype == torch.uint8 and samples.shape == (N, tracks * D) and samples.is_contiguous(), "sample: samples u8 [N,tracks*D]")
+    for w in (w_enc, w_dec):
+        _req(w.dtype == torch.float32 and w.is_contiguous() and w.numel() == tracks * D * Hn, "sample: weights")
+    if nll is not None:
+        _req(nll.dtype == torch.float32 and nll.numel() == tracks * N, "sample: nll")
+    ts, es = (1, tracks) if track_minor else (D, 1)
+    call("mnn_nade_sample", _stream(), tracks, N, D, Hn, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
+         float(-1.0 if temperature is None else temperature), int(seed), int(row0), int(sub), _ptr(samples), ts, tracks * D, es, _ptr(nll))
+
+
+# ------------------------------------------------------------------------------------------------
+def _ldb(b, n):
+    _req(b.dtype == torch.float32 and b.dim() == 2 and b.stride(1) == 1 and b.shape[1] >= n, "rbm: bias must be f32 [N or 1, n]")
+    return 0 if b.shape[0] == 1 else b.stride(0)
+
+
+def rbm_workspace(D, Hn, device):
+    return torch.empty(_lib.load().mnn_rbm_workspace_bytes(D, Hn), dtype=torch.uint8, device=device)
+
+
+def rbm_gibbs(v0, W, bh, bv, k, seed, row0=0, row_ids=None, sub0=0, p_v=None, v_out=None):
+    N, D = v0.shape
+    Hn = W.shape[1]
+    _req(v0.dtype == torch.uint8 and v0.is_contiguous(), "gibbs: v0 u8 [N,D]")
+    _req(W.dtype == torch.float32 and W.shape == (D, Hn) and W.is_contiguous(), "gibbs: W f32 [D,Hn]")
+    _req(bh.shape[0] in (1, N) and bv.shape[0] in (1, N), "gibbs: bias rows")
+    if p_v is not None:
+        _req(p_v.dtype == torch.float32 and p_v.shape == (N, D) and p_v.is_contiguous(), "gibbs: p_v f32 [N,D]")
+    if v_out is not None:
+        _req(v_out.dtype == torch.uint8 and v_out.shape == (N, D) and v_out.is_contiguous(), "gibbs: v_out u8 [N,D]")
+    if row_ids is not None:
+        _req(row_ids.dtype == torch.int32 and row_ids.numel() == N, "gibbs: row_ids int32 [N]")
+    ws = rbm_workspace(D, Hn, v0.device)
+    call("mnn_rbm_gibbs", _stream(), N, D, Hn, int(k), _ptr(v0), _ptr(W), _ptr(bh), _ldb(bh, Hn), _ptr(bv), _ldb(bv, D), int(seed), int(row0),
+         _ptr(row_ids), int(sub0), _ptr(p_v), _ptr(v_out), _ptr(ws))
+
+
+def rbm_hidden(v, W, bh, stream_id, seed, row0, sub, p_h=None, h=None):
+    N, D = v.shape
+    Hn = W.shape[1]
+    _req(v.dtype in (torch.uint8, torch.float32) and v.is_contiguous() and W.shape == (D, Hn) and W.is_contiguous(), "rbm_hidden: shapes")
+    _req(bh.shape[0] in (1, N), "rbm_hidden: bias rows")
+    for t, dt in ((p_h, torch.float32), (h, torch.uint8)):
+        if t is not None:
+            _req(t.dtype == dt and t.shape == (N, Hn) and t.is_contiguous(), "rbm_hidden: outputs [N,Hn]")
+    call("mnn_rbm_hidden", _stream(), N, D, Hn, _ptr(v), dtype_code(v), _ptr(W), _ptr(bh), _ldb(bh, Hn), int(stream_id), int(seed), int(row0),
+         int(sub), _ptr(p_h), _ptr(h))
+
+
+def rbm_visible(h, W, bv, stream_id, seed, row0, sub, p_v=None, v=None):
+    N, Hn = h.shape
+    D = W.shape[0]
+    _req(h.dtype in (torch.uint8, torch.float32) and h.is_contiguous() and W.shape == (D, Hn) and W.is_contiguous(), "rbm_visible: shapes")
+    _req(bv.shape[0] in (1, N), "rbm_visible: bias rows")
+    for t, dt in ((p_v, torch.float32), (v, torch.uint8)):
+        if t is not None:
+            _req(t.dtype == dt and t.shape == (N, D) and t.is_contiguous(), "rbm_visible: outputs [N,D]")
+    ws = rbm_workspace(D, Hn, h.device)
+    call("mnn_rbm_visible", _stream(), N, D, Hn, _ptr(h), dtype_code(h), _ptr(W), _ptr(bv), _ldb(bv, D), int(stream_id), int(seed), int(row0),
+         int(sub), _ptr(p_v), _ptr(v), _ptr(ws))
+
+
+def rbm_free_energy(v, W, bh, bv, F):
+    N, D = v.shape
+    Hn = W.shape[1]
+    _req(v.dtype == torch.uint8 and v.is_contiguous() and W.shape == (D, Hn) and W.is_contiguous(), "free_energy: shapes")
+    _req(F.dtype == torch.float32 and F.numel() == N, "free_energy: F f32 [N]")
+    _req(bh.shape[0] in (1, N) and bv.shape[0] in (1, N), "free_energy: bias rows")
+    call("mnn_rbm_free_energy", _stream(), N, D, Hn, _ptr(v), _ptr(W), _ptr(bh), _ldb(bh, Hn), _ptr(bv), _ldb(bv, D), _ptr(F))
+    return F
+
+
+# ------------------------------------------------------------------------------------------------
+def sumsq(x, out):
+    _req(x.dtype == torch.float32 and x.is_contiguous() and out.dtype == torch.float32, "sumsq: f32")
+    call("mnn_sumsq", _stream(), _ptr(x), x.numel(), _ptr(out))
+
+
+def weighted_sum(x, w, out):
+    _req(x.dtype == torch.float32 and x.is_contiguous() and (w is None or (w.numel() == x.numel() and w.dtype == torch.float32)), "weighted_sum")
+    call("mnn_weighted_sum", _stream(), _ptr(x), _ptr(w), x.numel(), _ptr(out))
+
+
+def clip_adam_step(theta, grad, m, v, sumsq_buf, clip_norm, lr, beta1, beta2, eps, step, sgd=False):
+    n = theta.numel()
+    for t in (theta, grad) + (() if sgd else (m, v)):
+        _req(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n, "adam: flat f32 buffers of equal size")
+    call("mnn_clip_adam_step", _stream(), _ptr(theta), _ptr(grad), _ptr(m), _ptr(v), n, _ptr(sumsq_buf), float(clip_norm), float(lr),
+         float(beta1), float(beta2), float(eps), int(step), int(sgd))
+
+
+def bias_grad(dY, db, accumulate=False):
+    _rowmajor(dY, "bias_grad dY")
+    _req(dY.dtype == torch.float32 and db.dtype == torch.float32 and db.numel() == dY.shape[1] and db.is_contiguous(), "bias_grad: shapes")
+    call("mnn_bias_grad", _stream(), _ptr(dY), dY.shape[0], dY.shape[1], dY.stride(0), _ptr(db), int(accumulate))
+
+
+def fill(x, value):
+    _req(x.dtype == torch.float32 and x.is_contiguous(), "fill: f32 contiguous")
+    call("mnn_fill_f32", _stream(), _ptr(x), x.numel(), float(value))
