@@ -77,8 +77,8 @@ nade_fwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
         if (i < D) {
             const float l = bd[i] + ((red[buf][0][w][lane] + red[buf][1][w][lane]) + (red[buf][2][w][lane] + red[buf][3][w][lane]));
             const float p = fast_sigmoid(l);
-            const float vi = vi4[w];
-            const float q = 1.0f - p;
+            const float vi = w == 0 ? vi4[0] : (w == 1 ? vi4[1] : (w == 2 ? vi4[2] : vi4[3]));
+            const float q = fast_sigmoid(-l);   // 1-p without cancellation (closer to the exact value than f32 `1 - p`)
             lp += vi > 0.5f ? fast_ln(NADE_EPS + p) : fast_ln(NADE_EPS + q);
             if (valid) {
                 if (cond_p != nullptr) cond_p[((size_t)m * N + row) * D + i] = p;
@@ -183,7 +183,7 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
                 for (int q = 0; q < HQ; ++q) {
                     const float h = fast_sigmoid(a[r][q]);
                     accd[q] = fmaf(dl, h, accd[q]);
-                    G[r][q] = fmaf(dl * wdv[q], h - h * h, G[r][q]);
+                    G[r][q] = fmaf(dl * wdv[q], fmaf(-h, h, h), G[r][q]);
                 }
             }
         }
