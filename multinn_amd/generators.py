@@ -1,0 +1,749 @@
+"""Host-side mirror of /root/reference/multinn/models/generators: Generator, RnnEstimator,
+RnnNade, RnnMultiNADE, RnnRBM -- same constructor arguments, method names and return arity.
+
+Eager semantics: ``build(x, y, lengths, is_train, mode)`` RUNS the forward pass (the reference
+builds graph ops that a later ``sess.run`` executes), ``train(optimizer, lr)`` runs the backward
+pass, the data-parallel all-reduce and the clipped optimiser step.  All compute goes through
+the C ABI (multinn_amd.ops); internal tensors are time-major ([T,B,...], row n = t*B + b) and
+rows past ``lengths`` are masked by a zero row weight instead of being gathered away
+(utils/sequences.py:6-37 defines only the ORDER of the API-level flat outputs, reproduced by
+``flat_index``).
+"""
+import abc
+import collections
+
+import torch
+
+from . import ops
+from .common import Model, RNN, NADE, RBM, ParamStore, glorot_uniform, zeros_init, default_device
+from .training import compute_gradients, world, AdamOptimizer
+
+_RnnEstimatorStateTuple = collections.namedtuple("RnnEstimatorStateTuple", ("b_enc", "b_dec", "rnn_state"))
+
+
+class RnnEstimatorStateTuple(_RnnEstimatorStateTuple):
+    """rnn_estimator.py:12-36."""
+    __slots__ = ()
+
+    @property
+    def dtype(self):
+        return self.b_enc.dtype
+
+
+def _compute_dtype(precision):
+    if precision in ("bf16", torch.bfloat16):
+        return torch.bfloat16
+    if precision in ("fp32", "f32", torch.float32):
+        return torch.float32
+    raise ValueError("precision must be 'bf16' or 'fp32'")
+
+
+def flat_index(lengths, B, T, device):
+    """Time-major row ids (t*B+b) of the valid rows in the reference's flat order: b-major,
+    then t (utils/sequences.py:30-31)."""
+    t = torch.arange(T, device=device)[None, :].expand(B, T)
+    b = torch.arange(B, device=device)[:, None].expand(B, T)
+    if lengths is None:
+        return (t * B + b).reshape(-1)
+    m = t < lengths.to(device)[:, None]
+    return (t * B + b)[m]
+
+
+# ------------------------------------------------------------------------------------------------
+class LstmStack:
+    """Executes an RNN (multi-layer LSTM) on packed, gate-interleaved weights."""
+
+    def __init__(self, rnn, store, dtype):
+        self.rnn, self.store, self.dtype = rnn, store, dtype
+        self.al = 8 if dtype == torch.bfloat16 else 4
+        self.ld0 = ops.round_up(rnn.n_in, 8)
+        self.packed = None
+
+    def pack(self):
+        dev = self.store.theta.device
+        self.packed = []
+        for l, (n_in, u) in enumerate(zip(self.rnn.layer_inputs(), self.rnn.num_units)):
+            ld = self.ld0 if l == 0 else n_in
+            p = dict(wx_t=torch.empty((4 * u, ld), device=dev, dtype=self.dtype), wh_t=torch.empty((4 * u, u), device=dev, dtype=self.dtype),
+                     wh_p=torch.empty((u, 4 * u), device=dev, dtype=self.dtype),
+                     wx_p=torch.empty((n_in, 4 * u), device=dev, dtype=self.dtype) if l > 0 else None,
+                     bias_p=torch.empty(4 * u, device=dev), n_in=n_in, u=u, ld=ld)
+            ops.lstm_pack_weights(self.store[f"{self.rnn.prefix}/cell_{l}/kernel"], self.store[f"{self.rnn.prefix}/cell_{l}/bias"], n_in, u,
+                                  p["wx_t"], p["wh_t"], p["wh_p"], p["wx_p"], p["bias_p"])
+            self.packed.append(p)
+
+    def forward(self, x_tm, keep_prob=1.0, seed=0, row0=0, save=True, state0=None):
+        """x_tm [T,B,ld0] compute dtype.  Returns (y [T,B,u_last], ctx, final_state[(c,h)...])."""
+        T, B, _ = x_tm.shape
+        dev = x_tm.device
+        ctx, final = [], []
+        inp = x_tm
+        for l, p in enumerate(self.packed):
+            u = p["u"]
+            xproj = torch.empty((T, B, 4 * u), device=dev)
+            ops.gemm_tn(inp.view(T * B, -1), p["wx_t"], xproj.view(T * B, 4 * u), bias=p["bias_p"])
+            gates = torch.empty((T, B, 4 * u), device=dev) if save else None
+            c = torch.empty((T, B, u), device=dev)
+            h = torch.empty((T, B, u), device=dev, dtype=self.dtype)
+            c0, h0 = (state0[l][0], state0[l][1].to(self.dtype)) if state0 is not None else (None, None)
+            ops.lstm_seq_fwd(xproj, p["wh_t"], h0, c0, gates, c, h)
+            del xproj
+            if keep_prob < 1.0:
+                y = torch.empty_like(h)
+                ops.dropout_fwd(h, y, keep_prob, seed, row0, l)
+            else:
+                y = h
+            if save:
+                ctx.append(dict(inp=inp, gates=gates, c=c, h=h, c0=c0, h0=h0))
+            final.append((c[-1], h[-1]))
+            inp = y
+        return inp, ctx, final
+
+    @staticmethod
+    def _split_k(rows_out, cols_out, K):
+        tiles = -(-rows_out // 128) * -(-cols_out // 128)
+        return int(max(1, min(1024 // max(tiles, 1), K // 1024)))
+
+    def backward(self, dy, ctx, keep_prob=1.0, seed=0, row0=0, need_dx=False):
+        """dy f32 [T,B,u_last]: gradient wrt the (dropped) top output.  Accumulates the kernel /
+        bias gradients into the store's flat gradient buffer."""
+        T, B, _ = dy.shape
+        N = T * B
+        Np = ops.round_up(N, 8)
+        dev = dy.device
+        zalloc = torch.zeros if Np != N else torch.empty
+        dx = None
+        for l in range(len(self.packed) - 1, -1, -1):
+            p, cx = self.packed[l], ctx[l]
+            u, ld, n_in = p["u"], p["ld"], p["n_in"]
+            if keep_prob < 1.0:
+                dh = torch.empty((T, B, u), device=dev)
+                ops.dropout_bwd(dy.view(T, B, u), dh, keep_prob, seed, row0, l)
+            else:
+                dh = dy.view(T, B, u)
+            dz = torch.empty((T, B, 4 * u), device=dev)
+            dzc = dz if self.dtype == torch.float32 else torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype)
+            ops.lstm_seq_bwd(dh, p["wh_p"], cx["gates"], cx["c"], cx["c0"], dz, dzc)
+            # weight gradients: dWx^T[4u,ld] = dz^T . inp ; dWh^T[4u,u] = dz^T . h_prev  (reduction over the N rows)
+            dzT = zalloc((4 * u, Np), device=dev, dtype=self.dtype)
+            ops.transpose(dzc.view(N, 4 * u), dzT)
+            inT = zalloc((ld, Np), device=dev, dtype=self.dtype)
+            ops.transpose(cx["inp"].view(N, ld), inT)
+            dwx_t = torch.empty((4 * u, ld), device=dev)
+            ops.gemm_tn(dzT, inT, dwx_t, split_k=self._split_k(4 * u, ld, Np))
+            del inT
+            hT = torch.zeros((u, Np), device=dev, dtype=self.dtype)
+            if cx["h0"] is not None:
+                ops.transpose(cx["h0"], hT[:, :B])
+            if T > 1:
+                ops.transpose(cx["h"][:-1].view((T - 1) * B, u), hT[:, B:N])
+            dwh_t = torch.empty((4 * u, u), device=dev)
+            ops.gemm_tn(dzT, hT, dwh_t, split_k=self._split_k(4 * u, u, Np))
+            del hT, dzT
+            db_p = torch.empty(4 * u, device=dev)
+            ops.bias_grad(dz.view(N, 4 * u), db_p)
+            ops.lstm_unpack_grads(dwx_t, dwh_t, db_p, n_in, u, self.store.gviews[f"{self.rnn.prefix}/cell_{l}/kernel"],
+                                  self.store.gviews[f"{self.rnn.prefix}/cell_{l}/bias"])
+            if l > 0:
+                dy = torch.empty((N, n_in), device=dev)
+                ops.gemm_tn(dzc.view(N, 4 * u), p["wx_p"], dy)
+            elif need_dx:
+                raise NotImplementedError("gradient wrt the generator inputs (tune_encoder) is a 'next' row")
+        return dx
+
+    def single_step(self, x, state):
+        """One time step (rnn_nade.py:268): x [B,ld0] compute dtype, state [(c,h)...] -> (h_top, new_state)."""
+        y, _, final = self.forward(x.view(1, *x.shape), 1.0, save=False, state0=state)
+        return y[0], [(c, h) for c, h in final]
+
+
+# ------------------------------------------------------------------------------------------------
+class Generator(Model):
+    """models/generators/generator.py:9-205."""
+
+    def __init__(self, num_dims, num_hidden, num_hidden_rnn, keep_prob=1.0, internal_bias=False, name="generator", track_name="all"):
+        super().__init__(name=name)
+        self._track_name = track_name
+        self._num_dims = num_dims
+        self._num_hidden = [num_hidden] if isinstance(num_hidden, int) else list(num_hidden)
+        self._num_hidden_rnn = [num_hidden_rnn] if isinstance(num_hidden_rnn, int) else list(num_hidden_rnn)
+        self._keep_prob, self._internal_bias = keep_prob, internal_bias
+        self._lengths = self._inputs = None
+
+    num_dims = property(lambda self: self._num_dims)
+    num_hidden = property(lambda self: self._num_hidden)
+    num_hidden_rnn = property(lambda self: self._num_hidden_rnn)
+    track_name = property(lambda self: self._track_name)
+    keep_prob = property(lambda self: self._keep_prob)
+    internal_bias = property(lambda self: self._internal_bias)
+
+    def build(self, x=None, y=None, lengths=None, is_train=None, mode="eval"):
+        super().build(mode=mode)
+        self._inputs, self._lengths = x, lengths
+
+    @abc.abstractmethod
+    def zero_state(self, batch_size):
+        ...
+
+    def forward(self):
+        return self._outputs
+
+    @abc.abstractmethod
+    def generate(self, x, num_steps):
+        ...
+
+    def pretrain(self, optimizer, lr, run_optimizer=True):
+        return [], [], self.metrics, self.metrics_upd, self.summaries
+
+    def train(self, optimizer, lr, run_optimizer=True):
+        """generator.py:176-205: backward of metrics['batch/loss'] + clipped optimiser step."""
+        self.backward()
+        summaries = dict(self.summaries)
+        if run_optimizer:
+            self._grad_sumsq = compute_gradients(optimizer, self.store, self.clip_norm, lr)
+            self._packed_step = -1          # weights changed: re-pack before the next forward
+        return [], [], self.metrics, self.metrics_upd, summaries
+
+
+class RnnEstimator(Generator):
+    """models/generators/rnn_estimator.py:39-323."""
+
+    def __init__(self, num_dims, num_hidden, num_hidden_rnn, keep_prob=1.0, internal_bias=True, name="rnn-rbm", track_name="all",
+                 num_inputs=None, precision="bf16", seed=23, device=None, clip_norm=5.0):
+        super().__init__(num_dims, num_hidden, num_hidden_rnn, keep_prob, internal_bias, name, track_name)
+        self.dtype = _compute_dtype(precision)
+        self.seed, self.clip_norm = seed, clip_norm
+        self.row0 = 0                     # global index of this rank's first sequence (data parallel)
+        self.store = ParamStore(device)
+        self._gen = torch.Generator().manual_seed(seed)
+        self._num_inputs = num_inputs
+        self._packed_step = -1
+        self._init_rnn()
+        self._init_estimator()
+
+    # -- construction ---------------------------------------------------------------------------
+    def _init_rnn(self):
+        self._rnn = RNN(num_units=self.num_hidden_rnn, keep_prob=self.keep_prob)
+
+    @abc.abstractmethod
+    def _init_estimator(self):
+        ...
+
+    def _materialize(self, num_inputs):
+        if self.store.theta is not None:
+            return
+        self._num_inputs = self._num_inputs or num_inputs
+        self._declare(self._num_inputs)
+        self.store.materialize()
+        self._stack = LstmStack(self._rnn, self.store, self.dtype)
+        self._trainable_variables = [self.store[n] for n in self.store.names()]
+        self._variables = dict(self.store.views)
+
+    def _get_rnn_zero_state(self, batch_size):
+        return self._rnn.zero_state(batch_size, self.dtype)
+
+    def _ensure_packed(self):
+        if self._packed_step != self.store.step or self._stack.packed is None:
+            self._stack.pack()
+            self._pack_estimator()
+            self._packed_step = self.store.step
+
+    # -- layout helpers -------------------------------------------------------------------------
+    def _to_time_major_inputs(self, x):
+        """x [B,T,Din] (u8/float) -> [T,B,ld0] compute dtype, zero padded."""
+        B, T, Din = x.shape
+        out = torch.zeros((T, B, self._stack.ld0), device=x.device, dtype=self.dtype)
+        out[:, :, :Din] = x.transpose(0, 1).to(self.dtype)
+        return out
+
+    def _row_weight(self, lengths, B, T, device):
+        """1/N_valid on valid rows (N_valid summed over ALL ranks), 0 on padding."""
+        if lengths is None:
+            n_local = torch.tensor(float(B * T), device=device)
+            mask = torch.ones((T, B), device=device)
+        else:
+            mask = (torch.arange(T, device=device)[:, None] < lengths.to(device)[None, :]).float()
+            n_local = mask.sum()
+        n_tot = n_local.clone()
+        if world()[1] > 1:
+            torch.distributed.all_reduce(n_tot)
+        return (mask / n_tot).reshape(-1).contiguous()
+
+    def steps(self, inputs, initial_state=None):
+        return self._get_state(inputs, initial_state=initial_state, last_outputs=True)
+
+    # -- sampling -------------------------------------------------------------------------------
+    def generate(self, x, num_steps):
+        """rnn_estimator.py:271-298: intro pass, then num_steps x {sample_single, single_step}.
+        x [B,Ti,Din]; returns samples u8 [B,num_steps,num_output]."""
+        self._materialize(x.shape[-1])
+        self._rnn.build_cell(False)
+        self._ensure_packed()
+        state = self._get_state(x, lengths=None, last_outputs=True)
+        intro = x[:, -1, :]
+        out = []
+        for s in range(num_steps):
+            self._gen_step = s
+            samples, _ = self.sample_single(intro, state)
+            state = self.single_step(samples, state)
+            intro = samples
+            out.append(samples)
+        return torch.stack(out, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+class RnnNade(RnnEstimator):
+    """models/generators/rnn_nade.py: LSTM -> Dense -> NADE."""
+
+    def __init__(self, num_dims, num_hidden, num_hidden_rnn, keep_prob=1.0, internal_bias=False, name="rnn-nade", track_name="all", **kw):
+        self._tracks = getattr(self, "_tracks", ["all"])
+        super().__init__(num_dims, num_hidden, num_hidden_rnn, keep_prob, internal_bias, name, track_name, **kw)
+        self._num_output = self.num_tracks * self.num_dims
+
+    tracks = property(lambda self: self._tracks)
+    num_tracks = property(lambda self: len(self._tracks))
+
+    def _init_estimator(self):
+        if self.internal_bias:
+            raise NotImplementedError("internal_bias=True is not on the hot path (default False, rnn_nade.py:28)")
+        self._nades = [NADE(self.num_dims, self.num_hidden[-1], internal_bias=False, name=f"nade_{m}") for m in range(self.num_tracks)]
+        self._nade = self._nades[0]
+
+    def _declare(self, num_inputs):
+        """Variable order rnn, nade(s), dense (rnn_nade.py:117-120)."""
+        M, D, Hn, R = self.num_tracks, self.num_dims, self.num_hidden[-1], self.num_hidden_rnn[-1]
+        self._rnn.declare(self.store, num_inputs, self._gen)
+        # all tracks' NADE weights are contiguous so that the kernels see [tracks, D, Hn]
+        from .common import truncated_normal
+        std = 1.0 / (D ** 0.5)
+        self.store.declare("nade/w_enc", (M, D, Hn), truncated_normal(self._gen, std))
+        self.store.declare("nade/w_dec", (M, D, Hn), truncated_normal(self._gen, std))
+        n_out = M * (D + Hn)
+        self.store.declare("dense/kernel", (R, n_out), glorot_uniform(self._gen, R, n_out))
+        self.store.declare("dense/bias", (n_out,), zeros_init)
+        self.n_out = n_out
+        self.ldo = ops.round_up(n_out, 8)
+
+    def _materialize(self, num_inputs):
+        first = self.store.theta is None
+        super()._materialize(num_inputs)
+        if first:
+            for m, nd in enumerate(self._nades):            # per-track views of the stacked NADE weights
+                nd._w_enc_t, nd._w_dec_t = self.store["nade/w_enc"][m], self.store["nade/w_dec"][m]
+
+    def _pack_estimator(self):
+        dev = self.store.theta.device
+        R = self.num_hidden_rnn[-1]
+        self._fc_t = torch.empty((self.n_out, R), device=dev, dtype=self.dtype)        # [n_out, R]: forward B operand
+        ops.transpose(self.store["dense/kernel"], self._fc_t)
+        self._fc_p = torch.zeros((R, self.ldo), device=dev, dtype=self.dtype)           # [R, n_out]: dgrad B operand
+        ops.convert2d(self.store["dense/kernel"], self._fc_p[:, :self.n_out])
+
+    # -- forward --------------------------------------------------------------------------------
+    def build(self, x=None, y=None, lengths=None, is_train=None, mode="eval"):
+        """rnn_nade.py:64-124.  x inputs [B,T,Din], y targets [B,T,tracks*D] (u8 or float)."""
+        Generator.build(self, x, y, lengths, is_train, mode)
+        self._materialize(x.shape[-1] if x is not None else self._num_inputs)
+        self._rnn.build_cell(is_train)
+        if mode in ("train", "eval"):
+            B, T, _ = x.shape
+            M, D = self.num_tracks, self.num_dims
+            x_tm = self._to_time_major_inputs(x)
+            # rnn_multinade.py:97-101: reshape(flat,[-1,D,M]) unstacked on the last axis (track-minor)
+            v = y.to(torch.uint8).transpose(0, 1).reshape(T, B, D, M).permute(3, 0, 1, 2).contiguous() if M > 1 \
+                else y.to(torch.uint8).transpose(0, 1).contiguous().view(1, T, B, D)
+            rw = self._row_weight(lengths, B, T, x.device)
+            self._forward_tm(x_tm, v, rw, lengths, B, T, train=(mode == "train"))
+        self._is_built = True
+
+    def build_pianoroll(self, x_u8, lengths=None, is_train=True, mode="train"):
+        """Fast joint path: x_u8 [B,T,P,M] piano-roll batch; fuses multinn_joint.py:83-89,132-139
+        (zero first step, inputs = enc[:, :-1], targets = enc[:, 1:]) into one kernel."""
+        if self.num_tracks != 1:
+            raise ValueError("build_pianoroll is the joint (single NADE) path")
+        B, T, P, Mtr = x_u8.shape
+        D = P * Mtr
+        self._materialize(D)
+        Generator.build(self, None, None, lengths, is_train, mode)
+        self._rnn.build_cell(is_train)
+        dev = x_u8.device
+        x_tm = torch.empty((T, B, self._stack.ld0), device=dev, dtype=self.dtype)
+        v = torch.empty((T, B, D), device=dev, dtype=torch.uint8)
+        rw = torch.empty(T * B, device=dev)
+        if lengths is not None:
+            n_tot = lengths.sum().to(dev).float()
+            if world()[1] > 1:
+                torch.distributed.all_reduce(n_tot)
+            n_valid = int(n_tot)
+        else:
+            n_valid = B * T * world()[1]
+        ops.pianoroll_shift_timemajor(x_u8.view(B, T, D), lengths, x_tm, v, rw, n_valid)
+        self._forward_tm(x_tm, v.view(1, T, B, D), rw, lengths, B, T, train=(mode == "train"))
+        self._is_built = True
+
+    def _forward_tm(self, x_tm, v, rw, lengths, B, T, train):
+        M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
+        N, dev = T * B, x_tm.device
+        self._ensure_packed()
+        kp = self._rnn.effective_keep_prob()
+        y, ctx, _ = self._stack.forward(x_tm, kp, self.seed + self.store.step, self.row0, save=train)
+        out = torch.empty((N, self.ldo), device=dev)
+        if self.ldo != self.n_out:
+            out[:, self.n_out:].zero_()
+        ops.gemm_tn(y.view(N, -1), self._fc_t, out[:, :self.n_out], bias=self.store["dense/bias"])
+        nll = torch.empty((M, N), device=dev)
+        cond_p = torch.empty((M, N, D), device=dev)
+        rw_m = rw / M if M > 1 else rw
+        d_out = None
+        if train:
+            d_out = torch.empty((N, self.ldo), device=dev)
+            if self.ldo != self.n_out:
+                d_out[:, self.n_out:].zero_()
+        ops.nade_logprob_fwd(v.view(M, N, D), out, self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn,
+                             rw_m if train else None, nll, cond_p, d_out)
+        loss = torch.zeros(1, device=dev)
+        ops.weighted_sum(nll.view(-1), rw_m.repeat(M) if M > 1 else rw_m, loss)      # statistical.py:34 / rnn_multinade.py:202-203
+        self._ctx = dict(x_tm=x_tm, v=v, rw=rw_m, y=y, lstm=ctx, out=out, d_out=d_out, kp=kp, seed=self.seed + self.store.step, B=B, T=T)
+        self._nll_tm, self._cond_tm, self._loss = nll, cond_p, loss
+        self._flat_idx = None
+        self._lengths = lengths
+        self._metrics = {"batch/loss": loss, "log_likelihood": loss}
+        self._metrics_upd = []
+
+    # -- API-order views of the flat outputs (b-major then t, sequences.py:30-31) ---------------
+    def _idx(self):
+        if self._flat_idx is None:
+            self._flat_idx = flat_index(self._lengths, self._ctx["B"], self._ctx["T"], self._loss.device)
+        return self._flat_idx
+
+    @property
+    def log_probs(self):
+        r = [self._nll_tm[m][self._idx()] for m in range(self.num_tracks)]
+        return r[0] if self.num_tracks == 1 else r
+
+    @property
+    def cond_probs(self):
+        r = [self._cond_tm[m][self._idx()] for m in range(self.num_tracks)]
+        return r[0] if self.num_tracks == 1 else r
+
+    @property
+    def _outputs(self):
+        """rnn_nade.py:100: cast(cond_probs >= .5)."""
+        cp = self.cond_probs
+        return (cp >= 0.5).float() if self.num_tracks == 1 else [(c >= 0.5).float() for c in cp]
+
+    def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None):
+        return self._nade.build_metrics(targets, predictions, cond_probs, log_probs)
+
+    # -- backward -------------------------------------------------------------------------------
+    def backward(self):
+        """Gradient of metrics['batch/loss'] wrt rnn + nade + dense variables into store.grad."""
+        cx = self._ctx
+        if cx["d_out"] is None:
+            raise RuntimeError("build(..., mode='train') must run before train()")
+        M, D, Hn, R = self.num_tracks, self.num_dims, self.num_hidden[-1], self.num_hidden_rnn[-1]
+        B, T = cx["B"], cx["T"]
+        N, dev = B * T, cx["out"].device
+        g = self.store.gviews
+        self.store.grad.zero_()
+        d_out = cx["d_out"]
+        ops.nade_logprob_bwd(cx["v"].view(M, N, D), cx["out"], self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn, d_out,
+                             g["nade/w_enc"], g["nade/w_dec"])
+        # dense: dK[R,n_out] = y^T d_out ; db = sum d_out ; dy = d_out K^T
+        Np = ops.round_up(N, 8)
+        zalloc = torch.zeros if Np != N else torch.empty
+        yT = zalloc((R, Np), device=dev, dtype=self.dtype)
+        ops.transpose(cx["y"].view(N, R), yT)
+        doT = zalloc((self.n_out, Np), device=dev, dtype=self.dtype)
+        ops.transpose(d_out[:, :self.n_out], doT)
+        ops.gemm_tn(yT, doT, g["dense/kernel"], accumulate=True, split_k=LstmStack._split_k(R, self.n_out, Np))
+        del yT, doT
+        ops.bias_grad(d_out[:, :self.n_out], g["dense/bias"], accumulate=True)
+        if self.dtype == torch.float32:
+            do_c = d_out
+        else:
+            do_c = torch.empty((N, self.ldo), device=dev, dtype=self.dtype)
+            ops.convert2d(d_out, do_c)
+        dy = torch.empty((N, R), device=dev)
+        ops.gemm_tn(do_c, self._fc_p, dy)
+        self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], cx["seed"], self.row0)
+
+    def train_step(self, x_u8, lengths, optimizer, lr=None):
+        """One optimiser step on a piano-roll batch (train.py:178-189's sess.run)."""
+        self.build_pianoroll(x_u8, lengths, is_train=True, mode="train")
+        self.train(optimizer, lr)
+        return self._loss
+
+    # -- state / sampling -----------------------------------------------------------------------
+    def zero_state(self, batch_size):
+        """rnn_nade.py:158-171 (RnnMultiNADE: per-track lists, R8)."""
+        self._materialize(self._num_inputs)
+        dev = self.store.theta.device
+        z = lambda n: torch.zeros((batch_size, n), device=dev)
+        be = z(self.num_hidden[-1]) if self.num_tracks == 1 else [z(self.num_hidden[-1]) for _ in self._tracks]
+        bd = z(self.num_dims) if self.num_tracks == 1 else [z(self.num_dims) for _ in self._tracks]
+        return RnnEstimatorStateTuple(be, bd, self._get_rnn_zero_state(batch_size))
+
+    def _build_biases(self, outputs):
+        """rnn_nade.py:234-251 / rnn_multinade.py:231-256: b_enc block(s) first, then b_dec block(s)."""
+        M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
+        be = [outputs[:, m * Hn:(m + 1) * Hn] for m in range(M)]
+        bd = [outputs[:, M * Hn + m * D:M * Hn + (m + 1) * D] for m in range(M)]
+        return (be[0], bd[0]) if M == 1 else (be, bd)
+
+    def _dense(self, h):
+        out = torch.empty((h.shape[0], self.ldo), device=h.device)
+        if self.ldo != self.n_out:
+            out[:, self.n_out:].zero_()
+        ops.gemm_tn(h, self._fc_t, out[:, :self.n_out], bias=self.store["dense/bias"])
+        return out
+
+    def _state_from_dense(self, out, rnn_state):
+        be, bd = self._build_biases(out)
+        st = RnnEstimatorStateTuple(be, bd, rnn_state)
+        self._last_dense = out
+        return st
+
+    def _get_state(self, inputs, lengths=None, initial_state=None, last_outputs=False):
+        """rnn_nade.py:173-232."""
+        self._materialize(inputs.shape[-1])
+        self._ensure_packed()
+        if inputs.dim() == 2:
+            inputs = inputs[:, None, :]
+        B, T, _ = inputs.shape
+        x_tm = self._to_time_major_inputs(inputs)
+        st0 = [(c, h) for c, h in initial_state.rnn_state] if initial_state is not None else None
+        y, _, final = self._stack.forward(x_tm, self._rnn.effective_keep_prob(), self.seed, self.row0, save=False, state0=st0)
+        if last_outputs:
+            out = self._dense(y[-1].contiguous())
+        else:
+            out = self._dense(y.view(T * B, -1))[flat_index(lengths, B, T, inputs.device)]
+        return self._state_from_dense(out, tuple((c.clone(), h.clone()) for c, h in final))
+
+    def single_step(self, inputs, initial_state):
+        """rnn_nade.py:253-277."""
+        x = torch.zeros((inputs.shape[0], self._stack.ld0), device=inputs.device, dtype=self.dtype)
+        ops.convert2d(inputs.contiguous() if inputs.dtype in (torch.uint8, torch.float32, torch.bfloat16) else inputs.float(),
+                      x[:, :inputs.shape[1]])
+        h, new = self._stack.single_step(x, [(c, hh) for c, hh in initial_state.rnn_state])
+        return self._state_from_dense(self._dense(h.contiguous()), tuple((c.clone(), hh.clone()) for c, hh in new))
+
+    def log_prob(self, inputs, targets_flat, lengths=None):
+        """rnn_nade.py:279-302 (API-order outputs)."""
+        state = self._get_state(inputs, lengths=lengths)
+        return self._nade.log_prob(targets_flat, state.b_enc, state.b_dec)
+
+    def sample_single(self, inputs, state, temperature=1.0):
+        """rnn_nade.py:304-318 / rnn_multinade.py:295-317: returns (sample u8 [B,num_output], nll)."""
+        M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
+        out = self._last_dense
+        Bn = out.shape[0]
+        smp = torch.empty((Bn, M * D), device=out.device, dtype=torch.uint8)
+        nll = torch.empty((M, Bn), device=out.device)
+        ops.nade_sample(out, self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn, temperature, self.seed, self.row0,
+                        getattr(self, "_gen_step", 0), smp, track_minor=(M > 1), nll=nll)
+        return smp, (nll[0] if M == 1 else [nll[m] for m in range(M)])
+
+
+class RnnMultiNADE(RnnNade):
+    """models/generators/rnn_multinade.py: one LSTM, one Dense, ``len(tracks)`` NADEs."""
+
+    def __init__(self, num_dims, num_hidden, num_hidden_rnn, tracks, keep_prob=1.0, internal_bias=False, name="rnn-multinade", **kw):
+        self._tracks = list(tracks)
+        super().__init__(num_dims, num_hidden, num_hidden_rnn, keep_prob, internal_bias, name, track_name="all", **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+class RnnRBM(RnnEstimator):
+    """models/generators/rnn_rbm.py: LSTM -> (Wuh, Wuv) -> RBM with CD-k Gibbs sampling.
+
+    Reference defects R1-R4 are resolved as recorded there: k = rbm.k in
+    sample_single, lengths forwarded to _get_state, per-row free energy, and
+    ``bias_mode='conditional'`` (Boulanger-Lewandowski) as the trained loss; 'internal'
+    reproduces the as-written metric."""
+
+    def __init__(self, num_dims, num_hidden, num_hidden_rnn, keep_prob=1.0, internal_bias=True, k=10, name="rnn-rbm", track_name="all",
+                 bias_mode="conditional", **kw):
+        self._k = k
+        self.bias_mode = bias_mode
+        super().__init__(num_dims, num_hidden, num_hidden_rnn, keep_prob, internal_bias, name, track_name, **kw)
+        self._num_output = self.num_dims
+
+    k = property(lambda self: self._k)
+
+    def _init_estimator(self):
+        self._rbm = RBM(self.num_dims, self.num_hidden[-1], k=self._k)
+
+    def _declare(self, num_inputs):
+        """Variable order rbm [W,bv,bh], rnn, [Wuh, Wuv] (rnn_rbm.py:135-138)."""
+        D, Hn, R = self.num_dims, self.num_hidden[-1], self.num_hidden_rnn[-1]
+        self._rbm.declare(self.store, self._gen)
+        self._rnn.declare(self.store, num_inputs, self._gen)
+        self.store.declare("Wuh", (R, Hn), glorot_uniform(self._gen, R, Hn))
+        self.store.declare("Wuv", (R, D), glorot_uniform(self._gen, R, D))
+        self.n_out = Hn + D
+        self.ldo = ops.round_up(self.n_out, 8)
+
+    def _pack_estimator(self):
+        dev = self.store.theta.device
+        R, Hn, D = self.num_hidden_rnn[-1], self.num_hidden[-1], self.num_dims
+        wu = torch.cat([self.store["Wuh"], self.store["Wuv"]], 1).contiguous()          # [R, Hn+D]
+        self._wu_t = torch.empty((self.n_out, R), device=dev, dtype=self.dtype)
+        ops.transpose(wu, self._wu_t)
+        self._wu_p = torch.zeros((R, self.ldo), device=dev, dtype=self.dtype)
+        ops.convert2d(wu, self._wu_p[:, :self.n_out])
+        self._bias_cat = torch.cat([self._rbm.bh.view(-1), self._rbm.bv.view(-1)]).contiguous() if self.internal_bias \
+            else torch.zeros(self.n_out, device=dev)
+
+    def _biases(self, h):
+        """rnn_rbm.py:240-259: bh_t = rbm.bh + o.Wuh ; bv_t = rbm.bv + o.Wuv as ONE GEMM."""
+        out = torch.empty((h.shape[0], self.ldo), device=h.device)
+        if self.ldo != self.n_out:
+            out[:, self.n_out:].zero_()
+        ops.gemm_tn(h, self._wu_t, out[:, :self.n_out], bias=self._bias_cat)
+        return out
+
+    def build(self, x=None, y=None, lengths=None, is_train=None, mode="eval"):
+        """rnn_rbm.py:71-143."""
+        Generator.build(self, x, y, lengths, is_train, mode)
+        self._materialize(x.shape[-1] if x is not None else self._num_inputs)
+        self._rnn.build_cell(is_train)
+        if mode in ("train", "eval"):
+            B, T, _ = x.shape
+            D, Hn = self.num_dims, self.num_hidden[-1]
+            N, dev = B * T, x.device
+            self._ensure_packed()
+            x_tm = self._to_time_major_inputs(x)
+            v0 = x.to(torch.uint8).transpose(0, 1).contiguous().view(N, -1)       # chain starts from inputs_flat (rnn_rbm.py:112)
+            tgt = y.to(torch.uint8).transpose(0, 1).contiguous().view(N, D)
+            rw = self._row_weight(lengths, B, T, dev)
+            kp = self._rnn.effective_keep_prob()
+            seed = self.seed + self.store.step
+            yy, ctx, _ = self._stack.forward(x_tm, kp, seed, self.row0, save=(mode == "train"))
+            out = self._biases(yy.view(N, -1))
+            bh_t, bv_t = out[:, :Hn], out[:, Hn:Hn + D]
+            # global flat row ids keep the Gibbs uniforms independent of the data-parallel split
+            rows = (torch.arange(T, device=dev)[:, None] * 65536 + (self.row0 + torch.arange(B, device=dev))[None, :]).reshape(-1).int()
+            p_v = torch.empty((N, D), device=dev)
+            v_s = torch.empty((N, D), device=dev, dtype=torch.uint8)
+            ops.rbm_gibbs(v0[:, :D].contiguous(), self._rbm.W, bh_t, bv_t, self._k, seed, 0, rows, 0, p_v, v_s)
+            if self.bias_mode == "conditional":
+                bh_u, bv_u = bh_t, bv_t
+            else:
+                bh_u, bv_u = self._rbm.bh, self._rbm.bv
+            Fv = torch.empty(N, device=dev); Fs = torch.empty(N, device=dev)
+            ops.rbm_free_energy(tgt, self._rbm.W, bh_u, bv_u, Fv)
+            ops.rbm_free_energy(v_s, self._rbm.W, bh_u, bv_u, Fs)
+            cost = Fv - Fs
+            loss = torch.zeros(1, device=dev)
+            ops.weighted_sum(cost, rw, loss)
+            self._ctx = dict(y=yy, lstm=ctx, out=out, tgt=tgt, v_s=v_s, rw=rw, kp=kp, seed=seed, B=B, T=T, bh_u=bh_u, bv_u=bv_u)
+            self._cost_tm, self._F_tm, self._pv_tm, self._vs_tm, self._loss = cost, Fv, p_v, v_s, loss
+            self._lengths, self._flat_idx = lengths, None
+            t = tgt.float()
+            self._recon_tm = (-t * torch.log(p_v + 1e-7) - (1 - t) * torch.log(1 - p_v + 1e-7)).sum(1)       # rbm.py:124-129
+            self._metrics = {"batch/loss": loss, "free_energy": (Fv * rw).sum(), "log_likelihood": (self._recon_tm * rw).sum()}
+            self._metrics_upd = []
+        self._is_built = True
+
+    def _idx(self):
+        if self._flat_idx is None:
+            self._flat_idx = flat_index(self._lengths, self._ctx["B"], self._ctx["T"], self._loss.device)
+        return self._flat_idx
+
+    cond_probs = property(lambda self: self._pv_tm[self._idx()])
+    _outputs = property(lambda self: self._vs_tm[self._idx()].float())
+    free_energy = property(lambda self: self._F_tm[self._idx()])
+    cost = property(lambda self: self._cost_tm[self._idx()])
+    reconstruction_cost = property(lambda self: self._recon_tm[self._idx()])
+
+    def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None):
+        return self._rbm.build_metrics(targets, predictions, cond_probs, log_probs)
+
+    def backward(self):
+        cx = self._ctx
+        D, Hn, R = self.num_dims, self.num_hidden[-1], self.num_hidden_rnn[-1]
+        B, T = cx["B"], cx["T"]
+        N, dev = B * T, cx["out"].device
+        g = self.store.gviews
+        self.store.grad.zero_()
+        sv = torch.empty((N, Hn), device=dev); ss = torch.empty((N, Hn), device=dev)
+        ops.rbm_hidden(cx["tgt"], self._rbm.W, cx["bh_u"], 0, 0, 0, 0, sv, None)
+        ops.rbm_hidden(cx["v_s"], self._rbm.W, cx["bh_u"], 0, 0, 0, 0, ss, None)
+        rw = cx["rw"][:, None]
+        # dF/dbh = -sigmoid(z), dF/dbv = -v, dF/dW = -v^T sigmoid(z); cost = F(v) - F(v_s), v_s constant (rbm.py:229)
+        d_out = torch.zeros((N, self.ldo), device=dev)
+        d_out[:, :Hn] = rw * (ss - sv)
+        d_out[:, Hn:Hn + D] = rw * (cx["v_s"].float() - cx["tgt"].float())
+        Np = ops.round_up(N, 4)
+        def tr(xm, rows):
+            o = torch.zeros((rows, Np), device=dev)
+            return ops.transpose(xm.contiguous(), o)
+        ops.gemm_tn(tr(cx["v_s"], D), tr(rw * ss, Hn), g[f"{self._rbm.prefix}/W"], accumulate=True)
+        neg = torch.empty((D, Hn), device=dev)
+        ops.gemm_tn(tr(cx["tgt"], D), tr(rw * sv, Hn), neg)
+        g[f"{self._rbm.prefix}/W"].sub_(neg)
+        if self.bias_mode != "conditional":
+            g[f"{self._rbm.prefix}/bh"].add_(d_out[:, :Hn].sum(0, keepdim=True))
+            g[f"{self._rbm.prefix}/bv"].add_(d_out[:, Hn:Hn + D].sum(0, keepdim=True))
+            return                                   # as written: no gradient reaches the LSTM / Wuh / Wuv (R3)
+        if self.internal_bias:
+            ops.bias_grad(d_out[:, :Hn], g[f"{self._rbm.prefix}/bh"].view(-1), accumulate=True)
+            ops.bias_grad(d_out[:, Hn:Hn + D], g[f"{self._rbm.prefix}/bv"].view(-1), accumulate=True)
+        Np8 = ops.round_up(N, 8)
+        yT = torch.zeros((R, Np8), device=dev, dtype=self.dtype)
+        ops.transpose(cx["y"].view(N, R), yT)
+        doT = torch.zeros((self.n_out, Np8), device=dev, dtype=self.dtype)
+        ops.transpose(d_out[:, :self.n_out], doT)
+        dwu = torch.empty((R, self.n_out), device=dev)
+        ops.gemm_tn(yT, doT, dwu, split_k=LstmStack._split_k(R, self.n_out, Np8))
+        g["Wuh"].add_(dwu[:, :Hn]); g["Wuv"].add_(dwu[:, Hn:])
+        do_c = d_out if self.dtype == torch.float32 else d_out.to(self.dtype)
+        dy = torch.empty((N, R), device=dev)
+        ops.gemm_tn(do_c, self._wu_p, dy)
+        self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], cx["seed"], self.row0)
+
+    def zero_state(self, batch_size):
+        self._materialize(self._num_inputs)
+        dev = self.store.theta.device
+        return RnnEstimatorStateTuple(torch.zeros((batch_size, self.num_hidden[-1]), device=dev),
+                                      torch.zeros((batch_size, self.num_dims), device=dev), self._get_rnn_zero_state(batch_size))
+
+    def _get_state(self, inputs, lengths=None, initial_state=None, last_outputs=False):
+        """rnn_rbm.py:184-238 (dynamic_rnn; identical to the decode loop on valid rows)."""
+        self._materialize(inputs.shape[-1])
+        self._ensure_packed()
+        if inputs.dim() == 2:
+            inputs = inputs[:, None, :]
+        B, T, _ = inputs.shape
+        x_tm = self._to_time_major_inputs(inputs)
+        st0 = [(c, h) for c, h in initial_state.rnn_state] if initial_state is not None else None
+        y, _, final = self._stack.forward(x_tm, self._rnn.effective_keep_prob(), self.seed, self.row0, save=False, state0=st0)
+        out = self._biases(y[-1].contiguous()) if last_outputs else self._biases(y.view(T * B, -1))[flat_index(lengths, B, T, inputs.device)]
+        Hn, D = self.num_hidden[-1], self.num_dims
+        return RnnEstimatorStateTuple(out[:, :Hn], out[:, Hn:Hn + D], tuple((c.clone(), h.clone()) for c, h in final))
+
+    def single_step(self, inputs, initial_state):
+        """rnn_rbm.py:261-281."""
+        x = torch.zeros((inputs.shape[0], self._stack.ld0), device=inputs.device, dtype=self.dtype)
+        ops.convert2d(inputs.contiguous(), x[:, :inputs.shape[1]])
+        h, new = self._stack.single_step(x, [(c, hh) for c, hh in initial_state.rnn_state])
+        out = self._biases(h.contiguous())
+        Hn, D = self.num_hidden[-1], self.num_dims
+        return RnnEstimatorStateTuple(out[:, :Hn], out[:, Hn:Hn + D], tuple((c.clone(), hh.clone()) for c, hh in new))
+
+    def sample_single(self, inputs, state):
+        """rnn_rbm.py:283-297 with k = rbm.k (R1): returns (sample u8, cond_prob)."""
+        p_v, v = self._rbm.sample(inputs[:, :self.num_dims], state.b_enc, state.b_dec, self._k, self.seed, self.row0, None,
+                                  getattr(self, "_gen_step", 0) * max(self._k, 1))
+        return v, p_v
+
+    def pretrain(self, optimizer, lr, run_optimizer=True):
+        """rnn_rbm.py:299-322: CD-k on the flattened inputs."""
+        x = self._inputs
+        B, T, _ = x.shape
+        flat = x.to(torch.uint8)[:, :, :self.num_dims].reshape(B * T, self.num_dims)
+        if self._lengths is not None:
+            m = torch.arange(T, device=x.device)[None, :] < self._lengths.to(x.device)[:, None]
+            flat = flat[m.reshape(-1)]
+        return self._rbm.train(flat.contiguous(), lr, seed=self.seed + self.store.step)

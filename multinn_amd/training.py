@@ -1,0 +1,50 @@
+"""utils/training.py:151-177 + train.py:61-64 -- optimiser objects and the gradient step.
+
+``compute_gradients(optimizer, loss_model, store)`` = global-norm clip + apply, on the flat
+buffer of a ParamStore, with ONE all-reduce of that buffer when torch.distributed is initialised
+(backend "nccl" is RCCL over xGMI on ROCm; "gloo" in CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class AdamOptimizer:
+    """tf.train.AdamOptimizer(lr, epsilon=1e-4) (train.py:64): epsilon outside the bias correction."""
+
+    def __init__(self, learning_rate=0.01, beta1=0.9, beta2=0.999, epsilon=1e-4):
+        self.lr, self.beta1, self.beta2, self.epsilon = learning_rate, beta1, beta2, epsilon
+        self.sgd = False
+
+
+class GradientDescentOptimizer:
+    """tf.train.GradientDescentOptimizer (train.py:61-62)."""
+
+    def __init__(self, learning_rate=0.01):
+        self.lr, self.beta1, self.beta2, self.epsilon = learning_rate, 0.9, 0.999, 1e-4
+        self.sgd = True
+
+
+def world():
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+
+
+def allreduce_flat(grad):
+    """The single data-parallel exchange of the step: sum the flat gradient over ranks."""
+    if world()[1] > 1:
+        dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+    return grad
+
+
+def compute_gradients(optimizer, store, clip_norm=5.0, lr=None):
+    """clip_by_global_norm(5.0) (hard-coded in the reference, training.py:166; R9 honours the
+    argument) + optimizer.apply_gradients.  The gradient must already be in store.grad.
+    Returns the device scalar holding sum(grad^2) (global norm squared, after the all-reduce)."""
+    allreduce_flat(store.grad)
+    sumsq = torch.zeros(1, device=store.grad.device)
+    ops.sumsq(store.grad, sumsq)
+    store.step += 1
+    ops.clip_adam_step(store.theta, store.grad, store.m, store.v, sumsq, clip_norm, optimizer.lr if lr is None else lr,
+                       optimizer.beta1, optimizer.beta2, optimizer.epsilon, store.step, optimizer.sgd)
+    return sumsq

@@ -1,0 +1,296 @@
+"""End-to-end parity of the Generator plugin classes (RnnNade, RnnMultiNADE, RnnRBM, encoders)
+against the CPU oracle: forward metrics, every gradient, and the clipped TF-Adam step.
+
+fp32 path: 1e-4 relative (the BASELINE.json gate).  bf16 path: its own error is reported against
+the fp32 oracle with a loose bound (bf16 carries 8 significant bits)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import generators as G, nade as onade, rbm as orbm, philox, det   # noqa: E402
+from oracle import tf_semantics as S   # noqa: E402
+
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(1e-30, np.abs(b).max())
+
+
+def load_nade_params(gen, p):
+    s = gen.store
+    for l, (W, b) in enumerate(p['lstm']):
+        s[f"rnn/cell_{l}/kernel"].copy_(dev(W.astype(np.float32)))
+        s[f"rnn/cell_{l}/bias"].copy_(dev(b.astype(np.float32)))
+    s["nade/w_enc"].copy_(dev(np.stack(p['w_enc']).astype(np.float32)))
+    s["nade/w_dec"].copy_(dev(np.stack(p['w_dec']).astype(np.float32)))
+    s["dense/kernel"].copy_(dev(p['fc_k'].astype(np.float32)))
+    s["dense/bias"].copy_(dev(p['fc_b'].astype(np.float32)))
+
+
+def oracle_grad_list(g):
+    out = []
+    for W, b in g['lstm']:
+        out += [W, b]
+    out += [np.stack(g['w_enc']), np.stack(g['w_dec']), g['fc_k'], g['fc_b']]
+    return out
+
+
+def make_batch(B, T, P, M, seed, rho=0.25):
+    R = np.random.default_rng(seed)
+    return (R.random((B, T, P, M)) < rho).astype(np.uint8)
+
+
+@pytest.mark.parametrize("precision,ragged", [("fp32", False), ("fp32", True), ("bf16", True)])
+def test_rnn_nade_joint_train_step(precision, ragged):
+    from multinn_amd import RnnNade, AdamOptimizer
+    B, T, P, M, Hn, units = 6, 5, 4, 3, 20, [32, 64]
+    D = P * M
+    x = make_batch(B, T, P, M, 1)
+    lengths = np.array([5, 2, 4, 5, 1, 3], np.int32) if ragged else None
+    p = G.init_rnn_nade(3, D, D, Hn, units, np.float64)
+    for W, b in p['lstm']:
+        b += 0.05
+    p['fc_b'] += 0.02
+    gen = RnnNade(D, Hn, units, keep_prob=0.9, precision=precision, seed=23)
+    gen.build_pianoroll(dev(x), None if lengths is None else dev(lengths), is_train=True, mode="train")   # materialises the store
+    load_nade_params(gen, p)
+    gen._packed_step = -1
+    gen.build_pianoroll(dev(x), None if lengths is None else dev(lengths), is_train=True, mode="train")
+    # oracle
+    inp, tgt = G.joint_inputs(x.astype(np.float64))
+    du = G.dropout_uniforms(23, B, T, units)
+    fw = G.rnn_nade_forward(inp, tgt, lengths, p, 0.9, du)
+    g = G.rnn_nade_backward(fw, p)
+    tol = 1e-4 if precision == "fp32" else 6e-2
+    assert abs(float(gen.metrics['batch/loss']) - fw['loss']) < tol * abs(fw['loss'])
+    assert rel(gen.log_probs.cpu().numpy(), fw['nll'][0]) < tol
+    assert np.abs(gen.cond_probs.cpu().numpy() - fw['cond_p'][0]).max() < (1e-5 if precision == "fp32" else 3e-2)
+    assert gen.forward().shape == fw['cond_p'][0].shape
+    gen.backward()
+    names = gen.store.names()
+    for name, ref in zip(names, oracle_grad_list(g)):
+        got = gen.store.gviews[name].cpu().numpy().reshape(ref.shape)
+        assert rel(got, ref) < tol * (1 if precision == "fp32" else 2), name
+    # optimiser step (clip 5.0 + TF Adam) on the oracle's own gradients vs the device step
+    opt_ref = G.new_opt(G.flat_params(p))
+    gn = G.apply_clip_adam(G.flat_params(p), G.flat_grads(g), opt_ref, lr=0.01)
+    gen.train(AdamOptimizer(0.01), None)
+    assert abs(float(gen._grad_sumsq.sqrt()) - gn) < tol * gn
+    if precision == "fp32":
+        ref_params = [x_ for pair in p['lstm'] for x_ in pair] + [np.stack(p['w_enc']), np.stack(p['w_dec']), p['fc_k'], p['fc_b']]
+        for name, ref in zip(names, ref_params):
+            # Adam's first step moves every weight by ~lr*sign(g): compare the UPDATE, not just the value
+            assert np.abs(gen.store[name].cpu().numpy().reshape(ref.shape) - ref).max() < 2e-4, name
+
+
+def test_rnn_nade_generic_build_equals_pianoroll_path():
+    from multinn_amd import RnnNade
+    B, T, P, M, Hn, units = 4, 6, 4, 2, 16, [32, 32]
+    D = P * M
+    x = make_batch(B, T, P, M, 2)
+    inp, tgt = G.joint_inputs(x)
+    lengths = np.array([6, 3, 5, 2], np.int32)
+    gen = RnnNade(D, Hn, units, keep_prob=1.0, precision="fp32", seed=5)
+    gen.build(dev(inp), dev(tgt), dev(lengths), is_train=False, mode="eval")
+    l1, n1 = float(gen.metrics['batch/loss']), gen.log_probs.clone()
+    gen.build_pianoroll(dev(x), dev(lengths), is_train=False, mode="eval")
+    assert abs(l1 - float(gen.metrics['batch/loss'])) < 1e-6 * abs(l1) and torch.allclose(n1, gen.log_probs, rtol=1e-6)
+    assert n1.shape[0] == int(lengths.sum())
+    with pytest.raises(ValueError):
+        gen.build(dev(inp), dev(tgt), None, None, mode="bogus")
+    with pytest.raises(RuntimeError):
+        gen.train(None, None)                      # eval build keeps no backward context
+
+
+def test_rnn_multinade_train_step():
+    from multinn_amd import RnnMultiNADE
+    B, T, E, M, Hn, units = 5, 4, 6, 3, 12, [32, 32]
+    R = np.random.default_rng(4)
+    enc = (R.random((B, T + 1, E * M)) < .3).astype(np.uint8)      # stacked per-track codes, track-minor (multinn_composer.py:73-87)
+    enc[:, 0] = 0
+    inp, tgt = enc[:, :-1], enc[:, 1:]
+    p = G.init_rnn_nade(7, E * M, E, Hn, units, np.float64, tracks=M)
+    gen = RnnMultiNADE(E, Hn, units, tracks=[f"t{m}" for m in range(M)], keep_prob=0.9, precision="fp32", seed=11)
+    gen.build(dev(inp), dev(tgt), None, True, "train")
+    load_nade_params(gen, p)
+    gen._packed_step = -1
+    gen.build(dev(inp), dev(tgt), None, True, "train")
+    du = G.dropout_uniforms(11, B, T, units)
+    fw = G.rnn_nade_forward(inp.astype(np.float64), tgt.astype(np.float64), None, p, 0.9, du, tracks=M)
+    g = G.rnn_nade_backward(fw, p, tracks=M)
+    assert abs(float(gen.metrics['batch/loss']) - fw['loss']) < 1e-4 * abs(fw['loss'])
+    for m in range(M):
+        assert rel(gen.log_probs[m].cpu().numpy(), fw['nll'][m]) < 1e-4
+    gen.backward()
+    for name, ref in zip(gen.store.names(), oracle_grad_list(g)):
+        assert rel(gen.store.gviews[name].cpu().numpy().reshape(ref.shape), ref) < 1e-4, name
+    st = gen.zero_state(3)
+    assert len(st.b_enc) == M and st.b_enc[0].shape == (3, Hn) and len(st.rnn_state) == 2
+
+
+def _check_autoregressive_samples(samples, intro, p, seed, tracks, D, tol=2e-5):
+    """Teacher-forced verification of a sampling scan: replay the oracle on the DEVICE's own
+    samples and require every draw to agree with u < p unless |u - p| is within tol."""
+    from oracle import lstm as olstm
+    B, steps, _ = samples.shape
+    Hn = p['w_enc'][0].shape[1]
+    y, state, _ = olstm.seq_fwd(intro.astype(np.float64), p['lstm'])
+    out = S.dense(y[:, -1], p['fc_k'], p['fc_b'])
+    n_amb = 0
+    for s in range(steps):
+        b_enc, b_dec = G.split_biases(out, Hn, D, tracks)
+        u = philox.uniform_block(seed, philox.STREAM_NADE, np.arange(B), s, tracks * D)
+        step = samples[:, s].astype(np.float64)
+        per = [step] if tracks == 1 else [step.reshape(B, D, tracks)[..., m] for m in range(tracks)]
+        for m in range(tracks):
+            _, cp = onade.log_prob(per[m], b_enc[m], b_dec[m], p['w_enc'][m], p['w_dec'][m])
+            um = u[:, m * D:(m + 1) * D]
+            want = um < cp
+            bad = want != (per[m] > 0.5)
+            amb = np.abs(um - cp) < tol
+            assert not (bad & ~amb).any(), f"step {s} track {m}: draw disagrees with u<p beyond tolerance"
+            n_amb += int((bad & amb).sum())
+        h, state = G.lstm_single_step(step, state, p['lstm'])
+        out = S.dense(h, p['fc_k'], p['fc_b'])
+    return n_amb
+
+
+@pytest.mark.parametrize("tracks", [1, 3])
+def test_generate_scan(tracks):
+    from multinn_amd import RnnNade, RnnMultiNADE
+    B, Ti, E, Hn, units, steps = 5, 4, 8, 16, [32, 32], 6
+    Din = E * tracks
+    R = np.random.default_rng(6)
+    intro = (R.random((B, Ti, Din)) < .3).astype(np.uint8)
+    p = G.init_rnn_nade(9, Din, E, Hn, units, np.float64, tracks=tracks)
+    gen = RnnNade(E, Hn, units, precision="fp32", seed=31) if tracks == 1 else \
+        RnnMultiNADE(E, Hn, units, tracks=list("abc"), precision="fp32", seed=31)
+    gen._materialize(Din)
+    load_nade_params(gen, p)
+    out = gen.generate(dev(intro), steps)
+    assert out.shape == (B, steps, Din) and out.dtype == torch.uint8
+    _check_autoregressive_samples(out.cpu().numpy(), intro, p, 31, tracks, E)
+    assert torch.equal(out, gen.generate(dev(intro), steps))          # fixed RNG -> reproducible
+    gen.row0 = 2                                                        # row-keyed RNG: a batch slice reproduces its rows
+    sub = gen.generate(dev(intro[2:]), steps)
+    assert torch.equal(sub, out[2:])
+
+
+@pytest.mark.parametrize("bias_mode", ["conditional", "internal"])
+def test_rnn_rbm_train_step(bias_mode):
+    from multinn_amd import RnnRBM
+    B, T, D, Hn, units, k = 5, 4, 12, 20, [32, 32], 3
+    x = make_batch(B, T, D, 1, 8)
+    inp, tgt = G.joint_inputs(x)
+    p = G.init_rnn_rbm(5, D, D, Hn, units, np.float64)
+    p['bh'] += 0.1
+    p['bv'] -= 0.2
+    gen = RnnRBM(D, Hn, units, keep_prob=1.0, k=k, precision="fp32", seed=13, bias_mode=bias_mode)
+    gen.build(dev(inp), dev(tgt), None, True, "train")
+    s = gen.store
+    for l, (W, b) in enumerate(p['lstm']):
+        s[f"rnn/cell_{l}/kernel"].copy_(dev(W.astype(np.float32))); s[f"rnn/cell_{l}/bias"].copy_(dev(b.astype(np.float32)))
+    for kk in ("W", "bh", "bv"):
+        s[f"rbm/{kk}"].copy_(dev(p[kk].astype(np.float32)))
+    s["Wuh"].copy_(dev(p['Wuh'].astype(np.float32))); s["Wuv"].copy_(dev(p['Wuv'].astype(np.float32)))
+    gen._packed_step = -1
+    gen.build(dev(inp), dev(tgt), None, True, "train")
+    rows = np.array([t * 65536 + b for b in range(B) for t in range(T)])     # b-major flat order, time/batch keyed ids
+    fw = G.rnn_rbm_forward(inp.astype(np.float64), tgt.astype(np.float64), None, p, k, seed=13, bias_mode=bias_mode, row_ids=rows)
+    vs_dev = gen._outputs.cpu().numpy()
+    agree = (vs_dev == fw['v_sample']).all(1).mean()
+    assert agree >= 0.9, f"only {agree:.2f} of the Gibbs rows agree with the float64 oracle"
+    # evaluate the oracle on the device's own sample so a rare u~p flip cannot hide an arithmetic error
+    fw['v_sample'] = vs_dev.astype(np.float64)
+    bh_u, bv_u = (fw['bh_t'], fw['bv_t']) if bias_mode == "conditional" else (p['bh'], p['bv'])
+    cost, F = orbm.free_energy_cost(fw['tgt'], fw['v_sample'], p['W'], bh_u, bv_u)
+    assert rel(gen.cost.cpu().numpy(), cost) < 1e-4 and rel(gen.free_energy.cpu().numpy(), F) < 1e-4
+    assert abs(float(gen.metrics['batch/loss']) - cost.mean()) < 1e-4 * max(1.0, abs(cost.mean()))
+    if agree == 1.0:
+        assert rel(gen.reconstruction_cost.cpu().numpy(), fw['recon']) < 1e-4
+    g = G.rnn_rbm_backward(fw, p)
+    gen.backward()
+    gv = gen.store.gviews
+    assert rel(gv["rbm/W"].cpu().numpy(), g['W']) < 1e-4
+    if bias_mode == "conditional":
+        assert rel(gv["rbm/bh"].cpu().numpy(), g['bh']) < 1e-4 and rel(gv["rbm/bv"].cpu().numpy(), g['bv']) < 1e-4
+        assert rel(gv["Wuh"].cpu().numpy(), g['Wuh']) < 1e-4 and rel(gv["Wuv"].cpu().numpy(), g['Wuv']) < 1e-4
+        for l, (dW, db) in enumerate(g['lstm']):
+            assert rel(gv[f"rnn/cell_{l}/kernel"].cpu().numpy(), dW) < 1e-4
+            assert rel(gv[f"rnn/cell_{l}/bias"].cpu().numpy(), db) < 1e-4
+    else:
+        assert float(gv["Wuh"].abs().max()) == 0 and float(gv["rnn/cell_0/kernel"].abs().max()) == 0      # R3: as written
+    # sampling path: sample_single uses k = rbm.k (R1)
+    out = gen.generate(dev(inp[:, :2]), 3)
+    assert out.shape == (B, 3, D) and out.dtype == torch.uint8
+
+
+def test_rbm_cd_update_and_dbn_encoder():
+    from multinn_amd import DBNEncoder
+    from multinn_amd.common import RBM, ParamStore
+    R = np.random.default_rng(12)
+    N, D, Hn, k = 40, 16, 12, 2
+    v = (R.random((N, D)) < .3).astype(np.uint8)
+    store = ParamStore(torch.device(DEV))
+    rbm = RBM(D, Hn, k=k)
+    rbm.declare(store, torch.Generator().manual_seed(1))
+    store.materialize()
+    W0, bh0, bv0 = rbm.W.cpu().numpy().copy(), rbm.bh.cpu().numpy().copy(), rbm.bv.cpu().numpy().copy()
+    rbm.seed = 99
+    _, upd, grads = rbm.train(dev(v), lr=0.1, row0=7, sub0=0)
+    rows = np.arange(7, 7 + N)
+    u_h, u_v = G.gibbs_uniforms(99, rows, k, Hn, D, 0)
+    u0 = philox.uniform_block(99, philox.STREAM_RBM_H, rows, k, Hn)
+    uk = philox.uniform_block(99, philox.STREAM_RBM_H, rows, k + 1, Hn)
+    dW, dbv, dbh = orbm.cd_update(v.astype(np.float64), W0.astype(np.float64), bh0.astype(np.float64), bv0.astype(np.float64), k, 0.1,
+                                  u_h, u_v, u0, uk)
+    assert rel(grads[0].cpu().numpy(), dW) < 1e-4 and rel(grads[1].cpu().numpy(), dbv) < 1e-4 and rel(grads[2].cpu().numpy(), dbh) < 1e-4
+    assert rel(rbm.W.cpu().numpy(), W0 + dW) < 1e-5
+    # DBN encoder: sampled codes up, reconstruction down (dbn_encoder.py:136-190)
+    enc = DBNEncoder(D, [12, 8], seed=3)
+    x = dev(v.reshape(4, 10, D))
+    enc.build(x)
+    assert enc.encodings.shape == (4, 10, 8) and enc.encodings.dtype == torch.uint8
+    assert enc.dec_probs.shape == (4, 10, D) and float(enc.dec_probs.min()) > 0 and float(enc.dec_probs.max()) < 1
+    W1, W2 = [r.W.cpu().numpy() for r in enc.dbn.rbms]
+    b1, b2 = [r.bh.cpu().numpy() for r in enc.dbn.rbms]
+    ph1 = det.rbm_hidden(v, W1, b1)
+    h1 = (philox.uniform_block(3, philox.STREAM_DBN_ENC, np.arange(N), 0, 12) < ph1).astype(np.uint8)
+    ph2 = det.rbm_hidden(h1, W2, b2)
+    h2 = (philox.uniform_block(3, philox.STREAM_DBN_ENC, np.arange(N), 1, 8) < ph2).astype(np.uint8)
+    assert np.array_equal(enc.encodings.cpu().numpy().reshape(N, 8), h2)
+    assert np.array_equal(enc.enc_probs.cpu().numpy().reshape(N, 8), ph2)
+    enc.train(None, 0.05, layer=1)
+
+
+def test_save_load_roundtrip(tmp_path):
+    from multinn_amd import RnnNade, AdamOptimizer
+    x = make_batch(4, 4, 4, 2, 3)
+    gen = RnnNade(8, 8, [32], keep_prob=1.0, precision="fp32", seed=1)
+    gen.train_step(dev(x), None, AdamOptimizer(0.01))
+    gen.save(None, str(tmp_path))
+    other = RnnNade(8, 8, [32], keep_prob=1.0, precision="fp32", seed=2)
+    other._materialize(8)
+    assert not other.load(None, str(tmp_path / "missing"))
+    assert other.load(None, str(tmp_path))
+    assert torch.equal(other.store.theta, gen.store.theta) and torch.equal(other.store.m, gen.store.m) and other.store.step == 1
+    l1 = float(gen.train_step(dev(x), None, AdamOptimizer(0.01)))
+    l2 = float(other.train_step(dev(x), None, AdamOptimizer(0.01)))
+    assert l1 == l2
+
+
+def test_training_reduces_loss():
+    from multinn_amd import RnnNade, AdamOptimizer
+    x = make_batch(8, 8, 8, 2, 5, rho=0.1)
+    gen = RnnNade(16, 16, [32, 32], keep_prob=0.9, precision="bf16", seed=3)
+    opt = AdamOptimizer(0.01)
+    losses = [float(gen.train_step(dev(x), None, opt)) for _ in range(40)]
+    assert losses[-1] < 0.7 * losses[0], losses[::8]
