@@ -73,9 +73,20 @@ def check(rc, what=""):
         raise MnnError(f"{what} failed ({rc}): {load().mnn_last_error().decode()}")
 
 
+TIMING = None      # bench.py sets this to a dict: entry point -> list of (start_event, end_event)
+
+
 def call(name, *args):
     """Call an int-returning entry point and raise MnnError on a non-zero code."""
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if TIMING is not None:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()            # the library launches on torch's current stream, so these events bracket its kernels
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        TIMING.setdefault(name, []).append((e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise MnnError(f"{name} failed ({rc}): {lib.mnn_last_error().decode()}")

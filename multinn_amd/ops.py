@@ -9,7 +9,11 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, U8, GEMM_ACCUMULATE, call
+from ._lib import F32, BF16, U8, GEMM_ACCUMULATE
+
+
+def call(name, *args):
+    return _lib.call(name, *args)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.uint8: U8}
 
