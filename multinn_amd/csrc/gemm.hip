@@ -273,6 +273,153 @@ lstm_fwd_step_kernel(const T* __restrict__ h_prev, const T* __restrict__ wh_t, c
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Latency-optimised bf16 step kernels (the recurrence is T sequential tiny GEMMs: per-step latency,
+// not throughput, sets the time).  One block = one 32-row x 32-unit output tile; the K dimension is
+// split over the block's waves; every wave loads ALL its operands straight into registers with
+// 16-byte loads issued back to back (no LDS staging, no K-loop barrier), runs its MFMAs, and the
+// partial tiles meet once in LDS.  K is permuted inside a wave (lane half h owns 8*KS consecutive
+// elements) so each lane reads one contiguous run; A and B use the same permutation.
+// ----------------------------------------------------------------------------------------------
+template <int KS>
+__device__ __forceinline__ void load_frags(const bf16_t* __restrict__ p, bf16x8_t (&f)[KS]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) f[s] = *reinterpret_cast<const bf16x8_t*>(p + 8 * s);
+}
+
+// forward: 4 waves, K = U = 64*KS.  Tile columns = 4 gates x 32 units (gate-interleaved layout).
+template <int KS>
+__global__ void __launch_bounds__(256)
+lstm_fwd_step_v2(const bf16_t* __restrict__ h_prev, const bf16_t* __restrict__ wh_t, const float* __restrict__ xproj,
+                 const float* __restrict__ c_prev, float* __restrict__ gates, float* __restrict__ c_out, bf16_t* __restrict__ h_out,
+                 int B, int U) {
+    __shared__ float red[4][4][16][64];
+    const int nt = blockIdx.x, m0 = blockIdx.y * 32, n0 = nt * 128, N4 = 4 * U;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    // epilogue operands of this wave's 4 fragment rows, requested first so they fly under the MFMAs
+    const int col = r, unit = nt * 32 + col;
+    float xp[4][4], cp[4];
+    bool live[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = m0 + 8 * w + q + 4 * hh;
+        live[q] = row < B;
+        const int rr = live[q] ? row : B - 1;
+        const size_t zo = (size_t)rr * N4 + n0 + col;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xp[q][g] = xproj[zo + 32 * g];
+        cp[q] = c_prev != nullptr ? c_prev[(size_t)rr * U + unit] : 0.f;
+    }
+    f32x16_t acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
+    if (h_prev != nullptr) {
+        const int kb = w * 16 * KS + hh * 8 * KS;
+        const int arow = min(m0 + r, B - 1);
+        bf16x8_t a[KS], b[4][KS];
+        load_frags<KS>(h_prev + (size_t)arow * U + kb, a);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) load_frags<KS>(wh_t + (size_t)(n0 + 32 * g + r) * U + kb, b[g]);
+        __builtin_amdgcn_sched_barrier(0);      // keep EVERY load in flight before the first MFMA (latency, not registers, is scarce)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[g][s], acc[g], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[w][g][i][lane] = acc[g][i];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = 4 * w + q;                       // fragment reg -> row 8w + q + 4h of the tile
+        float z[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) z[g] = xp[q][g] + ((red[0][g][i][lane] + red[1][g][i][lane]) + (red[2][g][i][lane] + red[3][g][i][lane]));
+        if (!live[q]) continue;
+        const int row = m0 + 8 * w + q + 4 * hh;
+        const float gi = fast_sigmoid(z[0]), gg = fast_tanh(z[1]), gf = fast_sigmoid(z[2]), go = fast_sigmoid(z[3]);
+        const float c = gg * gi + cp[q] * gf;
+        const float h = fast_tanh(c) * go;
+        const size_t zo = (size_t)row * N4 + n0 + col, uo = (size_t)row * U + unit;
+        if (gates != nullptr) { gates[zo] = gi; gates[zo + 32] = gg; gates[zo + 64] = gf; gates[zo + 96] = go; }
+        c_out[uo] = c;
+        h_out[uo] = f32_to_bf16(h);
+    }
+}
+
+// backward: 8 waves, K = 4U = 128*KS.  dh = dh_ext + dz_next . Wh^T, then the gate pointwise.
+template <int KS>
+__global__ void __launch_bounds__(512)
+lstm_bwd_step_v2(const bf16_t* __restrict__ dz_next, const bf16_t* __restrict__ wh_p, const float* __restrict__ dh_ext,
+                 const float* __restrict__ gates, const float* __restrict__ c_t, const float* __restrict__ c_prev, float* __restrict__ dc,
+                 float* __restrict__ dz, bf16_t* __restrict__ dzT, int B, int U, int first) {
+    __shared__ float red[8][16][64];
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32, N4 = 4 * U;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int unit = n0 + r, pc = gate_perm_col(0, unit);
+    float e_dh[2], e_g[2][4], e_c[2], e_cp[2], e_dc[2];
+    bool live[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = 2 * w + q;
+        const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        live[q] = row < B;
+        const int rr = live[q] ? row : B - 1;
+        const size_t uo = (size_t)rr * U + unit, zo = (size_t)rr * N4 + pc;
+        e_dh[q] = dh_ext[uo];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e_g[q][g] = gates[zo + 32 * g];
+        e_c[q] = c_t[uo];
+        e_cp[q] = c_prev != nullptr ? c_prev[uo] : 0.f;
+        e_dc[q] = first ? 0.f : dc[uo];
+    }
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if (dz_next != nullptr) {
+        const int kb = w * 16 * KS + hh * 8 * KS;
+        const int arow = min(m0 + r, B - 1);
+        bf16x8_t a[KS], b[KS];
+        load_frags<KS>(dz_next + (size_t)arow * N4 + kb, a);
+        load_frags<KS>(wh_p + (size_t)unit * N4 + kb, b);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[w][i][lane] = acc[i];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = 2 * w + q;
+        float sum = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) sum += red[ww][i][lane];
+        if (!live[q]) continue;
+        const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        const size_t uo = (size_t)row * U + unit, zo = (size_t)row * N4 + pc;
+        const float dh = e_dh[q] + sum;
+        const float gi = e_g[q][0], gg = e_g[q][1], gf = e_g[q][2], go = e_g[q][3];
+        const float tc = fast_tanh(e_c[q]);
+        const float d_o = dh * tc;
+        const float d_c = dh * go * (1.f - tc * tc) + e_dc[q];
+        const float dzi = d_c * gg * gi * (1.f - gi);
+        const float dzg = d_c * gi * (1.f - gg * gg);
+        const float dzf = d_c * e_cp[q] * gf * (1.f - gf);
+        const float dzo = d_o * go * (1.f - go);
+        dc[uo] = d_c * gf;
+        if (dz != nullptr) { dz[zo] = dzi; dz[zo + 32] = dzg; dz[zo + 64] = dzf; dz[zo + 96] = dzo; }
+        dzT[zo] = f32_to_bf16(dzi); dzT[zo + 32] = f32_to_bf16(dzg); dzT[zo + 64] = f32_to_bf16(dzf); dzT[zo + 96] = f32_to_bf16(dzo);
+    }
+}
+
 extern "C" int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int units, const float* xproj, const void* wh_t,
                                 const void* h0, const float* c0, float* gates, float* c, void* h) {
     hipStream_t st = (hipStream_t)s;
@@ -289,7 +436,12 @@ extern "C" int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int uni
         const float* cp = t == 0 ? c0 : c + (size_t)(t - 1) * B * units;
         char* ht = (char*)h + (size_t)t * B * units * esz;
         const char* hp = t == 0 ? (const char*)h0 : (const char*)h + (size_t)(t - 1) * B * units * esz;
-        if (dtype == MNN_BF16)
+        if (dtype == MNN_BF16 && (units == 128 || units == 256 || units == 512)) {
+            dim3 g2(units / 32, cdiv(B, 32));
+#define FWD2(KS) hipLaunchKernelGGL(lstm_fwd_step_v2<KS>, g2, dim3(256), 0, st, (const bf16_t*)hp, (const bf16_t*)wh_t, xp, cp, gt, ct, (bf16_t*)ht, B, units)
+            if (units == 512) FWD2(8); else if (units == 256) FWD2(4); else FWD2(2);
+#undef FWD2
+        } else if (dtype == MNN_BF16)
             hipLaunchKernelGGL(lstm_fwd_step_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)hp, (const bf16_t*)wh_t, xp, cp, gt, ct,
                                (bf16_t*)ht, B, units);
         else
@@ -385,7 +537,13 @@ extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int uni
         float* dzt = dz ? dz + (size_t)tt * zs : nullptr;
         char* dzTt = (char*)dz_T + (size_t)tt * zs * esz;
         float* dho = t < 0 ? dh0 : nullptr;
-        if (dtype == MNN_BF16)
+        if (dtype == MNN_BF16 && t >= 0 && (units == 128 || units == 256 || units == 512)) {
+            dim3 g2(units / 32, cdiv(B, 32));
+#define BWD2(KS) hipLaunchKernelGGL(lstm_bwd_step_v2<KS>, g2, dim3(512), 0, st, (const bf16_t*)dzn, (const bf16_t*)wh_p, dh_ext + (size_t)tt * us, \
+                                    gates + (size_t)tt * zs, c + (size_t)tt * us, cp, dc, dzt, (bf16_t*)dzTt, B, units, t == T - 1 ? 1 : 0)
+            if (units == 512) BWD2(16); else if (units == 256) BWD2(8); else BWD2(4);
+#undef BWD2
+        } else if (dtype == MNN_BF16)
             hipLaunchKernelGGL(lstm_bwd_step_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)dzn, (const bf16_t*)wh_p,
                                dh_ext + (size_t)tt * us, gates + (size_t)tt * zs, c + (size_t)tt * us, cp, dc, dzt, (bf16_t*)dzTt, dho, B,
                                units, t == T - 1 ? 1 : 0);
