@@ -128,18 +128,20 @@ int mnn_dropout_bwd(mnn_stream_t s, const float* dy, float* dh, int T, int B, in
  * (rnn_nade.py:245; rnn_multinade.py:242-249).  Hn <= 256.
  *
  * mnn_nade_logprob_fwd (nade.py:155-229): nll f32 [tracks,N], cond_p f32 [tracks,N,D];
- *   if row_weight != NULL also dl f32 [N, ld_bias] columns tracks*Hn.. := d(sum_n w[n]*nll)/d b_dec.
- * mnn_nade_logprob_bwd: reverse scan -> d_bias[:, m*Hn..] (= d b_enc), d_w_enc, d_w_dec f32
- *   [tracks,D,Hn] (ACCUMULATED with atomics: zero them first).
+ *   if row_weight != NULL also dl f32 [N, ld_bias] columns tracks*Hn.. := d(sum_n w[n]*nll)/d b_dec;
+ *   a_final f32 [tracks,N,Hn] (optional) receives the final hidden pre-activation for the backward.
+ * mnn_nade_logprob_bwd: reverse scan from a_final -> d_bias[:, m*Hn..] (= d b_enc), d_w_enc, d_w_dec f32
+ *   [tracks,D,Hn] (ACCUMULATED with atomics: zero them first).  Exploits v sparsity exactly: h is
+ *   recomputed only where v = 1.
  * mnn_nade_sample (nade.py:231-308): deterministic-order kernel, Bernoulli u < sigmoid(l/T);
  *   u = Philox(stream 1, row = row0+n, sub, elem = m*D+i); temperature <= 0 -> threshold 0.5.
  * ------------------------------------------------------------------------------------------ */
 int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                          const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* row_weight,
-                         float* nll, float* cond_p, float* d_bias);
+                         float* nll, float* cond_p, float* d_bias, float* a_final);
 int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
-                         const float* bias, int ld_bias, const float* w_enc, const float* w_dec, float* d_bias,
-                         float* d_w_enc, float* d_w_dec);
+                         const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* a_final,
+                         float* d_bias, float* d_w_enc, float* d_w_dec);
 int mnn_nade_sample(mnn_stream_t s, int tracks, int N, int D, int Hn, const float* bias, int ld_bias, const float* w_enc,
                     const float* w_dec, float temperature, uint64_t seed, uint32_t row0, uint32_t sub, uint8_t* samples,
                     long s_track_stride, int s_row_stride, int s_elem_stride, float* nll);

@@ -30,8 +30,8 @@ SIGNATURES = {
     "mnn_lstm_seq_bwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "mnn_dropout_fwd": (_i, [_p, _i, _p, _p, _i, _i, _i, _f, _u64, _u32, _i]),
     "mnn_dropout_bwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _u64, _u32, _i, _i]),
-    "mnn_nade_logprob_fwd": (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p]),
-    "mnn_nade_logprob_bwd": (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p]),
+    "mnn_nade_logprob_fwd": (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "mnn_nade_logprob_bwd": (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p]),
     "mnn_nade_sample": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _f, _u64, _u32, _u32, _p, _l, _i, _i, _p]),
     "mnn_rbm_workspace_bytes": (_sz, [_i, _i]),
     "mnn_rbm_gibbs": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _u64, _u32, _p, _u32, _p, _p, _p]),

@@ -1,10 +1,9 @@
 // NADE visible-order conditional scan for gfx950: log_prob forward, reverse-scan backward, sampling.
 // Reference: /root/reference/multinn/models/common/nade.py:155-229 (log_prob), 231-308 (sample).
 //
-// Forward  (lane = row):     4 waves split the hidden units, each lane keeps its slice of the running
-//                            pre-activation `a` in registers; w_enc/w_dec rows are wave-uniform scalar
-//                            loads; the per-visible dot product needs NO cross-lane reduction, only one
-//                            4-way cross-wave sum through LDS per block of 4 visibles.
+// Forward  (lane = hidden):  8 waves x 8 rows; h = sigmoid(a) cached and recomputed only at v = 1; the
+//                            64 per-lane partial dot products of 8 rows x 8 visibles are reduced across
+//                            lanes by one halving butterfly (permlane swaps + DPP), no LDS, no barrier.
 // Backward (lane = hidden):  8 waves x 8 rows; the row is wave-uniform, so d l and v are scalars and the
 //                            sums over rows for d w_dec / d w_enc accumulate in-lane; one LDS reduction
 //                            + one 1 KiB-contiguous f32 atomic per visible per block.
@@ -18,97 +17,200 @@
 __device__ __forceinline__ float fast_ln(float x) { return __builtin_amdgcn_logf(x) * LN2; }
 
 // ----------------------------------------------------------------------------------------------
-// forward
+// forward (lane = hidden unit, 8 waves x 8 rows per block; no barrier, no cross-wave traffic)
+//
+// Sparsity (exact): `a` only changes at visibles with v = 1 (nade.py:219), so h = sigmoid(a) is cached in
+// registers and recomputed only there (the row is wave-uniform, so that branch is scalar).  Per visible and
+// row each lane forms its partial dot product over its HQ hidden units; the 8 rows x 8 visibles = 64
+// partials per lane are then summed ACROSS the 64 lanes by a halving butterfly (v_permlane32_swap,
+// v_permlane16_swap, DPP/swizzle xor steps): ~2.5 VALU ops per output instead of a 6-step reduction each,
+// and lane L ends up owning the logit of (row L>>3, visible L&7).
 // ----------------------------------------------------------------------------------------------
-template <int HS>
-__global__ void __launch_bounds__(256)
+__device__ __forceinline__ float dpp_xor8(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false)); }
+__device__ __forceinline__ float swz_xor4(float x) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x101F)); }
+__device__ __forceinline__ float dpp_xor2(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_xor1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false)); }
+
+// Halving butterfly, applied in two parts.  rows8(): the 8 per-row partials of ONE visible -> one value per
+// lane, lane bits 5..3 selecting the row (3 steps: permlane32_swap, permlane16_swap, xor-8).  vis8(): the 8
+// such values of a chunk -> the lane's final sum, lane bits 2..0 selecting the visible (xor 4, 2, 1).
+__device__ __forceinline__ float rows8(float (&x)[8], int lane) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {        // lane bit 5 <-> row bit 2
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[k]), __float_as_uint(x[k + 4]), false, false);
+        x[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {        // lane bit 4 <-> row bit 1
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[k]), __float_as_uint(x[k + 2]), false, false);
+        x[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const float t = x[0] + dpp_xor8(x[0]), u = x[1] + dpp_xor8(x[1]);   // lane bit 3 <-> row bit 0
+    return (lane & 8) ? u : t;
+}
+__device__ __forceinline__ float vis8(float (&y)[8], int lane) {
+    const bool b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float t = y[k] + swz_xor4(y[k]), u = y[k + 4] + swz_xor4(y[k + 4]);
+        y[k] = b2 ? u : t;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float t = y[k] + dpp_xor2(y[k]), u = y[k + 2] + dpp_xor2(y[k + 2]);
+        y[k] = b1 ? u : t;
+    }
+    const float t = y[0] + dpp_xor1(y[0]), u = y[1] + dpp_xor1(y[1]);
+    return b0 ? u : t;
+}
+
+#define FWD_R 8
+// Cooperative, double-buffered LDS staging of 8 consecutive rows of w_dec and w_enc (shared by the block's
+// 8 waves): registers <- global for chunk c+1 while chunk c is consumed from LDS; one barrier per chunk.
+template <int HQ>
+struct WStage {
+    static constexpr int W = HQ * 64;            // padded hidden width
+    static constexpr int NE = (8 * W) / 512;     // elements per thread per matrix
+    float rd[NE], re[NE];
+    __device__ __forceinline__ void gload(const float* __restrict__ wd, const float* __restrict__ we, int i0, int D, int Hn) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = threadIdx.x + k * 512;
+            const int ii = e / W, j = e - ii * W, i = i0 + ii;
+            const bool ok = i >= 0 && i < D && j < Hn;
+            rd[k] = ok ? wd[(size_t)i * Hn + j] : 0.f;
+            re[k] = ok ? we[(size_t)i * Hn + j] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void lstore(float* __restrict__ sd, float* __restrict__ se) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            sd[threadIdx.x + k * 512] = rd[k];
+            se[threadIdx.x + k * 512] = re[k];
+        }
+    }
+};
+
+template <int HQ>
+__global__ void __launch_bounds__(512)
 nade_fwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias,
                 int ld_bias, const float* __restrict__ w_enc, const float* __restrict__ w_dec, const float* __restrict__ row_weight,
-                float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias) {
-    __shared__ float red[2][4][4][64];
-    __shared__ float red2[4][64];
+                float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias, float* __restrict__ a_final) {
+    constexpr int W = HQ * 64;
+    __shared__ float wl[2][2][8 * W];            // [buffer][w_dec | w_enc][visible-in-chunk][hidden]
     const int m = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int row = blockIdx.x * 64 + lane;
-    const bool valid = row < N;
-    const int rr = valid ? row : N - 1;
-    const float* __restrict__ be = bias + (size_t)rr * ld_bias + m * Hn;
-    const float* __restrict__ bd = bias + (size_t)rr * ld_bias + tracks * Hn + m * D;
-    const uint8_t* __restrict__ vr = v + (size_t)m * v_track_stride + (size_t)rr * D;
+    const int rbase = blockIdx.x * 64 + w * FWD_R;
+    const uint8_t* __restrict__ vm = v + (size_t)m * v_track_stride;
     const float* __restrict__ we = w_enc + (size_t)m * D * Hn;
     const float* __restrict__ wd = w_dec + (size_t)m * D * Hn;
-    const int j0 = w * HS;
+    const int bd_off = tracks * Hn + m * D;
 
-    // running pre-activation kept pre-scaled: a' = -log2(e) * a, so sigmoid(a) = rcp(1 + exp2(a'))
-    float a[HS];
+    float a[FWD_R][HQ], h[FWD_R][HQ];
 #pragma unroll
-    for (int j = 0; j < HS; ++j) a[j] = (j0 + j < Hn) ? -MNN_LOG2E * be[j0 + j] : 0.f;
-
-    const float rw = (row_weight != nullptr && valid) ? row_weight[row] : 0.f;
+    for (int r = 0; r < FWD_R; ++r)
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) {
+            const int j = lane + 64 * q, row = rbase + r;
+            a[r][q] = (row < N && j < Hn) ? bias[(size_t)row * ld_bias + m * Hn + j] : 0.f;
+            h[r][q] = fast_sigmoid(a[r][q]);
+        }
+    // lane L owns (row L>>3, visible L&7) of every chunk: it prefetches that v / b_dec and finalises that logit
+    const int frow = rbase + (lane >> 3), fi = lane & 7;
+    const bool fvalid = frow < N;
+    const int frr = fvalid ? frow : N - 1;
+    const float rw = (row_weight != nullptr && fvalid) ? row_weight[frow] : 0.f;
     float lp = 0.f;
-    int buf = 0;
-    for (int i0 = 0; i0 < D; i0 += 4) {
-        float vi4[4];
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib) vi4[ib] = (i0 + ib < D) ? (float)vr[i0 + ib] : 0.f;
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib) {
-            const int i = i0 + ib;
-            float acc = 0.f;
-            if (i < D) {
-                const float vs = -MNN_LOG2E * vi4[ib];
-                const float* __restrict__ wdi = wd + (size_t)i * Hn + j0;
-                const float* __restrict__ wei = we + (size_t)i * Hn + j0;
-#pragma unroll
-                for (int j = 0; j < HS; ++j) {
-                    const bool in = j0 + j < Hn;
-                    const float wdj = in ? wdi[j] : 0.f;
-                    const float wej = in ? wei[j] : 0.f;
-                    const float h = fast_rcp(1.0f + fast_exp2(a[j]));
-                    acc = fmaf(h, wdj, acc);
-                    a[j] = fmaf(vs, wej, a[j]);
-                }
-            }
-            red[buf][w][ib][lane] = acc;
-        }
-        __syncthreads();
-        const int i = i0 + w;          // wave w finalises visible i0 + w
-        if (i < D) {
-            const float l = bd[i] + ((red[buf][0][w][lane] + red[buf][1][w][lane]) + (red[buf][2][w][lane] + red[buf][3][w][lane]));
-            const float p = fast_sigmoid(l);
-            const float vi = w == 0 ? vi4[0] : (w == 1 ? vi4[1] : (w == 2 ? vi4[2] : vi4[3]));
-            const float q = fast_sigmoid(-l);   // 1-p without cancellation (closer to the exact value than f32 `1 - p`)
-            lp += vi > 0.5f ? fast_ln(NADE_EPS + p) : fast_ln(NADE_EPS + q);
-            if (valid) {
-                if (cond_p != nullptr) cond_p[((size_t)m * N + row) * D + i] = p;
-                if (d_bias != nullptr) {
-                    const float dnll_dp = vi > 0.5f ? -fast_rcp(NADE_EPS + p) : fast_rcp(NADE_EPS + q);
-                    d_bias[(size_t)row * ld_bias + tracks * Hn + m * D + i] = rw * dnll_dp * p * q;
-                }
-            }
-        }
-        buf ^= 1;
-    }
-    red2[w][lane] = lp;
+
+    WStage<HQ> st;
+    st.gload(wd, we, 0, D, Hn);
+    st.lstore(wl[0][0], wl[0][1]);
+    bool vcur = fvalid && fi < D && vm[(size_t)frr * D + fi] != 0;
+    float bcur = fi < D ? bias[(size_t)frr * ld_bias + bd_off + fi] : 0.f;
     __syncthreads();
-    if (w == 0 && valid && nll != nullptr) nll[(size_t)m * N + row] = -((red2[0][lane] + red2[1][lane]) + (red2[2][lane] + red2[3][lane]));
+    const int nch = (D + 7) / 8;
+    for (int c = 0; c < nch; ++c) {
+        const int i0 = c * 8;
+        const int inext = i0 + 8 + fi;
+        st.gload(wd, we, i0 + 8, D, Hn);                                      // chunk c+1 (zeros past D)
+        const bool vnext = fvalid && inext < D && vm[(size_t)frr * D + inext] != 0;
+        const float bnext = inext < D ? bias[(size_t)frr * ld_bias + bd_off + inext] : 0.f;
+        const unsigned long long mask = __ballot(vcur);                          // bit r*8+ii : v[row r][i0+ii]
+        const float* __restrict__ sd = wl[c & 1][0];
+        const float* __restrict__ se = wl[c & 1][1];
+        float y[8];
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            float wdv[HQ], pr[8];
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) wdv[q] = sd[ii * W + lane + 64 * q];
+#pragma unroll
+            for (int r = 0; r < FWD_R; ++r) {
+                float acc = h[r][0] * wdv[0];
+#pragma unroll
+                for (int q = 1; q < HQ; ++q) acc = fmaf(h[r][q], wdv[q], acc);
+                pr[r] = acc;
+                if ((mask >> (r * 8 + ii)) & 1ull) {                             // wave-uniform: encode v_i = 1 (nade.py:219)
+#pragma unroll
+                    for (int q = 0; q < HQ; ++q) {
+                        a[r][q] += se[ii * W + lane + 64 * q];
+                        h[r][q] = fast_sigmoid(a[r][q]);
+                    }
+                }
+            }
+            y[ii] = rows8(pr, lane);
+        }
+        const float tot = vis8(y, lane);
+        const int i = i0 + fi;
+        if (i < D) {
+            const float l = bcur + tot;
+            const float pr = fast_sigmoid(l);
+            const float qr = fast_sigmoid(-l);      // 1-p without cancellation (closer to the exact value than f32 `1 - p`)
+            lp += vcur ? fast_ln(NADE_EPS + pr) : fast_ln(NADE_EPS + qr);
+            if (fvalid) {
+                if (cond_p != nullptr) cond_p[((size_t)m * N + frow) * D + i] = pr;
+                if (d_bias != nullptr) {
+                    const float dnll_dp = vcur ? -fast_rcp(NADE_EPS + pr) : fast_rcp(NADE_EPS + qr);
+                    d_bias[(size_t)frow * ld_bias + bd_off + i] = rw * dnll_dp * pr * qr;
+                }
+            }
+        }
+        st.lstore(wl[(c + 1) & 1][0], wl[(c + 1) & 1][1]);
+        vcur = vnext;
+        bcur = bnext;
+        __syncthreads();
+    }
+    lp += dpp_xor1(lp);
+    lp += dpp_xor2(lp);
+    lp += swz_xor4(lp);
+    if (fi == 0 && fvalid && nll != nullptr) nll[(size_t)m * N + frow] = -lp;
+    // hand the final pre-activation a_D (forward-order sum) to the backward kernel
+    if (a_final != nullptr) {
+#pragma unroll
+        for (int r = 0; r < FWD_R; ++r)
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) {
+                const int j = lane + 64 * q, row = rbase + r;
+                if (row < N && j < Hn) a_final[((size_t)m * N + row) * Hn + j] = a[r][q];
+            }
+    }
 }
 
 extern "C" int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                     const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* row_weight,
-                                    float* nll, float* cond_p, float* d_bias) {
+                                    float* nll, float* cond_p, float* d_bias, float* a_final) {
     MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn > 0 && Hn <= 256, "mnn_nade_logprob_fwd: need tracks,N,D>0 and 0<Hn<=256 (Hn=%d)", Hn);
     MNN_REQUIRE(v && bias && w_enc && w_dec, "mnn_nade_logprob_fwd: null pointer");
     MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_logprob_fwd: ld_bias %d < tracks*(Hn+D)", ld_bias);
     MNN_REQUIRE(d_bias == nullptr || row_weight != nullptr, "mnn_nade_logprob_fwd: d_bias needs row_weight");
     dim3 grid(cdiv(N, 64), tracks);
     hipStream_t st = (hipStream_t)s;
-#define FWD(HS) hipLaunchKernelGGL(nade_fwd_kernel<HS>, grid, dim3(256), 0, st, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, \
-                                   w_dec, row_weight, nll, cond_p, d_bias)
-    if (Hn <= 64) FWD(16);
-    else if (Hn <= 128) FWD(32);
-    else FWD(64);
+#define FWD(HQ) hipLaunchKernelGGL(nade_fwd_kernel<HQ>, grid, dim3(512), 0, st, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, \
+                                   w_dec, row_weight, nll, cond_p, d_bias, a_final)
+    if (Hn <= 64) FWD(1);
+    else if (Hn <= 128) FWD(2);
+    else FWD(4);
 #undef FWD
     MNN_LAUNCH_CHECK();
     return MNN_OK;
@@ -121,9 +223,11 @@ extern "C" int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, in
 template <int HQ>
 __global__ void __launch_bounds__(512)
 nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias,
-                int ld_bias, const float* __restrict__ w_enc, const float* __restrict__ w_dec, float* __restrict__ d_bias,
-                float* __restrict__ d_w_enc, float* __restrict__ d_w_dec) {
-    __shared__ float red[2][8][2][HQ * 64];
+                int ld_bias, const float* __restrict__ w_enc, const float* __restrict__ w_dec, const float* __restrict__ a_final,
+                float* __restrict__ d_bias, float* __restrict__ d_w_enc, float* __restrict__ d_w_dec) {
+    constexpr int W = HQ * 64;
+    __shared__ float wl[2][2][8 * W];
+    __shared__ float red[2][8][2][W];
     const int m = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -133,77 +237,98 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
     const float* __restrict__ wd = w_dec + (size_t)m * D * Hn;
     const int dl_off = tracks * Hn + m * D;
 
-    float a[BWD_R][HQ], G[BWD_R][HQ];
+    // Sparsity (exact): `a` only changes at visibles with v = 1 (nade.py:219), so h = sigmoid(a) is cached
+    // and recomputed only there, and sum_i dl_i * w_dec[i] is accumulated per constant-h segment (c) and
+    // folded into G with ONE h(1-h) factor when the segment ends.  a_D comes from the forward kernel.
+    float a[BWD_R][HQ], h[BWD_R][HQ], c[BWD_R][HQ], G[BWD_R][HQ];
 #pragma unroll
     for (int r = 0; r < BWD_R; ++r)
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
             const int j = lane + 64 * q, row = rbase + r;
-            a[r][q] = (row < N && j < Hn) ? bias[(size_t)row * ld_bias + m * Hn + j] : 0.f;
+            a[r][q] = (row < N && j < Hn) ? a_final[((size_t)m * N + row) * Hn + j] : 0.f;
+            h[r][q] = fast_sigmoid(a[r][q]);
             G[r][q] = 0.f;
+            c[r][q] = 0.f;
         }
-    // a_D: replay the encoder updates in forward order (nade.py:219)
-    for (int i = 0; i < D; ++i) {
-        float wev[HQ];
-#pragma unroll
-        for (int q = 0; q < HQ; ++q) wev[q] = (lane + 64 * q < Hn) ? we[(size_t)i * Hn + lane + 64 * q] : 0.f;
-#pragma unroll
-        for (int r = 0; r < BWD_R; ++r) {
-            const int row = rbase + r;
-            if (row < N && vm[(size_t)row * D + i] != 0) {
-#pragma unroll
-                for (int q = 0; q < HQ; ++q) a[r][q] += wev[q];
-            }
-        }
-    }
+    const int frow = rbase + (lane >> 3), fi = lane & 7;
+    const bool fvalid = frow < N;
+    const int frr = fvalid ? frow : N - 1;
+    const int nch = (D + 7) / 8;
+    WStage<HQ> st;
+    st.gload(wd, we, (nch - 1) * 8, D, Hn);
+    st.lstore(wl[0][0], wl[0][1]);
+    int icur = (nch - 1) * 8 + fi;
+    bool vcur = fvalid && icur < D && vm[(size_t)frr * D + icur] != 0;
+    float dcur = (fvalid && icur < D) ? d_bias[(size_t)frr * ld_bias + dl_off + icur] : 0.f;
+    __syncthreads();
     int buf = 0;
-    for (int i = D - 1; i >= 0; --i) {
-        float wev[HQ], wdv[HQ], accd[HQ], acce[HQ];
+    for (int cc = 0; cc < nch; ++cc) {
+        const int i0 = (nch - 1 - cc) * 8;
+        const int inext = i0 - 8 + fi;
+        st.gload(wd, we, i0 - 8, D, Hn);                                      // next (lower) chunk, zeros below 0
+        const bool vnext = fvalid && inext >= 0 && vm[(size_t)frr * D + inext] != 0;
+        const float dnext = (fvalid && inext >= 0) ? d_bias[(size_t)frr * ld_bias + dl_off + inext] : 0.f;
+        const unsigned long long mask = __ballot(vcur);
+        const float* __restrict__ sd = wl[cc & 1][0];
+        const float* __restrict__ se = wl[cc & 1][1];
 #pragma unroll
-        for (int q = 0; q < HQ; ++q) {
-            const bool in = lane + 64 * q < Hn;
-            wev[q] = in ? we[(size_t)i * Hn + lane + 64 * q] : 0.f;
-            wdv[q] = in ? wd[(size_t)i * Hn + lane + 64 * q] : 0.f;
-            accd[q] = 0.f;
-            acce[q] = 0.f;
-        }
+        for (int ii = 7; ii >= 0; --ii) {
+            const int i = i0 + ii;
+            if (i >= D) continue;                                               // block-uniform (tail chunk)
+            float wev[HQ], wdv[HQ], accd[HQ], acce[HQ];
 #pragma unroll
-        for (int r = 0; r < BWD_R; ++r) {
-            const int row = rbase + r;
-            if (row < N) {
-                const float dl = d_bias[(size_t)row * ld_bias + dl_off + i];
-                if (vm[(size_t)row * D + i] != 0) {
+            for (int q = 0; q < HQ; ++q) {
+                wdv[q] = sd[ii * W + lane + 64 * q];
+                wev[q] = se[ii * W + lane + 64 * q];
+                accd[q] = 0.f;
+                acce[q] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < BWD_R; ++r) {
+                const float dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dcur), r * 8 + ii));
+                if ((mask >> (r * 8 + ii)) & 1ull) {
 #pragma unroll
                     for (int q = 0; q < HQ; ++q) {
+                        G[r][q] = fmaf(c[r][q], fmaf(-h[r][q], h[r][q], h[r][q]), G[r][q]);   // close the segment that used a_{i+1}
+                        c[r][q] = 0.f;
                         acce[q] += G[r][q];          // d w_enc[i] += v_i * G_{i+1}
                         a[r][q] -= wev[q];           // a_i = a_{i+1} - v_i * w_enc[i]
+                        h[r][q] = fast_sigmoid(a[r][q]);
                     }
                 }
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) {
-                    const float h = fast_sigmoid(a[r][q]);
-                    accd[q] = fmaf(dl, h, accd[q]);
-                    G[r][q] = fmaf(dl * wdv[q], fmaf(-h, h, h), G[r][q]);
+                    accd[q] = fmaf(dl, h[r][q], accd[q]);
+                    c[r][q] = fmaf(dl, wdv[q], c[r][q]);
                 }
             }
-        }
 #pragma unroll
-        for (int q = 0; q < HQ; ++q) {
-            red[buf][w][0][lane + 64 * q] = accd[q];
-            red[buf][w][1][lane + 64 * q] = acce[q];
-        }
-        __syncthreads();
-        for (int e = threadIdx.x; e < 2 * HQ * 64; e += 512) {
-            const int which = e / (HQ * 64), j = e % (HQ * 64);
-            if (j < Hn) {
-                float sum = 0.f;
-#pragma unroll
-                for (int ww = 0; ww < 8; ++ww) sum += red[buf][ww][which][j];
-                atomicAdd((which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * Hn + j, sum);
+            for (int q = 0; q < HQ; ++q) {
+                red[buf][w][0][lane + 64 * q] = accd[q];
+                red[buf][w][1][lane + 64 * q] = acce[q];
             }
+            __syncthreads();
+            for (int e = threadIdx.x; e < 2 * W; e += 512) {
+                const int which = e / W, j = e % W;
+                if (j < Hn) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int ww = 0; ww < 8; ++ww) sum += red[buf][ww][which][j];
+                    atomicAdd((which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * Hn + j, sum);
+                }
+            }
+            buf ^= 1;
         }
-        buf ^= 1;
+        st.lstore(wl[(cc + 1) & 1][0], wl[(cc + 1) & 1][1]);
+        vcur = vnext;
+        dcur = dnext;
+        __syncthreads();
     }
+#pragma unroll
+    for (int r = 0; r < BWD_R; ++r)
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) G[r][q] = fmaf(c[r][q], fmaf(-h[r][q], h[r][q], h[r][q]), G[r][q]);
 #pragma unroll
     for (int r = 0; r < BWD_R; ++r)
 #pragma unroll
@@ -214,15 +339,15 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
 }
 
 extern "C" int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
-                                    const float* bias, int ld_bias, const float* w_enc, const float* w_dec, float* d_bias, float* d_w_enc,
-                                    float* d_w_dec) {
+                                    const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* a_final,
+                                    float* d_bias, float* d_w_enc, float* d_w_dec) {
     MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn > 0 && Hn <= 256, "mnn_nade_logprob_bwd: need tracks,N,D>0 and 0<Hn<=256 (Hn=%d)", Hn);
-    MNN_REQUIRE(v && bias && w_enc && w_dec && d_bias && d_w_enc && d_w_dec, "mnn_nade_logprob_bwd: null pointer");
+    MNN_REQUIRE(v && bias && w_enc && w_dec && a_final && d_bias && d_w_enc && d_w_dec, "mnn_nade_logprob_bwd: null pointer");
     MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_logprob_bwd: ld_bias too small");
     dim3 grid(cdiv(N, 64), tracks);
     hipStream_t st = (hipStream_t)s;
 #define BWD(HQ) hipLaunchKernelGGL(nade_bwd_kernel<HQ>, grid, dim3(512), 0, st, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, \
-                                   w_dec, d_bias, d_w_enc, d_w_dec)
+                                   w_dec, a_final, d_bias, d_w_enc, d_w_dec)
     if (Hn <= 64) BWD(1);
     else if (Hn <= 128) BWD(2);
     else BWD(4);

@@ -399,11 +399,12 @@ class RnnNade(RnnEstimator):
             d_out = torch.empty((N, self.ldo), device=dev)
             if self.ldo != self.n_out:
                 d_out[:, self.n_out:].zero_()
+        a_fin = torch.empty((M, N, Hn), device=dev) if train else None
         ops.nade_logprob_fwd(v.view(M, N, D), out, self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn,
-                             rw_m if train else None, nll, cond_p, d_out)
+                             rw_m if train else None, nll, cond_p, d_out, a_fin)
         loss = torch.zeros(1, device=dev)
         ops.weighted_sum(nll.view(-1), rw_m.repeat(M) if M > 1 else rw_m, loss)      # statistical.py:34 / rnn_multinade.py:202-203
-        self._ctx = dict(x_tm=x_tm, v=v, rw=rw_m, y=y, lstm=ctx, out=out, d_out=d_out, kp=kp, seed=self.seed + self.store.step, B=B, T=T)
+        self._ctx = dict(x_tm=x_tm, v=v, rw=rw_m, y=y, lstm=ctx, out=out, d_out=d_out, a_fin=a_fin, kp=kp, seed=self.seed + self.store.step, B=B, T=T)
         self._nll_tm, self._cond_tm, self._loss = nll, cond_p, loss
         self._flat_idx = None
         self._lengths = lengths
@@ -447,8 +448,8 @@ class RnnNade(RnnEstimator):
         g = self.store.gviews
         self.store.grad.zero_()
         d_out = cx["d_out"]
-        ops.nade_logprob_bwd(cx["v"].view(M, N, D), cx["out"], self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn, d_out,
-                             g["nade/w_enc"], g["nade/w_dec"])
+        ops.nade_logprob_bwd(cx["v"].view(M, N, D), cx["out"], self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn, cx["a_fin"],
+                             d_out, g["nade/w_enc"], g["nade/w_dec"])
         # dense: dK[R,n_out] = y^T d_out ; db = sum d_out ; dy = d_out K^T
         Np = ops.round_up(N, 8)
         zalloc = torch.zeros if Np != N else torch.empty

@@ -186,7 +186,7 @@ def _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec):
     _req(0 < Hn <= 256, "nade: Hn must be in 1..256")
 
 
-def nade_logprob_fwd(v, bias, w_enc, w_dec, tracks, D, Hn, row_weight=None, nll=None, cond_p=None, d_bias=None):
+def nade_logprob_fwd(v, bias, w_enc, w_dec, tracks, D, Hn, row_weight=None, nll=None, cond_p=None, d_bias=None, a_final=None):
     N = bias.shape[0]
     _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)
     if nll is not None:
@@ -198,18 +198,21 @@ def nade_logprob_fwd(v, bias, w_enc, w_dec, tracks, D, Hn, row_weight=None, nll=
              "nade: d_bias must mirror bias and needs row_weight")
     if row_weight is not None:
         _req(row_weight.dtype == torch.float32 and row_weight.numel() == N, "nade: row_weight f32 [N]")
+    if a_final is not None:
+        _req(a_final.dtype == torch.float32 and a_final.numel() == tracks * N * Hn and a_final.is_contiguous(), "nade: a_final f32 [tracks,N,Hn]")
     call("mnn_nade_logprob_fwd", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
-         _ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias))
+         _ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final))
 
 
-def nade_logprob_bwd(v, bias, w_enc, w_dec, tracks, D, Hn, d_bias, d_w_enc, d_w_dec):
+def nade_logprob_bwd(v, bias, w_enc, w_dec, tracks, D, Hn, a_final, d_bias, d_w_enc, d_w_dec):
     N = bias.shape[0]
     _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)
     _req(d_bias.shape == bias.shape and d_bias.stride() == bias.stride() and d_bias.dtype == torch.float32, "nade bwd: d_bias")
     for w in (d_w_enc, d_w_dec):
         _req(w.dtype == torch.float32 and w.is_contiguous() and w.numel() == tracks * D * Hn, "nade bwd: grad weights f32 [tracks,D,Hn]")
+    _req(a_final.dtype == torch.float32 and a_final.numel() == tracks * N * Hn and a_final.is_contiguous(), "nade bwd: a_final f32 [tracks,N,Hn]")
     call("mnn_nade_logprob_bwd", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
-         _ptr(d_bias), _ptr(d_w_enc), _ptr(d_w_dec))
+         _ptr(a_final), _ptr(d_bias), _ptr(d_w_enc), _ptr(d_w_dec))
 
 
 def nade_sample(bias, w_enc, w_dec, tracks, D, Hn, temperature, seed, row0, sub, samples, track_minor=False, nll=None):

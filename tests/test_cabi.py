@@ -40,7 +40,7 @@ def test_argument_validation_without_gpu(lib):
     from multinn_amd import _lib
     rc = lib.mnn_gemm_tn(None, 7, 1, 1, 8, None, 8, None, 8, None, 1, 0, None, 0, 1)
     assert rc == -1 and b"dtype" in lib.mnn_last_error()
-    rc = lib.mnn_nade_logprob_fwd(None, 1, 4, 8, 300, None, 0, None, 400, None, None, None, None, None, None)
+    rc = lib.mnn_nade_logprob_fwd(None, 1, 4, 8, 300, None, 0, None, 400, None, None, None, None, None, None, None)
     assert rc == -1 and b"Hn" in lib.mnn_last_error()
     with pytest.raises(_lib.MnnError):
         _lib.call("mnn_lstm_seq_fwd", None, 0, 1, 1, 33, None, None, None, None, None, None, None)

@@ -250,9 +250,10 @@ def test_nade_logprob_fwd_bwd(ops, N, D, Hn, tracks):
     bt = dev(bias)
     nll = torch.zeros((tracks, N), device=DEV); cp = torch.zeros((tracks, N, D), device=DEV)
     d_bias = torch.zeros_like(bt)
-    ops.nade_logprob_fwd(dev(v), bt, dev(we), dev(wd), tracks, D, Hn, dev(rw), nll, cp, d_bias)
+    a_fin = torch.zeros((tracks, N, Hn), device=DEV)
+    ops.nade_logprob_fwd(dev(v), bt, dev(we), dev(wd), tracks, D, Hn, dev(rw), nll, cp, d_bias, a_fin)
     dwe = torch.zeros((tracks, D, Hn), device=DEV); dwd = torch.zeros((tracks, D, Hn), device=DEV)
-    ops.nade_logprob_bwd(dev(v), bt, dev(we), dev(wd), tracks, D, Hn, d_bias, dwe, dwd)
+    ops.nade_logprob_bwd(dev(v), bt, dev(we), dev(wd), tracks, D, Hn, a_fin, d_bias, dwe, dwd)
     f8 = np.float64
     for m in range(tracks):
         be = bias[:, m * Hn:(m + 1) * Hn].astype(f8)
