@@ -188,6 +188,110 @@ gemm_tn_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ld
         }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// bf16 GEMM, direct-to-LDS staging (global_load_lds_dwordx4): 128x128 tile, BK = 64, 4 waves (2x2),
+// two LDS buffers, one barrier per K-tile.  An LDS-DMA wave-instruction writes 64 lanes x 16 B = 1 KiB
+// LINEARLY (8 tile rows of 128 B), so the tile image cannot be padded; bank conflicts of the
+// ds_read_b128 fragment reads are removed by an XOR swizzle applied on the per-lane SOURCE address and
+// again on the read (cdna_hip_programming.md rule 21): 16-byte chunk c of row r lives at chunk
+// c ^ ((r >> 1) & 7).  Requires K % 64 == 0 (operands are zero-padded by the callers).
+// ----------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* gas_ptr_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void glds_stage_tile(const bf16_t* __restrict__ G, int ld, int rows_total, int r0, int k0, char* tile, int wave,
+                                                int lane) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int p = (s * 4 + wave) * 64 + lane;          // linear 16-byte slot of the 16 KiB tile image
+        const int row = p >> 3, pc = p & 7;
+        const int c = pc ^ ((row >> 1) & 7);                // logical K chunk held by this slot
+        const int gr = min(r0 + row, rows_total - 1);       // rows past the edge replicate the last row (never stored)
+        __builtin_amdgcn_global_load_lds((gas_ptr_t)(G + (size_t)gr * ld + k0 + c * 8), (lds_ptr_t)(tile + (s * 4 + wave) * 1024), 16, 0, 0);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+gemm_tn_glds_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c_bf16,
+                    const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
+    __shared__ __attribute__((aligned(16))) char smem[2][2][128 * 128];
+    const int bid = blockIdx.x;
+    const int grp = bid / (8 * ntn), within = bid % (8 * ntn);
+    const int mt = grp * 8 + (within & 7), nt = within >> 3;
+    if (mt >= ntm) return;
+    const int m0 = mt * 128, n0 = nt * 128;
+    const int nkt = K / 64;
+    const int z = blockIdx.y;
+    const int per = (nkt + split_k - 1) / split_k;
+    const int kt0 = z * per, kt1 = min(nkt, kt0 + per);
+    if (kt0 >= kt1) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    glds_stage_tile(A, lda, M, m0, kt0 * 64, smem[0][0], wave, lane);
+    glds_stage_tile(B, ldb, N, n0, kt0 * 64, smem[0][1], wave, lane);
+    __syncthreads();                                        // hipcc drains vmcnt(0) before the barrier
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        if (kt + 1 < kt1) {
+            glds_stage_tile(A, lda, M, m0, (kt + 1) * 64, smem[cur ^ 1][0], wave, lane);
+            glds_stage_tile(B, ldb, N, n0, (kt + 1) * 64, smem[cur ^ 1][1], wave, lane);
+        }
+        const char* sA = smem[cur][0];
+        const char* sB = smem[cur][1];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + r;
+                a[i] = *reinterpret_cast<const bf16x8_t*>(sA + row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 64 + j * 32 + r;
+                b[j] = *reinterpret_cast<const bf16x8_t*>(sB + row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    float* Cf = reinterpret_cast<float*>(Cv);
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= N) continue;
+            const float bv = (bias != nullptr && z == 0) ? bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + i * 32 + frag_row(e, lane);
+                if (row >= M) continue;
+                const float val = acc[i][j][e] + bv;
+                const size_t o = (size_t)row * ldc + col;
+                if (c_bf16) Cb[o] = f32_to_bf16(val);
+                else if (flags & MNN_GEMM_ATOMIC) atomicAdd(Cf + o, val);
+                else if (flags & MNN_GEMM_ACCUMULATE) Cf[o] += val;
+                else Cf[o] = val;
+            }
+        }
+}
+
 template <typename T>
 static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                        int c_bf16, const float* bias, int flags, int split_k) {
@@ -195,6 +299,14 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
     const int ntm = cdiv(M, BM), ntn = cdiv(N, BN);
     const int ngrp = cdiv(ntm, 8);
     dim3 grid(ngrp * 8 * ntn, split_k);
+    if constexpr (sizeof(T) == 2) {
+        if (K % 64 == 0) {
+            hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, c_bf16, bias, M,
+                               N, K, flags, split_k, ntm, ntn);
+            MNN_LAUNCH_CHECK();
+            return MNN_OK;
+        }
+    }
     hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, 2, 2>), grid, dim3(256), 0, st, (const T*)A, lda, (const T*)B, ldb, C, ldc,
                        c_bf16, bias, M, N, K, flags, split_k, ntm, ntn);
     MNN_LAUNCH_CHECK();

@@ -56,7 +56,7 @@ class LstmStack:
     def __init__(self, rnn, store, dtype):
         self.rnn, self.store, self.dtype = rnn, store, dtype
         self.al = 8 if dtype == torch.bfloat16 else 4
-        self.ld0 = ops.round_up(rnn.n_in, 8)
+        self.ld0 = ops.round_up(rnn.n_in, 64)          # K of the input projection: multiple of 64 selects the LDS-DMA GEMM
         self.packed = None
 
     def pack(self):
@@ -109,7 +109,7 @@ class LstmStack:
         bias gradients into the store's flat gradient buffer."""
         T, B, _ = dy.shape
         N = T * B
-        Np = ops.round_up(N, 8)
+        Np = ops.round_up(N, 64)
         dev = dy.device
         zalloc = torch.zeros if Np != N else torch.empty
         dx = None
@@ -322,7 +322,7 @@ class RnnNade(RnnEstimator):
         self.store.declare("dense/kernel", (R, n_out), glorot_uniform(self._gen, R, n_out))
         self.store.declare("dense/bias", (n_out,), zeros_init)
         self.n_out = n_out
-        self.ldo = ops.round_up(n_out, 8)
+        self.ldo = ops.round_up(n_out, 64)
 
     def _materialize(self, num_inputs):
         first = self.store.theta is None
@@ -451,7 +451,7 @@ class RnnNade(RnnEstimator):
         ops.nade_logprob_bwd(cx["v"].view(M, N, D), cx["out"], self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn, cx["a_fin"],
                              d_out, g["nade/w_enc"], g["nade/w_dec"])
         # dense: dK[R,n_out] = y^T d_out ; db = sum d_out ; dy = d_out K^T
-        Np = ops.round_up(N, 8)
+        Np = ops.round_up(N, 64)
         zalloc = torch.zeros if Np != N else torch.empty
         yT = zalloc((R, Np), device=dev, dtype=self.dtype)
         ops.transpose(cx["y"].view(N, R), yT)
@@ -583,7 +583,7 @@ class RnnRBM(RnnEstimator):
         self.store.declare("Wuh", (R, Hn), glorot_uniform(self._gen, R, Hn))
         self.store.declare("Wuv", (R, D), glorot_uniform(self._gen, R, D))
         self.n_out = Hn + D
-        self.ldo = ops.round_up(self.n_out, 8)
+        self.ldo = ops.round_up(self.n_out, 64)
 
     def _pack_estimator(self):
         dev = self.store.theta.device
@@ -691,7 +691,7 @@ class RnnRBM(RnnEstimator):
         if self.internal_bias:
             ops.bias_grad(d_out[:, :Hn], g[f"{self._rbm.prefix}/bh"].view(-1), accumulate=True)
             ops.bias_grad(d_out[:, Hn:Hn + D], g[f"{self._rbm.prefix}/bv"].view(-1), accumulate=True)
-        Np8 = ops.round_up(N, 8)
+        Np8 = ops.round_up(N, 64)
         yT = torch.zeros((R, Np8), device=dev, dtype=self.dtype)
         ops.transpose(cx["y"].view(N, R), yT)
         doT = torch.zeros((self.n_out, Np8), device=dev, dtype=self.dtype)

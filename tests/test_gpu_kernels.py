@@ -35,7 +35,7 @@ def rel(a, b):
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 88), (1, 696, 256), (333, 2048, 440), (64, 40, 8)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 88), (1, 696, 256), (333, 2048, 440), (64, 40, 8), (300, 130, 448), (129, 257, 1024)])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_gemm_tn(ops, M, N, K, dt):
     R = np.random.default_rng(M * 7 + N)
