@@ -138,13 +138,15 @@ def rnn_nade_forward(inputs, targets, lengths, p, keep_prob=1.0, drop_u=None, tr
                 lengths=lengths, BT=(B, T))
 
 
-def rnn_nade_backward(fw, p, tracks=1):
-    """Gradients of fw['loss'] wrt every trainable variable (rnn_nade.py:117-120)."""
+def rnn_nade_backward(fw, p, tracks=1, n_total=None):
+    """Gradients of fw['loss'] wrt every trainable variable (rnn_nade.py:117-120).
+    n_total: number of valid rows over ALL data-parallel shards (the loss is a mean over rows,
+    statistical.py:34, so a shard's gradient carries weight N_shard/N_total)."""
     B, T = fw['BT']
     lengths = fw['lengths']
     dt = p['fc_k'].dtype
     N = fw['yf'].shape[0]
-    rw = np.full(N, 1.0 / (N * tracks), dt)
+    rw = np.full(N, 1.0 / ((n_total or N) * tracks), dt)
     d_out = np.zeros((N, p['fc_k'].shape[1]), dt)
     Hn = p['w_enc'][0].shape[1]
     D = p['w_enc'][0].shape[0]
