@@ -114,12 +114,14 @@ int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int units, const f
                      float* dh0, float* dc0, void* workspace);
 
 /* Output dropout of DropoutWrapper (rnn.py:132): y = h/kp * floor(kp+u), u = Philox(stream 0,
- * row = row0+b, sub = (t<<8)|layer, elem = unit).  h,y T [T,B,u].  kp>=1 -> copy. */
+ * row = row0+b, sub = (t<<8)|layer, elem = unit).  h,y T [T,B,u].  kp>=1 -> copy.
+ * step_dev (optional device int32): the effective seed is seed + *step_dev, so a captured hipGraph
+ * of the train step draws fresh masks on every replay. */
 int mnn_dropout_fwd(mnn_stream_t s, int dtype, const void* h, void* y, int T, int B, int units, float keep_prob,
-                    uint64_t seed, uint32_t row0, int layer);
+                    uint64_t seed, const int32_t* step_dev, uint32_t row0, int layer);
 /* dh[t,b,j] (+)= dy[t,b,j]/kp*keep  (f32 in/out, mask recomputed) */
 int mnn_dropout_bwd(mnn_stream_t s, const float* dy, float* dh, int T, int B, int units, float keep_prob, uint64_t seed,
-                    uint32_t row0, int layer, int accumulate);
+                    const int32_t* step_dev, uint32_t row0, int layer, int accumulate);
 
 /* ------------------------------------------------------------------------------------------
  * NADE (models/common/nade.py).  Weights w_enc,w_dec f32 [tracks,D,Hn].  Rows: v u8
@@ -173,12 +175,14 @@ int mnn_rbm_free_energy(mnn_stream_t s, int N, int D, int Hn, const uint8_t* v, 
  * mnn_sumsq: out[0] += sum(x^2) (f32 atomic; zero first).  mnn_weighted_sum: out[0] += sum w*x.
  * mnn_clip_adam_step (utils/training.py:163-175 + train.py:64): scale = clip*min(1/gn,1/clip) with
  *   gn = sqrt(*sumsq) read ON DEVICE; TF Adam with epsilon outside the bias correction;
- *   `step` is the 1-based step count.  sgd != 0 -> plain SGD (train.py:61-62).
+ *   `step` is the 1-based step count; if step_dev (device int32) is given the count is *step_dev + 1,
+ *   read ON DEVICE (hipGraph replay) and mnn_step_increment advances it.  sgd != 0 -> plain SGD (train.py:61-62).
  * ------------------------------------------------------------------------------------------ */
 int mnn_sumsq(mnn_stream_t s, const float* x, long n, float* out);
 int mnn_weighted_sum(mnn_stream_t s, const float* x, const float* w, long n, float* out);
 int mnn_clip_adam_step(mnn_stream_t s, float* theta, const float* grad, float* m, float* v, long n, const float* sumsq,
-                       float clip_norm, float lr, float beta1, float beta2, float eps, int step, int sgd);
+                       float clip_norm, float lr, float beta1, float beta2, float eps, int step, const int32_t* step_dev, int sgd);
+int mnn_step_increment(mnn_stream_t s, int32_t* step_dev);
 int mnn_bias_grad(mnn_stream_t s, const float* dY, int rows, int cols, int ld, float* db, int accumulate);
 int mnn_fill_f32(mnn_stream_t s, float* x, long n, float value);
 

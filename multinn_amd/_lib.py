@@ -28,8 +28,8 @@ SIGNATURES = {
     "mnn_lstm_seq_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "mnn_lstm_seq_bwd_workspace_bytes": (_sz, [_i, _i]),
     "mnn_lstm_seq_bwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "mnn_dropout_fwd": (_i, [_p, _i, _p, _p, _i, _i, _i, _f, _u64, _u32, _i]),
-    "mnn_dropout_bwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _u64, _u32, _i, _i]),
+    "mnn_dropout_fwd": (_i, [_p, _i, _p, _p, _i, _i, _i, _f, _u64, _p, _u32, _i]),
+    "mnn_dropout_bwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _u64, _p, _u32, _i, _i]),
     "mnn_nade_logprob_fwd": (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
     "mnn_nade_logprob_bwd": (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p]),
     "mnn_nade_sample": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _f, _u64, _u32, _u32, _p, _l, _i, _i, _p]),
@@ -40,7 +40,8 @@ SIGNATURES = {
     "mnn_rbm_free_energy": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p]),
     "mnn_sumsq": (_i, [_p, _p, _l, _p]),
     "mnn_weighted_sum": (_i, [_p, _p, _p, _l, _p]),
-    "mnn_clip_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _f, _i, _i]),
+    "mnn_clip_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _f, _i, _p, _i]),
+    "mnn_step_increment": (_i, [_p, _p]),
     "mnn_bias_grad": (_i, [_p, _p, _i, _i, _i, _p, _i]),
     "mnn_fill_f32": (_i, [_p, _p, _l, _f]),
 }

@@ -50,6 +50,7 @@ class ParamStore:
         self.grad = torch.zeros(n, device=dev)
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
+        self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)     # device copy of `step` (read by kernels under hipGraph replay)
         off = 0
         for name, shape, init in self._specs:
             k = math.prod(shape)
@@ -74,6 +75,7 @@ class ParamStore:
             raise ValueError("checkpoint does not match the model's variables")
         self.theta.copy_(sd["theta"]); self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
         self.step = int(sd["step"])
+        self.step_dev.fill_(self.step)
 
 
 def glorot_uniform(gen, fan_in, fan_out):

@@ -229,7 +229,8 @@ extern "C" int mnn_lstm_unpack_grads(mnn_stream_t s, const float* dwx_t, const f
 // ----------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void dropout_fwd_kernel(const T* __restrict__ h, T* __restrict__ y, int Tn, int B, int U, float kp, uint64_t seed,
-                                   uint32_t row0, int layer) {
+                                   const int32_t* __restrict__ step_dev, uint32_t row0, int layer) {
+    if (step_dev != nullptr) seed += (uint64_t)step_dev[0];
     const int U4 = U >> 2;
     const long total = (long)Tn * B * U4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -248,7 +249,7 @@ __global__ void dropout_fwd_kernel(const T* __restrict__ h, T* __restrict__ y, i
 }
 
 extern "C" int mnn_dropout_fwd(mnn_stream_t s, int dtype, const void* h, void* y, int T, int B, int units, float keep_prob, uint64_t seed,
-                               uint32_t row0, int layer) {
+                               const int32_t* step_dev, uint32_t row0, int layer) {
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(h && y && T > 0 && B > 0 && units > 0 && units % 4 == 0, "mnn_dropout_fwd: bad arguments");
     MNN_REQUIRE(dtype == MNN_F32 || dtype == MNN_BF16, "mnn_dropout_fwd: dtype must be f32/bf16");
@@ -261,16 +262,17 @@ extern "C" int mnn_dropout_fwd(mnn_stream_t s, int dtype, const void* h, void* y
     const int blocks = (int)min((long)4096, ((long)T * B * units / 4 + 255) / 256);
     if (dtype == MNN_F32)
         hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)h, (float*)y, T, B, units, keep_prob, seed,
-                           row0, layer);
+                           step_dev, row0, layer);
     else
         hipLaunchKernelGGL(dropout_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)h, (bf16_t*)y, T, B, units, keep_prob,
-                           seed, row0, layer);
+                           seed, step_dev, row0, layer);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
 
 __global__ void dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dh, int Tn, int B, int U, float kp, uint64_t seed,
-                                   uint32_t row0, int layer, int accumulate) {
+                                   const int32_t* __restrict__ step_dev, uint32_t row0, int layer, int accumulate) {
+    if (step_dev != nullptr) seed += (uint64_t)step_dev[0];
     const int U4 = U >> 2;
     const long total = (long)Tn * B * U4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -289,11 +291,11 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ dy, float* __restri
 }
 
 extern "C" int mnn_dropout_bwd(mnn_stream_t s, const float* dy, float* dh, int T, int B, int units, float keep_prob, uint64_t seed,
-                               uint32_t row0, int layer, int accumulate) {
+                               const int32_t* step_dev, uint32_t row0, int layer, int accumulate) {
     MNN_REQUIRE(dy && dh && T > 0 && B > 0 && units > 0 && units % 4 == 0 && keep_prob > 0.f, "mnn_dropout_bwd: bad arguments");
     const int blocks = (int)min((long)4096, ((long)T * B * units / 4 + 255) / 256);
-    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, dy, dh, T, B, units, keep_prob, seed, row0, layer,
-                       accumulate);
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, dy, dh, T, B, units, keep_prob, seed, step_dev, row0,
+                       layer, accumulate);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
@@ -342,7 +344,11 @@ extern "C" int mnn_weighted_sum(mnn_stream_t s, const float* x, const float* w, 
 
 __global__ void clip_adam_kernel(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
                                  long n, const float* __restrict__ sumsq, float clip, float lr_t, float lr, float b1, float b2, float eps,
-                                 int sgd) {
+                                 int sgd, const int32_t* __restrict__ step_dev) {
+    if (step_dev != nullptr) {          // step counter lives on the device (hipGraph replay): t = *step_dev + 1
+        const double t = (double)(step_dev[0] + 1);
+        lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+    }
     float scale = 1.f;
     if (clip > 0.f && sumsq != nullptr) {
         const float gn = sqrtf(sumsq[0]);
@@ -363,11 +369,12 @@ __global__ void clip_adam_kernel(float* __restrict__ theta, const float* __restr
 }
 
 extern "C" int mnn_clip_adam_step(mnn_stream_t s, float* theta, const float* grad, float* m, float* v, long n, const float* sumsq,
-                                  float clip_norm, float lr, float beta1, float beta2, float eps, int step, int sgd) {
-    MNN_REQUIRE(theta && grad && n > 0 && (sgd || (m && v)) && step >= 1, "mnn_clip_adam_step: bad arguments");
+                                  float clip_norm, float lr, float beta1, float beta2, float eps, int step, const int32_t* step_dev, int sgd) {
+    MNN_REQUIRE(theta && grad && n > 0 && (sgd || (m && v)) && (step >= 1 || step_dev != nullptr), "mnn_clip_adam_step: bad arguments");
+    if (step < 1) step = 1;
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
     hipLaunchKernelGGL(clip_adam_kernel, dim3((int)min(2048L, (n + 255) / 256)), dim3(256), 0, (hipStream_t)s, theta, grad, m, v, n, sumsq,
-                       clip_norm, (float)lr_t, lr, beta1, beta2, eps, sgd);
+                       clip_norm, (float)lr_t, lr, beta1, beta2, eps, sgd, step_dev);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
@@ -390,6 +397,14 @@ extern "C" int mnn_bias_grad(mnn_stream_t s, const float* dY, int rows, int cols
     if (!accumulate) MNN_HIP(hipMemsetAsync(db, 0, (size_t)cols * 4, st));
     dim3 grid(cdiv(cols, 64), min(256, cdiv(rows, 64)));
     hipLaunchKernelGGL(bias_grad_kernel, grid, dim3(256), 0, st, dY, rows, cols, ld, db);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+__global__ void step_increment_kernel(int32_t* step_dev) { step_dev[0] += 1; }
+extern "C" int mnn_step_increment(mnn_stream_t s, int32_t* step_dev) {
+    MNN_REQUIRE(step_dev, "mnn_step_increment: null pointer");
+    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, step_dev);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

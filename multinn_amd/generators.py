@@ -72,7 +72,7 @@ class LstmStack:
                                   p["wx_t"], p["wh_t"], p["wh_p"], p["wx_p"], p["bias_p"])
             self.packed.append(p)
 
-    def forward(self, x_tm, keep_prob=1.0, seed=0, row0=0, save=True, state0=None):
+    def forward(self, x_tm, keep_prob=1.0, seed=0, row0=0, save=True, state0=None, step_dev=None):
         """x_tm [T,B,ld0] compute dtype.  Returns (y [T,B,u_last], ctx, final_state[(c,h)...])."""
         T, B, _ = x_tm.shape
         dev = x_tm.device
@@ -90,7 +90,7 @@ class LstmStack:
             del xproj
             if keep_prob < 1.0:
                 y = torch.empty_like(h)
-                ops.dropout_fwd(h, y, keep_prob, seed, row0, l)
+                ops.dropout_fwd(h, y, keep_prob, seed, row0, l, step_dev)
             else:
                 y = h
             if save:
@@ -104,7 +104,7 @@ class LstmStack:
         tiles = -(-rows_out // 128) * -(-cols_out // 128)
         return int(max(1, min(1024 // max(tiles, 1), K // 1024)))
 
-    def backward(self, dy, ctx, keep_prob=1.0, seed=0, row0=0, need_dx=False):
+    def backward(self, dy, ctx, keep_prob=1.0, seed=0, row0=0, need_dx=False, step_dev=None):
         """dy f32 [T,B,u_last]: gradient wrt the (dropped) top output.  Accumulates the kernel /
         bias gradients into the store's flat gradient buffer."""
         T, B, _ = dy.shape
@@ -118,7 +118,7 @@ class LstmStack:
             u, ld, n_in = p["u"], p["ld"], p["n_in"]
             if keep_prob < 1.0:
                 dh = torch.empty((T, B, u), device=dev)
-                ops.dropout_bwd(dy.view(T, B, u), dh, keep_prob, seed, row0, l)
+                ops.dropout_bwd(dy.view(T, B, u), dh, keep_prob, seed, row0, l, False, step_dev)
             else:
                 dh = dy.view(T, B, u)
             dz = torch.empty((T, B, 4 * u), device=dev)
@@ -386,7 +386,7 @@ class RnnNade(RnnEstimator):
         N, dev = T * B, x_tm.device
         self._ensure_packed()
         kp = self._rnn.effective_keep_prob()
-        y, ctx, _ = self._stack.forward(x_tm, kp, self.seed + self.store.step, self.row0, save=train)
+        y, ctx, _ = self._stack.forward(x_tm, kp, self.seed, self.row0, save=train, step_dev=self.store.step_dev)
         out = torch.empty((N, self.ldo), device=dev)
         if self.ldo != self.n_out:
             out[:, self.n_out:].zero_()
@@ -404,7 +404,7 @@ class RnnNade(RnnEstimator):
                              rw_m if train else None, nll, cond_p, d_out, a_fin)
         loss = torch.zeros(1, device=dev)
         ops.weighted_sum(nll.view(-1), rw_m.repeat(M) if M > 1 else rw_m, loss)      # statistical.py:34 / rnn_multinade.py:202-203
-        self._ctx = dict(x_tm=x_tm, v=v, rw=rw_m, y=y, lstm=ctx, out=out, d_out=d_out, a_fin=a_fin, kp=kp, seed=self.seed + self.store.step, B=B, T=T)
+        self._ctx = dict(x_tm=x_tm, v=v, rw=rw_m, y=y, lstm=ctx, out=out, d_out=d_out, a_fin=a_fin, kp=kp, seed=self.seed, B=B, T=T)
         self._nll_tm, self._cond_tm, self._loss = nll, cond_p, loss
         self._flat_idx = None
         self._lengths = lengths
@@ -467,13 +467,40 @@ class RnnNade(RnnEstimator):
             ops.convert2d(d_out, do_c)
         dy = torch.empty((N, R), device=dev)
         ops.gemm_tn(do_c, self._fc_p, dy)
-        self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], cx["seed"], self.row0)
+        self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], cx["seed"], self.row0, step_dev=self.store.step_dev)
 
     def train_step(self, x_u8, lengths, optimizer, lr=None):
         """One optimiser step on a piano-roll batch (train.py:178-189's sess.run)."""
         self.build_pianoroll(x_u8, lengths, is_train=True, mode="train")
         self.train(optimizer, lr)
         return self._loss
+
+    def graphed_train_step(self, x_u8, optimizer, lr=None, warmup=2):
+        """Capture one whole optimiser step (plumbing, packing, forward, backward, clip, Adam: ~600 launches)
+        into a hipGraph and return ``run(x=None) -> loss``: the T-step recurrences are launch-bound on the host
+        otherwise.  Step-dependent values (dropout seed, Adam step) are read from store.step_dev on the device.
+        Full-length batches only (ragged lengths need a host-side row count)."""
+        static_x = x_u8.clone()
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.train_step(static_x, None, optimizer, lr)
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = self.train_step(static_x, None, optimizer, lr)
+        self.store.step -= 1            # the captured step has not executed (host mirror of store.step_dev)
+
+        def run(x=None):
+            if x is not None:
+                static_x.copy_(x)
+            graph.replay()
+            self.store.step += 1
+            return loss
+        run.graph = graph
+        return run
 
     # -- state / sampling -----------------------------------------------------------------------
     def zero_state(self, batch_size):
@@ -620,7 +647,7 @@ class RnnRBM(RnnEstimator):
             rw = self._row_weight(lengths, B, T, dev)
             kp = self._rnn.effective_keep_prob()
             seed = self.seed + self.store.step
-            yy, ctx, _ = self._stack.forward(x_tm, kp, seed, self.row0, save=(mode == "train"))
+            yy, ctx, _ = self._stack.forward(x_tm, kp, self.seed, self.row0, save=(mode == "train"), step_dev=self.store.step_dev)
             out = self._biases(yy.view(N, -1))
             bh_t, bv_t = out[:, :Hn], out[:, Hn:Hn + D]
             # global flat row ids keep the Gibbs uniforms independent of the data-parallel split
@@ -702,7 +729,7 @@ class RnnRBM(RnnEstimator):
         do_c = d_out if self.dtype == torch.float32 else d_out.to(self.dtype)
         dy = torch.empty((N, R), device=dev)
         ops.gemm_tn(do_c, self._wu_p, dy)
-        self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], cx["seed"], self.row0)
+        self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], self.seed, self.row0, step_dev=self.store.step_dev)
 
     def zero_state(self, batch_size):
         self._materialize(self._num_inputs)

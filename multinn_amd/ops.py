@@ -163,17 +163,25 @@ def lstm_seq_bwd(dh_ext, wh_p, gates, c, c0, dz, dz_T, dh0=None, dc0=None):
          _ptr(dz_T), _ptr(dh0), _ptr(dc0), _ptr(ws))
 
 
-def dropout_fwd(h, y, keep_prob, seed, row0, layer):
+def _step_ok(step_dev):
+    _req(step_dev is None or (step_dev.dtype == torch.int32 and step_dev.numel() == 1), "step_dev must be a device int32 scalar")
+
+
+def dropout_fwd(h, y, keep_prob, seed, row0, layer, step_dev=None):
     T, B, u = h.shape
     _req(h.is_contiguous() and y.is_contiguous() and h.shape == y.shape and h.dtype == y.dtype and u % 4 == 0, "dropout_fwd: shapes")
-    call("mnn_dropout_fwd", _stream(), dtype_code(h), _ptr(h), _ptr(y), T, B, u, float(keep_prob), int(seed), int(row0), int(layer))
+    _step_ok(step_dev)
+    call("mnn_dropout_fwd", _stream(), dtype_code(h), _ptr(h), _ptr(y), T, B, u, float(keep_prob), int(seed), _ptr(step_dev), int(row0),
+         int(layer))
 
 
-def dropout_bwd(dy, dh, keep_prob, seed, row0, layer, accumulate=False):
+def dropout_bwd(dy, dh, keep_prob, seed, row0, layer, accumulate=False, step_dev=None):
     T, B, u = dy.shape
     _req(dy.dtype == torch.float32 and dh.dtype == torch.float32 and dy.is_contiguous() and dh.is_contiguous() and dy.shape == dh.shape,
          "dropout_bwd: f32 [T,B,u]")
-    call("mnn_dropout_bwd", _stream(), _ptr(dy), _ptr(dh), T, B, u, float(keep_prob), int(seed), int(row0), int(layer), int(accumulate))
+    _step_ok(step_dev)
+    call("mnn_dropout_bwd", _stream(), _ptr(dy), _ptr(dh), T, B, u, float(keep_prob), int(seed), _ptr(step_dev), int(row0), int(layer),
+         int(accumulate))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -302,12 +310,17 @@ def weighted_sum(x, w, out):
     call("mnn_weighted_sum", _stream(), _ptr(x), _ptr(w), x.numel(), _ptr(out))
 
 
-def clip_adam_step(theta, grad, m, v, sumsq_buf, clip_norm, lr, beta1, beta2, eps, step, sgd=False):
+def clip_adam_step(theta, grad, m, v, sumsq_buf, clip_norm, lr, beta1, beta2, eps, step, sgd=False, step_dev=None):
     n = theta.numel()
     for t in (theta, grad) + (() if sgd else (m, v)):
         _req(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n, "adam: flat f32 buffers of equal size")
     call("mnn_clip_adam_step", _stream(), _ptr(theta), _ptr(grad), _ptr(m), _ptr(v), n, _ptr(sumsq_buf), float(clip_norm), float(lr),
-         float(beta1), float(beta2), float(eps), int(step), int(sgd))
+         float(beta1), float(beta2), float(eps), int(step), _ptr(step_dev), int(sgd))
+
+
+def step_increment(step_dev):
+    _step_ok(step_dev)
+    call("mnn_step_increment", _stream(), _ptr(step_dev))
 
 
 def bias_grad(dY, db, accumulate=False):

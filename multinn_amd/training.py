@@ -45,6 +45,8 @@ def compute_gradients(optimizer, store, clip_norm=5.0, lr=None):
     sumsq = torch.zeros(1, device=store.grad.device)
     ops.sumsq(store.grad, sumsq)
     store.step += 1
+    # the step count is read from store.step_dev ON DEVICE (= store.step - 1 here), so a captured graph stays valid
     ops.clip_adam_step(store.theta, store.grad, store.m, store.v, sumsq, clip_norm, optimizer.lr if lr is None else lr,
-                       optimizer.beta1, optimizer.beta2, optimizer.epsilon, store.step, optimizer.sgd)
+                       optimizer.beta1, optimizer.beta2, optimizer.epsilon, store.step, optimizer.sgd, store.step_dev)
+    ops.step_increment(store.step_dev)
     return sumsq

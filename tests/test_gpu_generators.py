@@ -287,6 +287,24 @@ def test_save_load_roundtrip(tmp_path):
     assert l1 == l2
 
 
+def test_graphed_train_step_matches_eager():
+    from multinn_amd import RnnNade, AdamOptimizer
+    x = make_batch(8, 6, 8, 2, 7, rho=0.2)
+    a = RnnNade(16, 16, [128, 128], keep_prob=0.9, precision="bf16", seed=3)
+    b = RnnNade(16, 16, [128, 128], keep_prob=0.9, precision="bf16", seed=3)
+    b._materialize(16)
+    a._materialize(16)
+    b.store.theta.copy_(a.store.theta)
+    opt = AdamOptimizer(0.01)
+    run = b.graphed_train_step(dev(x), opt, warmup=2)          # 2 eager warm-up steps + 1 captured (not executed) step
+    la = [float(a.train_step(dev(x), None, opt)) for _ in range(5)]
+    lb = [float(run()) for _ in range(3)]
+    # graph replays are steps 3,4,5 of the same trajectory (dropout seed and Adam step come from the device counter)
+    assert np.allclose(lb, la[2:], rtol=2e-3), (la, lb)
+    assert b.store.step == 5 and int(b.store.step_dev) == 5
+    assert torch.allclose(a.store.theta, b.store.theta, atol=2e-3)
+
+
 def test_training_reduces_loss():
     from multinn_amd import RnnNade, AdamOptimizer
     x = make_batch(8, 8, 8, 2, 5, rho=0.1)

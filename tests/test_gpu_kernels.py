@@ -231,6 +231,10 @@ def test_dropout_matches_contract(ops):
     assert np.array_equal(y.cpu().numpy(), ref)
     dh = torch.ones((T, B, u), device=DEV)
     ops.dropout_bwd(dev(h), dh, 0.9, 23, 100, 1, accumulate=True)
+    # device-side step counter: seed_eff = seed + *step_dev
+    y3 = torch.empty((T, B, u), device=DEV)
+    ops.dropout_fwd(dev(h), y3, 0.9, seed=20, row0=100, layer=1, step_dev=torch.tensor([3], device=DEV, dtype=torch.int32))
+    assert torch.equal(y3, y)
     assert np.allclose(dh.cpu().numpy(), 1 + h / np.float32(0.9) * keep, rtol=1e-6)
     y2 = torch.empty((T, B, u), device=DEV)
     ops.dropout_fwd(dev(h), y2, 1.0, 23, 100, 1)
@@ -383,6 +387,12 @@ def test_reductions_and_adam(ops):
         clipped, gn = S.clip_by_global_norm([g.astype(np.float64)], 5.0)
         ref_th, ref_m, ref_v = S.adam_tf_step(ref_th, clipped[0], ref_m, ref_v, step, 0.01)
         ops.clip_adam_step(tht, dev(g), m, v, out, 5.0, 0.01, 0.9, 0.999, 1e-4, step)
+    th_d, m_d, v_d = dev(th), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    sd = torch.zeros(1, device=DEV, dtype=torch.int32)
+    for step in (1, 2, 3):          # same three steps with the counter on the device
+        ops.clip_adam_step(th_d, dev(g), m_d, v_d, out, 5.0, 0.01, 0.9, 0.999, 1e-4, 0, step_dev=sd)
+        ops.step_increment(sd)
+    assert int(sd) == 3 and rel(th_d.cpu().numpy(), tht.cpu().numpy()) < 1e-6
     assert rel(tht.cpu().numpy(), ref_th) < 1e-5 and rel(m.cpu().numpy(), ref_m) < 1e-5 and rel(v.cpu().numpy(), ref_v) < 5e-5   # beta2 = 0.999f carries a 1.3e-5 relative error in (1-beta2), as in TF's f32 kernel
     th2 = dev(th)
     ops.clip_adam_step(th2, dev(g), None, None, None, 0.0, 0.1, 0.9, 0.999, 1e-4, 1, sgd=True)
