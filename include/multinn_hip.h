@@ -96,32 +96,36 @@ int mnn_lstm_pack_weights(mnn_stream_t s, const float* W, const float* bias, int
 int mnn_lstm_unpack_grads(mnn_stream_t s, const float* dwx_t, const float* dwh_t, const float* db_p, int n_in, int units,
                           int ld_in, float* dW, float* db);
 
-/* One layer over a whole sequence, time-major.  xproj f32 [T,B,4u] = inputs . Wx + b (already
- * computed with mnn_gemm_tn).  Runs T fused {recurrent GEMM + gate pointwise} kernels.
+/* One layer over steps [t_begin, t_end) of a sequence, time-major (chunked calls let the layers of a
+ * stack run as a wavefront on separate streams).  xproj f32 [T,B,4u] = inputs . Wx + b (already
+ * computed with mnn_gemm_tn).  Runs one fused {recurrent GEMM + gate pointwise} kernel per step;
+ * step t > 0 reads its previous state from h[t-1], c[t-1].
  *   h0,c0 may be NULL (zero state, rnn.py:155-176).
  *   gates f32 [T,B,4u] (post-activation i,g,f,o; saved for backward; may be NULL for inference)
  *   c f32 [T,B,u], h T [T,B,u]
  * Replaces: dynamic_decode/dynamic_rnn over the cell -- rnn_nade.py:204-218, rnn_rbm.py:217-223. */
-int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int units, const float* xproj, const void* wh_t,
-                     const void* h0, const float* c0, float* gates, float* c, void* h);
+int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int units, int t_begin, int t_end, const float* xproj,
+                     const void* wh_t, const void* h0, const float* c0, float* gates, float* c, void* h);
 
-/* BPTT for one layer.  dh_ext f32 [T,B,u] (gradient arriving at h_t from above),
- * dz f32 [T,B,4u] out (gate-interleaved pre-activation gradient), dh0/dc0 f32 [B,u] out (may be NULL).
+/* BPTT for one layer over steps [t_begin, t_end), processed downwards; successive calls must cover
+ * the sequence from the top range to 0 and share `workspace` (it carries d c between calls).
+ * dh_ext f32 [T,B,u] (gradient arriving at h_t from above), dz f32 [T,B,4u] out (gate-interleaved
+ * pre-activation gradient), dh0/dc0 f32 [B,u] out with the t_begin == 0 call (may be NULL).
  * workspace: mnn_lstm_seq_bwd_workspace_bytes(B, units). */
 size_t mnn_lstm_seq_bwd_workspace_bytes(int B, int units);
-int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int units, const float* dh_ext, const void* wh_p,
-                     const float* gates, const float* c, const float* c0, float* dz, void* dz_T /* T copy of dz or NULL */,
-                     float* dh0, float* dc0, void* workspace);
+int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int units, int t_begin, int t_end, const float* dh_ext,
+                     const void* wh_p, const float* gates, const float* c, const float* c0, float* dz,
+                     void* dz_T /* T copy of dz or NULL */, float* dh0, float* dc0, void* workspace);
 
 /* Output dropout of DropoutWrapper (rnn.py:132): y = h/kp * floor(kp+u), u = Philox(stream 0,
  * row = row0+b, sub = (t<<8)|layer, elem = unit).  h,y T [T,B,u].  kp>=1 -> copy.
  * step_dev (optional device int32): the effective seed is seed + *step_dev, so a captured hipGraph
- * of the train step draws fresh masks on every replay. */
+ * of the train step draws fresh masks on every replay.  t_offset: absolute time index of h[0] (chunked calls). */
 int mnn_dropout_fwd(mnn_stream_t s, int dtype, const void* h, void* y, int T, int B, int units, float keep_prob,
-                    uint64_t seed, const int32_t* step_dev, uint32_t row0, int layer);
+                    uint64_t seed, const int32_t* step_dev, uint32_t row0, int layer, int t_offset);
 /* dh[t,b,j] (+)= dy[t,b,j]/kp*keep  (f32 in/out, mask recomputed) */
 int mnn_dropout_bwd(mnn_stream_t s, const float* dy, float* dh, int T, int B, int units, float keep_prob, uint64_t seed,
-                    const int32_t* step_dev, uint32_t row0, int layer, int accumulate);
+                    const int32_t* step_dev, uint32_t row0, int layer, int accumulate, int t_offset);
 
 /* ------------------------------------------------------------------------------------------
  * NADE (models/common/nade.py).  Weights w_enc,w_dec f32 [tracks,D,Hn].  Rows: v u8

@@ -229,7 +229,7 @@ extern "C" int mnn_lstm_unpack_grads(mnn_stream_t s, const float* dwx_t, const f
 // ----------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void dropout_fwd_kernel(const T* __restrict__ h, T* __restrict__ y, int Tn, int B, int U, float kp, uint64_t seed,
-                                   const int32_t* __restrict__ step_dev, uint32_t row0, int layer) {
+                                   const int32_t* __restrict__ step_dev, uint32_t row0, int layer, int t_offset) {
     if (step_dev != nullptr) seed += (uint64_t)step_dev[0];
     const int U4 = U >> 2;
     const long total = (long)Tn * B * U4;
@@ -238,7 +238,7 @@ __global__ void dropout_fwd_kernel(const T* __restrict__ h, T* __restrict__ y, i
         const long tb = i / U4;
         const int b = (int)(tb % B), t = (int)(tb / B);
         float u[4];
-        philox_uniform4(seed, MNN_STREAM_DROPOUT, row0 + (uint32_t)b, ((uint32_t)t << 8) | (uint32_t)layer, (uint32_t)q, u);
+        philox_uniform4(seed, MNN_STREAM_DROPOUT, row0 + (uint32_t)b, ((uint32_t)(t + t_offset) << 8) | (uint32_t)layer, (uint32_t)q, u);
         const size_t o = (size_t)tb * U + q * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -249,7 +249,7 @@ __global__ void dropout_fwd_kernel(const T* __restrict__ h, T* __restrict__ y, i
 }
 
 extern "C" int mnn_dropout_fwd(mnn_stream_t s, int dtype, const void* h, void* y, int T, int B, int units, float keep_prob, uint64_t seed,
-                               const int32_t* step_dev, uint32_t row0, int layer) {
+                               const int32_t* step_dev, uint32_t row0, int layer, int t_offset) {
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(h && y && T > 0 && B > 0 && units > 0 && units % 4 == 0, "mnn_dropout_fwd: bad arguments");
     MNN_REQUIRE(dtype == MNN_F32 || dtype == MNN_BF16, "mnn_dropout_fwd: dtype must be f32/bf16");
@@ -262,16 +262,16 @@ extern "C" int mnn_dropout_fwd(mnn_stream_t s, int dtype, const void* h, void* y
     const int blocks = (int)min((long)4096, ((long)T * B * units / 4 + 255) / 256);
     if (dtype == MNN_F32)
         hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)h, (float*)y, T, B, units, keep_prob, seed,
-                           step_dev, row0, layer);
+                           step_dev, row0, layer, t_offset);
     else
         hipLaunchKernelGGL(dropout_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)h, (bf16_t*)y, T, B, units, keep_prob,
-                           seed, step_dev, row0, layer);
+                           seed, step_dev, row0, layer, t_offset);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
 
 __global__ void dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dh, int Tn, int B, int U, float kp, uint64_t seed,
-                                   const int32_t* __restrict__ step_dev, uint32_t row0, int layer, int accumulate) {
+                                   const int32_t* __restrict__ step_dev, uint32_t row0, int layer, int accumulate, int t_offset) {
     if (step_dev != nullptr) seed += (uint64_t)step_dev[0];
     const int U4 = U >> 2;
     const long total = (long)Tn * B * U4;
@@ -280,7 +280,7 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ dy, float* __restri
         const long tb = i / U4;
         const int b = (int)(tb % B), t = (int)(tb / B);
         float u[4] = {1.f, 1.f, 1.f, 1.f};
-        if (kp < 1.0f) philox_uniform4(seed, MNN_STREAM_DROPOUT, row0 + (uint32_t)b, ((uint32_t)t << 8) | (uint32_t)layer, (uint32_t)q, u);
+        if (kp < 1.0f) philox_uniform4(seed, MNN_STREAM_DROPOUT, row0 + (uint32_t)b, ((uint32_t)(t + t_offset) << 8) | (uint32_t)layer, (uint32_t)q, u);
         const size_t o = (size_t)tb * U + q * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -291,11 +291,11 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ dy, float* __restri
 }
 
 extern "C" int mnn_dropout_bwd(mnn_stream_t s, const float* dy, float* dh, int T, int B, int units, float keep_prob, uint64_t seed,
-                               const int32_t* step_dev, uint32_t row0, int layer, int accumulate) {
+                               const int32_t* step_dev, uint32_t row0, int layer, int accumulate, int t_offset) {
     MNN_REQUIRE(dy && dh && T > 0 && B > 0 && units > 0 && units % 4 == 0 && keep_prob > 0.f, "mnn_dropout_bwd: bad arguments");
     const int blocks = (int)min((long)4096, ((long)T * B * units / 4 + 255) / 256);
     hipLaunchKernelGGL(dropout_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, dy, dh, T, B, units, keep_prob, seed, step_dev, row0,
-                       layer, accumulate);
+                       layer, accumulate, t_offset);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

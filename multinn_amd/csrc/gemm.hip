@@ -532,16 +532,17 @@ lstm_bwd_step_v2(const bf16_t* __restrict__ dz_next, const bf16_t* __restrict__ 
     }
 }
 
-extern "C" int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int units, const float* xproj, const void* wh_t,
-                                const void* h0, const float* c0, float* gates, float* c, void* h) {
+extern "C" int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int units, int t_begin, int t_end, const float* xproj,
+                                const void* wh_t, const void* h0, const float* c0, float* gates, float* c, void* h) {
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F32, "mnn_lstm_seq_fwd: dtype must be bf16 or f32");
     MNN_REQUIRE(T > 0 && B > 0 && units > 0 && units % 32 == 0, "mnn_lstm_seq_fwd: units must be a positive multiple of 32 (T=%d B=%d u=%d)",
                 T, B, units);
     MNN_REQUIRE(xproj && wh_t && c && h, "mnn_lstm_seq_fwd: null pointer");
+    MNN_REQUIRE(0 <= t_begin && t_begin < t_end && t_end <= T, "mnn_lstm_seq_fwd: bad step range [%d,%d) of %d", t_begin, t_end, T);
     const size_t esz = dtype == MNN_BF16 ? 2 : 4;
     dim3 grid(units / 32, cdiv(B, 64));
-    for (int t = 0; t < T; ++t) {
+    for (int t = t_begin; t < t_end; ++t) {
         const float* xp = xproj + (size_t)t * B * 4 * units;
         float* gt = gates ? gates + (size_t)t * B * 4 * units : nullptr;
         float* ct = c + (size_t)t * B * units;
@@ -628,21 +629,22 @@ lstm_bwd_step_kernel(const T* __restrict__ dz_next, const T* __restrict__ wh_p, 
 
 extern "C" size_t mnn_lstm_seq_bwd_workspace_bytes(int B, int units) { return (size_t)B * units * sizeof(float); }
 
-extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int units, const float* dh_ext, const void* wh_p,
-                                const float* gates, const float* c, const float* c0, float* dz, void* dz_T, float* dh0, float* dc0,
-                                void* workspace) {
+extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int units, int t_begin, int t_end, const float* dh_ext,
+                                const void* wh_p, const float* gates, const float* c, const float* c0, float* dz, void* dz_T, float* dh0,
+                                float* dc0, void* workspace) {
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F32, "mnn_lstm_seq_bwd: dtype must be bf16 or f32");
     MNN_REQUIRE(T > 0 && B > 0 && units > 0 && units % 32 == 0, "mnn_lstm_seq_bwd: units must be a positive multiple of 32");
     MNN_REQUIRE(dh_ext && wh_p && gates && c && workspace, "mnn_lstm_seq_bwd: null pointer");
     MNN_REQUIRE(dtype == MNN_F32 ? (dz != nullptr) : (dz_T != nullptr), "mnn_lstm_seq_bwd: dz (f32) / dz_T (bf16) output required");
+    MNN_REQUIRE(0 <= t_begin && t_begin < t_end && t_end <= T, "mnn_lstm_seq_bwd: bad step range [%d,%d) of %d", t_begin, t_end, T);
     if (dtype == MNN_F32) dz_T = dz;
     const size_t esz = dtype == MNN_BF16 ? 2 : 4;
-    float* dc = dc0 ? dc0 : (float*)workspace;
+    float* dc = (float*)workspace;        // carried d c between calls: process [t_begin,t_end) from the top range downwards
     dim3 grid(cdiv(units, 64), cdiv(B, 64));
     const size_t zs = (size_t)B * 4 * units, us = (size_t)B * units;
-    for (int t = T - 1; t >= -1; --t) {
-        if (t < 0 && dh0 == nullptr) break;
+    for (int t = t_end - 1; t >= t_begin - 1; --t) {
+        if (t < t_begin && !(t_begin == 0 && dh0 != nullptr)) break;
         const char* dzn = t == T - 1 ? nullptr : (const char*)dz_T + (size_t)(t + 1) * zs * esz;
         const int tt = t < 0 ? 0 : t;
         const float* cp = t <= 0 ? c0 : c + (size_t)(t - 1) * us;
@@ -665,5 +667,6 @@ extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int uni
                                units, t == T - 1 ? 1 : 0);
     }
     MNN_LAUNCH_CHECK();
+    if (t_begin == 0 && dc0 != nullptr) MNN_HIP(hipMemcpyAsync(dc0, dc, us * sizeof(float), hipMemcpyDeviceToDevice, st));
     return MNN_OK;
 }

@@ -72,84 +72,156 @@ class LstmStack:
                                   p["wx_t"], p["wh_t"], p["wh_p"], p["wx_p"], p["bias_p"])
             self.packed.append(p)
 
+    chunk = 16        # timesteps per wavefront chunk
+    # Measured on MI355X / ROCm 7.2 (profiles/round1_c_wavefront_note.md): hipGraph replay runs the per-layer branches
+    # one after the other and the eager multi-stream form is host-bound, so the wavefront is OFF by default.
+    pipelined = False
+
+    def _lanes(self, n, dev):
+        """n streams: the current one plus cached side streams (one per LSTM layer)."""
+        if not hasattr(self, "_side") or len(self._side) < n - 1:
+            self._side = [torch.cuda.Stream(device=dev) for _ in range(n - 1)]
+        return [torch.cuda.current_stream()] + self._side[:n - 1]
+
+    @staticmethod
+    def _chunks(T, step):
+        return [(t0, min(T, t0 + step)) for t0 in range(0, T, step)]
+
     def forward(self, x_tm, keep_prob=1.0, seed=0, row0=0, save=True, state0=None, step_dev=None):
-        """x_tm [T,B,ld0] compute dtype.  Returns (y [T,B,u_last], ctx, final_state[(c,h)...])."""
+        """x_tm [T,B,ld0] compute dtype.  Returns (y [T,B,u_last], ctx, final_state[(c,h)...]).
+
+        The T-step recurrences are latency-bound chains, so the layers run as a WAVEFRONT: layer l works on
+        time chunk c on its own HIP stream while layer l-1 is already on chunk c+1 (events order the chunks)."""
         T, B, _ = x_tm.shape
         dev = x_tm.device
-        ctx, final = [], []
-        inp = x_tm
+        L = len(self.packed)
+        bufs = []
         for l, p in enumerate(self.packed):
             u = p["u"]
-            xproj = torch.empty((T, B, 4 * u), device=dev)
-            ops.gemm_tn(inp.view(T * B, -1), p["wx_t"], xproj.view(T * B, 4 * u), bias=p["bias_p"])
-            gates = torch.empty((T, B, 4 * u), device=dev) if save else None
-            c = torch.empty((T, B, u), device=dev)
             h = torch.empty((T, B, u), device=dev, dtype=self.dtype)
-            c0, h0 = (state0[l][0], state0[l][1].to(self.dtype)) if state0 is not None else (None, None)
-            ops.lstm_seq_fwd(xproj, p["wh_t"], h0, c0, gates, c, h)
-            del xproj
-            if keep_prob < 1.0:
-                y = torch.empty_like(h)
-                ops.dropout_fwd(h, y, keep_prob, seed, row0, l, step_dev)
-            else:
-                y = h
-            if save:
-                ctx.append(dict(inp=inp, gates=gates, c=c, h=h, c0=c0, h0=h0))
-            final.append((c[-1], h[-1]))
-            inp = y
-        return inp, ctx, final
+            bufs.append(dict(xproj=torch.empty((T, B, 4 * u), device=dev), gates=torch.empty((T, B, 4 * u), device=dev) if save else None,
+                             c=torch.empty((T, B, u), device=dev), h=h, y=torch.empty_like(h) if keep_prob < 1.0 else h,
+                             c0=state0[l][0] if state0 is not None else None,
+                             h0=state0[l][1].to(self.dtype) if state0 is not None else None))
+        piped = self.pipelined and L > 1 and T > self.chunk
+        chunks = self._chunks(T, self.chunk if piped else T)
+        lanes = self._lanes(L if piped else 1, dev)
+        main = lanes[0]
+        for s in lanes[1:]:
+            s.wait_stream(main)
+        # layer 0's input projection has no dependency: one big GEMM
+        p0, b0 = self.packed[0], bufs[0]
+        ops.gemm_tn(x_tm.view(T * B, -1), p0["wx_t"], b0["xproj"].view(T * B, -1), bias=p0["bias_p"])
+        done = [[None] * len(chunks) for _ in range(L)]
+        for ci, (t0, t1) in enumerate(chunks):
+            for l, (p, bf) in enumerate(zip(self.packed, bufs)):
+                lane = lanes[l] if piped else main
+                with torch.cuda.stream(lane):
+                    if l > 0:
+                        if piped:
+                            lane.wait_event(done[l - 1][ci])
+                        inp = bufs[l - 1]["y"]
+                        ops.gemm_tn(inp[t0:t1].view((t1 - t0) * B, -1), p["wx_t"], bf["xproj"][t0:t1].view((t1 - t0) * B, -1), bias=p["bias_p"])
+                    ops.lstm_seq_fwd(bf["xproj"], p["wh_t"], bf["h0"], bf["c0"], bf["gates"], bf["c"], bf["h"], t0, t1)
+                    if keep_prob < 1.0:
+                        ops.dropout_fwd(bf["h"][t0:t1], bf["y"][t0:t1], keep_prob, seed, row0, l, step_dev, t0)
+                    if piped and l < L - 1:
+                        done[l][ci] = torch.cuda.Event()
+                        done[l][ci].record(lane)
+        for s in lanes[1:]:
+            main.wait_stream(s)
+        ctx = []
+        if save:
+            for l, bf in enumerate(bufs):
+                ctx.append(dict(inp=x_tm if l == 0 else bufs[l - 1]["y"], gates=bf["gates"], c=bf["c"], h=bf["h"], c0=bf["c0"], h0=bf["h0"]))
+        final = [(bf["c"][-1], bf["h"][-1]) for bf in bufs]
+        return bufs[-1]["y"], ctx, final
 
     @staticmethod
     def _split_k(rows_out, cols_out, K):
         tiles = -(-rows_out // 128) * -(-cols_out // 128)
         return int(max(1, min(1024 // max(tiles, 1), K // 1024)))
 
-    def backward(self, dy, ctx, keep_prob=1.0, seed=0, row0=0, need_dx=False, step_dev=None):
-        """dy f32 [T,B,u_last]: gradient wrt the (dropped) top output.  Accumulates the kernel /
-        bias gradients into the store's flat gradient buffer."""
-        T, B, _ = dy.shape
+    def _weight_grads(self, l, cx, dz, dzc, T, B):
+        """dWx^T[4u,ld] = dz^T . inp ; dWh^T[4u,u] = dz^T . h_prev ; db = sum dz  (reduction over the N rows)."""
+        p = self.packed[l]
+        u, ld, n_in = p["u"], p["ld"], p["n_in"]
         N = T * B
         Np = ops.round_up(N, 64)
-        dev = dy.device
+        dev = dz.device
         zalloc = torch.zeros if Np != N else torch.empty
-        dx = None
-        for l in range(len(self.packed) - 1, -1, -1):
-            p, cx = self.packed[l], ctx[l]
-            u, ld, n_in = p["u"], p["ld"], p["n_in"]
-            if keep_prob < 1.0:
-                dh = torch.empty((T, B, u), device=dev)
-                ops.dropout_bwd(dy.view(T, B, u), dh, keep_prob, seed, row0, l, False, step_dev)
-            else:
-                dh = dy.view(T, B, u)
+        dzT = zalloc((4 * u, Np), device=dev, dtype=self.dtype)
+        ops.transpose(dzc.view(N, 4 * u), dzT)
+        inT = zalloc((ld, Np), device=dev, dtype=self.dtype)
+        ops.transpose(cx["inp"].view(N, ld), inT)
+        dwx_t = torch.empty((4 * u, ld), device=dev)
+        ops.gemm_tn(dzT, inT, dwx_t, split_k=self._split_k(4 * u, ld, Np))
+        hT = torch.zeros((u, Np), device=dev, dtype=self.dtype)
+        if cx["h0"] is not None:
+            ops.transpose(cx["h0"], hT[:, :B])
+        if T > 1:
+            ops.transpose(cx["h"][:-1].view((T - 1) * B, u), hT[:, B:N])
+        dwh_t = torch.empty((4 * u, u), device=dev)
+        ops.gemm_tn(dzT, hT, dwh_t, split_k=self._split_k(4 * u, u, Np))
+        db_p = torch.empty(4 * u, device=dev)
+        ops.bias_grad(dz.view(N, 4 * u), db_p)
+        ops.lstm_unpack_grads(dwx_t, dwh_t, db_p, n_in, u, self.store.gviews[f"{self.rnn.prefix}/cell_{l}/kernel"],
+                              self.store.gviews[f"{self.rnn.prefix}/cell_{l}/bias"])
+        return (dzT, inT, hT, dwx_t, dwh_t, db_p)      # kept alive until the streams are joined
+
+    def backward(self, dy, ctx, keep_prob=1.0, seed=0, row0=0, need_dx=False, step_dev=None):
+        """dy f32 [T,B,u_last]: gradient wrt the (dropped) top output.  Accumulates the kernel / bias gradients
+        into the store's flat gradient buffer.  Same wavefront as forward, top layer first, chunks descending;
+        each layer's weight-gradient GEMMs then run on that layer's stream."""
+        if need_dx:
+            raise NotImplementedError("gradient wrt the generator inputs (tune_encoder) is a 'next' row")
+        T, B, _ = dy.shape
+        dev = dy.device
+        L = len(self.packed)
+        piped = self.pipelined and L > 1 and T > self.chunk
+        chunks = self._chunks(T, self.chunk if piped else T)
+        lanes = self._lanes(L if piped else 1, dev)
+        main = lanes[0]
+        for s in lanes[1:]:
+            s.wait_stream(main)
+        dyl = [None] * L
+        dyl[L - 1] = dy.view(T, B, -1)
+        st = []
+        for l, p in enumerate(self.packed):
+            u = p["u"]
             dz = torch.empty((T, B, 4 * u), device=dev)
-            dzc = dz if self.dtype == torch.float32 else torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype)
-            ops.lstm_seq_bwd(dh, p["wh_p"], cx["gates"], cx["c"], cx["c0"], dz, dzc)
-            # weight gradients: dWx^T[4u,ld] = dz^T . inp ; dWh^T[4u,u] = dz^T . h_prev  (reduction over the N rows)
-            dzT = zalloc((4 * u, Np), device=dev, dtype=self.dtype)
-            ops.transpose(dzc.view(N, 4 * u), dzT)
-            inT = zalloc((ld, Np), device=dev, dtype=self.dtype)
-            ops.transpose(cx["inp"].view(N, ld), inT)
-            dwx_t = torch.empty((4 * u, ld), device=dev)
-            ops.gemm_tn(dzT, inT, dwx_t, split_k=self._split_k(4 * u, ld, Np))
-            del inT
-            hT = torch.zeros((u, Np), device=dev, dtype=self.dtype)
-            if cx["h0"] is not None:
-                ops.transpose(cx["h0"], hT[:, :B])
-            if T > 1:
-                ops.transpose(cx["h"][:-1].view((T - 1) * B, u), hT[:, B:N])
-            dwh_t = torch.empty((4 * u, u), device=dev)
-            ops.gemm_tn(dzT, hT, dwh_t, split_k=self._split_k(4 * u, u, Np))
-            del hT, dzT
-            db_p = torch.empty(4 * u, device=dev)
-            ops.bias_grad(dz.view(N, 4 * u), db_p)
-            ops.lstm_unpack_grads(dwx_t, dwh_t, db_p, n_in, u, self.store.gviews[f"{self.rnn.prefix}/cell_{l}/kernel"],
-                                  self.store.gviews[f"{self.rnn.prefix}/cell_{l}/bias"])
-            if l > 0:
-                dy = torch.empty((N, n_in), device=dev)
-                ops.gemm_tn(dzc.view(N, 4 * u), p["wx_p"], dy)
-            elif need_dx:
-                raise NotImplementedError("gradient wrt the generator inputs (tune_encoder) is a 'next' row")
-        return dx
+            st.append(dict(dz=dz, dzc=dz if self.dtype == torch.float32 else torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype),
+                           dh=torch.empty((T, B, u), device=dev) if keep_prob < 1.0 else None, ws=ops.lstm_seq_bwd_workspace(B, u, dev)))
+            if l < L - 1:
+                dyl[l] = torch.empty((T, B, u), device=dev)
+        lane_of = lambda l: lanes[L - 1 - l] if piped else main          # the top layer leads, on the current stream
+        done = [[None] * len(chunks) for _ in range(L)]
+        for ci in range(len(chunks) - 1, -1, -1):
+            t0, t1 = chunks[ci]
+            for l in range(L - 1, -1, -1):
+                p, cx, s_ = self.packed[l], ctx[l], st[l]
+                lane = lane_of(l)
+                with torch.cuda.stream(lane):
+                    if piped and l < L - 1:
+                        lane.wait_event(done[l + 1][ci])
+                    if keep_prob < 1.0:
+                        ops.dropout_bwd(dyl[l][t0:t1], s_["dh"][t0:t1], keep_prob, seed, row0, l, False, step_dev, t0)
+                        dh = s_["dh"]
+                    else:
+                        dh = dyl[l]
+                    ops.lstm_seq_bwd(dh, p["wh_p"], cx["gates"], cx["c"], cx["c0"], s_["dz"], s_["dzc"], None, None, t0, t1, s_["ws"])
+                    if l > 0:
+                        ops.gemm_tn(s_["dzc"][t0:t1].view((t1 - t0) * B, -1), p["wx_p"], dyl[l - 1][t0:t1].view((t1 - t0) * B, -1))
+                        if piped:
+                            done[l][ci] = torch.cuda.Event()
+                            done[l][ci].record(lane)
+        keep = []
+        for l in range(L - 1, -1, -1):
+            with torch.cuda.stream(lane_of(l)):
+                keep.append(self._weight_grads(l, ctx[l], st[l]["dz"], st[l]["dzc"], T, B))
+        for s in lanes[1:]:
+            main.wait_stream(s)
+        return None
 
     def single_step(self, x, state):
         """One time step (rnn_nade.py:268): x [B,ld0] compute dtype, state [(c,h)...] -> (h_top, new_state)."""

@@ -131,7 +131,7 @@ def lstm_unpack_grads(dwx_t, dwh_t, db_p, n_in, units, dW, db):
     call("mnn_lstm_unpack_grads", _stream(), _ptr(dwx_t), _ptr(dwh_t), _ptr(db_p), n_in, units, ld_in, _ptr(dW), _ptr(db))
 
 
-def lstm_seq_fwd(xproj, wh_t, h0, c0, gates, c, h):
+def lstm_seq_fwd(xproj, wh_t, h0, c0, gates, c, h, t_begin=0, t_end=None):
     T, B, N4 = xproj.shape
     units = N4 // 4
     _req(xproj.dtype == torch.float32 and xproj.is_contiguous() and units % 32 == 0, "lstm_fwd: xproj f32 [T,B,4u], u%32==0")
@@ -144,10 +144,17 @@ def lstm_seq_fwd(xproj, wh_t, h0, c0, gates, c, h):
         _req(h0.shape == (B, units) and h0.dtype == h.dtype and h0.is_contiguous(), "lstm_fwd: h0")
     if c0 is not None:
         _req(c0.shape == (B, units) and c0.dtype == torch.float32 and c0.is_contiguous(), "lstm_fwd: c0")
-    call("mnn_lstm_seq_fwd", _stream(), dtype_code(h), T, B, units, _ptr(xproj), _ptr(wh_t), _ptr(h0), _ptr(c0), _ptr(gates), _ptr(c), _ptr(h))
+    t_end = T if t_end is None else t_end
+    _req(0 <= t_begin < t_end <= T, "lstm_fwd: bad step range")
+    call("mnn_lstm_seq_fwd", _stream(), dtype_code(h), T, B, units, int(t_begin), int(t_end), _ptr(xproj), _ptr(wh_t), _ptr(h0), _ptr(c0),
+         _ptr(gates), _ptr(c), _ptr(h))
 
 
-def lstm_seq_bwd(dh_ext, wh_p, gates, c, c0, dz, dz_T, dh0=None, dc0=None):
+def lstm_seq_bwd_workspace(B, units, device):
+    return torch.empty(_lib.load().mnn_lstm_seq_bwd_workspace_bytes(B, units), dtype=torch.uint8, device=device)
+
+
+def lstm_seq_bwd(dh_ext, wh_p, gates, c, c0, dz, dz_T, dh0=None, dc0=None, t_begin=0, t_end=None, ws=None):
     T, B, units = dh_ext.shape
     N4 = 4 * units
     _req(dh_ext.dtype == torch.float32 and dh_ext.is_contiguous(), "lstm_bwd: dh_ext f32 [T,B,u]")
@@ -158,30 +165,34 @@ def lstm_seq_bwd(dh_ext, wh_p, gates, c, c0, dz, dz_T, dh0=None, dc0=None):
         _req(dz.shape == (T, B, N4) and dz.dtype == torch.float32 and dz.is_contiguous(), "lstm_bwd: dz f32 [T,B,4u]")
     if dz_T is not None:
         _req(dz_T.shape == (T, B, N4) and dz_T.dtype == wh_p.dtype and dz_T.is_contiguous(), "lstm_bwd: dz_T")
-    ws = torch.empty(_lib.load().mnn_lstm_seq_bwd_workspace_bytes(B, units), dtype=torch.uint8, device=dh_ext.device)
-    call("mnn_lstm_seq_bwd", _stream(), dtype_code(wh_p), T, B, units, _ptr(dh_ext), _ptr(wh_p), _ptr(gates), _ptr(c), _ptr(c0), _ptr(dz),
-         _ptr(dz_T), _ptr(dh0), _ptr(dc0), _ptr(ws))
+    t_end = T if t_end is None else t_end
+    _req(0 <= t_begin < t_end <= T, "lstm_bwd: bad step range")
+    if ws is None:
+        _req(t_begin == 0 and t_end == T, "lstm_bwd: chunked calls must share a workspace (lstm_seq_bwd_workspace)")
+        ws = lstm_seq_bwd_workspace(B, units, dh_ext.device)
+    call("mnn_lstm_seq_bwd", _stream(), dtype_code(wh_p), T, B, units, int(t_begin), int(t_end), _ptr(dh_ext), _ptr(wh_p), _ptr(gates),
+         _ptr(c), _ptr(c0), _ptr(dz), _ptr(dz_T), _ptr(dh0), _ptr(dc0), _ptr(ws))
 
 
 def _step_ok(step_dev):
     _req(step_dev is None or (step_dev.dtype == torch.int32 and step_dev.numel() == 1), "step_dev must be a device int32 scalar")
 
 
-def dropout_fwd(h, y, keep_prob, seed, row0, layer, step_dev=None):
+def dropout_fwd(h, y, keep_prob, seed, row0, layer, step_dev=None, t_offset=0):
     T, B, u = h.shape
     _req(h.is_contiguous() and y.is_contiguous() and h.shape == y.shape and h.dtype == y.dtype and u % 4 == 0, "dropout_fwd: shapes")
     _step_ok(step_dev)
     call("mnn_dropout_fwd", _stream(), dtype_code(h), _ptr(h), _ptr(y), T, B, u, float(keep_prob), int(seed), _ptr(step_dev), int(row0),
-         int(layer))
+         int(layer), int(t_offset))
 
 
-def dropout_bwd(dy, dh, keep_prob, seed, row0, layer, accumulate=False, step_dev=None):
+def dropout_bwd(dy, dh, keep_prob, seed, row0, layer, accumulate=False, step_dev=None, t_offset=0):
     T, B, u = dy.shape
     _req(dy.dtype == torch.float32 and dh.dtype == torch.float32 and dy.is_contiguous() and dh.is_contiguous() and dy.shape == dh.shape,
          "dropout_bwd: f32 [T,B,u]")
     _step_ok(step_dev)
     call("mnn_dropout_bwd", _stream(), _ptr(dy), _ptr(dh), T, B, u, float(keep_prob), int(seed), _ptr(step_dev), int(row0), int(layer),
-         int(accumulate))
+         int(accumulate), int(t_offset))
 
 
 # ------------------------------------------------------------------------------------------------

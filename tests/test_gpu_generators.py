@@ -287,6 +287,23 @@ def test_save_load_roundtrip(tmp_path):
     assert l1 == l2
 
 
+def test_wavefront_pipelining_matches_sequential():
+    """Layers as a wavefront on separate streams (chunked seq calls + events) give the same step."""
+    from multinn_amd import RnnNade, AdamOptimizer
+    from multinn_amd.generators import LstmStack
+    x = make_batch(6, 40, 8, 2, 9, rho=0.2)
+    a = RnnNade(16, 16, [128, 128], keep_prob=0.9, precision="bf16", seed=3)
+    b = RnnNade(16, 16, [128, 128], keep_prob=0.9, precision="bf16", seed=3)
+    a._materialize(16); b._materialize(16)
+    b.store.theta.copy_(a.store.theta)
+    b._stack.pipelined = True
+    opt = AdamOptimizer(0.01)
+    la = [float(a.train_step(dev(x), None, opt)) for _ in range(3)]
+    lb = [float(b.train_step(dev(x), None, opt)) for _ in range(3)]
+    assert np.allclose(la, lb, rtol=1e-3), (la, lb)
+    assert torch.allclose(a.store.theta, b.store.theta, atol=1e-3)
+
+
 def test_graphed_train_step_matches_eager():
     from multinn_amd import RnnNade, AdamOptimizer
     x = make_batch(8, 6, 8, 2, 7, rho=0.2)

@@ -194,6 +194,29 @@ def test_lstm_layer_fwd_bwd(ops, dt, B, T, n_in, u):
     assert rel(dx.view(T, B, n_in).cpu().numpy().transpose(1, 0, 2), dx_ref) < tol * 3
 
 
+def test_lstm_chunked_calls_equal_full_sequence(ops):
+    B, T, n_in, u = 20, 7, 8, 128
+    x, W, b, (wx_t, wh_t, wh_p, wx_p, bias_p), xin, tdt = _lstm_setup(ops, B, T, n_in, u, "bf16", seed=8)
+    xproj = torch.empty((T, B, 4 * u), device=DEV)
+    ops.gemm_tn(xin.view(T * B, -1), wx_t, xproj.view(T * B, -1), bias=bias_p)
+    mk = lambda: (torch.zeros((T, B, 4 * u), device=DEV), torch.zeros((T, B, u), device=DEV), torch.zeros((T, B, u), device=DEV, dtype=tdt))
+    g1, c1, h1 = mk(); g2, c2, h2 = mk()
+    ops.lstm_seq_fwd(xproj, wh_t, None, None, g1, c1, h1)
+    for t0, t1 in [(0, 3), (3, 4), (4, 7)]:
+        ops.lstm_seq_fwd(xproj, wh_t, None, None, g2, c2, h2, t0, t1)
+    assert torch.equal(h1, h2) and torch.equal(c1, c2) and torch.equal(g1, g2)
+    dy = dev(np.random.default_rng(1).standard_normal((T, B, u)).astype(np.float32))
+    dz1 = torch.zeros((T, B, 4 * u), device=DEV); dzb1 = torch.zeros((T, B, 4 * u), device=DEV, dtype=tdt)
+    dz2 = torch.zeros_like(dz1); dzb2 = torch.zeros_like(dzb1)
+    ops.lstm_seq_bwd(dy, wh_p, g1, c1, None, dz1, dzb1)
+    ws = ops.lstm_seq_bwd_workspace(B, u, DEV)
+    for t0, t1 in [(5, 7), (2, 5), (0, 2)]:
+        ops.lstm_seq_bwd(dy, wh_p, g1, c1, None, dz2, dzb2, None, None, t0, t1, ws)
+    assert torch.equal(dz1, dz2) and torch.equal(dzb1, dzb2)
+    with pytest.raises(ValueError):
+        ops.lstm_seq_bwd(dy, wh_p, g1, c1, None, dz2, dzb2, None, None, 2, 5)      # chunked call without a shared workspace
+
+
 def test_lstm_initial_state_and_dh0(ops):
     B, T, n_in, u = 9, 3, 8, 32
     x, W, b, (wx_t, wh_t, wh_p, wx_p, bias_p), xin, tdt = _lstm_setup(ops, B, T, n_in, u, "f32", seed=5)
@@ -235,6 +258,9 @@ def test_dropout_matches_contract(ops):
     y3 = torch.empty((T, B, u), device=DEV)
     ops.dropout_fwd(dev(h), y3, 0.9, seed=20, row0=100, layer=1, step_dev=torch.tensor([3], device=DEV, dtype=torch.int32))
     assert torch.equal(y3, y)
+    y4 = torch.empty((T - 1, B, u), device=DEV)
+    ops.dropout_fwd(dev(h[1:]), y4, 0.9, seed=23, row0=100, layer=1, t_offset=1)       # chunk starting at t = 1
+    assert torch.equal(y4, y[1:])
     assert np.allclose(dh.cpu().numpy(), 1 + h / np.float32(0.9) * keep, rtol=1e-6)
     y2 = torch.empty((T, B, u), device=DEV)
     ops.dropout_fwd(dev(h), y2, 1.0, 23, 100, 1)
