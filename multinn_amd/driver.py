@@ -1,0 +1,234 @@
+"""train.py:138-282 counterpart: the batching / windowing loop, loss accumulation,
+best/last checkpoint policy and early stopping around ``Generator.train_step``.
+
+Same YAML keys as multinn/configs/default_config.yaml / default_params.yaml and the same CLI flags as
+train.py:287-329 (``python -m multinn_amd.driver -m NAME -c CONFIG -p PARAMS``).  Only the joint mode
+with a NADE generator is wired (the hot path); other modes raise NotImplementedError.
+"""
+import argparse
+import math
+import os
+import pickle
+import sys
+import time
+
+import numpy as np
+
+
+class LossAccumulator:
+    """utils/training.py:98-148: mean loss omitting NaN / +-inf values (which are counted)."""
+
+    def __init__(self):
+        self.clear()
+
+    def clear(self):
+        self._sum_loss, self._num_loss, self._num_nan, self._num_posinf, self._num_neginf, self._num_total = 0.0, 0, 0, 0, 0, 0
+
+    def update(self, loss):
+        self._num_total += 1
+        if np.isnan(loss):
+            self._num_nan += 1
+        elif np.isposinf(loss):
+            self._num_posinf += 1
+        elif np.isneginf(loss):
+            self._num_neginf += 1
+        else:
+            self._num_loss += 1
+            self._sum_loss += loss
+
+    def loss(self):
+        return self._sum_loss / self._num_loss if self._num_loss > 0 else float("nan")
+
+    def num_bad(self):
+        return self._num_nan + self._num_posinf + self._num_neginf
+
+    def ratio_bad(self):
+        return self.num_bad() / self._num_total
+
+    def __str__(self):
+        return (f" - loss: {self.loss():7.3f} (nan: {self._num_nan}, +inf: {self._num_posinf}, -inf: {self._num_neginf}, "
+                f"bad: {100. * self.ratio_bad():.2f}%)")
+
+
+class TrainingStats:
+    """utils/training.py:12-95: (steps, epoch, run, metric_best) pickled next to the checkpoint."""
+
+    def __init__(self):
+        self.steps, self.epoch, self.run, self.metric_best, self.idle_epochs = 0, 0, 1, float("inf"), 0
+
+    def new_step(self):
+        self.steps += 1
+
+    def new_epoch(self):
+        self.epoch += 1
+
+    def new_idle_epoch(self):
+        self.idle_epochs += 1
+
+    def reset_idle_epochs(self):
+        self.idle_epochs = 0
+
+    def update_metric_best(self, m):
+        self.metric_best = m
+
+    def save(self, path):
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        with open(path, "wb") as f:
+            pickle.dump((self.steps, self.epoch, self.run, self.metric_best), f)
+
+    def load(self, path):
+        if not os.path.exists(path):
+            return False
+        with open(path, "rb") as f:
+            self.steps, self.epoch, self.run, self.metric_best = pickle.load(f)
+        self.run += 1
+        return True
+
+
+def iter_windows(ids, lengths, T_total, batch_size, piece_size):
+    """train.py:164-173: for every batch of shuffled song ids and every piece of ``piece_size`` steps yield
+    (song_ids, j, max_length, clipped_lengths) for the songs that still have steps (empty songs dropped)."""
+    lengths = np.asarray(lengths)
+    for i in range(0, len(ids), batch_size):
+        batch = ids[i:i + batch_size]
+        for j in range(0, T_total, piece_size):
+            len_batch = lengths[batch] - j
+            non_empty = np.where(len_batch > 0)[0]
+            if len(non_empty) > 0:
+                lb = np.minimum(len_batch[non_empty], piece_size)
+                yield batch[non_empty], j, int(lb.max()), lb.astype(np.int32)
+        yield None                                    # end of a song batch: stats.new_step() (train.py:194)
+
+
+def train_epoch(generator, X, lengths, ids, batch_size, piece_size, optimizer, loss_accum, stats, lr=None, device=None):
+    """One epoch of train.py:164-194.  X uint8 [S,T,P,M] (numpy); every window starts from a ZERO rnn state."""
+    import torch
+    for w in iter_windows(ids, lengths, X.shape[1], batch_size, piece_size):
+        if w is None:
+            stats.new_step()
+            continue
+        song_ids, j, max_len, len_batch = w
+        xb = torch.from_numpy(np.ascontiguousarray(X[song_ids, j:j + max_len])).to(device or "cuda")
+        full = bool((len_batch == max_len).all())
+        loss = generator.train_step(xb, None if full else torch.from_numpy(len_batch).to(xb.device), optimizer, lr)
+        loss_accum.update(float(loss))
+    return loss_accum.loss()
+
+
+def evaluate(generator, X, lengths, batch_size, piece_size, device=None):
+    """utils/training.py:180-213 collect_metrics: mean generator NLL per valid row over all windows."""
+    import torch
+    tot, cnt = 0.0, 0
+    ids = np.arange(X.shape[0])
+    for w in iter_windows(ids, lengths, X.shape[1], batch_size, piece_size):
+        if w is None:
+            continue
+        song_ids, j, max_len, len_batch = w
+        xb = torch.from_numpy(np.ascontiguousarray(X[song_ids, j:j + max_len])).to(device or "cuda")
+        full = bool((len_batch == max_len).all())
+        generator.build_pianoroll(xb, None if full else torch.from_numpy(len_batch).to(xb.device), is_train=False, mode="eval")
+        n = int(len_batch.sum())
+        tot += float(generator.metrics["batch/loss"]) * n
+        cnt += n
+    return tot / max(cnt, 1)
+
+
+def fit(generator, optimizer, X_train, len_train, X_valid, len_valid, training_config, logs_config, dirs, stats=None, beat_size=4,
+        save_best_only=False, log=print):
+    """train.py:150-282: epochs, shuffling (np.random.seed(epoch)), evaluation, best / last checkpoints,
+    early stopping after ``early_stopping`` idle epochs."""
+    stats = stats or TrainingStats()
+    batch_size = training_config["batch_size"]
+    piece_size = int(training_config["piece_size"] * beat_size)
+    ids = np.arange(X_train.shape[0])
+    acc = LossAccumulator()
+    past = stats.epoch
+    for epoch in range(past + 1, past + training_config["epochs"] + 1):
+        stats.new_epoch()
+        np.random.seed(epoch)
+        t0 = time.time()
+        np.random.shuffle(ids)
+        acc.clear()
+        train_epoch(generator, X_train, len_train, ids, batch_size, piece_size, optimizer, acc, stats, training_config.get("learning_rate"))
+        loglik_val = evaluate(generator, X_valid, len_valid, batch_size, piece_size) if logs_config.get("evaluate_epochs", 1) else acc.loss()
+        log(f" epoch: {epoch:3d} (steps: {stats.steps:5d}) time: {time.time() - t0:.2f}s{acc} valid nll: {loglik_val:.4f}")
+        if loglik_val < stats.metric_best:
+            stats.update_metric_best(loglik_val)
+            stats.reset_idle_epochs()
+            if logs_config.get("save_checkpoint_epochs", 1) > 0 and epoch % logs_config.get("save_checkpoint_epochs", 1) == 0:
+                generator.save(None, dirs["model_dir"], global_step=stats.steps)
+                stats.save(os.path.join(dirs["model_dir"], "steps"))
+        else:
+            stats.new_idle_epoch()
+            if stats.idle_epochs >= training_config["early_stopping"]:
+                log(f"[WARN]  No improvement after {training_config['early_stopping']} epochs, quiting")
+                break
+    if not save_best_only:
+        generator.save(None, dirs["model_last_dir"], global_step=stats.steps)
+        stats.save(os.path.join(dirs["model_last_dir"], "steps"))
+    return stats
+
+
+def build_generator(params, P, M, precision="bf16", seed=23):
+    """multinn_joint.py:41-74 for `mode: joint`, `encoder.type: Pass`, `generator.type: NADE|RBM`."""
+    from .generators import RnnNade, RnnRBM
+    if params.get("mode", "joint") != "joint":
+        raise NotImplementedError("only `mode: joint` is wired into the driver (the hot path); the other modes are composed from the "
+                                  "same Generator/Encoder classes")
+    if (params.get("encoder") or {}).get("type", "Pass") != "Pass":
+        raise NotImplementedError("joint mode with a non-Pass encoder")
+    g = params["generator"]
+    cls = {"NADE": RnnNade, "RBM": RnnRBM}[g["type"]]
+    return cls(P * M, g["num_hidden"], g["num_hidden_rnn"], keep_prob=params.get("keep_prob", 0.9), precision=precision, seed=seed)
+
+
+def main(argv=None):
+    import yaml
+    ap = argparse.ArgumentParser(description="MultINN joint LSTM-NADE training on MI355X (flags of multinn/train.py)")
+    ap.add_argument("--model-name", "-m", required=True)
+    ap.add_argument("--config", "-c", default="configs/default_config.yaml")
+    ap.add_argument("--params", "-p", default="configs/default_params.yaml")
+    ap.add_argument("--epochs", "-e", type=int, default=None)
+    ap.add_argument("--learning-rate", "--lr", type=float, default=None)
+    ap.add_argument("--from-init", action="store_true")
+    ap.add_argument("--from-last", action="store_true")
+    ap.add_argument("--encoders", default=None)
+    ap.add_argument("--save-best-only", action="store_true")
+    ap.add_argument("--reuse-config", action="store_true")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    a = ap.parse_args(argv)
+    from .training import AdamOptimizer
+    root = os.path.join("..", "results", a.model_name)                  # utils/setup.py:50
+    dirs = dict(model_dir=os.path.join(root, "ckpt", "model"), model_last_dir=os.path.join(root, "ckpt", "model", "last"),
+                config_dir=os.path.join(root, "config"))
+    if a.reuse_config:
+        a.config, a.params = os.path.join(dirs["config_dir"], "config.yaml"), os.path.join(dirs["config_dir"], "params.yaml")
+    config, params = yaml.safe_load(open(a.config)), yaml.safe_load(open(a.params))
+    if a.epochs is not None:
+        config["training"]["epochs"] = a.epochs
+    if a.learning_rate is not None:
+        config["training"]["learning_rate"] = a.learning_rate
+    os.makedirs(dirs["config_dir"], exist_ok=True)
+    yaml.safe_dump(config, open(os.path.join(dirs["config_dir"], "config.yaml"), "w"))
+    yaml.safe_dump(params, open(os.path.join(dirs["config_dir"], "params.yaml"), "w"))
+    d, tr = config["data"], config["training"]
+    X = np.load(d["filename"] if d["filename"].endswith(".npy") else d["filename"] + ".npy").astype(np.uint8)
+    npx = tr.get("num_pixels", 1)
+    if npx > 1:                                                            # utils/data.py:71-79
+        S, T, P, M = X.shape
+        X = X[:, :T // npx * npx].reshape(S, T // npx, npx, P, M).transpose(0, 1, 3, 2, 4).reshape(S, T // npx, P * npx, M)
+    lengths = np.full(X.shape[0], X.shape[1], np.int64) if not d.get("sequence_lengths") else np.load(d["sequence_lengths"]) // npx
+    nt, nv = d["split"]["num_train"], d["split"]["num_valid"]
+    gen = build_generator(params, X.shape[2], X.shape[3], a.precision, tr["random_seed"])
+    gen._materialize(X.shape[2] * X.shape[3])
+    stats = TrainingStats()
+    if not a.from_init:
+        src = dirs["model_last_dir"] if a.from_last else dirs["model_dir"]
+        if gen.load(None, src):
+            stats.load(os.path.join(src, "steps"))
+    fit(gen, AdamOptimizer(tr["learning_rate"]), X[:nt], lengths[:nt], X[nt:nt + nv], lengths[nt:nt + nv], tr, config["logs"], dirs, stats,
+        beat_size=d["beat_resolution"] / npx, save_best_only=a.save_best_only)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,84 @@
+"""Feedback-RNN sampling scan: multinn_feedback.py:120-218 with the recurrent feedback
+module of multinn_feedback_rnn.py:41-79.  Composition of the per-track RnnNade generators and one more
+LSTM stack, all running through the same C-ABI kernels."""
+import torch
+
+from . import ops
+from .common import Model, RNN, ParamStore
+from .generators import LstmStack, _compute_dtype
+
+
+class FeedbackRnn(Model):
+    """The Feedback module: RNN(num_units) over the stacked per-track codes (multinn_feedback_rnn.py:30-79)."""
+
+    def __init__(self, num_inputs, num_units, keep_prob=1.0, precision="bf16", seed=23, device=None, name="feedback"):
+        super().__init__(name=name)
+        self.dtype = _compute_dtype(precision)
+        self._rnn = RNN(num_units=num_units, keep_prob=keep_prob)
+        self.store = ParamStore(device)
+        self._rnn.declare(self.store, num_inputs, torch.Generator().manual_seed(seed), prefix="feedback/rnn")
+        self.store.materialize()
+        self._stack = LstmStack(self._rnn, self.store, self.dtype)
+        self._rnn.build_cell(False)
+        self.num_inputs, self.num_units = num_inputs, list(self._rnn.num_units)
+        self._is_built = True
+
+    def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None):
+        return [], [], None
+
+    def _tm(self, x):
+        B, T, Din = x.shape
+        out = torch.zeros((T, B, self._stack.ld0), device=x.device, dtype=self.dtype)
+        out[:, :, :Din] = x.transpose(0, 1).to(self.dtype)
+        return out
+
+    def run(self, x, initial_state=None):
+        """_apply_feedback(single_step=False): x [B,T,Din] -> (outputs [B,T,F] f32, final_state)."""
+        self._stack.pack()
+        y, _, final = self._stack.forward(self._tm(x), 1.0, save=False, state0=initial_state)
+        return y.transpose(0, 1).float(), [(c.clone(), h.clone()) for c, h in final]
+
+    def single(self, x, state):
+        """_apply_feedback(single_step=True): x [B,Din] -> (output [B,F] f32, new_state)."""
+        xin = torch.zeros((x.shape[0], self._stack.ld0), device=x.device, dtype=self.dtype)
+        ops.convert2d(x.contiguous(), xin[:, :x.shape[1]])
+        h, new = self._stack.single_step(xin, state)
+        return h.float(), [(c.clone(), hh.clone()) for c, hh in new]
+
+
+class FeedbackRnnSampler:
+    """MultINNFeedback.generate (multinn_feedback.py:120-173) with PassEncoders: M per-track generators whose
+    inputs are concat(track code, feedback vector)."""
+
+    def __init__(self, generators, feedback):
+        self.generators, self.feedback = generators, feedback
+        self.num_tracks = len(generators)
+
+    def generate(self, x_u8, num_steps):
+        """x_u8 [B,Ti,P,M] intro piano-rolls -> samples u8 [B,num_steps,P,M]."""
+        B, Ti, P, M = x_u8.shape
+        assert M == self.num_tracks
+        dev = x_u8.device
+        enc = torch.cat([torch.zeros((B, 1, P, M), device=dev, dtype=torch.uint8), x_u8], 1)      # multi_encoder_nn.py:73-76
+        stack = enc.reshape(B, Ti + 1, P * M)                                                       # feature p*M+m (stack axis 3 + reshape)
+        x_fb, fb_state = self.feedback.run(stack)
+        states = []
+        for i, g in enumerate(self.generators):
+            g._materialize(P + x_fb.shape[-1])
+            g._rnn.build_cell(False)
+            g._ensure_packed()
+            states.append(g.steps(torch.cat([enc[..., i].float(), x_fb], -1)))                      # multinn_feedback.py:143-149
+        out = torch.empty((B, num_steps, P, M), device=dev, dtype=torch.uint8)
+        for s in range(num_steps):                                                                  # _feedback_recurrence (175-218)
+            samples = []
+            for i, g in enumerate(self.generators):
+                g._gen_step = s
+                g._last_dense = states[i].dense
+                smp, _ = g.sample_single(None, states[i])
+                samples.append(smp)
+            st = torch.stack(samples, -1)                                                           # [B,P,M]
+            out[:, s] = st
+            fb, fb_state = self.feedback.single(st.reshape(B, P * M), fb_state)
+            for i, g in enumerate(self.generators):
+                states[i] = g.single_step(torch.cat([samples[i].float(), fb], 1), states[i])
+        return out

@@ -22,8 +22,9 @@ _RnnEstimatorStateTuple = collections.namedtuple("RnnEstimatorStateTuple", ("b_e
 
 
 class RnnEstimatorStateTuple(_RnnEstimatorStateTuple):
-    """rnn_estimator.py:12-36."""
-    __slots__ = ()
+    """rnn_estimator.py:12-36.  `dense` (not in the reference) keeps the [b_enc | b_dec] matrix the biases are
+    views of, so the sampling kernel can take it without a copy."""
+    dense = None
 
     @property
     def dtype(self):
@@ -601,6 +602,7 @@ class RnnNade(RnnEstimator):
     def _state_from_dense(self, out, rnn_state):
         be, bd = self._build_biases(out)
         st = RnnEstimatorStateTuple(be, bd, rnn_state)
+        st.dense = out
         self._last_dense = out
         return st
 
@@ -636,7 +638,7 @@ class RnnNade(RnnEstimator):
     def sample_single(self, inputs, state, temperature=1.0):
         """rnn_nade.py:304-318 / rnn_multinade.py:295-317: returns (sample u8 [B,num_output], nll)."""
         M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
-        out = self._last_dense
+        out = state.dense if getattr(state, "dense", None) is not None else self._last_dense
         Bn = out.shape[0]
         smp = torch.empty((Bn, M * D), device=out.device, dtype=torch.uint8)
         nll = torch.empty((M, Bn), device=out.device)

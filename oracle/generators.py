@@ -317,3 +317,70 @@ def rnn_rbm_backward(fw, p):
                                                 np.broadcast_to(p['bv'], fw['bv_t'].shape), rw)
         g['W'], g['bh'], g['bv'] = dW, dbh.sum(0, keepdims=True), dbv.sum(0, keepdims=True)
     return g
+
+
+# --------------------------------------------------------------------------- #
+# Feedback-RNN sampling scan (multinn_feedback.py:120-218, multinn_feedback_rnn.py:41-79), A19
+# --------------------------------------------------------------------------- #
+def feedback_rnn_generate(x, num_steps, gen_params, fb_layers, seeds, row0=0):
+    """x [B,Ti,P,M] -> samples [B,num_steps,P,M].  gen_params[i]: RnnNade params with n_in = P+F;
+    fb_layers: feedback LSTM layers over P*M inputs; seeds[i]: RNG seed of generator i
+    (uniforms: stream 1, row = global batch index, sub = step, elem = visible)."""
+    B, Ti, P, M = x.shape
+    dt = gen_params[0]['fc_k'].dtype
+    enc = np.concatenate([np.zeros((B, 1, P, M), dt), x.astype(dt)], axis=1)
+    stack = enc.reshape(B, Ti + 1, P * M)
+    x_fb, fb_state, _ = lstm.seq_fwd(stack, fb_layers)
+    Hn = gen_params[0]['w_enc'][0].shape[1]
+    states, outs = [], []
+    for i, p in enumerate(gen_params):
+        y, st, _ = lstm.seq_fwd(np.concatenate([enc[..., i], x_fb], -1), p['lstm'])
+        states.append(st)
+        outs.append(dense(y[:, -1], p['fc_k'], p['fc_b']))
+    rows = np.arange(row0, row0 + B, dtype=np.uint32)
+    samples = np.empty((B, num_steps, P, M), dt)
+    probs = np.empty((B, num_steps, P, M), dt)
+    for s in range(num_steps):
+        cur = []
+        for i, p in enumerate(gen_params):
+            b_enc, b_dec = split_biases(outs[i], Hn, P, 1)
+            u = philox.uniform_block(seeds[i], philox.STREAM_NADE, rows, s, P)
+            smp, _ = nade.sample(b_enc[0], b_dec[0], p['w_enc'][0], p['w_dec'][0], u, 1.0)
+            _, cp = nade.log_prob(smp, b_enc[0], b_dec[0], p['w_enc'][0], p['w_dec'][0])
+            probs[:, s, :, i] = cp
+            cur.append(smp)
+        st = np.stack(cur, -1)
+        samples[:, s] = st
+        fb, fb_state = lstm_single_step(st.reshape(B, P * M), fb_state, fb_layers)
+        for i, p in enumerate(gen_params):
+            h, states[i] = lstm_single_step(np.concatenate([cur[i], fb], 1), states[i], p['lstm'])
+            outs[i] = dense(h, p['fc_k'], p['fc_b'])
+    return samples, probs
+
+
+def feedback_rnn_teacher_forced(x, samples, gen_params, fb_layers, seeds, row0=0):
+    """Replay the scan on GIVEN samples: returns (probs, uniforms) so a device scan can be verified draw by draw."""
+    B, Ti, P, M = x.shape
+    dt = gen_params[0]['fc_k'].dtype
+    enc = np.concatenate([np.zeros((B, 1, P, M), dt), x.astype(dt)], axis=1)
+    x_fb, fb_state, _ = lstm.seq_fwd(enc.reshape(B, Ti + 1, P * M), fb_layers)
+    Hn = gen_params[0]['w_enc'][0].shape[1]
+    states, outs = [], []
+    for i, p in enumerate(gen_params):
+        y, st, _ = lstm.seq_fwd(np.concatenate([enc[..., i], x_fb], -1), p['lstm'])
+        states.append(st)
+        outs.append(dense(y[:, -1], p['fc_k'], p['fc_b']))
+    rows = np.arange(row0, row0 + B, dtype=np.uint32)
+    S = samples.shape[1]
+    probs, us = np.empty((B, S, P, M), dt), np.empty((B, S, P, M), np.float32)
+    for s in range(S):
+        cur = [samples[:, s, :, i].astype(dt) for i in range(M)]
+        for i, p in enumerate(gen_params):
+            b_enc, b_dec = split_biases(outs[i], Hn, P, 1)
+            _, probs[:, s, :, i] = nade.log_prob(cur[i], b_enc[0], b_dec[0], p['w_enc'][0], p['w_dec'][0])
+            us[:, s, :, i] = philox.uniform_block(seeds[i], philox.STREAM_NADE, rows, s, P)
+        fb, fb_state = lstm_single_step(np.stack(cur, -1).reshape(B, P * M), fb_state, fb_layers)
+        for i, p in enumerate(gen_params):
+            h, states[i] = lstm_single_step(np.concatenate([cur[i], fb], 1), states[i], p['lstm'])
+            outs[i] = dense(h, p['fc_k'], p['fc_b'])
+    return probs, us

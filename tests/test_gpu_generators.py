@@ -271,6 +271,51 @@ def test_rbm_cd_update_and_dbn_encoder():
     enc.train(None, 0.05, layer=1)
 
 
+def test_feedback_rnn_sampling_scan():
+    """C5 / A19: M per-track RnnNade generators + recurrent feedback module, teacher-forced replay check."""
+    from multinn_amd import RnnNade
+    from multinn_amd.feedback import FeedbackRnn, FeedbackRnnSampler
+    B, Ti, P, M, Hn, F, steps = 4, 3, 8, 3, 16, 32, 5
+    R = np.random.default_rng(14)
+    x = (R.random((B, Ti, P, M)) < .3).astype(np.uint8)
+    fb = FeedbackRnn(P * M, [64, F], precision="fp32", seed=40)
+    gens, gparams, seeds = [], [], []
+    for i in range(M):
+        g = RnnNade(P, Hn, [32, 32], precision="fp32", seed=50 + i)
+        g._materialize(P + F)
+        p = G.init_rnn_nade(60 + i, P + F, P, Hn, [32, 32], np.float64)
+        load_nade_params(g, p)
+        gens.append(g); gparams.append(p); seeds.append(50 + i)
+    fb_layers = [(fb.store[f"feedback/rnn/cell_{l}/kernel"].cpu().numpy().astype(np.float64),
+                  fb.store[f"feedback/rnn/cell_{l}/bias"].cpu().numpy().astype(np.float64)) for l in range(2)]
+    out = FeedbackRnnSampler(gens, fb).generate(dev(x), steps)
+    assert out.shape == (B, steps, P, M) and out.dtype == torch.uint8
+    got = out.cpu().numpy()
+    probs, us = G.feedback_rnn_teacher_forced(x, got, gparams, fb_layers, seeds)
+    bad = (us < probs) != (got > 0)
+    assert not (bad & (np.abs(us - probs) > 2e-5)).any()
+    ref, _ = G.feedback_rnn_generate(x, steps, gparams, fb_layers, seeds)
+    assert (ref == got).mean() > 0.99
+    assert torch.equal(out, FeedbackRnnSampler(gens, fb).generate(dev(x), steps))
+
+
+def test_driver_fit_and_checkpoints(tmp_path):
+    """A13: the train.py loop (windows, ragged lengths, best/last checkpoints) on a tiny synthetic set."""
+    from multinn_amd import RnnNade, AdamOptimizer
+    from multinn_amd.driver import fit, TrainingStats
+    R = np.random.default_rng(3)
+    X = (R.random((12, 16, 8, 2)) < .15).astype(np.uint8)
+    lengths = np.array([16, 16, 9, 16, 4, 16, 16, 12, 16, 16, 16, 7])
+    gen = RnnNade(16, 16, [32], keep_prob=0.9, precision="fp32", seed=1)
+    dirs = dict(model_dir=str(tmp_path / "best"), model_last_dir=str(tmp_path / "last"))
+    cfg = dict(epochs=3, batch_size=4, piece_size=2, early_stopping=5, learning_rate=0.02)
+    stats = fit(gen, AdamOptimizer(0.02), X[:8], lengths[:8], X[8:], lengths[8:], cfg, dict(evaluate_epochs=1, save_checkpoint_epochs=1),
+                dirs, TrainingStats(), beat_size=4, log=lambda *_: None)
+    assert stats.epoch == 3 and stats.steps == 6                      # steps count song batches, not pieces (train.py:194)
+    assert (tmp_path / "best" / "rnn-nade.pt").exists() and (tmp_path / "last" / "rnn-nade.pt").exists()
+    assert stats.metric_best < float("inf")
+
+
 def test_save_load_roundtrip(tmp_path):
     from multinn_amd import RnnNade, AdamOptimizer
     x = make_batch(4, 4, 4, 2, 3)
