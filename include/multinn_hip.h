@@ -104,8 +104,10 @@ int mnn_lstm_unpack_grads(mnn_stream_t s, const float* dwx_t, const float* dwh_t
  *   gates f32 [T,B,4u] (post-activation i,g,f,o; saved for backward; may be NULL for inference)
  *   c f32 [T,B,u], h T [T,B,u]
  * Replaces: dynamic_decode/dynamic_rnn over the cell -- rnn_nade.py:204-218, rnn_rbm.py:217-223. */
+/* hT (optional, T dtype [u, ld_hT], ld_hT >= T*B): transposed PREVIOUS-state operand of the recurrent
+ * weight gradient, hT[:, (t+1)*B + b] = h[t, b, :] for t < T-1 (columns [0,B) are the caller's h0^T). */
 int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int units, int t_begin, int t_end, const float* xproj,
-                     const void* wh_t, const void* h0, const float* c0, float* gates, float* c, void* h);
+                     const void* wh_t, const void* h0, const float* c0, float* gates, float* c, void* h, void* hT, int ld_hT);
 
 /* BPTT for one layer over steps [t_begin, t_end), processed downwards; successive calls must cover
  * the sequence from the top range to 0 and share `workspace` (it carries d c between calls).
@@ -113,9 +115,14 @@ int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int units, int t_b
  * pre-activation gradient), dh0/dc0 f32 [B,u] out with the t_begin == 0 call (may be NULL).
  * workspace: mnn_lstm_seq_bwd_workspace_bytes(B, units). */
 size_t mnn_lstm_seq_bwd_workspace_bytes(int B, int units);
+/* dzT_t (optional, T dtype [4u, ld_t], ld_t >= T*B): transposed dz, dzT_t[col, t*B + b] = dz[t, b, col] (the
+ * K-contiguous operand of both weight-gradient GEMMs); db_p (optional f32 [4u]): += sum over rows of dz.
+ * The bf16 step kernels (units 128/256/512) produce both in their epilogue; then dz (f32) may be NULL. */
+int mnn_lstm_fused_outputs(int dtype, int units);   /* 1 if the step kernels emit hT / dzT_t / db_p themselves */
 int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int units, int t_begin, int t_end, const float* dh_ext,
                      const void* wh_p, const float* gates, const float* c, const float* c0, float* dz,
-                     void* dz_T /* T copy of dz or NULL */, float* dh0, float* dc0, void* workspace);
+                     void* dz_T /* T copy of dz or NULL */, float* dh0, float* dc0, void* workspace, void* dzT_t, int ld_t,
+                     float* db_p);
 
 /* Output dropout of DropoutWrapper (rnn.py:132): y = h/kp * floor(kp+u), u = Philox(stream 0,
  * row = row0+b, sub = (t<<8)|layer, elem = unit).  h,y T [T,B,u].  kp>=1 -> copy.

@@ -405,8 +405,9 @@ template <int KS>
 __global__ void __launch_bounds__(256)
 lstm_fwd_step_v2(const bf16_t* __restrict__ h_prev, const bf16_t* __restrict__ wh_t, const float* __restrict__ xproj,
                  const float* __restrict__ c_prev, float* __restrict__ gates, float* __restrict__ c_out, bf16_t* __restrict__ h_out,
-                 int B, int U) {
+                 int B, int U, bf16_t* __restrict__ hT, int ld_hT, int colT) {
     __shared__ float red[4][4][16][64];
+    __shared__ bf16_t sT[32][40];          // h tile, [unit][row] (+pad), for the transposed copy
     const int nt = blockIdx.x, m0 = blockIdx.y * 32, n0 = nt * 128, N4 = 4 * U;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -461,7 +462,23 @@ lstm_fwd_step_v2(const bf16_t* __restrict__ h_prev, const bf16_t* __restrict__ w
         const size_t zo = (size_t)row * N4 + n0 + col, uo = (size_t)row * U + unit;
         if (gates != nullptr) { gates[zo] = gi; gates[zo + 32] = gg; gates[zo + 64] = gf; gates[zo + 96] = go; }
         c_out[uo] = c;
-        h_out[uo] = f32_to_bf16(h);
+        const bf16_t hb = f32_to_bf16(h);
+        h_out[uo] = hb;
+        if (hT != nullptr) sT[col][8 * w + q + 4 * hh] = hb;
+    }
+    if (hT != nullptr) {                    // hT[unit][colT + row]: 32 units x 64-byte row segments (weight-gradient operand)
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int uu = threadIdx.x >> 2, piece = threadIdx.x & 3;
+            const int row = m0 + piece * 8;
+            bf16_t* dst = hT + (size_t)(nt * 32 + uu) * ld_hT + colT + row;
+            if (row + 8 <= B && (((size_t)(colT + row) & 7) == 0) && ((ld_hT & 7) == 0)) {
+                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sT[uu][piece * 8]);
+            } else {
+                for (int k = 0; k < 8; ++k)
+                    if (row + k < B) dst[k] = sT[uu][piece * 8 + k];
+            }
+        }
     }
 }
 
@@ -470,8 +487,9 @@ template <int KS>
 __global__ void __launch_bounds__(512)
 lstm_bwd_step_v2(const bf16_t* __restrict__ dz_next, const bf16_t* __restrict__ wh_p, const float* __restrict__ dh_ext,
                  const float* __restrict__ gates, const float* __restrict__ c_t, const float* __restrict__ c_prev, float* __restrict__ dc,
-                 float* __restrict__ dz, bf16_t* __restrict__ dzT, int B, int U, int first) {
+                 float* __restrict__ dz, bf16_t* __restrict__ dzT, int B, int U, int first, bf16_t* __restrict__ dzTt, int ld_t, int colT) {
     __shared__ float red[8][16][64];
+    __shared__ bf16_t sT[4][32][40];       // dz tile, [gate][unit][row] (+pad), for the transposed copy
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32, N4 = 4 * U;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -528,20 +546,62 @@ lstm_bwd_step_v2(const bf16_t* __restrict__ dz_next, const bf16_t* __restrict__ 
         const float dzo = d_o * go * (1.f - go);
         dc[uo] = d_c * gf;
         if (dz != nullptr) { dz[zo] = dzi; dz[zo + 32] = dzg; dz[zo + 64] = dzf; dz[zo + 96] = dzo; }
-        dzT[zo] = f32_to_bf16(dzi); dzT[zo + 32] = f32_to_bf16(dzg); dzT[zo + 64] = f32_to_bf16(dzf); dzT[zo + 96] = f32_to_bf16(dzo);
+        const bf16_t bi = f32_to_bf16(dzi), bg = f32_to_bf16(dzg), bff = f32_to_bf16(dzf), bo = f32_to_bf16(dzo);
+        dzT[zo] = bi; dzT[zo + 32] = bg; dzT[zo + 64] = bff; dzT[zo + 96] = bo;
+        if (dzTt != nullptr) {
+            const int lr = (i & 3) + 8 * (i >> 2) + 4 * hh;
+            sT[0][r][lr] = bi; sT[1][r][lr] = bg; sT[2][r][lr] = bff; sT[3][r][lr] = bo;
+        }
+    }
+    if (dzTt != nullptr) {
+        __syncthreads();
+        {                                    // dzT_t[pc + 32 g][colT + row]: 128 rows x 64-byte segments, one 16-byte piece per thread
+            const int gu = threadIdx.x >> 2, piece = threadIdx.x & 3;      // gu = g*32 + unit
+            const int g = gu >> 5, uu = gu & 31;
+            const int row = m0 + piece * 8;
+            bf16_t* dst = dzTt + (size_t)(gate_perm_col(g, n0 + uu)) * ld_t + colT + row;
+            if (row + 8 <= B && (((size_t)(colT + row) & 7) == 0) && ((ld_t & 7) == 0)) {
+                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sT[g][uu][piece * 8]);
+            } else {
+                for (int k = 0; k < 8; ++k)
+                    if (row + k < B) dst[k] = sT[g][uu][piece * 8 + k];
+            }
+        }
     }
 }
 
+// db_p[c] += sum over columns [c0, c1) of row c of dzT (contiguous bf16 rows): the LSTM bias gradient, one pass over the
+// transposed dz the step kernels already wrote (no per-step reduction on the latency-critical chain).
+__global__ void __launch_bounds__(256) rowsum_bf16_kernel(const bf16_t* __restrict__ X, int ld, int c0, int c1, float* __restrict__ out) {
+    __shared__ float part[4];
+    const bf16_t* row = X + (size_t)blockIdx.x * ld;
+    float acc = 0.f;
+    for (int c = c0 + threadIdx.x; c < c1; c += 256) acc += bf16_to_f32(row[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] += (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+extern "C" int mnn_transpose(mnn_stream_t s, const void* in, int in_dtype, int R, int C, int ld_in, void* out, int out_dtype, int ld_out);
+extern "C" int mnn_bias_grad(mnn_stream_t s, const float* dY, int rows, int cols, int ld, float* db, int accumulate);
+
+static bool lstm_v2_ok(int dtype, int units) { return dtype == MNN_BF16 && (units == 128 || units == 256 || units == 512); }
+extern "C" int mnn_lstm_fused_outputs(int dtype, int units) { return lstm_v2_ok(dtype, units) ? 1 : 0; }
+
 extern "C" int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int units, int t_begin, int t_end, const float* xproj,
-                                const void* wh_t, const void* h0, const float* c0, float* gates, float* c, void* h) {
+                                const void* wh_t, const void* h0, const float* c0, float* gates, float* c, void* h, void* hT, int ld_hT) {
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F32, "mnn_lstm_seq_fwd: dtype must be bf16 or f32");
     MNN_REQUIRE(T > 0 && B > 0 && units > 0 && units % 32 == 0, "mnn_lstm_seq_fwd: units must be a positive multiple of 32 (T=%d B=%d u=%d)",
                 T, B, units);
     MNN_REQUIRE(xproj && wh_t && c && h, "mnn_lstm_seq_fwd: null pointer");
     MNN_REQUIRE(0 <= t_begin && t_begin < t_end && t_end <= T, "mnn_lstm_seq_fwd: bad step range [%d,%d) of %d", t_begin, t_end, T);
+    MNN_REQUIRE(hT == nullptr || ld_hT >= T * B, "mnn_lstm_seq_fwd: ld_hT %d < T*B", ld_hT);
     const size_t esz = dtype == MNN_BF16 ? 2 : 4;
     dim3 grid(units / 32, cdiv(B, 64));
+    const bool v2 = lstm_v2_ok(dtype, units);
     for (int t = t_begin; t < t_end; ++t) {
         const float* xp = xproj + (size_t)t * B * 4 * units;
         float* gt = gates ? gates + (size_t)t * B * 4 * units : nullptr;
@@ -549,9 +609,10 @@ extern "C" int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int uni
         const float* cp = t == 0 ? c0 : c + (size_t)(t - 1) * B * units;
         char* ht = (char*)h + (size_t)t * B * units * esz;
         const char* hp = t == 0 ? (const char*)h0 : (const char*)h + (size_t)(t - 1) * B * units * esz;
-        if (dtype == MNN_BF16 && (units == 128 || units == 256 || units == 512)) {
+        if (v2) {
             dim3 g2(units / 32, cdiv(B, 32));
-#define FWD2(KS) hipLaunchKernelGGL(lstm_fwd_step_v2<KS>, g2, dim3(256), 0, st, (const bf16_t*)hp, (const bf16_t*)wh_t, xp, cp, gt, ct, (bf16_t*)ht, B, units)
+#define FWD2(KS) hipLaunchKernelGGL(lstm_fwd_step_v2<KS>, g2, dim3(256), 0, st, (const bf16_t*)hp, (const bf16_t*)wh_t, xp, cp, gt, ct, (bf16_t*)ht, B, units, \
+                                    (bf16_t*)(t + 1 < T ? hT : nullptr), ld_hT, (t + 1) * B)
             if (units == 512) FWD2(8); else if (units == 256) FWD2(4); else FWD2(2);
 #undef FWD2
         } else if (dtype == MNN_BF16)
@@ -562,6 +623,12 @@ extern "C" int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int uni
                                (float*)ht, B, units);
     }
     MNN_LAUNCH_CHECK();
+    if (hT != nullptr && !v2) {            // generic path: hT[:, (t+1)*B + b] = h[t, b, :] for the steps of this call
+        const int rows = (min(t_end, T - 1) - t_begin) * B;     // h[T-1] is nobody's previous state
+        if (rows > 0)
+            return mnn_transpose(s, (const char*)h + (size_t)t_begin * B * units * esz, dtype, rows, units, units,
+                                 (char*)hT + (size_t)(t_begin + 1) * B * esz, dtype, ld_hT);
+    }
     return MNN_OK;
 }
 
@@ -631,13 +698,16 @@ extern "C" size_t mnn_lstm_seq_bwd_workspace_bytes(int B, int units) { return (s
 
 extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int units, int t_begin, int t_end, const float* dh_ext,
                                 const void* wh_p, const float* gates, const float* c, const float* c0, float* dz, void* dz_T, float* dh0,
-                                float* dc0, void* workspace) {
+                                float* dc0, void* workspace, void* dzT_t, int ld_t, float* db_p) {
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F32, "mnn_lstm_seq_bwd: dtype must be bf16 or f32");
     MNN_REQUIRE(T > 0 && B > 0 && units > 0 && units % 32 == 0, "mnn_lstm_seq_bwd: units must be a positive multiple of 32");
     MNN_REQUIRE(dh_ext && wh_p && gates && c && workspace, "mnn_lstm_seq_bwd: null pointer");
     MNN_REQUIRE(dtype == MNN_F32 ? (dz != nullptr) : (dz_T != nullptr), "mnn_lstm_seq_bwd: dz (f32) / dz_T (bf16) output required");
     MNN_REQUIRE(0 <= t_begin && t_begin < t_end && t_end <= T, "mnn_lstm_seq_bwd: bad step range [%d,%d) of %d", t_begin, t_end, T);
+    MNN_REQUIRE(dzT_t == nullptr || ld_t >= T * B, "mnn_lstm_seq_bwd: ld_t %d < T*B", ld_t);
+    const bool v2 = lstm_v2_ok(dtype, units);
+    MNN_REQUIRE(v2 || db_p == nullptr || dz != nullptr, "mnn_lstm_seq_bwd: the generic path needs the f32 dz for the bias gradient");
     if (dtype == MNN_F32) dz_T = dz;
     const size_t esz = dtype == MNN_BF16 ? 2 : 4;
     float* dc = (float*)workspace;        // carried d c between calls: process [t_begin,t_end) from the top range downwards
@@ -651,10 +721,11 @@ extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int uni
         float* dzt = dz ? dz + (size_t)tt * zs : nullptr;
         char* dzTt = (char*)dz_T + (size_t)tt * zs * esz;
         float* dho = t < 0 ? dh0 : nullptr;
-        if (dtype == MNN_BF16 && t >= 0 && (units == 128 || units == 256 || units == 512)) {
+        if (v2 && t >= 0) {
             dim3 g2(units / 32, cdiv(B, 32));
 #define BWD2(KS) hipLaunchKernelGGL(lstm_bwd_step_v2<KS>, g2, dim3(512), 0, st, (const bf16_t*)dzn, (const bf16_t*)wh_p, dh_ext + (size_t)tt * us, \
-                                    gates + (size_t)tt * zs, c + (size_t)tt * us, cp, dc, dzt, (bf16_t*)dzTt, B, units, t == T - 1 ? 1 : 0)
+                                    gates + (size_t)tt * zs, c + (size_t)tt * us, cp, dc, dzt, (bf16_t*)dzTt, B, units, t == T - 1 ? 1 : 0,        \
+                                    (bf16_t*)dzT_t, ld_t, t * B)
             if (units == 512) BWD2(16); else if (units == 256) BWD2(8); else BWD2(4);
 #undef BWD2
         } else if (dtype == MNN_BF16)
@@ -668,5 +739,19 @@ extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int uni
     }
     MNN_LAUNCH_CHECK();
     if (t_begin == 0 && dc0 != nullptr) MNN_HIP(hipMemcpyAsync(dc0, dc, us * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (v2 && db_p != nullptr) {
+        MNN_REQUIRE(dzT_t != nullptr, "mnn_lstm_seq_bwd: db_p needs dzT_t on the fused path");
+        hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(4 * units), dim3(256), 0, st, (const bf16_t*)dzT_t, ld_t, t_begin * B, t_end * B, db_p);
+        MNN_LAUNCH_CHECK();
+    }
+    if (!v2) {                             // generic path: separate transpose / column-sum kernels for the steps of this call
+        const int rows = (t_end - t_begin) * B;
+        if (dzT_t != nullptr) {
+            int rc = mnn_transpose(s, (const char*)dz_T + (size_t)t_begin * zs * esz, dtype, rows, 4 * units, 4 * units,
+                                   (char*)dzT_t + (size_t)t_begin * B * esz, dtype, ld_t);
+            if (rc != MNN_OK) return rc;
+        }
+        if (db_p != nullptr) return mnn_bias_grad(s, dz + (size_t)t_begin * zs, rows, 4 * units, 4 * units, db_p, 1);
+    }
     return MNN_OK;
 }

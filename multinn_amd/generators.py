@@ -100,8 +100,13 @@ class LstmStack:
         for l, p in enumerate(self.packed):
             u = p["u"]
             h = torch.empty((T, B, u), device=dev, dtype=self.dtype)
+            hT = None
+            if save:                        # transposed previous-state operand of dWh, written by the step kernels
+                hT = torch.zeros((u, ops.round_up(T * B, 64)), device=dev, dtype=self.dtype)
+                if state0 is not None:
+                    ops.transpose(state0[l][1].to(self.dtype).contiguous(), hT[:, :B])
             bufs.append(dict(xproj=torch.empty((T, B, 4 * u), device=dev), gates=torch.empty((T, B, 4 * u), device=dev) if save else None,
-                             c=torch.empty((T, B, u), device=dev), h=h, y=torch.empty_like(h) if keep_prob < 1.0 else h,
+                             c=torch.empty((T, B, u), device=dev), h=h, y=torch.empty_like(h) if keep_prob < 1.0 else h, hT=hT,
                              c0=state0[l][0] if state0 is not None else None,
                              h0=state0[l][1].to(self.dtype) if state0 is not None else None))
         piped = self.pipelined and L > 1 and T > self.chunk
@@ -123,7 +128,7 @@ class LstmStack:
                             lane.wait_event(done[l - 1][ci])
                         inp = bufs[l - 1]["y"]
                         ops.gemm_tn(inp[t0:t1].view((t1 - t0) * B, -1), p["wx_t"], bf["xproj"][t0:t1].view((t1 - t0) * B, -1), bias=p["bias_p"])
-                    ops.lstm_seq_fwd(bf["xproj"], p["wh_t"], bf["h0"], bf["c0"], bf["gates"], bf["c"], bf["h"], t0, t1)
+                    ops.lstm_seq_fwd(bf["xproj"], p["wh_t"], bf["h0"], bf["c0"], bf["gates"], bf["c"], bf["h"], t0, t1, bf["hT"])
                     if keep_prob < 1.0:
                         ops.dropout_fwd(bf["h"][t0:t1], bf["y"][t0:t1], keep_prob, seed, row0, l, step_dev, t0)
                     if piped and l < L - 1:
@@ -134,7 +139,8 @@ class LstmStack:
         ctx = []
         if save:
             for l, bf in enumerate(bufs):
-                ctx.append(dict(inp=x_tm if l == 0 else bufs[l - 1]["y"], gates=bf["gates"], c=bf["c"], h=bf["h"], c0=bf["c0"], h0=bf["h0"]))
+                ctx.append(dict(inp=x_tm if l == 0 else bufs[l - 1]["y"], gates=bf["gates"], c=bf["c"], h=bf["h"], c0=bf["c0"], h0=bf["h0"],
+                                hT=bf["hT"]))
         final = [(bf["c"][-1], bf["h"][-1]) for bf in bufs]
         return bufs[-1]["y"], ctx, final
 
@@ -143,32 +149,23 @@ class LstmStack:
         tiles = -(-rows_out // 128) * -(-cols_out // 128)
         return int(max(1, min(1024 // max(tiles, 1), K // 1024)))
 
-    def _weight_grads(self, l, cx, dz, dzc, T, B):
-        """dWx^T[4u,ld] = dz^T . inp ; dWh^T[4u,u] = dz^T . h_prev ; db = sum dz  (reduction over the N rows)."""
+    def _weight_grads(self, l, cx, dzT, db_p, T, B):
+        """dWx^T[4u,ld] = dz^T . inp ; dWh^T[4u,u] = dz^T . h_prev  (reduction over the N rows); dzT [4u,Np] and
+        h_prev^T come straight from the step kernels, db_p from their epilogue."""
         p = self.packed[l]
         u, ld, n_in = p["u"], p["ld"], p["n_in"]
         N = T * B
-        Np = ops.round_up(N, 64)
-        dev = dz.device
-        zalloc = torch.zeros if Np != N else torch.empty
-        dzT = zalloc((4 * u, Np), device=dev, dtype=self.dtype)
-        ops.transpose(dzc.view(N, 4 * u), dzT)
-        inT = zalloc((ld, Np), device=dev, dtype=self.dtype)
+        Np = dzT.shape[1]
+        dev = dzT.device
+        inT = (torch.zeros if Np != N else torch.empty)((ld, Np), device=dev, dtype=self.dtype)
         ops.transpose(cx["inp"].view(N, ld), inT)
         dwx_t = torch.empty((4 * u, ld), device=dev)
         ops.gemm_tn(dzT, inT, dwx_t, split_k=self._split_k(4 * u, ld, Np))
-        hT = torch.zeros((u, Np), device=dev, dtype=self.dtype)
-        if cx["h0"] is not None:
-            ops.transpose(cx["h0"], hT[:, :B])
-        if T > 1:
-            ops.transpose(cx["h"][:-1].view((T - 1) * B, u), hT[:, B:N])
         dwh_t = torch.empty((4 * u, u), device=dev)
-        ops.gemm_tn(dzT, hT, dwh_t, split_k=self._split_k(4 * u, u, Np))
-        db_p = torch.empty(4 * u, device=dev)
-        ops.bias_grad(dz.view(N, 4 * u), db_p)
+        ops.gemm_tn(dzT, cx["hT"], dwh_t, split_k=self._split_k(4 * u, u, Np))
         ops.lstm_unpack_grads(dwx_t, dwh_t, db_p, n_in, u, self.store.gviews[f"{self.rnn.prefix}/cell_{l}/kernel"],
                               self.store.gviews[f"{self.rnn.prefix}/cell_{l}/bias"])
-        return (dzT, inT, hT, dwx_t, dwh_t, db_p)      # kept alive until the streams are joined
+        return (inT, dwx_t, dwh_t)      # kept alive until the streams are joined
 
     def backward(self, dy, ctx, keep_prob=1.0, seed=0, row0=0, need_dx=False, step_dev=None):
         """dy f32 [T,B,u_last]: gradient wrt the (dropped) top output.  Accumulates the kernel / bias gradients
@@ -188,10 +185,14 @@ class LstmStack:
         dyl = [None] * L
         dyl[L - 1] = dy.view(T, B, -1)
         st = []
+        Np = ops.round_up(T * B, 64)
         for l, p in enumerate(self.packed):
             u = p["u"]
-            dz = torch.empty((T, B, 4 * u), device=dev)
+            fused = ops.lstm_fused_outputs(self.dtype, u)          # bf16 step kernels emit dz^T and sum(dz) themselves
+            dz = None if fused else torch.empty((T, B, 4 * u), device=dev)
             st.append(dict(dz=dz, dzc=dz if self.dtype == torch.float32 else torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype),
+                           dzT=(torch.zeros if Np != T * B else torch.empty)((4 * u, Np), device=dev, dtype=self.dtype),
+                           db_p=torch.zeros(4 * u, device=dev),
                            dh=torch.empty((T, B, u), device=dev) if keep_prob < 1.0 else None, ws=ops.lstm_seq_bwd_workspace(B, u, dev)))
             if l < L - 1:
                 dyl[l] = torch.empty((T, B, u), device=dev)
@@ -210,7 +211,8 @@ class LstmStack:
                         dh = s_["dh"]
                     else:
                         dh = dyl[l]
-                    ops.lstm_seq_bwd(dh, p["wh_p"], cx["gates"], cx["c"], cx["c0"], s_["dz"], s_["dzc"], None, None, t0, t1, s_["ws"])
+                    ops.lstm_seq_bwd(dh, p["wh_p"], cx["gates"], cx["c"], cx["c0"], s_["dz"], s_["dzc"], None, None, t0, t1, s_["ws"],
+                                     s_["dzT"], s_["db_p"])
                     if l > 0:
                         ops.gemm_tn(s_["dzc"][t0:t1].view((t1 - t0) * B, -1), p["wx_p"], dyl[l - 1][t0:t1].view((t1 - t0) * B, -1))
                         if piped:
@@ -219,7 +221,7 @@ class LstmStack:
         keep = []
         for l in range(L - 1, -1, -1):
             with torch.cuda.stream(lane_of(l)):
-                keep.append(self._weight_grads(l, ctx[l], st[l]["dz"], st[l]["dzc"], T, B))
+                keep.append(self._weight_grads(l, ctx[l], st[l]["dzT"], st[l]["db_p"], T, B))
         for s in lanes[1:]:
             main.wait_stream(s)
         return None

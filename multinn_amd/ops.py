@@ -131,7 +131,11 @@ def lstm_unpack_grads(dwx_t, dwh_t, db_p, n_in, units, dW, db):
     call("mnn_lstm_unpack_grads", _stream(), _ptr(dwx_t), _ptr(dwh_t), _ptr(db_p), n_in, units, ld_in, _ptr(dW), _ptr(db))
 
 
-def lstm_seq_fwd(xproj, wh_t, h0, c0, gates, c, h, t_begin=0, t_end=None):
+def lstm_fused_outputs(dtype, units):
+    return bool(_lib.load().mnn_lstm_fused_outputs(dtype_code(dtype), int(units)))
+
+
+def lstm_seq_fwd(xproj, wh_t, h0, c0, gates, c, h, t_begin=0, t_end=None, hT=None):
     T, B, N4 = xproj.shape
     units = N4 // 4
     _req(xproj.dtype == torch.float32 and xproj.is_contiguous() and units % 32 == 0, "lstm_fwd: xproj f32 [T,B,4u], u%32==0")
@@ -146,15 +150,17 @@ def lstm_seq_fwd(xproj, wh_t, h0, c0, gates, c, h, t_begin=0, t_end=None):
         _req(c0.shape == (B, units) and c0.dtype == torch.float32 and c0.is_contiguous(), "lstm_fwd: c0")
     t_end = T if t_end is None else t_end
     _req(0 <= t_begin < t_end <= T, "lstm_fwd: bad step range")
+    if hT is not None:
+        _req(hT.dim() == 2 and hT.shape[0] == units and hT.stride(1) == 1 and hT.shape[1] >= T * B and hT.dtype == h.dtype, "lstm_fwd: hT [u, >=T*B]")
     call("mnn_lstm_seq_fwd", _stream(), dtype_code(h), T, B, units, int(t_begin), int(t_end), _ptr(xproj), _ptr(wh_t), _ptr(h0), _ptr(c0),
-         _ptr(gates), _ptr(c), _ptr(h))
+         _ptr(gates), _ptr(c), _ptr(h), _ptr(hT), hT.stride(0) if hT is not None else 0)
 
 
 def lstm_seq_bwd_workspace(B, units, device):
     return torch.empty(_lib.load().mnn_lstm_seq_bwd_workspace_bytes(B, units), dtype=torch.uint8, device=device)
 
 
-def lstm_seq_bwd(dh_ext, wh_p, gates, c, c0, dz, dz_T, dh0=None, dc0=None, t_begin=0, t_end=None, ws=None):
+def lstm_seq_bwd(dh_ext, wh_p, gates, c, c0, dz, dz_T, dh0=None, dc0=None, t_begin=0, t_end=None, ws=None, dzT_t=None, db_p=None):
     T, B, units = dh_ext.shape
     N4 = 4 * units
     _req(dh_ext.dtype == torch.float32 and dh_ext.is_contiguous(), "lstm_bwd: dh_ext f32 [T,B,u]")
@@ -170,8 +176,14 @@ def lstm_seq_bwd(dh_ext, wh_p, gates, c, c0, dz, dz_T, dh0=None, dc0=None, t_beg
     if ws is None:
         _req(t_begin == 0 and t_end == T, "lstm_bwd: chunked calls must share a workspace (lstm_seq_bwd_workspace)")
         ws = lstm_seq_bwd_workspace(B, units, dh_ext.device)
+    if dzT_t is not None:
+        _req(dzT_t.dim() == 2 and dzT_t.shape[0] == N4 and dzT_t.stride(1) == 1 and dzT_t.shape[1] >= T * B and dzT_t.dtype == wh_p.dtype,
+             "lstm_bwd: dzT_t [4u, >=T*B]")
+    if db_p is not None:
+        _req(db_p.dtype == torch.float32 and db_p.numel() == N4 and db_p.is_contiguous(), "lstm_bwd: db_p f32 [4u]")
     call("mnn_lstm_seq_bwd", _stream(), dtype_code(wh_p), T, B, units, int(t_begin), int(t_end), _ptr(dh_ext), _ptr(wh_p), _ptr(gates),
-         _ptr(c), _ptr(c0), _ptr(dz), _ptr(dz_T), _ptr(dh0), _ptr(dc0), _ptr(ws))
+         _ptr(c), _ptr(c0), _ptr(dz), _ptr(dz_T), _ptr(dh0), _ptr(dc0), _ptr(ws), _ptr(dzT_t), dzT_t.stride(0) if dzT_t is not None else 0,
+         _ptr(db_p))
 
 
 def _step_ok(step_dev):

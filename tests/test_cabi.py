@@ -43,7 +43,7 @@ def test_argument_validation_without_gpu(lib):
     rc = lib.mnn_nade_logprob_fwd(None, 1, 4, 8, 300, None, 0, None, 400, None, None, None, None, None, None, None)
     assert rc == -1 and b"Hn" in lib.mnn_last_error()
     with pytest.raises(_lib.MnnError):
-        _lib.call("mnn_lstm_seq_fwd", None, 0, 1, 1, 33, 0, 1, None, None, None, None, None, None, None)
+        _lib.call("mnn_lstm_seq_fwd", None, 0, 1, 1, 33, 0, 1, None, None, None, None, None, None, None, None, 0)
 
 
 def test_ops_refuse_cpu_tensors():

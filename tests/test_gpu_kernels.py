@@ -215,6 +215,25 @@ def test_lstm_chunked_calls_equal_full_sequence(ops):
     assert torch.equal(dz1, dz2) and torch.equal(dzb1, dzb2)
     with pytest.raises(ValueError):
         ops.lstm_seq_bwd(dy, wh_p, g1, c1, None, dz2, dzb2, None, None, 2, 5)      # chunked call without a shared workspace
+    # fused epilogue outputs of the bf16 step kernels: h_prev^T, dz^T and sum(dz)
+    assert ops.lstm_fused_outputs(torch.bfloat16, u) and not ops.lstm_fused_outputs(torch.float32, u)
+    Np = ops.round_up(T * B, 64)
+    hT = torch.zeros((u, Np), device=DEV, dtype=tdt)
+    g3, c3, h3 = mk()
+    ops.lstm_seq_fwd(xproj, wh_t, None, None, g3, c3, h3, 0, T, hT)
+    ref_hT = torch.zeros((u, Np), device=DEV, dtype=tdt)
+    ref_hT[:, B:T * B] = h1[:-1].reshape((T - 1) * B, u).t()
+    assert torch.equal(hT, ref_hT)
+    dzT = torch.zeros((4 * u, Np), device=DEV, dtype=tdt); db = torch.zeros(4 * u, device=DEV)
+    dzb3 = torch.zeros_like(dzb1)
+    ws = ops.lstm_seq_bwd_workspace(B, u, DEV)
+    for t0, t1 in [(4, 7), (0, 4)]:
+        ops.lstm_seq_bwd(dy, wh_p, g1, c1, None, None, dzb3, None, None, t0, t1, ws, dzT, db)     # no f32 dz at all
+    assert torch.equal(dzb3, dzb1)
+    assert torch.equal(dzT[:, :T * B], dzb1.view(T * B, 4 * u).t()) and float(dzT[:, T * B:].abs().max()) == 0
+    # the bias gradient is the row sum of the bf16 dz^T (one pass, off the per-step chain)
+    assert rel(db.cpu().numpy(), dzb1.float().view(T * B, -1).sum(0).cpu().numpy()) < 1e-5
+    assert rel(db.cpu().numpy(), dz1.view(T * B, -1).sum(0).cpu().numpy()) < 1e-2
 
 
 def test_lstm_initial_state_and_dh0(ops):
