@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmultinn_hip.so")
+LIB_PATH = os.environ.get("MULTINN_HIP_LIB", os.path.join(HERE, "libmultinn_hip.so"))   # override: A/B builds of the same ABI
 
 F32, BF16, U8 = 0, 1, 2
 GEMM_ACCUMULATE, GEMM_ATOMIC = 1, 2
@@ -46,6 +46,18 @@ SIGNATURES = {
     "mnn_bias_grad": (_i, [_p, _p, _i, _i, _i, _p, _i]),
     "mnn_fill_f32": (_i, [_p, _p, _l, _f]),
 }
+
+class LstmFwdLayer(C.Structure):
+    _fields_ = [("units", _i), ("xproj", _p), ("wh_t", _p), ("h0", _p), ("c0", _p), ("gates", _p), ("c", _p), ("h", _p), ("hT", _p), ("ld_hT", _i)]
+
+
+class LstmBwdLayer(C.Structure):
+    _fields_ = [("units", _i), ("dh_ext", _p), ("wh_p", _p), ("gates", _p), ("c", _p), ("c0", _p), ("dz", _p), ("dz_T", _p), ("workspace", _p),
+                ("dzT_t", _p), ("ld_t", _i), ("db_p", _p)]
+
+
+SIGNATURES["mnn_lstm2_seq_fwd"] = (_i, [_p, _i, _i, C.POINTER(LstmFwdLayer), C.POINTER(LstmFwdLayer), _i, _i, _i])
+SIGNATURES["mnn_lstm2_seq_bwd"] = (_i, [_p, _i, _i, C.POINTER(LstmBwdLayer), C.POINTER(LstmBwdLayer), _i, _i, _i])
 
 _lib = None
 

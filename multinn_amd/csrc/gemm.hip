@@ -401,14 +401,20 @@ __device__ __forceinline__ void load_frags(const bf16_t* __restrict__ p, bf16x8_
 }
 
 // forward: 4 waves, K = U = 64*KS.  Tile columns = 4 gates x 32 units (gate-interleaved layout).
+struct LstmFwdArgs {
+    const bf16_t* h_prev; const bf16_t* wh_t; const float* xproj; const float* c_prev;
+    float* gates; float* c_out; bf16_t* h_out; bf16_t* hT;
+    int U, ld_hT, colT, active;
+};
+
 template <int KS>
-__global__ void __launch_bounds__(256)
-lstm_fwd_step_v2(const bf16_t* __restrict__ h_prev, const bf16_t* __restrict__ wh_t, const float* __restrict__ xproj,
-                 const float* __restrict__ c_prev, float* __restrict__ gates, float* __restrict__ c_out, bf16_t* __restrict__ h_out,
-                 int B, int U, bf16_t* __restrict__ hT, int ld_hT, int colT) {
-    __shared__ float red[4][4][16][64];
-    __shared__ bf16_t sT[32][40];          // h tile, [unit][row] (+pad), for the transposed copy
-    const int nt = blockIdx.x, m0 = blockIdx.y * 32, n0 = nt * 128, N4 = 4 * U;
+__device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgs& A, int B, int bx, int by, float (&red)[4][4][16][64], bf16_t (&sT)[32][40]) {
+    const bf16_t* __restrict__ h_prev = A.h_prev; const bf16_t* __restrict__ wh_t = A.wh_t;
+    const float* __restrict__ xproj = A.xproj; const float* __restrict__ c_prev = A.c_prev;
+    float* __restrict__ gates = A.gates; float* __restrict__ c_out = A.c_out; bf16_t* __restrict__ h_out = A.h_out;
+    bf16_t* __restrict__ hT = A.hT;
+    const int U = A.U, ld_hT = A.ld_hT, colT = A.colT;
+    const int nt = bx, m0 = by * 32, n0 = nt * 128, N4 = 4 * U;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     // epilogue operands of this wave's 4 fragment rows, requested first so they fly under the MFMAs
@@ -482,15 +488,42 @@ lstm_fwd_step_v2(const bf16_t* __restrict__ h_prev, const bf16_t* __restrict__ w
     }
 }
 
-// backward: 8 waves, K = 4U = 128*KS.  dh = dh_ext + dz_next . Wh^T, then the gate pointwise.
 template <int KS>
-__global__ void __launch_bounds__(512)
-lstm_bwd_step_v2(const bf16_t* __restrict__ dz_next, const bf16_t* __restrict__ wh_p, const float* __restrict__ dh_ext,
-                 const float* __restrict__ gates, const float* __restrict__ c_t, const float* __restrict__ c_prev, float* __restrict__ dc,
-                 float* __restrict__ dz, bf16_t* __restrict__ dzT, int B, int U, int first, bf16_t* __restrict__ dzTt, int ld_t, int colT) {
-    __shared__ float red[8][16][64];
-    __shared__ bf16_t sT[4][32][40];       // dz tile, [gate][unit][row] (+pad), for the transposed copy
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32, N4 = 4 * U;
+__global__ void __launch_bounds__(256) lstm_fwd_step_v2(LstmFwdArgs A, int B) {
+    __shared__ float red[4][4][16][64];
+    __shared__ bf16_t sT[32][40];          // h tile, [unit][row] (+pad), for the transposed copy
+    lstm_fwd_body<KS>(A, B, blockIdx.x, blockIdx.y, red, sT);
+}
+
+// Two layers in ONE launch (layer wavefront): blocks [0, U1/32) run layer 1's step, the rest layer 2's (an earlier)
+// step.  The two bodies are independent, so the second chain hides behind the first and half the kernel
+// boundaries of the sequential form disappear.
+template <int KS1, int KS2>
+__global__ void __launch_bounds__(256) lstm2_fwd_step(LstmFwdArgs A1, LstmFwdArgs A2, int B) {
+    __shared__ float red[4][4][16][64];
+    __shared__ bf16_t sT[32][40];
+    const int nb1 = A1.U / 32;
+    if ((int)blockIdx.x < nb1) {
+        if (A1.active) lstm_fwd_body<KS1>(A1, B, blockIdx.x, blockIdx.y, red, sT);
+    } else {
+        if (A2.active) lstm_fwd_body<KS2>(A2, B, blockIdx.x - nb1, blockIdx.y, red, sT);
+    }
+}
+
+// backward: 8 waves, K = 4U = 128*KS.  dh = dh_ext + dz_next . Wh^T, then the gate pointwise.
+struct LstmBwdArgs {
+    const bf16_t* dz_next; const bf16_t* wh_p; const float* dh_ext; const float* gates; const float* c_t; const float* c_prev;
+    float* dc; float* dz; bf16_t* dzT; bf16_t* dzTt;
+    int U, first, ld_t, colT, active;
+};
+
+template <int KS>
+__device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& A, int B, int bx, int by, float (&red)[8][16][64], bf16_t (&sT)[4][32][40]) {
+    const bf16_t* __restrict__ dz_next = A.dz_next; const bf16_t* __restrict__ wh_p = A.wh_p; const float* __restrict__ dh_ext = A.dh_ext;
+    const float* __restrict__ gates = A.gates; const float* __restrict__ c_t = A.c_t; const float* __restrict__ c_prev = A.c_prev;
+    float* __restrict__ dc = A.dc; float* __restrict__ dz = A.dz; bf16_t* __restrict__ dzT = A.dzT; bf16_t* __restrict__ dzTt = A.dzTt;
+    const int U = A.U, first = A.first, ld_t = A.ld_t, colT = A.colT;
+    const int m0 = by * 32, n0 = bx * 32, N4 = 4 * U;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int unit = n0 + r, pc = gate_perm_col(0, unit);
@@ -570,6 +603,25 @@ lstm_bwd_step_v2(const bf16_t* __restrict__ dz_next, const bf16_t* __restrict__ 
     }
 }
 
+template <int KS>
+__global__ void __launch_bounds__(512) lstm_bwd_step_v2(LstmBwdArgs A, int B) {
+    __shared__ float red[8][16][64];
+    __shared__ bf16_t sT[4][32][40];       // dz tile, [gate][unit][row] (+pad), for the transposed copy
+    lstm_bwd_body<KS>(A, B, blockIdx.x, blockIdx.y, red, sT);
+}
+
+template <int KS1, int KS2>
+__global__ void __launch_bounds__(512) lstm2_bwd_step(LstmBwdArgs A1, LstmBwdArgs A2, int B) {
+    __shared__ float red[8][16][64];
+    __shared__ bf16_t sT[4][32][40];
+    const int nb1 = A1.U / 32;
+    if ((int)blockIdx.x < nb1) {
+        if (A1.active) lstm_bwd_body<KS1>(A1, B, blockIdx.x, blockIdx.y, red, sT);
+    } else {
+        if (A2.active) lstm_bwd_body<KS2>(A2, B, blockIdx.x - nb1, blockIdx.y, red, sT);
+    }
+}
+
 // db_p[c] += sum over columns [c0, c1) of row c of dzT (contiguous bf16 rows): the LSTM bias gradient, one pass over the
 // transposed dz the step kernels already wrote (no per-step reduction on the latency-critical chain).
 __global__ void __launch_bounds__(256) rowsum_bf16_kernel(const bf16_t* __restrict__ X, int ld, int c0, int c1, float* __restrict__ out) {
@@ -611,8 +663,9 @@ extern "C" int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int uni
         const char* hp = t == 0 ? (const char*)h0 : (const char*)h + (size_t)(t - 1) * B * units * esz;
         if (v2) {
             dim3 g2(units / 32, cdiv(B, 32));
-#define FWD2(KS) hipLaunchKernelGGL(lstm_fwd_step_v2<KS>, g2, dim3(256), 0, st, (const bf16_t*)hp, (const bf16_t*)wh_t, xp, cp, gt, ct, (bf16_t*)ht, B, units, \
-                                    (bf16_t*)(t + 1 < T ? hT : nullptr), ld_hT, (t + 1) * B)
+            LstmFwdArgs fa{(const bf16_t*)hp, (const bf16_t*)wh_t, xp, cp, gt, ct, (bf16_t*)ht, (bf16_t*)(t + 1 < T ? hT : nullptr), units, ld_hT,
+                           (t + 1) * B, 1};
+#define FWD2(KS) hipLaunchKernelGGL(lstm_fwd_step_v2<KS>, g2, dim3(256), 0, st, fa, B)
             if (units == 512) FWD2(8); else if (units == 256) FWD2(4); else FWD2(2);
 #undef FWD2
         } else if (dtype == MNN_BF16)
@@ -723,9 +776,9 @@ extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int uni
         float* dho = t < 0 ? dh0 : nullptr;
         if (v2 && t >= 0) {
             dim3 g2(units / 32, cdiv(B, 32));
-#define BWD2(KS) hipLaunchKernelGGL(lstm_bwd_step_v2<KS>, g2, dim3(512), 0, st, (const bf16_t*)dzn, (const bf16_t*)wh_p, dh_ext + (size_t)tt * us, \
-                                    gates + (size_t)tt * zs, c + (size_t)tt * us, cp, dc, dzt, (bf16_t*)dzTt, B, units, t == T - 1 ? 1 : 0,        \
-                                    (bf16_t*)dzT_t, ld_t, t * B)
+            LstmBwdArgs ba{(const bf16_t*)dzn, (const bf16_t*)wh_p, dh_ext + (size_t)tt * us, gates + (size_t)tt * zs, c + (size_t)tt * us, cp, dc,
+                           dzt, (bf16_t*)dzTt, (bf16_t*)dzT_t, units, t == T - 1 ? 1 : 0, ld_t, t * B, 1};
+#define BWD2(KS) hipLaunchKernelGGL(lstm_bwd_step_v2<KS>, g2, dim3(512), 0, st, ba, B)
             if (units == 512) BWD2(16); else if (units == 256) BWD2(8); else BWD2(4);
 #undef BWD2
         } else if (dtype == MNN_BF16)
@@ -753,5 +806,117 @@ extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int uni
         }
         if (db_p != nullptr) return mnn_bias_grad(s, dz + (size_t)t_begin * zs, rows, 4 * units, 4 * units, db_p, 1);
     }
+    return MNN_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Two-layer wavefront entries (bf16, units in {128,256,512}): launch s runs layer 1's step s and layer 2's step
+// s - lag in ONE kernel; between chunks of `lag` launches the caller inserts layer 2's batched input projection
+// for the chunk layer 1 has just finished (forward) / layer 1's input-gradient GEMM + dropout for the chunk
+// layer 2 has just finished (backward).
+// ----------------------------------------------------------------------------------------------
+template <int K1>
+static void launch_fwd2(hipStream_t st, dim3 grid, const LstmFwdArgs& a1, const LstmFwdArgs& a2, int B, int u2) {
+    if (u2 == 512) hipLaunchKernelGGL((lstm2_fwd_step<K1, 8>), grid, dim3(256), 0, st, a1, a2, B);
+    else if (u2 == 256) hipLaunchKernelGGL((lstm2_fwd_step<K1, 4>), grid, dim3(256), 0, st, a1, a2, B);
+    else hipLaunchKernelGGL((lstm2_fwd_step<K1, 2>), grid, dim3(256), 0, st, a1, a2, B);
+}
+template <int K1>
+static void launch_bwd2(hipStream_t st, dim3 grid, const LstmBwdArgs& a1, const LstmBwdArgs& a2, int B, int u2) {
+    if (u2 == 512) hipLaunchKernelGGL((lstm2_bwd_step<K1, 16>), grid, dim3(512), 0, st, a1, a2, B);
+    else if (u2 == 256) hipLaunchKernelGGL((lstm2_bwd_step<K1, 8>), grid, dim3(512), 0, st, a1, a2, B);
+    else hipLaunchKernelGGL((lstm2_bwd_step<K1, 4>), grid, dim3(512), 0, st, a1, a2, B);
+}
+
+static LstmFwdArgs make_fwd_args(const mnn_lstm_fwd_layer* L, int T, int B, int t) {
+    LstmFwdArgs a{};
+    a.U = L->units;
+    a.active = (t >= 0 && t < T) ? 1 : 0;
+    if (!a.active) return a;
+    const size_t us = (size_t)B * L->units, zs = 4 * us;
+    a.h_prev = t == 0 ? (const bf16_t*)L->h0 : (const bf16_t*)L->h + (size_t)(t - 1) * us;
+    a.wh_t = (const bf16_t*)L->wh_t;
+    a.xproj = L->xproj + (size_t)t * zs;
+    a.c_prev = t == 0 ? L->c0 : L->c + (size_t)(t - 1) * us;
+    a.gates = L->gates ? L->gates + (size_t)t * zs : nullptr;
+    a.c_out = L->c + (size_t)t * us;
+    a.h_out = (bf16_t*)L->h + (size_t)t * us;
+    a.hT = (t + 1 < T) ? (bf16_t*)L->hT : nullptr;
+    a.ld_hT = L->ld_hT;
+    a.colT = (t + 1) * B;
+    return a;
+}
+
+extern "C" int mnn_lstm2_seq_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L1, const mnn_lstm_fwd_layer* L2, int lag, int s_begin,
+                                 int s_end) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(L1 && L2 && T > 0 && B > 0 && lag > 0, "mnn_lstm2_seq_fwd: bad arguments");
+    MNN_REQUIRE(lstm_v2_ok(MNN_BF16, L1->units) && lstm_v2_ok(MNN_BF16, L2->units), "mnn_lstm2_seq_fwd: units must be 128/256/512 (bf16)");
+    MNN_REQUIRE(0 <= s_begin && s_begin < s_end && s_end <= T + lag, "mnn_lstm2_seq_fwd: bad launch range [%d,%d) of %d", s_begin, s_end, T + lag);
+    for (const mnn_lstm_fwd_layer* L : {L1, L2}) {
+        MNN_REQUIRE(L->xproj && L->wh_t && L->c && L->h, "mnn_lstm2_seq_fwd: null pointer");
+        MNN_REQUIRE(L->hT == nullptr || L->ld_hT >= T * B, "mnn_lstm2_seq_fwd: ld_hT too small");
+    }
+    dim3 grid(L1->units / 32 + L2->units / 32, cdiv(B, 32));
+    for (int si = s_begin; si < s_end; ++si) {
+        const LstmFwdArgs a1 = make_fwd_args(L1, T, B, si), a2 = make_fwd_args(L2, T, B, si - lag);
+        if (L1->units == 512) launch_fwd2<8>(st, grid, a1, a2, B, L2->units);
+        else if (L1->units == 256) launch_fwd2<4>(st, grid, a1, a2, B, L2->units);
+        else launch_fwd2<2>(st, grid, a1, a2, B, L2->units);
+    }
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+static LstmBwdArgs make_bwd_args(const mnn_lstm_bwd_layer* L, int T, int B, int t) {
+    LstmBwdArgs a{};
+    a.U = L->units;
+    a.active = (t >= 0 && t < T) ? 1 : 0;
+    if (!a.active) return a;
+    const size_t us = (size_t)B * L->units, zs = 4 * us;
+    a.dz_next = t == T - 1 ? nullptr : (const bf16_t*)L->dz_T + (size_t)(t + 1) * zs;
+    a.wh_p = (const bf16_t*)L->wh_p;
+    a.dh_ext = L->dh_ext + (size_t)t * us;
+    a.gates = L->gates + (size_t)t * zs;
+    a.c_t = L->c + (size_t)t * us;
+    a.c_prev = t == 0 ? L->c0 : L->c + (size_t)(t - 1) * us;
+    a.dc = (float*)L->workspace;
+    a.dz = L->dz ? L->dz + (size_t)t * zs : nullptr;
+    a.dzT = (bf16_t*)L->dz_T + (size_t)t * zs;
+    a.dzTt = (bf16_t*)L->dzT_t;
+    a.first = t == T - 1 ? 1 : 0;
+    a.ld_t = L->ld_t;
+    a.colT = t * B;
+    return a;
+}
+
+extern "C" int mnn_lstm2_seq_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L1, const mnn_lstm_bwd_layer* L2, int lag, int k_begin,
+                                 int k_end) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(L1 && L2 && T > 0 && B > 0 && lag > 0, "mnn_lstm2_seq_bwd: bad arguments");
+    MNN_REQUIRE(lstm_v2_ok(MNN_BF16, L1->units) && lstm_v2_ok(MNN_BF16, L2->units), "mnn_lstm2_seq_bwd: units must be 128/256/512 (bf16)");
+    MNN_REQUIRE(0 <= k_begin && k_begin < k_end && k_end <= T + lag, "mnn_lstm2_seq_bwd: bad launch range [%d,%d) of %d", k_begin, k_end, T + lag);
+    for (const mnn_lstm_bwd_layer* L : {L1, L2}) {
+        MNN_REQUIRE(L->dh_ext && L->wh_p && L->gates && L->c && L->dz_T && L->workspace, "mnn_lstm2_seq_bwd: null pointer");
+        MNN_REQUIRE(L->dzT_t == nullptr || L->ld_t >= T * B, "mnn_lstm2_seq_bwd: ld_t too small");
+        MNN_REQUIRE(L->db_p == nullptr || L->dzT_t != nullptr, "mnn_lstm2_seq_bwd: db_p needs dzT_t");
+    }
+    dim3 grid(L1->units / 32 + L2->units / 32, cdiv(B, 32));
+    for (int k = k_begin; k < k_end; ++k) {
+        // the top layer (L2) leads; layer 1 follows `lag` launches later
+        const LstmBwdArgs a1 = make_bwd_args(L1, T, B, T - 1 - k + lag), a2 = make_bwd_args(L2, T, B, T - 1 - k);
+        if (L1->units == 512) launch_bwd2<16>(st, grid, a1, a2, B, L2->units);
+        else if (L1->units == 256) launch_bwd2<8>(st, grid, a1, a2, B, L2->units);
+        else launch_bwd2<4>(st, grid, a1, a2, B, L2->units);
+    }
+    MNN_LAUNCH_CHECK();
+    // bias gradients: row sums of dz^T over the steps each layer finished in this call
+    const int lo2 = max(0, T - k_end), hi2 = min(T, T - k_begin);
+    const int lo1 = max(0, T - k_end + lag), hi1 = min(T, T - k_begin + lag);
+    if (L2->db_p && hi2 > lo2)
+        hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(4 * L2->units), dim3(256), 0, st, (const bf16_t*)L2->dzT_t, L2->ld_t, lo2 * B, hi2 * B, L2->db_p);
+    if (L1->db_p && hi1 > lo1)
+        hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(4 * L1->units), dim3(256), 0, st, (const bf16_t*)L1->dzT_t, L1->ld_t, lo1 * B, hi1 * B, L1->db_p);
+    MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

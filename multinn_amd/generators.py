@@ -84,6 +84,17 @@ class LstmStack:
             self._side = [torch.cuda.Stream(device=dev) for _ in range(n - 1)]
         return [torch.cuda.current_stream()] + self._side[:n - 1]
 
+    fused_layers = True   # run two-layer stacks as a wavefront inside single launches (mnn_lstm2_seq_*)
+
+    def _fused2(self, B=0):
+        """Two layers per launch pay off while one layer's step does not fill the chip (measured: C2 B=256 7.1 -> 6.2
+        ms/step; TGT B=1024, 768 blocks per launch, 35.7 -> 36.4 ms/step)."""
+        if not (self.fused_layers and len(self.packed) == 2 and self.dtype == torch.bfloat16
+                and all(ops.lstm_fused_outputs(self.dtype, p["u"]) for p in self.packed)):
+            return False
+        blocks = sum(p["u"] // 32 for p in self.packed) * -(-max(B, 1) // 32)
+        return blocks <= 512
+
     @staticmethod
     def _chunks(T, step):
         return [(t0, min(T, t0 + step)) for t0 in range(0, T, step)]
@@ -118,6 +129,23 @@ class LstmStack:
         # layer 0's input projection has no dependency: one big GEMM
         p0, b0 = self.packed[0], bufs[0]
         ops.gemm_tn(x_tm.view(T * B, -1), p0["wx_t"], b0["xproj"].view(T * B, -1), bias=p0["bias_p"])
+        if self._fused2(B):
+            # two-layer wavefront inside single launches: launch s = layer 0 step s + layer 1 step s - lag
+            p1, b1 = self.packed[1], bufs[1]
+            lag = self.chunk
+            d0 = ops.lstm2_fwd_layer(b0["xproj"], p0["wh_t"], b0["h0"], b0["c0"], b0["gates"], b0["c"], b0["h"], b0["hT"])
+            d1 = ops.lstm2_fwd_layer(b1["xproj"], p1["wh_t"], b1["h0"], b1["c0"], b1["gates"], b1["c"], b1["h"], b1["hT"])
+            for s0 in range(0, T + lag, lag):
+                s1 = min(s0 + lag, T + lag)
+                ops.lstm2_seq_fwd(T, B, d0, d1, lag, s0, s1)
+                if s0 < T:                                   # layer 1's inputs for the chunk layer 0 has just finished
+                    t0, t1 = s0, min(s1, T)
+                    if keep_prob < 1.0:
+                        ops.dropout_fwd(b0["h"][t0:t1], b0["y"][t0:t1], keep_prob, seed, row0, 0, step_dev, t0)
+                    ops.gemm_tn(b0["y"][t0:t1].view((t1 - t0) * B, -1), p1["wx_t"], b1["xproj"][t0:t1].view((t1 - t0) * B, -1), bias=p1["bias_p"])
+            if keep_prob < 1.0:
+                ops.dropout_fwd(b1["h"], b1["y"], keep_prob, seed, row0, 1, step_dev, 0)
+            chunks = []
         done = [[None] * len(chunks) for _ in range(L)]
         for ci, (t0, t1) in enumerate(chunks):
             for l, (p, bf) in enumerate(zip(self.packed, bufs)):
@@ -198,6 +226,24 @@ class LstmStack:
                 dyl[l] = torch.empty((T, B, u), device=dev)
         lane_of = lambda l: lanes[L - 1 - l] if piped else main          # the top layer leads, on the current stream
         done = [[None] * len(chunks) for _ in range(L)]
+        if self._fused2(B) and ctx[0]["h0"] is None:
+            lag = self.chunk
+            p0, p1 = self.packed
+            if keep_prob < 1.0:
+                ops.dropout_bwd(dyl[1], st[1]["dh"], keep_prob, seed, row0, 1, False, step_dev, 0)
+            dh1 = st[1]["dh"] if keep_prob < 1.0 else dyl[1]
+            dh0 = st[0]["dh"] if keep_prob < 1.0 else dyl[0]
+            e0 = ops.lstm2_bwd_layer(dh0, p0["wh_p"], ctx[0]["gates"], ctx[0]["c"], ctx[0]["c0"], st[0]["dzc"], st[0]["ws"], st[0]["dzT"], st[0]["db_p"])
+            e1 = ops.lstm2_bwd_layer(dh1, p1["wh_p"], ctx[1]["gates"], ctx[1]["c"], ctx[1]["c0"], st[1]["dzc"], st[1]["ws"], st[1]["dzT"], st[1]["db_p"])
+            for k0 in range(0, T + lag, lag):
+                k1 = min(k0 + lag, T + lag)
+                ops.lstm2_seq_bwd(T, B, e0, e1, lag, k0, k1)
+                tA, tB = max(0, T - k1), T - k0
+                if tB > tA:                                  # layer 0's dh for the chunk layer 1 has just finished
+                    ops.gemm_tn(st[1]["dzc"][tA:tB].view((tB - tA) * B, -1), p1["wx_p"], dyl[0][tA:tB].view((tB - tA) * B, -1))
+                    if keep_prob < 1.0:
+                        ops.dropout_bwd(dyl[0][tA:tB], st[0]["dh"][tA:tB], keep_prob, seed, row0, 0, False, step_dev, tA)
+            chunks = []
         for ci in range(len(chunks) - 1, -1, -1):
             t0, t1 = chunks[ci]
             for l in range(L - 1, -1, -1):

@@ -190,6 +190,55 @@ def _step_ok(step_dev):
     _req(step_dev is None or (step_dev.dtype == torch.int32 and step_dev.numel() == 1), "step_dev must be a device int32 scalar")
 
 
+def _p0(t):
+    return t.data_ptr() if t is not None else None
+
+
+def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT):
+    """Descriptor of one layer for lstm2_seq_fwd (same tensors as lstm_seq_fwd; bf16, contiguous, time-major)."""
+    T, B, N4 = xproj.shape
+    u = N4 // 4
+    _req(xproj.dtype == torch.float32 and xproj.is_contiguous() and h.dtype == torch.bfloat16 and h.shape == (T, B, u) and h.is_contiguous(),
+         "lstm2: xproj f32 [T,B,4u], h bf16 [T,B,u]")
+    _req(wh_t.shape == (N4, u) and wh_t.is_contiguous() and wh_t.dtype == torch.bfloat16, "lstm2: wh_t bf16 [4u,u]")
+    _req(c.dtype == torch.float32 and c.shape == (T, B, u) and c.is_contiguous(), "lstm2: c")
+    _req(gates is None or (gates.dtype == torch.float32 and gates.shape == (T, B, N4) and gates.is_contiguous()), "lstm2: gates")
+    _req(h0 is None or (h0.shape == (B, u) and h0.dtype == torch.bfloat16 and h0.is_contiguous()), "lstm2: h0")
+    _req(c0 is None or (c0.shape == (B, u) and c0.dtype == torch.float32 and c0.is_contiguous()), "lstm2: c0")
+    _req(hT is None or (hT.dim() == 2 and hT.shape[0] == u and hT.stride(1) == 1 and hT.shape[1] >= T * B and hT.dtype == torch.bfloat16), "lstm2: hT")
+    for t in (xproj, wh_t, c, h):
+        _ptr(t)
+    return _lib.LstmFwdLayer(u, _p0(xproj), _p0(wh_t), _p0(h0), _p0(c0), _p0(gates), _p0(c), _p0(h), _p0(hT), hT.stride(0) if hT is not None else 0)
+
+
+def lstm2_seq_fwd(T, B, L1, L2, lag, s_begin, s_end):
+    _req(0 <= s_begin < s_end <= T + lag and lag > 0, "lstm2_fwd: bad launch range")
+    call("mnn_lstm2_seq_fwd", _stream(), T, B, C.byref(L1), C.byref(L2), int(lag), int(s_begin), int(s_end))
+
+
+def lstm2_bwd_layer(dh_ext, wh_p, gates, c, c0, dz_T, ws, dzT_t, db_p):
+    T, B, u = dh_ext.shape
+    N4 = 4 * u
+    _req(dh_ext.dtype == torch.float32 and dh_ext.is_contiguous(), "lstm2 bwd: dh_ext f32 [T,B,u]")
+    _req(wh_p.shape == (u, N4) and wh_p.is_contiguous() and wh_p.dtype == torch.bfloat16, "lstm2 bwd: wh_p bf16 [u,4u]")
+    _req(gates.shape == (T, B, N4) and gates.dtype == torch.float32 and gates.is_contiguous(), "lstm2 bwd: gates")
+    _req(c.shape == (T, B, u) and c.dtype == torch.float32 and c.is_contiguous(), "lstm2 bwd: c")
+    _req(dz_T.shape == (T, B, N4) and dz_T.dtype == torch.bfloat16 and dz_T.is_contiguous(), "lstm2 bwd: dz_T bf16 [T,B,4u]")
+    _req(dzT_t is None or (dzT_t.dim() == 2 and dzT_t.shape[0] == N4 and dzT_t.stride(1) == 1 and dzT_t.shape[1] >= T * B
+                           and dzT_t.dtype == torch.bfloat16), "lstm2 bwd: dzT_t")
+    _req(db_p is None or (db_p.dtype == torch.float32 and db_p.numel() == N4 and dzT_t is not None), "lstm2 bwd: db_p")
+    _req(ws.numel() >= B * u * 4, "lstm2 bwd: workspace too small")
+    for t in (dh_ext, wh_p, gates, c, dz_T, ws):
+        _ptr(t)
+    return _lib.LstmBwdLayer(u, _p0(dh_ext), _p0(wh_p), _p0(gates), _p0(c), _p0(c0), None, _p0(dz_T), _p0(ws), _p0(dzT_t),
+                             dzT_t.stride(0) if dzT_t is not None else 0, _p0(db_p))
+
+
+def lstm2_seq_bwd(T, B, L1, L2, lag, k_begin, k_end):
+    _req(0 <= k_begin < k_end <= T + lag and lag > 0, "lstm2_bwd: bad launch range")
+    call("mnn_lstm2_seq_bwd", _stream(), T, B, C.byref(L1), C.byref(L2), int(lag), int(k_begin), int(k_end))
+
+
 def dropout_fwd(h, y, keep_prob, seed, row0, layer, step_dev=None, t_offset=0):
     T, B, u = h.shape
     _req(h.is_contiguous() and y.is_contiguous() and h.shape == y.shape and h.dtype == y.dtype and u % 4 == 0, "dropout_fwd: shapes")

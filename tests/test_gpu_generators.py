@@ -349,6 +349,28 @@ def test_wavefront_pipelining_matches_sequential():
     assert torch.allclose(a.store.theta, b.store.theta, atol=1e-3)
 
 
+def test_fused_two_layer_wavefront_matches_sequential():
+    """mnn_lstm2_seq_fwd/bwd (both layers' steps in one launch, lag = chunk) vs the per-layer sequence."""
+    from multinn_amd import RnnNade, AdamOptimizer
+    for T, units in [(40, [128, 128]), (7, [256, 128]), (33, [128, 256])]:
+        x = make_batch(6, T, 8, 2, 9, rho=0.2)
+        a = RnnNade(16, 16, units, keep_prob=0.9, precision="bf16", seed=3)
+        b = RnnNade(16, 16, units, keep_prob=0.9, precision="bf16", seed=3)
+        a._materialize(16); b._materialize(16)
+        b.store.theta.copy_(a.store.theta)
+        a._stack.fused_layers = False
+        assert b._stack.fused_layers
+        opt = AdamOptimizer(0.01)
+        a.build_pianoroll(dev(x), None, True, "train"); b.build_pianoroll(dev(x), None, True, "train")
+        assert b._stack._fused2(6) and not a._stack._fused2(6) and not b._stack._fused2(4096)
+        assert torch.equal(a._nll_tm, b._nll_tm)                     # forward is bit-identical (same kernels' bodies)
+        a.backward(); b.backward()
+        assert torch.allclose(a.store.grad, b.store.grad, rtol=1e-4, atol=1e-7)
+        la = [float(a.train_step(dev(x), None, opt)) for _ in range(3)]
+        lb = [float(b.train_step(dev(x), None, opt)) for _ in range(3)]
+        assert np.allclose(la, lb, rtol=1e-3), (la, lb)
+
+
 def test_graphed_train_step_matches_eager():
     from multinn_amd import RnnNade, AdamOptimizer
     x = make_batch(8, 6, 8, 2, 7, rho=0.2)
