@@ -227,7 +227,7 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
                 float* __restrict__ d_bias, float* __restrict__ d_w_enc, float* __restrict__ d_w_dec) {
     constexpr int W = HQ * 64;
     __shared__ float wl[2][2][8 * W];
-    __shared__ float red[2][8][2][W];
+    __shared__ float red[8][4][2][W];     // [wave][visible-in-half-chunk][d w_dec | d w_enc][hidden]: one exchange per 4 visibles
     const int m = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -262,7 +262,6 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
     bool vcur = fvalid && icur < D && vm[(size_t)frr * D + icur] != 0;
     float dcur = (fvalid && icur < D) ? d_bias[(size_t)frr * ld_bias + dl_off + icur] : 0.f;
     __syncthreads();
-    int buf = 0;
     for (int cc = 0; cc < nch; ++cc) {
         const int i0 = (nch - 1 - cc) * 8;
         const int inext = i0 - 8 + fi;
@@ -273,52 +272,61 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
         const float* __restrict__ sd = wl[cc & 1][0];
         const float* __restrict__ se = wl[cc & 1][1];
 #pragma unroll
-        for (int ii = 7; ii >= 0; --ii) {
-            const int i = i0 + ii;
-            if (i >= D) continue;                                               // block-uniform (tail chunk)
-            float wev[HQ], wdv[HQ], accd[HQ], acce[HQ];
+        for (int half = 1; half >= 0; --half) {
+            float accd[4][HQ], acce[4][HQ];
 #pragma unroll
-            for (int q = 0; q < HQ; ++q) {
-                wdv[q] = sd[ii * W + lane + 64 * q];
-                wev[q] = se[ii * W + lane + 64 * q];
-                accd[q] = 0.f;
-                acce[q] = 0.f;
-            }
+            for (int k = 3; k >= 0; --k) {
+                const int ii = half * 4 + k;
+                const int i = i0 + ii;
 #pragma unroll
-            for (int r = 0; r < BWD_R; ++r) {
-                const float dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dcur), r * 8 + ii));
-                if ((mask >> (r * 8 + ii)) & 1ull) {
-#pragma unroll
-                    for (int q = 0; q < HQ; ++q) {
-                        G[r][q] = fmaf(c[r][q], fmaf(-h[r][q], h[r][q], h[r][q]), G[r][q]);   // close the segment that used a_{i+1}
-                        c[r][q] = 0.f;
-                        acce[q] += G[r][q];          // d w_enc[i] += v_i * G_{i+1}
-                        a[r][q] -= wev[q];           // a_i = a_{i+1} - v_i * w_enc[i]
-                        h[r][q] = fast_sigmoid(a[r][q]);
-                    }
-                }
+                for (int q = 0; q < HQ; ++q) { accd[k][q] = 0.f; acce[k][q] = 0.f; }
+                if (i >= D) continue;                                           // block-uniform (tail chunk)
+                float wev[HQ], wdv[HQ];
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) {
-                    accd[q] = fmaf(dl, h[r][q], accd[q]);
-                    c[r][q] = fmaf(dl, wdv[q], c[r][q]);
+                    wdv[q] = sd[ii * W + lane + 64 * q];
+                    wev[q] = se[ii * W + lane + 64 * q];
+                }
+#pragma unroll
+                for (int r = 0; r < BWD_R; ++r) {
+                    const float dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dcur), r * 8 + ii));
+                    if ((mask >> (r * 8 + ii)) & 1ull) {
+#pragma unroll
+                        for (int q = 0; q < HQ; ++q) {
+                            G[r][q] = fmaf(c[r][q], fmaf(-h[r][q], h[r][q], h[r][q]), G[r][q]);   // close the segment that used a_{i+1}
+                            c[r][q] = 0.f;
+                            acce[k][q] += G[r][q];       // d w_enc[i] += v_i * G_{i+1}
+                            a[r][q] -= wev[q];           // a_i = a_{i+1} - v_i * w_enc[i]
+                            h[r][q] = fast_sigmoid(a[r][q]);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < HQ; ++q) {
+                        accd[k][q] = fmaf(dl, h[r][q], accd[k][q]);
+                        c[r][q] = fmaf(dl, wdv[q], c[r][q]);
+                    }
                 }
             }
+            // one cross-wave exchange per 4 visibles (the per-visible barrier was 60 % of the wave time)
+            __syncthreads();                             // the previous exchange has been read
 #pragma unroll
-            for (int q = 0; q < HQ; ++q) {
-                red[buf][w][0][lane + 64 * q] = accd[q];
-                red[buf][w][1][lane + 64 * q] = acce[q];
-            }
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int q = 0; q < HQ; ++q) {
+                    red[w][k][0][lane + 64 * q] = accd[k][q];
+                    red[w][k][1][lane + 64 * q] = acce[k][q];
+                }
             __syncthreads();
-            for (int e = threadIdx.x; e < 2 * W; e += 512) {
-                const int which = e / W, j = e % W;
-                if (j < Hn) {
+            for (int e = threadIdx.x; e < 4 * 2 * W; e += 512) {
+                const int k = e / (2 * W), which = (e / W) & 1, j = e % W;
+                const int i = i0 + half * 4 + k;
+                if (j < Hn && i < D) {
                     float sum = 0.f;
 #pragma unroll
-                    for (int ww = 0; ww < 8; ++ww) sum += red[buf][ww][which][j];
+                    for (int ww = 0; ww < 8; ++ww) sum += red[ww][k][which][j];
                     atomicAdd((which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * Hn + j, sum);
                 }
             }
-            buf ^= 1;
         }
         st.lstore(wl[(cc + 1) & 1][0], wl[(cc + 1) & 1][1]);
         vcur = vnext;
