@@ -510,6 +510,128 @@ __global__ void __launch_bounds__(256) lstm2_fwd_step(LstmFwdArgs A1, LstmFwdArg
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Big-batch forward step (B >= 512): the step is a real GEMM ([B,U] x [U,4U]) and the register-direct kernel above
+// re-reads the 128 KiB weight slice once per 32 rows (82 MB of L2 traffic per step at B = 1024).  Here a block
+// owns 64 rows x 32 units (128 gate columns), streams K in 64-wide tiles through a double-buffered, XOR-swizzled
+// LDS image filled by global_load_lds (as gemm_tn_glds_kernel), 4 waves = 2 row halves x 2 k-step halves, one
+// exchange of the two k-halves through LDS, then the same gate epilogue.
+// ----------------------------------------------------------------------------------------------
+template <int ROWS>
+__device__ __forceinline__ void glds_stage_rows(const bf16_t* __restrict__ G, int ld, int rows_total, int r0, int k0, char* tile, int wave, int lane) {
+#pragma unroll
+    for (int s = 0; s < ROWS * 8 / 256; ++s) {
+        const int p = (s * 4 + wave) * 64 + lane;
+        const int row = p >> 3, pc = p & 7;
+        const int c = pc ^ ((row >> 1) & 7);
+        const int gr = min(r0 + row, rows_total - 1);
+        __builtin_amdgcn_global_load_lds((gas_ptr_t)(G + (size_t)gr * ld + k0 + c * 8), (lds_ptr_t)(tile + (s * 4 + wave) * 1024), 16, 0, 0);
+    }
+}
+
+__global__ void __launch_bounds__(256) lstm_fwd_step_v3(LstmFwdArgs A, int B) {
+    __shared__ __attribute__((aligned(16))) char smem[2][24 * 1024];      // [buffer][A 64x128 B | B 128x128 B]
+    __shared__ bf16_t sT[32][72];                                          // h tile [unit][row] for the transposed copy
+    const bf16_t* __restrict__ h_prev = A.h_prev; const bf16_t* __restrict__ wh_t = A.wh_t;
+    const float* __restrict__ xproj = A.xproj; const float* __restrict__ c_prev = A.c_prev;
+    float* __restrict__ gates = A.gates; float* __restrict__ c_out = A.c_out; bf16_t* __restrict__ h_out = A.h_out;
+    bf16_t* __restrict__ hT = A.hT;
+    const int U = A.U, N4 = 4 * U;
+    const int nt = blockIdx.x, m0 = blockIdx.y * 64, n0 = nt * 128;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave & 1, wk = wave >> 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int col = r, unit = nt * 32 + col;
+    // epilogue operands of this wave's 8 fragment rows (regs 8wk .. 8wk+7), requested first
+    float xp[8][4], cp[8];
+    bool live[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int i = 8 * wk + q;
+        const int row = m0 + 32 * wm + frag_row(i, lane);
+        live[q] = row < B;
+        const int rr = live[q] ? row : B - 1;
+        const size_t zo = (size_t)rr * N4 + n0 + col;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xp[q][g] = xproj[zo + 32 * g];
+        cp[q] = c_prev != nullptr ? c_prev[(size_t)rr * U + unit] : 0.f;
+    }
+    f32x16_t acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
+    if (h_prev != nullptr) {
+        const int nkt = U / 64;
+        glds_stage_rows<64>(h_prev, U, B, m0, 0, smem[0], wave, lane);
+        glds_stage_rows<128>(wh_t, U, N4, n0, 0, smem[0] + 8192, wave, lane);
+        __syncthreads();
+        int cur = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt + 1 < nkt) {
+                glds_stage_rows<64>(h_prev, U, B, m0, (kt + 1) * 64, smem[cur ^ 1], wave, lane);
+                glds_stage_rows<128>(wh_t, U, N4, n0, (kt + 1) * 64, smem[cur ^ 1] + 8192, wave, lane);
+            }
+            const char* sA = smem[cur];
+            const char* sB = smem[cur] + 8192;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int ks = 2 * wk + k2;
+                const int arow = wm * 32 + r;
+                const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(sA + arow * 128 + (((ks * 2 + hh) ^ ((arow >> 1) & 7)) << 4));
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int brow = g * 32 + r;
+                    const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(sB + brow * 128 + (((ks * 2 + hh) ^ ((brow >> 1) & 7)) << 4));
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[g], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    // exchange the two k-halves: wave (wm, wk) keeps fragment regs 8wk..8wk+7 and receives them from wave (wm, 1-wk)
+    float* ex = reinterpret_cast<float*>(&smem[0][0]);                     // [wave][gate][8][64] f32 = 32 KiB
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ex[((wave * 4 + g) * 8 + q) * 64 + lane] = acc[g][8 * (1 - wk) + q];
+    __syncthreads();
+    const int pw = wave ^ 2;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int i = 8 * wk + q;
+        float z[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) z[g] = xp[q][g] + (acc[g][i] + ex[((pw * 4 + g) * 8 + q) * 64 + lane]);
+        const int lrow = 32 * wm + frag_row(i, lane);
+        if (!live[q]) continue;
+        const int row = m0 + lrow;
+        const float gi = fast_sigmoid(z[0]), gg = fast_tanh(z[1]), gf = fast_sigmoid(z[2]), go = fast_sigmoid(z[3]);
+        const float c = gg * gi + cp[q] * gf;
+        const float h = fast_tanh(c) * go;
+        const size_t zo = (size_t)row * N4 + n0 + col, uo = (size_t)row * U + unit;
+        if (gates != nullptr) { gates[zo] = gi; gates[zo + 32] = gg; gates[zo + 64] = gf; gates[zo + 96] = go; }
+        c_out[uo] = c;
+        const bf16_t hb = f32_to_bf16(h);
+        h_out[uo] = hb;
+        if (hT != nullptr) sT[col][lrow] = hb;
+    }
+    if (hT != nullptr) {
+        __syncthreads();
+        const int uu = threadIdx.x >> 3, piece = threadIdx.x & 7;
+        const int row = m0 + piece * 8;
+        bf16_t* dst = hT + (size_t)(nt * 32 + uu) * A.ld_hT + A.colT + row;
+        if (row + 8 <= B && (((size_t)(A.colT + row) & 7) == 0) && ((A.ld_hT & 7) == 0)) {
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sT[uu][piece * 8]);
+        } else {
+            for (int k = 0; k < 8; ++k)
+                if (row + k < B) dst[k] = sT[uu][piece * 8 + k];
+        }
+    }
+}
+
 // backward: 8 waves, K = 4U = 128*KS.  dh = dh_ext + dz_next . Wh^T, then the gate pointwise.
 struct LstmBwdArgs {
     const bf16_t* dz_next; const bf16_t* wh_p; const float* dh_ext; const float* gates; const float* c_t; const float* c_prev;
@@ -622,6 +744,7 @@ __global__ void __launch_bounds__(512) lstm2_bwd_step(LstmBwdArgs A1, LstmBwdArg
     }
 }
 
+
 // db_p[c] += sum over columns [c0, c1) of row c of dzT (contiguous bf16 rows): the LSTM bias gradient, one pass over the
 // transposed dz the step kernels already wrote (no per-step reduction on the latency-critical chain).
 __global__ void __launch_bounds__(256) rowsum_bf16_kernel(const bf16_t* __restrict__ X, int ld, int c0, int c1, float* __restrict__ out) {
@@ -666,7 +789,8 @@ extern "C" int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int uni
             LstmFwdArgs fa{(const bf16_t*)hp, (const bf16_t*)wh_t, xp, cp, gt, ct, (bf16_t*)ht, (bf16_t*)(t + 1 < T ? hT : nullptr), units, ld_hT,
                            (t + 1) * B, 1};
 #define FWD2(KS) hipLaunchKernelGGL(lstm_fwd_step_v2<KS>, g2, dim3(256), 0, st, fa, B)
-            if (units == 512) FWD2(8); else if (units == 256) FWD2(4); else FWD2(2);
+            if (B >= 512) hipLaunchKernelGGL(lstm_fwd_step_v3, dim3(units / 32, cdiv(B, 64)), dim3(256), 0, st, fa, B);   // GEMM-shaped step
+            else if (units == 512) FWD2(8); else if (units == 256) FWD2(4); else FWD2(2);
 #undef FWD2
         } else if (dtype == MNN_BF16)
             hipLaunchKernelGGL(lstm_fwd_step_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)hp, (const bf16_t*)wh_t, xp, cp, gt, ct,
@@ -779,6 +903,8 @@ extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int uni
             LstmBwdArgs ba{(const bf16_t*)dzn, (const bf16_t*)wh_p, dh_ext + (size_t)tt * us, gates + (size_t)tt * zs, c + (size_t)tt * us, cp, dc,
                            dzt, (bf16_t*)dzTt, (bf16_t*)dzT_t, units, t == T - 1 ? 1 : 0, ld_t, t * B, 1};
 #define BWD2(KS) hipLaunchKernelGGL(lstm_bwd_step_v2<KS>, g2, dim3(512), 0, st, ba, B)
+            // (a GEMM-shaped 64x64-tile variant for B >= 512 measured SLOWER: 25 vs 17 us/step at B = 1024 -- K = 4U makes a
+            //  32-tile barrier loop on half the CUs; see profiles/round1_d_notes.md)
             if (units == 512) BWD2(16); else if (units == 256) BWD2(8); else BWD2(4);
 #undef BWD2
         } else if (dtype == MNN_BF16)

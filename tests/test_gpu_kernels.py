@@ -142,7 +142,8 @@ def _unperm(z, u):
 
 
 @pytest.mark.parametrize("dt,B,T,n_in,u", [("f32", 5, 6, 12, 32), ("f32", 70, 4, 20, 64), ("bf16", 33, 5, 16, 64),
-                                          ("bf16", 40, 3, 24, 128), ("bf16", 33, 3, 16, 256), ("bf16", 70, 3, 8, 512), ("f32", 9, 2, 8, 128)])
+                                          ("bf16", 40, 3, 24, 128), ("bf16", 33, 3, 16, 256), ("bf16", 70, 3, 8, 512), ("f32", 9, 2, 8, 128),
+                                          ("bf16", 520, 3, 8, 128), ("bf16", 640, 2, 16, 512)])
 def test_lstm_layer_fwd_bwd(ops, dt, B, T, n_in, u):
     x, W, b, (wx_t, wh_t, wh_p, wx_p, bias_p), xin, tdt = _lstm_setup(ops, B, T, n_in, u, dt)
     tol = 2e-5 if dt == "f32" else 3e-2
