@@ -143,22 +143,26 @@ def main():
     # dominant entry point and its roofline (algorithmic counts: DESIGN.md "Roofline accounting")
     dom, (dom_ms, dom_calls) = top[0]
     R1, R2 = UNITS
+    peak_mfma = PEAK_MFMA_BF16_TFLOPS if a.precision == "bf16" else 157.3
+    rec_flops = 2.0 * N * (R1 * 4 * R1 + R2 * 4 * R2)          # the T sequential [B,u]x[u,4u] products of both layers, one direction
     if dom in ("mnn_nade_logprob_bwd", "mnn_nade_logprob_fwd"):
         # NADE scan: VALU/transcendental work, almost no HBM; priced here against HBM with its algorithmic bytes
         byts = N * (D + 4 * (HN + D) * (2 if dom.endswith("bwd") else 1) + 4 * D)
-        roof = dict(bound="hbm", achieved=byts / (dom_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", traffic=None,
-                    kernel=dom, ms_per_launch=dom_ms / dom_calls,
-                    note="VALU/transcendental-bound scan (SURVEY 8d): HBM fraction shown only to show it is not the limiter")
-    else:
-        if dom == "mnn_lstm_seq_fwd":
-            flops = 2.0 * N * (R1 * 4 * R1 + R2 * 4 * R2)
-        elif dom == "mnn_lstm_seq_bwd":
-            flops = 2.0 * N * (R1 * 4 * R1 + R2 * 4 * R2)
-        else:   # all plain GEMMs of the step: input projections, dense, their dgrad + wgrad, recurrent wgrad
-            fwd = 2.0 * N * (D * 4 * R1 + R1 * 4 * R2 + R2 * (HN + D))
-            flops = 3.0 * fwd - 2.0 * N * D * 4 * R1 + 2.0 * N * (R1 * 4 * R1 + R2 * 4 * R2)
-        roof = dict(bound="mfma", achieved=flops / (dom_ms * 1e-3) / 1e12, peak=PEAK_MFMA_BF16_TFLOPS if a.precision == "bf16" else 157.3,
-                    unit="TFLOP/s", traffic=None, kernel=dom, ms_per_launch=dom_ms / dom_calls)
+        roof = dict(bound="hbm", achieved=byts / (dom_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", traffic=None, kernel=dom,
+                    launches_per_step=1, avg_launch_us=dom_ms * 1e3,
+                    note="VALU-bound scan (SURVEY 8d): the HBM fraction only shows HBM is not the limiter")
+    elif dom in ("mnn_lstm_seq_fwd", "mnn_lstm_seq_bwd", "mnn_lstm2_seq_fwd", "mnn_lstm2_seq_bwd"):
+        fused = dom.startswith("mnn_lstm2")
+        launches = (T + 16) if fused else 2 * T           # fused: one launch per timestep for both layers (+ lag)
+        roof = dict(bound="mfma", achieved=rec_flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
+                    kernel=("lstm2_%s_step" if fused else "lstm_%s_step_v2") % ("bwd" if dom.endswith("bwd") else "fwd"),
+                    launches_per_step=launches, avg_launch_us=dom_ms * 1e3 / launches,
+                    note="latency-bound chain of T sequential launches: the number to watch is avg_launch_us")
+    else:   # all plain GEMMs of the step: input projections, dense, their dgrad + wgrad, recurrent wgrad
+        fwd = 2.0 * N * (D * 4 * R1 + R1 * 4 * R2 + R2 * (HN + D))
+        flops = 3.0 * fwd - 2.0 * N * D * 4 * R1 + rec_flops
+        roof = dict(bound="mfma", achieved=flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
+                    kernel="gemm_tn_glds_kernel", launches_per_step=dom_calls, avg_launch_us=dom_ms * 1e3 / dom_calls)
     roof["frac"] = roof["achieved"] / roof["peak"]
 
     out = {

@@ -194,34 +194,42 @@ gemm_tn_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ld
 // two LDS buffers, one barrier per K-tile.  An LDS-DMA wave-instruction writes 64 lanes x 16 B = 1 KiB
 // LINEARLY (8 tile rows of 128 B), so the tile image cannot be padded; bank conflicts of the
 // ds_read_b128 fragment reads are removed by an XOR swizzle applied on the per-lane SOURCE address and
-// again on the read (cdna_hip_programming.md rule 21): 16-byte chunk c of row r lives at chunk
-// c ^ ((r >> 1) & 7).  Requires K % 64 == 0 (operands are zero-padded by the callers).
+// again on the read (cdna_hip_programming.md rule 21).  BK = 64 (128-byte tile rows) by default, BK = 128 for the
+// tall-K weight-gradient GEMMs.  Requires K % 64 == 0 (operands are zero-padded by the callers).
 // ----------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) const void* gas_ptr_t;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// CPR = 16-byte chunks per tile row (8 for BK = 64, 16 for BK = 128); swizzle: chunk c of row r lives at
+// c ^ ((r >> 1) & 7) for 128-byte rows and c ^ (r & 15) for 256-byte rows (16 rows of a ds_read_b128 group -> 16 slots).
+template <int CPR>
+__device__ __forceinline__ int swz(int row) { return CPR == 8 ? ((row >> 1) & 7) : (row & 15); }
+
+template <int CPR>
 __device__ __forceinline__ void glds_stage_tile(const bf16_t* __restrict__ G, int ld, int rows_total, int r0, int k0, char* tile, int wave,
                                                 int lane) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int p = (s * 4 + wave) * 64 + lane;          // linear 16-byte slot of the 16 KiB tile image
-        const int row = p >> 3, pc = p & 7;
-        const int c = pc ^ ((row >> 1) & 7);                // logical K chunk held by this slot
+    for (int s = 0; s < 128 * CPR / 256; ++s) {
+        const int p = (s * 4 + wave) * 64 + lane;          // linear 16-byte slot of the tile image
+        const int row = p / CPR, pc = p % CPR;
+        const int c = pc ^ swz<CPR>(row);                   // logical K chunk held by this slot
         const int gr = min(r0 + row, rows_total - 1);       // rows past the edge replicate the last row (never stored)
         __builtin_amdgcn_global_load_lds((gas_ptr_t)(G + (size_t)gr * ld + k0 + c * 8), (lds_ptr_t)(tile + (s * 4 + wave) * 1024), 16, 0, 0);
     }
 }
 
+template <int BK>
 __global__ void __launch_bounds__(256)
 gemm_tn_glds_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c_bf16,
                     const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
-    __shared__ __attribute__((aligned(16))) char smem[2][2][128 * 128];
+    constexpr int CPR = BK / 8, ROWB = BK * 2, TILE = 128 * ROWB;
+    __shared__ __attribute__((aligned(16))) char smem[2][2][TILE];
     const int bid = blockIdx.x;
     const int grp = bid / (8 * ntn), within = bid % (8 * ntn);
     const int mt = grp * 8 + (within & 7), nt = within >> 3;
     if (mt >= ntm) return;
     const int m0 = mt * 128, n0 = nt * 128;
-    const int nkt = K / 64;
+    const int nkt = K / BK;
     const int z = blockIdx.y;
     const int per = (nkt + split_k - 1) / split_k;
     const int kt0 = z * per, kt1 = min(nkt, kt0 + per);
@@ -237,29 +245,29 @@ gemm_tn_glds_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restr
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    glds_stage_tile(A, lda, M, m0, kt0 * 64, smem[0][0], wave, lane);
-    glds_stage_tile(B, ldb, N, n0, kt0 * 64, smem[0][1], wave, lane);
+    glds_stage_tile<CPR>(A, lda, M, m0, kt0 * BK, smem[0][0], wave, lane);
+    glds_stage_tile<CPR>(B, ldb, N, n0, kt0 * BK, smem[0][1], wave, lane);
     __syncthreads();                                        // hipcc drains vmcnt(0) before the barrier
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
         if (kt + 1 < kt1) {
-            glds_stage_tile(A, lda, M, m0, (kt + 1) * 64, smem[cur ^ 1][0], wave, lane);
-            glds_stage_tile(B, ldb, N, n0, (kt + 1) * 64, smem[cur ^ 1][1], wave, lane);
+            glds_stage_tile<CPR>(A, lda, M, m0, (kt + 1) * BK, smem[cur ^ 1][0], wave, lane);
+            glds_stage_tile<CPR>(B, ldb, N, n0, (kt + 1) * BK, smem[cur ^ 1][1], wave, lane);
         }
         const char* sA = smem[cur][0];
         const char* sB = smem[cur][1];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8_t a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = wm * 64 + i * 32 + r;
-                a[i] = *reinterpret_cast<const bf16x8_t*>(sA + row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4));
+                a[i] = *reinterpret_cast<const bf16x8_t*>(sA + row * ROWB + (((ks * 2 + h) ^ swz<CPR>(row)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int row = wn * 64 + j * 32 + r;
-                b[j] = *reinterpret_cast<const bf16x8_t*>(sB + row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4));
+                b[j] = *reinterpret_cast<const bf16x8_t*>(sB + row * ROWB + (((ks * 2 + h) ^ swz<CPR>(row)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -300,8 +308,9 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
     const int ngrp = cdiv(ntm, 8);
     dim3 grid(ngrp * 8 * ntn, split_k);
     if constexpr (sizeof(T) == 2) {
+        // (BK = 128 for the tall-K weight-gradient GEMMs was measured slower: C2 1.28 -> 1.54 ms, 1 block/CU at 128 KiB LDS)
         if (K % 64 == 0) {
-            hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, c_bf16, bias, M,
+            hipLaunchKernelGGL(gemm_tn_glds_kernel<64>, grid, dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, c_bf16, bias, M,
                                N, K, flags, split_k, ntm, ntn);
             MNN_LAUNCH_CHECK();
             return MNN_OK;
@@ -920,7 +929,8 @@ extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int uni
     if (t_begin == 0 && dc0 != nullptr) MNN_HIP(hipMemcpyAsync(dc0, dc, us * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (v2 && db_p != nullptr) {
         MNN_REQUIRE(dzT_t != nullptr, "mnn_lstm_seq_bwd: db_p needs dzT_t on the fused path");
-        hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(4 * units), dim3(256), 0, st, (const bf16_t*)dzT_t, ld_t, t_begin * B, t_end * B, db_p);
+        if (t_begin == 0)      // calls cover the sequence from the top down: the t_begin == 0 call is the last one
+            hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(4 * units), dim3(256), 0, st, (const bf16_t*)dzT_t, ld_t, 0, T * B, db_p);
         MNN_LAUNCH_CHECK();
     }
     if (!v2) {                             // generic path: separate transpose / column-sum kernels for the steps of this call
@@ -1036,13 +1046,11 @@ extern "C" int mnn_lstm2_seq_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bw
         else launch_bwd2<4>(st, grid, a1, a2, B, L2->units);
     }
     MNN_LAUNCH_CHECK();
-    // bias gradients: row sums of dz^T over the steps each layer finished in this call
-    const int lo2 = max(0, T - k_end), hi2 = min(T, T - k_begin);
-    const int lo1 = max(0, T - k_end + lag), hi1 = min(T, T - k_begin + lag);
-    if (L2->db_p && hi2 > lo2)
-        hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(4 * L2->units), dim3(256), 0, st, (const bf16_t*)L2->dzT_t, L2->ld_t, lo2 * B, hi2 * B, L2->db_p);
-    if (L1->db_p && hi1 > lo1)
-        hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(4 * L1->units), dim3(256), 0, st, (const bf16_t*)L1->dzT_t, L1->ld_t, lo1 * B, hi1 * B, L1->db_p);
+    // bias gradients: ONE row-sum pass over dz^T per layer, when that layer has finished its last (t = 0) step
+    if (L2->db_p && k_begin < T && k_end >= T)
+        hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(4 * L2->units), dim3(256), 0, st, (const bf16_t*)L2->dzT_t, L2->ld_t, 0, T * B, L2->db_p);
+    if (L1->db_p && k_end == T + lag)
+        hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(4 * L1->units), dim3(256), 0, st, (const bf16_t*)L1->dzT_t, L1->ld_t, 0, T * B, L1->db_p);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

@@ -35,7 +35,7 @@ def rel(a, b):
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 88), (1, 696, 256), (333, 2048, 440), (64, 40, 8), (300, 130, 448), (129, 257, 1024)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 88), (1, 696, 256), (333, 2048, 440), (64, 40, 8), (300, 130, 448), (129, 257, 1024), (200, 300, 8192)])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_gemm_tn(ops, M, N, K, dt):
     R = np.random.default_rng(M * 7 + N)
@@ -50,7 +50,7 @@ def test_gemm_tn(ops, M, N, K, dt):
     ref = Ar @ Br.T + bias
     C = torch.full((M, N), 7.0, device=DEV)
     ops.gemm_tn(At, Bt, C, bias=dev(bias))
-    assert rel(C.cpu().numpy(), ref) < (2e-6 if dt == "f32" else 1e-5)      # products of bf16 inputs are exact in f32
+    assert rel(C.cpu().numpy(), ref) < (2e-6 if dt == "f32" else 1e-5) * max(1, K // 1024)      # products of bf16 inputs are exact in f32
     C2 = torch.ones((M, N), device=DEV)
     ops.gemm_tn(At, Bt, C2, accumulate=True)
     assert rel(C2.cpu().numpy(), Ar @ Br.T + 1.0) < 1e-5
