@@ -103,7 +103,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = world == 1 and not a.no_graph          # one hipGraph replay per step (the recurrences are ~600 launches)
+    use_graph = not a.no_graph          # hipGraph replay of the step (N>1: forward+backward | eager all-reduce | clip+Adam)
     for _ in range(a.warmup):
         gen.train_step(x, None, opt)
     step_fn = gen.graphed_train_step(x, opt, warmup=1) if use_graph else (lambda: gen.train_step(x, None, opt))
@@ -153,9 +153,9 @@ def main():
                     note="VALU-bound scan (SURVEY 8d): the HBM fraction only shows HBM is not the limiter")
     elif dom in ("mnn_lstm_seq_fwd", "mnn_lstm_seq_bwd", "mnn_lstm2_seq_fwd", "mnn_lstm2_seq_bwd"):
         fused = dom.startswith("mnn_lstm2")
-        launches = (T + 16) if fused else 2 * T           # fused: one launch per timestep for both layers (+ lag)
+        launches = (T + 2) if fused else 2 * T            # fused: one three-stage launch per timestep for both layers (lag 2)
         roof = dict(bound="mfma", achieved=rec_flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
-                    kernel=("lstm2_%s_step" if fused else "lstm_%s_step_v2") % ("bwd" if dom.endswith("bwd") else "fwd"),
+                    kernel=("lstm3_%s_step" if fused else "lstm_%s_step_v2") % ("bwd" if dom.endswith("bwd") else "fwd"),
                     launches_per_step=launches, avg_launch_us=dom_ms * 1e3 / launches,
                     note="latency-bound chain of T sequential launches: the number to watch is avg_launch_us")
     else:   # all plain GEMMs of the step: input projections, dense, their dgrad + wgrad, recurrent wgrad

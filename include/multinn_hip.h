@@ -124,20 +124,23 @@ int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int units, int t_b
                      void* dz_T /* T copy of dz or NULL */, float* dh0, float* dc0, void* workspace, void* dzT_t, int ld_t,
                      float* db_p);
 
-/* Two-layer wavefront (bf16, both layers' units in {128,256,512}).  Launch index s of the forward entry runs
- * layer 1's step s (if s < T) and layer 2's step s - lag (if >= 0) in ONE kernel, s in [s_begin, s_end) within
- * [0, T+lag); the backward entry's launch k runs layer 2's step T-1-k and layer 1's step T-1-k+lag.  Between
- * chunks of `lag` launches the caller computes layer 2's xproj for the chunk layer 1 finished (forward) or layer
- * 1's dh_ext for the chunk layer 2 finished (backward).  Pointers as in mnn_lstm_seq_fwd / _bwd; backward needs
- * no f32 dz, no dh0/dc0. */
+/* Two-layer wavefront (bf16, both layers' units in {128,256,512}): ONE launch per timestep for the whole stack,
+ * three stages, lag 2.  Forward launch s in [0, T+2): layer-1 step s | layer-2 input projection of step s-1
+ * (xproj2 = y1 . Wx2 + b2, written into L2->xproj) | layer-2 step s-2.  Backward launch k in [0, T+2): layer-2 step
+ * T-1-k | layer-1 incoming gradient of step T-k (dh1 = (dz2 . Wx2^T) * keep/kp, written into L1->dh_ext) | layer-1
+ * step T+1-k.  Dropout (rnn.py:132) uses keep masks precomputed by mnn_dropout_mask (u8 [T,B,u], same Philox
+ * counters as mnn_dropout_fwd); y = h/kp*mask is written by the step kernels.  Other pointers as in
+ * mnn_lstm_seq_fwd / _bwd; backward needs no f32 dz, no dh0/dc0. */
 typedef struct { int units; const float* xproj; const void* wh_t; const void* h0; const float* c0; float* gates; float* c; void* h;
-                 void* hT; int ld_hT; } mnn_lstm_fwd_layer;
+                 void* hT; int ld_hT; void* y; const uint8_t* mask; const void* wx_t; int ld_w; const float* bias_p; } mnn_lstm_fwd_layer;
 typedef struct { int units; const float* dh_ext; const void* wh_p; const float* gates; const float* c; const float* c0; float* dz;
-                 void* dz_T; void* workspace; void* dzT_t; int ld_t; float* db_p; } mnn_lstm_bwd_layer;
-int mnn_lstm2_seq_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L1, const mnn_lstm_fwd_layer* L2, int lag,
+                 void* dz_T; void* workspace; void* dzT_t; int ld_t; float* db_p; const uint8_t* mask; const void* wx_p; } mnn_lstm_bwd_layer;
+int mnn_lstm2_seq_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L1, const mnn_lstm_fwd_layer* L2, float keep_prob,
                       int s_begin, int s_end);
-int mnn_lstm2_seq_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L1, const mnn_lstm_bwd_layer* L2, int lag,
+int mnn_lstm2_seq_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L1, const mnn_lstm_bwd_layer* L2, float keep_prob,
                       int k_begin, int k_end);
+int mnn_dropout_mask(mnn_stream_t s, uint8_t* mask, int T, int B, int units, float keep_prob, uint64_t seed, const int32_t* step_dev,
+                     uint32_t row0, int layer);
 
 /* Output dropout of DropoutWrapper (rnn.py:132): y = h/kp * floor(kp+u), u = Philox(stream 0,
  * row = row0+b, sub = (t<<8)|layer, elem = unit).  h,y T [T,B,u].  kp>=1 -> copy.

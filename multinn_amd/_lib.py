@@ -48,16 +48,18 @@ SIGNATURES = {
 }
 
 class LstmFwdLayer(C.Structure):
-    _fields_ = [("units", _i), ("xproj", _p), ("wh_t", _p), ("h0", _p), ("c0", _p), ("gates", _p), ("c", _p), ("h", _p), ("hT", _p), ("ld_hT", _i)]
+    _fields_ = [("units", _i), ("xproj", _p), ("wh_t", _p), ("h0", _p), ("c0", _p), ("gates", _p), ("c", _p), ("h", _p), ("hT", _p), ("ld_hT", _i), ("y", _p), ("mask", _p),
+                ("wx_t", _p), ("ld_w", _i), ("bias_p", _p)]
 
 
 class LstmBwdLayer(C.Structure):
     _fields_ = [("units", _i), ("dh_ext", _p), ("wh_p", _p), ("gates", _p), ("c", _p), ("c0", _p), ("dz", _p), ("dz_T", _p), ("workspace", _p),
-                ("dzT_t", _p), ("ld_t", _i), ("db_p", _p)]
+                ("dzT_t", _p), ("ld_t", _i), ("db_p", _p), ("mask", _p), ("wx_p", _p)]
 
 
-SIGNATURES["mnn_lstm2_seq_fwd"] = (_i, [_p, _i, _i, C.POINTER(LstmFwdLayer), C.POINTER(LstmFwdLayer), _i, _i, _i])
-SIGNATURES["mnn_lstm2_seq_bwd"] = (_i, [_p, _i, _i, C.POINTER(LstmBwdLayer), C.POINTER(LstmBwdLayer), _i, _i, _i])
+SIGNATURES["mnn_lstm2_seq_fwd"] = (_i, [_p, _i, _i, C.POINTER(LstmFwdLayer), C.POINTER(LstmFwdLayer), _f, _i, _i])
+SIGNATURES["mnn_lstm2_seq_bwd"] = (_i, [_p, _i, _i, C.POINTER(LstmBwdLayer), C.POINTER(LstmBwdLayer), _f, _i, _i])
+SIGNATURES["mnn_dropout_mask"] = (_i, [_p, _p, _i, _i, _i, _f, _u64, _p, _u32, _i])
 
 _lib = None
 

@@ -270,6 +270,35 @@ extern "C" int mnn_dropout_fwd(mnn_stream_t s, int dtype, const void* h, void* y
     return MNN_OK;
 }
 
+// keep flags of DropoutWrapper for a whole sequence, mask[t,b,j] = floor(kp + u) in {0,1} (same Philox counters as
+// mnn_dropout_fwd), so the fused step kernels can apply dropout with one load instead of a Philox call on the
+// latency-critical chain
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ mask, int Tn, int B, int U, float kp, uint64_t seed, const int32_t* __restrict__ step_dev,
+                                    uint32_t row0, int layer) {
+    if (step_dev != nullptr) seed += (uint64_t)step_dev[0];
+    const int U4 = U >> 2;
+    const long total = (long)Tn * B * U4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % U4);
+        const long tb = i / U4;
+        const int b = (int)(tb % B), t = (int)(tb / B);
+        float u[4];
+        philox_uniform4(seed, MNN_STREAM_DROPOUT, row0 + (uint32_t)b, ((uint32_t)t << 8) | (uint32_t)layer, (uint32_t)q, u);
+        uchar4 k;
+        k.x = (uint8_t)floorf(kp + u[0]); k.y = (uint8_t)floorf(kp + u[1]); k.z = (uint8_t)floorf(kp + u[2]); k.w = (uint8_t)floorf(kp + u[3]);
+        *reinterpret_cast<uchar4*>(mask + (size_t)tb * U + q * 4) = k;
+    }
+}
+
+extern "C" int mnn_dropout_mask(mnn_stream_t s, uint8_t* mask, int T, int B, int units, float keep_prob, uint64_t seed, const int32_t* step_dev,
+                                uint32_t row0, int layer) {
+    MNN_REQUIRE(mask && T > 0 && B > 0 && units > 0 && units % 4 == 0 && keep_prob > 0.f && keep_prob < 1.f, "mnn_dropout_mask: bad arguments");
+    const int blocks = (int)min((long)4096, ((long)T * B * units / 4 + 255) / 256);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, mask, T, B, units, keep_prob, seed, step_dev, row0, layer);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
 __global__ void dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dh, int Tn, int B, int U, float kp, uint64_t seed,
                                    const int32_t* __restrict__ step_dev, uint32_t row0, int layer, int accumulate, int t_offset) {
     if (step_dev != nullptr) seed += (uint64_t)step_dev[0];

@@ -414,6 +414,7 @@ struct LstmFwdArgs {
     const bf16_t* h_prev; const bf16_t* wh_t; const float* xproj; const float* c_prev;
     float* gates; float* c_out; bf16_t* h_out; bf16_t* hT;
     int U, ld_hT, colT, active;
+    bf16_t* y_out; const uint8_t* mask; float kp;      // optional dropped output y = h/kp*mask (DropoutWrapper, rnn.py:132) with a precomputed keep mask
 };
 
 template <int KS>
@@ -479,6 +480,7 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgs& A, int B, int b
         c_out[uo] = c;
         const bf16_t hb = f32_to_bf16(h);
         h_out[uo] = hb;
+        if (A.y_out != nullptr) A.y_out[uo] = f32_to_bf16(bf16_to_f32(hb) / A.kp * (float)A.mask[uo]);
         if (hT != nullptr) sT[col][8 * w + q + 4 * hh] = hb;
     }
     if (hT != nullptr) {                    // hT[unit][colT + row]: 32 units x 64-byte row segments (weight-gradient operand)
@@ -504,21 +506,70 @@ __global__ void __launch_bounds__(256) lstm_fwd_step_v2(LstmFwdArgs A, int B) {
     lstm_fwd_body<KS>(A, B, blockIdx.x, blockIdx.y, red, sT);
 }
 
-// Two layers in ONE launch (layer wavefront): blocks [0, U1/32) run layer 1's step, the rest layer 2's (an earlier)
-// step.  The two bodies are independent, so the second chain hides behind the first and half the kernel
-// boundaries of the sequential form disappear.
-template <int KS1, int KS2>
-__global__ void __launch_bounds__(256) lstm2_fwd_step(LstmFwdArgs A1, LstmFwdArgs A2, int B) {
-    __shared__ float red[4][4][16][64];
-    __shared__ bf16_t sT[32][40];
-    const int nb1 = A1.U / 32;
-    if ((int)blockIdx.x < nb1) {
-        if (A1.active) lstm_fwd_body<KS1>(A1, B, blockIdx.x, blockIdx.y, red, sT);
-    } else {
-        if (A2.active) lstm_fwd_body<KS2>(A2, B, blockIdx.x - nb1, blockIdx.y, red, sT);
+// Stage P of the three-stage wavefront: layer 2's input projection for ONE timestep,
+// out[B,4U2] = y[B,U1] . Wx2^T + bias (gate-interleaved columns).  Same structure as the step body: 32 rows x 128
+// columns per block, K split over the 4 waves, operands straight to registers, one LDS reduction.
+struct LstmProjArgs {
+    const bf16_t* y; const bf16_t* wx_t; const float* bias_p; float* out;
+    int K, ld_w, N4, active;
+};
+
+template <int KS>
+__device__ __forceinline__ void lstm_proj_body(const LstmProjArgs& A, int B, int bx, int by, float (&red)[4][4][16][64]) {
+    const int m0 = by * 32, n0 = bx * 128;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    f32x16_t acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
+    {
+        const int kb = w * 16 * KS + hh * 8 * KS;
+        const int arow = min(m0 + r, B - 1);
+        bf16x8_t a[KS], b[4][KS];
+        load_frags<KS>(A.y + (size_t)arow * A.K + kb, a);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) load_frags<KS>(A.wx_t + (size_t)(n0 + 32 * g + r) * A.ld_w + kb, b[g]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[g][s], acc[g], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[w][g][i][lane] = acc[g][i];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = 4 * w + q;
+        const int row = m0 + 8 * w + q + 4 * hh;
+        if (row >= B) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = n0 + 32 * g + r;
+            A.out[(size_t)row * A.N4 + col] = A.bias_p[col] + ((red[0][g][i][lane] + red[1][g][i][lane]) + (red[2][g][i][lane] + red[3][g][i][lane]));
+        }
     }
 }
 
+// Three-stage forward wavefront, lag 2: launch s = layer-1 step s | layer-2 projection of step s-1 | layer-2 step s-2.
+template <int KS1, int KS2>
+__global__ void __launch_bounds__(256) lstm3_fwd_step(LstmFwdArgs A1, LstmProjArgs P, LstmFwdArgs A2, int B) {
+    __shared__ float red[4][4][16][64];
+    __shared__ bf16_t sT[32][40];
+    const int nb1 = A1.U / 32, nb2 = A2.U / 32;
+    const int bx = blockIdx.x;
+    if (bx < nb1) {
+        if (A1.active) lstm_fwd_body<KS1>(A1, B, bx, blockIdx.y, red, sT);
+    } else if (bx < nb1 + nb2) {
+        if (P.active) lstm_proj_body<KS1>(P, B, bx - nb1, blockIdx.y, red);
+    } else {
+        if (A2.active) lstm_fwd_body<KS2>(A2, B, bx - nb1 - nb2, blockIdx.y, red, sT);
+    }
+}
 
 // ----------------------------------------------------------------------------------------------
 // Big-batch forward step (B >= 512): the step is a real GEMM ([B,U] x [U,4U]) and the register-direct kernel above
@@ -741,18 +792,66 @@ __global__ void __launch_bounds__(512) lstm_bwd_step_v2(LstmBwdArgs A, int B) {
     lstm_bwd_body<KS>(A, B, blockIdx.x, blockIdx.y, red, sT);
 }
 
-template <int KS1, int KS2>
-__global__ void __launch_bounds__(512) lstm2_bwd_step(LstmBwdArgs A1, LstmBwdArgs A2, int B) {
-    __shared__ float red[8][16][64];
-    __shared__ bf16_t sT[4][32][40];
-    const int nb1 = A1.U / 32;
-    if ((int)blockIdx.x < nb1) {
-        if (A1.active) lstm_bwd_body<KS1>(A1, B, blockIdx.x, blockIdx.y, red, sT);
-    } else {
-        if (A2.active) lstm_bwd_body<KS2>(A2, B, blockIdx.x - nb1, blockIdx.y, red, sT);
+
+// Stage Q of the three-stage backward wavefront: layer 1's incoming gradient for ONE timestep,
+// dh1[B,U1] = (dz2[B,4U2] . Wx2) * keep/kp  (the dgrad of layer 2's input projection through the dropout of
+// rnn.py:132).  32 rows x 32 units per block, K = 4U2 split over the 8 waves, one LDS reduction.
+struct LstmDgradArgs {
+    const bf16_t* dz; const bf16_t* wx_p; const uint8_t* mask; float* out;
+    int K, U, active; float kp;
+};
+
+template <int KS>
+__device__ __forceinline__ void lstm_dgrad_body(const LstmDgradArgs& A, int B, int bx, int by, float (&red)[8][16][64]) {
+    const int m0 = by * 32, n0 = bx * 32;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int unit = n0 + r;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    {
+        const int kb = w * 16 * KS + hh * 8 * KS;
+        const int arow = min(m0 + r, B - 1);
+        bf16x8_t a[KS], b[KS];
+        load_frags<KS>(A.dz + (size_t)arow * A.K + kb, a);
+        load_frags<KS>(A.wx_p + (size_t)unit * A.K + kb, b);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[w][i][lane] = acc[i];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = 2 * w + q;
+        const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        float sum = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) sum += red[ww][i][lane];
+        if (row >= B) continue;
+        const size_t uo = (size_t)row * A.U + unit;
+        A.out[uo] = A.mask != nullptr ? sum / A.kp * (float)A.mask[uo] : sum;
     }
 }
 
+// Three-stage backward wavefront, lag 2: launch k = layer-2 step T-1-k | layer-1 incoming gradient of step T-k |
+// layer-1 step T+1-k.
+template <int KS1, int KS2>
+__global__ void __launch_bounds__(512) lstm3_bwd_step(LstmBwdArgs A1, LstmDgradArgs Q, LstmBwdArgs A2, int B) {
+    __shared__ float red[8][16][64];
+    __shared__ bf16_t sT[4][32][40];
+    const int nb1 = A1.U / 32, nb2 = A2.U / 32;
+    const int bx = blockIdx.x;
+    if (bx < nb2) {
+        if (A2.active) lstm_bwd_body<KS2>(A2, B, bx, blockIdx.y, red, sT);
+    } else if (bx < nb2 + nb1) {
+        if (Q.active) lstm_dgrad_body<KS2>(Q, B, bx - nb2, blockIdx.y, red);
+    } else {
+        if (A1.active) lstm_bwd_body<KS1>(A1, B, bx - nb2 - nb1, blockIdx.y, red, sT);
+    }
+}
 
 // db_p[c] += sum over columns [c0, c1) of row c of dzT (contiguous bf16 rows): the LSTM bias gradient, one pass over the
 // transposed dz the step kernels already wrote (no per-step reduction on the latency-critical chain).
@@ -946,25 +1045,26 @@ extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int uni
 }
 
 // ----------------------------------------------------------------------------------------------
-// Two-layer wavefront entries (bf16, units in {128,256,512}): launch s runs layer 1's step s and layer 2's step
-// s - lag in ONE kernel; between chunks of `lag` launches the caller inserts layer 2's batched input projection
-// for the chunk layer 1 has just finished (forward) / layer 1's input-gradient GEMM + dropout for the chunk
-// layer 2 has just finished (backward).
+// Two-layer wavefront entries (bf16, units in {128,256,512}), three stages per launch, lag 2:
+//   forward  launch s: layer-1 step s | layer-2 input projection of step s-1 | layer-2 step s-2      s in [0, T+2)
+//   backward launch k: layer-2 step T-1-k | layer-1 incoming gradient of step T-k | layer-1 step T+1-k
+// One launch per timestep for the whole stack: half the kernel boundaries of the per-layer form, the second chain
+// hidden behind the first, no per-chunk host work.
 // ----------------------------------------------------------------------------------------------
 template <int K1>
-static void launch_fwd2(hipStream_t st, dim3 grid, const LstmFwdArgs& a1, const LstmFwdArgs& a2, int B, int u2) {
-    if (u2 == 512) hipLaunchKernelGGL((lstm2_fwd_step<K1, 8>), grid, dim3(256), 0, st, a1, a2, B);
-    else if (u2 == 256) hipLaunchKernelGGL((lstm2_fwd_step<K1, 4>), grid, dim3(256), 0, st, a1, a2, B);
-    else hipLaunchKernelGGL((lstm2_fwd_step<K1, 2>), grid, dim3(256), 0, st, a1, a2, B);
+static void launch_fwd3(hipStream_t st, dim3 grid, const LstmFwdArgs& a1, const LstmProjArgs& p, const LstmFwdArgs& a2, int B, int u2) {
+    if (u2 == 512) hipLaunchKernelGGL((lstm3_fwd_step<K1, 8>), grid, dim3(256), 0, st, a1, p, a2, B);
+    else if (u2 == 256) hipLaunchKernelGGL((lstm3_fwd_step<K1, 4>), grid, dim3(256), 0, st, a1, p, a2, B);
+    else hipLaunchKernelGGL((lstm3_fwd_step<K1, 2>), grid, dim3(256), 0, st, a1, p, a2, B);
 }
 template <int K1>
-static void launch_bwd2(hipStream_t st, dim3 grid, const LstmBwdArgs& a1, const LstmBwdArgs& a2, int B, int u2) {
-    if (u2 == 512) hipLaunchKernelGGL((lstm2_bwd_step<K1, 16>), grid, dim3(512), 0, st, a1, a2, B);
-    else if (u2 == 256) hipLaunchKernelGGL((lstm2_bwd_step<K1, 8>), grid, dim3(512), 0, st, a1, a2, B);
-    else hipLaunchKernelGGL((lstm2_bwd_step<K1, 4>), grid, dim3(512), 0, st, a1, a2, B);
+static void launch_bwd3(hipStream_t st, dim3 grid, const LstmBwdArgs& a1, const LstmDgradArgs& q, const LstmBwdArgs& a2, int B, int u2) {
+    if (u2 == 512) hipLaunchKernelGGL((lstm3_bwd_step<K1, 16>), grid, dim3(512), 0, st, a1, q, a2, B);
+    else if (u2 == 256) hipLaunchKernelGGL((lstm3_bwd_step<K1, 8>), grid, dim3(512), 0, st, a1, q, a2, B);
+    else hipLaunchKernelGGL((lstm3_bwd_step<K1, 4>), grid, dim3(512), 0, st, a1, q, a2, B);
 }
 
-static LstmFwdArgs make_fwd_args(const mnn_lstm_fwd_layer* L, int T, int B, int t) {
+static LstmFwdArgs make_fwd_args(const mnn_lstm_fwd_layer* L, int T, int B, int t, float kp) {
     LstmFwdArgs a{};
     a.U = L->units;
     a.active = (t >= 0 && t < T) ? 1 : 0;
@@ -980,25 +1080,44 @@ static LstmFwdArgs make_fwd_args(const mnn_lstm_fwd_layer* L, int T, int B, int 
     a.hT = (t + 1 < T) ? (bf16_t*)L->hT : nullptr;
     a.ld_hT = L->ld_hT;
     a.colT = (t + 1) * B;
+    if (L->mask != nullptr) {
+        a.y_out = (bf16_t*)L->y + (size_t)t * us;
+        a.mask = L->mask + (size_t)t * us;
+        a.kp = kp;
+    }
     return a;
 }
 
-extern "C" int mnn_lstm2_seq_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L1, const mnn_lstm_fwd_layer* L2, int lag, int s_begin,
-                                 int s_end) {
+extern "C" int mnn_lstm2_seq_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L1, const mnn_lstm_fwd_layer* L2, float keep_prob,
+                                 int s_begin, int s_end) {
     hipStream_t st = (hipStream_t)s;
-    MNN_REQUIRE(L1 && L2 && T > 0 && B > 0 && lag > 0, "mnn_lstm2_seq_fwd: bad arguments");
+    MNN_REQUIRE(L1 && L2 && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm2_seq_fwd: bad arguments");
     MNN_REQUIRE(lstm_v2_ok(MNN_BF16, L1->units) && lstm_v2_ok(MNN_BF16, L2->units), "mnn_lstm2_seq_fwd: units must be 128/256/512 (bf16)");
-    MNN_REQUIRE(0 <= s_begin && s_begin < s_end && s_end <= T + lag, "mnn_lstm2_seq_fwd: bad launch range [%d,%d) of %d", s_begin, s_end, T + lag);
+    MNN_REQUIRE(0 <= s_begin && s_begin < s_end && s_end <= T + 2, "mnn_lstm2_seq_fwd: bad launch range [%d,%d) of %d", s_begin, s_end, T + 2);
     for (const mnn_lstm_fwd_layer* L : {L1, L2}) {
         MNN_REQUIRE(L->xproj && L->wh_t && L->c && L->h, "mnn_lstm2_seq_fwd: null pointer");
         MNN_REQUIRE(L->hT == nullptr || L->ld_hT >= T * B, "mnn_lstm2_seq_fwd: ld_hT too small");
+        MNN_REQUIRE((L->mask == nullptr) == (keep_prob >= 1.0f) && (L->mask == nullptr || L->y != nullptr),
+                    "mnn_lstm2_seq_fwd: a keep mask and a y buffer are needed exactly when keep_prob < 1");
     }
-    dim3 grid(L1->units / 32 + L2->units / 32, cdiv(B, 32));
+    MNN_REQUIRE(L2->wx_t && L2->bias_p && L2->ld_w >= L1->units, "mnn_lstm2_seq_fwd: layer 2 needs its input-projection weights");
+    const size_t us1 = (size_t)B * L1->units;
+    dim3 grid(L1->units / 32 + 2 * (L2->units / 32), cdiv(B, 32));
     for (int si = s_begin; si < s_end; ++si) {
-        const LstmFwdArgs a1 = make_fwd_args(L1, T, B, si), a2 = make_fwd_args(L2, T, B, si - lag);
-        if (L1->units == 512) launch_fwd2<8>(st, grid, a1, a2, B, L2->units);
-        else if (L1->units == 256) launch_fwd2<4>(st, grid, a1, a2, B, L2->units);
-        else launch_fwd2<2>(st, grid, a1, a2, B, L2->units);
+        const LstmFwdArgs a1 = make_fwd_args(L1, T, B, si, keep_prob), a2 = make_fwd_args(L2, T, B, si - 2, keep_prob);
+        LstmProjArgs p{};
+        const int tp = si - 1;
+        p.active = (tp >= 0 && tp < T) ? 1 : 0;
+        if (p.active) {
+            p.y = (const bf16_t*)(L1->mask ? L1->y : L1->h) + (size_t)tp * us1;
+            p.wx_t = (const bf16_t*)L2->wx_t;
+            p.bias_p = L2->bias_p;
+            p.out = const_cast<float*>(L2->xproj) + (size_t)tp * B * 4 * L2->units;
+            p.K = L1->units; p.ld_w = L2->ld_w; p.N4 = 4 * L2->units;
+        }
+        if (L1->units == 512) launch_fwd3<8>(st, grid, a1, p, a2, B, L2->units);
+        else if (L1->units == 256) launch_fwd3<4>(st, grid, a1, p, a2, B, L2->units);
+        else launch_fwd3<2>(st, grid, a1, p, a2, B, L2->units);
     }
     MNN_LAUNCH_CHECK();
     return MNN_OK;
@@ -1026,30 +1145,42 @@ static LstmBwdArgs make_bwd_args(const mnn_lstm_bwd_layer* L, int T, int B, int 
     return a;
 }
 
-extern "C" int mnn_lstm2_seq_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L1, const mnn_lstm_bwd_layer* L2, int lag, int k_begin,
-                                 int k_end) {
+extern "C" int mnn_lstm2_seq_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L1, const mnn_lstm_bwd_layer* L2, float keep_prob,
+                                 int k_begin, int k_end) {
     hipStream_t st = (hipStream_t)s;
-    MNN_REQUIRE(L1 && L2 && T > 0 && B > 0 && lag > 0, "mnn_lstm2_seq_bwd: bad arguments");
+    MNN_REQUIRE(L1 && L2 && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm2_seq_bwd: bad arguments");
     MNN_REQUIRE(lstm_v2_ok(MNN_BF16, L1->units) && lstm_v2_ok(MNN_BF16, L2->units), "mnn_lstm2_seq_bwd: units must be 128/256/512 (bf16)");
-    MNN_REQUIRE(0 <= k_begin && k_begin < k_end && k_end <= T + lag, "mnn_lstm2_seq_bwd: bad launch range [%d,%d) of %d", k_begin, k_end, T + lag);
+    MNN_REQUIRE(0 <= k_begin && k_begin < k_end && k_end <= T + 2, "mnn_lstm2_seq_bwd: bad launch range [%d,%d) of %d", k_begin, k_end, T + 2);
     for (const mnn_lstm_bwd_layer* L : {L1, L2}) {
         MNN_REQUIRE(L->dh_ext && L->wh_p && L->gates && L->c && L->dz_T && L->workspace, "mnn_lstm2_seq_bwd: null pointer");
         MNN_REQUIRE(L->dzT_t == nullptr || L->ld_t >= T * B, "mnn_lstm2_seq_bwd: ld_t too small");
         MNN_REQUIRE(L->db_p == nullptr || L->dzT_t != nullptr, "mnn_lstm2_seq_bwd: db_p needs dzT_t");
     }
-    dim3 grid(L1->units / 32 + L2->units / 32, cdiv(B, 32));
+    MNN_REQUIRE(L2->wx_p != nullptr, "mnn_lstm2_seq_bwd: layer 2 needs wx_p (its input weights, [u1, 4u2])");
+    MNN_REQUIRE((L1->mask == nullptr) == (keep_prob >= 1.0f), "mnn_lstm2_seq_bwd: layer 1's keep mask is needed exactly when keep_prob < 1");
+    const size_t us1 = (size_t)B * L1->units;
+    dim3 grid(2 * (L1->units / 32) + L2->units / 32, cdiv(B, 32));
     for (int k = k_begin; k < k_end; ++k) {
-        // the top layer (L2) leads; layer 1 follows `lag` launches later
-        const LstmBwdArgs a1 = make_bwd_args(L1, T, B, T - 1 - k + lag), a2 = make_bwd_args(L2, T, B, T - 1 - k);
-        if (L1->units == 512) launch_bwd2<16>(st, grid, a1, a2, B, L2->units);
-        else if (L1->units == 256) launch_bwd2<8>(st, grid, a1, a2, B, L2->units);
-        else launch_bwd2<4>(st, grid, a1, a2, B, L2->units);
+        const LstmBwdArgs a2 = make_bwd_args(L2, T, B, T - 1 - k), a1 = make_bwd_args(L1, T, B, T + 1 - k);
+        LstmDgradArgs q{};
+        const int tq = T - k;
+        q.active = (tq >= 0 && tq < T) ? 1 : 0;
+        if (q.active) {
+            q.dz = (const bf16_t*)L2->dz_T + (size_t)tq * B * 4 * L2->units;
+            q.wx_p = (const bf16_t*)L2->wx_p;
+            q.mask = L1->mask ? L1->mask + (size_t)tq * us1 : nullptr;
+            q.out = const_cast<float*>(L1->dh_ext) + (size_t)tq * us1;
+            q.K = 4 * L2->units; q.U = L1->units; q.kp = keep_prob;
+        }
+        if (L1->units == 512) launch_bwd3<16>(st, grid, a1, q, a2, B, L2->units);
+        else if (L1->units == 256) launch_bwd3<8>(st, grid, a1, q, a2, B, L2->units);
+        else launch_bwd3<4>(st, grid, a1, q, a2, B, L2->units);
     }
     MNN_LAUNCH_CHECK();
     // bias gradients: ONE row-sum pass over dz^T per layer, when that layer has finished its last (t = 0) step
     if (L2->db_p && k_begin < T && k_end >= T)
         hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(4 * L2->units), dim3(256), 0, st, (const bf16_t*)L2->dzT_t, L2->ld_t, 0, T * B, L2->db_p);
-    if (L1->db_p && k_end == T + lag)
+    if (L1->db_p && k_end == T + 2)
         hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(4 * L1->units), dim3(256), 0, st, (const bf16_t*)L1->dzT_t, L1->ld_t, 0, T * B, L1->db_p);
     MNN_LAUNCH_CHECK();
     return MNN_OK;

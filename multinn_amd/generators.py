@@ -130,21 +130,20 @@ class LstmStack:
         p0, b0 = self.packed[0], bufs[0]
         ops.gemm_tn(x_tm.view(T * B, -1), p0["wx_t"], b0["xproj"].view(T * B, -1), bias=p0["bias_p"])
         if self._fused2(B):
-            # two-layer wavefront inside single launches: launch s = layer 0 step s + layer 1 step s - lag
+            # ONE launch per timestep for the whole stack: layer-0 step s | layer-1 projection s-1 | layer-1 step s-2
             p1, b1 = self.packed[1], bufs[1]
-            lag = self.chunk
-            d0 = ops.lstm2_fwd_layer(b0["xproj"], p0["wh_t"], b0["h0"], b0["c0"], b0["gates"], b0["c"], b0["h"], b0["hT"])
-            d1 = ops.lstm2_fwd_layer(b1["xproj"], p1["wh_t"], b1["h0"], b1["c0"], b1["gates"], b1["c"], b1["h"], b1["hT"])
-            for s0 in range(0, T + lag, lag):
-                s1 = min(s0 + lag, T + lag)
-                ops.lstm2_seq_fwd(T, B, d0, d1, lag, s0, s1)
-                if s0 < T:                                   # layer 1's inputs for the chunk layer 0 has just finished
-                    t0, t1 = s0, min(s1, T)
-                    if keep_prob < 1.0:
-                        ops.dropout_fwd(b0["h"][t0:t1], b0["y"][t0:t1], keep_prob, seed, row0, 0, step_dev, t0)
-                    ops.gemm_tn(b0["y"][t0:t1].view((t1 - t0) * B, -1), p1["wx_t"], b1["xproj"][t0:t1].view((t1 - t0) * B, -1), bias=p1["bias_p"])
+            masks = [None, None]
             if keep_prob < 1.0:
-                ops.dropout_fwd(b1["h"], b1["y"], keep_prob, seed, row0, 1, step_dev, 0)
+                for l, bf in enumerate(bufs):
+                    masks[l] = torch.empty(bf["h"].shape, device=dev, dtype=torch.uint8)
+                    ops.dropout_mask(masks[l], keep_prob, seed, row0, l, step_dev)
+            d0 = ops.lstm2_fwd_layer(b0["xproj"], p0["wh_t"], b0["h0"], b0["c0"], b0["gates"], b0["c"], b0["h"], b0["hT"],
+                                     b0["y"] if masks[0] is not None else None, masks[0])
+            d1 = ops.lstm2_fwd_layer(b1["xproj"], p1["wh_t"], b1["h0"], b1["c0"], b1["gates"], b1["c"], b1["h"], b1["hT"],
+                                     b1["y"] if masks[1] is not None else None, masks[1], p1["wx_t"], p1["bias_p"])
+            ops.lstm2_seq_fwd(T, B, d0, d1, keep_prob)
+            for bf, mk in zip(bufs, masks):
+                bf["mask"] = mk
             chunks = []
         done = [[None] * len(chunks) for _ in range(L)]
         for ci, (t0, t1) in enumerate(chunks):
@@ -168,7 +167,7 @@ class LstmStack:
         if save:
             for l, bf in enumerate(bufs):
                 ctx.append(dict(inp=x_tm if l == 0 else bufs[l - 1]["y"], gates=bf["gates"], c=bf["c"], h=bf["h"], c0=bf["c0"], h0=bf["h0"],
-                                hT=bf["hT"]))
+                                hT=bf["hT"], mask=bf.get("mask")))
         final = [(bf["c"][-1], bf["h"][-1]) for bf in bufs]
         return bufs[-1]["y"], ctx, final
 
@@ -226,23 +225,17 @@ class LstmStack:
                 dyl[l] = torch.empty((T, B, u), device=dev)
         lane_of = lambda l: lanes[L - 1 - l] if piped else main          # the top layer leads, on the current stream
         done = [[None] * len(chunks) for _ in range(L)]
-        if self._fused2(B) and ctx[0]["h0"] is None:
-            lag = self.chunk
+        if self._fused2(B) and ctx[0]["h0"] is None and (keep_prob >= 1.0 or ctx[0].get("mask") is not None):
             p0, p1 = self.packed
             if keep_prob < 1.0:
                 ops.dropout_bwd(dyl[1], st[1]["dh"], keep_prob, seed, row0, 1, False, step_dev, 0)
             dh1 = st[1]["dh"] if keep_prob < 1.0 else dyl[1]
-            dh0 = st[0]["dh"] if keep_prob < 1.0 else dyl[0]
-            e0 = ops.lstm2_bwd_layer(dh0, p0["wh_p"], ctx[0]["gates"], ctx[0]["c"], ctx[0]["c0"], st[0]["dzc"], st[0]["ws"], st[0]["dzT"], st[0]["db_p"])
-            e1 = ops.lstm2_bwd_layer(dh1, p1["wh_p"], ctx[1]["gates"], ctx[1]["c"], ctx[1]["c0"], st[1]["dzc"], st[1]["ws"], st[1]["dzT"], st[1]["db_p"])
-            for k0 in range(0, T + lag, lag):
-                k1 = min(k0 + lag, T + lag)
-                ops.lstm2_seq_bwd(T, B, e0, e1, lag, k0, k1)
-                tA, tB = max(0, T - k1), T - k0
-                if tB > tA:                                  # layer 0's dh for the chunk layer 1 has just finished
-                    ops.gemm_tn(st[1]["dzc"][tA:tB].view((tB - tA) * B, -1), p1["wx_p"], dyl[0][tA:tB].view((tB - tA) * B, -1))
-                    if keep_prob < 1.0:
-                        ops.dropout_bwd(dyl[0][tA:tB], st[0]["dh"][tA:tB], keep_prob, seed, row0, 0, False, step_dev, tA)
+            dh0 = dyl[0]                                   # written by the fused launches (stage Q), dropout already applied
+            e0 = ops.lstm2_bwd_layer(dh0, p0["wh_p"], ctx[0]["gates"], ctx[0]["c"], ctx[0]["c0"], st[0]["dzc"], st[0]["ws"], st[0]["dzT"], st[0]["db_p"],
+                                     ctx[0].get("mask"))
+            e1 = ops.lstm2_bwd_layer(dh1, p1["wh_p"], ctx[1]["gates"], ctx[1]["c"], ctx[1]["c0"], st[1]["dzc"], st[1]["ws"], st[1]["dzT"], st[1]["db_p"],
+                                     None, p1["wx_p"])
+            ops.lstm2_seq_bwd(T, B, e0, e1, keep_prob)
             chunks = []
         for ci in range(len(chunks) - 1, -1, -1):
             t0, t1 = chunks[ci]
@@ -597,10 +590,13 @@ class RnnNade(RnnEstimator):
         return self._loss
 
     def graphed_train_step(self, x_u8, optimizer, lr=None, warmup=2):
-        """Capture one whole optimiser step (plumbing, packing, forward, backward, clip, Adam: ~600 launches)
-        into a hipGraph and return ``run(x=None) -> loss``: the T-step recurrences are launch-bound on the host
-        otherwise.  Step-dependent values (dropout seed, Adam step) are read from store.step_dev on the device.
-        Full-length batches only (ragged lengths need a host-side row count)."""
+        """Capture one whole optimiser step (plumbing, packing, forward, backward, clip, Adam: ~300 launches) into
+        hipGraphs and return ``run(x=None) -> loss``: the T-step recurrences are launch-bound on the host otherwise.
+        Step-dependent values (dropout seed, Adam step) are read from store.step_dev on the device.  Under data
+        parallelism the ONE gradient all-reduce stays an eager torch.distributed call between two graphs
+        (forward+backward | clip+Adam), so nothing of RCCL is captured.  Full-length batches only (ragged lengths
+        need a host-side row count)."""
+        from .training import allreduce_flat
         static_x = x_u8.clone()
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
@@ -609,18 +605,32 @@ class RnnNade(RnnEstimator):
             for _ in range(warmup):
                 self.train_step(static_x, None, optimizer, lr)
         cur.wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            loss = self.train_step(static_x, None, optimizer, lr)
+        multi = world()[1] > 1
+        g_fb, g_opt = torch.cuda.CUDAGraph(), None
+        if not multi:
+            with torch.cuda.graph(g_fb):
+                loss = self.train_step(static_x, None, optimizer, lr)
+        else:
+            with torch.cuda.graph(g_fb):
+                self.build_pianoroll(static_x, None, is_train=True, mode="train")
+                self.backward()
+                loss = self._loss
+            g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_opt, pool=g_fb.pool()):
+                self._grad_sumsq = compute_gradients(optimizer, self.store, self.clip_norm, lr, reduce=False)
+            self._packed_step = -1
         self.store.step -= 1            # the captured step has not executed (host mirror of store.step_dev)
 
         def run(x=None):
             if x is not None:
                 static_x.copy_(x)
-            graph.replay()
+            g_fb.replay()
+            if g_opt is not None:
+                allreduce_flat(self.store.grad)
+                g_opt.replay()
             self.store.step += 1
             return loss
-        run.graph = graph
+        run.graph = g_fb
         return run
 
     # -- state / sampling -----------------------------------------------------------------------

@@ -194,8 +194,9 @@ def _p0(t):
     return t.data_ptr() if t is not None else None
 
 
-def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT):
-    """Descriptor of one layer for lstm2_seq_fwd (same tensors as lstm_seq_fwd; bf16, contiguous, time-major)."""
+def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT, y=None, mask=None, wx_t=None, bias_p=None):
+    """Descriptor of one layer for lstm2_seq_fwd (same tensors as lstm_seq_fwd; bf16, contiguous, time-major).
+    y/mask: dropped output and u8 keep mask (keep_prob < 1); wx_t/bias_p: this layer's input projection (layer 2)."""
     T, B, N4 = xproj.shape
     u = N4 // 4
     _req(xproj.dtype == torch.float32 and xproj.is_contiguous() and h.dtype == torch.bfloat16 and h.shape == (T, B, u) and h.is_contiguous(),
@@ -206,17 +207,28 @@ def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT):
     _req(h0 is None or (h0.shape == (B, u) and h0.dtype == torch.bfloat16 and h0.is_contiguous()), "lstm2: h0")
     _req(c0 is None or (c0.shape == (B, u) and c0.dtype == torch.float32 and c0.is_contiguous()), "lstm2: c0")
     _req(hT is None or (hT.dim() == 2 and hT.shape[0] == u and hT.stride(1) == 1 and hT.shape[1] >= T * B and hT.dtype == torch.bfloat16), "lstm2: hT")
+    _req((y is None) == (mask is None), "lstm2: y and mask come together")
+    if mask is not None:
+        _req(mask.dtype == torch.uint8 and mask.shape == (T, B, u) and mask.is_contiguous(), "lstm2: mask u8 [T,B,u]")
+        _req(y.dtype == torch.bfloat16 and y.shape == (T, B, u) and y.is_contiguous(), "lstm2: y bf16 [T,B,u]")
+    ld_w = 0
+    if wx_t is not None:
+        _req(wx_t.dim() == 2 and wx_t.shape[0] == N4 and wx_t.stride(1) == 1 and wx_t.dtype == torch.bfloat16, "lstm2: wx_t bf16 [4u, ld]")
+        _req(bias_p is not None and bias_p.dtype == torch.float32 and bias_p.numel() == N4, "lstm2: bias_p f32 [4u]")
+        ld_w = wx_t.stride(0)
     for t in (xproj, wh_t, c, h):
         _ptr(t)
-    return _lib.LstmFwdLayer(u, _p0(xproj), _p0(wh_t), _p0(h0), _p0(c0), _p0(gates), _p0(c), _p0(h), _p0(hT), hT.stride(0) if hT is not None else 0)
+    return _lib.LstmFwdLayer(u, _p0(xproj), _p0(wh_t), _p0(h0), _p0(c0), _p0(gates), _p0(c), _p0(h), _p0(hT), hT.stride(0) if hT is not None else 0,
+                             _p0(y), _p0(mask), _p0(wx_t), ld_w, _p0(bias_p))
 
 
-def lstm2_seq_fwd(T, B, L1, L2, lag, s_begin, s_end):
-    _req(0 <= s_begin < s_end <= T + lag and lag > 0, "lstm2_fwd: bad launch range")
-    call("mnn_lstm2_seq_fwd", _stream(), T, B, C.byref(L1), C.byref(L2), int(lag), int(s_begin), int(s_end))
+def lstm2_seq_fwd(T, B, L1, L2, keep_prob, s_begin=0, s_end=None):
+    s_end = T + 2 if s_end is None else s_end
+    _req(0 <= s_begin < s_end <= T + 2, "lstm2_fwd: bad launch range")
+    call("mnn_lstm2_seq_fwd", _stream(), T, B, C.byref(L1), C.byref(L2), float(keep_prob), int(s_begin), int(s_end))
 
 
-def lstm2_bwd_layer(dh_ext, wh_p, gates, c, c0, dz_T, ws, dzT_t, db_p):
+def lstm2_bwd_layer(dh_ext, wh_p, gates, c, c0, dz_T, ws, dzT_t, db_p, mask=None, wx_p=None):
     T, B, u = dh_ext.shape
     N4 = 4 * u
     _req(dh_ext.dtype == torch.float32 and dh_ext.is_contiguous(), "lstm2 bwd: dh_ext f32 [T,B,u]")
@@ -228,15 +240,25 @@ def lstm2_bwd_layer(dh_ext, wh_p, gates, c, c0, dz_T, ws, dzT_t, db_p):
                            and dzT_t.dtype == torch.bfloat16), "lstm2 bwd: dzT_t")
     _req(db_p is None or (db_p.dtype == torch.float32 and db_p.numel() == N4 and dzT_t is not None), "lstm2 bwd: db_p")
     _req(ws.numel() >= B * u * 4, "lstm2 bwd: workspace too small")
+    _req(mask is None or (mask.dtype == torch.uint8 and mask.shape == (T, B, u) and mask.is_contiguous()), "lstm2 bwd: mask u8 [T,B,u]")
+    _req(wx_p is None or (wx_p.dim() == 2 and wx_p.shape[1] == N4 and wx_p.is_contiguous() and wx_p.dtype == torch.bfloat16), "lstm2 bwd: wx_p [n_in,4u]")
     for t in (dh_ext, wh_p, gates, c, dz_T, ws):
         _ptr(t)
     return _lib.LstmBwdLayer(u, _p0(dh_ext), _p0(wh_p), _p0(gates), _p0(c), _p0(c0), None, _p0(dz_T), _p0(ws), _p0(dzT_t),
-                             dzT_t.stride(0) if dzT_t is not None else 0, _p0(db_p))
+                             dzT_t.stride(0) if dzT_t is not None else 0, _p0(db_p), _p0(mask), _p0(wx_p))
 
 
-def lstm2_seq_bwd(T, B, L1, L2, lag, k_begin, k_end):
-    _req(0 <= k_begin < k_end <= T + lag and lag > 0, "lstm2_bwd: bad launch range")
-    call("mnn_lstm2_seq_bwd", _stream(), T, B, C.byref(L1), C.byref(L2), int(lag), int(k_begin), int(k_end))
+def lstm2_seq_bwd(T, B, L1, L2, keep_prob, k_begin=0, k_end=None):
+    k_end = T + 2 if k_end is None else k_end
+    _req(0 <= k_begin < k_end <= T + 2, "lstm2_bwd: bad launch range")
+    call("mnn_lstm2_seq_bwd", _stream(), T, B, C.byref(L1), C.byref(L2), float(keep_prob), int(k_begin), int(k_end))
+
+
+def dropout_mask(mask, keep_prob, seed, row0, layer, step_dev=None):
+    T, B, u = mask.shape
+    _req(mask.dtype == torch.uint8 and mask.is_contiguous() and u % 4 == 0 and 0 < keep_prob < 1, "dropout_mask: u8 [T,B,u], 0<kp<1")
+    _step_ok(step_dev)
+    call("mnn_dropout_mask", _stream(), _ptr(mask), T, B, u, float(keep_prob), int(seed), _ptr(step_dev), int(row0), int(layer))
 
 
 def dropout_fwd(h, y, keep_prob, seed, row0, layer, step_dev=None, t_offset=0):

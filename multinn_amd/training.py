@@ -37,11 +37,12 @@ def allreduce_flat(grad):
     return grad
 
 
-def compute_gradients(optimizer, store, clip_norm=5.0, lr=None):
+def compute_gradients(optimizer, store, clip_norm=5.0, lr=None, reduce=True):
     """clip_by_global_norm(5.0) (hard-coded in the reference, training.py:166; R9 honours the
     argument) + optimizer.apply_gradients.  The gradient must already be in store.grad.
     Returns the device scalar holding sum(grad^2) (global norm squared, after the all-reduce)."""
-    allreduce_flat(store.grad)
+    if reduce:
+        allreduce_flat(store.grad)
     sumsq = torch.zeros(1, device=store.grad.device)
     ops.sumsq(store.grad, sumsq)
     store.step += 1

@@ -48,10 +48,11 @@ def make_batch(B, T, P, M, seed, rho=0.25):
     return (R.random((B, T, P, M)) < rho).astype(np.uint8)
 
 
-@pytest.mark.parametrize("precision,ragged", [("fp32", False), ("fp32", True), ("bf16", True)])
-def test_rnn_nade_joint_train_step(precision, ragged):
+@pytest.mark.parametrize("precision,ragged,units", [("fp32", False, [32, 64]), ("fp32", True, [32, 64]), ("bf16", True, [32, 64]),
+                                                    ("bf16", False, [128, 128])])          # last: the fused three-stage launches
+def test_rnn_nade_joint_train_step(precision, ragged, units):
     from multinn_amd import RnnNade, AdamOptimizer
-    B, T, P, M, Hn, units = 6, 5, 4, 3, 20, [32, 64]
+    B, T, P, M, Hn = 6, 5, 4, 3, 20
     D = P * M
     x = make_batch(B, T, P, M, 1)
     lengths = np.array([5, 2, 4, 5, 1, 3], np.int32) if ragged else None
@@ -350,7 +351,7 @@ def test_wavefront_pipelining_matches_sequential():
 
 
 def test_fused_two_layer_wavefront_matches_sequential():
-    """mnn_lstm2_seq_fwd/bwd (both layers' steps in one launch, lag = chunk) vs the per-layer sequence."""
+    """mnn_lstm2_seq_fwd/bwd (three-stage launches, lag 2) vs the per-layer sequence."""
     from multinn_amd import RnnNade, AdamOptimizer
     for T, units in [(40, [128, 128]), (7, [256, 128]), (33, [128, 256])]:
         x = make_batch(6, T, 8, 2, 9, rho=0.2)
@@ -363,9 +364,14 @@ def test_fused_two_layer_wavefront_matches_sequential():
         opt = AdamOptimizer(0.01)
         a.build_pianoroll(dev(x), None, True, "train"); b.build_pianoroll(dev(x), None, True, "train")
         assert b._stack._fused2(6) and not a._stack._fused2(6) and not b._stack._fused2(4096)
-        assert torch.equal(a._nll_tm, b._nll_tm)                     # forward is bit-identical (same kernels' bodies)
+        assert torch.allclose(a._nll_tm, b._nll_tm, rtol=1e-4)      # same step bodies; layer 2's projection is summed in another order
         a.backward(); b.backward()
-        assert torch.allclose(a.store.grad, b.store.grad, rtol=1e-4, atol=1e-7)
+        # bf16 activations: the two summation orders differ by rounding only (a wrong mask / time index would be O(1))
+        for name in a.store.names():
+            ga, gb = a.store.gviews[name], b.store.gviews[name]
+            assert float((ga - gb).abs().max()) < 1e-2 * float(ga.abs().max()) + 1e-9, name
+        cos = torch.nn.functional.cosine_similarity(a.store.grad, b.store.grad, dim=0)
+        assert float(cos) > 0.99995, float(cos)
         la = [float(a.train_step(dev(x), None, opt)) for _ in range(3)]
         lb = [float(b.train_step(dev(x), None, opt)) for _ in range(3)]
         assert np.allclose(la, lb, rtol=1e-3), (la, lb)
