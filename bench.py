@@ -106,7 +106,14 @@ def main():
     use_graph = not a.no_graph          # hipGraph replay of the step (N>1: forward+backward | eager all-reduce | clip+Adam)
     for _ in range(a.warmup):
         gen.train_step(x, None, opt)
-    step_fn = gen.graphed_train_step(x, opt, warmup=1) if use_graph else (lambda: gen.train_step(x, None, opt))
+    step_fn = lambda: gen.train_step(x, None, opt)
+    if use_graph:
+        try:
+            step_fn = gen.graphed_train_step(x, opt, warmup=1)
+        except Exception as e:      # keep the run alive: fall back to eager launches and say so in the JSON line
+            print(f"# hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            use_graph = False
+            torch.cuda.synchronize()
     if not use_graph:
         _lib.TIMING = {}
     barrier()

@@ -400,13 +400,14 @@ lstm_fwd_step_kernel(const T* __restrict__ h_prev, const T* __restrict__ wh_t, c
 // not throughput, sets the time).  One block = one 32-row x 32-unit output tile; the K dimension is
 // split over the block's waves; every wave loads ALL its operands straight into registers with
 // 16-byte loads issued back to back (no LDS staging, no K-loop barrier), runs its MFMAs, and the
-// partial tiles meet once in LDS.  K is permuted inside a wave (lane half h owns 8*KS consecutive
-// elements) so each lane reads one contiguous run; A and B use the same permutation.
+// partial tiles meet once in LDS.  Within a wave's K slice the natural MFMA order is kept (k = 16 s + 8 h + j), so
+// one load instruction touches 32 contiguous bytes of each row (half the cache-line visits of a per-lane-contiguous
+// split).
 // ----------------------------------------------------------------------------------------------
 template <int KS>
 __device__ __forceinline__ void load_frags(const bf16_t* __restrict__ p, bf16x8_t (&f)[KS]) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) f[s] = *reinterpret_cast<const bf16x8_t*>(p + 8 * s);
+    for (int s = 0; s < KS; ++s) f[s] = *reinterpret_cast<const bf16x8_t*>(p + 16 * s);
 }
 
 // forward: 4 waves, K = U = 64*KS.  Tile columns = 4 gates x 32 units (gate-interleaved layout).
@@ -447,7 +448,7 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgs& A, int B, int b
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
     if (h_prev != nullptr) {
-        const int kb = w * 16 * KS + hh * 8 * KS;
+        const int kb = w * 16 * KS + hh * 8;     // natural MFMA K order: the two lane halves read ADJACENT 16-byte pieces of a row
         const int arow = min(m0 + r, B - 1);
         bf16x8_t a[KS], b[4][KS];
         load_frags<KS>(h_prev + (size_t)arow * U + kb, a);
@@ -525,7 +526,7 @@ __device__ __forceinline__ void lstm_proj_body(const LstmProjArgs& A, int B, int
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
     {
-        const int kb = w * 16 * KS + hh * 8 * KS;
+        const int kb = w * 16 * KS + hh * 8;     // natural MFMA K order: the two lane halves read ADJACENT 16-byte pieces of a row
         const int arow = min(m0 + r, B - 1);
         bf16x8_t a[KS], b[4][KS];
         load_frags<KS>(A.y + (size_t)arow * A.K + kb, a);
@@ -555,19 +556,40 @@ __device__ __forceinline__ void lstm_proj_body(const LstmProjArgs& A, int B, int
     }
 }
 
+// Block -> (unit tile, row tile) map of the fused launches.  MNN_XCD_ROWS: blocks that share an XCD (linear id mod 8,
+// speed only) share a ROW tile, so the step's activations are fetched into one XCD's L2 once; otherwise they share
+// unit tiles (the weight slice stays per-XCD but every XCD re-reads all activation rows).
+#ifndef MNN_XCD_ROWS
+#define MNN_XCD_ROWS 0     // measured: sharing row tiles per XCD is 3 % slower (every XCD then streams all weights)
+#endif
+__device__ __forceinline__ bool fused_tile(int nrt, int& bx, int& by) {
+#if MNN_XCD_ROWS
+    const int id = blockIdx.x;                   // 1-D grid of 8 * ceil(nrt/8) * (unit tiles)
+    const int nrt8 = (nrt + 7) >> 3;
+    const int j = id >> 3;
+    by = (id & 7) + 8 * (j % nrt8);
+    bx = j / nrt8;
+    return by < nrt;
+#else
+    bx = blockIdx.x; by = blockIdx.y;
+    return true;
+#endif
+}
+
 // Three-stage forward wavefront, lag 2: launch s = layer-1 step s | layer-2 projection of step s-1 | layer-2 step s-2.
 template <int KS1, int KS2>
 __global__ void __launch_bounds__(256) lstm3_fwd_step(LstmFwdArgs A1, LstmProjArgs P, LstmFwdArgs A2, int B) {
     __shared__ float red[4][4][16][64];
     __shared__ bf16_t sT[32][40];
     const int nb1 = A1.U / 32, nb2 = A2.U / 32;
-    const int bx = blockIdx.x;
+    int bx, by;
+    if (!fused_tile((B + 31) / 32, bx, by)) return;
     if (bx < nb1) {
-        if (A1.active) lstm_fwd_body<KS1>(A1, B, bx, blockIdx.y, red, sT);
+        if (A1.active) lstm_fwd_body<KS1>(A1, B, bx, by, red, sT);
     } else if (bx < nb1 + nb2) {
-        if (P.active) lstm_proj_body<KS1>(P, B, bx - nb1, blockIdx.y, red);
+        if (P.active) lstm_proj_body<KS1>(P, B, bx - nb1, by, red);
     } else {
-        if (A2.active) lstm_fwd_body<KS2>(A2, B, bx - nb1 - nb2, blockIdx.y, red, sT);
+        if (A2.active) lstm_fwd_body<KS2>(A2, B, bx - nb1 - nb2, by, red, sT);
     }
 }
 
@@ -729,7 +751,7 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& A, int B, int b
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     if (dz_next != nullptr) {
-        const int kb = w * 16 * KS + hh * 8 * KS;
+        const int kb = w * 16 * KS + hh * 8;     // natural MFMA K order: the two lane halves read ADJACENT 16-byte pieces of a row
         const int arow = min(m0 + r, B - 1);
         bf16x8_t a[KS], b[KS];
         load_frags<KS>(dz_next + (size_t)arow * N4 + kb, a);
@@ -811,7 +833,7 @@ __device__ __forceinline__ void lstm_dgrad_body(const LstmDgradArgs& A, int B, i
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     {
-        const int kb = w * 16 * KS + hh * 8 * KS;
+        const int kb = w * 16 * KS + hh * 8;     // natural MFMA K order: the two lane halves read ADJACENT 16-byte pieces of a row
         const int arow = min(m0 + r, B - 1);
         bf16x8_t a[KS], b[KS];
         load_frags<KS>(A.dz + (size_t)arow * A.K + kb, a);
@@ -843,13 +865,14 @@ __global__ void __launch_bounds__(512) lstm3_bwd_step(LstmBwdArgs A1, LstmDgradA
     __shared__ float red[8][16][64];
     __shared__ bf16_t sT[4][32][40];
     const int nb1 = A1.U / 32, nb2 = A2.U / 32;
-    const int bx = blockIdx.x;
+    int bx, by;
+    if (!fused_tile((B + 31) / 32, bx, by)) return;
     if (bx < nb2) {
-        if (A2.active) lstm_bwd_body<KS2>(A2, B, bx, blockIdx.y, red, sT);
+        if (A2.active) lstm_bwd_body<KS2>(A2, B, bx, by, red, sT);
     } else if (bx < nb2 + nb1) {
-        if (Q.active) lstm_dgrad_body<KS2>(Q, B, bx - nb2, blockIdx.y, red);
+        if (Q.active) lstm_dgrad_body<KS2>(Q, B, bx - nb2, by, red);
     } else {
-        if (A1.active) lstm_bwd_body<KS1>(A1, B, bx - nb2 - nb1, blockIdx.y, red, sT);
+        if (A1.active) lstm_bwd_body<KS1>(A1, B, bx - nb2 - nb1, by, red, sT);
     }
 }
 
@@ -1102,7 +1125,8 @@ extern "C" int mnn_lstm2_seq_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fw
     }
     MNN_REQUIRE(L2->wx_t && L2->bias_p && L2->ld_w >= L1->units, "mnn_lstm2_seq_fwd: layer 2 needs its input-projection weights");
     const size_t us1 = (size_t)B * L1->units;
-    dim3 grid(L1->units / 32 + 2 * (L2->units / 32), cdiv(B, 32));
+    const int ut_f = L1->units / 32 + 2 * (L2->units / 32);
+    dim3 grid = MNN_XCD_ROWS ? dim3(8 * cdiv(cdiv(B, 32), 8) * ut_f) : dim3(ut_f, cdiv(B, 32));
     for (int si = s_begin; si < s_end; ++si) {
         const LstmFwdArgs a1 = make_fwd_args(L1, T, B, si, keep_prob), a2 = make_fwd_args(L2, T, B, si - 2, keep_prob);
         LstmProjArgs p{};
@@ -1159,7 +1183,8 @@ extern "C" int mnn_lstm2_seq_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bw
     MNN_REQUIRE(L2->wx_p != nullptr, "mnn_lstm2_seq_bwd: layer 2 needs wx_p (its input weights, [u1, 4u2])");
     MNN_REQUIRE((L1->mask == nullptr) == (keep_prob >= 1.0f), "mnn_lstm2_seq_bwd: layer 1's keep mask is needed exactly when keep_prob < 1");
     const size_t us1 = (size_t)B * L1->units;
-    dim3 grid(2 * (L1->units / 32) + L2->units / 32, cdiv(B, 32));
+    const int ut_b = 2 * (L1->units / 32) + L2->units / 32;
+    dim3 grid = MNN_XCD_ROWS ? dim3(8 * cdiv(cdiv(B, 32), 8) * ut_b) : dim3(ut_b, cdiv(B, 32));
     for (int k = k_begin; k < k_end; ++k) {
         const LstmBwdArgs a2 = make_bwd_args(L2, T, B, T - 1 - k), a1 = make_bwd_args(L1, T, B, T + 1 - k);
         LstmDgradArgs q{};

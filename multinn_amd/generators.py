@@ -611,12 +611,13 @@ class RnnNade(RnnEstimator):
             with torch.cuda.graph(g_fb):
                 loss = self.train_step(static_x, None, optimizer, lr)
         else:
-            with torch.cuda.graph(g_fb):
+            # thread_local: the process group's watchdog thread may touch the runtime while this thread captures
+            with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
                 self.build_pianoroll(static_x, None, is_train=True, mode="train")
                 self.backward()
                 loss = self._loss
             g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_opt, pool=g_fb.pool()):
+            with torch.cuda.graph(g_opt, pool=g_fb.pool(), capture_error_mode="thread_local"):
                 self._grad_sumsq = compute_gradients(optimizer, self.store, self.clip_norm, lr, reduce=False)
             self._packed_step = -1
         self.store.step -= 1            # the captured step has not executed (host mirror of store.step_dev)
