@@ -11,6 +11,7 @@ rows past ``lengths`` are masked by a zero row weight instead of being gathered 
 """
 import abc
 import collections
+import os
 
 import torch
 
@@ -95,6 +96,26 @@ class LstmStack:
         blocks = sum(p["u"] // 32 for p in self.packed) * -(-max(B, 1) // 32)
         return blocks <= 512
 
+    persistent = os.environ.get("MULTINN_PERSIST", "1") != "0"   # one launch for all T steps (lstm_persist.hip) when the grid fits the device
+
+    def _persist(self, B):
+        if not (self.persistent and len(self.packed) == 2 and self.dtype == torch.bfloat16):
+            return False
+        return ops.lstm2_persist_ok(B, self.packed[0]["u"], self.packed[1]["u"])
+
+    def _sync(self, B, dev):
+        """Progress-flag scratch of the persistent launches, one per batch size (kept alive: captured graphs point at it)."""
+        if not hasattr(self, "_sync_ws"):
+            self._sync_ws = {}
+        if B not in self._sync_ws:
+            self._sync_ws[B] = ops.lstm2_persist_sync(B, dev)
+        return self._sync_ws[B]
+
+    def check(self):
+        """Raise if a persistent launch ever gave up waiting (synchronises the device)."""
+        for ws in getattr(self, "_sync_ws", {}).values():
+            ops.lstm2_persist_check(ws)
+
     @staticmethod
     def _chunks(T, step):
         return [(t0, min(T, t0 + step)) for t0 in range(0, T, step)]
@@ -107,6 +128,7 @@ class LstmStack:
         T, B, _ = x_tm.shape
         dev = x_tm.device
         L = len(self.packed)
+        persist = self._persist(B)
         bufs = []
         for l, p in enumerate(self.packed):
             u = p["u"]
@@ -116,7 +138,7 @@ class LstmStack:
                 hT = torch.zeros((u, ops.round_up(T * B, 64)), device=dev, dtype=self.dtype)
                 if state0 is not None:
                     ops.transpose(state0[l][1].to(self.dtype).contiguous(), hT[:, :B])
-            bufs.append(dict(xproj=torch.empty((T, B, 4 * u), device=dev), gates=torch.empty((T, B, 4 * u), device=dev) if save else None,
+            bufs.append(dict(xproj=None if (persist and l == 1) else torch.empty((T, B, 4 * u), device=dev), gates=torch.empty((T, B, 4 * u), device=dev) if save else None,
                              c=torch.empty((T, B, u), device=dev), h=h, y=torch.empty_like(h) if keep_prob < 1.0 else h, hT=hT,
                              c0=state0[l][0] if state0 is not None else None,
                              h0=state0[l][1].to(self.dtype) if state0 is not None else None))
@@ -129,8 +151,9 @@ class LstmStack:
         # layer 0's input projection has no dependency: one big GEMM
         p0, b0 = self.packed[0], bufs[0]
         ops.gemm_tn(x_tm.view(T * B, -1), p0["wx_t"], b0["xproj"].view(T * B, -1), bias=p0["bias_p"])
-        if self._fused2(B):
-            # ONE launch per timestep for the whole stack: layer-0 step s | layer-1 projection s-1 | layer-1 step s-2
+        if persist or self._fused2(B):
+            # persist: ONE launch for the whole recurrence of both layers; else ONE launch per timestep for the whole
+            # stack: layer-0 step s | layer-1 projection s-1 | layer-1 step s-2
             p1, b1 = self.packed[1], bufs[1]
             masks = [None, None]
             if keep_prob < 1.0:
@@ -141,7 +164,10 @@ class LstmStack:
                                      b0["y"] if masks[0] is not None else None, masks[0])
             d1 = ops.lstm2_fwd_layer(b1["xproj"], p1["wh_t"], b1["h0"], b1["c0"], b1["gates"], b1["c"], b1["h"], b1["hT"],
                                      b1["y"] if masks[1] is not None else None, masks[1], p1["wx_t"], p1["bias_p"])
-            ops.lstm2_seq_fwd(T, B, d0, d1, keep_prob)
+            if persist:
+                ops.lstm2_persist_fwd(T, B, d0, d1, keep_prob, self._sync(B, dev))
+            else:
+                ops.lstm2_seq_fwd(T, B, d0, d1, keep_prob)
             for bf, mk in zip(bufs, masks):
                 bf["mask"] = mk
             chunks = []
@@ -225,17 +251,21 @@ class LstmStack:
                 dyl[l] = torch.empty((T, B, u), device=dev)
         lane_of = lambda l: lanes[L - 1 - l] if piped else main          # the top layer leads, on the current stream
         done = [[None] * len(chunks) for _ in range(L)]
-        if self._fused2(B) and ctx[0]["h0"] is None and (keep_prob >= 1.0 or ctx[0].get("mask") is not None):
+        persist = self._persist(B) and (keep_prob >= 1.0 or ctx[0].get("mask") is not None)
+        if (persist or (self._fused2(B) and ctx[0]["h0"] is None)) and (keep_prob >= 1.0 or ctx[0].get("mask") is not None):
             p0, p1 = self.packed
             if keep_prob < 1.0:
                 ops.dropout_bwd(dyl[1], st[1]["dh"], keep_prob, seed, row0, 1, False, step_dev, 0)
             dh1 = st[1]["dh"] if keep_prob < 1.0 else dyl[1]
-            dh0 = dyl[0]                                   # written by the fused launches (stage Q), dropout already applied
+            dh0 = None if persist else dyl[0]              # written by the fused launches (stage Q), dropout already applied
             e0 = ops.lstm2_bwd_layer(dh0, p0["wh_p"], ctx[0]["gates"], ctx[0]["c"], ctx[0]["c0"], st[0]["dzc"], st[0]["ws"], st[0]["dzT"], st[0]["db_p"],
                                      ctx[0].get("mask"))
             e1 = ops.lstm2_bwd_layer(dh1, p1["wh_p"], ctx[1]["gates"], ctx[1]["c"], ctx[1]["c0"], st[1]["dzc"], st[1]["ws"], st[1]["dzT"], st[1]["db_p"],
                                      None, p1["wx_p"])
-            ops.lstm2_seq_bwd(T, B, e0, e1, keep_prob)
+            if persist:
+                ops.lstm2_persist_bwd(T, B, e0, e1, keep_prob, self._sync(B, dev))
+            else:
+                ops.lstm2_seq_bwd(T, B, e0, e1, keep_prob)
             chunks = []
         for ci in range(len(chunks) - 1, -1, -1):
             t0, t1 = chunks[ci]

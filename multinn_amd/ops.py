@@ -197,10 +197,11 @@ def _p0(t):
 def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT, y=None, mask=None, wx_t=None, bias_p=None):
     """Descriptor of one layer for lstm2_seq_fwd (same tensors as lstm_seq_fwd; bf16, contiguous, time-major).
     y/mask: dropped output and u8 keep mask (keep_prob < 1); wx_t/bias_p: this layer's input projection (layer 2)."""
-    T, B, N4 = xproj.shape
-    u = N4 // 4
-    _req(xproj.dtype == torch.float32 and xproj.is_contiguous() and h.dtype == torch.bfloat16 and h.shape == (T, B, u) and h.is_contiguous(),
-         "lstm2: xproj f32 [T,B,4u], h bf16 [T,B,u]")
+    _req(h.dim() == 3 and h.dtype == torch.bfloat16 and h.is_contiguous(), "lstm2: h bf16 [T,B,u]")
+    T, B, u = h.shape
+    N4 = 4 * u
+    _req(xproj is not None or wx_t is not None, "lstm2: xproj may be omitted only for a layer with its own input projection (persistent form)")
+    _req(xproj is None or (xproj.dtype == torch.float32 and xproj.is_contiguous() and xproj.shape == (T, B, N4)), "lstm2: xproj f32 [T,B,4u]")
     _req(wh_t.shape == (N4, u) and wh_t.is_contiguous() and wh_t.dtype == torch.bfloat16, "lstm2: wh_t bf16 [4u,u]")
     _req(c.dtype == torch.float32 and c.shape == (T, B, u) and c.is_contiguous(), "lstm2: c")
     _req(gates is None or (gates.dtype == torch.float32 and gates.shape == (T, B, N4) and gates.is_contiguous()), "lstm2: gates")
@@ -216,7 +217,7 @@ def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT, y=None, mask=None, wx_
         _req(wx_t.dim() == 2 and wx_t.shape[0] == N4 and wx_t.stride(1) == 1 and wx_t.dtype == torch.bfloat16, "lstm2: wx_t bf16 [4u, ld]")
         _req(bias_p is not None and bias_p.dtype == torch.float32 and bias_p.numel() == N4, "lstm2: bias_p f32 [4u]")
         ld_w = wx_t.stride(0)
-    for t in (xproj, wh_t, c, h):
+    for t in (wh_t, c, h):
         _ptr(t)
     return _lib.LstmFwdLayer(u, _p0(xproj), _p0(wh_t), _p0(h0), _p0(c0), _p0(gates), _p0(c), _p0(h), _p0(hT), hT.stride(0) if hT is not None else 0,
                              _p0(y), _p0(mask), _p0(wx_t), ld_w, _p0(bias_p))
@@ -229,9 +230,9 @@ def lstm2_seq_fwd(T, B, L1, L2, keep_prob, s_begin=0, s_end=None):
 
 
 def lstm2_bwd_layer(dh_ext, wh_p, gates, c, c0, dz_T, ws, dzT_t, db_p, mask=None, wx_p=None):
-    T, B, u = dh_ext.shape
+    T, B, u = c.shape
     N4 = 4 * u
-    _req(dh_ext.dtype == torch.float32 and dh_ext.is_contiguous(), "lstm2 bwd: dh_ext f32 [T,B,u]")
+    _req(dh_ext is None or (dh_ext.dtype == torch.float32 and dh_ext.is_contiguous() and dh_ext.shape == (T, B, u)), "lstm2 bwd: dh_ext f32 [T,B,u]")
     _req(wh_p.shape == (u, N4) and wh_p.is_contiguous() and wh_p.dtype == torch.bfloat16, "lstm2 bwd: wh_p bf16 [u,4u]")
     _req(gates.shape == (T, B, N4) and gates.dtype == torch.float32 and gates.is_contiguous(), "lstm2 bwd: gates")
     _req(c.shape == (T, B, u) and c.dtype == torch.float32 and c.is_contiguous(), "lstm2 bwd: c")
@@ -242,7 +243,7 @@ def lstm2_bwd_layer(dh_ext, wh_p, gates, c, c0, dz_T, ws, dzT_t, db_p, mask=None
     _req(ws.numel() >= B * u * 4, "lstm2 bwd: workspace too small")
     _req(mask is None or (mask.dtype == torch.uint8 and mask.shape == (T, B, u) and mask.is_contiguous()), "lstm2 bwd: mask u8 [T,B,u]")
     _req(wx_p is None or (wx_p.dim() == 2 and wx_p.shape[1] == N4 and wx_p.is_contiguous() and wx_p.dtype == torch.bfloat16), "lstm2 bwd: wx_p [n_in,4u]")
-    for t in (dh_ext, wh_p, gates, c, dz_T, ws):
+    for t in (wh_p, gates, c, dz_T, ws):
         _ptr(t)
     return _lib.LstmBwdLayer(u, _p0(dh_ext), _p0(wh_p), _p0(gates), _p0(c), _p0(c0), None, _p0(dz_T), _p0(ws), _p0(dzT_t),
                              dzT_t.stride(0) if dzT_t is not None else 0, _p0(db_p), _p0(mask), _p0(wx_p))
@@ -252,6 +253,38 @@ def lstm2_seq_bwd(T, B, L1, L2, keep_prob, k_begin=0, k_end=None):
     k_end = T + 2 if k_end is None else k_end
     _req(0 <= k_begin < k_end <= T + 2, "lstm2_bwd: bad launch range")
     call("mnn_lstm2_seq_bwd", _stream(), T, B, C.byref(L1), C.byref(L2), float(keep_prob), int(k_begin), int(k_end))
+
+
+def lstm2_persist_ok(B, u1, u2):
+    """True when the persistent (one launch for all T steps) recurrence can run this shape on this device."""
+    return bool(_lib.load().mnn_lstm2_persist_ok(int(B), int(u1), int(u2)))
+
+
+def lstm2_persist_sync(B, device):
+    """Progress-flag scratch of the persistent recurrence: int32 words, zeroed here once; [-1] is the sticky give-up word."""
+    n = _lib.load().mnn_lstm2_persist_sync_bytes(int(B))
+    return torch.zeros(n // 4, dtype=torch.int32, device=device)
+
+
+def _sync_ok(sync, B):
+    _req(sync.dtype == torch.int32 and sync.is_contiguous() and sync.numel() * 4 >= _lib.load().mnn_lstm2_persist_sync_bytes(int(B))
+         and sync.data_ptr() % 128 == 0, "lstm2 persist: sync must be the int32 tensor of lstm2_persist_sync(B)")
+
+
+def lstm2_persist_fwd(T, B, L1, L2, keep_prob, sync):
+    _sync_ok(sync, B)
+    call("mnn_lstm2_persist_fwd", _stream(), T, B, C.byref(L1), C.byref(L2), float(keep_prob), _ptr(sync))
+
+
+def lstm2_persist_bwd(T, B, L1, L2, keep_prob, sync):
+    _sync_ok(sync, B)
+    call("mnn_lstm2_persist_bwd", _stream(), T, B, C.byref(L1), C.byref(L2), float(keep_prob), _ptr(sync))
+
+
+def lstm2_persist_check(sync):
+    """Raise if any persistent launch that used this scratch gave up on a bounded spin (synchronises)."""
+    if int(sync[-1].item()) != 0:
+        raise _lib.MnnError("persistent LSTM launch timed out waiting for a neighbouring workgroup (grid not co-resident?)")
 
 
 def dropout_mask(mask, keep_prob, seed, row0, layer, step_dev=None):

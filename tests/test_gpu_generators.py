@@ -360,6 +360,7 @@ def test_fused_two_layer_wavefront_matches_sequential():
         a._materialize(16); b._materialize(16)
         b.store.theta.copy_(a.store.theta)
         a._stack.fused_layers = False
+        a._stack.persistent = b._stack.persistent = False
         assert b._stack.fused_layers
         opt = AdamOptimizer(0.01)
         a.build_pianoroll(dev(x), None, True, "train"); b.build_pianoroll(dev(x), None, True, "train")
@@ -375,6 +376,41 @@ def test_fused_two_layer_wavefront_matches_sequential():
         la = [float(a.train_step(dev(x), None, opt)) for _ in range(3)]
         lb = [float(b.train_step(dev(x), None, opt)) for _ in range(3)]
         assert np.allclose(la, lb, rtol=1e-3), (la, lb)
+
+
+@pytest.mark.parametrize("B,T,units,kp", [(6, 40, [128, 128], 0.9), (70, 9, [256, 128], 0.9), (33, 12, [128, 256], 1.0), (256, 24, [512, 256], 0.9)])
+def test_persistent_recurrence_matches_sequential(B, T, units, kp):
+    """mnn_lstm2_persist_fwd/bwd (ONE launch for all T steps, register-resident weights, flag hand-offs between the
+    workgroups of a row tile) vs the per-layer launch-per-step sequence: same step bodies, layer 2's projection summed
+    in another order."""
+    from multinn_amd import RnnNade, AdamOptimizer
+    x = make_batch(B, T, 8, 2, 9, rho=0.2)
+    a = RnnNade(16, 16, units, keep_prob=kp, precision="bf16", seed=3)
+    b = RnnNade(16, 16, units, keep_prob=kp, precision="bf16", seed=3)
+    a._materialize(16); b._materialize(16)
+    b.store.theta.copy_(a.store.theta)
+    a._stack.fused_layers = False
+    a._stack.persistent = False
+    assert b._stack.persistent
+    a.build_pianoroll(dev(x), None, True, "train"); b.build_pianoroll(dev(x), None, True, "train")
+    assert b._stack._persist(B) and not a._stack._persist(B)
+    b._stack.check()
+    assert torch.allclose(a._nll_tm, b._nll_tm, rtol=1e-4)
+    nll1 = b._nll_tm.clone()
+    b.build_pianoroll(dev(x), None, True, "train")
+    assert torch.equal(nll1, b._nll_tm)                          # a stale hand-off would show as run-to-run noise
+    a.backward(); b.backward()
+    b._stack.check()
+    for name in a.store.names():
+        ga, gb = a.store.gviews[name], b.store.gviews[name]
+        assert float((ga - gb).abs().max()) < 1e-2 * float(ga.abs().max()) + 1e-9, name
+    cos = torch.nn.functional.cosine_similarity(a.store.grad, b.store.grad, dim=0)
+    assert float(cos) > 0.99995, float(cos)
+    opt = AdamOptimizer(0.01)
+    la = [float(a.train_step(dev(x), None, opt)) for _ in range(3)]
+    lb = [float(b.train_step(dev(x), None, opt)) for _ in range(3)]
+    b._stack.check()
+    assert np.allclose(la, lb, rtol=1e-3), (la, lb)
 
 
 def test_graphed_train_step_matches_eager():
