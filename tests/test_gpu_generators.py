@@ -343,6 +343,8 @@ def test_wavefront_pipelining_matches_sequential():
     a._materialize(16); b._materialize(16)
     b.store.theta.copy_(a.store.theta)
     b._stack.pipelined = True
+    a._stack.persistent = b._stack.persistent = False          # this test is about the per-layer chunked form
+    a._stack.fused_layers = b._stack.fused_layers = False
     opt = AdamOptimizer(0.01)
     la = [float(a.train_step(dev(x), None, opt)) for _ in range(3)]
     lb = [float(b.train_step(dev(x), None, opt)) for _ in range(3)]
