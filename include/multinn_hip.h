@@ -143,18 +143,22 @@ int mnn_lstm2_seq_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L1
 /* Persistent form of the two-layer recurrence: ONE launch runs all T steps of both layers (replaces the T+2 launches of
  * mnn_lstm2_seq_fwd / _bwd; same layer descriptors, same outputs).  A workgroup keeps its slice of the recurrent weights in
  * registers for the whole sequence and hands 32-row state tiles to the workgroups of the same row tile through
- * write-through stores + progress flags (multinn_amd/csrc/lstm_persist.hip).  Layer 2's input projection is folded into
- * its step, so L2->xproj is not used (may be NULL) and, backward, L1->dh_ext is not used (may be NULL).
- * sync: device scratch of mnn_lstm2_persist_sync_bytes(B) bytes, 128-byte aligned, zeroed ONCE by the caller at
- * allocation; each call re-zeroes its progress words itself (a memset node under hipGraph capture).  The LAST word of
- * sync is sticky: non-zero after any launch that gave up on a bounded spin (its outputs are then garbage) --
- * mnn_lstm2_persist_ok() says whether the grid fits this device at once; the entries refuse shapes for which it does not. */
+ * write-through stores into an exchange area + progress flags (multinn_amd/csrc/lstm_persist.hip).  Layer 2's input
+ * projection is folded into its step, so L2->xproj is not used (may be NULL); backward, L1->dh_ext and both dz_T are
+ * not used (may be NULL) and dz must be NULL.
+ * workspace: mnn_lstm2_persist_workspace_bytes(T,B,u1,u2) bytes of device memory, 256-byte aligned, zeroed ONCE by the
+ * caller at allocation (progress flags, a sticky give-up word, the exchange area); each call re-zeroes its progress
+ * words itself (a memset node under hipGraph capture); forward and backward calls may share one workspace.
+ * mnn_lstm2_persist_status copies the sticky word to the host (synchronises): non-zero after any launch that gave up
+ * on a bounded spin -- its outputs are then garbage.  mnn_lstm2_persist_ok() says whether the grid fits this device at
+ * once (one workgroup per CU); the entries refuse shapes for which it does not. */
 int mnn_lstm2_persist_ok(int B, int units1, int units2);
-size_t mnn_lstm2_persist_sync_bytes(int B);
+size_t mnn_lstm2_persist_workspace_bytes(int T, int B, int units1, int units2);
+int mnn_lstm2_persist_status(const void* workspace, int B, int units1, int units2, int* status);
 int mnn_lstm2_persist_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L1, const mnn_lstm_fwd_layer* L2, float keep_prob,
-                          void* sync);
+                          void* workspace);
 int mnn_lstm2_persist_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L1, const mnn_lstm_bwd_layer* L2, float keep_prob,
-                          void* sync);
+                          void* workspace);
 int mnn_dropout_mask(mnn_stream_t s, uint8_t* mask, int T, int B, int units, float keep_prob, uint64_t seed, const int32_t* step_dev,
                      uint32_t row0, int layer);
 

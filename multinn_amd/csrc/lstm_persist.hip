@@ -4,10 +4,13 @@
 // step; the recurrence is a latency chain, so both sit on the critical path.  Here ONE launch runs all T steps:
 //   * a workgroup owns one (unit tile, row tile) of one layer for the whole sequence and keeps its slice of the
 //     recurrent weights in REGISTERS (32 units x K, K split over the waves) -- weights are read once per launch;
-//   * the 32-row hidden-state tiles move between workgroups through global memory: 16-byte write-through (sc1)
-//     stores, `s_waitcnt vmcnt(0)` in every storing wave, workgroup barrier, one sc1 flag store per workgroup;
-//     consumers poll the flags of their row tile with sc1 loads from one wave, join a barrier, then read the tile with
-//     16-byte sc1 buffer loads (MI355X_MICROARCH.md, "Valid forms", first table row; cdna_hip_programming.md G16 R1);
+//   * the 32-row hidden-state tiles move between workgroups through an EXCHANGE area in global memory, laid out in MFMA
+//     A-fragment order ([t][row tile][k-step][lane][8 bf16]) so that every hand-off load and store instruction moves one
+//     contiguous KiB: 16-byte write-through (sc1) stores, `s_waitcnt vmcnt(0)` in every storing wave, workgroup
+//     barrier, one sc1 flag store per workgroup; consumers poll the flags of their row tile with sc1 loads from one wave,
+//     join a barrier, then read with 16-byte sc1 buffer loads (MI355X_MICROARCH.md, "Valid forms", first table row;
+//     cdna_hip_programming.md G16 R1).  The row-major copies the rest of the train step needs are written with plain
+//     stores one item later, off the chain (after the next hand-off's loads have been issued);
 //   * only workgroups of the same ROW TILE ever wait for each other (16 + 8 of them for units 512/256), never the grid;
 //   * layer 2 consumes layer 1's step t as soon as its flags say so: its input projection is folded into its step
 //     (K = U1 + U2), so the xproj round trip of the launch-per-step form disappears too.
@@ -22,6 +25,14 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned gu32;
 
+#ifdef PST_TRACE     // development only: per-stage timestamps of one workgroup per role (scratch/persist_trace.hip reads them)
+__device__ long long pst_trace[4][512][8];
+#define PST_TR(ptr, k) do { if (ptr) (ptr)[k] = wall_clock64(); } while (0)
+#define PST_TRP(role, cond, step) ((cond) && threadIdx.x == 0 ? &pst_trace[role][step][0] : nullptr)
+#else
+#define PST_TR(ptr, k) do { } while (0)
+#define PST_TRP(role, cond, step) nullptr
+#endif
 #define PST_LIMIT 100000000LL      // spin bound: 1 s of wall_clock64() (100 MHz)
 #define PST_FLAGS_OFF 32           // words: [0] status, [32 + 32*rt + member] progress flags, then one sticky word
 #define PST_SC1 16                 // aux bit of raw buffer loads/stores: device-scope (write-through / L1-bypassing)
@@ -32,10 +43,16 @@ __device__ __forceinline__ void st_agent(unsigned* p, unsigned v) { __hip_atomic
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const void* base, size_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
+// k-steps [f0, f0+KS) of one exchange slab ([k-step][lane][16 B]): one contiguous KiB per instruction
 template <int KS>
-__device__ __forceinline__ void load_frags_sc1(__amdgpu_buffer_rsrc_t rs, int byte_off, bf16x8_t (&f)[KS]) {
+__device__ __forceinline__ void load_frags_xchg(const void* slab, size_t slab_bytes, int f0, bf16x8_t (&f)[KS]) {
+    const __amdgpu_buffer_rsrc_t rs = slice_rsrc(slab, slab_bytes);
+    const int off = (f0 * 64 + (int)(threadIdx.x & 63)) * 16;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) f[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off + 32 * s, 0, PST_SC1));
+    for (int s = 0; s < KS; ++s) f[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024 * s, 0, PST_SC1));
+}
+__device__ __forceinline__ void store_frag_xchg(void* slab, size_t slab_bytes, int f, int lane, u32x4_t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, slice_rsrc(slab, slab_bytes), (f * 64 + lane) * 16, 0, PST_SC1);
 }
 template <int KS>
 __device__ __forceinline__ void load_frags_plain(const bf16_t* __restrict__ p, bf16x8_t (&f)[KS]) {
@@ -75,28 +92,30 @@ __device__ __forceinline__ void pst_publish(unsigned* flag, unsigned value) {
 }
 
 struct PFwdLayer {
-    const float* xproj; const bf16_t* wh_t; const bf16_t* h0; const float* c0;
+    const float* xproj; const bf16_t* wh_t; const float* c0;
     float* gates; float* c; bf16_t* h; bf16_t* hT; int ld_hT; bf16_t* y; const uint8_t* mask;
     const bf16_t* wx_t; int ld_w; const float* bias_p; int U;
+    char* hx; char* yx;            // exchange copies of h[t] (and of the dropped output y[t]), A-fragment order, slab (t, row tile)
+    const char* hx0;               // slabs of the initial state h[-1] (zeros, or h0 re-laid by pst_fill_h0_kernel), one per row tile
 };
 struct PFwdArgs { PFwdLayer l1, l2; int T, B, nrt, G, R; float kp; unsigned* sync; };
 
 struct FwdTiles {
     float red[4][4][16][64];       // K-split partial tiles
-    bf16_t sH[32][40];             // h tile [row][unit] for the 16-byte write-through stores
+    bf16_t sH[32][40];             // h tile [row][unit] (+pad)
     bf16_t sY[32][40];             // dropped output tile
     bf16_t sT[32][40];             // h tile [unit][row] for the transposed copy (weight-gradient operand)
     int abort;
 };
 
-// Gate pointwise + the stores of one (t, row tile) for one workgroup; z = pre-activations of this wave's 4 fragment rows.
-__device__ __forceinline__ void pf_finish(const PFwdLayer& L, FwdTiles& S, int T, int B, int t, int m0, int nt, float kp, const float (&z)[4][4],
-                                          const float (&cp)[4], const float (&mk)[4], const bool (&live)[4], unsigned* flag) {
+// What one finished item leaves for its deferred tail (plain stores issued one item later, off the chain).
+struct FwdTail { float gv[4][4], cv[4]; int t, m0; bool valid; };
+
+// Gate pointwise of this wave's 4 fragment rows -> tiles in LDS, then the hand-off of the h (and y) tile.
+__device__ __forceinline__ void pf_finish(const PFwdLayer& L, FwdTiles& S, int T, int nrt, int t, int rt, int nt, float kp, const float (&z)[4][4],
+                                          const float (&cp)[4], const unsigned (&mk)[4], FwdTail& tl, unsigned* flag, long long* trc) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int U = L.U, N4 = 4 * U, n0 = nt * 128, unit = nt * 32 + r;
-    const size_t us = (size_t)B * U;
-    float gv[4][4], cv[4];
     const bool drop = L.mask != nullptr;
     const bool wantT = L.hT != nullptr && t + 1 < T;
 #pragma unroll
@@ -104,34 +123,54 @@ __device__ __forceinline__ void pf_finish(const PFwdLayer& L, FwdTiles& S, int T
         const float gi = fast_sigmoid(z[q][0]), gg = fast_tanh(z[q][1]), gf = fast_sigmoid(z[q][2]), go = fast_sigmoid(z[q][3]);
         const float c = gg * gi + cp[q] * gf;
         const float h = fast_tanh(c) * go;
-        gv[q][0] = gi; gv[q][1] = gg; gv[q][2] = gf; gv[q][3] = go; cv[q] = c;
+        tl.gv[q][0] = gi; tl.gv[q][1] = gg; tl.gv[q][2] = gf; tl.gv[q][3] = go; tl.cv[q] = c;
         const bf16_t hb = f32_to_bf16(h);
         const int lr = 8 * w + q + 4 * hh;
         S.sH[lr][r] = hb;
-        if (drop) S.sY[lr][r] = f32_to_bf16(bf16_to_f32(hb) / kp * mk[q]);
+        if (drop) S.sY[lr][r] = f32_to_bf16(bf16_to_f32(hb) / kp * (float)mk[q]);     // mk: raw keep byte, converted here (not at the load)
         if (wantT) S.sT[r][lr] = hb;
     }
+    tl.t = t; tl.m0 = rt * 32; tl.valid = true;
     __syncthreads();
-    {   // handed-off tiles: 32 rows x 64 bytes each, one 16-byte write-through store per thread (h: threads 0..127, y: 128..255)
-        const int tt = threadIdx.x & 127, row = tt >> 2, piece = tt & 3;
-        const bool second = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)) != 0;      // wave-uniform: keeps the resource in SGPRs
-        if (m0 + row < B && (!second || drop)) {
-            bf16_t* base = (second ? L.y : L.h) + (size_t)t * us;
-            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(second ? &S.sY[row][piece * 8] : &S.sH[row][piece * 8]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, slice_rsrc(base, us * 2), (int)(((size_t)(m0 + row) * U + nt * 32 + piece * 8) * 2), 0, PST_SC1);
+    PST_TR(trc, 3);
+    {   // exchange slab of (t, row tile): k-steps 2nt, 2nt+1 of this unit tile; waves 0,1 store h, waves 2,3 the dropped y
+        const size_t slab = (size_t)(L.U / 16) * 1024;
+        const bool second = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)) != 0;
+        const int ks = (threadIdx.x >> 6) & 1;
+        if (!second || (drop && L.yx != nullptr)) {
+            const bf16_t (*src)[40] = second ? S.sY : S.sH;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&src[r][ks * 16 + hh * 8]);
+            store_frag_xchg((second ? L.yx : L.hx) + ((size_t)t * nrt + rt) * slab, slab, 2 * nt + ks, lane, v);
         }
     }
     pst_publish(flag, (unsigned)(t + 1));
-    // everything below is consumed after the launch (or by this workgroup only): plain stores, off the critical chain
+    PST_TR(trc, 4);
+}
+
+// Deferred plain stores of a finished item: gates, c, the row-major h / y tiles, the transposed h tile.
+__device__ __forceinline__ void pf_tail(const PFwdLayer& L, const FwdTiles& S, int T, int B, int nt, const FwdTail& tl) {
+    if (!tl.valid) return;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int U = L.U, N4 = 4 * U, n0 = nt * 128, unit = nt * 32 + r, t = tl.t, m0 = tl.m0;
+    const size_t us = (size_t)B * U;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        if (!live[q]) continue;
         const int row = m0 + 8 * w + q + 4 * hh;
+        if (row >= B) continue;
         const size_t zo = (size_t)t * 4 * us + (size_t)row * N4 + n0 + r, uo = (size_t)t * us + (size_t)row * U + unit;
-        if (L.gates != nullptr) { L.gates[zo] = gv[q][0]; L.gates[zo + 32] = gv[q][1]; L.gates[zo + 64] = gv[q][2]; L.gates[zo + 96] = gv[q][3]; }
-        L.c[uo] = cv[q];
+        if (L.gates != nullptr) { L.gates[zo] = tl.gv[q][0]; L.gates[zo + 32] = tl.gv[q][1]; L.gates[zo + 64] = tl.gv[q][2]; L.gates[zo + 96] = tl.gv[q][3]; }
+        L.c[uo] = tl.cv[q];
     }
-    if (wantT && threadIdx.x < 128) {      // hT[unit][(t+1) B + row]
+    {   // row-major tiles: 32 rows x 64 bytes, one 16-byte store per thread (h: threads 0..127, y: 128..255)
+        const int tt = threadIdx.x & 127, row = tt >> 2, piece = tt & 3;
+        const bool second = threadIdx.x >= 128;
+        if (m0 + row < B && (!second || L.mask != nullptr)) {
+            bf16_t* dst = (second ? L.y : L.h) + (size_t)t * us + (size_t)(m0 + row) * U + nt * 32 + piece * 8;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(second ? &S.sY[row][piece * 8] : &S.sH[row][piece * 8]);
+        }
+    }
+    if (L.hT != nullptr && t + 1 < T && threadIdx.x < 128) {      // hT[unit][(t+1) B + row]
         const int uu = threadIdx.x >> 2, piece = threadIdx.x & 3;
         const int row = m0 + piece * 8, colT = (t + 1) * B;
         bf16_t* dst = L.hT + (size_t)(nt * 32 + uu) * L.ld_hT + colT + row;
@@ -144,6 +183,10 @@ __device__ __forceinline__ void pf_finish(const PFwdLayer& L, FwdTiles& S, int T
     }
 }
 
+// Rule for the stretch between a hand-off's loads and its MFMAs: unconditional loads into registers only -- a load
+// under a branch feeds a phi, the phi's copy is a use, and the compiler then waits (vmcnt(0)) right behind the load.
+// So addresses are selected, never loads; `zero` points at always-zero words of the workspace.
+
 // KS1 = U1 / 64, KS2 = U2 / 64 (k-steps of 16 per wave, 4 waves).
 template <int KS1, int KS2>
 __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
@@ -152,78 +195,106 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
     const int grp = blockIdx.x % A.G, member = blockIdx.x / A.G;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int T = A.T, B = A.B;
+    const int T = A.T, B = A.B, nrt = A.nrt;
+    const int Rv = (nrt - grp + A.G - 1) / A.G;            // row tiles of this workgroup: grp, grp + G, ...
     unsigned* status = A.sync;
     unsigned* flags = A.sync + PST_FLAGS_OFF;
+    const float* zero = reinterpret_cast<const float*>(A.sync + 4);
     if (threadIdx.x == 0) S.abort = 0;
     __syncthreads();
+    FwdTail tl;
+    tl.valid = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tl.cv[q] = 0.f;
     if (member < nb1) {
         // ---------------- layer 1: z = xproj[t] + h[t-1] . Wh^T ----------------
         const PFwdLayer& L = A.l1;
         const int nt = member, U = L.U, N4 = 4 * U, n0 = nt * 128, unit = nt * 32 + r;
         const int kb = w * 16 * KS1 + hh * 8;
-        const size_t us = (size_t)B * U;
+        const size_t us = (size_t)B * U, slab = (size_t)(U / 16) * 1024;
         bf16x8_t b[4][KS1];
 #pragma unroll
         for (int g = 0; g < 4; ++g) load_frags_plain<KS1>(L.wh_t + (size_t)(n0 + 32 * g + r) * U + kb, b[g]);
-        for (int t = 0; t < T; ++t) {
-            for (int j = 0; j < A.R; ++j) {
-                const int rt = grp + A.G * j;
-                if (rt >= A.nrt) break;
-                const int m0 = rt * 32;
-                float xp[4][4], cp[4], mk[4];
-                bool live[4];
+        float xp[4][4];
+        unsigned mk[4];
+        auto epi_load = [&](int t, int m0, float (&xp_)[4][4], unsigned (&mk_)[4]) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = m0 + 8 * w + q + 4 * hh;
-                    live[q] = row < B;
-                    const int rr = live[q] ? row : B - 1;
-                    const size_t zo = (size_t)t * 4 * us + (size_t)rr * N4 + n0 + r, uo = (size_t)rr * U + unit;
+            for (int q = 0; q < 4; ++q) {
+                const int rr = min(m0 + 8 * w + q + 4 * hh, B - 1);
+                const size_t zo = (size_t)t * 4 * us + (size_t)rr * N4 + n0 + r;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) xp[q][g] = L.xproj[zo + 32 * g];
-                    cp[q] = t > 0 ? L.c[(size_t)(t - 1) * us + uo] : (L.c0 != nullptr ? L.c0[uo] : 0.f);
-                    mk[q] = L.mask != nullptr ? (float)L.mask[(size_t)t * us + uo] : 1.f;
-                }
-                f32x16_t acc[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
-                if (t > 0 && !pst_wait(flags + rt * 32, status, nb1, (unsigned)t, nb1, 0u, &S.abort)) return;
-                const bf16_t* hp = t > 0 ? L.h + (size_t)(t - 1) * us : L.h0;
-                if (hp != nullptr) {
-                    const int arow = min(m0 + r, B - 1);
-                    bf16x8_t a[KS1];
-                    load_frags_sc1<KS1>(slice_rsrc(hp, us * 2), (arow * U + kb) * 2, a);
-#pragma unroll
-                    for (int s = 0; s < KS1; ++s)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[g][s], acc[g], 0, 0, 0);
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) S.red[w][g][i][lane] = acc[g][i];
-                __syncthreads();
-                float z[4][4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = 4 * w + q;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        z[q][g] = xp[q][g] + ((S.red[0][g][i][lane] + S.red[1][g][i][lane]) + (S.red[2][g][i][lane] + S.red[3][g][i][lane]));
-                }
-                pf_finish(L, S, T, B, t, m0, nt, A.kp, z, cp, mk, live, flags + rt * 32 + member);
+                for (int g = 0; g < 4; ++g) xp_[q][g] = L.xproj[zo + 32 * g];
+                const uint8_t* mp = L.mask != nullptr ? L.mask + (size_t)t * us + (size_t)rr * U + unit : reinterpret_cast<const uint8_t*>(zero);
+                mk_[q] = *mp;
             }
+        };
+        epi_load(0, grp * 32, xp, mk);
+        const int n_items = T * Rv;
+        for (int i = 0; i < n_items; ++i) {
+            const int t = i / Rv, rt = grp + A.G * (i - t * Rv), m0 = rt * 32;
+            long long* trc = PST_TRP(0, member == 0 && rt == 0, t);
+            PST_TR(trc, 0);
+            if (t > 0 && !pst_wait(flags + rt * 32, status, nb1, (unsigned)t, nb1, 0u, &S.abort)) return;
+            PST_TR(trc, 1);
+            bf16x8_t a[KS1];
+            load_frags_xchg<KS1>(t > 0 ? L.hx + ((size_t)(t - 1) * nrt + rt) * slab : L.hx0 + (size_t)rt * slab, slab, w * KS1, a);
+            // behind the hand-off loads: this item's cell state, the next item's operands, the previous item's plain stores
+            float cl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t uo = (size_t)min(m0 + 8 * w + q + 4 * hh, B - 1) * U + unit;
+                const float* cptr = t == 0 ? (L.c0 != nullptr ? L.c0 + uo : zero) : (Rv == 1 ? zero : L.c + (size_t)(t - 1) * us + uo);
+                cl[q] = *cptr;
+            }
+            float xpn[4][4];
+            unsigned mkn[4];
+            {
+                const int i2 = min(i + 1, n_items - 1), t2 = i2 / Rv;
+                epi_load(t2, (grp + A.G * (i2 - t2 * Rv)) * 32, xpn, mkn);
+            }
+            pf_tail(L, S, T, B, nt, tl);
+            f32x16_t acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[g][k] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS1; ++s)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[g][s], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) S.red[w][g][k][lane] = acc[g][k];
+            __syncthreads();
+            float z[4][4], cp[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 4 * w + q;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    z[q][g] = xp[q][g] + ((S.red[0][g][k][lane] + S.red[1][g][k][lane]) + (S.red[2][g][k][lane] + S.red[3][g][k][lane]));
+                cp[q] = (Rv == 1 && t > 0) ? tl.cv[q] : cl[q];
+            }
+            PST_TR(trc, 2);
+            pf_finish(L, S, T, nrt, t, rt, nt, A.kp, z, cp, mk, tl, flags + rt * 32 + member, trc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                mk[q] = mkn[q];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xp[q][g] = xpn[q][g];
+            }
+            PST_TR(trc, 5);
         }
+        pf_tail(L, S, T, B, nt, tl);
     } else {
         // ---------------- layer 2: z = bias + y1[t] . Wx^T + h[t-1] . Wh^T ----------------
         const PFwdLayer& L = A.l2;
         const PFwdLayer& L1 = A.l1;
         const int nt = member - nb1, U = L.U, U1 = L1.U, n0 = nt * 128, unit = nt * 32 + r;
         const int kb1 = w * 16 * KS1 + hh * 8, kb2 = w * 16 * KS2 + hh * 8;
-        const size_t us = (size_t)B * U, us1 = (size_t)B * U1;
-        const bf16_t* y1 = L1.mask != nullptr ? L1.y : L1.h;
+        const size_t us = (size_t)B * U, slab = (size_t)(U / 16) * 1024, slab1 = (size_t)(U1 / 16) * 1024;
+        const char* y1x = L1.mask != nullptr ? L1.yx : L1.hx;
         bf16x8_t bx[4][KS1], bh[4][KS2];
         float bz[4];
 #pragma unroll
@@ -232,60 +303,68 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             load_frags_plain<KS2>(L.wh_t + (size_t)(n0 + 32 * g + r) * U + kb2, bh[g]);
             bz[g] = L.bias_p[n0 + 32 * g + r];
         }
-        for (int t = 0; t < T; ++t) {
-            for (int j = 0; j < A.R; ++j) {
-                const int rt = grp + A.G * j;
-                if (rt >= A.nrt) break;
-                const int m0 = rt * 32;
-                float cp[4], mk[4];
-                bool live[4];
+        const int n_items = T * Rv;
+        for (int i = 0; i < n_items; ++i) {
+            const int t = i / Rv, rt = grp + A.G * (i - t * Rv), m0 = rt * 32;
+            long long* trc = PST_TRP(1, member == nb1 && rt == 0, t);
+            PST_TR(trc, 0);
+            if (!pst_wait(flags + rt * 32, status, nb1, (unsigned)(t + 1), nm, (unsigned)t, &S.abort)) return;
+            PST_TR(trc, 1);
+            bf16x8_t a1[KS1], a2[KS2];
+            load_frags_xchg<KS1>(y1x + ((size_t)t * nrt + rt) * slab1, slab1, w * KS1, a1);
+            load_frags_xchg<KS2>(t > 0 ? L.hx + ((size_t)(t - 1) * nrt + rt) * slab : L.hx0 + (size_t)rt * slab, slab, w * KS2, a2);
+            float cl[4];
+            unsigned mk[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = m0 + 8 * w + q + 4 * hh;
-                    live[q] = row < B;
-                    const int rr = live[q] ? row : B - 1;
-                    const size_t uo = (size_t)rr * U + unit;
-                    cp[q] = t > 0 ? L.c[(size_t)(t - 1) * us + uo] : (L.c0 != nullptr ? L.c0[uo] : 0.f);
-                    mk[q] = L.mask != nullptr ? (float)L.mask[(size_t)t * us + uo] : 1.f;
-                }
-                f32x16_t acc[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
-                if (!pst_wait(flags + rt * 32, status, nb1, (unsigned)(t + 1), nm, (unsigned)t, &S.abort)) return;
-                const int arow = min(m0 + r, B - 1);
-                const bf16_t* hp = t > 0 ? L.h + (size_t)(t - 1) * us : L.h0;
-                bf16x8_t a1[KS1], a2[KS2];
-                load_frags_sc1<KS1>(slice_rsrc(y1 + (size_t)t * us1, us1 * 2), (arow * U1 + kb1) * 2, a1);
-                if (hp != nullptr) load_frags_sc1<KS2>(slice_rsrc(hp, us * 2), (arow * U + kb2) * 2, a2);
-#pragma unroll
-                for (int s = 0; s < KS1; ++s)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s], bx[g][s], acc[g], 0, 0, 0);
-                if (hp != nullptr) {
-#pragma unroll
-                    for (int s = 0; s < KS2; ++s)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s], bh[g][s], acc[g], 0, 0, 0);
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) S.red[w][g][i][lane] = acc[g][i];
-                __syncthreads();
-                float z[4][4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = 4 * w + q;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        z[q][g] = bz[g] + ((S.red[0][g][i][lane] + S.red[1][g][i][lane]) + (S.red[2][g][i][lane] + S.red[3][g][i][lane]));
-                }
-                pf_finish(L, S, T, B, t, m0, nt, A.kp, z, cp, mk, live, flags + rt * 32 + member);
+            for (int q = 0; q < 4; ++q) {
+                const size_t uo = (size_t)min(m0 + 8 * w + q + 4 * hh, B - 1) * U + unit;
+                const float* cptr = t == 0 ? (L.c0 != nullptr ? L.c0 + uo : zero) : (Rv == 1 ? zero : L.c + (size_t)(t - 1) * us + uo);
+                cl[q] = *cptr;
+                const uint8_t* mp = L.mask != nullptr ? L.mask + (size_t)t * us + uo : reinterpret_cast<const uint8_t*>(zero);
+                mk[q] = *mp;
             }
+            pf_tail(L, S, T, B, nt, tl);
+            f32x16_t acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[g][k] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS1; ++s)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s], bx[g][s], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < KS2; ++s)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s], bh[g][s], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) S.red[w][g][k][lane] = acc[g][k];
+            __syncthreads();
+            float z[4][4], cp[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 4 * w + q;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    z[q][g] = bz[g] + ((S.red[0][g][k][lane] + S.red[1][g][k][lane]) + (S.red[2][g][k][lane] + S.red[3][g][k][lane]));
+                cp[q] = (Rv == 1 && t > 0) ? tl.cv[q] : cl[q];
+            }
+            PST_TR(trc, 2);
+            pf_finish(L, S, T, nrt, t, rt, nt, A.kp, z, cp, mk, tl, flags + rt * 32 + member, trc);
+            PST_TR(trc, 5);
         }
+        pf_tail(L, S, T, B, nt, tl);
     }
+}
+
+// h0 [B,U] row-major -> one exchange slab per row tile (initial state of a stateful call); grid (nrt, U/16), 64 threads
+__global__ void __launch_bounds__(64) pst_fill_h0_kernel(const bf16_t* __restrict__ h0, int B, int U, char* __restrict__ slab0) {
+    const int rt = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    const int row = min(rt * 32 + (lane & 31), B - 1);
+    const uint4 v = *reinterpret_cast<const uint4*>(h0 + (size_t)row * U + f * 16 + (lane >> 5) * 8);
+    *reinterpret_cast<uint4*>(slab0 + ((size_t)rt * (U / 16) + f) * 1024 + lane * 16) = v;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -293,67 +372,71 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
 //   layer 2, step t:  dh = dh_ext[t] + dz2[t+1] . Wh2            (K = 4 U2)
 //   layer 1, step t:  dh = (dz2[t] . Wx2) * keep/kp + dz1[t+1] . Wh1   (K = 4 U2 + 4 U1; the dgrad of layer 2's input
 //                     projection through the dropout of rnn.py:132 is folded in)
-// followed by the gate pointwise; the handed-off tile is dz (bf16, [B, 4U], gate-interleaved: 256 bytes per row per tile).
+// followed by the gate pointwise; the handed-off tile is dz (bf16, 32 rows x 128 gate-interleaved columns = 8 k-steps of
+// its row tile's exchange slab).  No row-major dz is written: only this launch reads it.  dz[T] is a slab of zeros.
 // ------------------------------------------------------------------------------------------------------------------
 struct PBwdLayer {
     const float* dh_ext; const bf16_t* wh_p; const float* gates; const float* c; const float* c0;
-    float* dc; float* dz; bf16_t* dzc; bf16_t* dzTt; int ld_t; const uint8_t* mask; const bf16_t* wx_p; int U;
+    float* dc; bf16_t* dzTt; int ld_t; const uint8_t* mask; const bf16_t* wx_p; int U;
+    char* dzx;                     // exchange copy of dz[t], A-fragment order, slab (t, row tile)
+    const char* dzxT;              // zero slabs standing for dz[T], one per row tile
 };
 struct PBwdArgs { PBwdLayer l1, l2; int T, B, nrt, G, R; float kp; unsigned* sync; };
 
 struct BwdTiles {
     float red[2][8][16][64];
-    bf16_t sZ[32][136];            // dz tile [row][gate*32 + unit] (+pad) for the 16-byte write-through stores
+    bf16_t sZ[32][136];            // dz tile [row][gate*32 + unit] (+pad)
     bf16_t sT[4][32][40];          // dz tile [gate][unit][row] for the transposed copy
     int abort;
 };
+struct BwdEpi { float dh, g[4], c, cp; unsigned keep; };      // per fragment row: external gradient, gates, cell states, raw keep byte
+struct BwdTail { float dcv[2]; int t, m0; bool valid; };
 
-__device__ __forceinline__ void pb_finish(const PBwdLayer& L, BwdTiles& S, int T, int B, int t, int m0, int nt, const float (&dh)[2],
-                                          const float (&e_g)[2][4], const float (&e_c)[2], const float (&e_cp)[2], const float (&e_dc)[2],
-                                          const bool (&live)[2], unsigned* flag, unsigned epoch) {
+__device__ __forceinline__ void pb_finish(const PBwdLayer& L, BwdTiles& S, int nrt, int t, int rt, int nt, const float (&dh)[2], const BwdEpi (&e)[2],
+                                          const float (&e_dc)[2], BwdTail& tl, unsigned* flag, unsigned epoch, long long* trc) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int U = L.U, N4 = 4 * U, unit = nt * 32 + r, pc = nt * 128 + r;
-    const size_t us = (size_t)B * U;
-    float dzv[2][4], dcv[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int i = 2 * w + q;
         const int lr = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const float gi = e_g[q][0], gg = e_g[q][1], gf = e_g[q][2], go = e_g[q][3];
-        const float tc = fast_tanh(e_c[q]);
+        const float gi = e[q].g[0], gg = e[q].g[1], gf = e[q].g[2], go = e[q].g[3];
+        const float tc = fast_tanh(e[q].c);
         const float d_o = dh[q] * tc;
         const float d_c = dh[q] * go * (1.f - tc * tc) + e_dc[q];
-        dzv[q][0] = d_c * gg * gi * (1.f - gi);
-        dzv[q][1] = d_c * gi * (1.f - gg * gg);
-        dzv[q][2] = d_c * e_cp[q] * gf * (1.f - gf);
-        dzv[q][3] = d_o * go * (1.f - go);
-        dcv[q] = d_c * gf;
+        const float dzv[4] = {d_c * gg * gi * (1.f - gi), d_c * gi * (1.f - gg * gg), d_c * e[q].cp * gf * (1.f - gf), d_o * go * (1.f - go)};
+        tl.dcv[q] = d_c * gf;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const bf16_t bv = f32_to_bf16(dzv[q][g]);
+            const bf16_t bv = f32_to_bf16(dzv[g]);
             S.sZ[lr][32 * g + r] = bv;
             if (L.dzTt != nullptr) S.sT[g][r][lr] = bv;
         }
     }
+    tl.t = t; tl.m0 = rt * 32; tl.valid = true;
     __syncthreads();
-    {   // 32 rows x 256 bytes: one 16-byte write-through store per thread
-        const int row = threadIdx.x >> 4, piece = threadIdx.x & 15;
-        if (m0 + row < B) {
-            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&S.sZ[row][piece * 8]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, slice_rsrc(L.dzc + (size_t)t * 4 * us, 4 * us * 2),
-                                                   (int)(((size_t)(m0 + row) * N4 + nt * 128 + piece * 8) * 2), 0, PST_SC1);
-        }
+    PST_TR(trc, 3);
+    {   // k-steps 8nt .. 8nt+7 of the slab, one per wave: a contiguous KiB per store instruction
+        const size_t slab = (size_t)(4 * L.U / 16) * 1024;
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&S.sZ[r][w * 16 + hh * 8]);
+        store_frag_xchg(L.dzx + ((size_t)t * nrt + rt) * slab, slab, 8 * nt + w, lane, v);
     }
     pst_publish(flag, epoch);
+    PST_TR(trc, 4);
+}
+
+__device__ __forceinline__ void pb_tail(const PBwdLayer& L, const BwdTiles& S, int B, int Rv, int nt, const BwdTail& tl) {
+    if (!tl.valid) return;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int U = L.U, unit = nt * 32 + r, t = tl.t, m0 = tl.m0;
+    if (Rv > 1) {                                   // with one row tile per workgroup the cell gradient never leaves its registers
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        if (!live[q]) continue;
-        const int i = 2 * w + q;
-        const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const size_t uo = (size_t)row * U + unit, zo = (size_t)t * 4 * us + (size_t)row * N4 + pc;
-        L.dc[uo] = dcv[q];
-        if (L.dz != nullptr) { L.dz[zo] = dzv[q][0]; L.dz[zo + 32] = dzv[q][1]; L.dz[zo + 64] = dzv[q][2]; L.dz[zo + 96] = dzv[q][3]; }
+        for (int q = 0; q < 2; ++q) {
+            const int i = 2 * w + q;
+            const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            if (row < B) L.dc[(size_t)row * U + unit] = tl.dcv[q];
+        }
     }
     if (L.dzTt != nullptr) {              // dzT_t[pc + 32 g][t B + row]
         const int gu = threadIdx.x >> 2, piece = threadIdx.x & 3;
@@ -369,6 +452,30 @@ __device__ __forceinline__ void pb_finish(const PBwdLayer& L, BwdTiles& S, int T
     }
 }
 
+// Epilogue operands of one (t, row tile) for this wave's 2 fragment rows: unconditional loads (see the rule above).
+template <bool LAYER1>
+__device__ __forceinline__ void pb_epi_load(const PBwdLayer& L, int B, int nt, int t, int m0, const float* zero, BwdEpi (&e)[2]) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int U = L.U, N4 = 4 * U, unit = nt * 32 + r, pc = nt * 128 + r;
+    const size_t us = (size_t)B * U;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = 2 * w + q;
+        const int rr = min(m0 + (i & 3) + 8 * (i >> 2) + 4 * hh, B - 1);
+        const size_t uo = (size_t)rr * U + unit, zo = (size_t)t * 4 * us + (size_t)rr * N4 + pc;
+        if (LAYER1) e[q].dh = 0.f;
+        else e[q].dh = L.dh_ext[(size_t)t * us + uo];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e[q].g[g] = L.gates[zo + 32 * g];
+        e[q].c = L.c[(size_t)t * us + uo];
+        const float* cpp = t > 0 ? L.c + (size_t)(t - 1) * us + uo : (L.c0 != nullptr ? L.c0 + uo : zero);
+        e[q].cp = *cpp;
+        const uint8_t* mp = (LAYER1 && L.mask != nullptr) ? L.mask + (size_t)t * us + uo : reinterpret_cast<const uint8_t*>(zero);
+        e[q].keep = *mp;
+    }
+}
+
 // KA = 4 U1 / 128, KB = 4 U2 / 128 (k-steps of 16 per wave, 8 waves).
 template <int KA, int KB>
 __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
@@ -377,134 +484,127 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
     const int grp = blockIdx.x % A.G, member = blockIdx.x / A.G;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int T = A.T, B = A.B;
+    const int T = A.T, B = A.B, nrt = A.nrt;
+    const int Rv = (nrt - grp + A.G - 1) / A.G;
+    const int n_items = T * Rv;
     unsigned* status = A.sync;
     unsigned* flags = A.sync + PST_FLAGS_OFF;
+    const float* zero = reinterpret_cast<const float*>(A.sync + 4);
     if (threadIdx.x == 0) S.abort = 0;
     __syncthreads();
+    BwdTail tl;
+    tl.valid = false;
+    tl.dcv[0] = tl.dcv[1] = 0.f;
     if (member < nb2) {
-        // ---------------- layer 2 ----------------
+        // ---------------- layer 2 (leads) ----------------
         const PBwdLayer& L = A.l2;
-        const int nt = member, U = L.U, N4 = 4 * U, unit = nt * 32 + r, pc = nt * 128 + r;
+        const int nt = member, U = L.U, N4 = 4 * U, unit = nt * 32 + r;
+        const size_t slab = (size_t)(N4 / 16) * 1024;
         const int kb = w * 16 * KB + hh * 8;
-        const size_t us = (size_t)B * U;
         bf16x8_t bw[KB];
         load_frags_plain<KB>(L.wh_p + (size_t)unit * N4 + kb, bw);
-        for (int k = 0; k < T; ++k) {
-            const int t = T - 1 - k;
-            for (int j = 0; j < A.R; ++j) {
-                const int rt = grp + A.G * j;
-                if (rt >= A.nrt) break;
-                const int m0 = rt * 32;
-                float e_dh[2], e_g[2][4], e_c[2], e_cp[2], e_dc[2];
-                bool live[2];
+        BwdEpi e[2], en[2];
+        pb_epi_load<false>(L, B, nt, T - 1, grp * 32, zero, e);
+        for (int i = 0; i < n_items; ++i) {
+            const int k = i / Rv, t = T - 1 - k, rt = grp + A.G * (i - k * Rv), m0 = rt * 32;
+            long long* trc = PST_TRP(2, member == 0 && rt == 0, k);
+            PST_TR(trc, 0);
+            if (k > 0 && !pst_wait(flags + rt * 32, status, nb2, (unsigned)k, nb2, 0u, &S.abort)) return;
+            PST_TR(trc, 1);
+            bf16x8_t a[KB];
+            load_frags_xchg<KB>(k > 0 ? L.dzx + ((size_t)(t + 1) * nrt + rt) * slab : L.dzxT + (size_t)rt * slab, slab, w * KB, a);
+            float dcl[2];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int i = 2 * w + q;
-                    const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    live[q] = row < B;
-                    const int rr = live[q] ? row : B - 1;
-                    const size_t uo = (size_t)rr * U + unit, zo = (size_t)t * 4 * us + (size_t)rr * N4 + pc;
-                    e_dh[q] = L.dh_ext[(size_t)t * us + uo];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) e_g[q][g] = L.gates[zo + 32 * g];
-                    e_c[q] = L.c[(size_t)t * us + uo];
-                    e_cp[q] = t > 0 ? L.c[(size_t)(t - 1) * us + uo] : (L.c0 != nullptr ? L.c0[uo] : 0.f);
-                    e_dc[q] = k > 0 ? L.dc[uo] : 0.f;
-                }
-                f32x16_t acc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-                if (k > 0) {
-                    if (!pst_wait(flags + rt * 32, status, nb2, (unsigned)k, nb2, 0u, &S.abort)) return;
-                    const int arow = min(m0 + r, B - 1);
-                    bf16x8_t a[KB];
-                    load_frags_sc1<KB>(slice_rsrc(L.dzc + (size_t)(t + 1) * 4 * us, 4 * us * 2), (arow * N4 + kb) * 2, a);
-#pragma unroll
-                    for (int s = 0; s < KB; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bw[s], acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) S.red[0][w][i][lane] = acc[i];
-                __syncthreads();
-                float dh[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int i = 2 * w + q;
-                    float sum = 0.f;
-#pragma unroll
-                    for (int ww = 0; ww < 8; ++ww) sum += S.red[0][ww][i][lane];
-                    dh[q] = e_dh[q] + sum;
-                }
-                pb_finish(L, S, T, B, t, m0, nt, dh, e_g, e_c, e_cp, e_dc, live, flags + rt * 32 + member, (unsigned)(k + 1));
+            for (int q = 0; q < 2; ++q) {
+                const int ii = 2 * w + q;
+                const size_t uo = (size_t)min(m0 + (ii & 3) + 8 * (ii >> 2) + 4 * hh, B - 1) * U + unit;
+                const float* dp = (k == 0 || Rv == 1) ? zero : L.dc + uo;
+                dcl[q] = *dp;
             }
+            {
+                const int i2 = min(i + 1, n_items - 1), k2 = i2 / Rv;
+                pb_epi_load<false>(L, B, nt, T - 1 - k2, (grp + A.G * (i2 - k2 * Rv)) * 32, zero, en);
+            }
+            pb_tail(L, S, B, Rv, nt, tl);
+            f32x16_t acc;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KB; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bw[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) S.red[0][w][j][lane] = acc[j];
+            __syncthreads();
+            float dh[2], e_dc[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = 2 * w + q;
+                float sum = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) sum += S.red[0][ww][j][lane];
+                dh[q] = e[q].dh + sum;
+                e_dc[q] = (Rv == 1 && k > 0) ? tl.dcv[q] : dcl[q];
+            }
+            PST_TR(trc, 2);
+            pb_finish(L, S, nrt, t, rt, nt, dh, e, e_dc, tl, flags + rt * 32 + member, (unsigned)(k + 1), trc);
+            e[0] = en[0]; e[1] = en[1];
+            PST_TR(trc, 5);
         }
+        pb_tail(L, S, B, Rv, nt, tl);
     } else {
         // ---------------- layer 1 ----------------
         const PBwdLayer& L = A.l1;
         const PBwdLayer& L2 = A.l2;
-        const int nt = member - nb2, U = L.U, N4 = 4 * U, K2 = 4 * L2.U, unit = nt * 32 + r, pc = nt * 128 + r;
+        const int nt = member - nb2, U = L.U, N4 = 4 * U, K2 = 4 * L2.U, unit = nt * 32 + r;
+        const size_t slab = (size_t)(N4 / 16) * 1024, slab2 = (size_t)(K2 / 16) * 1024;
         const int kba = w * 16 * KA + hh * 8, kbb = w * 16 * KB + hh * 8;
-        const size_t us = (size_t)B * U, us2 = (size_t)B * L2.U;
         bf16x8_t bw[KA], bq[KB];
         load_frags_plain<KA>(L.wh_p + (size_t)unit * N4 + kba, bw);
         load_frags_plain<KB>(L2.wx_p + (size_t)unit * K2 + kbb, bq);
-        for (int k = 0; k < T; ++k) {
-            const int t = T - 1 - k;
-            for (int j = 0; j < A.R; ++j) {
-                const int rt = grp + A.G * j;
-                if (rt >= A.nrt) break;
-                const int m0 = rt * 32;
-                float e_g[2][4], e_c[2], e_cp[2], e_dc[2], e_f[2];
-                bool live[2];
+        for (int i = 0; i < n_items; ++i) {
+            const int k = i / Rv, t = T - 1 - k, rt = grp + A.G * (i - k * Rv), m0 = rt * 32;
+            long long* trc = PST_TRP(3, member == nb2 && rt == 0, k);
+            PST_TR(trc, 0);
+            if (!pst_wait(flags + rt * 32, status, nb2, (unsigned)(k + 1), nm, (unsigned)k, &S.abort)) return;
+            PST_TR(trc, 1);
+            bf16x8_t aq[KB], aw[KA];
+            load_frags_xchg<KB>(L2.dzx + ((size_t)t * nrt + rt) * slab2, slab2, w * KB, aq);
+            load_frags_xchg<KA>(k > 0 ? L.dzx + ((size_t)(t + 1) * nrt + rt) * slab : L.dzxT + (size_t)rt * slab, slab, w * KA, aw);
+            float dcl[2];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int i = 2 * w + q;
-                    const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    live[q] = row < B;
-                    const int rr = live[q] ? row : B - 1;
-                    const size_t uo = (size_t)rr * U + unit, zo = (size_t)t * 4 * us + (size_t)rr * N4 + pc;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) e_g[q][g] = L.gates[zo + 32 * g];
-                    e_c[q] = L.c[(size_t)t * us + uo];
-                    e_cp[q] = t > 0 ? L.c[(size_t)(t - 1) * us + uo] : (L.c0 != nullptr ? L.c0[uo] : 0.f);
-                    e_dc[q] = k > 0 ? L.dc[uo] : 0.f;
-                    e_f[q] = L.mask != nullptr ? (float)L.mask[(size_t)t * us + uo] / A.kp : 1.f;
-                }
-                f32x16_t accq, accw;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { accq[i] = 0.f; accw[i] = 0.f; }
-                if (!pst_wait(flags + rt * 32, status, nb2, (unsigned)(k + 1), nm, (unsigned)k, &S.abort)) return;
-                const int arow = min(m0 + r, B - 1);
-                {
-                    bf16x8_t aq[KB];
-                    load_frags_sc1<KB>(slice_rsrc(L2.dzc + (size_t)t * 4 * us2, 4 * us2 * 2), (arow * K2 + kbb) * 2, aq);
-                    if (k > 0) {
-                        bf16x8_t aw[KA];
-                        load_frags_sc1<KA>(slice_rsrc(L.dzc + (size_t)(t + 1) * 4 * us, 4 * us * 2), (arow * N4 + kba) * 2, aw);
-#pragma unroll
-                        for (int s = 0; s < KB; ++s) accq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[s], bq[s], accq, 0, 0, 0);
-#pragma unroll
-                        for (int s = 0; s < KA; ++s) accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[s], bw[s], accw, 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int s = 0; s < KB; ++s) accq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[s], bq[s], accq, 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { S.red[0][w][i][lane] = accq[i]; S.red[1][w][i][lane] = accw[i]; }
-                __syncthreads();
-                float dh[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int i = 2 * w + q;
-                    float sq = 0.f, sw = 0.f;
-#pragma unroll
-                    for (int ww = 0; ww < 8; ++ww) { sq += S.red[0][ww][i][lane]; sw += S.red[1][ww][i][lane]; }
-                    dh[q] = (L.mask != nullptr ? sq * e_f[q] : sq) + sw;
-                }
-                pb_finish(L, S, T, B, t, m0, nt, dh, e_g, e_c, e_cp, e_dc, live, flags + rt * 32 + member, (unsigned)(k + 1));
+            for (int q = 0; q < 2; ++q) {
+                const int ii = 2 * w + q;
+                const size_t uo = (size_t)min(m0 + (ii & 3) + 8 * (ii >> 2) + 4 * hh, B - 1) * U + unit;
+                const float* dp = (k == 0 || Rv == 1) ? zero : L.dc + uo;
+                dcl[q] = *dp;
             }
+            BwdEpi e[2];
+            pb_epi_load<true>(L, B, nt, t, m0, zero, e);      // same item, behind the hand-off loads: registers are scarce in this role
+            pb_tail(L, S, B, Rv, nt, tl);
+            f32x16_t accq, accw;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { accq[j] = 0.f; accw[j] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KB; ++s) accq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[s], bq[s], accq, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < KA; ++s) accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[s], bw[s], accw, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { S.red[0][w][j][lane] = accq[j]; S.red[1][w][j][lane] = accw[j]; }
+            __syncthreads();
+            float dh[2], e_dc[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = 2 * w + q;
+                float sq = 0.f, sw = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) { sq += S.red[0][ww][j][lane]; sw += S.red[1][ww][j][lane]; }
+                dh[q] = (L.mask != nullptr ? sq * ((float)e[q].keep / A.kp) : sq) + sw;
+                e_dc[q] = (Rv == 1 && k > 0) ? tl.dcv[q] : dcl[q];
+            }
+            PST_TR(trc, 2);
+            pb_finish(L, S, nrt, t, rt, nt, dh, e, e_dc, tl, flags + rt * 32 + member, (unsigned)(k + 1), trc);
+            PST_TR(trc, 5);
         }
+        pb_tail(L, S, B, Rv, nt, tl);
     }
 }
 
@@ -552,13 +652,31 @@ static bool persist_plan(int B, int u1, int u2, int& nrt, int& G, int& R) {
     return true;
 }
 
+// workspace: [status | 31 zero words][32 flags per row tile][boundary slabs: layer 1, layer 2 (zeros / h0)] -- one memset
+// per call covers all of that -- [sticky word, padded][exchange area]
+static size_t sync_words(int nrt) { return (size_t)PST_FLAGS_OFF + 32 * (size_t)nrt; }
+static size_t edge_bytes(int nrt, int u1, int u2, bool bwd) { return (size_t)nrt * (bwd ? 256 : 64) * ((size_t)u1 + u2); }
+static size_t edge_max(int nrt, int u1, int u2) { return edge_bytes(nrt, u1, u2, true); }
+static size_t sticky_offset(int nrt, int u1, int u2) { return sync_words(nrt) * sizeof(unsigned) + edge_max(nrt, u1, u2); }
+static size_t xchg_offset(int nrt, int u1, int u2) { return (sticky_offset(nrt, u1, u2) + 16 + 255) / 256 * 256; }
+
 extern "C" int mnn_lstm2_persist_ok(int B, int u1, int u2) {
     int nrt, G, R;
     return persist_plan(B, u1, u2, nrt, G, R) ? 1 : 0;
 }
 
-extern "C" size_t mnn_lstm2_persist_sync_bytes(int B) {
-    return ((size_t)PST_FLAGS_OFF + 32 * (size_t)cdiv(B, 32) + 4) * sizeof(unsigned);
+extern "C" size_t mnn_lstm2_persist_workspace_bytes(int T, int B, int u1, int u2) {
+    const size_t nrt = (size_t)cdiv(B, 32), per = (size_t)T * nrt;
+    const size_t fwd = per * 64 * (2 * (size_t)u1 + u2), bwd = per * 256 * ((size_t)u1 + u2);
+    return xchg_offset((int)nrt, u1, u2) + (fwd > bwd ? fwd : bwd);
+}
+
+extern "C" int mnn_lstm2_persist_status(const void* workspace, int B, int u1, int u2, int* status) {
+    MNN_REQUIRE(workspace && status && B > 0 && u1 > 0 && u2 > 0, "mnn_lstm2_persist_status: bad arguments");
+    unsigned v = 0;
+    MNN_HIP(hipMemcpy(&v, (const char*)workspace + sticky_offset(cdiv(B, 32), u1, u2), sizeof(v), hipMemcpyDeviceToHost));
+    *status = (int)v;
+    return MNN_OK;
 }
 
 template <int K1>
@@ -578,40 +696,46 @@ static hipError_t launch_pbwd(hipStream_t st, int grid, const PBwdArgs& a, int u
 
 static PFwdLayer fwd_layer(const mnn_lstm_fwd_layer* L) {
     PFwdLayer p{};
-    p.xproj = L->xproj; p.wh_t = (const bf16_t*)L->wh_t; p.h0 = (const bf16_t*)L->h0; p.c0 = L->c0;
+    p.xproj = L->xproj; p.wh_t = (const bf16_t*)L->wh_t; p.c0 = L->c0;
     p.gates = L->gates; p.c = L->c; p.h = (bf16_t*)L->h; p.hT = (bf16_t*)L->hT; p.ld_hT = L->ld_hT; p.y = (bf16_t*)L->y; p.mask = L->mask;
     p.wx_t = (const bf16_t*)L->wx_t; p.ld_w = L->ld_w; p.bias_p = L->bias_p; p.U = L->units;
     return p;
 }
 
 extern "C" int mnn_lstm2_persist_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L1, const mnn_lstm_fwd_layer* L2, float keep_prob,
-                                     void* sync) {
+                                     void* workspace) {
     hipStream_t st = (hipStream_t)s;
-    MNN_REQUIRE(L1 && L2 && sync && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm2_persist_fwd: bad arguments");
+    MNN_REQUIRE(L1 && L2 && workspace && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm2_persist_fwd: bad arguments");
+    MNN_REQUIRE(((size_t)workspace & 255) == 0, "mnn_lstm2_persist_fwd: workspace must be 256-byte aligned");
     PFwdArgs a{};
     MNN_REQUIRE(persist_plan(B, L1->units, L2->units, a.nrt, a.G, a.R),
                 "mnn_lstm2_persist_fwd: units must be 128/256/512 with (u1+u2)/32 <= 32 and the grid must fit the device (B=%d u=%d,%d)", B,
                 L1->units, L2->units);
     MNN_REQUIRE(L1->xproj && L1->wh_t && L1->c && L1->h && L2->wh_t && L2->c && L2->h, "mnn_lstm2_persist_fwd: null pointer");
     MNN_REQUIRE(L2->wx_t && L2->bias_p && L2->ld_w >= L1->units, "mnn_lstm2_persist_fwd: layer 2 needs its input-projection weights");
-    MNN_REQUIRE((size_t)T * B * 4 * (L1->units > L2->units ? L1->units : L2->units) * 4 < ((size_t)1 << 40), "mnn_lstm2_persist_fwd: sequence too large");
-    MNN_REQUIRE((size_t)B * L1->units * 2 < ((size_t)1 << 31), "mnn_lstm2_persist_fwd: B*units too large for 32-bit tile offsets");
     for (const mnn_lstm_fwd_layer* L : {L1, L2}) {
         MNN_REQUIRE(L->hT == nullptr || L->ld_hT >= T * B, "mnn_lstm2_persist_fwd: ld_hT too small");
         MNN_REQUIRE((L->mask == nullptr) == (keep_prob >= 1.0f) && (L->mask == nullptr || L->y != nullptr),
                     "mnn_lstm2_persist_fwd: a keep mask and a y buffer are needed exactly when keep_prob < 1");
     }
+    const int u1 = L1->units, u2 = L2->units;
     a.l1 = fwd_layer(L1); a.l2 = fwd_layer(L2);
-    a.T = T; a.B = B; a.kp = keep_prob; a.sync = (unsigned*)sync;
-    const int grid = a.G * (L1->units / 32 + L2->units / 32);
-    const size_t zero_bytes = ((size_t)PST_FLAGS_OFF + 32 * (size_t)a.nrt) * sizeof(unsigned);
-    MNN_HIP(hipMemsetAsync(sync, 0, zero_bytes, st));
+    a.T = T; a.B = B; a.kp = keep_prob; a.sync = (unsigned*)workspace;
+    const size_t per = (size_t)T * a.nrt;
+    char* edge = (char*)workspace + sync_words(a.nrt) * sizeof(unsigned);
+    char* x = (char*)workspace + xchg_offset(a.nrt, u1, u2);
+    a.l1.hx0 = edge; a.l2.hx0 = edge + (size_t)a.nrt * 64 * u1;
+    a.l1.hx = x; a.l1.yx = x + per * 64 * u1; a.l2.hx = x + per * 128 * u1; a.l2.yx = nullptr;    // layer 2's dropped output is not handed off
+    const int grid = a.G * (u1 / 32 + u2 / 32);
+    MNN_HIP(hipMemsetAsync(workspace, 0, sync_words(a.nrt) * sizeof(unsigned) + edge_bytes(a.nrt, u1, u2, false), st));
+    if (L1->h0) hipLaunchKernelGGL(pst_fill_h0_kernel, dim3(a.nrt, u1 / 16), dim3(64), 0, st, (const bf16_t*)L1->h0, B, u1, edge);
+    if (L2->h0) hipLaunchKernelGGL(pst_fill_h0_kernel, dim3(a.nrt, u2 / 16), dim3(64), 0, st, (const bf16_t*)L2->h0, B, u2, edge + (size_t)a.nrt * 64 * u1);
     hipError_t e;
-    if (L1->units == 512) e = launch_pfwd<8>(st, grid, a, L2->units);
-    else if (L1->units == 256) e = launch_pfwd<4>(st, grid, a, L2->units);
-    else e = launch_pfwd<2>(st, grid, a, L2->units);
+    if (u1 == 512) e = launch_pfwd<8>(st, grid, a, u2);
+    else if (u1 == 256) e = launch_pfwd<4>(st, grid, a, u2);
+    else e = launch_pfwd<2>(st, grid, a, u2);
     MNN_HIP(e);
-    hipLaunchKernelGGL(pst_sticky_kernel, dim3(1), dim3(1), 0, st, (unsigned*)sync, PST_FLAGS_OFF + 32 * a.nrt);
+    hipLaunchKernelGGL(pst_sticky_kernel, dim3(1), dim3(1), 0, st, (unsigned*)workspace, (int)(sticky_offset(a.nrt, u1, u2) / sizeof(unsigned)));
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
@@ -619,40 +743,46 @@ extern "C" int mnn_lstm2_persist_fwd(mnn_stream_t s, int T, int B, const mnn_lst
 static PBwdLayer bwd_layer(const mnn_lstm_bwd_layer* L) {
     PBwdLayer p{};
     p.dh_ext = L->dh_ext; p.wh_p = (const bf16_t*)L->wh_p; p.gates = L->gates; p.c = L->c; p.c0 = L->c0;
-    p.dc = (float*)L->workspace; p.dz = L->dz; p.dzc = (bf16_t*)L->dz_T; p.dzTt = (bf16_t*)L->dzT_t; p.ld_t = L->ld_t; p.mask = L->mask;
+    p.dc = (float*)L->workspace; p.dzTt = (bf16_t*)L->dzT_t; p.ld_t = L->ld_t; p.mask = L->mask;
     p.wx_p = (const bf16_t*)L->wx_p; p.U = L->units;
     return p;
 }
 
 extern "C" int mnn_lstm2_persist_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L1, const mnn_lstm_bwd_layer* L2, float keep_prob,
-                                     void* sync) {
+                                     void* workspace) {
     hipStream_t st = (hipStream_t)s;
-    MNN_REQUIRE(L1 && L2 && sync && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm2_persist_bwd: bad arguments");
+    MNN_REQUIRE(L1 && L2 && workspace && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm2_persist_bwd: bad arguments");
+    MNN_REQUIRE(((size_t)workspace & 255) == 0, "mnn_lstm2_persist_bwd: workspace must be 256-byte aligned");
     PBwdArgs a{};
     MNN_REQUIRE(persist_plan(B, L1->units, L2->units, a.nrt, a.G, a.R),
                 "mnn_lstm2_persist_bwd: units must be 128/256/512 with (u1+u2)/32 <= 32 and the grid must fit the device (B=%d u=%d,%d)", B,
                 L1->units, L2->units);
     MNN_REQUIRE(L2->dh_ext && L2->wx_p, "mnn_lstm2_persist_bwd: layer 2 needs dh_ext and wx_p (its input weights, [u1, 4u2])");
-    MNN_REQUIRE((size_t)B * 4 * L1->units * 2 < ((size_t)1 << 31), "mnn_lstm2_persist_bwd: B*units too large for 32-bit tile offsets");
     for (const mnn_lstm_bwd_layer* L : {L1, L2}) {
-        MNN_REQUIRE(L->wh_p && L->gates && L->c && L->dz_T && L->workspace, "mnn_lstm2_persist_bwd: null pointer");
+        MNN_REQUIRE(L->wh_p && L->gates && L->c && L->workspace, "mnn_lstm2_persist_bwd: null pointer");
+        MNN_REQUIRE(L->dz == nullptr, "mnn_lstm2_persist_bwd: an f32 dz output is not produced by the persistent form");
         MNN_REQUIRE(L->dzT_t == nullptr || L->ld_t >= T * B, "mnn_lstm2_persist_bwd: ld_t too small");
         MNN_REQUIRE(L->db_p == nullptr || L->dzT_t != nullptr, "mnn_lstm2_persist_bwd: db_p needs dzT_t");
     }
     MNN_REQUIRE((L1->mask == nullptr) == (keep_prob >= 1.0f), "mnn_lstm2_persist_bwd: layer 1's keep mask is needed exactly when keep_prob < 1");
+    const int u1 = L1->units, u2 = L2->units;
     a.l1 = bwd_layer(L1); a.l2 = bwd_layer(L2);
-    a.T = T; a.B = B; a.kp = keep_prob; a.sync = (unsigned*)sync;
-    const int grid = a.G * (L1->units / 32 + L2->units / 32);
-    const size_t zero_bytes = ((size_t)PST_FLAGS_OFF + 32 * (size_t)a.nrt) * sizeof(unsigned);
-    MNN_HIP(hipMemsetAsync(sync, 0, zero_bytes, st));
+    a.T = T; a.B = B; a.kp = keep_prob; a.sync = (unsigned*)workspace;
+    const size_t per = (size_t)T * a.nrt;
+    char* edge = (char*)workspace + sync_words(a.nrt) * sizeof(unsigned);
+    char* x = (char*)workspace + xchg_offset(a.nrt, u1, u2);
+    a.l1.dzxT = edge; a.l2.dzxT = edge + (size_t)a.nrt * 256 * u1;
+    a.l1.dzx = x; a.l2.dzx = x + per * 256 * u1;
+    const int grid = a.G * (u1 / 32 + u2 / 32);
+    MNN_HIP(hipMemsetAsync(workspace, 0, sync_words(a.nrt) * sizeof(unsigned) + edge_bytes(a.nrt, u1, u2, true), st));
     hipError_t e;
-    if (L1->units == 512) e = launch_pbwd<16>(st, grid, a, L2->units);
-    else if (L1->units == 256) e = launch_pbwd<8>(st, grid, a, L2->units);
-    else e = launch_pbwd<4>(st, grid, a, L2->units);
+    if (u1 == 512) e = launch_pbwd<16>(st, grid, a, u2);
+    else if (u1 == 256) e = launch_pbwd<8>(st, grid, a, u2);
+    else e = launch_pbwd<4>(st, grid, a, u2);
     MNN_HIP(e);
-    hipLaunchKernelGGL(pst_sticky_kernel, dim3(1), dim3(1), 0, st, (unsigned*)sync, PST_FLAGS_OFF + 32 * a.nrt);
-    if (L2->db_p) hipLaunchKernelGGL(pst_rowsum_bf16_kernel, dim3(4 * L2->units), dim3(256), 0, st, (const bf16_t*)L2->dzT_t, L2->ld_t, 0, T * B, L2->db_p);
-    if (L1->db_p) hipLaunchKernelGGL(pst_rowsum_bf16_kernel, dim3(4 * L1->units), dim3(256), 0, st, (const bf16_t*)L1->dzT_t, L1->ld_t, 0, T * B, L1->db_p);
+    hipLaunchKernelGGL(pst_sticky_kernel, dim3(1), dim3(1), 0, st, (unsigned*)workspace, (int)(sticky_offset(a.nrt, u1, u2) / sizeof(unsigned)));
+    if (L2->db_p) hipLaunchKernelGGL(pst_rowsum_bf16_kernel, dim3(4 * u2), dim3(256), 0, st, (const bf16_t*)L2->dzT_t, L2->ld_t, 0, T * B, L2->db_p);
+    if (L1->db_p) hipLaunchKernelGGL(pst_rowsum_bf16_kernel, dim3(4 * u1), dim3(256), 0, st, (const bf16_t*)L1->dzT_t, L1->ld_t, 0, T * B, L1->db_p);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

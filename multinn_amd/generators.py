@@ -103,18 +103,18 @@ class LstmStack:
             return False
         return ops.lstm2_persist_ok(B, self.packed[0]["u"], self.packed[1]["u"])
 
-    def _sync(self, B, dev):
-        """Progress-flag scratch of the persistent launches, one per batch size (kept alive: captured graphs point at it)."""
-        if not hasattr(self, "_sync_ws"):
-            self._sync_ws = {}
-        if B not in self._sync_ws:
-            self._sync_ws[B] = ops.lstm2_persist_sync(B, dev)
-        return self._sync_ws[B]
+    def _workspace(self, T, B, dev):
+        """Flags + exchange area of the persistent launches, one per (T, B) (kept alive: captured graphs point at it)."""
+        if not hasattr(self, "_pws"):
+            self._pws = {}
+        if (T, B) not in self._pws:
+            self._pws[(T, B)] = ops.lstm2_persist_workspace(T, B, self.packed[0]["u"], self.packed[1]["u"], dev)
+        return self._pws[(T, B)]
 
     def check(self):
         """Raise if a persistent launch ever gave up waiting (synchronises the device)."""
-        for ws in getattr(self, "_sync_ws", {}).values():
-            ops.lstm2_persist_check(ws)
+        for (T, B), ws in getattr(self, "_pws", {}).items():
+            ops.lstm2_persist_check(ws, B, self.packed[0]["u"], self.packed[1]["u"])
 
     @staticmethod
     def _chunks(T, step):
@@ -165,7 +165,7 @@ class LstmStack:
             d1 = ops.lstm2_fwd_layer(b1["xproj"], p1["wh_t"], b1["h0"], b1["c0"], b1["gates"], b1["c"], b1["h"], b1["hT"],
                                      b1["y"] if masks[1] is not None else None, masks[1], p1["wx_t"], p1["bias_p"])
             if persist:
-                ops.lstm2_persist_fwd(T, B, d0, d1, keep_prob, self._sync(B, dev))
+                ops.lstm2_persist_fwd(T, B, d0, d1, keep_prob, self._workspace(T, B, dev))
             else:
                 ops.lstm2_seq_fwd(T, B, d0, d1, keep_prob)
             for bf, mk in zip(bufs, masks):
@@ -237,21 +237,21 @@ class LstmStack:
             s.wait_stream(main)
         dyl = [None] * L
         dyl[L - 1] = dy.view(T, B, -1)
+        persist = self._persist(B) and (keep_prob >= 1.0 or ctx[0].get("mask") is not None)
         st = []
         Np = ops.round_up(T * B, 64)
         for l, p in enumerate(self.packed):
             u = p["u"]
             fused = ops.lstm_fused_outputs(self.dtype, u)          # bf16 step kernels emit dz^T and sum(dz) themselves
             dz = None if fused else torch.empty((T, B, 4 * u), device=dev)
-            st.append(dict(dz=dz, dzc=dz if self.dtype == torch.float32 else torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype),
+            st.append(dict(dz=dz, dzc=None if persist else (dz if self.dtype == torch.float32 else torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype)),
                            dzT=(torch.zeros if Np != T * B else torch.empty)((4 * u, Np), device=dev, dtype=self.dtype),
                            db_p=torch.zeros(4 * u, device=dev),
                            dh=torch.empty((T, B, u), device=dev) if keep_prob < 1.0 else None, ws=ops.lstm_seq_bwd_workspace(B, u, dev)))
-            if l < L - 1:
+            if l < L - 1 and not persist:
                 dyl[l] = torch.empty((T, B, u), device=dev)
         lane_of = lambda l: lanes[L - 1 - l] if piped else main          # the top layer leads, on the current stream
         done = [[None] * len(chunks) for _ in range(L)]
-        persist = self._persist(B) and (keep_prob >= 1.0 or ctx[0].get("mask") is not None)
         if (persist or (self._fused2(B) and ctx[0]["h0"] is None)) and (keep_prob >= 1.0 or ctx[0].get("mask") is not None):
             p0, p1 = self.packed
             if keep_prob < 1.0:
@@ -263,7 +263,7 @@ class LstmStack:
             e1 = ops.lstm2_bwd_layer(dh1, p1["wh_p"], ctx[1]["gates"], ctx[1]["c"], ctx[1]["c0"], st[1]["dzc"], st[1]["ws"], st[1]["dzT"], st[1]["db_p"],
                                      None, p1["wx_p"])
             if persist:
-                ops.lstm2_persist_bwd(T, B, e0, e1, keep_prob, self._sync(B, dev))
+                ops.lstm2_persist_bwd(T, B, e0, e1, keep_prob, self._workspace(T, B, dev))
             else:
                 ops.lstm2_seq_bwd(T, B, e0, e1, keep_prob)
             chunks = []

@@ -236,14 +236,14 @@ def lstm2_bwd_layer(dh_ext, wh_p, gates, c, c0, dz_T, ws, dzT_t, db_p, mask=None
     _req(wh_p.shape == (u, N4) and wh_p.is_contiguous() and wh_p.dtype == torch.bfloat16, "lstm2 bwd: wh_p bf16 [u,4u]")
     _req(gates.shape == (T, B, N4) and gates.dtype == torch.float32 and gates.is_contiguous(), "lstm2 bwd: gates")
     _req(c.shape == (T, B, u) and c.dtype == torch.float32 and c.is_contiguous(), "lstm2 bwd: c")
-    _req(dz_T.shape == (T, B, N4) and dz_T.dtype == torch.bfloat16 and dz_T.is_contiguous(), "lstm2 bwd: dz_T bf16 [T,B,4u]")
+    _req(dz_T is None or (dz_T.shape == (T, B, N4) and dz_T.dtype == torch.bfloat16 and dz_T.is_contiguous()), "lstm2 bwd: dz_T bf16 [T,B,4u]")
     _req(dzT_t is None or (dzT_t.dim() == 2 and dzT_t.shape[0] == N4 and dzT_t.stride(1) == 1 and dzT_t.shape[1] >= T * B
                            and dzT_t.dtype == torch.bfloat16), "lstm2 bwd: dzT_t")
     _req(db_p is None or (db_p.dtype == torch.float32 and db_p.numel() == N4 and dzT_t is not None), "lstm2 bwd: db_p")
     _req(ws.numel() >= B * u * 4, "lstm2 bwd: workspace too small")
     _req(mask is None or (mask.dtype == torch.uint8 and mask.shape == (T, B, u) and mask.is_contiguous()), "lstm2 bwd: mask u8 [T,B,u]")
     _req(wx_p is None or (wx_p.dim() == 2 and wx_p.shape[1] == N4 and wx_p.is_contiguous() and wx_p.dtype == torch.bfloat16), "lstm2 bwd: wx_p [n_in,4u]")
-    for t in (wh_p, gates, c, dz_T, ws):
+    for t in (wh_p, gates, c, ws):
         _ptr(t)
     return _lib.LstmBwdLayer(u, _p0(dh_ext), _p0(wh_p), _p0(gates), _p0(c), _p0(c0), None, _p0(dz_T), _p0(ws), _p0(dzT_t),
                              dzT_t.stride(0) if dzT_t is not None else 0, _p0(db_p), _p0(mask), _p0(wx_p))
@@ -260,30 +260,33 @@ def lstm2_persist_ok(B, u1, u2):
     return bool(_lib.load().mnn_lstm2_persist_ok(int(B), int(u1), int(u2)))
 
 
-def lstm2_persist_sync(B, device):
-    """Progress-flag scratch of the persistent recurrence: int32 words, zeroed here once; [-1] is the sticky give-up word."""
-    n = _lib.load().mnn_lstm2_persist_sync_bytes(int(B))
-    return torch.zeros(n // 4, dtype=torch.int32, device=device)
+def lstm2_persist_workspace(T, B, u1, u2, device):
+    """Progress flags + exchange area of the persistent recurrence (zeroed here, once)."""
+    n = _lib.load().mnn_lstm2_persist_workspace_bytes(int(T), int(B), int(u1), int(u2))
+    return torch.zeros(n, dtype=torch.uint8, device=device)
 
 
-def _sync_ok(sync, B):
-    _req(sync.dtype == torch.int32 and sync.is_contiguous() and sync.numel() * 4 >= _lib.load().mnn_lstm2_persist_sync_bytes(int(B))
-         and sync.data_ptr() % 128 == 0, "lstm2 persist: sync must be the int32 tensor of lstm2_persist_sync(B)")
+def _ws_ok(ws, T, B, L1, L2):
+    _req(ws.dtype == torch.uint8 and ws.is_contiguous() and ws.data_ptr() % 256 == 0
+         and ws.numel() >= _lib.load().mnn_lstm2_persist_workspace_bytes(int(T), int(B), L1.units, L2.units),
+         "lstm2 persist: workspace must be the tensor of lstm2_persist_workspace(T, B, u1, u2)")
 
 
-def lstm2_persist_fwd(T, B, L1, L2, keep_prob, sync):
-    _sync_ok(sync, B)
-    call("mnn_lstm2_persist_fwd", _stream(), T, B, C.byref(L1), C.byref(L2), float(keep_prob), _ptr(sync))
+def lstm2_persist_fwd(T, B, L1, L2, keep_prob, ws):
+    _ws_ok(ws, T, B, L1, L2)
+    call("mnn_lstm2_persist_fwd", _stream(), T, B, C.byref(L1), C.byref(L2), float(keep_prob), _ptr(ws))
 
 
-def lstm2_persist_bwd(T, B, L1, L2, keep_prob, sync):
-    _sync_ok(sync, B)
-    call("mnn_lstm2_persist_bwd", _stream(), T, B, C.byref(L1), C.byref(L2), float(keep_prob), _ptr(sync))
+def lstm2_persist_bwd(T, B, L1, L2, keep_prob, ws):
+    _ws_ok(ws, T, B, L1, L2)
+    call("mnn_lstm2_persist_bwd", _stream(), T, B, C.byref(L1), C.byref(L2), float(keep_prob), _ptr(ws))
 
 
-def lstm2_persist_check(sync):
-    """Raise if any persistent launch that used this scratch gave up on a bounded spin (synchronises)."""
-    if int(sync[-1].item()) != 0:
+def lstm2_persist_check(ws, B, u1, u2):
+    """Raise if any persistent launch that used this workspace gave up on a bounded spin (synchronises)."""
+    st = C.c_int(0)
+    call("mnn_lstm2_persist_status", _ptr(ws), int(B), int(u1), int(u2), C.byref(st))
+    if st.value != 0:
         raise _lib.MnnError("persistent LSTM launch timed out waiting for a neighbouring workgroup (grid not co-resident?)")
 
 
