@@ -130,6 +130,7 @@ def main():
             gen.train_step(x, None, opt)
         torch.cuda.synchronize()
     timing, _lib.TIMING = _lib.TIMING, None
+    gen._stack.check()                  # a persistent launch that gave up on a bounded spin would have produced garbage: fail loudly
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -158,6 +159,14 @@ def main():
         roof = dict(bound="hbm", achieved=byts / (dom_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", traffic=None, kernel=dom,
                     launches_per_step=1, avg_launch_us=dom_ms * 1e3,
                     note="VALU-bound scan (SURVEY 8d): the HBM fraction only shows HBM is not the limiter")
+    elif dom in ("mnn_lstm2_persist_fwd", "mnn_lstm2_persist_bwd"):
+        # ONE launch for the T-step recurrence of both layers; layer 2's input projection (its dgrad, backward) is folded in
+        flops = rec_flops + 2.0 * N * R1 * 4 * R2
+        roof = dict(bound="mfma", achieved=flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
+                    kernel="lstm2_persist_%s_kernel" % ("bwd" if dom.endswith("bwd") else "fwd"), launches_per_step=1,
+                    avg_launch_us=dom_ms * 1e3, avg_timestep_us=dom_ms * 1e3 / T,
+                    note="latency-bound chain of T in-kernel tile hand-offs (flag + 32-row tile through the fabric per timestep): "
+                         "the number to watch is avg_timestep_us")
     elif dom in ("mnn_lstm_seq_fwd", "mnn_lstm_seq_bwd", "mnn_lstm2_seq_fwd", "mnn_lstm2_seq_bwd"):
         fused = dom.startswith("mnn_lstm2")
         launches = (T + 2) if fused else 2 * T            # fused: one three-stage launch per timestep for both layers (lag 2)
