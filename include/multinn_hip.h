@@ -172,6 +172,15 @@ int mnn_dropout_fwd(mnn_stream_t s, int dtype, const void* h, void* y, int T, in
 int mnn_dropout_bwd(mnn_stream_t s, const float* dy, float* dh, int T, int B, int units, float keep_prob, uint64_t seed,
                     const int32_t* step_dev, uint32_t row0, int layer, int accumulate, int t_offset);
 
+/* NADE log-prob on the matrix cores (multinn_amd/csrc/nade_mfma.hip), Hn == 256 only (mnn_nade_mfma_ok): same contract and
+ * outputs as mnn_nade_logprob_fwd, but the D x Hn decoder dot products of a row run as a block-sparse bf16 GEMM over the
+ * row's 1 + nnz(v) distinct hidden states (f32 accumulation; the encoder sums stay f32).  w_dec_bf16: bf16 copy of w_dec,
+ * [tracks,D,Hn] (mnn_convert2d).  Used by the bf16 compute mode; the f32 entries above remain the parity path. */
+int mnn_nade_mfma_ok(int Hn);
+int mnn_nade_logprob_fwd_mfma(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride, const float* bias,
+                              int ld_bias, const float* w_enc, const void* w_dec_bf16, const float* row_weight, float* nll, float* cond_p,
+                              float* d_bias, float* a_final);
+
 /* ------------------------------------------------------------------------------------------
  * NADE (models/common/nade.py).  Weights w_enc,w_dec f32 [tracks,D,Hn].  Rows: v u8
  * [tracks][N][D] (track stride v_track_stride, row stride D); biases come from one Dense output

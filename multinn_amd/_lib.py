@@ -64,6 +64,8 @@ SIGNATURES["mnn_lstm2_persist_workspace_bytes"] = (_sz, [_i, _i, _i, _i])
 SIGNATURES["mnn_lstm2_persist_status"] = (_i, [_p, _i, _i, _i, C.POINTER(C.c_int)])
 SIGNATURES["mnn_lstm2_persist_fwd"] = (_i, [_p, _i, _i, C.POINTER(LstmFwdLayer), C.POINTER(LstmFwdLayer), _f, _p])
 SIGNATURES["mnn_lstm2_persist_bwd"] = (_i, [_p, _i, _i, C.POINTER(LstmBwdLayer), C.POINTER(LstmBwdLayer), _f, _p])
+SIGNATURES["mnn_nade_mfma_ok"] = (_i, [_i])
+SIGNATURES["mnn_nade_logprob_fwd_mfma"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p])
 SIGNATURES["mnn_dropout_mask"] = (_i, [_p, _p, _i, _i, _i, _f, _u64, _p, _u32, _i])
 
 _lib = None

@@ -1,0 +1,335 @@
+// NADE log-prob on the matrix cores (bf16 operands, f32 accumulation) for Hn = 256: forward scan.
+// Reference: /root/reference/multinn/models/common/nade.py:155-229.
+//
+// The conditional of visible d is  p_d = sigmoid(b_dec[d] + w_dec[d] . h_d),  h_d = sigmoid(a_d),
+// a_{d+1} = a_d + v_d w_enc[d]  (nade.py:206-219).  `a` only moves at visibles with v = 1, so a row has
+// 1 + nnz(v) distinct hidden STATES and the D dot products are a block-sparse GEMM
+//     logits[row, d] = state(row, d) . w_dec[d]
+// A workgroup owns 32 rows and walks the visibles in tiles of 32 columns.  Per tile:
+//   * base states (one per row, as of the tile's first column) x w_dec tile  -> 32 x 32 logits on MFMA
+//   * every flip (v = 1) inside the tile creates a new state: a += w_enc[d] in f32 (thread = hidden unit),
+//     h = sigmoid(a) -> bf16 into a flip-state tile; flip states x w_dec tile -> 32-slot x 32 logits on MFMA
+//   * each (row, d) picks the logit of the latest state created before d (popcount of the row's v bits), adds
+//     b_dec, and finishes p, the NLL term and d nll / d b_dec.
+// The dense work (D x Hn MACs per row) runs on v_mfma_f32_16x16x32_bf16; the VALU keeps only the sparse encoder
+// adds, one sigmoid per state element and the per-(row, d) pointwise.  w_enc stays f32 (a is exact up to f32
+// summation order and is handed to the backward pass as a_final); w_dec is read as a bf16 copy.
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* gas_ptr_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#ifdef NM_TRACE      // development only: per-phase clocks of one workgroup (scratch/nade_trace.hip)
+__device__ long long nm_trace[16];
+#define NM_T(k) do { if (tid == 0 && blockIdx.x == NM_TRACE) { const long long now_ = wall_clock64(); nm_trace[k] += now_ - tprev_; tprev_ = now_; } } while (0)
+#else
+#define NM_T(k) do { } while (0)
+#endif
+#define NADE_EPS 1e-6f
+#define LN2F 0.6931471805599453f
+#define NM_H 256          // hidden width this kernel is specialised for
+#define NM_PITCH 264      // bf16 elements per state-tile row (256 + 8 pad: rows 16 B aligned, 4-bank skew)
+#define NM_LP 36          // floats per logit-tile row
+
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt(0), i.e. every
+// prefetch load and every result store in flight would be waited for at each of the tile's barriers.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ float nm_ln(float x) { return __builtin_amdgcn_logf(x) * LN2F; }
+
+struct NadeFwdSmem {
+    float sA[32][NM_H];                 // pre-activations a[row][hidden] (f32; thread = hidden unit owns a column)
+    bf16_t sH[32][NM_PITCH];            // current state of every row (as of the tile being processed)
+    bf16_t sF[32][NM_PITCH];            // states created by the flips of the tile (one chunk of 32 slots)
+    float sLb[32][NM_LP];               // logits of the base states  [row][column]
+    float sLf[32][NM_LP];               // logits of the flip states  [slot][column]
+    unsigned sMask[2][32];              // v bits of the tile, per row (double buffered: tile c, tile c+1)
+    unsigned sSb[2][33];                // exclusive prefix of popcounts (slot of a row's first flip); [32] = flips in the tile
+    unsigned short sFl[2][1024];        // flips in pass order: row << 5 | column
+    unsigned short sPs[2][34];          // first slot of pass j (the j-th flips of the rows)
+    unsigned sAct[2][32];               // rows taking part in pass j (bit n: row n has more than j flips in the tile)
+};
+
+// 16 rows x K=256 of a state tile as MFMA A fragments (lane: row l & 15, k = 32 s + 8 (l >> 4) + j)
+__device__ __forceinline__ void nm_load_a(const bf16_t (*tile)[NM_PITCH], int mi, int lane, bf16x8_t (&a)[8]) {
+    const bf16_t* p = &tile[16 * mi + (lane & 15)][8 * (lane >> 4)];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) a[s] = *reinterpret_cast<const bf16x8_t*>(p + 32 * s);
+}
+
+// thread = hidden unit: the 32 rows' pre-activations a[32] live in registers and are indexed by the (wave-uniform) row of
+// each flip -- the compiler lowers that to s_set_gpr_idx, no scratch.  Per flip the VALU does one add, one sigmoid,
+// one bf16 convert and two LDS writes; everything it needs (the flip list, the flips' w_enc values) was fetched a tile ahead.
+__global__ void __launch_bounds__(256)
+nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias, int ld_bias,
+                     const float* __restrict__ w_enc, const bf16_t* __restrict__ w_dec_bf, const float* __restrict__ row_weight,
+                     float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias, float* __restrict__ a_final) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    NadeFwdSmem& S = *reinterpret_cast<NadeFwdSmem*>(smem_raw);
+    constexpr int Hn = NM_H;
+    const int m = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mi = w & 1, ni = w >> 1;                       // this wave's 16 x 16 quadrant of a 32 x 32 logit tile
+    const int rb = blockIdx.x * 32;
+    const uint8_t* __restrict__ vm = v + (size_t)m * v_track_stride;
+    const float* __restrict__ we = w_enc + (size_t)m * D * Hn;
+    const bf16_t* __restrict__ wd = w_dec_bf + (size_t)m * D * Hn;
+    const int bd_off = tracks * Hn + m * D;
+    const int ntile = (D + 31) / 32;
+
+#pragma unroll 4
+    for (int n = 0; n < 32; ++n) {
+        const int row = rb + n;
+        const float av = row < N ? bias[(size_t)row * ld_bias + m * Hn + tid] : 0.f;
+        S.sA[n][tid] = av;
+        S.sH[n][tid] = f32_to_bf16(fast_sigmoid(av));
+    }
+    // v bytes of rows 8w .. 8w+7 of a tile: lane -> (row 8w + 2i + (lane >> 5), column lane & 31)
+    auto load_v = [&](int c, unsigned char (&vb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = min(rb + 8 * w + 2 * i + (lane >> 5), N - 1), dd = min(32 * c + (lane & 31), D - 1);
+            vb[i] = vm[(size_t)row * D + dd];
+        }
+    };
+    auto ballots = [&](int c, const unsigned char (&vb)[4], unsigned (&msk)[32]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = rb + 8 * w + 2 * i + (lane >> 5), dd = 32 * c + (lane & 31);
+            const unsigned long long bal = __ballot(row < N && dd < D && vb[i] != 0);
+            if (lane == 0) { msk[8 * w + 2 * i] = (unsigned)bal; msk[8 * w + 2 * i + 1] = (unsigned)(bal >> 32); }
+        }
+    };
+    // wave 0: flip list of the tile whose masks are in sMask[buf], in PASS order (all first flips of the rows, then all second
+    // flips, ...): consecutive entries touch different rows, so their read-modify-writes of sA are independent.
+    // sSb[buf][n] keeps the rank-0 slot of row n; the slot of its j-th flip is looked up through sPs (start of pass j).
+    auto build_list = [&](int buf) {
+        if (w == 0) {
+            const unsigned mk = lane < 32 ? S.sMask[buf][lane] : 0u;
+            const int cnt = __popc(mk);
+            unsigned rest = mk;
+            int base = 0;
+            for (int j = 0; j < 32; ++j) {                   // pass j: rows with more than j flips, in row order
+                const unsigned act = (unsigned)__ballot(cnt > j);
+                if (lane == 0) { S.sPs[buf][j] = (unsigned short)base; S.sAct[buf][j] = act; }
+                if (act == 0u) break;
+                if (cnt > j) {
+                    const int pos = base + __popc(act & ((1u << lane) - 1u));
+                    const int dpos = __builtin_ctz(rest);
+                    rest &= rest - 1;
+                    S.sFl[buf][pos] = (unsigned short)((lane << 5) | dpos);
+                }
+                base += __popc(act);
+            }
+            if (lane == 0) S.sSb[buf][32] = (unsigned)base;
+        }
+    };
+    auto load_b = [&](int c, bf16x8_t (&b)[8]) {            // lane: column l & 15 of the wave's column half, k = 32 s + 8 (l >> 4) + j
+        const int d = min(32 * c + 16 * ni + (lane & 15), D - 1);
+        const bf16_t* p = wd + (size_t)d * Hn + 8 * (lane >> 4);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) b[s] = *reinterpret_cast<const bf16x8_t*>(p + 32 * s);
+    };
+    // w_enc[column of flip k0+u][this hidden unit] for the 32 flips of a chunk (entries past the tile's count re-read flip 0's row)
+    auto load_we = [&](int c, int buf, int k0, float (&wv)[32]) {
+        const int F = (int)S.sSb[buf][32];
+        int ent[32];                                         // all list reads first, then all global loads: nothing serialises on LDS latency
+#pragma unroll
+        for (int u = 0; u < 32; ++u) ent[u] = S.sFl[buf][(k0 + u < F) ? k0 + u : 0];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int e = __builtin_amdgcn_readfirstlane(ent[u]);
+            wv[u] = we[(size_t)min(32 * c + (e & 31), D - 1) * Hn + tid];
+        }
+    };
+    unsigned char vb[4];
+    bf16x8_t bfr[8];
+    float wev[32];
+    load_v(0, vb);
+    load_b(0, bfr);
+    ballots(0, vb, S.sMask[0]);
+    if (ntile > 1) load_v(1, vb);
+    __syncthreads();
+    build_list(0);
+    __syncthreads();
+    load_we(0, 0, 0, wev);
+
+    // epilogue ownership: thread -> row n = tid >> 3, columns 4 (tid & 7) + k
+    const int en = tid >> 3, ed0 = 4 * (tid & 7), erow = rb + en;
+    const bool evalid = erow < N;
+    const int err = evalid ? erow : N - 1;
+    const float rw = (row_weight != nullptr && evalid) ? row_weight[erow] : 0.f;
+    float lp = 0.f;
+#ifdef NM_TRACE
+    long long tprev_ = wall_clock64();
+#endif
+    for (int c = 0; c < ntile; ++c) {
+        const int buf = c & 1, nbuf = buf ^ 1;
+        // ---- S0: base logits; the next tile's operands start flying ----
+        float bdec[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bdec[k] = bias[(size_t)err * ld_bias + bd_off + min(32 * c + ed0 + k, D - 1)];
+        {
+            bf16x8_t af[8];
+            nm_load_a(S.sH, mi, lane, af);
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], bfr[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S.sLb[16 * mi + 4 * (lane >> 4) + i][16 * ni + (lane & 15)] = acc[i];
+        }
+        if (c + 1 < ntile) {
+            ballots(c + 1, vb, S.sMask[nbuf]);               // v bytes requested one tile ago
+            if (c + 2 < ntile) load_v(c + 2, vb);
+        }
+        NM_T(0);
+        lds_barrier();                                     // B1: sLb complete, sH consumed, next masks written
+        NM_T(1);
+        const int F = (int)S.sSb[buf][32];
+        const unsigned mk = S.sMask[buf][en];
+        float lsel[4];                                       // the logit of each of this thread's 4 (row, column) pairs
+        int jj[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            jj[k] = __popc(mk & ((1u << (ed0 + k)) - 1u));   // flips of this row strictly before the column
+            lsel[k] = S.sLb[en][ed0 + k];
+        }
+        int slot_of[4];                                      // slot of the state each pair uses: pass jj-1, rank of the row among that pass's rows
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pj = max(jj[k] - 1, 0);
+            slot_of[k] = jj[k] > 0 ? (int)S.sPs[buf][pj] + __popc(S.sAct[buf][pj] & ((1u << en) - 1u)) : -1;
+        }
+        for (int k0 = 0; k0 < F; k0 += 32) {
+            // ---- S1: the chunk's flips in pass order: a[row] += w_enc[d]; new state -> sF[slot] and the row's current state.
+            //      Eight at a time: within a pass the rows are distinct (and ascending), so the eight read-modify-writes of
+            //      sA are issued together and the in-order VALU sees eight independent chains.
+            if (k0 > 0) load_we(c, buf, k0, wev);            // rare: more than 32 flips in one tile
+            const int cnt = min(32, F - k0);
+#pragma unroll
+            for (int u0 = 0; u0 < 32; u0 += 8) {
+                if (u0 < cnt) {
+                    int n[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) n[i] = __builtin_amdgcn_readfirstlane((int)S.sFl[buf][min(k0 + u0 + i, F - 1)]) >> 5;
+                    bool indep = u0 + 8 <= cnt;              // a full batch inside one pass: rows strictly ascending, hence distinct
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) indep = indep && n[i] < n[i + 1];
+                    if (indep) {
+                        float x[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x[i] = S.sA[n[i]][tid];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x[i] += wev[u0 + i];
+                        bf16_t hb[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) hb[i] = f32_to_bf16(fast_sigmoid(x[i]));
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            if (u0 + i < cnt) {
+                                S.sA[n[i]][tid] = x[i];
+                                S.sF[u0 + i][tid] = hb[i];
+                                S.sH[n[i]][tid] = hb[i];
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            if (u0 + i < cnt) {
+                                const float av = S.sA[n[i]][tid] + wev[u0 + i];
+                                S.sA[n[i]][tid] = av;
+                                const bf16_t hb1 = f32_to_bf16(fast_sigmoid(av));
+                                S.sF[u0 + i][tid] = hb1;
+                                S.sH[n[i]][tid] = hb1;
+                            }
+                        }
+                    }
+                }
+            }
+            NM_T(2);
+            if (k0 == 0 && c + 1 < ntile) build_list(nbuf);
+            NM_T(3);
+            lds_barrier();                                 // B2: sF complete (and the next tile's list)
+            NM_T(4);
+            // ---- S2: flip logits; each pair whose state sits in this chunk picks its logit ----
+            {
+                bf16x8_t af[8];
+                nm_load_a(S.sF, mi, lane, af);
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], bfr[s], acc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) S.sLf[16 * mi + 4 * (lane >> 4) + i][16 * ni + (lane & 15)] = acc[i];
+            }
+            if (k0 == 0 && F <= 32 && c + 1 < ntile) load_we(c + 1, nbuf, 0, wev);     // behind the MFMAs: the next tile's encoder rows
+            NM_T(5);
+            lds_barrier();                                 // B3: sLf ready
+            NM_T(6);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int slot = slot_of[k] - k0;
+                if (slot_of[k] >= 0 && slot >= 0 && slot < 32) lsel[k] = S.sLf[slot][ed0 + k];
+            }
+        }
+        if (F == 0 && c + 1 < ntile) {                       // no flip in this tile: the bookkeeping of the loop body still has to happen
+            build_list(nbuf);
+            lds_barrier();
+            load_we(c + 1, nbuf, 0, wev);
+        } else if (F > 32 && c + 1 < ntile) {
+            load_we(c + 1, nbuf, 0, wev);                    // the extra chunks overwrote the prefetched values
+        }
+        if (c + 1 < ntile) load_b(c + 1, bfr);               // the tile's MFMAs are issued: fetch the next tile's w_dec fragments under the pointwise
+        NM_T(7);
+        // ---- S3: pointwise of this thread's 4 pairs, once per tile ----
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int dpos = ed0 + k, gd = 32 * c + dpos;
+            if (gd >= D) continue;
+            const float l = bdec[k] + lsel[k];
+            const bool on = (mk >> dpos) & 1u;
+            const float pr = fast_sigmoid(l);
+            const float qr = fast_sigmoid(-l);               // 1-p without cancellation
+            lp += on ? nm_ln(NADE_EPS + pr) : nm_ln(NADE_EPS + qr);
+            if (evalid) {
+                if (cond_p != nullptr) cond_p[((size_t)m * N + erow) * D + gd] = pr;
+                if (d_bias != nullptr) {
+                    const float dnll_dp = on ? -fast_rcp(NADE_EPS + pr) : fast_rcp(NADE_EPS + qr);
+                    d_bias[(size_t)erow * ld_bias + bd_off + gd] = rw * dnll_dp * pr * qr;
+                }
+            }
+        }
+        NM_T(8);
+    }
+    lp += __shfl_xor(lp, 1);
+    lp += __shfl_xor(lp, 2);
+    lp += __shfl_xor(lp, 4);
+    if ((tid & 7) == 0 && evalid && nll != nullptr) nll[(size_t)m * N + erow] = -lp;
+    if (a_final != nullptr) {
+#pragma unroll 4
+        for (int n = 0; n < 32; ++n)
+            if (rb + n < N) a_final[((size_t)m * N + rb + n) * Hn + tid] = S.sA[n][tid];
+    }
+}
+
+extern "C" int mnn_nade_mfma_ok(int Hn) { return Hn == NM_H ? 1 : 0; }
+
+extern "C" int mnn_nade_logprob_fwd_mfma(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
+                                         const float* bias, int ld_bias, const float* w_enc, const void* w_dec_bf16, const float* row_weight,
+                                         float* nll, float* cond_p, float* d_bias, float* a_final) {
+    MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn == NM_H, "mnn_nade_logprob_fwd_mfma: need tracks,N,D>0 and Hn == 256 (Hn=%d)", Hn);
+    MNN_REQUIRE(v && bias && w_enc && w_dec_bf16, "mnn_nade_logprob_fwd_mfma: null pointer");
+    MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_logprob_fwd_mfma: ld_bias %d < tracks*(Hn+D)", ld_bias);
+    MNN_REQUIRE(d_bias == nullptr || row_weight != nullptr, "mnn_nade_logprob_fwd_mfma: d_bias needs row_weight");
+    static bool attr_set = false;
+    if (!attr_set) {
+        MNN_HIP(hipFuncSetAttribute((const void*)nade_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(NadeFwdSmem)));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(N, 32), tracks);
+    hipLaunchKernelGGL(nade_fwd_mfma_kernel, grid, dim3(256), sizeof(NadeFwdSmem), (hipStream_t)s, tracks, N, D, v, v_track_stride, bias, ld_bias,
+                       w_enc, (const bf16_t*)w_dec_bf16, row_weight, nll, cond_p, d_bias, a_final);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}

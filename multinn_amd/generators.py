@@ -482,6 +482,16 @@ class RnnNade(RnnEstimator):
         ops.transpose(self.store["dense/kernel"], self._fc_t)
         self._fc_p = torch.zeros((R, self.ldo), device=dev, dtype=self.dtype)           # [R, n_out]: dgrad B operand
         ops.convert2d(self.store["dense/kernel"], self._fc_p[:, :self.n_out])
+        if self._nade_mfma():                           # bf16 copy of the decoder weights for the matrix-core NADE kernels
+            M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
+            self._wdec_bf = torch.empty((M, D, Hn), device=dev, dtype=torch.bfloat16)
+            ops.convert2d(self.store["nade/w_dec"].view(M * D, Hn), self._wdec_bf.view(M * D, Hn))
+
+    nade_mfma = os.environ.get("MULTINN_NADE_MFMA", "1") != "0"
+
+    def _nade_mfma(self):
+        """bf16 compute mode + a hidden width the matrix-core NADE kernels cover (the f32 VALU kernels remain the parity path)."""
+        return self.nade_mfma and self.dtype == torch.bfloat16 and ops.nade_mfma_ok(self.num_hidden[-1])
 
     # -- forward --------------------------------------------------------------------------------
     def build(self, x=None, y=None, lengths=None, is_train=None, mode="eval"):
@@ -544,8 +554,13 @@ class RnnNade(RnnEstimator):
             if self.ldo != self.n_out:
                 d_out[:, self.n_out:].zero_()
         a_fin = torch.empty((M, N, Hn), device=dev) if train else None
-        ops.nade_logprob_fwd(v.view(M, N, D), out, self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn,
-                             rw_m if train else None, nll, cond_p, d_out, a_fin)
+        if self._nade_mfma():
+            # bf16 compute mode: the decoder dot products run as a block-sparse bf16 GEMM over each row's hidden states
+            ops.nade_logprob_fwd_mfma(v.view(M, N, D), out, self.store["nade/w_enc"], self._wdec_bf, M, D, Hn,
+                                      rw_m if train else None, nll, cond_p, d_out, a_fin)
+        else:
+            ops.nade_logprob_fwd(v.view(M, N, D), out, self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn,
+                                 rw_m if train else None, nll, cond_p, d_out, a_fin)
         loss = torch.zeros(1, device=dev)
         ops.weighted_sum(nll.view(-1), rw_m.repeat(M) if M > 1 else rw_m, loss)      # statistical.py:34 / rnn_multinade.py:202-203
         self._ctx = dict(x_tm=x_tm, v=v, rw=rw_m, y=y, lstm=ctx, out=out, d_out=d_out, a_fin=a_fin, kp=kp, seed=self.seed, B=B, T=T)

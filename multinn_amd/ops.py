@@ -342,6 +342,31 @@ def nade_logprob_fwd(v, bias, w_enc, w_dec, tracks, D, Hn, row_weight=None, nll=
          _ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final))
 
 
+def nade_mfma_ok(Hn):
+    """True when the matrix-core NADE kernels cover this hidden width."""
+    return bool(_lib.load().mnn_nade_mfma_ok(int(Hn)))
+
+
+def nade_logprob_fwd_mfma(v, bias, w_enc, w_dec_bf, tracks, D, Hn, row_weight=None, nll=None, cond_p=None, d_bias=None, a_final=None):
+    """nade_logprob_fwd with the decoder dot products on MFMA (bf16 operands): w_dec_bf is the bf16 copy of w_dec."""
+    N = bias.shape[0]
+    _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_enc)
+    _req(w_dec_bf.dtype == torch.bfloat16 and w_dec_bf.is_contiguous() and w_dec_bf.numel() == tracks * D * Hn, "nade mfma: w_dec_bf bf16 [tracks,D,Hn]")
+    if nll is not None:
+        _req(nll.dtype == torch.float32 and nll.numel() == tracks * N and nll.is_contiguous(), "nade: nll f32 [tracks,N]")
+    if cond_p is not None:
+        _req(cond_p.dtype == torch.float32 and cond_p.numel() == tracks * N * D and cond_p.is_contiguous(), "nade: cond_p f32 [tracks,N,D]")
+    if d_bias is not None:
+        _req(row_weight is not None and d_bias.shape == bias.shape and d_bias.stride() == bias.stride() and d_bias.dtype == torch.float32,
+             "nade: d_bias must mirror bias and needs row_weight")
+    if row_weight is not None:
+        _req(row_weight.dtype == torch.float32 and row_weight.numel() == N, "nade: row_weight f32 [N]")
+    if a_final is not None:
+        _req(a_final.dtype == torch.float32 and a_final.numel() == tracks * N * Hn and a_final.is_contiguous(), "nade: a_final f32 [tracks,N,Hn]")
+    call("mnn_nade_logprob_fwd_mfma", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec_bf),
+         _ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final))
+
+
 def nade_logprob_bwd(v, bias, w_enc, w_dec, tracks, D, Hn, a_final, d_bias, d_w_enc, d_w_dec):
     N = bias.shape[0]
     _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)

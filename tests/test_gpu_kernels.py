@@ -319,6 +319,31 @@ def test_nade_logprob_fwd_bwd(ops, N, D, Hn, tracks):
         assert rel(dwd[m].cpu().numpy(), g[3]) < 1e-4
 
 
+@pytest.mark.parametrize("N,D,tracks,rho", [(70, 100, 1, 0.05), (64, 440, 1, 0.03), (33, 31, 2, 0.5), (40, 65, 1, 1.0), (5, 440, 1, 0.0)])
+def test_nade_mfma_forward_matches_f32_kernel(ops, N, D, tracks, rho):
+    """Matrix-core NADE forward (bf16 states and decoder weights, f32 accumulation) against the f32 VALU kernel on the
+    same inputs: p within bf16 rounding of the logits, a_final identical up to f32 summation order; dense rows (rho = 1:
+    more than 32 flips per column tile) exercise the chunked flip path."""
+    Hn = 256
+    g = torch.Generator(device="cuda").manual_seed(N + D)
+    v = (torch.rand((tracks, N, D), device="cuda", generator=g) < rho).to(torch.uint8)
+    bias = torch.randn((N, tracks * (Hn + D)), device="cuda", generator=g) * 0.5
+    we = torch.randn((tracks, D, Hn), device="cuda", generator=g) * 0.1
+    wd = torch.randn((tracks, D, Hn), device="cuda", generator=g) * 0.1
+    rw = torch.rand(N, device="cuda", generator=g)
+    z = lambda *s: torch.zeros(s, device="cuda")
+    nll0, cp0, db0, af0 = z(tracks, N), z(tracks, N, D), torch.zeros_like(bias), z(tracks, N, Hn)
+    ops.nade_logprob_fwd(v, bias, we, wd, tracks, D, Hn, rw, nll0, cp0, db0, af0)
+    nll1, cp1, db1, af1 = z(tracks, N), z(tracks, N, D), torch.zeros_like(bias), z(tracks, N, Hn)
+    ops.nade_logprob_fwd_mfma(v, bias, we, wd.to(torch.bfloat16), tracks, D, Hn, rw, nll1, cp1, db1, af1)
+    assert float((cp0 - cp1).abs().max()) < 1.5e-2
+    assert torch.allclose(nll0, nll1, rtol=5e-3, atol=5e-2)
+    assert float((db0 - db1).abs().max()) < 1.5e-2
+    assert torch.allclose(af0, af1, rtol=1e-5, atol=1e-5)
+    ops.nade_logprob_fwd_mfma(v, bias, we, wd.to(torch.bfloat16), tracks, D, Hn, rw, nll0, cp0, db0, af0)
+    assert torch.equal(nll0, nll1) and torch.equal(cp0, cp1)            # deterministic
+
+
 def test_nade_edge_cases(ops):
     # K1: zero weights -> p = .5 and NLL = -D log(0.500001); all-ones / all-zeros visibles
     N, D, Hn = 3, 440, 256
