@@ -60,6 +60,10 @@ __device__ __forceinline__ void load_frags_plain(const bf16_t* __restrict__ p, b
     for (int s = 0; s < KS; ++s) f[s] = *reinterpret_cast<const bf16x8_t*>(p + 16 * s);
 }
 
+// Workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt(0), which would make
+// every barrier of a step wait for the prefetch loads (HBM latency) and deferred stores issued just before it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Wave 0 polls one 128-byte line of progress flags: lanes [0,n1) need >= need1, lanes [n1,nm) need >= need2, the rest
 // watch the status word.  All threads of the workgroup call this; returns false (uniformly) when the launch is aborting.
 __device__ __forceinline__ bool pst_wait(const unsigned* line, unsigned* status, int n1, unsigned need1, int nm, unsigned need2, int* s_abort) {
@@ -80,7 +84,7 @@ __device__ __forceinline__ bool pst_wait(const unsigned* line, unsigned* status,
             __builtin_amdgcn_s_sleep(1);
         }
     }
-    __syncthreads();
+    lds_barrier();
     return *reinterpret_cast<volatile int*>(s_abort) == 0;
 }
 
@@ -131,7 +135,7 @@ __device__ __forceinline__ void pf_finish(const PFwdLayer& L, FwdTiles& S, int T
         if (wantT) S.sT[r][lr] = hb;
     }
     tl.t = t; tl.m0 = rt * 32; tl.valid = true;
-    __syncthreads();
+    lds_barrier();
     PST_TR(trc, 3);
     {   // exchange slab of (t, row tile): k-steps 2nt, 2nt+1 of this unit tile; waves 0,1 store h, waves 2,3 the dropped y
         const size_t slab = (size_t)(L.U / 16) * 1024;
@@ -266,7 +270,7 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int k = 0; k < 16; ++k) S.red[w][g][k][lane] = acc[g][k];
-            __syncthreads();
+            lds_barrier();
             float z[4][4], cp[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -341,7 +345,7 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int k = 0; k < 16; ++k) S.red[w][g][k][lane] = acc[g][k];
-            __syncthreads();
+            lds_barrier();
             float z[4][4], cp[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -414,7 +418,7 @@ __device__ __forceinline__ void pb_finish(const PBwdLayer& L, BwdTiles& S, int n
         }
     }
     tl.t = t; tl.m0 = rt * 32; tl.valid = true;
-    __syncthreads();
+    lds_barrier();
     PST_TR(trc, 3);
     {   // k-steps 8nt .. 8nt+7 of the slab, one per wave: a contiguous KiB per store instruction
         const size_t slab = (size_t)(4 * L.U / 16) * 1024;
@@ -533,7 +537,7 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
             for (int s = 0; s < KB; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bw[s], acc, 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < 16; ++j) S.red[0][w][j][lane] = acc[j];
-            __syncthreads();
+            lds_barrier();
             float dh[2], e_dc[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -589,7 +593,7 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
             for (int s = 0; s < KA; ++s) accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[s], bw[s], accw, 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < 16; ++j) { S.red[0][w][j][lane] = accq[j]; S.red[1][w][j][lane] = accw[j]; }
-            __syncthreads();
+            lds_barrier();
             float dh[2], e_dc[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
