@@ -382,6 +382,7 @@ __global__ void __launch_bounds__(64) pst_fill_h0_kernel(const bf16_t* __restric
 struct PBwdLayer {
     const float* dh_ext; const bf16_t* wh_p; const float* gates; const float* c; const float* c0;
     float* dc; bf16_t* dzTt; int ld_t; const uint8_t* mask; const bf16_t* wx_p; int U;
+    float* db_p;                   // bias gradient [4U] (gate-interleaved), accumulated in registers over the launch, or NULL
     char* dzx;                     // exchange copy of dz[t], A-fragment order, slab (t, row tile)
     const char* dzxT;              // zero slabs standing for dz[T], one per row tile
 };
@@ -394,7 +395,7 @@ struct BwdTiles {
     int abort;
 };
 struct BwdEpi { float dh, g[4], c, cp; unsigned keep; };      // per fragment row: external gradient, gates, cell states, raw keep byte
-struct BwdTail { float dcv[2]; int t, m0; bool valid; };
+struct BwdTail { float dcv[2]; float dbv; int t, m0; bool valid; };      // dbv: threads 0..127: running column sum of the dz tiles (bias gradient)
 
 __device__ __forceinline__ void pb_finish(const PBwdLayer& L, BwdTiles& S, int nrt, int t, int rt, int nt, const float (&dh)[2], const BwdEpi (&e)[2],
                                           const float (&e_dc)[2], BwdTail& tl, unsigned* flag, unsigned epoch, long long* trc) {
@@ -429,8 +430,14 @@ __device__ __forceinline__ void pb_finish(const PBwdLayer& L, BwdTiles& S, int n
     PST_TR(trc, 4);
 }
 
-__device__ __forceinline__ void pb_tail(const PBwdLayer& L, const BwdTiles& S, int B, int Rv, int nt, const BwdTail& tl) {
+__device__ __forceinline__ void pb_tail(const PBwdLayer& L, const BwdTiles& S, int B, int Rv, int nt, BwdTail& tl) {
     if (!tl.valid) return;
+    if (L.db_p != nullptr && threadIdx.x < 128) {   // bias gradient: column sums of the (bf16) dz tile that is still in LDS
+        const int rows = min(32, B - tl.m0);
+        float sum = 0.f;
+        for (int rr = 0; rr < rows; ++rr) sum += bf16_to_f32(S.sZ[rr][threadIdx.x]);
+        tl.dbv += sum;
+    }
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int U = L.U, unit = nt * 32 + r, t = tl.t, m0 = tl.m0;
@@ -454,6 +461,11 @@ __device__ __forceinline__ void pb_tail(const PBwdLayer& L, const BwdTiles& S, i
                 if (row + k < B) dst[k] = S.sT[g][uu][piece * 8 + k];
         }
     }
+}
+
+// End of the launch: one f32 atomic per gate column (the other row tiles' workgroups add to the same words).
+__device__ __forceinline__ void pb_flush_db(const PBwdLayer& L, int nt, const BwdTail& tl) {
+    if (L.db_p != nullptr && threadIdx.x < 128) atomicAdd(L.db_p + nt * 128 + threadIdx.x, tl.dbv);
 }
 
 // Epilogue operands of one (t, row tile) for this wave's 2 fragment rows: unconditional loads (see the rule above).
@@ -499,6 +511,7 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
     BwdTail tl;
     tl.valid = false;
     tl.dcv[0] = tl.dcv[1] = 0.f;
+    tl.dbv = 0.f;
     if (member < nb2) {
         // ---------------- layer 2 (leads) ----------------
         const PBwdLayer& L = A.l2;
@@ -554,6 +567,7 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
             PST_TR(trc, 5);
         }
         pb_tail(L, S, B, Rv, nt, tl);
+        pb_flush_db(L, nt, tl);
     } else {
         // ---------------- layer 1 ----------------
         const PBwdLayer& L = A.l1;
@@ -609,21 +623,10 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
             PST_TR(trc, 5);
         }
         pb_tail(L, S, B, Rv, nt, tl);
+        pb_flush_db(L, nt, tl);
     }
 }
 
-// db_p[c] += sum over columns [c0, c1) of row c of dz^T (the LSTM bias gradient; same pass as gemm.hip's step-per-launch form)
-__global__ void __launch_bounds__(256) pst_rowsum_bf16_kernel(const bf16_t* __restrict__ X, int ld, int c0, int c1, float* __restrict__ out) {
-    __shared__ float part[4];
-    const bf16_t* row = X + (size_t)blockIdx.x * ld;
-    float acc = 0.f;
-    for (int c = c0 + threadIdx.x; c < c1; c += 256) acc += bf16_to_f32(row[c]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] += (part[0] + part[1]) + (part[2] + part[3]);
-}
 __global__ void pst_sticky_kernel(unsigned* sync, int sticky_off) {
     if (sync[0] != 0u) sync[sticky_off] = sync[0];
 }
@@ -748,7 +751,7 @@ static PBwdLayer bwd_layer(const mnn_lstm_bwd_layer* L) {
     PBwdLayer p{};
     p.dh_ext = L->dh_ext; p.wh_p = (const bf16_t*)L->wh_p; p.gates = L->gates; p.c = L->c; p.c0 = L->c0;
     p.dc = (float*)L->workspace; p.dzTt = (bf16_t*)L->dzT_t; p.ld_t = L->ld_t; p.mask = L->mask;
-    p.wx_p = (const bf16_t*)L->wx_p; p.U = L->units;
+    p.wx_p = (const bf16_t*)L->wx_p; p.U = L->units; p.db_p = L->db_p;
     return p;
 }
 
@@ -766,7 +769,6 @@ extern "C" int mnn_lstm2_persist_bwd(mnn_stream_t s, int T, int B, const mnn_lst
         MNN_REQUIRE(L->wh_p && L->gates && L->c && L->workspace, "mnn_lstm2_persist_bwd: null pointer");
         MNN_REQUIRE(L->dz == nullptr, "mnn_lstm2_persist_bwd: an f32 dz output is not produced by the persistent form");
         MNN_REQUIRE(L->dzT_t == nullptr || L->ld_t >= T * B, "mnn_lstm2_persist_bwd: ld_t too small");
-        MNN_REQUIRE(L->db_p == nullptr || L->dzT_t != nullptr, "mnn_lstm2_persist_bwd: db_p needs dzT_t");
     }
     MNN_REQUIRE((L1->mask == nullptr) == (keep_prob >= 1.0f), "mnn_lstm2_persist_bwd: layer 1's keep mask is needed exactly when keep_prob < 1");
     const int u1 = L1->units, u2 = L2->units;
@@ -785,8 +787,6 @@ extern "C" int mnn_lstm2_persist_bwd(mnn_stream_t s, int T, int B, const mnn_lst
     else e = launch_pbwd<4>(st, grid, a, u2);
     MNN_HIP(e);
     hipLaunchKernelGGL(pst_sticky_kernel, dim3(1), dim3(1), 0, st, (unsigned*)workspace, (int)(sticky_offset(a.nrt, u1, u2) / sizeof(unsigned)));
-    if (L2->db_p) hipLaunchKernelGGL(pst_rowsum_bf16_kernel, dim3(4 * u2), dim3(256), 0, st, (const bf16_t*)L2->dzT_t, L2->ld_t, 0, T * B, L2->db_p);
-    if (L1->db_p) hipLaunchKernelGGL(pst_rowsum_bf16_kernel, dim3(4 * u1), dim3(256), 0, st, (const bf16_t*)L1->dzT_t, L1->ld_t, 0, T * B, L1->db_p);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
