@@ -132,7 +132,10 @@ int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int units, int t_b
  * counters as mnn_dropout_fwd); y = h/kp*mask is written by the step kernels.  Other pointers as in
  * mnn_lstm_seq_fwd / _bwd; backward needs no f32 dz, no dh0/dc0. */
 typedef struct { int units; const float* xproj; const void* wh_t; const void* h0; const float* c0; float* gates; float* c; void* h;
-                 void* hT; int ld_hT; void* y; const uint8_t* mask; const void* wx_t; int ld_w; const float* bias_p; } mnn_lstm_fwd_layer;
+                 void* hT; int ld_hT; void* y; const uint8_t* mask; const void* wx_t; int ld_w; const float* bias_p;
+                 void* yT; int ld_yT; /* persistent form only (else NULL): transposed copy of the layer's output (y, or h without
+                                         dropout), yT[unit][t*B + row] -- the K-contiguous operand of the next weight gradient */
+               } mnn_lstm_fwd_layer;
 typedef struct { int units; const float* dh_ext; const void* wh_p; const float* gates; const float* c; const float* c0; float* dz;
                  void* dz_T; void* workspace; void* dzT_t; int ld_t; float* db_p; const uint8_t* mask; const void* wx_p; } mnn_lstm_bwd_layer;
 int mnn_lstm2_seq_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L1, const mnn_lstm_fwd_layer* L2, float keep_prob,

@@ -99,6 +99,7 @@ struct PFwdLayer {
     const float* xproj; const bf16_t* wh_t; const float* c0;
     float* gates; float* c; bf16_t* h; bf16_t* hT; int ld_hT; bf16_t* y; const uint8_t* mask;
     const bf16_t* wx_t; int ld_w; const float* bias_p; int U;
+    bf16_t* yT; int ld_yT;         // transposed copy of the layer's output (y, or h without dropout): yT[unit][t B + row]
     char* hx; char* yx;            // exchange copies of h[t] (and of the dropped output y[t]), A-fragment order, slab (t, row tile)
     const char* hx0;               // slabs of the initial state h[-1] (zeros, or h0 re-laid by pst_fill_h0_kernel), one per row tile
 };
@@ -109,6 +110,7 @@ struct FwdTiles {
     bf16_t sH[32][40];             // h tile [row][unit] (+pad)
     bf16_t sY[32][40];             // dropped output tile
     bf16_t sT[32][40];             // h tile [unit][row] for the transposed copy (weight-gradient operand)
+    bf16_t sYT[32][40];            // output tile [unit][row] (y, or h without dropout) for the transposed copy
     int abort;
 };
 
@@ -131,8 +133,10 @@ __device__ __forceinline__ void pf_finish(const PFwdLayer& L, FwdTiles& S, int T
         const bf16_t hb = f32_to_bf16(h);
         const int lr = 8 * w + q + 4 * hh;
         S.sH[lr][r] = hb;
-        if (drop) S.sY[lr][r] = f32_to_bf16(bf16_to_f32(hb) / kp * (float)mk[q]);     // mk: raw keep byte, converted here (not at the load)
+        bf16_t yb = hb;
+        if (drop) { yb = f32_to_bf16(bf16_to_f32(hb) / kp * (float)mk[q]); S.sY[lr][r] = yb; }     // mk: raw keep byte, converted here (not at the load)
         if (wantT) S.sT[r][lr] = hb;
+        if (L.yT != nullptr) S.sYT[r][lr] = yb;
     }
     tl.t = t; tl.m0 = rt * 32; tl.valid = true;
     lds_barrier();
@@ -172,6 +176,17 @@ __device__ __forceinline__ void pf_tail(const PFwdLayer& L, const FwdTiles& S, i
         if (m0 + row < B && (!second || L.mask != nullptr)) {
             bf16_t* dst = (second ? L.y : L.h) + (size_t)t * us + (size_t)(m0 + row) * U + nt * 32 + piece * 8;
             *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(second ? &S.sY[row][piece * 8] : &S.sH[row][piece * 8]);
+        }
+    }
+    if (L.yT != nullptr && threadIdx.x >= 128) {                  // yT[unit][t B + row]
+        const int tt = threadIdx.x - 128, uu = tt >> 2, piece = tt & 3;
+        const int row = m0 + piece * 8, colT = t * B;
+        bf16_t* dst = L.yT + (size_t)(nt * 32 + uu) * L.ld_yT + colT + row;
+        if (row + 8 <= B && (((size_t)(colT + row) & 7) == 0) && ((L.ld_yT & 7) == 0)) {
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&S.sYT[uu][piece * 8]);
+        } else {
+            for (int k = 0; k < 8; ++k)
+                if (row + k < B) dst[k] = S.sYT[uu][piece * 8 + k];
         }
     }
     if (L.hT != nullptr && t + 1 < T && threadIdx.x < 128) {      // hT[unit][(t+1) B + row]
@@ -706,6 +721,7 @@ static PFwdLayer fwd_layer(const mnn_lstm_fwd_layer* L) {
     p.xproj = L->xproj; p.wh_t = (const bf16_t*)L->wh_t; p.c0 = L->c0;
     p.gates = L->gates; p.c = L->c; p.h = (bf16_t*)L->h; p.hT = (bf16_t*)L->hT; p.ld_hT = L->ld_hT; p.y = (bf16_t*)L->y; p.mask = L->mask;
     p.wx_t = (const bf16_t*)L->wx_t; p.ld_w = L->ld_w; p.bias_p = L->bias_p; p.U = L->units;
+    p.yT = (bf16_t*)L->yT; p.ld_yT = L->ld_yT;
     return p;
 }
 
@@ -722,6 +738,7 @@ extern "C" int mnn_lstm2_persist_fwd(mnn_stream_t s, int T, int B, const mnn_lst
     MNN_REQUIRE(L2->wx_t && L2->bias_p && L2->ld_w >= L1->units, "mnn_lstm2_persist_fwd: layer 2 needs its input-projection weights");
     for (const mnn_lstm_fwd_layer* L : {L1, L2}) {
         MNN_REQUIRE(L->hT == nullptr || L->ld_hT >= T * B, "mnn_lstm2_persist_fwd: ld_hT too small");
+        MNN_REQUIRE(L->yT == nullptr || L->ld_yT >= T * B, "mnn_lstm2_persist_fwd: ld_yT too small");
         MNN_REQUIRE((L->mask == nullptr) == (keep_prob >= 1.0f) && (L->mask == nullptr || L->y != nullptr),
                     "mnn_lstm2_persist_fwd: a keep mask and a y buffer are needed exactly when keep_prob < 1");
     }

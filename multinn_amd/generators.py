@@ -160,10 +160,16 @@ class LstmStack:
                 for l, bf in enumerate(bufs):
                     masks[l] = torch.empty(bf["h"].shape, device=dev, dtype=torch.uint8)
                     ops.dropout_mask(masks[l], keep_prob, seed, row0, l, step_dev)
+            yT = [None, None]
+            if persist and save:            # the persistent launch also emits y^T of both layers: no transposes before the weight gradients
+                Np = ops.round_up(T * B, 64)
+                yT = [(torch.zeros if Np != T * B else torch.empty)((p["u"], Np), device=dev, dtype=self.dtype) for p in self.packed]
             d0 = ops.lstm2_fwd_layer(b0["xproj"], p0["wh_t"], b0["h0"], b0["c0"], b0["gates"], b0["c"], b0["h"], b0["hT"],
-                                     b0["y"] if masks[0] is not None else None, masks[0])
+                                     b0["y"] if masks[0] is not None else None, masks[0], yT=yT[0])
             d1 = ops.lstm2_fwd_layer(b1["xproj"], p1["wh_t"], b1["h0"], b1["c0"], b1["gates"], b1["c"], b1["h"], b1["hT"],
-                                     b1["y"] if masks[1] is not None else None, masks[1], p1["wx_t"], p1["bias_p"])
+                                     b1["y"] if masks[1] is not None else None, masks[1], p1["wx_t"], p1["bias_p"], yT=yT[1])
+            for bf, yt in zip(bufs, yT):
+                bf["yT"] = yt
             if persist:
                 ops.lstm2_persist_fwd(T, B, d0, d1, keep_prob, self._workspace(T, B, dev))
             else:
@@ -193,7 +199,7 @@ class LstmStack:
         if save:
             for l, bf in enumerate(bufs):
                 ctx.append(dict(inp=x_tm if l == 0 else bufs[l - 1]["y"], gates=bf["gates"], c=bf["c"], h=bf["h"], c0=bf["c0"], h0=bf["h0"],
-                                hT=bf["hT"], mask=bf.get("mask")))
+                                hT=bf["hT"], mask=bf.get("mask"), yT=bf.get("yT"), inT=bufs[l - 1].get("yT") if l > 0 else None))
         final = [(bf["c"][-1], bf["h"][-1]) for bf in bufs]
         return bufs[-1]["y"], ctx, final
 
@@ -210,8 +216,10 @@ class LstmStack:
         N = T * B
         Np = dzT.shape[1]
         dev = dzT.device
-        inT = (torch.zeros if Np != N else torch.empty)((ld, Np), device=dev, dtype=self.dtype)
-        ops.transpose(cx["inp"].view(N, ld), inT)
+        inT = cx.get("inT")                 # the producer's own transposed copy (persistent forward: y^T of the layer below)
+        if inT is None:
+            inT = (torch.zeros if Np != N else torch.empty)((ld, Np), device=dev, dtype=self.dtype)
+            ops.transpose(cx["inp"].view(N, ld), inT)
         dwx_t = torch.empty((4 * u, ld), device=dev)
         ops.gemm_tn(dzT, inT, dwx_t, split_k=self._split_k(4 * u, ld, Np))
         dwh_t = torch.empty((4 * u, u), device=dev)
@@ -612,8 +620,10 @@ class RnnNade(RnnEstimator):
         # dense: dK[R,n_out] = y^T d_out ; db = sum d_out ; dy = d_out K^T
         Np = ops.round_up(N, 64)
         zalloc = torch.zeros if Np != N else torch.empty
-        yT = zalloc((R, Np), device=dev, dtype=self.dtype)
-        ops.transpose(cx["y"].view(N, R), yT)
+        yT = cx["lstm"][-1].get("yT") if cx["lstm"] else None      # emitted by the persistent recurrence
+        if yT is None:
+            yT = zalloc((R, Np), device=dev, dtype=self.dtype)
+            ops.transpose(cx["y"].view(N, R), yT)
         doT = zalloc((self.n_out, Np), device=dev, dtype=self.dtype)
         ops.transpose(d_out[:, :self.n_out], doT)
         ops.gemm_tn(yT, doT, g["dense/kernel"], accumulate=True, split_k=LstmStack._split_k(R, self.n_out, Np))

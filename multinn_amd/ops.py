@@ -194,7 +194,7 @@ def _p0(t):
     return t.data_ptr() if t is not None else None
 
 
-def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT, y=None, mask=None, wx_t=None, bias_p=None):
+def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT, y=None, mask=None, wx_t=None, bias_p=None, yT=None):
     """Descriptor of one layer for lstm2_seq_fwd (same tensors as lstm_seq_fwd; bf16, contiguous, time-major).
     y/mask: dropped output and u8 keep mask (keep_prob < 1); wx_t/bias_p: this layer's input projection (layer 2)."""
     _req(h.dim() == 3 and h.dtype == torch.bfloat16 and h.is_contiguous(), "lstm2: h bf16 [T,B,u]")
@@ -219,8 +219,9 @@ def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT, y=None, mask=None, wx_
         ld_w = wx_t.stride(0)
     for t in (wh_t, c, h):
         _ptr(t)
+    _req(yT is None or (yT.dim() == 2 and yT.shape[0] == u and yT.stride(1) == 1 and yT.shape[1] >= T * B and yT.dtype == torch.bfloat16), "lstm2: yT")
     return _lib.LstmFwdLayer(u, _p0(xproj), _p0(wh_t), _p0(h0), _p0(c0), _p0(gates), _p0(c), _p0(h), _p0(hT), hT.stride(0) if hT is not None else 0,
-                             _p0(y), _p0(mask), _p0(wx_t), ld_w, _p0(bias_p))
+                             _p0(y), _p0(mask), _p0(wx_t), ld_w, _p0(bias_p), _p0(yT), yT.stride(0) if yT is not None else 0)
 
 
 def lstm2_seq_fwd(T, B, L1, L2, keep_prob, s_begin=0, s_end=None):
