@@ -7,6 +7,7 @@
 // K-chunk (32 bf16 / 16 f32) padded to 80 bytes so that the 16 rows a ds_read_b128 lane group
 // touches fall on 16 distinct 16-byte slots (conflict-free, MI355X_MICROARCH "LDS").
 #include "common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
@@ -224,13 +225,15 @@ gemm_tn_glds_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restr
                     const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
     constexpr int CPR = BK / 8, ROWB = BK * 2, TILE = 128 * ROWB;
     __shared__ __attribute__((aligned(16))) char smem[2][2][TILE];
-    const int bid = blockIdx.x;
+    // split-K: consecutive workgroup ids (= consecutive XCDs) take different K slices of the SAME output tile, so the tiles
+    // that share an XCD read the same K slice of A and B at the same time and the re-reads hit that XCD's L2
+    const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+    const int z = lin % split_k, bid = lin / split_k;
     const int grp = bid / (8 * ntn), within = bid % (8 * ntn);
     const int mt = grp * 8 + (within & 7), nt = within >> 3;
     if (mt >= ntm) return;
     const int m0 = mt * 128, n0 = nt * 128;
     const int nkt = K / BK;
-    const int z = blockIdx.y;
     const int per = (nkt + split_k - 1) / split_k;
     const int kt0 = z * per, kt1 = min(nkt, kt0 + per);
     if (kt0 >= kt1) return;
@@ -300,6 +303,107 @@ gemm_tn_glds_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restr
         }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Large-tile variant: 256 x 256 x 64 per workgroup, 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 4 x 2 MFMA tiles.
+// The 128 x 128 kernel above reads one LDS fragment per MFMA (2 A + 2 B fragments feed 4 MFMAs) and stages 0.5 KiB of
+// operands per MFMA through LDS-DMA: 1.5 KiB of LDS traffic per 32-cycle MFMA against a 128 B/clk LDS -- it is LDS-bound
+// at two thirds of the MFMA rate before any latency.  Here 4 A + 2 B fragments feed 8 MFMAs and a stage carries 0.25 KiB
+// per MFMA: 1.0 KiB per MFMA, and one workgroup per CU holds two 64 KiB stages.
+// ----------------------------------------------------------------------------------------------
+template <int ROWS, int NW>
+__device__ __forceinline__ void glds_stage_tile_n(const bf16_t* __restrict__ G, int ld, int rows_total, int r0, int k0, char* tile, int wave,
+                                                  int lane) {
+    constexpr int CPR = 8;                                  // 16-byte chunks per 64-element row
+#pragma unroll
+    for (int s = 0; s < ROWS * CPR / (64 * NW); ++s) {
+        const int p = (s * NW + wave) * 64 + lane;          // linear 16-byte slot of the tile image
+        const int row = p / CPR, pc = p % CPR;
+        const int c = pc ^ swz<CPR>(row);
+        const int gr = min(r0 + row, rows_total - 1);
+        __builtin_amdgcn_global_load_lds((gas_ptr_t)(G + (size_t)gr * ld + k0 + c * 8), (lds_ptr_t)(tile + (s * NW + wave) * 1024), 16, 0, 0);
+    }
+}
+
+__global__ void __launch_bounds__(512)
+gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c_bf16,
+                       const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
+    constexpr int BK = 64, CPR = 8, ROWB = 128, TILE = 256 * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem256[];        // [stage][A | B][256 rows x 128 B]
+    const int lin = blockIdx.x + blockIdx.y * gridDim.x;   // split-K slices of one tile on consecutive ids / XCDs (see the 128 x 128 kernel)
+    const int z = lin % split_k, bid = lin / split_k;
+    const int grp = bid / (8 * ntn), within = bid % (8 * ntn);
+    const int mt = grp * 8 + (within & 7), nt = within >> 3;
+    if (mt >= ntm) return;
+    const int m0 = mt * 256, n0 = nt * 256;
+    const int nkt = K / BK;
+    const int per = (nkt + split_k - 1) / split_k;
+    const int kt0 = z * per, kt1 = min(nkt, kt0 + per);
+    if (kt0 >= kt1) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    auto stage = [&](int buf, int kt) {
+        glds_stage_tile_n<256, 8>(A, lda, M, m0, kt * BK, smem256 + (buf * 2 + 0) * TILE, wave, lane);
+        glds_stage_tile_n<256, 8>(B, ldb, N, n0, kt * BK, smem256 + (buf * 2 + 1) * TILE, wave, lane);
+    };
+    stage(0, kt0);
+    __syncthreads();                                        // hipcc drains vmcnt(0) before the barrier
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
+        const char* sA = smem256 + (cur * 2 + 0) * TILE;
+        const char* sB = smem256 + (cur * 2 + 1) * TILE;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8_t a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 128 + i * 32 + r;
+                a[i] = *reinterpret_cast<const bf16x8_t*>(sA + row * ROWB + (((ks * 2 + h) ^ swz<CPR>(row)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 64 + j * 32 + r;
+                b[j] = *reinterpret_cast<const bf16x8_t*>(sB + row * ROWB + (((ks * 2 + h) ^ swz<CPR>(row)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    float* Cf = reinterpret_cast<float*>(Cv);
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= N) continue;
+            const float bv = (bias != nullptr && z == 0) ? bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 128 + i * 32 + frag_row(e, lane);
+                if (row >= M) continue;
+                const float val = acc[i][j][e] + bv;
+                const size_t o = (size_t)row * ldc + col;
+                if (c_bf16) Cb[o] = f32_to_bf16(val);
+                else if (flags & MNN_GEMM_ATOMIC) atomicAdd(Cf + o, val);
+                else if (flags & MNN_GEMM_ACCUMULATE) Cf[o] += val;
+                else Cf[o] = val;
+            }
+        }
+}
+
 template <typename T>
 static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                        int c_bf16, const float* bias, int flags, int split_k) {
@@ -308,6 +412,21 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
     const int ngrp = cdiv(ntm, 8);
     dim3 grid(ngrp * 8 * ntn, split_k);
     if constexpr (sizeof(T) == 2) {
+        // large problems: 256 x 256 tiles (enough of them to occupy the chip, each with enough K tiles to amortise its prologue)
+        const int ntm2 = cdiv(M, 256), ntn2 = cdiv(N, 256);
+        static const bool no256 = getenv("MNN_GEMM_NO256") != nullptr;
+        if (!no256 && K % 64 == 0 && M >= 256 && N >= 192 && (long)ntm2 * ntn2 * split_k >= 192 && K / 64 / split_k >= 6) {     // measured per shape: profiles/round1_f_gemm_shapes.md
+            static bool attr_set = false;
+            if (!attr_set) {
+                MNN_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128));
+                attr_set = true;
+            }
+            dim3 grid2(cdiv(ntm2, 8) * 8 * ntn2, split_k);
+            hipLaunchKernelGGL(gemm_tn_glds256_kernel, grid2, dim3(512), 4 * 256 * 128, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, c_bf16,
+                               bias, M, N, K, flags, split_k, ntm2, ntn2);
+            MNN_LAUNCH_CHECK();
+            return MNN_OK;
+        }
         // (BK = 128 for the tall-K weight-gradient GEMMs was measured slower: C2 1.28 -> 1.54 ms, 1 block/CU at 128 KiB LDS)
         if (K % 64 == 0) {
             hipLaunchKernelGGL(gemm_tn_glds_kernel<64>, grid, dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, c_bf16, bias, M,
