@@ -135,7 +135,11 @@ class LstmStack:
             h = torch.empty((T, B, u), device=dev, dtype=self.dtype)
             hT = None
             if save:                        # transposed previous-state operand of dWh, written by the step kernels
-                hT = torch.zeros((u, ops.round_up(T * B, 64)), device=dev, dtype=self.dtype)
+                Np = ops.round_up(T * B, 64)            # columns [0,B) = h_{-1} = 0 (or h0), [B, T*B) written by the step kernels
+                hT = torch.empty((u, Np), device=dev, dtype=self.dtype)
+                hT[:, :B].zero_()
+                if Np != T * B:
+                    hT[:, T * B:].zero_()
                 if state0 is not None:
                     ops.transpose(state0[l][1].to(self.dtype).contiguous(), hT[:, :B])
             bufs.append(dict(xproj=None if (persist and l == 1) else torch.empty((T, B, 4 * u), device=dev), gates=torch.empty((T, B, 4 * u), device=dev) if save else None,
