@@ -19,7 +19,6 @@
 // grid is not resident at once (one workgroup per CU).  Block -> tile map: blocks with equal (id % G) share a row tile,
 // so with G = 8 a row tile's workgroups share an XCD under round-robin dispatch (speed only, never correctness).
 #include "common.h"
-#include <stdlib.h>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
@@ -379,294 +378,6 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Forward, 16-row tiles, two or more row tiles per workgroup, software-pipelined hand-offs (used when every workgroup gets
-// at least two row tiles: B >= 32 * groups).  Same roles and hand-off protocol as above, but a workgroup interleaves
-// INDEPENDENT chains: while the tile of (t, row tile A) is on its way through the fabric, the workgroup computes (t, row
-// tile B).  The hand-off loads of item i+1 are issued BEFORE the arithmetic of item i: with R >= 2 row tiles per
-// workgroup, what item i+1 waits for was published one item ago by every workgroup of its row tile (they walk the items in
-// the same order), so the poll rarely spins and the ~1.2 us tile latency hides under the MFMAs / pointwise of item i.
-// MFMA shape v_mfma_f32_16x16x32_bf16: A fragment = 16 rows x 32 k (lane: row l & 15, k = 8 (l >> 4) + j), so a unit tile
-// of 32 units is exactly ONE k-step of its row tile's exchange slab ([k-step of 32][lane][16 B]).
-// ------------------------------------------------------------------------------------------------------------------
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-
-struct FwdTiles16 {
-    float red[4][8][4][64];        // K-split partial tiles: [wave][N-tile of 16 gate columns][reg][lane]
-    bf16_t sH[16][40];             // h tile [row][unit] (+pad)
-    bf16_t sY[16][40];             // dropped output tile
-    bf16_t sT[32][24];             // h tile [unit][row] for the transposed copy
-    bf16_t sYT[32][24];            // output tile [unit][row]
-    int abort;
-};
-// per lane: 2 elements = (row 4 (l >> 4) + wave, units (l & 15) and 16 + (l & 15)) of the 16 x 32 tile
-struct FwdTail16 { float gv[2][4], cv[2]; int t, m0; bool valid; };
-
-template <int KS>
-__device__ __forceinline__ void load_frags_xchg16(const void* slab, size_t slab_bytes, int f0, bf16x8_t (&f)[KS]) {
-    const __amdgpu_buffer_rsrc_t rs = slice_rsrc(slab, slab_bytes);
-    const int off = (f0 * 64 + (int)(threadIdx.x & 63)) * 16;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) f[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024 * s, 0, PST_SC1));
-}
-
-__device__ __forceinline__ void pf16_finish(const PFwdLayer& L, FwdTiles16& S, int T, int nrt, int t, int rt, int nt, float kp, const float (&z)[2][4],
-                                            const float (&cp)[2], const unsigned (&mk)[2], FwdTail16& tl, unsigned* flag) {
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 15, lr = 4 * (lane >> 4) + w;
-    const bool drop = L.mask != nullptr;
-    const bool wantT = L.hT != nullptr && t + 1 < T;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int ul = 16 * e + c;
-        const float gi = fast_sigmoid(z[e][0]), gg = fast_tanh(z[e][1]), gf = fast_sigmoid(z[e][2]), go = fast_sigmoid(z[e][3]);
-        const float cc = gg * gi + cp[e] * gf;
-        const float h = fast_tanh(cc) * go;
-        tl.gv[e][0] = gi; tl.gv[e][1] = gg; tl.gv[e][2] = gf; tl.gv[e][3] = go; tl.cv[e] = cc;
-        const bf16_t hb = f32_to_bf16(h);
-        S.sH[lr][ul] = hb;
-        bf16_t yb = hb;
-        if (drop) { yb = f32_to_bf16(bf16_to_f32(hb) / kp * (float)mk[e]); S.sY[lr][ul] = yb; }
-        if (wantT) S.sT[ul][lr] = hb;
-        if (L.yT != nullptr) S.sYT[ul][lr] = yb;
-    }
-    tl.t = t; tl.m0 = rt * 16; tl.valid = true;
-    lds_barrier();
-    {   // k-step nt of the (t, row tile) slab: wave 0 stores h, wave 1 the dropped y
-        const size_t slab = (size_t)(L.U / 32) * 1024;
-        if (w == 0 || (w == 1 && drop && L.yx != nullptr)) {
-            const bf16_t (*src)[40] = w == 1 ? S.sY : S.sH;
-            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&src[lane & 15][8 * (lane >> 4)]);
-            store_frag_xchg((w == 1 ? L.yx : L.hx) + ((size_t)t * nrt + rt) * slab, slab, nt, lane, v);
-        }
-    }
-    pst_publish(flag, (unsigned)(t + 1));
-}
-
-__device__ __forceinline__ void pf16_tail(const PFwdLayer& L, const FwdTiles16& S, int T, int B, int nt, const FwdTail16& tl) {
-    if (!tl.valid) return;
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 15;
-    const int U = L.U, N4 = 4 * U, n0 = nt * 128, t = tl.t, m0 = tl.m0;
-    const size_t us = (size_t)B * U;
-    const int row = m0 + 4 * (lane >> 4) + w;
-    if (row < B) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int ul = 16 * e + c;
-            const size_t zo = (size_t)t * 4 * us + (size_t)row * N4 + n0 + ul, uo = (size_t)t * us + (size_t)row * U + nt * 32 + ul;
-            if (L.gates != nullptr) { L.gates[zo] = tl.gv[e][0]; L.gates[zo + 32] = tl.gv[e][1]; L.gates[zo + 64] = tl.gv[e][2]; L.gates[zo + 96] = tl.gv[e][3]; }
-            L.c[uo] = tl.cv[e];
-        }
-    }
-    const int tid = threadIdx.x;
-    if (tid < 128) {                     // row-major tiles: 16 rows x 64 bytes (h: threads 0..63, y: 64..127)
-        const int tt = tid & 63, r2 = tt >> 2, piece = tt & 3;
-        const bool second = tid >= 64;
-        if (m0 + r2 < B && (!second || L.mask != nullptr)) {
-            bf16_t* dst = (second ? L.y : L.h) + (size_t)t * us + (size_t)(m0 + r2) * U + nt * 32 + piece * 8;
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(second ? &S.sY[r2][piece * 8] : &S.sH[r2][piece * 8]);
-        }
-    } else {                             // transposed copies: [unit][16 rows] = 2 pieces of 8 rows (hT: threads 128..191, yT: 192..255)
-        const int tt = tid & 63, uu = tt >> 1, piece = tt & 1;
-        const bool second = tid >= 192;
-        bf16_t* base = second ? L.yT : L.hT;
-        const int ldT = second ? L.ld_yT : L.ld_hT;
-        const bool want = second ? L.yT != nullptr : (L.hT != nullptr && t + 1 < T);
-        if (want) {
-            const int rw = m0 + piece * 8, colT = (second ? t : t + 1) * B;
-            bf16_t* dst = base + (size_t)(nt * 32 + uu) * ldT + colT + rw;
-            const bf16_t* src = second ? &S.sYT[uu][piece * 8] : &S.sT[uu][piece * 8];
-            if (rw + 8 <= B && (((size_t)(colT + rw) & 7) == 0) && ((ldT & 7) == 0)) {
-                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
-            } else {
-                for (int k = 0; k < 8; ++k)
-                    if (rw + k < B) dst[k] = src[k];
-            }
-        }
-    }
-}
-
-// KS1 = U1 / 128, KS2 = U2 / 128 (k-steps of 32 per wave, 4 waves).  Requires at least two row tiles per workgroup.
-template <int KS1, int KS2>
-__global__ void __launch_bounds__(256) lstm2_persist_fwd16_kernel(PFwdArgs A) {
-    __shared__ FwdTiles16 S;
-    const int nb1 = A.l1.U / 32, nb2 = A.l2.U / 32, nm = nb1 + nb2;
-    const int grp = blockIdx.x % A.G, member = blockIdx.x / A.G;
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 15, kg = lane >> 4;
-    const int T = A.T, B = A.B, nrt = A.nrt;
-    const int Rv = (nrt - grp + A.G - 1) / A.G;
-    const int n_items = T * Rv;
-    unsigned* status = A.sync;
-    unsigned* flags = A.sync + PST_FLAGS_OFF;
-    const float* zero = reinterpret_cast<const float*>(A.sync + 4);
-    if (threadIdx.x == 0) S.abort = 0;
-    __syncthreads();
-    FwdTail16 tl;
-    tl.valid = false;
-    tl.cv[0] = tl.cv[1] = 0.f;
-    // Order inside an item (every wave's vmcnt queue is a FIFO and the publish must drain it):
-    //   poll + hand-off loads of item i+1 | MFMAs, reduction, pointwise of item i | write-through stores, drain, flag |
-    //   plain stores of item i and the epilogue operands of item i+1 (HBM latency: they have a whole item to arrive).
-    if (member < nb1) {
-        // ---------------- layer 1 ----------------
-        const PFwdLayer& L = A.l1;
-        const int nt = member, U = L.U, N4 = 4 * U, n0 = nt * 128;
-        const size_t us = (size_t)B * U, slab = (size_t)(U / 32) * 1024;
-        bf16x8_t b[8][KS1];                                   // gate column n0 + 16 q + c, k = 32 (w KS1 + s) + 8 kg + j
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-#pragma unroll
-            for (int s = 0; s < KS1; ++s)
-                b[q][s] = *reinterpret_cast<const bf16x8_t*>(L.wh_t + (size_t)(n0 + 16 * q + c) * U + 32 * (w * KS1 + s) + 8 * kg);
-        auto epi_load = [&](int t, int m0, float (&xp_)[2][4], unsigned (&mk_)[2], float (&cl_)[2]) {
-            const int rr = min(m0 + 4 * kg + w, B - 1);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const size_t zo = (size_t)t * 4 * us + (size_t)rr * N4 + n0 + 16 * e + c, uo = (size_t)rr * U + nt * 32 + 16 * e + c;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) xp_[e][g] = L.xproj[zo + 32 * g];
-                const uint8_t* mp = L.mask != nullptr ? L.mask + (size_t)t * us + uo : reinterpret_cast<const uint8_t*>(zero);
-                mk_[e] = *mp;
-                const float* cptr = t == 0 ? (L.c0 != nullptr ? L.c0 + uo : zero) : L.c + (size_t)(t - 1) * us + uo;
-                cl_[e] = *cptr;
-            }
-        };
-        float xp[2][4], cl[2];
-        unsigned mk[2];
-        epi_load(0, grp * 16, xp, mk, cl);
-        bf16x8_t a[KS1];
-        load_frags_xchg16<KS1>(L.hx0 + (size_t)grp * slab, slab, w * KS1, a);       // item 0: t = 0, initial state
-        for (int i = 0; i < n_items; ++i) {
-            const int t = i / Rv, rt = grp + A.G * (i - t * Rv);
-            const int i2 = min(i + 1, n_items - 1), t2 = i2 / Rv, rt2 = grp + A.G * (i2 - t2 * Rv);
-            // hand-off of the NEXT item first: its tile was published one item ago by every workgroup of that row tile
-            long long* trc = PST_TRP(0, member == 0 && grp == 0 && i < 512, i);
-            PST_TR(trc, 0);
-            bf16x8_t an[KS1];
-            if (t2 > 0 && i + 1 < n_items && !pst_wait(flags + rt2 * 32, status, nb1, (unsigned)t2, nb1, 0u, &S.abort)) return;
-            PST_TR(trc, 1);
-            load_frags_xchg16<KS1>(t2 > 0 ? L.hx + ((size_t)(t2 - 1) * nrt + rt2) * slab : L.hx0 + (size_t)rt2 * slab, slab, w * KS1, an);
-            f32x4_t acc[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KS1; ++s)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s], b[q][s], acc[q], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) S.red[w][q][k][lane] = acc[q][k];
-            lds_barrier();
-            float z[2][4];
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int q = 2 * g + e;
-                    z[e][g] = xp[e][g] + ((S.red[0][q][w][lane] + S.red[1][q][w][lane]) + (S.red[2][q][w][lane] + S.red[3][q][w][lane]));
-                }
-            PST_TR(trc, 2);
-            pf16_finish(L, S, T, nrt, t, rt, nt, A.kp, z, cl, mk, tl, flags + rt * 32 + member);
-            PST_TR(trc, 4);
-            pf16_tail(L, S, T, B, nt, tl);                   // this item's plain stores (c[t] before the next item of this row tile reads it)
-            epi_load(t2, rt2 * 16, xp, mk, cl);             // the next item's operands
-            PST_TR(trc, 5);
-#pragma unroll
-            for (int s = 0; s < KS1; ++s) a[s] = an[s];
-        }
-    } else {
-        // ---------------- layer 2 ----------------
-        const PFwdLayer& L = A.l2;
-        const PFwdLayer& L1 = A.l1;
-        const int nt = member - nb1, U = L.U, U1 = L1.U, n0 = nt * 128;
-        const size_t us = (size_t)B * U, slab = (size_t)(U / 32) * 1024, slab1 = (size_t)(U1 / 32) * 1024;
-        const char* y1x = L1.mask != nullptr ? L1.yx : L1.hx;
-        bf16x8_t bx[8][KS1], bh[8][KS2];
-        float bz[2][4];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-#pragma unroll
-            for (int s = 0; s < KS1; ++s)
-                bx[q][s] = *reinterpret_cast<const bf16x8_t*>(L.wx_t + (size_t)(n0 + 16 * q + c) * L.ld_w + 32 * (w * KS1 + s) + 8 * kg);
-#pragma unroll
-            for (int s = 0; s < KS2; ++s)
-                bh[q][s] = *reinterpret_cast<const bf16x8_t*>(L.wh_t + (size_t)(n0 + 16 * q + c) * U + 32 * (w * KS2 + s) + 8 * kg);
-        }
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bz[e][g] = L.bias_p[n0 + 32 * g + 16 * e + c];
-        auto epi_load = [&](int t, int m0, unsigned (&mk_)[2], float (&cl_)[2]) {
-            const int rr = min(m0 + 4 * kg + w, B - 1);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const size_t uo = (size_t)rr * U + nt * 32 + 16 * e + c;
-                const uint8_t* mp = L.mask != nullptr ? L.mask + (size_t)t * us + uo : reinterpret_cast<const uint8_t*>(zero);
-                mk_[e] = *mp;
-                const float* cptr = t == 0 ? (L.c0 != nullptr ? L.c0 + uo : zero) : L.c + (size_t)(t - 1) * us + uo;
-                cl_[e] = *cptr;
-            }
-        };
-        float cl[2];
-        unsigned mk[2];
-        epi_load(0, grp * 16, mk, cl);
-        bf16x8_t a1[KS1], a2[KS2];
-        if (!pst_wait(flags + grp * 32, status, nb1, 1u, nm, 0u, &S.abort)) return;       // item 0
-        load_frags_xchg16<KS1>(y1x + (size_t)grp * slab1, slab1, w * KS1, a1);
-        load_frags_xchg16<KS2>(L.hx0 + (size_t)grp * slab, slab, w * KS2, a2);
-        for (int i = 0; i < n_items; ++i) {
-            const int t = i / Rv, rt = grp + A.G * (i - t * Rv);
-            const int i2 = min(i + 1, n_items - 1), t2 = i2 / Rv, rt2 = grp + A.G * (i2 - t2 * Rv);
-            bf16x8_t a1n[KS1], a2n[KS2];
-            if (i + 1 < n_items && !pst_wait(flags + rt2 * 32, status, nb1, (unsigned)(t2 + 1), nm, (unsigned)t2, &S.abort)) return;
-            load_frags_xchg16<KS1>(y1x + ((size_t)t2 * nrt + rt2) * slab1, slab1, w * KS1, a1n);
-            load_frags_xchg16<KS2>(t2 > 0 ? L.hx + ((size_t)(t2 - 1) * nrt + rt2) * slab : L.hx0 + (size_t)rt2 * slab, slab, w * KS2, a2n);
-            f32x4_t acc[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KS1; ++s)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[s], bx[q][s], acc[q], 0, 0, 0);
-#pragma unroll
-            for (int s = 0; s < KS2; ++s)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[s], bh[q][s], acc[q], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) S.red[w][q][k][lane] = acc[q][k];
-            lds_barrier();
-            float z[2][4];
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int q = 2 * g + e;
-                    z[e][g] = bz[e][g] + ((S.red[0][q][w][lane] + S.red[1][q][w][lane]) + (S.red[2][q][w][lane] + S.red[3][q][w][lane]));
-                }
-            pf16_finish(L, S, T, nrt, t, rt, nt, A.kp, z, cl, mk, tl, flags + rt * 32 + member);
-            pf16_tail(L, S, T, B, nt, tl);
-            epi_load(t2, rt2 * 16, mk, cl);
-#pragma unroll
-            for (int s = 0; s < KS1; ++s) a1[s] = a1n[s];
-#pragma unroll
-            for (int s = 0; s < KS2; ++s) a2[s] = a2n[s];
-        }
-    }
-}
-
-// h0 [B,U] row-major -> one 16-row exchange slab per row tile; grid (nrt16, U/32), 64 threads
-__global__ void __launch_bounds__(64) pst_fill_h0_16_kernel(const bf16_t* __restrict__ h0, int B, int U, char* __restrict__ slab0) {
-    const int rt = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
-    const int row = min(rt * 16 + (lane & 15), B - 1);
-    const uint4 v = *reinterpret_cast<const uint4*>(h0 + (size_t)row * U + f * 32 + (lane >> 4) * 8);
-    *reinterpret_cast<uint4*>(slab0 + ((size_t)rt * (U / 32) + f) * 1024 + lane * 16) = v;
-}
-
 // h0 [B,U] row-major -> one exchange slab per row tile (initial state of a stateful call); grid (nrt, U/16), 64 threads
 __global__ void __launch_bounds__(64) pst_fill_h0_kernel(const bf16_t* __restrict__ h0, int B, int U, char* __restrict__ slab0) {
     const int rt = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
@@ -963,24 +674,13 @@ static bool persist_plan(int B, int u1, int u2, int& nrt, int& G, int& R) {
     return true;
 }
 
-// workspace: [status | 31 zero words][32 flags per row tile (room for 16-row tiles)][boundary slabs: layer 1, layer 2 (zeros / h0)]
-// -- one memset per call covers the words and slabs that call uses -- [sticky word, padded][exchange area].  The sticky word and
-// the exchange area sit at offsets that do not depend on the row-tile height a launch picks.
-static size_t pad32(int B) { return (size_t)cdiv(B, 32) * 32; }
-static size_t sync_words(int B) { return (size_t)PST_FLAGS_OFF + 32 * (size_t)cdiv(B, 16); }
-static size_t edge_bytes(int B, int u1, int u2, bool bwd) { return pad32(B) * (bwd ? 8 : 2) * ((size_t)u1 + u2); }
-static size_t sticky_offset(int B, int u1, int u2) { return sync_words(B) * sizeof(unsigned) + edge_bytes(B, u1, u2, true); }
-static size_t xchg_offset(int B, int u1, int u2) { return (sticky_offset(B, u1, u2) + 16 + 255) / 256 * 256; }
-
-// 16-row tiles with at least two row tiles per workgroup (the pipelined forward): groups G, or 0 when not applicable
-static int plan16(int B, int u1, int u2) {
-    static const bool off = getenv("MNN_PERSIST_ROWS32") != nullptr;
-    if (off || !units_ok(u1) || !units_ok(u2)) return 0;
-    const int nm = u1 / 32 + u2 / 32, nrt = cdiv(B, 16), cus = cu_count();
-    if (nm > 32 || cus < nm || nrt < 2) return 0;
-    const int g = cus / nm < nrt / 2 ? cus / nm : nrt / 2;
-    return g;
-}
+// workspace: [status | 31 zero words][32 flags per row tile][boundary slabs: layer 1, layer 2 (zeros / h0)] -- one memset
+// per call covers all of that -- [sticky word, padded][exchange area]
+static size_t sync_words(int nrt) { return (size_t)PST_FLAGS_OFF + 32 * (size_t)nrt; }
+static size_t edge_bytes(int nrt, int u1, int u2, bool bwd) { return (size_t)nrt * (bwd ? 256 : 64) * ((size_t)u1 + u2); }
+static size_t edge_max(int nrt, int u1, int u2) { return edge_bytes(nrt, u1, u2, true); }
+static size_t sticky_offset(int nrt, int u1, int u2) { return sync_words(nrt) * sizeof(unsigned) + edge_max(nrt, u1, u2); }
+static size_t xchg_offset(int nrt, int u1, int u2) { return (sticky_offset(nrt, u1, u2) + 16 + 255) / 256 * 256; }
 
 extern "C" int mnn_lstm2_persist_ok(int B, int u1, int u2) {
     int nrt, G, R;
@@ -988,15 +688,15 @@ extern "C" int mnn_lstm2_persist_ok(int B, int u1, int u2) {
 }
 
 extern "C" size_t mnn_lstm2_persist_workspace_bytes(int T, int B, int u1, int u2) {
-    const size_t per = (size_t)T * pad32(B);
-    const size_t fwd = per * 2 * (2 * (size_t)u1 + u2), bwd = per * 8 * ((size_t)u1 + u2);
-    return xchg_offset(B, u1, u2) + (fwd > bwd ? fwd : bwd);
+    const size_t nrt = (size_t)cdiv(B, 32), per = (size_t)T * nrt;
+    const size_t fwd = per * 64 * (2 * (size_t)u1 + u2), bwd = per * 256 * ((size_t)u1 + u2);
+    return xchg_offset((int)nrt, u1, u2) + (fwd > bwd ? fwd : bwd);
 }
 
 extern "C" int mnn_lstm2_persist_status(const void* workspace, int B, int u1, int u2, int* status) {
     MNN_REQUIRE(workspace && status && B > 0 && u1 > 0 && u2 > 0, "mnn_lstm2_persist_status: bad arguments");
     unsigned v = 0;
-    MNN_HIP(hipMemcpy(&v, (const char*)workspace + sticky_offset(B, u1, u2), sizeof(v), hipMemcpyDeviceToHost));
+    MNN_HIP(hipMemcpy(&v, (const char*)workspace + sticky_offset(cdiv(B, 32), u1, u2), sizeof(v), hipMemcpyDeviceToHost));
     *status = (int)v;
     return MNN_OK;
 }
@@ -1006,13 +706,6 @@ static hipError_t launch_pfwd(hipStream_t st, int grid, const PFwdArgs& a, int u
     if (u2 == 512) hipLaunchKernelGGL((lstm2_persist_fwd_kernel<K1, 8>), dim3(grid), dim3(256), 0, st, a);
     else if (u2 == 256) hipLaunchKernelGGL((lstm2_persist_fwd_kernel<K1, 4>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((lstm2_persist_fwd_kernel<K1, 2>), dim3(grid), dim3(256), 0, st, a);
-    return hipGetLastError();
-}
-template <int K1>
-static hipError_t launch_pfwd16(hipStream_t st, int grid, const PFwdArgs& a, int u2) {
-    if (u2 == 512) hipLaunchKernelGGL((lstm2_persist_fwd16_kernel<K1, 4>), dim3(grid), dim3(256), 0, st, a);
-    else if (u2 == 256) hipLaunchKernelGGL((lstm2_persist_fwd16_kernel<K1, 2>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((lstm2_persist_fwd16_kernel<K1, 1>), dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 template <int KA>
@@ -1052,32 +745,21 @@ extern "C" int mnn_lstm2_persist_fwd(mnn_stream_t s, int T, int B, const mnn_lst
     const int u1 = L1->units, u2 = L2->units;
     a.l1 = fwd_layer(L1); a.l2 = fwd_layer(L2);
     a.T = T; a.B = B; a.kp = keep_prob; a.sync = (unsigned*)workspace;
-    const int g16 = plan16(B, u1, u2);
-    const int rows = g16 > 0 ? 16 : 32;                      // row-tile height of this launch
-    if (g16 > 0) { a.nrt = cdiv(B, 16); a.G = g16; a.R = cdiv(a.nrt, g16); }
-    const size_t per = (size_t)T * a.nrt * rows;              // padded rows x timesteps
-    char* edge = (char*)workspace + sync_words(B) * sizeof(unsigned);
-    char* x = (char*)workspace + xchg_offset(B, u1, u2);
-    a.l1.hx0 = edge; a.l2.hx0 = edge + (size_t)a.nrt * rows * 2 * u1;
-    a.l1.hx = x; a.l1.yx = x + per * 2 * u1; a.l2.hx = x + per * 4 * u1; a.l2.yx = nullptr;    // layer 2's dropped output is not handed off
+    const size_t per = (size_t)T * a.nrt;
+    char* edge = (char*)workspace + sync_words(a.nrt) * sizeof(unsigned);
+    char* x = (char*)workspace + xchg_offset(a.nrt, u1, u2);
+    a.l1.hx0 = edge; a.l2.hx0 = edge + (size_t)a.nrt * 64 * u1;
+    a.l1.hx = x; a.l1.yx = x + per * 64 * u1; a.l2.hx = x + per * 128 * u1; a.l2.yx = nullptr;    // layer 2's dropped output is not handed off
     const int grid = a.G * (u1 / 32 + u2 / 32);
-    MNN_HIP(hipMemsetAsync(workspace, 0, sync_words(B) * sizeof(unsigned) + edge_bytes(B, u1, u2, false), st));
+    MNN_HIP(hipMemsetAsync(workspace, 0, sync_words(a.nrt) * sizeof(unsigned) + edge_bytes(a.nrt, u1, u2, false), st));
+    if (L1->h0) hipLaunchKernelGGL(pst_fill_h0_kernel, dim3(a.nrt, u1 / 16), dim3(64), 0, st, (const bf16_t*)L1->h0, B, u1, edge);
+    if (L2->h0) hipLaunchKernelGGL(pst_fill_h0_kernel, dim3(a.nrt, u2 / 16), dim3(64), 0, st, (const bf16_t*)L2->h0, B, u2, edge + (size_t)a.nrt * 64 * u1);
     hipError_t e;
-    if (g16 > 0) {
-        if (L1->h0) hipLaunchKernelGGL(pst_fill_h0_16_kernel, dim3(a.nrt, u1 / 32), dim3(64), 0, st, (const bf16_t*)L1->h0, B, u1, edge);
-        if (L2->h0) hipLaunchKernelGGL(pst_fill_h0_16_kernel, dim3(a.nrt, u2 / 32), dim3(64), 0, st, (const bf16_t*)L2->h0, B, u2, edge + (size_t)a.nrt * 32 * u1);
-        if (u1 == 512) e = launch_pfwd16<4>(st, grid, a, u2);
-        else if (u1 == 256) e = launch_pfwd16<2>(st, grid, a, u2);
-        else e = launch_pfwd16<1>(st, grid, a, u2);
-    } else {
-        if (L1->h0) hipLaunchKernelGGL(pst_fill_h0_kernel, dim3(a.nrt, u1 / 16), dim3(64), 0, st, (const bf16_t*)L1->h0, B, u1, edge);
-        if (L2->h0) hipLaunchKernelGGL(pst_fill_h0_kernel, dim3(a.nrt, u2 / 16), dim3(64), 0, st, (const bf16_t*)L2->h0, B, u2, edge + (size_t)a.nrt * 64 * u1);
-        if (u1 == 512) e = launch_pfwd<8>(st, grid, a, u2);
-        else if (u1 == 256) e = launch_pfwd<4>(st, grid, a, u2);
-        else e = launch_pfwd<2>(st, grid, a, u2);
-    }
+    if (u1 == 512) e = launch_pfwd<8>(st, grid, a, u2);
+    else if (u1 == 256) e = launch_pfwd<4>(st, grid, a, u2);
+    else e = launch_pfwd<2>(st, grid, a, u2);
     MNN_HIP(e);
-    hipLaunchKernelGGL(pst_sticky_kernel, dim3(1), dim3(1), 0, st, (unsigned*)workspace, (int)(sticky_offset(B, u1, u2) / sizeof(unsigned)));
+    hipLaunchKernelGGL(pst_sticky_kernel, dim3(1), dim3(1), 0, st, (unsigned*)workspace, (int)(sticky_offset(a.nrt, u1, u2) / sizeof(unsigned)));
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
@@ -1110,18 +792,18 @@ extern "C" int mnn_lstm2_persist_bwd(mnn_stream_t s, int T, int B, const mnn_lst
     a.l1 = bwd_layer(L1); a.l2 = bwd_layer(L2);
     a.T = T; a.B = B; a.kp = keep_prob; a.sync = (unsigned*)workspace;
     const size_t per = (size_t)T * a.nrt;
-    char* edge = (char*)workspace + sync_words(B) * sizeof(unsigned);
-    char* x = (char*)workspace + xchg_offset(B, u1, u2);
+    char* edge = (char*)workspace + sync_words(a.nrt) * sizeof(unsigned);
+    char* x = (char*)workspace + xchg_offset(a.nrt, u1, u2);
     a.l1.dzxT = edge; a.l2.dzxT = edge + (size_t)a.nrt * 256 * u1;
     a.l1.dzx = x; a.l2.dzx = x + per * 256 * u1;
     const int grid = a.G * (u1 / 32 + u2 / 32);
-    MNN_HIP(hipMemsetAsync(workspace, 0, sync_words(B) * sizeof(unsigned) + edge_bytes(B, u1, u2, true), st));
+    MNN_HIP(hipMemsetAsync(workspace, 0, sync_words(a.nrt) * sizeof(unsigned) + edge_bytes(a.nrt, u1, u2, true), st));
     hipError_t e;
     if (u1 == 512) e = launch_pbwd<16>(st, grid, a, u2);
     else if (u1 == 256) e = launch_pbwd<8>(st, grid, a, u2);
     else e = launch_pbwd<4>(st, grid, a, u2);
     MNN_HIP(e);
-    hipLaunchKernelGGL(pst_sticky_kernel, dim3(1), dim3(1), 0, st, (unsigned*)workspace, (int)(sticky_offset(B, u1, u2) / sizeof(unsigned)));
+    hipLaunchKernelGGL(pst_sticky_kernel, dim3(1), dim3(1), 0, st, (unsigned*)workspace, (int)(sticky_offset(a.nrt, u1, u2) / sizeof(unsigned)));
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
