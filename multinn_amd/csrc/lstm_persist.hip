@@ -19,6 +19,7 @@
 // grid is not resident at once (one workgroup per CU).  Block -> tile map: blocks with equal (id % G) share a row tile,
 // so with G = 8 a row tile's workgroups share an XCD under round-robin dispatch (speed only, never correctness).
 #include "common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
@@ -51,8 +52,12 @@ __device__ __forceinline__ void load_frags_xchg(const void* slab, size_t slab_by
 #pragma unroll
     for (int s = 0; s < KS; ++s) f[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024 * s, 0, PST_SC1));
 }
-__device__ __forceinline__ void store_frag_xchg(void* slab, size_t slab_bytes, int f, int lane, u32x4_t v) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, slice_rsrc(slab, slab_bytes), (f * 64 + lane) * 16, 0, PST_SC1);
+// `local`: every workgroup of this row tile sits on ONE XCD (checked at launch start, pst_same_xcd): then the tile is stored
+// write-BACK -- it stays in that XCD's L2, which all of them share, and the consumers' sc1 (L1-bypassing, L2-served) loads hit
+// it there instead of fetching a write-through line back through the fabric.  Otherwise write-through (device scope).
+__device__ __forceinline__ void store_frag_xchg(void* slab, size_t slab_bytes, int f, int lane, u32x4_t v, bool local) {
+    if (local) __builtin_amdgcn_raw_buffer_store_b128(v, slice_rsrc(slab, slab_bytes), (f * 64 + lane) * 16, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(v, slice_rsrc(slab, slab_bytes), (f * 64 + lane) * 16, 0, PST_SC1);
 }
 template <int KS>
 __device__ __forceinline__ void load_frags_plain(const bf16_t* __restrict__ p, bf16x8_t (&f)[KS]) {
@@ -89,10 +94,30 @@ __device__ __forceinline__ bool pst_wait(const unsigned* line, unsigned* status,
 }
 
 // Publish: every storing wave drains its write-through stores, the workgroup meets, one lane raises the flag.
-__device__ __forceinline__ void pst_publish(unsigned* flag, unsigned value) {
+__device__ __forceinline__ void pst_publish(unsigned* flag, unsigned value, bool local) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) st_agent(flag, value);
+    if (threadIdx.x == 0) {
+        if (local) __hip_atomic_store((gu32*)flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // plain store: lands in the shared L2
+        else st_agent(flag, value);
+    }
+}
+
+// Launch start: do the nm workgroups of this row-tile group share an XCD?  Each posts 0x100 | XCC_ID (device scope), waits for
+// the others (bounded) and compares.  The answer only selects the store policy of the hand-offs; results never depend on it.
+__device__ __forceinline__ bool pst_same_xcd(unsigned* xline, unsigned* status, int member, int nm, int* s_abort, int* s_local) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) st_agent(xline + member, 0x100u | (xcc & 0xfu));
+    if (!pst_wait(xline, status, nm, 1u, nm, 1u, s_abort)) return false;
+    if (threadIdx.x < 64) {
+        const unsigned v = ld_agent(xline + (threadIdx.x < (unsigned)nm ? threadIdx.x : 0));
+        const unsigned v0 = __builtin_amdgcn_readfirstlane(v);
+        const bool same = __all(v == v0);
+        if (threadIdx.x == 0) *s_local = same ? 1 : 0;
+    }
+    __syncthreads();
+    return true;
 }
 
 struct PFwdLayer {
@@ -103,7 +128,7 @@ struct PFwdLayer {
     char* hx; char* yx;            // exchange copies of h[t] (and of the dropped output y[t]), A-fragment order, slab (t, row tile)
     const char* hx0;               // slabs of the initial state h[-1] (zeros, or h0 re-laid by pst_fill_h0_kernel), one per row tile
 };
-struct PFwdArgs { PFwdLayer l1, l2; int T, B, nrt, G, R; float kp; unsigned* sync; };
+struct PFwdArgs { PFwdLayer l1, l2; int T, B, nrt, G, R; float kp; unsigned* sync; int xcc_off, allow_local; };
 
 struct FwdTiles {
     float red[4][4][16][64];       // K-split partial tiles
@@ -111,7 +136,7 @@ struct FwdTiles {
     bf16_t sY[32][40];             // dropped output tile
     bf16_t sT[32][40];             // h tile [unit][row] for the transposed copy (weight-gradient operand)
     bf16_t sYT[32][40];            // output tile [unit][row] (y, or h without dropout) for the transposed copy
-    int abort;
+    int abort, local;
 };
 
 // What one finished item leaves for its deferred tail (plain stores issued one item later, off the chain).
@@ -119,7 +144,7 @@ struct FwdTail { float gv[4][4], cv[4]; int t, m0; bool valid; };
 
 // Gate pointwise of this wave's 4 fragment rows -> tiles in LDS, then the hand-off of the h (and y) tile.
 __device__ __forceinline__ void pf_finish(const PFwdLayer& L, FwdTiles& S, int T, int nrt, int t, int rt, int nt, float kp, const float (&z)[4][4],
-                                          const float (&cp)[4], const unsigned (&mk)[4], FwdTail& tl, unsigned* flag, long long* trc) {
+                                          const float (&cp)[4], const unsigned (&mk)[4], FwdTail& tl, unsigned* flag, bool local, long long* trc) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const bool drop = L.mask != nullptr;
@@ -148,10 +173,10 @@ __device__ __forceinline__ void pf_finish(const PFwdLayer& L, FwdTiles& S, int T
         if (!second || (drop && L.yx != nullptr)) {
             const bf16_t (*src)[40] = second ? S.sY : S.sH;
             const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&src[r][ks * 16 + hh * 8]);
-            store_frag_xchg((second ? L.yx : L.hx) + ((size_t)t * nrt + rt) * slab, slab, 2 * nt + ks, lane, v);
+            store_frag_xchg((second ? L.yx : L.hx) + ((size_t)t * nrt + rt) * slab, slab, 2 * nt + ks, lane, v, local);
         }
     }
-    pst_publish(flag, (unsigned)(t + 1));
+    pst_publish(flag, (unsigned)(t + 1), local);
     PST_TR(trc, 4);
 }
 
@@ -219,8 +244,10 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
     unsigned* status = A.sync;
     unsigned* flags = A.sync + PST_FLAGS_OFF;
     const float* zero = reinterpret_cast<const float*>(A.sync + 4);
-    if (threadIdx.x == 0) S.abort = 0;
+    if (threadIdx.x == 0) { S.abort = 0; S.local = 0; }
     __syncthreads();
+    if (!pst_same_xcd(A.sync + A.xcc_off + grp * 32, status, member, nm, &S.abort, &S.local)) return;
+    const bool local = A.allow_local && S.local != 0;
     FwdTail tl;
     tl.valid = false;
 #pragma unroll
@@ -296,7 +323,7 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
                 cp[q] = (Rv == 1 && t > 0) ? tl.cv[q] : cl[q];
             }
             PST_TR(trc, 2);
-            pf_finish(L, S, T, nrt, t, rt, nt, A.kp, z, cp, mk, tl, flags + rt * 32 + member, trc);
+            pf_finish(L, S, T, nrt, t, rt, nt, A.kp, z, cp, mk, tl, flags + rt * 32 + member, local, trc);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 mk[q] = mkn[q];
@@ -371,7 +398,7 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
                 cp[q] = (Rv == 1 && t > 0) ? tl.cv[q] : cl[q];
             }
             PST_TR(trc, 2);
-            pf_finish(L, S, T, nrt, t, rt, nt, A.kp, z, cp, mk, tl, flags + rt * 32 + member, trc);
+            pf_finish(L, S, T, nrt, t, rt, nt, A.kp, z, cp, mk, tl, flags + rt * 32 + member, local, trc);
             PST_TR(trc, 5);
         }
         pf_tail(L, S, T, B, nt, tl);
@@ -401,19 +428,19 @@ struct PBwdLayer {
     char* dzx;                     // exchange copy of dz[t], A-fragment order, slab (t, row tile)
     const char* dzxT;              // zero slabs standing for dz[T], one per row tile
 };
-struct PBwdArgs { PBwdLayer l1, l2; int T, B, nrt, G, R; float kp; unsigned* sync; };
+struct PBwdArgs { PBwdLayer l1, l2; int T, B, nrt, G, R; float kp; unsigned* sync; int xcc_off, allow_local; };
 
 struct BwdTiles {
     float red[2][8][16][64];
     bf16_t sZ[32][136];            // dz tile [row][gate*32 + unit] (+pad)
     bf16_t sT[4][32][40];          // dz tile [gate][unit][row] for the transposed copy
-    int abort;
+    int abort, local;
 };
 struct BwdEpi { float dh, g[4], c, cp; unsigned keep; };      // per fragment row: external gradient, gates, cell states, raw keep byte
 struct BwdTail { float dcv[2]; float dbv; int t, m0; bool valid; };      // dbv: threads 0..127: running column sum of the dz tiles (bias gradient)
 
 __device__ __forceinline__ void pb_finish(const PBwdLayer& L, BwdTiles& S, int nrt, int t, int rt, int nt, const float (&dh)[2], const BwdEpi (&e)[2],
-                                          const float (&e_dc)[2], BwdTail& tl, unsigned* flag, unsigned epoch, long long* trc) {
+                                          const float (&e_dc)[2], BwdTail& tl, unsigned* flag, unsigned epoch, bool local, long long* trc) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
@@ -439,9 +466,9 @@ __device__ __forceinline__ void pb_finish(const PBwdLayer& L, BwdTiles& S, int n
     {   // k-steps 8nt .. 8nt+7 of the slab, one per wave: a contiguous KiB per store instruction
         const size_t slab = (size_t)(4 * L.U / 16) * 1024;
         const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&S.sZ[r][w * 16 + hh * 8]);
-        store_frag_xchg(L.dzx + ((size_t)t * nrt + rt) * slab, slab, 8 * nt + w, lane, v);
+        store_frag_xchg(L.dzx + ((size_t)t * nrt + rt) * slab, slab, 8 * nt + w, lane, v, local);
     }
-    pst_publish(flag, epoch);
+    pst_publish(flag, epoch, local);
     PST_TR(trc, 4);
 }
 
@@ -521,8 +548,10 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
     unsigned* status = A.sync;
     unsigned* flags = A.sync + PST_FLAGS_OFF;
     const float* zero = reinterpret_cast<const float*>(A.sync + 4);
-    if (threadIdx.x == 0) S.abort = 0;
+    if (threadIdx.x == 0) { S.abort = 0; S.local = 0; }
     __syncthreads();
+    if (!pst_same_xcd(A.sync + A.xcc_off + grp * 32, status, member, nm, &S.abort, &S.local)) return;
+    const bool local = A.allow_local && S.local != 0;
     BwdTail tl;
     tl.valid = false;
     tl.dcv[0] = tl.dcv[1] = 0.f;
@@ -577,7 +606,7 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
                 e_dc[q] = (Rv == 1 && k > 0) ? tl.dcv[q] : dcl[q];
             }
             PST_TR(trc, 2);
-            pb_finish(L, S, nrt, t, rt, nt, dh, e, e_dc, tl, flags + rt * 32 + member, (unsigned)(k + 1), trc);
+            pb_finish(L, S, nrt, t, rt, nt, dh, e, e_dc, tl, flags + rt * 32 + member, (unsigned)(k + 1), local, trc);
             e[0] = en[0]; e[1] = en[1];
             PST_TR(trc, 5);
         }
@@ -634,7 +663,7 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
                 e_dc[q] = (Rv == 1 && k > 0) ? tl.dcv[q] : dcl[q];
             }
             PST_TR(trc, 2);
-            pb_finish(L, S, nrt, t, rt, nt, dh, e, e_dc, tl, flags + rt * 32 + member, (unsigned)(k + 1), trc);
+            pb_finish(L, S, nrt, t, rt, nt, dh, e, e_dc, tl, flags + rt * 32 + member, (unsigned)(k + 1), local, trc);
             PST_TR(trc, 5);
         }
         pb_tail(L, S, B, Rv, nt, tl);
@@ -676,7 +705,7 @@ static bool persist_plan(int B, int u1, int u2, int& nrt, int& G, int& R) {
 
 // workspace: [status | 31 zero words][32 flags per row tile][boundary slabs: layer 1, layer 2 (zeros / h0)] -- one memset
 // per call covers all of that -- [sticky word, padded][exchange area]
-static size_t sync_words(int nrt) { return (size_t)PST_FLAGS_OFF + 32 * (size_t)nrt; }
+static size_t sync_words(int nrt) { return (size_t)PST_FLAGS_OFF + 64 * (size_t)nrt; }       // flags lines, then one XCC-id line per row-tile group
 static size_t edge_bytes(int nrt, int u1, int u2, bool bwd) { return (size_t)nrt * (bwd ? 256 : 64) * ((size_t)u1 + u2); }
 static size_t edge_max(int nrt, int u1, int u2) { return edge_bytes(nrt, u1, u2, true); }
 static size_t sticky_offset(int nrt, int u1, int u2) { return sync_words(nrt) * sizeof(unsigned) + edge_max(nrt, u1, u2); }
@@ -745,6 +774,7 @@ extern "C" int mnn_lstm2_persist_fwd(mnn_stream_t s, int T, int B, const mnn_lst
     const int u1 = L1->units, u2 = L2->units;
     a.l1 = fwd_layer(L1); a.l2 = fwd_layer(L2);
     a.T = T; a.B = B; a.kp = keep_prob; a.sync = (unsigned*)workspace;
+    a.xcc_off = PST_FLAGS_OFF + 32 * a.nrt; a.allow_local = getenv("MNN_PERSIST_NO_LOCAL") == nullptr;
     const size_t per = (size_t)T * a.nrt;
     char* edge = (char*)workspace + sync_words(a.nrt) * sizeof(unsigned);
     char* x = (char*)workspace + xchg_offset(a.nrt, u1, u2);
@@ -791,6 +821,7 @@ extern "C" int mnn_lstm2_persist_bwd(mnn_stream_t s, int T, int B, const mnn_lst
     const int u1 = L1->units, u2 = L2->units;
     a.l1 = bwd_layer(L1); a.l2 = bwd_layer(L2);
     a.T = T; a.B = B; a.kp = keep_prob; a.sync = (unsigned*)workspace;
+    a.xcc_off = PST_FLAGS_OFF + 32 * a.nrt; a.allow_local = getenv("MNN_PERSIST_NO_LOCAL") == nullptr;
     const size_t per = (size_t)T * a.nrt;
     char* edge = (char*)workspace + sync_words(a.nrt) * sizeof(unsigned);
     char* x = (char*)workspace + xchg_offset(a.nrt, u1, u2);
