@@ -156,6 +156,11 @@ int mnn_lstm2_seq_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L1
  * on a bounded spin -- its outputs are then garbage.  mnn_lstm2_persist_ok() says whether the grid fits this device at
  * once (one workgroup per CU); the entries refuse shapes for which it does not. */
 int mnn_lstm2_persist_ok(int B, int units1, int units2);
+/* The persistent form keeps its saved gates [T,B,4u] (both layers) and READS layer 1's xproj GATE-MINOR: column unit*4 + g
+ * instead of the gate-interleaved (unit/32)*128 + g*32 + unit%32 -- the four values of a (row, unit) are one 16-byte access.
+ * mnn_lstm_rows_gate_minor re-orders the rows of a packed wx_t [4u, ld] (and bias_p) accordingly, so the ordinary projection
+ * GEMM produces that xproj.  Gates written by mnn_lstm2_persist_fwd are only meaningful to mnn_lstm2_persist_bwd. */
+int mnn_lstm_rows_gate_minor(mnn_stream_t s, int dtype, int units, int ld, const void* wx_t, const float* bias_p, void* wx_gm, float* bias_gm);
 size_t mnn_lstm2_persist_workspace_bytes(int T, int B, int units1, int units2);
 int mnn_lstm2_persist_status(const void* workspace, int B, int units1, int units2, int* status);
 int mnn_lstm2_persist_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L1, const mnn_lstm_fwd_layer* L2, float keep_prob,

@@ -59,6 +59,7 @@ class LstmBwdLayer(C.Structure):
 
 SIGNATURES["mnn_lstm2_seq_fwd"] = (_i, [_p, _i, _i, C.POINTER(LstmFwdLayer), C.POINTER(LstmFwdLayer), _f, _i, _i])
 SIGNATURES["mnn_lstm2_seq_bwd"] = (_i, [_p, _i, _i, C.POINTER(LstmBwdLayer), C.POINTER(LstmBwdLayer), _f, _i, _i])
+SIGNATURES["mnn_lstm_rows_gate_minor"] = (_i, [_p, _i, _i, _i, _p, _p, _p, _p])
 SIGNATURES["mnn_lstm2_persist_ok"] = (_i, [_i, _i, _i])
 SIGNATURES["mnn_lstm2_persist_workspace_bytes"] = (_sz, [_i, _i, _i, _i])
 SIGNATURES["mnn_lstm2_persist_status"] = (_i, [_p, _i, _i, _i, C.POINTER(C.c_int)])

@@ -202,6 +202,33 @@ extern "C" int mnn_lstm_pack_weights(mnn_stream_t s, const float* W, const float
     return MNN_OK;
 }
 
+// Rows of a gate-interleaved [4u, ld] matrix (row (unit/32)*128 + g*32 + unit%32) re-ordered GATE-MINOR (row unit*4 + g), and
+// the matching bias: a projection GEMM with these rows writes the four pre-activations of a unit next to each other (16 bytes),
+// which is how the persistent recurrence reads them (one 16-byte load per (row, unit) instead of four 4-byte ones).
+template <typename T>
+__global__ void lstm_rows_gate_minor_kernel(const T* __restrict__ src, const float* __restrict__ bias_p, int U, int ld, T* __restrict__ dst,
+                                            float* __restrict__ bias_gm) {
+    const int row = blockIdx.x;                      // destination row = unit * 4 + g
+    const int unit = row >> 2, g = row & 3;
+    const int pc = gate_perm_col(g, unit);
+    for (int k = threadIdx.x; k < ld; k += blockDim.x) dst[(size_t)row * ld + k] = src[(size_t)pc * ld + k];
+    if (threadIdx.x == 0) bias_gm[row] = bias_p[pc];
+}
+
+extern "C" int mnn_lstm_rows_gate_minor(mnn_stream_t s, int dtype, int units, int ld, const void* wx_t, const float* bias_p, void* wx_gm,
+                                        float* bias_gm) {
+    MNN_REQUIRE(wx_t && bias_p && wx_gm && bias_gm && units > 0 && units % 32 == 0 && ld > 0, "mnn_lstm_rows_gate_minor: bad arguments");
+    MNN_REQUIRE(dtype == MNN_F32 || dtype == MNN_BF16, "mnn_lstm_rows_gate_minor: dtype must be f32/bf16");
+    if (dtype == MNN_F32)
+        hipLaunchKernelGGL(lstm_rows_gate_minor_kernel<float>, dim3(4 * units), dim3(128), 0, (hipStream_t)s, (const float*)wx_t, bias_p, units, ld,
+                           (float*)wx_gm, bias_gm);
+    else
+        hipLaunchKernelGGL(lstm_rows_gate_minor_kernel<bf16_t>, dim3(4 * units), dim3(128), 0, (hipStream_t)s, (const bf16_t*)wx_t, bias_p, units, ld,
+                           (bf16_t*)wx_gm, bias_gm);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
 __global__ void lstm_unpack_grads_kernel(const float* __restrict__ dwx_t, const float* __restrict__ dwh_t, const float* __restrict__ db_p,
                                          int n_in, int U, int ld_in, float* __restrict__ dW, float* __restrict__ db) {
     const int N4 = 4 * U;

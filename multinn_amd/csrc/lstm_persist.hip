@@ -191,8 +191,9 @@ __device__ __forceinline__ void pf_tail(const PFwdLayer& L, const FwdTiles& S, i
     for (int q = 0; q < 4; ++q) {
         const int row = m0 + 8 * w + q + 4 * hh;
         if (row >= B) continue;
-        const size_t zo = (size_t)t * 4 * us + (size_t)row * N4 + n0 + r, uo = (size_t)t * us + (size_t)row * U + unit;
-        if (L.gates != nullptr) { L.gates[zo] = tl.gv[q][0]; L.gates[zo + 32] = tl.gv[q][1]; L.gates[zo + 64] = tl.gv[q][2]; L.gates[zo + 96] = tl.gv[q][3]; }
+        const size_t uo = (size_t)t * us + (size_t)row * U + unit;
+        if (L.gates != nullptr)                       // gate-minor: the four gates of a (row, unit) are one 16-byte store
+            *reinterpret_cast<float4*>(L.gates + (size_t)t * 4 * us + (size_t)row * N4 + unit * 4) = make_float4(tl.gv[q][0], tl.gv[q][1], tl.gv[q][2], tl.gv[q][3]);
         L.c[uo] = tl.cv[q];
     }
     {   // row-major tiles: 32 rows x 64 bytes, one 16-byte store per thread (h: threads 0..127, y: 128..255)
@@ -267,9 +268,8 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int rr = min(m0 + 8 * w + q + 4 * hh, B - 1);
-                const size_t zo = (size_t)t * 4 * us + (size_t)rr * N4 + n0 + r;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) xp_[q][g] = L.xproj[zo + 32 * g];
+                const float4 xv = *reinterpret_cast<const float4*>(L.xproj + (size_t)t * 4 * us + (size_t)rr * N4 + unit * 4);     // gate-minor xproj
+                xp_[q][0] = xv.x; xp_[q][1] = xv.y; xp_[q][2] = xv.z; xp_[q][3] = xv.w;
                 const uint8_t* mp = L.mask != nullptr ? L.mask + (size_t)t * us + (size_t)rr * U + unit : reinterpret_cast<const uint8_t*>(zero);
                 mk_[q] = *mp;
             }
@@ -521,11 +521,11 @@ __device__ __forceinline__ void pb_epi_load(const PBwdLayer& L, int B, int nt, i
     for (int q = 0; q < 2; ++q) {
         const int i = 2 * w + q;
         const int rr = min(m0 + (i & 3) + 8 * (i >> 2) + 4 * hh, B - 1);
-        const size_t uo = (size_t)rr * U + unit, zo = (size_t)t * 4 * us + (size_t)rr * N4 + pc;
+        const size_t uo = (size_t)rr * U + unit;
         if (LAYER1) e[q].dh = 0.f;
         else e[q].dh = L.dh_ext[(size_t)t * us + uo];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) e[q].g[g] = L.gates[zo + 32 * g];
+        const float4 gv = *reinterpret_cast<const float4*>(L.gates + (size_t)t * 4 * us + (size_t)rr * N4 + unit * 4);       // gate-minor gates
+        e[q].g[0] = gv.x; e[q].g[1] = gv.y; e[q].g[2] = gv.z; e[q].g[3] = gv.w;
         e[q].c = L.c[(size_t)t * us + uo];
         const float* cpp = t > 0 ? L.c + (size_t)(t - 1) * us + uo : (L.c0 != nullptr ? L.c0 + uo : zero);
         e[q].cp = *cpp;

@@ -72,6 +72,10 @@ class LstmStack:
                      bias_p=torch.empty(4 * u, device=dev), n_in=n_in, u=u, ld=ld)
             ops.lstm_pack_weights(self.store[f"{self.rnn.prefix}/cell_{l}/kernel"], self.store[f"{self.rnn.prefix}/cell_{l}/bias"], n_in, u,
                                   p["wx_t"], p["wh_t"], p["wh_p"], p["wx_p"], p["bias_p"])
+            if l == 0 and self.dtype == torch.bfloat16 and len(self.rnn.num_units) == 2:
+                # the persistent recurrence reads layer 1's xproj gate-minor: the projection GEMM gets the rows in that order
+                p["wx_gm"], p["bias_gm"] = torch.empty_like(p["wx_t"]), torch.empty_like(p["bias_p"])
+                ops.lstm_rows_gate_minor(p["wx_t"], p["bias_p"], p["wx_gm"], p["bias_gm"])
             self.packed.append(p)
 
     chunk = 16        # timesteps per wavefront chunk
@@ -154,7 +158,10 @@ class LstmStack:
             s.wait_stream(main)
         # layer 0's input projection has no dependency: one big GEMM
         p0, b0 = self.packed[0], bufs[0]
-        ops.gemm_tn(x_tm.view(T * B, -1), p0["wx_t"], b0["xproj"].view(T * B, -1), bias=p0["bias_p"])
+        if persist:
+            ops.gemm_tn(x_tm.view(T * B, -1), p0["wx_gm"], b0["xproj"].view(T * B, -1), bias=p0["bias_gm"])       # gate-minor columns
+        else:
+            ops.gemm_tn(x_tm.view(T * B, -1), p0["wx_t"], b0["xproj"].view(T * B, -1), bias=p0["bias_p"])
         if persist or self._fused2(B):
             # persist: ONE launch for the whole recurrence of both layers; else ONE launch per timestep for the whole
             # stack: layer-0 step s | layer-1 projection s-1 | layer-1 step s-2
@@ -203,7 +210,8 @@ class LstmStack:
         if save:
             for l, bf in enumerate(bufs):
                 ctx.append(dict(inp=x_tm if l == 0 else bufs[l - 1]["y"], gates=bf["gates"], c=bf["c"], h=bf["h"], c0=bf["c0"], h0=bf["h0"],
-                                hT=bf["hT"], mask=bf.get("mask"), yT=bf.get("yT"), inT=bufs[l - 1].get("yT") if l > 0 else None))
+                                hT=bf["hT"], mask=bf.get("mask"), yT=bf.get("yT"), inT=bufs[l - 1].get("yT") if l > 0 else None,
+                                persist=persist))        # persist: the saved gates are gate-minor -- only the persistent backward reads them
         final = [(bf["c"][-1], bf["h"][-1]) for bf in bufs]
         return bufs[-1]["y"], ctx, final
 
@@ -249,7 +257,7 @@ class LstmStack:
             s.wait_stream(main)
         dyl = [None] * L
         dyl[L - 1] = dy.view(T, B, -1)
-        persist = self._persist(B) and (keep_prob >= 1.0 or ctx[0].get("mask") is not None)
+        persist = bool(ctx[0].get("persist"))       # the layout of the saved gates is the forward's choice
         st = []
         Np = ops.round_up(T * B, 64)
         for l, p in enumerate(self.packed):

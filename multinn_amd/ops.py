@@ -122,6 +122,15 @@ def lstm_pack_weights(W, b, n_in, units, wx_t, wh_t, wh_p, wx_p, bias_p):
          _ptr(wx_p), _ptr(bias_p))
 
 
+def lstm_rows_gate_minor(wx_t, bias_p, wx_gm, bias_gm):
+    """Gate-minor (row unit*4+g) copy of a packed wx_t [4u, ld] and its bias: the layout the persistent recurrence reads xproj in."""
+    N4, ld = wx_t.shape
+    _req(N4 % 128 == 0 and wx_t.is_contiguous() and wx_gm.shape == wx_t.shape and wx_gm.dtype == wx_t.dtype and wx_gm.is_contiguous(),
+         "rows_gate_minor: wx_t / wx_gm [4u, ld]")
+    _req(bias_p.dtype == torch.float32 and bias_gm.dtype == torch.float32 and bias_p.numel() == N4 and bias_gm.numel() == N4, "rows_gate_minor: bias f32 [4u]")
+    call("mnn_lstm_rows_gate_minor", _stream(), dtype_code(wx_t), N4 // 4, ld, _ptr(wx_t), _ptr(bias_p), _ptr(wx_gm), _ptr(bias_gm))
+
+
 def lstm_unpack_grads(dwx_t, dwh_t, db_p, n_in, units, dW, db):
     ld_in = dwx_t.shape[1]
     _req(dwx_t.dtype == torch.float32 and dwx_t.shape == (4 * units, ld_in) and dwx_t.is_contiguous(), "unpack: dwx_t f32 [4u,ld]")
