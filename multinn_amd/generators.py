@@ -307,6 +307,8 @@ class LstmStack:
                         if piped:
                             done[l][ci] = torch.cuda.Event()
                             done[l][ci].record(lane)
+        if getattr(self, "keep_debug", False):      # tests: the recurrence's own (atomic-free, hence run-to-run bit-stable) outputs
+            self._dbg_dzT = [s_["dzT"] for s_ in st]
         keep = []
         for l in range(L - 1, -1, -1):
             with torch.cuda.stream(lane_of(l)):

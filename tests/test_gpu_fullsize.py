@@ -142,3 +142,35 @@ def test_ragged_and_empty_sequences(gen):
     keep = lengths > 0
     gen.build_pianoroll(x[keep].contiguous(), lengths[keep].contiguous(), False, "eval")
     assert abs(float(gen.metrics["batch/loss"]) - l_all) < 1e-5 * abs(l_all)
+
+
+def test_persistent_recurrence_is_race_free_under_load():
+    """Hand-off protocol of the persistent LSTM launches (flags + tiles between workgroups): 40 forward + backward passes at
+    C2 size on the same parameters must reproduce the per-row NLL and the transposed dz of both layers BIT FOR BIT (a stale or
+    early tile read shows up as run-to-run noise; everything downstream of f32 atomics is excluded), also while a second
+    stream keeps the chip unevenly busy; no launch may have given up on a spin."""
+    from multinn_amd import RnnNade
+    x = synth(B, 64, 31)
+    g = RnnNade(D, HN, UNITS, keep_prob=0.9, precision="bf16", seed=5)
+    g._materialize(D)
+    g._stack.keep_debug = True
+    noise = torch.empty((64, 1 << 20), device=DEV)
+    side = torch.cuda.Stream()
+    ref = None
+    for i in range(40):
+        if i % 3 != 0:
+            with torch.cuda.stream(side):
+                noise[: 8 + (i % 5) * 8].mul_(1.0001)              # a few CUs' worth of unrelated streaming work, off and on
+        g.build_pianoroll(x, None, True, "train")
+        nll = g._nll_tm.clone()
+        g.backward()
+        dz = [d.clone() for d in g._stack._dbg_dzT]
+        if ref is None:
+            ref = (nll, dz)
+            assert bool(torch.isfinite(nll).all()) and all(bool(torch.isfinite(d.float()).all()) for d in dz)
+        else:
+            assert torch.equal(nll, ref[0]), i
+            assert all(torch.equal(a_, b_) for a_, b_ in zip(dz, ref[1])), i
+    torch.cuda.synchronize()
+    assert g._stack._persist(B)
+    g._stack.check()
