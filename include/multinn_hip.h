@@ -252,6 +252,21 @@ int mnn_step_increment(mnn_stream_t s, int32_t* step_dev);
 int mnn_bias_grad(mnn_stream_t s, const float* dY, int rows, int cols, int ld, float* db, int accumulate);
 int mnn_fill_f32(mnn_stream_t s, float* x, long n, float value);
 
+/* ------------------------------------------------------------------------------------------
+ * Musical sample metrics (metrics/musical.py:45-275): integer passes over a sampled piano-roll
+ * x u8 [B, bars, steps, P, M] (any non-zero byte = note on).  The host turns the tables into EB/UP/UPC/QN/PR/DP/TD in float64.
+ * mnn_musical_bar_stats: one workgroup per (sample, bar), nbars = B*bars; all outputs int32 [nbars, M] except
+ *   beat_chroma int32 [nbars, 4, 12, M] (notes per quarter-bar and chroma class; class of pitch p = p / (ceil(P/12)) as
+ *   _to_chroma's reshape does, musical.py:36-41).  poly_steps counts steps with MORE than poly_threshold pitches (:130);
+ *   pattern_class u8 [steps] (1 = weight 1, 2 = weight `tolerance`, 0 = none; NULL = all 0) feeds pat_on / pat_tol (:148-175).
+ *   steps: multiple of 4, <= 192; M <= 8.
+ * mnn_musical_note_stats: notes are maximal runs along the bars*steps time axis per (sample, pitch, track) (:93-106);
+ *   onsets[m] += notes, qualified[m] += notes longer than `threshold` steps (caller zeroes both int32 [M]). */
+int mnn_musical_bar_stats(mnn_stream_t s, const uint8_t* x, int nbars, int steps, int P, int M, int poly_threshold,
+                          const uint8_t* pattern_class, int32_t* notes, int32_t* used_pitches, int32_t* used_classes,
+                          int32_t* poly_steps, int32_t* pat_on, int32_t* pat_tol, int32_t* beat_chroma);
+int mnn_musical_note_stats(mnn_stream_t s, const uint8_t* x, int B, int T, int P, int M, int threshold, int32_t* onsets, int32_t* qualified);
+
 #ifdef __cplusplus
 }
 #endif

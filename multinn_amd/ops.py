@@ -497,3 +497,25 @@ def bias_grad(dY, db, accumulate=False):
 def fill(x, value):
     _req(x.dtype == torch.float32 and x.is_contiguous(), "fill: f32 contiguous")
     call("mnn_fill_f32", _stream(), _ptr(x), x.numel(), float(value))
+
+
+# ------------------------------------------------------------------------------------------------
+def musical_bar_stats(x, poly_threshold, pattern_class, notes, used_pitches, used_classes, poly_steps, pat_on, pat_tol, beat_chroma):
+    """x u8 [B,bars,steps,P,M]; int32 outputs [B*bars, M], beat_chroma int32 [B*bars,4,12,M] (metrics/musical.py)."""
+    _req(x.dtype == torch.uint8 and x.dim() == 5 and x.is_contiguous(), "musical_bar_stats: x u8 [B,bars,steps,P,M]")
+    B, bars, steps, P, M = x.shape
+    for t in (notes, used_pitches, used_classes, poly_steps, pat_on, pat_tol):
+        _req(t.dtype == torch.int32 and t.numel() == B * bars * M and t.is_contiguous(), "musical_bar_stats: int32 [B*bars, M] outputs")
+    _req(beat_chroma.dtype == torch.int32 and beat_chroma.numel() == B * bars * 48 * M and beat_chroma.is_contiguous(), "musical_bar_stats: beat_chroma")
+    _req(pattern_class is None or (pattern_class.dtype == torch.uint8 and pattern_class.numel() == steps), "musical_bar_stats: pattern_class u8 [steps]")
+    call("mnn_musical_bar_stats", _stream(), _ptr(x), B * bars, steps, P, M, int(poly_threshold), _ptr(pattern_class), _ptr(notes), _ptr(used_pitches),
+         _ptr(used_classes), _ptr(poly_steps), _ptr(pat_on), _ptr(pat_tol), _ptr(beat_chroma))
+
+
+def musical_note_stats(x, threshold, onsets, qualified):
+    """x u8 [B,T,P,M]; onsets / qualified int32 [M], accumulated (zero them first)."""
+    _req(x.dtype == torch.uint8 and x.dim() == 4 and x.is_contiguous(), "musical_note_stats: x u8 [B,T,P,M]")
+    B, T, P, M = x.shape
+    for t in (onsets, qualified):
+        _req(t.dtype == torch.int32 and t.numel() == M, "musical_note_stats: int32 [M] outputs")
+    call("mnn_musical_note_stats", _stream(), _ptr(x), B, T, P, M, int(threshold), _ptr(onsets), _ptr(qualified))

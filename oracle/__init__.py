@@ -11,4 +11,8 @@ reference files plus the TF op semantics recorded in ``oracle/tf_semantics.py``.
 It is pinned by analytical known-answer tests (tests/test_oracle_kats.py) and by
 agreement between two independent restatements (NumPy float64 loops here,
 torch-CPU float32 autograd in ``oracle/torch_ref.py``).
+
+Exception -- PINNED: ``oracle/musical.py`` (the musical sample metrics) is checked against outputs of
+the reference's own NumPy-only module, captured in this container as ``tests/golden/musical_metrics.npz`` by
+``tests/golden/make_musical_golden.py``.
 """
