@@ -267,6 +267,14 @@ int mnn_musical_bar_stats(mnn_stream_t s, const uint8_t* x, int nbars, int steps
                           int32_t* poly_steps, int32_t* pat_on, int32_t* pat_tol, int32_t* beat_chroma);
 int mnn_musical_note_stats(mnn_stream_t s, const uint8_t* x, int B, int T, int P, int M, int threshold, int32_t* onsets, int32_t* qualified);
 
+/* Evaluation statistics (metrics/statistical.py:6-47).
+ * mnn_eval_counts: counts u64[4] += {true positives, false positives, false negatives, equal cells} over n cells of
+ *   targets / predictions (u8, non-zero = 1): the raw sums of tf.metrics.accuracy / precision / recall (:28-32).
+ * mnn_log_loss_rows: out[row] = sum_d -(t log(p+1e-7) + (1-t) log(1-p+1e-7)): the encoders' reconstruction cost
+ *   (tf.losses.log_loss, pass_encoder.py:81-86, rbm.py:124-129); probs f32 [N, ld_probs]. */
+int mnn_eval_counts(mnn_stream_t s, const uint8_t* targets, const uint8_t* predictions, long n, unsigned long long* counts);
+int mnn_log_loss_rows(mnn_stream_t s, const uint8_t* targets, const float* probs, int N, int D, int ld_probs, float* out);
+
 #ifdef __cplusplus
 }
 #endif

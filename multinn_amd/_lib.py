@@ -69,6 +69,8 @@ SIGNATURES["mnn_nade_mfma_ok"] = (_i, [_i])
 SIGNATURES["mnn_nade_logprob_fwd_mfma"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p])
 SIGNATURES["mnn_musical_bar_stats"] = (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p])
 SIGNATURES["mnn_musical_note_stats"] = (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p])
+SIGNATURES["mnn_eval_counts"] = (_i, [_p, _p, _p, _l, _p])
+SIGNATURES["mnn_log_loss_rows"] = (_i, [_p, _p, _p, _i, _i, _i, _p])
 SIGNATURES["mnn_dropout_mask"] = (_i, [_p, _p, _i, _i, _i, _f, _u64, _p, _u32, _i])
 
 _lib = None

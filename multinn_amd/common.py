@@ -305,8 +305,8 @@ class RBM(Model):
         from .metrics import base_metrics
         cost, free_energy = self.free_energy_cost(targets, predictions)
         if log_probs is None and cond_probs is not None:
-            t = targets.float()
-            log_probs = (-t * torch.log(cond_probs + 1e-7) - (1 - t) * torch.log(1 - cond_probs + 1e-7)).sum(1)   # tf.losses.log_loss
+            from .encoders import reconstruction_cost
+            log_probs = reconstruction_cost(targets, cond_probs)   # tf.losses.log_loss summed over the visibles
         else:
             raise ValueError("Incorrect arguments. Either `cond_probs`, or `log_probs` should be provided on `rbm.build_metrics()` function call")
         metrics, upd, summ = base_metrics(cost, targets, predictions, log_probs)

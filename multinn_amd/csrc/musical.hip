@@ -119,3 +119,55 @@ extern "C" int mnn_musical_note_stats(mnn_stream_t s, const uint8_t* x, int B, i
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Evaluation statistics: the passes behind metrics/statistical.py:6-47 and the encoders' reconstruction cost
+// (pass_encoder.py:81-86, rbm.py:124-129: tf.losses.log_loss summed over the visibles, epsilon 1e-7).
+// ------------------------------------------------------------------------------------------------
+// counts[0..3] += true positives, false positives, false negatives, equal cells over n cells (targets / predictions: non-zero = 1)
+__global__ void __launch_bounds__(256) eval_counts_kernel(const uint8_t* __restrict__ targets, const uint8_t* __restrict__ predictions, long n,
+                                                          unsigned long long* __restrict__ counts) {
+    unsigned tp = 0, fp = 0, fn = 0, eq = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const bool t = targets[i] != 0, p = predictions[i] != 0;
+        tp += (t && p) ? 1u : 0u; fp += (!t && p) ? 1u : 0u; fn += (t && !p) ? 1u : 0u; eq += (t == p) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { tp += __shfl_xor(tp, o); fp += __shfl_xor(fp, o); fn += __shfl_xor(fn, o); eq += __shfl_xor(eq, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (tp) atomicAdd(counts + 0, (unsigned long long)tp);
+        if (fp) atomicAdd(counts + 1, (unsigned long long)fp);
+        if (fn) atomicAdd(counts + 2, (unsigned long long)fn);
+        if (eq) atomicAdd(counts + 3, (unsigned long long)eq);
+    }
+}
+
+extern "C" int mnn_eval_counts(mnn_stream_t s, const uint8_t* targets, const uint8_t* predictions, long n, unsigned long long* counts) {
+    MNN_REQUIRE(targets && predictions && counts && n > 0, "mnn_eval_counts: bad arguments");
+    const int blocks = (int)min((long)2048, (n + 255) / 256);
+    hipLaunchKernelGGL(eval_counts_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, targets, predictions, n, counts);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+// out[row] = sum_d -( t log(p + 1e-7) + (1 - t) log(1 - p + 1e-7) ), one wave per row (ascending-index partial sums per lane, xor tree)
+__global__ void __launch_bounds__(256) log_loss_rows_kernel(const uint8_t* __restrict__ targets, const float* __restrict__ probs, int N, int D,
+                                                            int ld_p, float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    float acc = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float p = probs[(size_t)row * ld_p + d];
+        acc += targets[(size_t)row * D + d] != 0 ? -logf(p + 1e-7f) : -logf(1.0f - p + 1e-7f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) out[row] = acc;
+}
+
+extern "C" int mnn_log_loss_rows(mnn_stream_t s, const uint8_t* targets, const float* probs, int N, int D, int ld_probs, float* out) {
+    MNN_REQUIRE(targets && probs && out && N > 0 && D > 0 && ld_probs >= D, "mnn_log_loss_rows: bad arguments");
+    hipLaunchKernelGGL(log_loss_rows_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)s, targets, probs, N, D, ld_probs, out);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}

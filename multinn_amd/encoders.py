@@ -62,9 +62,18 @@ class PassEncoder(Encoder):
     def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None):
         """pass_encoder.py:56-97: 'reconstruction cost' = sum_d tf.losses.log_loss(targets, cond_probs)."""
         from .metrics import base_metrics
-        t, p = targets.float(), cond_probs.float()
-        lp = (-t * torch.log(p + 1e-7) - (1 - t) * torch.log(1 - p + 1e-7)).sum(-1)
+        lp = reconstruction_cost(targets, cond_probs)
         return base_metrics(lp, targets, predictions, lp)
+
+
+def reconstruction_cost(targets, cond_probs):
+    """sum_d tf.losses.log_loss(targets, cond_probs) per row (epsilon 1e-7): mnn_log_loss_rows on the device."""
+    from . import ops
+    t2 = targets.reshape(-1, targets.shape[-1])
+    p2 = cond_probs.reshape(-1, cond_probs.shape[-1]).float().contiguous()
+    out = torch.empty(t2.shape[0], device=p2.device)
+    ops.log_loss_rows((t2 != 0).to(torch.uint8).contiguous(), p2, out)
+    return out.reshape(targets.shape[:-1])
 
 
 class DBNEncoder(Encoder):

@@ -21,9 +21,11 @@ class Running:
 
 
 def base_metrics(loss, targets, predictions, log_probs):
-    t = targets.reshape(predictions.shape).bool()
-    p = predictions.bool()
-    tp, fp, fn = (t & p).sum(), (~t & p).sum(), (t & ~p).sum()
+    from . import ops             # one HIP pass over the cells (mnn_eval_counts); no CPU path: ops raises without a ROCm device
+    cnt = torch.zeros(4, dtype=torch.int64, device=predictions.device)
+    ops.eval_counts((targets.reshape(predictions.shape) != 0).to(torch.uint8).contiguous(), (predictions != 0).to(torch.uint8).contiguous(), cnt)
+    tp, fp, fn, eq = (int(v) for v in cnt.tolist())
+    n_cells = predictions.numel()
     state = {k: Running() for k in ("loss", "log_likelihood", "perplexity", "accuracy", "tp", "fp", "fn")}
 
     def upd():
@@ -31,7 +33,7 @@ def base_metrics(loss, targets, predictions, log_probs):
         state["loss"].update(loss.sum(), n)
         state["log_likelihood"].update(log_probs.sum(), n)
         state["perplexity"].update(torch.exp(log_probs.double()).clamp(max=1e300).sum(), n)
-        state["accuracy"].update((t == p).sum(), t.numel())
+        state["accuracy"].update(eq, n_cells)
         state["tp"].update(tp, 1); state["fp"].update(fp, 1); state["fn"].update(fn, 1)
 
     upd()

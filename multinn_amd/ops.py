@@ -519,3 +519,20 @@ def musical_note_stats(x, threshold, onsets, qualified):
     for t in (onsets, qualified):
         _req(t.dtype == torch.int32 and t.numel() == M, "musical_note_stats: int32 [M] outputs")
     call("mnn_musical_note_stats", _stream(), _ptr(x), B, T, P, M, int(threshold), _ptr(onsets), _ptr(qualified))
+
+
+def eval_counts(targets, predictions, counts):
+    """counts int64 [4] += (tp, fp, fn, equal) over all cells of targets / predictions (u8, same shape)."""
+    _req(targets.dtype == torch.uint8 and predictions.dtype == torch.uint8 and targets.is_contiguous() and predictions.is_contiguous()
+         and targets.numel() == predictions.numel(), "eval_counts: targets / predictions u8, same size")
+    _req(counts.dtype == torch.int64 and counts.numel() == 4, "eval_counts: counts int64 [4]")
+    call("mnn_eval_counts", _stream(), _ptr(targets), _ptr(predictions), targets.numel(), _ptr(counts))
+
+
+def log_loss_rows(targets, probs, out):
+    """out[row] = sum_d tf.losses.log_loss(targets, probs) (epsilon 1e-7); targets u8 [N,D], probs f32 [N,D] (row stride >= D)."""
+    N, D = targets.shape
+    _req(targets.dtype == torch.uint8 and targets.is_contiguous(), "log_loss_rows: targets u8 [N,D]")
+    _req(probs.dtype == torch.float32 and probs.shape == (N, D) and probs.stride(1) == 1, "log_loss_rows: probs f32 [N,D]")
+    _req(out.dtype == torch.float32 and out.numel() == N and out.is_contiguous(), "log_loss_rows: out f32 [N]")
+    call("mnn_log_loss_rows", _stream(), _ptr(targets), _ptr(probs), N, D, probs.stride(0), _ptr(out))

@@ -472,3 +472,31 @@ def test_reductions_and_adam(ops):
     db = torch.ones(70, device=DEV)
     ops.bias_grad(dev(dY), db, accumulate=True)
     assert rel(db.cpu().numpy(), 1 + dY.astype(np.float64).sum(0)) < 1e-5
+
+
+def test_eval_counts_and_log_loss_rows(ops):
+    """N1: the raw sums behind tf.metrics.accuracy / precision / recall (statistical.py:28-32) and tf.losses.log_loss summed over
+    the visibles (pass_encoder.py:81-86): integer counts exact, costs to f32 rounding against float64 NumPy."""
+    rng = np.random.default_rng(5)
+    N, D = 1000, 440
+    t = (rng.random((N, D)) < 0.1).astype(np.uint8)
+    p = (rng.random((N, D)) < 0.12).astype(np.uint8)
+    cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
+    ops.eval_counts(dev(t), dev(p), cnt)
+    ops.eval_counts(dev(t), dev(p), cnt)                                           # accumulates
+    tb, pb = t.astype(bool), p.astype(bool)
+    ref = np.array([(tb & pb).sum(), (~tb & pb).sum(), (tb & ~pb).sum(), (tb == pb).sum()]) * 2
+    assert np.array_equal(cnt.cpu().numpy(), ref)
+    probs = rng.random((N, D)).astype(np.float32)
+    probs[0, :5] = [0.0, 1.0, 1e-9, 1 - 1e-7, 0.5]
+    out = torch.empty(N, device="cuda")
+    ops.log_loss_rows(dev(t), dev(probs), out)
+    pd = probs.astype(np.float64)
+    want = (-(t * np.log(pd + 1e-7)) - (1 - t) * np.log(1 - pd + 1e-7)).sum(1)
+    assert np.allclose(out.cpu().numpy(), want, rtol=2e-5, atol=1e-3)
+    from multinn_amd.metrics import base_metrics
+    loss = torch.rand(N, device="cuda")
+    m, upd, _ = base_metrics(loss, dev(t), dev(p), out)
+    assert abs(m["accuracy"] - (tb == pb).mean()) < 1e-12
+    assert abs(m["precision"] - (tb & pb).sum() / max(1, pb.sum())) < 1e-12 and abs(m["recall"] - (tb & pb).sum() / max(1, tb.sum())) < 1e-12
+    assert abs(float(m["batch/loss"]) - float(loss.mean())) < 1e-6 and abs(m["f1_score"] - m["precision"]) < 1e-12        # R5: f1 uses precision twice
