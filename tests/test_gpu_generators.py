@@ -415,6 +415,36 @@ def test_persistent_recurrence_matches_sequential(B, T, units, kp):
     assert np.allclose(la, lb, rtol=1e-3), (la, lb)
 
 
+def test_persistent_recurrence_with_initial_state():
+    """Stateful call (rnn_estimator.py:191-269 `_get_state` with an initial state): h0 is re-laid into the exchange slabs by
+    pst_fill_h0_kernel, c0 read through the pointer-selected path; against the launch-per-step kernels."""
+    from multinn_amd.generators import LstmStack
+    from multinn_amd import RnnNade
+    B, T = 70, 5
+    a = RnnNade(16, 16, [256, 128], keep_prob=1.0, precision="bf16", seed=3)
+    a._materialize(16)
+    a._ensure_packed()
+    st = a._stack
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = (torch.rand((T, B, st.ld0), device="cuda", generator=g) < 0.2).to(torch.bfloat16)
+    state = [((torch.randn((B, u), device="cuda", generator=g) * 0.5), (torch.randn((B, u), device="cuda", generator=g) * 0.5).to(torch.bfloat16).float())
+             for u in (256, 128)]                                             # [(c, h)] per layer
+    st.persistent = True
+    assert st._persist(B)
+    y1, _, f1 = st.forward(x, 1.0, save=False, state0=state)
+    st.check()
+    st.persistent = False
+    st.fused_layers = False
+    y0, _, f0 = st.forward(x, 1.0, save=False, state0=state)
+    assert float((y1.float() - y0.float()).abs().max()) < 2e-2 and float((y1.float() - y0.float()).abs().mean()) < 1e-3
+    for (c1, h1), (c0, h0) in zip(f1, f0):
+        assert float((c1 - c0).abs().max()) < 2e-2 and float((h1.float() - h0.float()).abs().max()) < 2e-2
+    # and the state matters: zero state gives a different answer
+    st.persistent = True
+    yz, _, _ = st.forward(x, 1.0, save=False, state0=None)
+    assert float((yz.float() - y1.float()).abs().max()) > 5e-2
+
+
 def test_graphed_train_step_matches_eager():
     from multinn_amd import RnnNade, AdamOptimizer
     x = make_batch(8, 6, 8, 2, 7, rho=0.2)
