@@ -17,6 +17,9 @@ def __getattr__(name):
     if name in ("NADE", "RBM", "RNN", "DBN", "Model", "ParamStore"):
         from . import common
         return getattr(common, name)
+    if name in ("DNN", "FeedbackDnn", "FeedbackRnn", "FeedbackRnnSampler", "FeedbackSampler"):
+        from . import feedback
+        return getattr(feedback, name)
     if name in ("AdamOptimizer", "GradientDescentOptimizer", "compute_gradients"):
         from . import training
         return getattr(training, name)

@@ -169,6 +169,42 @@ def fit(generator, optimizer, X_train, len_train, X_valid, len_valid, training_c
     return stats
 
 
+def pretrain_encoders(encoders, X_train, len_train, training_config, beat_size=4, lr=None, device=None, log=None):
+    """train_encoders.py:118-200: greedy layer-wise pre-training of the per-track (or joint) DBN encoders.  For every layer, for
+    `epochs` epochs, every shuffled song batch and every piece of `piece_size` beats: the encoder is built on the window of its
+    track (`x[..., i]` for track i, all tracks flattened for a single joint encoder) and `encoder.train(None, lr, layer)` runs one
+    CD-k update of that layer's RBM fed with the sampled codes of the layers below (dbn_encoder.py:192-240).
+    X_train uint8 [songs, T, P, M] (numpy).  Returns {(encoder index, layer): [mean reconstruction cost per epoch]}."""
+    import torch
+    batch_size = training_config['batch_size']
+    piece_size = int(training_config['piece_size'] * beat_size)
+    lr = training_config['learning_rate'] if lr is None else lr
+    ids = np.arange(X_train.shape[0])
+    history = {}
+    for e_i, enc in enumerate(encoders):
+        for layer in range(enc.num_layers):
+            costs = []
+            for epoch in range(1, training_config['epochs'] + 1):
+                np.random.seed(epoch)                           # train_encoders.py:134-135
+                np.random.shuffle(ids)
+                acc = LossAccumulator()
+                for w in iter_windows(ids, len_train, X_train.shape[1], batch_size, piece_size):
+                    if w is None:
+                        continue
+                    song_ids, j, max_len, _ = w
+                    xb = X_train[song_ids, j:j + max_len]
+                    xb = xb[..., e_i] if len(encoders) > 1 else xb.reshape(xb.shape[0], xb.shape[1], -1)
+                    xt = torch.from_numpy(np.ascontiguousarray(xb)).to(device or "cuda")
+                    enc.build(x=xt, is_train=True, mode="train")
+                    _, _, metrics, _, _ = enc.train(None, lr, layer=layer)
+                    acc.update(float(metrics["batch/loss"]) if metrics else 0.0)
+                costs.append(acc.loss())
+                if log is not None:
+                    log(f"[PRETRAIN] encoder {e_i} layer {layer} epoch {epoch}: reconstruction cost {costs[-1]:.4f}")
+            history[(e_i, layer)] = costs
+    return history
+
+
 def build_generator(params, P, M, precision="bf16", seed=23):
     """multinn_joint.py:41-74 for `mode: joint`, `encoder.type: Pass`, `generator.type: NADE|RBM`."""
     from .generators import RnnNade, RnnRBM

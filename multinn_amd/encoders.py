@@ -93,7 +93,17 @@ class DBNEncoder(Encoder):
         if x is not None:
             self._enc_probs, self._encodings = self.encode(x)
             self._dec_probs, self._decodings = self.decode(self._encodings)
+        self._metrics = self._metrics_upd = None             # dbn_encoder.py:98-104: built on demand (see `metrics`)
         self._is_built = True
+
+    def _ensure_metrics(self):
+        if self._metrics is None and self._inputs is not None:
+            self._metrics, self._metrics_upd, self._summaries["metrics"] = self.build_metrics(
+                targets=self._inputs, predictions=self._decodings, cond_probs=self._dec_probs)
+        return self._metrics
+
+    metrics = property(lambda self: self._ensure_metrics())
+    metrics_upd = property(lambda self: (self._ensure_metrics(), self._metrics_upd)[1])
 
     def _flat(self, x):
         return x.reshape(-1, x.shape[-1]).contiguous(), x.shape[:-1]

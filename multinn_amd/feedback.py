@@ -46,6 +46,78 @@ class FeedbackRnn(Model):
         return h.float(), [(c.clone(), hh.clone()) for c, hh in new]
 
 
+class DNN(Model):
+    """models/common/dnn.py:16-138: a stack of Dense layers with one activation (sigmoid in the reference's only use,
+    multinn_feedback.py:48-52), Xavier-uniform kernels, zero biases.  Each layer = sigmoid(x . W + b) runs as
+    `mnn_rbm_hidden` (f32, deterministic summation order: the same kernel as the RBM hidden pass)."""
+
+    def __init__(self, num_units=128, num_inputs=None, seed=23, device=None, name="dnn"):
+        super().__init__(name=name)
+        self._num_units = [num_units] if isinstance(num_units, int) else list(num_units)
+        self.store = ParamStore(device)
+        self._seed = seed
+        self._is_built = False
+        if num_inputs is not None:
+            self._materialize(num_inputs)
+
+    num_units = property(lambda self: self._num_units)
+    num_layers = property(lambda self: len(self._num_units))
+
+    def _materialize(self, num_inputs):
+        if self.store.theta is not None:
+            return
+        from .common import glorot_uniform, zeros_init
+        gen = torch.Generator().manual_seed(self._seed)
+        n_in = num_inputs
+        for l, u in enumerate(self._num_units):
+            self.store.declare(f"{self.name}/dense_{l}/kernel", (n_in, u), glorot_uniform(gen, n_in, u))
+            self.store.declare(f"{self.name}/dense_{l}/bias", (u,), zeros_init)
+            n_in = u
+        self.store.materialize()
+        self._is_built = True
+
+    def build(self, x=None, y=None, lengths=None, is_train=None, mode="eval"):
+        if x is not None:
+            self._materialize(x.shape[-1])
+        self._is_built = True
+
+    def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None):
+        return [], [], None                                  # dnn.py:96-110: a base block without metrics of its own
+
+    def __call__(self, x):
+        """x [..., n_in] (any float / u8 tensor) -> [..., units[-1]] f32."""
+        self._materialize(x.shape[-1])
+        h = x.reshape(-1, x.shape[-1]).float().contiguous()
+        for l, u in enumerate(self._num_units):
+            out = torch.empty((h.shape[0], u), device=h.device)
+            ops.rbm_hidden(h, self.store[f"{self.name}/dense_{l}/kernel"], self.store[f"{self.name}/dense_{l}/bias"].view(1, u), 0, 0, 0, 0, p_h=out)
+            h = out
+        return h.reshape(x.shape[:-1] + (self._num_units[-1],))
+
+
+class FeedbackDnn(Model):
+    """The Dense Feedback module of the Feedback MultINN (multinn_feedback.py:46-52, 103-123): a DNN over the stacked per-track
+    codes, applied to every time step independently; it carries no state (`_apply_feedback` returns zeros(1))."""
+
+    def __init__(self, num_inputs, num_units, seed=23, device=None, name="feedback"):
+        super().__init__(name=name)
+        self._dnn = DNN(num_units, num_inputs, seed=seed, device=device, name=f"{name}/dnn")
+        self.store = self._dnn.store
+        self.num_inputs, self.num_units = num_inputs, list(self._dnn.num_units)
+        self._is_built = True
+
+    def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None):
+        return [], [], None
+
+    def run(self, x, initial_state=None):
+        """_apply_feedback(single_step=False): x [B,T,Din] -> (outputs [B,T,F] f32, state placeholder)."""
+        return self._dnn(x), None
+
+    def single(self, x, state):
+        """_apply_feedback(single_step=True): x [B,Din] -> (output [B,F] f32, state placeholder)."""
+        return self._dnn(x), None
+
+
 class FeedbackRnnSampler:
     """MultINNFeedback.generate (multinn_feedback.py:120-173) with PassEncoders: M per-track generators whose
     inputs are concat(track code, feedback vector)."""
@@ -82,3 +154,6 @@ class FeedbackRnnSampler:
             for i, g in enumerate(self.generators):
                 states[i] = g.single_step(torch.cat([samples[i].float(), fb], 1), states[i])
         return out
+
+
+FeedbackSampler = FeedbackRnnSampler          # the scan is the same for both feedback modules (multinn_feedback.py:120-218)

@@ -300,6 +300,33 @@ def test_feedback_rnn_sampling_scan():
     assert torch.equal(out, FeedbackRnnSampler(gens, fb).generate(dev(x), steps))
 
 
+def test_dense_feedback_module_and_sampling_scan():
+    """N4: the Dense feedback module (models/common/dnn.py, multinn_feedback.py:46-52,103-123) -- sigmoid Dense layers over the
+    stacked codes, stateless -- against NumPy, and the feedback sampling scan run with it."""
+    from multinn_amd import DNN, FeedbackDnn, FeedbackSampler, RnnNade
+    rng = np.random.default_rng(3)
+    x = rng.random((5, 7, 24)).astype(np.float32)
+    net = DNN([16, 8], num_inputs=24, seed=4)
+    h = x.reshape(-1, 24).astype(np.float64)
+    for l in range(2):
+        W = net.store[f"dnn/dense_{l}/kernel"].cpu().numpy().astype(np.float64)
+        b = net.store[f"dnn/dense_{l}/bias"].cpu().numpy().astype(np.float64)
+        lim = np.sqrt(6.0 / sum(W.shape))
+        assert np.abs(W).max() <= lim + 1e-6 and np.abs(W).max() > 0.5 * lim and not b.any()       # Xavier-uniform kernels, zero biases
+        h = 1.0 / (1.0 + np.exp(-(h @ W + b)))
+    got = net(dev(x)).cpu().numpy()
+    assert got.shape == (5, 7, 8) and np.abs(got.reshape(-1, 8) - h).max() < 1e-5
+    P, M, B = 8, 2, 3
+    fb = FeedbackDnn(P * M, [12], seed=1)
+    out, st = fb.run(dev(rng.random((B, 4, P * M)).astype(np.float32)))
+    assert out.shape == (B, 4, 12) and st is None
+    gens = [RnnNade(P, 8, [32, 32], keep_prob=1.0, precision="fp32", seed=10 + i) for i in range(M)]
+    smp = FeedbackSampler(gens, fb)
+    intro = dev(make_batch(B, 5, P, M, 6))
+    s1 = smp.generate(intro, 3)
+    assert s1.shape == (B, 3, P, M) and s1.dtype == torch.uint8 and torch.equal(s1, smp.generate(intro, 3))
+
+
 def test_driver_fit_and_checkpoints(tmp_path):
     """A13: the train.py loop (windows, ragged lengths, best/last checkpoints) on a tiny synthetic set."""
     from multinn_amd import RnnNade, AdamOptimizer
@@ -470,3 +497,23 @@ def test_training_reduces_loss():
     opt = AdamOptimizer(0.01)
     losses = [float(gen.train_step(dev(x), None, opt)) for _ in range(40)]
     assert losses[-1] < 0.7 * losses[0], losses[::8]
+
+
+def test_encoder_pretraining_driver_lowers_reconstruction_cost():
+    """train_encoders.py:118-200 restated in driver.pretrain_encoders: greedy CD-k per layer over shuffled song windows."""
+    from multinn_amd import DBNEncoder, driver
+    R = np.random.default_rng(5)
+    S, T, P, M = 12, 16, 24, 2
+    proto = (R.random((4, P, M)) < .25)
+    X = (proto[R.integers(0, 4, (S, T))] ^ (R.random((S, T, P, M)) < .02)).astype(np.uint8)
+    lens = np.full(S, T, dtype=np.int64); lens[3] = 9
+    encs = [DBNEncoder(P, [16, 8], k=2, seed=3 + i, track_name=f"t{i}", device=torch.device(DEV)) for i in range(M)]
+    cfg = {"batch_size": 4, "piece_size": 2, "learning_rate": 0.05, "epochs": 6}
+    lines = []
+    hist = driver.pretrain_encoders(encs, X, lens, cfg, beat_size=4, device=DEV, log=lines.append)
+    assert set(hist) == {(i, l) for i in range(M) for l in range(2)} and len(lines) == M * 2 * 6
+    for i in range(M):
+        c = hist[(i, 0)]
+        assert all(np.isfinite(c)) and c[-1] < c[0], c
+        m = encs[i].metrics
+        assert {"loss", "log_likelihood", "batch/loss", "free_energy"} <= set(m)
