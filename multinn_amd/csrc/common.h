@@ -34,6 +34,51 @@ void mnn_set_error(const char* fmt, ...);
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ----------------------------------------------------------------------------------------------
+// Stream-ordered zero fills and device copies as plain kernels.  The library never calls hipMemsetAsync / hipMemcpyAsync
+// on a compute stream: their hipGraph memset nodes were observed (ROCm 7.2, gfx950) to fill with a stale 16-byte pattern
+// on the second replay of a graph once another graph had been instantiated in the process (the data-parallel step replays
+// two graphs around its all-reduce) -- the hand-off flags of the persistent recurrence then start non-zero.  A kernel node
+// carries its own arguments.  Templates so that every translation unit instantiates only what it uses (no RDC).
+// ----------------------------------------------------------------------------------------------
+template <int UNUSED>
+__global__ void __launch_bounds__(256) mnn_zero_rows_kernel(char* p, size_t row_bytes, size_t pitch, int rows) {
+    // row_bytes and pitch multiples of 4, p 4-byte aligned; 16-byte stores where the row allows
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+        char* row = p + (size_t)r * pitch;
+        const size_t head = (16 - ((uintptr_t)row & 15)) & 15;                  // bytes up to the first 16-byte boundary
+        const size_t h4 = (head < row_bytes ? head : row_bytes) / 4;
+        const size_t n16 = (row_bytes - h4 * 4) / 16, t4 = (row_bytes - h4 * 4 - n16 * 16) / 4;
+        const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+        if (tid < h4) reinterpret_cast<uint32_t*>(row)[tid] = 0u;
+        uint4* v = reinterpret_cast<uint4*>(row + h4 * 4);
+        for (size_t i = tid; i < n16; i += nth) v[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < t4) reinterpret_cast<uint32_t*>(row + h4 * 4 + n16 * 16)[tid] = 0u;
+    }
+}
+template <int UNUSED>
+__global__ void __launch_bounds__(256) mnn_copy_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// zero `rows` rows of `row_bytes` bytes, `pitch` bytes apart (rows = 1: a flat fill)
+static inline hipError_t mnn_zero_async(void* p, size_t row_bytes, size_t pitch, int rows, hipStream_t st) {
+    if (row_bytes == 0 || rows <= 0) return hipSuccess;
+    if (((uintptr_t)p & 3) || (row_bytes & 3) || (pitch & 3)) return hipErrorInvalidValue;
+    const int gx = (int)((row_bytes / 16 + 255) / 256);
+    dim3 grid(gx < 1 ? 1 : (gx > 1024 ? 1024 : gx), rows > 1024 ? 1024 : rows);
+    hipLaunchKernelGGL(mnn_zero_rows_kernel<0>, grid, dim3(256), 0, st, (char*)p, row_bytes, pitch, rows);
+    return hipGetLastError();
+}
+static inline hipError_t mnn_zero_async(void* p, size_t bytes, hipStream_t st) { return mnn_zero_async(p, bytes, bytes, 1, st); }
+static inline hipError_t mnn_copy_async(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    if (((uintptr_t)dst & 3) || ((uintptr_t)src & 3) || (bytes & 3)) return hipErrorInvalidValue;
+    const size_t n = bytes / 4;
+    const int g = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(mnn_copy_words_kernel<0>, dim3(g > 2048 ? 2048 : g), dim3(256), 0, st, (const uint32_t*)src, (uint32_t*)dst, n);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------------------
 // bf16 <-> f32 (round-to-nearest-even via the hardware cast; NaN stays NaN)
 // ----------------------------------------------------------------------------------------------
 typedef uint16_t bf16_t;

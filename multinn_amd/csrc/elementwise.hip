@@ -283,7 +283,7 @@ extern "C" int mnn_dropout_fwd(mnn_stream_t s, int dtype, const void* h, void* y
     MNN_REQUIRE(keep_prob > 0.f, "mnn_dropout_fwd: keep_prob must be > 0");
     const size_t bytes = (size_t)T * B * units * (dtype == MNN_BF16 ? 2 : 4);
     if (keep_prob >= 1.0f) {
-        if (h != y) MNN_HIP(hipMemcpyAsync(y, h, bytes, hipMemcpyDeviceToDevice, st));
+        if (h != y) MNN_HIP(mnn_copy_async(y, h, bytes, st));
         return MNN_OK;
     }
     const int blocks = (int)min((long)4096, ((long)T * B * units / 4 + 255) / 256);
@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(256) bias_grad_kernel(const float* __restrict_
 extern "C" int mnn_bias_grad(mnn_stream_t s, const float* dY, int rows, int cols, int ld, float* db, int accumulate) {
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(dY && db && rows > 0 && cols > 0 && ld >= cols, "mnn_bias_grad: bad arguments");
-    if (!accumulate) MNN_HIP(hipMemsetAsync(db, 0, (size_t)cols * 4, st));
+    if (!accumulate) MNN_HIP(mnn_zero_async(db, (size_t)cols * 4, st));
     dim3 grid(cdiv(cols, 64), min(256, cdiv(rows, 64)));
     hipLaunchKernelGGL(bias_grad_kernel, grid, dim3(256), 0, st, dY, rows, cols, ld, db);
     MNN_LAUNCH_CHECK();

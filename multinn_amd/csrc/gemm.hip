@@ -456,7 +456,7 @@ extern "C" int mnn_gemm_tn(mnn_stream_t s, int dtype, int M, int N, int K, const
     if (split_k > 1) {
         MNN_REQUIRE(c_dtype == MNN_F32, "mnn_gemm_tn: split-K needs an f32 C");
         if (!(flags & MNN_GEMM_ACCUMULATE)) {
-            MNN_HIP(hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, st));
+            MNN_HIP(mnn_zero_async(C, (size_t)N * 4, (size_t)ldc * 4, M, st));
         }
         flags |= MNN_GEMM_ATOMIC | MNN_GEMM_ACCUMULATE;
     }
@@ -1167,7 +1167,7 @@ extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int uni
                                units, t == T - 1 ? 1 : 0);
     }
     MNN_LAUNCH_CHECK();
-    if (t_begin == 0 && dc0 != nullptr) MNN_HIP(hipMemcpyAsync(dc0, dc, us * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (t_begin == 0 && dc0 != nullptr) MNN_HIP(mnn_copy_async(dc0, dc, us * sizeof(float), st));
     if (v2 && db_p != nullptr) {
         MNN_REQUIRE(dzT_t != nullptr, "mnn_lstm_seq_bwd: db_p needs dzT_t on the fused path");
         if (t_begin == 0)      // calls cover the sequence from the top down: the t_begin == 0 call is the last one

@@ -781,7 +781,7 @@ extern "C" int mnn_lstm2_persist_fwd(mnn_stream_t s, int T, int B, const mnn_lst
     a.l1.hx0 = edge; a.l2.hx0 = edge + (size_t)a.nrt * 64 * u1;
     a.l1.hx = x; a.l1.yx = x + per * 64 * u1; a.l2.hx = x + per * 128 * u1; a.l2.yx = nullptr;    // layer 2's dropped output is not handed off
     const int grid = a.G * (u1 / 32 + u2 / 32);
-    MNN_HIP(hipMemsetAsync(workspace, 0, sync_words(a.nrt) * sizeof(unsigned) + edge_bytes(a.nrt, u1, u2, false), st));
+    MNN_HIP(mnn_zero_async(workspace, sync_words(a.nrt) * sizeof(unsigned) + edge_bytes(a.nrt, u1, u2, false), st));
     if (L1->h0) hipLaunchKernelGGL(pst_fill_h0_kernel, dim3(a.nrt, u1 / 16), dim3(64), 0, st, (const bf16_t*)L1->h0, B, u1, edge);
     if (L2->h0) hipLaunchKernelGGL(pst_fill_h0_kernel, dim3(a.nrt, u2 / 16), dim3(64), 0, st, (const bf16_t*)L2->h0, B, u2, edge + (size_t)a.nrt * 64 * u1);
     hipError_t e;
@@ -828,7 +828,7 @@ extern "C" int mnn_lstm2_persist_bwd(mnn_stream_t s, int T, int B, const mnn_lst
     a.l1.dzxT = edge; a.l2.dzxT = edge + (size_t)a.nrt * 256 * u1;
     a.l1.dzx = x; a.l2.dzx = x + per * 256 * u1;
     const int grid = a.G * (u1 / 32 + u2 / 32);
-    MNN_HIP(hipMemsetAsync(workspace, 0, sync_words(a.nrt) * sizeof(unsigned) + edge_bytes(a.nrt, u1, u2, true), st));
+    MNN_HIP(mnn_zero_async(workspace, sync_words(a.nrt) * sizeof(unsigned) + edge_bytes(a.nrt, u1, u2, true), st));
     hipError_t e;
     if (u1 == 512) e = launch_pbwd<16>(st, grid, a, u2);
     else if (u1 == 256) e = launch_pbwd<8>(st, grid, a, u2);

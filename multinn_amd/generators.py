@@ -17,7 +17,7 @@ import torch
 
 from . import ops
 from .common import Model, RNN, NADE, RBM, ParamStore, glorot_uniform, zeros_init, default_device
-from .training import compute_gradients, world, AdamOptimizer
+from .training import compute_gradients, world, dp_active, AdamOptimizer
 
 _RnnEstimatorStateTuple = collections.namedtuple("RnnEstimatorStateTuple", ("b_enc", "b_dec", "rnn_state"))
 
@@ -431,7 +431,7 @@ class RnnEstimator(Generator):
             mask = (torch.arange(T, device=device)[:, None] < lengths.to(device)[None, :]).float()
             n_local = mask.sum()
         n_tot = n_local.clone()
-        if world()[1] > 1:
+        if dp_active():
             torch.distributed.all_reduce(n_tot)
         return (mask / n_tot).reshape(-1).contiguous()
 
@@ -548,7 +548,7 @@ class RnnNade(RnnEstimator):
         rw = torch.empty(T * B, device=dev)
         if lengths is not None:
             n_tot = lengths.sum().to(dev).float()
-            if world()[1] > 1:
+            if dp_active():
                 torch.distributed.all_reduce(n_tot)
             n_valid = int(n_tot)
         else:
@@ -665,7 +665,7 @@ class RnnNade(RnnEstimator):
         parallelism the ONE gradient all-reduce stays an eager torch.distributed call between two graphs
         (forward+backward | clip+Adam), so nothing of RCCL is captured.  Full-length batches only (ragged lengths
         need a host-side row count)."""
-        from .training import allreduce_flat
+        from .training import allreduce_flat, dp_active
         static_x = x_u8.clone()
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
@@ -674,7 +674,7 @@ class RnnNade(RnnEstimator):
             for _ in range(warmup):
                 self.train_step(static_x, None, optimizer, lr)
         cur.wait_stream(side)
-        multi = world()[1] > 1
+        multi = dp_active()
         g_fb, g_opt = torch.cuda.CUDAGraph(), None
         if not multi:
             with torch.cuda.graph(g_fb):

@@ -4,6 +4,8 @@
 buffer of a ParamStore, with ONE all-reduce of that buffer when torch.distributed is initialised
 (backend "nccl" is RCCL over xGMI on ROCm; "gloo" in CPU tests).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -30,9 +32,17 @@ def world():
     return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
 
 
+def dp_active():
+    """True when the step must take the data-parallel path: more than one rank, or MULTINN_DP_REHEARSAL=1 with an initialised
+    process group (a 1-rank RCCL rehearsal of exactly the N>1 code path on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("MULTINN_DP_REHEARSAL") == "1"
+
+
 def allreduce_flat(grad):
     """The single data-parallel exchange of the step: sum the flat gradient over ranks."""
-    if world()[1] > 1:
+    if dp_active():
         dist.all_reduce(grad, op=dist.ReduceOp.SUM)
     return grad
 

@@ -490,6 +490,29 @@ def test_graphed_train_step_matches_eager():
     assert torch.allclose(a.store.theta, b.store.theta, atol=2e-3)
 
 
+def test_two_graph_data_parallel_step_matches_eager(monkeypatch):
+    """The N>1 form of the captured step: forward+backward graph | (all-reduce) | clip+Adam graph, replayed back to back.
+    Regression: with hipMemsetAsync nodes the second replay of the first graph started from non-zero hand-off flags."""
+    from multinn_amd import RnnNade, AdamOptimizer
+    import multinn_amd.generators as gmod
+    monkeypatch.setattr(gmod, "dp_active", lambda: True)        # take the two-graph path without a process group
+    x = make_batch(32, 12, 8, 2, 7, rho=0.2)
+    a = RnnNade(16, 16, [128, 128], keep_prob=0.9, precision="bf16", seed=3)
+    b = RnnNade(16, 16, [128, 128], keep_prob=0.9, precision="bf16", seed=3)
+    b._materialize(16)
+    a._materialize(16)
+    b.store.theta.copy_(a.store.theta)
+    opt = AdamOptimizer(0.01)
+    run = b.graphed_train_step(dev(x), opt, warmup=2)
+    assert b._stack._persist(32)                                # the persistent recurrence is the path under test
+    la = [float(a.train_step(dev(x), None, opt)) for _ in range(7)]
+    lb = [float(run()) for _ in range(5)]
+    b._stack.check()
+    assert np.allclose(lb, la[2:], rtol=2e-3), (la, lb)
+    assert b.store.step == 7 and int(b.store.step_dev) == 7
+    assert torch.allclose(a.store.theta, b.store.theta, atol=3e-3)
+
+
 def test_training_reduces_loss():
     from multinn_amd import RnnNade, AdamOptimizer
     x = make_batch(8, 8, 8, 2, 5, rho=0.1)
