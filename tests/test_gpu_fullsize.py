@@ -174,3 +174,40 @@ def test_persistent_recurrence_is_race_free_under_load():
     torch.cuda.synchronize()
     assert g._stack._persist(B)
     g._stack.check()
+
+
+def test_two_graph_step_replays_at_full_size(monkeypatch):
+    """Data-parallel form of the captured step at C2 size: forward+backward graph | clip+Adam graph, five replays, no
+    persistent launch may give up on a spin (see test_bench_data_parallel_rehearsal_over_rccl for the failure this guards)."""
+    from multinn_amd import RnnNade, AdamOptimizer
+    import multinn_amd.generators as gmod
+    monkeypatch.setattr(gmod, "dp_active", lambda: True)
+    x = synth(B, 128, 37)
+    g = RnnNade(D, HN, UNITS, keep_prob=0.9, precision="bf16", seed=5)
+    opt = AdamOptimizer(0.01)
+    for _ in range(2):                                  # as bench.py does: eager steps on the main stream first
+        g.train_step(x, None, opt)
+    run = g.graphed_train_step(x, opt, warmup=1)
+    losses = []
+    for _ in range(5):
+        losses.append(float(run()))
+        g._stack.check()                                # also a blocking device-to-host copy between the replays, as the failing run had
+    assert all(np.isfinite(losses)) and max(losses) < 1.5 * losses[0] and min(losses) > 0.5 * losses[0], losses
+    assert g.store.step == 8 and int(g.store.step_dev) == 8
+
+
+def test_bench_data_parallel_rehearsal_over_rccl():
+    """bench.py's N>1 code path on this one GPU: torch.distributed.run with ONE rank, backend nccl (= RCCL), and
+    MULTINN_DP_REHEARSAL=1 so that the step takes the two-graph form with the eager all-reduce of the flat gradient between
+    them.  With hipMemsetAsync nodes in the graphs this run failed on the second replay (stale 16-byte fill pattern over the
+    hand-off flags -> 'persistent LSTM launch timed out'); the library now fills with its own kernels."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MULTINN_DP_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["launch"] == "hipgraph-replay" and out["value"] > 0
