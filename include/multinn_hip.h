@@ -72,6 +72,10 @@ int mnn_convert2d(mnn_stream_t s, const void* src, int src_dtype, int ld_src, vo
 int mnn_pianoroll_shift_timemajor(mnn_stream_t s, const uint8_t* x, int B, int T, int D, const int32_t* lengths,
                                   void* inputs, int in_dtype, int ld_in, uint8_t* targets, float* row_weight,
                                   long n_valid_total);
+/* Same plumbing for the bf16 train step, plus inputs_t[ld_in, ld_t >= B*T]: the transposed copy of `inputs` (feature-major,
+ * column t*B+b), the K-major operand of layer 1's weight-gradient GEMM (saves a transpose pass over `inputs`). */
+int mnn_pianoroll_shift_timemajor_t(mnn_stream_t s, const uint8_t* x, int B, int T, int D, const int32_t* lengths, void* inputs,
+                                    int ld_in, void* inputs_t, int ld_t, uint8_t* targets, float* row_weight, long n_valid_total);
 
 /* per-track variant: targets_tracks u8 [M,T,B,P] from x u8 [B,T,P,M]  (multi_encoder_nn.py:66-76) */
 int mnn_pianoroll_split_tracks(mnn_stream_t s, const uint8_t* x, int B, int T, int P, int M, uint8_t* targets_tracks);
@@ -251,6 +255,11 @@ int mnn_clip_adam_step(mnn_stream_t s, float* theta, const float* grad, float* m
 int mnn_step_increment(mnn_stream_t s, int32_t* step_dev);
 int mnn_bias_grad(mnn_stream_t s, const float* dY, int rows, int cols, int ld, float* db, int accumulate);
 int mnn_fill_f32(mnn_stream_t s, float* x, long n, float value);
+/* One pass over the f32 gradient block dY[rows, cols_c] of the dense layer (rnn_estimator.py:205-215's tf.gradients through the
+ * Dense layer): out_c = bf16 copy [rows, ld_c]; out_t = bf16 transpose of the first cols_t columns [cols_t, ld_t >= rows];
+ * db[c] += column sums for c < cols_t.  Replaces convert2d + transpose + bias_grad (three reads of dY) in bf16 mode. */
+int mnn_grad_rows_fanout(mnn_stream_t s, const float* dY, int rows, int cols_c, int cols_t, int ld, void* out_c, int ld_c, void* out_t,
+                         int ld_t, float* db);
 
 /* ------------------------------------------------------------------------------------------
  * Musical sample metrics (metrics/musical.py:45-275): integer passes over a sampled piano-roll

@@ -22,6 +22,7 @@ SIGNATURES = {
     "mnn_transpose": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _i]),
     "mnn_convert2d": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i]),
     "mnn_pianoroll_shift_timemajor": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _l]),
+    "mnn_pianoroll_shift_timemajor_t": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p, _l]),
     "mnn_pianoroll_split_tracks": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mnn_lstm_pack_weights": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "mnn_lstm_unpack_grads": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
@@ -44,6 +45,7 @@ SIGNATURES = {
     "mnn_clip_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _f, _i, _p, _i]),
     "mnn_step_increment": (_i, [_p, _p]),
     "mnn_bias_grad": (_i, [_p, _p, _i, _i, _i, _p, _i]),
+    "mnn_grad_rows_fanout": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
     "mnn_fill_f32": (_i, [_p, _p, _l, _f]),
 }
 

@@ -138,6 +138,98 @@ extern "C" int mnn_pianoroll_shift_timemajor(mnn_stream_t s, const uint8_t* x, i
     return MNN_OK;
 }
 
+// Tiled form for the bf16 train step: 64 (t, b) rows x 64 features per workgroup, 8-byte loads of the piano-roll, 16-byte
+// stores of the shifted inputs, and ALSO the transposed copy inputs_t[feature][t B + b] (the K-major operand of layer 1's
+// weight-gradient GEMM) through an LDS tile -- instead of a second pass (mnn_transpose) over the 29 MB of inputs.
+__global__ void __launch_bounds__(256)
+pianoroll_shift_tiled_kernel(const uint8_t* __restrict__ x, int B, int Tn, int D, const int32_t* __restrict__ lengths,
+                             bf16_t* __restrict__ inputs, int ld_in, bf16_t* __restrict__ inputs_t, int ld_t,
+                             uint8_t* __restrict__ targets, float* __restrict__ row_weight, float inv_n) {
+    __shared__ bf16_t tile[64][66];
+    const int N = B * Tn;
+    const int n0 = blockIdx.y * 64, f0 = blockIdx.x * 64;
+    const int fq = threadIdx.x & 7, f = f0 + 8 * fq;
+    const bool vec = (D & 7) == 0;                       // 8-byte source loads / target stores stay aligned
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int rr = (threadIdx.x >> 3) + 32 * k, n = n0 + rr;
+        uint8_t pv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (n < N && f < D) {
+            const int t = n / B, b = n - t * B;
+            const uint8_t* cur = x + ((size_t)b * Tn + t) * D + f;
+            if (vec) {                                   // f + 8 <= D because D and f are multiples of 8
+                *reinterpret_cast<uint2*>(cv) = *reinterpret_cast<const uint2*>(cur);
+                if (t > 0) *reinterpret_cast<uint2*>(pv) = *reinterpret_cast<const uint2*>(cur - D);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (f + e < D) { cv[e] = cur[e]; pv[e] = t > 0 ? cur[e - D] : (uint8_t)0; }
+            }
+        }
+        bf16_t o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = f32_to_bf16((float)pv[e]);              // 0..255 are exact in bf16
+            tile[rr][8 * fq + e] = o[e];
+        }
+        if (n < N) {
+            if (f + 8 <= ld_in) {
+                uint4 q;
+                q.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16); q.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+                q.z = (uint32_t)o[4] | ((uint32_t)o[5] << 16); q.w = (uint32_t)o[6] | ((uint32_t)o[7] << 16);
+                *reinterpret_cast<uint4*>(inputs + (size_t)n * ld_in + f) = q;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (f + e < ld_in) inputs[(size_t)n * ld_in + f + e] = o[e];
+            }
+            if (targets != nullptr && f < D) {
+                if (vec) *reinterpret_cast<uint2*>(targets + (size_t)n * D + f) = *reinterpret_cast<uint2*>(cv);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (f + e < D) targets[(size_t)n * D + f + e] = cv[e];
+                }
+            }
+            if (row_weight != nullptr && blockIdx.x == 0 && fq == 0) {
+                const int t = n / B, b = n - t * B;
+                row_weight[n] = (lengths == nullptr || t < lengths[b]) ? inv_n : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const int tc = threadIdx.x >> 2, rq = threadIdx.x & 3;
+    if (f0 + tc < ld_in) {
+        bf16_t* dst = inputs_t + (size_t)(f0 + tc) * ld_t + n0 + 16 * rq;
+        if (n0 + 16 * rq + 15 < N) {
+            uint32_t w[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = (uint32_t)tile[16 * rq + 2 * e][tc] | ((uint32_t)tile[16 * rq + 2 * e + 1][tc] << 16);
+            reinterpret_cast<uint4*>(dst)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            reinterpret_cast<uint4*>(dst)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (n0 + 16 * rq + e < N) dst[e] = tile[16 * rq + e][tc];
+        }
+    }
+}
+
+extern "C" int mnn_pianoroll_shift_timemajor_t(mnn_stream_t s, const uint8_t* x, int B, int T, int D, const int32_t* lengths, void* inputs,
+                                               int ld_in, void* inputs_t, int ld_t, uint8_t* targets, float* row_weight, long n_valid_total) {
+    MNN_REQUIRE(x && inputs && inputs_t && B > 0 && T > 0 && D > 0 && ld_in >= D, "mnn_pianoroll_shift_timemajor_t: bad arguments");
+    MNN_REQUIRE(ld_in % 8 == 0 && ld_t % 8 == 0 && ld_t >= B * T, "mnn_pianoroll_shift_timemajor_t: ld_in, ld_t must be multiples of 8, ld_t >= B*T");
+    MNN_REQUIRE(((uintptr_t)inputs & 15) == 0 && ((uintptr_t)inputs_t & 15) == 0 && ((uintptr_t)x & 7) == 0 && (targets == nullptr || ((uintptr_t)targets & 7) == 0),
+                "mnn_pianoroll_shift_timemajor_t: misaligned buffer");
+    MNN_REQUIRE(lengths == nullptr || n_valid_total > 0, "mnn_pianoroll_shift_timemajor_t: n_valid_total required with lengths");
+    const float inv_n = 1.0f / (float)(n_valid_total > 0 ? n_valid_total : (long)B * T);
+    dim3 grid(cdiv(ld_in, 64), cdiv((long)B * T, 64));
+    hipLaunchKernelGGL(pianoroll_shift_tiled_kernel, grid, dim3(256), 0, (hipStream_t)s, x, B, T, D, lengths, (bf16_t*)inputs, ld_in,
+                       (bf16_t*)inputs_t, ld_t, targets, row_weight, inv_n);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
 __global__ void __launch_bounds__(128) split_tracks_kernel(const uint8_t* __restrict__ x, int B, int Tn, int P, int M, uint8_t* __restrict__ out) {
     const int t = blockIdx.x / B, b = blockIdx.x % B;
     const uint8_t* src = x + ((size_t)b * Tn + t) * P * M;
@@ -453,6 +545,99 @@ extern "C" int mnn_bias_grad(mnn_stream_t s, const float* dY, int rows, int cols
     if (!accumulate) MNN_HIP(mnn_zero_async(db, (size_t)cols * 4, st));
     dim3 grid(cdiv(cols, 64), min(256, cdiv(rows, 64)));
     hipLaunchKernelGGL(bias_grad_kernel, grid, dim3(256), 0, st, dY, rows, cols, ld, db);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+// One pass over an f32 gradient block dY[rows, cols_c] that feeds three consumers (generators.py backward of the dense layer):
+//   out_c[r, c]  = bf16(dY[r, c])            c < cols_c   (A operand of the data-gradient GEMM)
+//   out_t[c, r]  = bf16(dY[r, c])            c < cols_t   (B operand of the weight-gradient GEMM, K-major)
+//   db[c]       += sum_r dY[r, c]            c < cols_t   (bias gradient)
+// instead of mnn_convert2d + mnn_transpose + mnn_bias_grad, each of which re-read the f32 block.
+// 64 x 64 tiles, 256 threads: thread (ty = tid / 16, tx = tid % 16) loads float4 at rows ty + 16 k, columns 4 tx.
+__global__ void __launch_bounds__(256)
+grad_rows_fanout_kernel(const float* __restrict__ dY, int rows, int cols_c, int cols_t, int ld, bf16_t* __restrict__ out_c, int ld_c,
+                        bf16_t* __restrict__ out_t, int ld_t, float* __restrict__ db) {
+    __shared__ bf16_t tile[64][66];
+    __shared__ float part[16][64];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c0 = blockIdx.x * 64;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = blockIdx.y * 64; r0 < rows; r0 += gridDim.y * 64) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ty + 16 * k, c = c0 + 4 * tx;
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            if (r < rows) {
+                if (c + 3 < cols_c && (ld & 3) == 0) {
+                    const float4 q = *reinterpret_cast<const float4*>(dY + (size_t)r * ld + c);
+                    x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < cols_c) x[e] = dY[(size_t)r * ld + c + e];
+                }
+            }
+            bf16_t b[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                b[e] = f32_to_bf16(x[e]);
+                acc[e] += x[e];
+                tile[ty + 16 * k][4 * tx + e] = b[e];
+            }
+            if (r < rows) {
+                if (c + 3 < cols_c && (ld_c & 3) == 0) {
+                    uint2 pk;
+                    pk.x = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
+                    pk.y = (uint32_t)b[2] | ((uint32_t)b[3] << 16);
+                    *reinterpret_cast<uint2*>(out_c + (size_t)r * ld_c + c) = pk;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < cols_c) out_c[(size_t)r * ld_c + c + e] = b[e];
+                }
+            }
+        }
+        __syncthreads();
+        {   // transposed copy: thread (column tc, row quarter rq) writes 16 consecutive rows of its column
+            const int tc = threadIdx.x >> 2, rq = threadIdx.x & 3;
+            const int c = c0 + tc;
+            if (c < cols_t) {
+                bf16_t* dst = out_t + (size_t)c * ld_t + r0 + 16 * rq;
+                if (r0 + 16 * rq + 15 < rows && (ld_t & 7) == 0) {
+                    uint32_t w[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] = (uint32_t)tile[16 * rq + 2 * e][tc] | ((uint32_t)tile[16 * rq + 2 * e + 1][tc] << 16);
+                    reinterpret_cast<uint4*>(dst)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+                    reinterpret_cast<uint4*>(dst)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (r0 + 16 * rq + e < rows) dst[e] = tile[16 * rq + e][tc];
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[ty][4 * tx + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64 && c0 + threadIdx.x < cols_t) {
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum += part[k][threadIdx.x];
+        atomicAdd(db + c0 + threadIdx.x, sum);
+    }
+}
+
+extern "C" int mnn_grad_rows_fanout(mnn_stream_t s, const float* dY, int rows, int cols_c, int cols_t, int ld, void* out_c, int ld_c,
+                                    void* out_t, int ld_t, float* db) {
+    MNN_REQUIRE(dY && out_c && out_t && db && rows > 0 && cols_c > 0 && cols_t > 0 && cols_t <= cols_c, "mnn_grad_rows_fanout: bad arguments");
+    MNN_REQUIRE(ld >= cols_c && ld_c >= cols_c && ld_t >= rows, "mnn_grad_rows_fanout: leading dimension too small");
+    MNN_REQUIRE(((uintptr_t)dY & 15) == 0 && ((uintptr_t)out_c & 7) == 0 && ((uintptr_t)out_t & 15) == 0, "mnn_grad_rows_fanout: misaligned buffer");
+    dim3 grid(cdiv(cols_c, 64), min(256, cdiv(rows, 64)));
+    hipLaunchKernelGGL(grad_rows_fanout_kernel, grid, dim3(256), 0, (hipStream_t)s, dY, rows, cols_c, cols_t, ld, (bf16_t*)out_c, ld_c,
+                       (bf16_t*)out_t, ld_t, db);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

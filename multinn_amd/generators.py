@@ -553,16 +553,22 @@ class RnnNade(RnnEstimator):
             n_valid = int(n_tot)
         else:
             n_valid = B * T * world()[1]
-        ops.pianoroll_shift_timemajor(x_u8.view(B, T, D), lengths, x_tm, v, rw, n_valid)
-        self._forward_tm(x_tm, v.view(1, T, B, D), rw, lengths, B, T, train=(mode == "train"))
+        x_tmT = None
+        if mode == "train" and self.dtype == torch.bfloat16:       # the same pass also writes x^T, layer 1's weight-gradient operand
+            Np = ops.round_up(T * B, 64)
+            x_tmT = (torch.zeros if Np != T * B else torch.empty)((self._stack.ld0, Np), device=dev, dtype=self.dtype)
+        ops.pianoroll_shift_timemajor(x_u8.view(B, T, D), lengths, x_tm, v, rw, n_valid, inputs_t=x_tmT)
+        self._forward_tm(x_tm, v.view(1, T, B, D), rw, lengths, B, T, train=(mode == "train"), x_tmT=x_tmT)
         self._is_built = True
 
-    def _forward_tm(self, x_tm, v, rw, lengths, B, T, train):
+    def _forward_tm(self, x_tm, v, rw, lengths, B, T, train, x_tmT=None):
         M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
         N, dev = T * B, x_tm.device
         self._ensure_packed()
         kp = self._rnn.effective_keep_prob()
         y, ctx, _ = self._stack.forward(x_tm, kp, self.seed, self.row0, save=train, step_dev=self.store.step_dev)
+        if ctx and x_tmT is not None:
+            ctx[0]["inT"] = x_tmT
         out = torch.empty((N, self.ldo), device=dev)
         if self.ldo != self.n_out:
             out[:, self.n_out:].zero_()
@@ -639,15 +645,15 @@ class RnnNade(RnnEstimator):
             yT = zalloc((R, Np), device=dev, dtype=self.dtype)
             ops.transpose(cx["y"].view(N, R), yT)
         doT = zalloc((self.n_out, Np), device=dev, dtype=self.dtype)
-        ops.transpose(d_out[:, :self.n_out], doT)
+        if self.dtype == torch.float32:
+            ops.transpose(d_out[:, :self.n_out], doT)
+            ops.bias_grad(d_out[:, :self.n_out], g["dense/bias"], accumulate=True)
+            do_c = d_out
+        else:                               # one pass over d_out: bf16 copy, bf16 transpose, bias gradient
+            do_c = torch.empty((N, self.ldo), device=dev, dtype=self.dtype)
+            ops.grad_rows_fanout(d_out, self.n_out, do_c, doT, g["dense/bias"])
         ops.gemm_tn(yT, doT, g["dense/kernel"], accumulate=True, split_k=LstmStack._split_k(R, self.n_out, Np))
         del yT, doT
-        ops.bias_grad(d_out[:, :self.n_out], g["dense/bias"], accumulate=True)
-        if self.dtype == torch.float32:
-            do_c = d_out
-        else:
-            do_c = torch.empty((N, self.ldo), device=dev, dtype=self.dtype)
-            ops.convert2d(d_out, do_c)
         dy = torch.empty((N, R), device=dev)
         ops.gemm_tn(do_c, self._fc_p, dy)
         self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], cx["seed"], self.row0, step_dev=self.store.step_dev)

@@ -81,8 +81,9 @@ def convert2d(src, dst):
     return dst
 
 
-def pianoroll_shift_timemajor(x, lengths, inputs, targets, row_weight, n_valid_total=0):
-    """x u8 [B,T,D] -> inputs [T,B,ld] (shifted, zero first step), targets u8 [T,B,D], row_weight f32 [T*B]."""
+def pianoroll_shift_timemajor(x, lengths, inputs, targets, row_weight, n_valid_total=0, inputs_t=None):
+    """x u8 [B,T,D] -> inputs [T,B,ld] (shifted, zero first step), targets u8 [T,B,D], row_weight f32 [T*B];
+    inputs_t (bf16 [ld, >= T*B], optional): the transposed copy of inputs, written by the same pass."""
     _req(x.dtype == torch.uint8 and x.dim() == 3 and x.is_contiguous(), "pianoroll: x must be contiguous u8 [B,T,D]")
     B, T, D = x.shape
     _req(inputs.dim() == 3 and inputs.shape[0] == T and inputs.shape[1] == B and inputs.shape[2] >= D and inputs.is_contiguous(),
@@ -94,6 +95,12 @@ def pianoroll_shift_timemajor(x, lengths, inputs, targets, row_weight, n_valid_t
     if lengths is not None:
         _req(lengths.dtype == torch.int32 and lengths.numel() == B, "pianoroll: lengths int32 [B]")
         _req(n_valid_total > 0, "pianoroll: n_valid_total required with lengths")
+    if inputs_t is not None:
+        _req(inputs.dtype == torch.bfloat16 and inputs_t.dtype == torch.bfloat16 and inputs_t.dim() == 2 and inputs_t.stride(1) == 1
+             and inputs_t.shape[0] == inputs.shape[2] and inputs_t.shape[1] >= T * B, "pianoroll: inputs_t must be bf16 [ld, >=T*B]")
+        call("mnn_pianoroll_shift_timemajor_t", _stream(), _ptr(x), B, T, D, _ptr(lengths), _ptr(inputs), inputs.shape[2], _ptr(inputs_t),
+             inputs_t.stride(0), _ptr(targets), _ptr(row_weight), int(n_valid_total))
+        return
     call("mnn_pianoroll_shift_timemajor", _stream(), _ptr(x), B, T, D, _ptr(lengths), _ptr(inputs), dtype_code(inputs), inputs.shape[2],
          _ptr(targets), _ptr(row_weight), int(n_valid_total))
 
@@ -492,6 +499,18 @@ def bias_grad(dY, db, accumulate=False):
     _rowmajor(dY, "bias_grad dY")
     _req(dY.dtype == torch.float32 and db.dtype == torch.float32 and db.numel() == dY.shape[1] and db.is_contiguous(), "bias_grad: shapes")
     call("mnn_bias_grad", _stream(), _ptr(dY), dY.shape[0], dY.shape[1], dY.stride(0), _ptr(db), int(accumulate))
+
+
+def grad_rows_fanout(dY, cols_t, out_c, out_t, db):
+    """One pass over dY f32 [rows, cols_c]: out_c = bf16 copy, out_t[:cols_t, :rows] = bf16 transpose, db[:cols_t] += column sums."""
+    _rowmajor(dY, "fanout dY"); _rowmajor(out_c, "fanout out_c"); _rowmajor(out_t, "fanout out_t")
+    rows, cols_c = dY.shape
+    _req(dY.dtype == torch.float32 and out_c.dtype == torch.bfloat16 and out_t.dtype == torch.bfloat16 and db.dtype == torch.float32,
+         "fanout: dY/db f32, outputs bf16")
+    _req(out_c.shape == dY.shape and out_t.shape[0] == cols_t and out_t.shape[1] >= rows and 0 < cols_t <= cols_c and db.numel() == cols_t
+         and db.is_contiguous(), "fanout: shapes")
+    call("mnn_grad_rows_fanout", _stream(), _ptr(dY), rows, cols_c, cols_t, dY.stride(0), _ptr(out_c), out_c.stride(0), _ptr(out_t),
+         out_t.stride(0), _ptr(db))
 
 
 def fill(x, value):

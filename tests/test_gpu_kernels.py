@@ -113,6 +113,51 @@ def test_pianoroll_shift(ops, ragged):
     assert np.array_equal(out.cpu().numpy(), x.transpose(3, 1, 0, 2))
 
 
+@pytest.mark.parametrize("shape", [(5, 7, 6, 3, 24), (16, 9, 8, 5, 40), (3, 50, 11, 2, 24)])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_pianoroll_shift_with_transposed_copy(ops, shape, ragged):
+    """The tiled bf16 form (mnn_pianoroll_shift_timemajor_t) against the oracle's joint_inputs: inputs, inputs^T, targets, row weights
+    (D a multiple of 8 -> 8-byte loads, and not -> byte loads; row counts that are not multiples of 64; velocities > 1 stay exact)."""
+    B, T, P, M, ld = shape
+    R = np.random.default_rng(4)
+    x = ((R.random((B, T, P, M)) < .3) * R.integers(1, 128, (B, T, P, M))).astype(np.uint8)
+    D = P * M
+    inp_ref, tgt_ref = G.joint_inputs(x.astype(np.float32))
+    lengths = R.integers(1, T + 1, B).astype(np.int32) if ragged else None
+    N, Np = T * B, ops.round_up(T * B, 64)
+    inputs = torch.full((T, B, ld), 9.0, device=DEV, dtype=torch.bfloat16)
+    inputs_t = torch.zeros((ld, Np), device=DEV, dtype=torch.bfloat16)
+    targets = torch.zeros((T, B, D), device=DEV, dtype=torch.uint8)
+    rw = torch.zeros(N, device=DEV)
+    ops.pianoroll_shift_timemajor(dev(x.reshape(B, T, D)), None if lengths is None else dev(lengths), inputs, targets, rw,
+                                  int(lengths.sum()) if ragged else 0, inputs_t=inputs_t)
+    got = inputs.float().cpu().numpy()
+    assert np.array_equal(got[:, :, :D], inp_ref.transpose(1, 0, 2)) and float(np.abs(got[:, :, D:]).max(initial=0)) == 0
+    assert np.array_equal(inputs_t.float().cpu().numpy()[:, :N], got.reshape(N, ld).T)
+    assert float(inputs_t[:, N:].abs().max()) == 0 if Np > N else True
+    assert np.array_equal(targets.cpu().numpy(), tgt_ref.transpose(1, 0, 2).astype(np.uint8))
+    m = S.sequence_mask(lengths, T) if ragged else np.ones((B, T), bool)
+    assert np.allclose(rw.cpu().numpy().reshape(T, B), m.T / m.sum())
+
+
+@pytest.mark.parametrize("shape", [(48, 40, 33, 40), (200, 704, 696, 704), (64, 64, 64, 64), (130, 24, 17, 28)])
+def test_grad_rows_fanout(ops, shape):
+    """mnn_grad_rows_fanout = bf16 copy + bf16 transpose + column sums of an f32 gradient block in one pass."""
+    rows, cols_c, cols_t, ld = shape
+    R = np.random.default_rng(6)
+    full = torch.from_numpy(R.standard_normal((rows, ld)).astype(np.float32)).to(DEV)
+    dY = full[:, :cols_c]
+    Np = ops.round_up(rows, 64)
+    out_c = torch.full((rows, cols_c), 7.0, device=DEV, dtype=torch.bfloat16)
+    out_t = torch.zeros((cols_t, Np), device=DEV, dtype=torch.bfloat16)
+    db = torch.full((cols_t,), 0.5, device=DEV)
+    ops.grad_rows_fanout(dY, cols_t, out_c, out_t, db)
+    ref = dY.to(torch.bfloat16)
+    assert torch.equal(out_c, ref)
+    assert torch.equal(out_t[:, :rows], ref[:, :cols_t].t()) and float(out_t[:, rows:].abs().max()) == 0 if Np > rows else True
+    assert torch.allclose(db, 0.5 + dY[:, :cols_t].double().sum(0).float(), atol=1e-4, rtol=1e-5)
+
+
 # ------------------------------------------------------------------------------------------------
 def _lstm_setup(ops, B, T, n_in, u, dt, seed=3):
     R = np.random.default_rng(seed)
