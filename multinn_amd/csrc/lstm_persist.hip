@@ -71,7 +71,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // Wave 0 polls one 128-byte line of progress flags: lanes [0,n1) need >= need1, lanes [n1,nm) need >= need2, the rest
 // watch the status word.  All threads of the workgroup call this; returns false (uniformly) when the launch is aborting.
-__device__ __forceinline__ bool pst_wait(const unsigned* line, unsigned* status, int n1, unsigned need1, int nm, unsigned need2, int* s_abort) {
+__device__ __forceinline__ bool pst_wait(const unsigned* line, unsigned* status, int n1, unsigned need1, int nm, unsigned need2, int* s_abort,
+                                         int sticky_off) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         const bool mine = lane < nm;
@@ -83,7 +84,7 @@ __device__ __forceinline__ bool pst_wait(const unsigned* line, unsigned* status,
             if (__all(mine ? v >= need : v == 0u)) break;
             const bool dead = __any(!mine && v != 0u) || ((spins & 127u) == 0u && wall_clock64() - t0 > PST_LIMIT);
             if (dead) {
-                if (lane == 0) { st_agent(status, 1u); *s_abort = 1; }
+                if (lane == 0) { st_agent(status, 1u); st_agent(status + sticky_off, 1u); *s_abort = 1; }   // sticky: survives the next launch's re-zeroing
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -105,11 +106,11 @@ __device__ __forceinline__ void pst_publish(unsigned* flag, unsigned value, bool
 
 // Launch start: do the nm workgroups of this row-tile group share an XCD?  Each posts 0x100 | XCC_ID (device scope), waits for
 // the others (bounded) and compares.  The answer only selects the store policy of the hand-offs; results never depend on it.
-__device__ __forceinline__ bool pst_same_xcd(unsigned* xline, unsigned* status, int member, int nm, int* s_abort, int* s_local) {
+__device__ __forceinline__ bool pst_same_xcd(unsigned* xline, unsigned* status, int member, int nm, int* s_abort, int* s_local, int sticky_off) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     if (threadIdx.x == 0) st_agent(xline + member, 0x100u | (xcc & 0xfu));
-    if (!pst_wait(xline, status, nm, 1u, nm, 1u, s_abort)) return false;
+    if (!pst_wait(xline, status, nm, 1u, nm, 1u, s_abort, sticky_off)) return false;
     if (threadIdx.x < 64) {
         const unsigned v = ld_agent(xline + (threadIdx.x < (unsigned)nm ? threadIdx.x : 0));
         const unsigned v0 = __builtin_amdgcn_readfirstlane(v);
@@ -128,7 +129,7 @@ struct PFwdLayer {
     char* hx; char* yx;            // exchange copies of h[t] (and of the dropped output y[t]), A-fragment order, slab (t, row tile)
     const char* hx0;               // slabs of the initial state h[-1] (zeros, or h0 re-laid by pst_fill_h0_kernel), one per row tile
 };
-struct PFwdArgs { PFwdLayer l1, l2; int T, B, nrt, G, R; float kp; unsigned* sync; int xcc_off, allow_local; };
+struct PFwdArgs { PFwdLayer l1, l2; int T, B, nrt, G, R; float kp; unsigned* sync; int xcc_off, allow_local, sticky_off; };
 
 struct FwdTiles {
     float red[4][4][16][64];       // K-split partial tiles
@@ -247,7 +248,7 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
     const float* zero = reinterpret_cast<const float*>(A.sync + 4);
     if (threadIdx.x == 0) { S.abort = 0; S.local = 0; }
     __syncthreads();
-    if (!pst_same_xcd(A.sync + A.xcc_off + grp * 32, status, member, nm, &S.abort, &S.local)) return;
+    if (!pst_same_xcd(A.sync + A.xcc_off + grp * 32, status, member, nm, &S.abort, &S.local, A.sticky_off)) return;
     const bool local = A.allow_local && S.local != 0;
     FwdTail tl;
     tl.valid = false;
@@ -280,7 +281,7 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             const int t = i / Rv, rt = grp + A.G * (i - t * Rv), m0 = rt * 32;
             long long* trc = PST_TRP(0, member == 0 && rt == 0, t);
             PST_TR(trc, 0);
-            if (t > 0 && !pst_wait(flags + rt * 32, status, nb1, (unsigned)t, nb1, 0u, &S.abort)) return;
+            if (t > 0 && !pst_wait(flags + rt * 32, status, nb1, (unsigned)t, nb1, 0u, &S.abort, A.sticky_off)) return;
             PST_TR(trc, 1);
             bf16x8_t a[KS1];
             load_frags_xchg<KS1>(t > 0 ? L.hx + ((size_t)(t - 1) * nrt + rt) * slab : L.hx0 + (size_t)rt * slab, slab, w * KS1, a);
@@ -354,7 +355,7 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             const int t = i / Rv, rt = grp + A.G * (i - t * Rv), m0 = rt * 32;
             long long* trc = PST_TRP(1, member == nb1 && rt == 0, t);
             PST_TR(trc, 0);
-            if (!pst_wait(flags + rt * 32, status, nb1, (unsigned)(t + 1), nm, (unsigned)t, &S.abort)) return;
+            if (!pst_wait(flags + rt * 32, status, nb1, (unsigned)(t + 1), nm, (unsigned)t, &S.abort, A.sticky_off)) return;
             PST_TR(trc, 1);
             bf16x8_t a1[KS1], a2[KS2];
             load_frags_xchg<KS1>(y1x + ((size_t)t * nrt + rt) * slab1, slab1, w * KS1, a1);
@@ -428,7 +429,7 @@ struct PBwdLayer {
     char* dzx;                     // exchange copy of dz[t], A-fragment order, slab (t, row tile)
     const char* dzxT;              // zero slabs standing for dz[T], one per row tile
 };
-struct PBwdArgs { PBwdLayer l1, l2; int T, B, nrt, G, R; float kp; unsigned* sync; int xcc_off, allow_local; };
+struct PBwdArgs { PBwdLayer l1, l2; int T, B, nrt, G, R; float kp; unsigned* sync; int xcc_off, allow_local, sticky_off; };
 
 struct BwdTiles {
     float red[2][8][16][64];
@@ -550,7 +551,7 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
     const float* zero = reinterpret_cast<const float*>(A.sync + 4);
     if (threadIdx.x == 0) { S.abort = 0; S.local = 0; }
     __syncthreads();
-    if (!pst_same_xcd(A.sync + A.xcc_off + grp * 32, status, member, nm, &S.abort, &S.local)) return;
+    if (!pst_same_xcd(A.sync + A.xcc_off + grp * 32, status, member, nm, &S.abort, &S.local, A.sticky_off)) return;
     const bool local = A.allow_local && S.local != 0;
     BwdTail tl;
     tl.valid = false;
@@ -570,7 +571,7 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
             const int k = i / Rv, t = T - 1 - k, rt = grp + A.G * (i - k * Rv), m0 = rt * 32;
             long long* trc = PST_TRP(2, member == 0 && rt == 0, k);
             PST_TR(trc, 0);
-            if (k > 0 && !pst_wait(flags + rt * 32, status, nb2, (unsigned)k, nb2, 0u, &S.abort)) return;
+            if (k > 0 && !pst_wait(flags + rt * 32, status, nb2, (unsigned)k, nb2, 0u, &S.abort, A.sticky_off)) return;
             PST_TR(trc, 1);
             bf16x8_t a[KB];
             load_frags_xchg<KB>(k > 0 ? L.dzx + ((size_t)(t + 1) * nrt + rt) * slab : L.dzxT + (size_t)rt * slab, slab, w * KB, a);
@@ -626,7 +627,7 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
             const int k = i / Rv, t = T - 1 - k, rt = grp + A.G * (i - k * Rv), m0 = rt * 32;
             long long* trc = PST_TRP(3, member == nb2 && rt == 0, k);
             PST_TR(trc, 0);
-            if (!pst_wait(flags + rt * 32, status, nb2, (unsigned)(k + 1), nm, (unsigned)k, &S.abort)) return;
+            if (!pst_wait(flags + rt * 32, status, nb2, (unsigned)(k + 1), nm, (unsigned)k, &S.abort, A.sticky_off)) return;
             PST_TR(trc, 1);
             bf16x8_t aq[KB], aw[KA];
             load_frags_xchg<KB>(L2.dzx + ((size_t)t * nrt + rt) * slab2, slab2, w * KB, aq);
@@ -671,9 +672,8 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
     }
 }
 
-__global__ void pst_sticky_kernel(unsigned* sync, int sticky_off) {
-    if (sync[0] != 0u) sync[sticky_off] = sync[0];
-}
+// Test hook (MNN_PERSIST_TEST_ABORT): raise the status word before the launch, so that every workgroup takes the give-up path.
+__global__ void pst_poison_kernel(unsigned* sync) { sync[0] = 1u; }
 
 // ---------------------------------------------------------------------------------------------- host side
 static bool units_ok(int u) { return u == 128 || u == 256 || u == 512; }
@@ -775,6 +775,7 @@ extern "C" int mnn_lstm2_persist_fwd(mnn_stream_t s, int T, int B, const mnn_lst
     a.l1 = fwd_layer(L1); a.l2 = fwd_layer(L2);
     a.T = T; a.B = B; a.kp = keep_prob; a.sync = (unsigned*)workspace;
     a.xcc_off = PST_FLAGS_OFF + 32 * a.nrt; a.allow_local = getenv("MNN_PERSIST_NO_LOCAL") == nullptr;
+    a.sticky_off = (int)(sticky_offset(a.nrt, L1->units, L2->units) / sizeof(unsigned));   // the aborting workgroup sets it; never re-zeroed
     const size_t per = (size_t)T * a.nrt;
     char* edge = (char*)workspace + sync_words(a.nrt) * sizeof(unsigned);
     char* x = (char*)workspace + xchg_offset(a.nrt, u1, u2);
@@ -782,6 +783,7 @@ extern "C" int mnn_lstm2_persist_fwd(mnn_stream_t s, int T, int B, const mnn_lst
     a.l1.hx = x; a.l1.yx = x + per * 64 * u1; a.l2.hx = x + per * 128 * u1; a.l2.yx = nullptr;    // layer 2's dropped output is not handed off
     const int grid = a.G * (u1 / 32 + u2 / 32);
     MNN_HIP(mnn_zero_async(workspace, sync_words(a.nrt) * sizeof(unsigned) + edge_bytes(a.nrt, u1, u2, false), st));
+    if (getenv("MNN_PERSIST_TEST_ABORT")) hipLaunchKernelGGL(pst_poison_kernel, dim3(1), dim3(1), 0, st, (unsigned*)workspace);   // tests: exercise the give-up path
     if (L1->h0) hipLaunchKernelGGL(pst_fill_h0_kernel, dim3(a.nrt, u1 / 16), dim3(64), 0, st, (const bf16_t*)L1->h0, B, u1, edge);
     if (L2->h0) hipLaunchKernelGGL(pst_fill_h0_kernel, dim3(a.nrt, u2 / 16), dim3(64), 0, st, (const bf16_t*)L2->h0, B, u2, edge + (size_t)a.nrt * 64 * u1);
     hipError_t e;
@@ -789,7 +791,6 @@ extern "C" int mnn_lstm2_persist_fwd(mnn_stream_t s, int T, int B, const mnn_lst
     else if (u1 == 256) e = launch_pfwd<4>(st, grid, a, u2);
     else e = launch_pfwd<2>(st, grid, a, u2);
     MNN_HIP(e);
-    hipLaunchKernelGGL(pst_sticky_kernel, dim3(1), dim3(1), 0, st, (unsigned*)workspace, (int)(sticky_offset(a.nrt, u1, u2) / sizeof(unsigned)));
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
@@ -822,6 +823,7 @@ extern "C" int mnn_lstm2_persist_bwd(mnn_stream_t s, int T, int B, const mnn_lst
     a.l1 = bwd_layer(L1); a.l2 = bwd_layer(L2);
     a.T = T; a.B = B; a.kp = keep_prob; a.sync = (unsigned*)workspace;
     a.xcc_off = PST_FLAGS_OFF + 32 * a.nrt; a.allow_local = getenv("MNN_PERSIST_NO_LOCAL") == nullptr;
+    a.sticky_off = (int)(sticky_offset(a.nrt, L1->units, L2->units) / sizeof(unsigned));   // the aborting workgroup sets it; never re-zeroed
     const size_t per = (size_t)T * a.nrt;
     char* edge = (char*)workspace + sync_words(a.nrt) * sizeof(unsigned);
     char* x = (char*)workspace + xchg_offset(a.nrt, u1, u2);
@@ -834,7 +836,6 @@ extern "C" int mnn_lstm2_persist_bwd(mnn_stream_t s, int T, int B, const mnn_lst
     else if (u1 == 256) e = launch_pbwd<8>(st, grid, a, u2);
     else e = launch_pbwd<4>(st, grid, a, u2);
     MNN_HIP(e);
-    hipLaunchKernelGGL(pst_sticky_kernel, dim3(1), dim3(1), 0, st, (unsigned*)workspace, (int)(sticky_offset(a.nrt, u1, u2) / sizeof(unsigned)));
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

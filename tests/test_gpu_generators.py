@@ -472,6 +472,30 @@ def test_persistent_recurrence_with_initial_state():
     assert float((yz.float() - y1.float()).abs().max()) > 5e-2
 
 
+def test_persistent_launch_gives_up_loudly(monkeypatch):
+    """A persistent launch whose status word is raised (here by the MNN_PERSIST_TEST_ABORT hook; in production by a workgroup whose
+    bounded spin ran out) must drain -- every workgroup leaves at its next wait -- and the failure must stay visible to
+    LstmStack.check() across later launches, which themselves run normally again."""
+    from multinn_amd import _lib, RnnNade
+    a = RnnNade(16, 16, [128, 128], keep_prob=1.0, precision="bf16", seed=3)
+    a._materialize(16)
+    a._ensure_packed()
+    st = a._stack
+    x = (torch.rand((6, 32, st.ld0), device=DEV) < .2).to(torch.bfloat16)
+    assert st._persist(32)
+    y_ok, _, _ = st.forward(x, 1.0, save=False)
+    st.check()
+    monkeypatch.setenv("MNN_PERSIST_TEST_ABORT", "1")
+    st.forward(x, 1.0, save=False)
+    monkeypatch.delenv("MNN_PERSIST_TEST_ABORT")
+    with pytest.raises(_lib.MnnError, match="timed out"):
+        st.check()
+    y2, _, _ = st.forward(x, 1.0, save=False)                  # the next launch re-zeroes its flags and runs normally ...
+    assert torch.equal(y2, y_ok)
+    with pytest.raises(_lib.MnnError):                          # ... but the earlier failure stays on record
+        st.check()
+
+
 def test_graphed_train_step_matches_eager():
     from multinn_amd import RnnNade, AdamOptimizer
     x = make_batch(8, 6, 8, 2, 7, rho=0.2)
