@@ -330,6 +330,13 @@ def test_dropout_matches_contract(ops):
     y2 = torch.empty((T, B, u), device=DEV)
     ops.dropout_fwd(dev(h), y2, 1.0, 23, 100, 1)
     assert np.array_equal(y2.cpu().numpy(), h)
+    # the keep masks the recurrences read: 16 flags per thread (u % 16 == 0) and 4 per thread (u = 20) against the same counters
+    for uw in (32, 20):
+        mk = torch.zeros((T, B, uw), device=DEV, dtype=torch.uint8)
+        ops.dropout_mask(mk, 0.9, 23, 100, 1)
+        uw_u = np.stack([philox.uniform_block(23, philox.STREAM_DROPOUT, np.arange(100, 100 + B), (t << 8) | 1, uw) for t in range(T)])
+        assert np.array_equal(mk.cpu().numpy(), np.floor(np.float32(0.9) + uw_u).astype(np.uint8))
+    assert np.array_equal(mk.cpu().numpy() * 0 + keep[:, :, :20].astype(np.uint8), np.floor(np.float32(0.9) + uu[:, :, :20]).astype(np.uint8))
 
 
 # ------------------------------------------------------------------------------------------------
