@@ -152,10 +152,12 @@ int mnn_lstm2_seq_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L1
  * registers for the whole sequence and hands 32-row state tiles to the workgroups of the same row tile through
  * write-through stores into an exchange area + progress flags (multinn_amd/csrc/lstm_persist.hip).  Layer 2's input
  * projection is folded into its step, so L2->xproj is not used (may be NULL); backward, L1->dh_ext and both dz_T are
- * not used (may be NULL) and dz must be NULL.
+ * not used (may be NULL) and dz must be NULL.  Backward, L2->mask (optional): when given, L2->dh_ext is the gradient wrt
+ * layer 2's DROPPED output and the launch applies the dropout backward itself (dh_ext / keep_prob * mask, the arithmetic of
+ * mnn_dropout_bwd); when NULL, dh_ext is taken as the gradient wrt h2.
  * workspace: mnn_lstm2_persist_workspace_bytes(T,B,u1,u2) bytes of device memory, 256-byte aligned, zeroed ONCE by the
  * caller at allocation (progress flags, a sticky give-up word, the exchange area); each call re-zeroes its progress
- * words itself (a memset node under hipGraph capture); forward and backward calls may share one workspace.
+ * words itself (a fill kernel: no memset node under hipGraph capture); forward and backward calls may share one workspace.
  * mnn_lstm2_persist_status copies the sticky word to the host (synchronises): non-zero after any launch that gave up
  * on a bounded spin -- its outputs are then garbage.  mnn_lstm2_persist_ok() says whether the grid fits this device at
  * once (one workgroup per CU); the entries refuse shapes for which it does not. */

@@ -530,7 +530,7 @@ __device__ __forceinline__ void pb_epi_load(const PBwdLayer& L, int B, int nt, i
         e[q].c = L.c[(size_t)t * us + uo];
         const float* cpp = t > 0 ? L.c + (size_t)(t - 1) * us + uo : (L.c0 != nullptr ? L.c0 + uo : zero);
         e[q].cp = *cpp;
-        const uint8_t* mp = (LAYER1 && L.mask != nullptr) ? L.mask + (size_t)t * us + uo : reinterpret_cast<const uint8_t*>(zero);
+        const uint8_t* mp = L.mask != nullptr ? L.mask + (size_t)t * us + uo : reinterpret_cast<const uint8_t*>(zero);
         e[q].keep = *mp;
     }
 }
@@ -603,7 +603,8 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
                 float sum = 0.f;
 #pragma unroll
                 for (int ww = 0; ww < 8; ++ww) sum += S.red[0][ww][j][lane];
-                dh[q] = e[q].dh + sum;
+                // layer 2's mask, when given, says dh_ext is the gradient wrt the DROPPED output: dropout backward happens here (dy / kp * keep)
+                dh[q] = (L.mask != nullptr ? e[q].dh / A.kp * (float)e[q].keep : e[q].dh) + sum;
                 e_dc[q] = (Rv == 1 && k > 0) ? tl.dcv[q] : dcl[q];
             }
             PST_TR(trc, 2);

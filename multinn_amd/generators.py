@@ -267,21 +267,23 @@ class LstmStack:
             st.append(dict(dz=dz, dzc=None if persist else (dz if self.dtype == torch.float32 else torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype)),
                            dzT=(torch.zeros if Np != T * B else torch.empty)((4 * u, Np), device=dev, dtype=self.dtype),
                            db_p=torch.zeros(4 * u, device=dev),
-                           dh=torch.empty((T, B, u), device=dev) if keep_prob < 1.0 else None, ws=ops.lstm_seq_bwd_workspace(B, u, dev)))
+                           dh=torch.empty((T, B, u), device=dev) if (keep_prob < 1.0 and not (persist and ctx[l].get("mask") is not None)) else None,
+                           ws=ops.lstm_seq_bwd_workspace(B, u, dev)))
             if l < L - 1 and not persist:
                 dyl[l] = torch.empty((T, B, u), device=dev)
         lane_of = lambda l: lanes[L - 1 - l] if piped else main          # the top layer leads, on the current stream
         done = [[None] * len(chunks) for _ in range(L)]
         if (persist or (self._fused2(B) and ctx[0]["h0"] is None)) and (keep_prob >= 1.0 or ctx[0].get("mask") is not None):
             p0, p1 = self.packed
-            if keep_prob < 1.0:
+            fold = persist and keep_prob < 1.0 and ctx[1].get("mask") is not None    # the persistent backward applies layer 2's mask itself
+            if keep_prob < 1.0 and not fold:
                 ops.dropout_bwd(dyl[1], st[1]["dh"], keep_prob, seed, row0, 1, False, step_dev, 0)
-            dh1 = st[1]["dh"] if keep_prob < 1.0 else dyl[1]
+            dh1 = st[1]["dh"] if (keep_prob < 1.0 and not fold) else dyl[1]
             dh0 = None if persist else dyl[0]              # written by the fused launches (stage Q), dropout already applied
             e0 = ops.lstm2_bwd_layer(dh0, p0["wh_p"], ctx[0]["gates"], ctx[0]["c"], ctx[0]["c0"], st[0]["dzc"], st[0]["ws"], st[0]["dzT"], st[0]["db_p"],
                                      ctx[0].get("mask"))
             e1 = ops.lstm2_bwd_layer(dh1, p1["wh_p"], ctx[1]["gates"], ctx[1]["c"], ctx[1]["c0"], st[1]["dzc"], st[1]["ws"], st[1]["dzT"], st[1]["db_p"],
-                                     None, p1["wx_p"])
+                                     ctx[1]["mask"] if fold else None, p1["wx_p"])
             if persist:
                 ops.lstm2_persist_bwd(T, B, e0, e1, keep_prob, self._workspace(T, B, dev))
             else:
