@@ -203,6 +203,71 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // CPR = 16-byte chunks per tile row (8 for BK = 64, 16 for BK = 128); swizzle: chunk c of row r lives at
 // c ^ ((r >> 1) & 7) for 128-byte rows and c ^ (r & 15) for 256-byte rows (16 rows of a ds_read_b128 group -> 16 slots).
+
+// Epilogue of the LDS-DMA kernels: one wave's NI x NJ accumulator tiles -> C.  The store mode is resolved ONCE (template), the row
+// part of every address is wave-uniform (scalar arithmetic), the per-lane part is one offset computed once.  The per-element form
+// (64-bit row * ldc per lane, four run-time mode branches per element) cost ~40 instructions per stored value: at K = 448 the
+// 256 x 256 tile spent 21 of its 35 us issuing its 128 stores per thread (scratch/gemm_trace.hip) -- 150 -> 89 us for xproj1.
+enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_ACCUM = 2, EPI_BF16 = 3 };
+template <int MODE>
+__device__ __forceinline__ void epi_put(float* __restrict__ rowf, bf16_t* __restrict__ rowb, unsigned lane_off, float val) {
+    // rowf / rowb are wave-uniform pointers (SGPR base), lane_off the one per-lane offset: the store needs no vector address arithmetic
+    if (MODE == EPI_BF16) rowb[lane_off] = f32_to_bf16(val);
+    else if (MODE == EPI_ATOMIC) atomicAdd(rowf + lane_off, val);
+    else if (MODE == EPI_ACCUM) rowf[lane_off] += val;
+    else rowf[lane_off] = val;
+}
+template <int MODE, int NI, int NJ>
+__device__ __forceinline__ void epi_store_tiles(void* __restrict__ Cv, int ldc, int M, int N, int row0, int col0, const f32x16_t (&acc)[NI][NJ],
+                                                const float* __restrict__ bias, int lane) {
+    const int r = lane & 31, h4 = 4 * (lane >> 5);
+    float* Cf = reinterpret_cast<float*>(Cv);
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv);
+    const unsigned lane_off = (unsigned)h4 * (unsigned)ldc + (unsigned)r;
+    if (row0 + NI * 32 <= M && col0 + NJ * 32 <= N) {          // interior (uniform): no predicates at all
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float bv = bias != nullptr ? bias[col0 + j * 32 + r] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const size_t ro = (size_t)(row0 + i * 32 + (e & 3) + 8 * (e >> 2)) * ldc + col0 + j * 32;      // uniform
+                    epi_put<MODE>(Cf + ro, Cb + ro, lane_off, acc[i][j][e] + bv);
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int cb = col0 + j * 32;                          // uniform
+        if (cb >= N) continue;
+        const bool colok = cb + r < N;
+        const float bv = (bias != nullptr && colok) ? bias[cb + r] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rb = row0 + i * 32 + (e & 3) + 8 * (e >> 2);      // uniform: this register's row for lanes 0..31 (lanes 32..63: +4)
+                if (rb >= M) continue;
+                if (colok && rb + h4 < M) {
+                    const size_t ro = (size_t)rb * ldc + cb;
+                    epi_put<MODE>(Cf + ro, Cb + ro, lane_off, acc[i][j][e] + bv);
+                }
+            }
+        }
+    }
+}
+template <int NI, int NJ>
+__device__ __forceinline__ void epi_dispatch(void* __restrict__ Cv, int ldc, int c_bf16, int flags, int M, int N, int row0, int col0,
+                                             const f32x16_t (&acc)[NI][NJ], const float* __restrict__ bias, int lane) {
+    if (c_bf16) epi_store_tiles<EPI_BF16, NI, NJ>(Cv, ldc, M, N, row0, col0, acc, bias, lane);
+    else if (flags & MNN_GEMM_ATOMIC) epi_store_tiles<EPI_ATOMIC, NI, NJ>(Cv, ldc, M, N, row0, col0, acc, bias, lane);
+    else if (flags & MNN_GEMM_ACCUMULATE) epi_store_tiles<EPI_ACCUM, NI, NJ>(Cv, ldc, M, N, row0, col0, acc, bias, lane);
+    else epi_store_tiles<EPI_STORE, NI, NJ>(Cv, ldc, M, N, row0, col0, acc, bias, lane);
+}
+
 template <int CPR>
 __device__ __forceinline__ int swz(int row) { return CPR == 8 ? ((row >> 1) & 7) : (row & 15); }
 
@@ -280,27 +345,7 @@ gemm_tn_glds_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restr
         __syncthreads();
         cur ^= 1;
     }
-    float* Cf = reinterpret_cast<float*>(Cv);
-    bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            if (col >= N) continue;
-            const float bv = (bias != nullptr && z == 0) ? bias[col] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 64 + i * 32 + frag_row(e, lane);
-                if (row >= M) continue;
-                const float val = acc[i][j][e] + bv;
-                const size_t o = (size_t)row * ldc + col;
-                if (c_bf16) Cb[o] = f32_to_bf16(val);
-                else if (flags & MNN_GEMM_ATOMIC) atomicAdd(Cf + o, val);
-                else if (flags & MNN_GEMM_ACCUMULATE) Cf[o] += val;
-                else Cf[o] = val;
-            }
-        }
+    epi_dispatch<2, 2>(Cv, ldc, c_bf16, flags, M, N, m0 + wm * 64, n0 + wn * 64, acc, z == 0 ? bias : nullptr, lane);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -381,27 +426,7 @@ gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
         __syncthreads();
         cur ^= 1;
     }
-    float* Cf = reinterpret_cast<float*>(Cv);
-    bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            if (col >= N) continue;
-            const float bv = (bias != nullptr && z == 0) ? bias[col] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 128 + i * 32 + frag_row(e, lane);
-                if (row >= M) continue;
-                const float val = acc[i][j][e] + bv;
-                const size_t o = (size_t)row * ldc + col;
-                if (c_bf16) Cb[o] = f32_to_bf16(val);
-                else if (flags & MNN_GEMM_ATOMIC) atomicAdd(Cf + o, val);
-                else if (flags & MNN_GEMM_ACCUMULATE) Cf[o] += val;
-                else Cf[o] = val;
-            }
-        }
+    epi_dispatch<4, 2>(Cv, ldc, c_bf16, flags, M, N, m0 + wm * 128, n0 + wn * 64, acc, z == 0 ? bias : nullptr, lane);
 }
 
 template <typename T>
