@@ -271,18 +271,31 @@ __device__ __forceinline__ void epi_dispatch(void* __restrict__ Cv, int ldc, int
 template <int CPR>
 __device__ __forceinline__ int swz(int row) { return CPR == 8 ? ((row >> 1) & 7) : (row & 15); }
 
-template <int CPR>
-__device__ __forceinline__ void glds_stage_tile(const bf16_t* __restrict__ G, int ld, int rows_total, int r0, int k0, char* tile, int wave,
-                                                int lane) {
+// This thread's LDS-DMA slots of one operand tile (ROWS rows x CPR 16-byte chunks, NW waves): the global address of every slot at
+// k = 0 is computed ONCE per workgroup (row clamp, swizzle, 64-bit row * ld); staging a K tile is then one 64-bit add per slot.
+// Recomputing them per K tile cost ~0.5 us of address arithmetic per tile in front of the 8 DMA instructions (scratch/gemm_trace.hip).
+template <int ROWS, int NW, int CPR>
+struct GldsSlots {
+    static constexpr int NS = ROWS * CPR / (64 * NW);
+    const bf16_t* base;                                    // wave-uniform
+    unsigned off[NS];                                       // element offset of the slot at k = 0 (operands stay below 2^31 elements)
+    __device__ __forceinline__ void init(const bf16_t* __restrict__ G, int ld, int rows_total, int r0, int wave, int lane) {
+        base = G;
 #pragma unroll
-    for (int s = 0; s < 128 * CPR / 256; ++s) {
-        const int p = (s * 4 + wave) * 64 + lane;          // linear 16-byte slot of the tile image
-        const int row = p / CPR, pc = p % CPR;
-        const int c = pc ^ swz<CPR>(row);                   // logical K chunk held by this slot
-        const int gr = min(r0 + row, rows_total - 1);       // rows past the edge replicate the last row (never stored)
-        __builtin_amdgcn_global_load_lds((gas_ptr_t)(G + (size_t)gr * ld + k0 + c * 8), (lds_ptr_t)(tile + (s * 4 + wave) * 1024), 16, 0, 0);
+        for (int s = 0; s < NS; ++s) {
+            const int p = (s * NW + wave) * 64 + lane;      // linear 16-byte slot of the tile image
+            const int row = p / CPR, pc = p % CPR;
+            const int c = pc ^ swz<CPR>(row);               // logical K chunk held by this slot
+            const int gr = min(r0 + row, rows_total - 1);   // rows past the edge replicate the last row (never stored)
+            off[s] = (unsigned)gr * (unsigned)ld + (unsigned)(c * 8);
+        }
     }
-}
+    __device__ __forceinline__ void stage(int k0, char* tile, int wave) const {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            __builtin_amdgcn_global_load_lds((gas_ptr_t)(base + (off[s] + (unsigned)k0)), (lds_ptr_t)(tile + (s * NW + wave) * 1024), 16, 0, 0);
+    }
+};
 
 template <int BK>
 __global__ void __launch_bounds__(256)
@@ -313,14 +326,17 @@ gemm_tn_glds_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restr
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    glds_stage_tile<CPR>(A, lda, M, m0, kt0 * BK, smem[0][0], wave, lane);
-    glds_stage_tile<CPR>(B, ldb, N, n0, kt0 * BK, smem[0][1], wave, lane);
+    GldsSlots<128, 4, CPR> slotA, slotB;
+    slotA.init(A, lda, M, m0, wave, lane);
+    slotB.init(B, ldb, N, n0, wave, lane);
+    slotA.stage(kt0 * BK, smem[0][0], wave);
+    slotB.stage(kt0 * BK, smem[0][1], wave);
     __syncthreads();                                        // hipcc drains vmcnt(0) before the barrier
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
         if (kt + 1 < kt1) {
-            glds_stage_tile<CPR>(A, lda, M, m0, (kt + 1) * BK, smem[cur ^ 1][0], wave, lane);
-            glds_stage_tile<CPR>(B, ldb, N, n0, (kt + 1) * BK, smem[cur ^ 1][1], wave, lane);
+            slotA.stage((kt + 1) * BK, smem[cur ^ 1][0], wave);
+            slotB.stage((kt + 1) * BK, smem[cur ^ 1][1], wave);
         }
         const char* sA = smem[cur][0];
         const char* sB = smem[cur][1];
@@ -355,20 +371,6 @@ gemm_tn_glds_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restr
 // at two thirds of the MFMA rate before any latency.  Here 4 A + 2 B fragments feed 8 MFMAs and a stage carries 0.25 KiB
 // per MFMA: 1.0 KiB per MFMA, and one workgroup per CU holds two 64 KiB stages.
 // ----------------------------------------------------------------------------------------------
-template <int ROWS, int NW>
-__device__ __forceinline__ void glds_stage_tile_n(const bf16_t* __restrict__ G, int ld, int rows_total, int r0, int k0, char* tile, int wave,
-                                                  int lane) {
-    constexpr int CPR = 8;                                  // 16-byte chunks per 64-element row
-#pragma unroll
-    for (int s = 0; s < ROWS * CPR / (64 * NW); ++s) {
-        const int p = (s * NW + wave) * 64 + lane;          // linear 16-byte slot of the tile image
-        const int row = p / CPR, pc = p % CPR;
-        const int c = pc ^ swz<CPR>(row);
-        const int gr = min(r0 + row, rows_total - 1);
-        __builtin_amdgcn_global_load_lds((gas_ptr_t)(G + (size_t)gr * ld + k0 + c * 8), (lds_ptr_t)(tile + (s * NW + wave) * 1024), 16, 0, 0);
-    }
-}
-
 __global__ void __launch_bounds__(512)
 gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c_bf16,
                        const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
@@ -394,9 +396,12 @@ gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    GldsSlots<256, 8, CPR> slotA, slotB;
+    slotA.init(A, lda, M, m0, wave, lane);
+    slotB.init(B, ldb, N, n0, wave, lane);
     auto stage = [&](int buf, int kt) {
-        glds_stage_tile_n<256, 8>(A, lda, M, m0, kt * BK, smem256 + (buf * 2 + 0) * TILE, wave, lane);
-        glds_stage_tile_n<256, 8>(B, ldb, N, n0, kt * BK, smem256 + (buf * 2 + 1) * TILE, wave, lane);
+        slotA.stage(kt * BK, smem256 + (buf * 2 + 0) * TILE, wave);
+        slotB.stage(kt * BK, smem256 + (buf * 2 + 1) * TILE, wave);
     };
     stage(0, kt0);
     __syncthreads();                                        // hipcc drains vmcnt(0) before the barrier
