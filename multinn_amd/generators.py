@@ -217,8 +217,12 @@ class LstmStack:
 
     @staticmethod
     def _split_k(rows_out, cols_out, K):
+        # about 512 workgroups of the 128 x 128 tile (two per CU): every slice adds its tile with f32 atomics, and those run at one
+        # chip-wide rate (~1.3 TB/s) -- 16 slices of dWh1 were 67 MB of adds, half of that GEMM's time (scratch/gemm_sweep.py)
+        # (at K >= 64 k the adds are a small share again and more slices win: 1024 workgroups)
         tiles = -(-rows_out // 128) * -(-cols_out // 128)
-        return int(max(1, min(1024 // max(tiles, 1), K // 1024)))
+        target = 512 if K < 65536 else 1024
+        return int(max(1, min(target // max(tiles, 1), K // 1024)))
 
     def _weight_grads(self, l, cx, dzT, db_p, T, B):
         """dWx^T[4u,ld] = dz^T . inp ; dWh^T[4u,u] = dz^T . h_prev  (reduction over the N rows); dzT [4u,Np] and
