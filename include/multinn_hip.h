@@ -99,6 +99,10 @@ int mnn_lstm_pack_weights(mnn_stream_t s, const float* W, const float* bias, int
  * into the natural TF layout dW[(in+u),4u], db[4u] (accumulating). */
 int mnn_lstm_unpack_grads(mnn_stream_t s, const float* dwx_t, const float* dwh_t, const float* db_p, int n_in, int units,
                           int ld_in, float* dW, float* db);
+/* Same, and the three packed sources are zeroed as they are read (each element by the thread that read it): persistent accumulators
+ * for the split-K weight-gradient GEMMs (MNN_GEMM_ACCUMULATE) and the recurrence's bias sums, no zero fill per step. */
+int mnn_lstm_unpack_grads_consume(mnn_stream_t s, float* dwx_t, float* dwh_t, float* db_p, int n_in, int units, int ld_in, float* dW,
+                                  float* db);
 
 /* One layer over steps [t_begin, t_end) of a sequence, time-major (chunked calls let the layers of a
  * stack run as a wavefront on separate streams).  xproj f32 [T,B,4u] = inputs . Wx + b (already

@@ -334,6 +334,31 @@ __global__ void lstm_unpack_grads_kernel(const float* __restrict__ dwx_t, const 
     }
 }
 
+// Same, and every source element is set back to zero by the thread that read it: the packed gradient buffers are then persistent
+// accumulators that the split-K GEMMs (and the recurrence's bias sums) add into, with no zero-fill launch in front of each of them.
+__global__ void lstm_unpack_grads_consume_kernel(float* __restrict__ dwx_t, float* __restrict__ dwh_t, float* __restrict__ db_p, int n_in, int U,
+                                                 int ld_in, float* __restrict__ dW, float* __restrict__ db) {
+    const int N4 = 4 * U;
+    const long total = (long)(n_in + U) * N4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i / N4), nat = (int)(i % N4);
+        const int pc = gate_perm_col(nat / U, nat % U);
+        float* src = k < n_in ? dwx_t + (size_t)pc * ld_in + k : dwh_t + (size_t)pc * U + (k - n_in);
+        dW[i] += *src;
+        *src = 0.f;
+        if (k == 0) { db[nat] += db_p[pc]; db_p[pc] = 0.f; }
+    }
+}
+
+extern "C" int mnn_lstm_unpack_grads_consume(mnn_stream_t s, float* dwx_t, float* dwh_t, float* db_p, int n_in, int units, int ld_in, float* dW,
+                                             float* db) {
+    MNN_REQUIRE(dwx_t && dwh_t && db_p && dW && db && units % 32 == 0 && ld_in >= n_in, "mnn_lstm_unpack_grads_consume: bad arguments");
+    const int blocks = (int)min((long)1024, ((long)(n_in + units) * 4 * units + 255) / 256);
+    hipLaunchKernelGGL(lstm_unpack_grads_consume_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, dwx_t, dwh_t, db_p, n_in, units, ld_in, dW, db);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
 extern "C" int mnn_lstm_unpack_grads(mnn_stream_t s, const float* dwx_t, const float* dwh_t, const float* db_p, int n_in, int units,
                                      int ld_in, float* dW, float* db) {
     MNN_REQUIRE(dwx_t && dwh_t && db_p && dW && db && units % 32 == 0 && ld_in >= n_in, "mnn_lstm_unpack_grads: bad arguments");

@@ -236,13 +236,24 @@ class LstmStack:
         if inT is None:
             inT = (torch.zeros if Np != N else torch.empty)((ld, Np), device=dev, dtype=self.dtype)
             ops.transpose(cx["inp"].view(N, ld), inT)
-        dwx_t = torch.empty((4 * u, ld), device=dev)
-        ops.gemm_tn(dzT, inT, dwx_t, split_k=self._split_k(4 * u, ld, Np))
-        dwh_t = torch.empty((4 * u, u), device=dev)
-        ops.gemm_tn(dzT, cx["hT"], dwh_t, split_k=self._split_k(4 * u, u, Np))
+        # dwx_t / dwh_t / db_p are persistent accumulators (zero between steps: the unpack below clears what it reads), so the
+        # split-K slices add into them without a zero-fill launch in front of every GEMM
+        dwx_t, dwh_t, _ = self._accum(l, dev)
+        ops.gemm_tn(dzT, inT, dwx_t, accumulate=True, split_k=self._split_k(4 * u, ld, Np))
+        ops.gemm_tn(dzT, cx["hT"], dwh_t, accumulate=True, split_k=self._split_k(4 * u, u, Np))
         ops.lstm_unpack_grads(dwx_t, dwh_t, db_p, n_in, u, self.store.gviews[f"{self.rnn.prefix}/cell_{l}/kernel"],
-                              self.store.gviews[f"{self.rnn.prefix}/cell_{l}/bias"])
+                              self.store.gviews[f"{self.rnn.prefix}/cell_{l}/bias"], consume=True)
         return (inT, dwx_t, dwh_t)      # kept alive until the streams are joined
+
+    def _accum(self, l, dev):
+        """Packed weight-gradient accumulators of layer l: (dWx^T [4u, ld], dWh^T [4u, u], db [4u]) f32, allocated zeroed once."""
+        if not hasattr(self, "_acc"):
+            self._acc = {}
+        if l not in self._acc:
+            p = self.packed[l]
+            self._acc[l] = (torch.zeros((4 * p["u"], p["ld"]), device=dev), torch.zeros((4 * p["u"], p["u"]), device=dev),
+                            torch.zeros(4 * p["u"], device=dev))
+        return self._acc[l]
 
     def backward(self, dy, ctx, keep_prob=1.0, seed=0, row0=0, need_dx=False, step_dev=None):
         """dy f32 [T,B,u_last]: gradient wrt the (dropped) top output.  Accumulates the kernel / bias gradients
@@ -270,7 +281,7 @@ class LstmStack:
             dz = None if fused else torch.empty((T, B, 4 * u), device=dev)
             st.append(dict(dz=dz, dzc=None if persist else (dz if self.dtype == torch.float32 else torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype)),
                            dzT=(torch.zeros if Np != T * B else torch.empty)((4 * u, Np), device=dev, dtype=self.dtype),
-                           db_p=torch.zeros(4 * u, device=dev),
+                           db_p=self._accum(l, dev)[2],
                            dh=torch.empty((T, B, u), device=dev) if (keep_prob < 1.0 and not (persist and ctx[l].get("mask") is not None)) else None,
                            ws=ops.lstm_seq_bwd_workspace(B, u, dev)))
             if l < L - 1 and not persist:

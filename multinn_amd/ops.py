@@ -138,13 +138,15 @@ def lstm_rows_gate_minor(wx_t, bias_p, wx_gm, bias_gm):
     call("mnn_lstm_rows_gate_minor", _stream(), dtype_code(wx_t), N4 // 4, ld, _ptr(wx_t), _ptr(bias_p), _ptr(wx_gm), _ptr(bias_gm))
 
 
-def lstm_unpack_grads(dwx_t, dwh_t, db_p, n_in, units, dW, db):
+def lstm_unpack_grads(dwx_t, dwh_t, db_p, n_in, units, dW, db, consume=False):
+    """consume=True: the packed sources are zeroed as they are read (persistent accumulators, see mnn_lstm_unpack_grads_consume)."""
     ld_in = dwx_t.shape[1]
     _req(dwx_t.dtype == torch.float32 and dwx_t.shape == (4 * units, ld_in) and dwx_t.is_contiguous(), "unpack: dwx_t f32 [4u,ld]")
     _req(dwh_t.dtype == torch.float32 and dwh_t.shape == (4 * units, units) and dwh_t.is_contiguous(), "unpack: dwh_t f32 [4u,u]")
     _req(dW.dtype == torch.float32 and dW.shape == (n_in + units, 4 * units) and dW.is_contiguous(), "unpack: dW f32 [(in+u),4u]")
     _req(db.numel() == 4 * units and db_p.numel() == 4 * units, "unpack: bias sizes")
-    call("mnn_lstm_unpack_grads", _stream(), _ptr(dwx_t), _ptr(dwh_t), _ptr(db_p), n_in, units, ld_in, _ptr(dW), _ptr(db))
+    call("mnn_lstm_unpack_grads_consume" if consume else "mnn_lstm_unpack_grads", _stream(), _ptr(dwx_t), _ptr(dwh_t), _ptr(db_p), n_in, units, ld_in,
+         _ptr(dW), _ptr(db))
 
 
 def lstm_fused_outputs(dtype, units):

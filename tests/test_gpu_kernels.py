@@ -235,6 +235,11 @@ def test_lstm_layer_fwd_bwd(ops, dt, B, T, n_in, u):
     ops.lstm_unpack_grads(dwx_t, dwh_t, db_p, n_in, u, dW, db)
     assert rel(dW.cpu().numpy(), grads[0][0]) < tol * 3
     assert rel(db.cpu().numpy(), grads[0][1]) < tol * 3
+    # the consuming form adds the same values and leaves every source it read at zero (persistent split-K accumulators)
+    dW2, db2 = torch.zeros_like(dW), torch.zeros_like(db)
+    ops.lstm_unpack_grads(dwx_t, dwh_t, db_p, n_in, u, dW2, db2, consume=True)
+    assert torch.equal(dW2, dW) and torch.equal(db2, db)
+    assert float(dwx_t[:, :n_in].abs().max()) == 0 and float(dwh_t.abs().max()) == 0 and float(db_p.abs().max()) == 0
     dx = torch.empty((T * B, n_in), device=DEV)
     ops.gemm_tn(dzT.view(T * B, -1), wx_p.view(n_in, -1), dx)
     assert rel(dx.view(T, B, n_in).cpu().numpy().transpose(1, 0, 2), dx_ref) < tol * 3
