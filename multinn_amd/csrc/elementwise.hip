@@ -321,40 +321,46 @@ extern "C" int mnn_lstm_rows_gate_minor(mnn_stream_t s, int dtype, int units, in
     return MNN_OK;
 }
 
-__global__ void lstm_unpack_grads_kernel(const float* __restrict__ dwx_t, const float* __restrict__ dwh_t, const float* __restrict__ db_p,
-                                         int n_in, int U, int ld_in, float* __restrict__ dW, float* __restrict__ db) {
-    const int N4 = 4 * U;
-    const long total = (long)(n_in + U) * N4;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(i / N4), nat = (int)(i % N4);
-        const int pc = gate_perm_col(nat / U, nat % U);
-        const float g = k < n_in ? dwx_t[(size_t)pc * ld_in + k] : dwh_t[(size_t)pc * U + (k - n_in)];
-        dW[i] += g;
-        if (k == 0) db[nat] += db_p[pc];
+// dW[k][nat] += src_t[pc(nat)][k], db[nat] += db_p[pc(nat)]: a transpose with the gate permutation.  One gate of one 32-unit block is
+// 32 consecutive rows pc of the packed sources AND 32 consecutive natural columns, so 32 x 32 tiles through LDS read along k and
+// write along nat, both coalesced (the element-per-thread form gathered with a stride of ld_in floats).  CONSUME: every source element
+// is set back to zero by the thread that read it -- the packed buffers are then persistent accumulators for the split-K GEMMs.
+template <bool CONSUME>
+__global__ void __launch_bounds__(256)
+lstm_unpack_grads_kernel(float* __restrict__ dwx_t, float* __restrict__ dwh_t, float* __restrict__ db_p, int n_in, int U, int ld_in,
+                         float* __restrict__ dW, float* __restrict__ db) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int pc0 = blockIdx.x * 32, ub = blockIdx.x >> 2, g = blockIdx.x & 3;
+    const int nat0 = g * U + ub * 32, N4 = 4 * U, k0 = blockIdx.y * 32, K = n_in + U;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int pc = pc0 + ty + 8 * jj, k = k0 + tx;
+        float val = 0.f;
+        if (k < K) {
+            float* src = k < n_in ? dwx_t + (size_t)pc * ld_in + k : dwh_t + (size_t)pc * U + (k - n_in);
+            val = *src;
+            if (CONSUME) *src = 0.f;
+        }
+        tile[ty + 8 * jj][tx] = val;
     }
-}
-
-// Same, and every source element is set back to zero by the thread that read it: the packed gradient buffers are then persistent
-// accumulators that the split-K GEMMs (and the recurrence's bias sums) add into, with no zero-fill launch in front of each of them.
-__global__ void lstm_unpack_grads_consume_kernel(float* __restrict__ dwx_t, float* __restrict__ dwh_t, float* __restrict__ db_p, int n_in, int U,
-                                                 int ld_in, float* __restrict__ dW, float* __restrict__ db) {
-    const int N4 = 4 * U;
-    const long total = (long)(n_in + U) * N4;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(i / N4), nat = (int)(i % N4);
-        const int pc = gate_perm_col(nat / U, nat % U);
-        float* src = k < n_in ? dwx_t + (size_t)pc * ld_in + k : dwh_t + (size_t)pc * U + (k - n_in);
-        dW[i] += *src;
-        *src = 0.f;
-        if (k == 0) { db[nat] += db_p[pc]; db_p[pc] = 0.f; }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int k = k0 + ty + 8 * jj;
+        if (k < K) dW[(size_t)k * N4 + nat0 + tx] += tile[tx][ty + 8 * jj];
+    }
+    if (blockIdx.y == 0 && ty == 0) {
+        db[nat0 + tx] += db_p[pc0 + tx];
+        if (CONSUME) db_p[pc0 + tx] = 0.f;
     }
 }
 
 extern "C" int mnn_lstm_unpack_grads_consume(mnn_stream_t s, float* dwx_t, float* dwh_t, float* db_p, int n_in, int units, int ld_in, float* dW,
                                              float* db) {
     MNN_REQUIRE(dwx_t && dwh_t && db_p && dW && db && units % 32 == 0 && ld_in >= n_in, "mnn_lstm_unpack_grads_consume: bad arguments");
-    const int blocks = (int)min((long)1024, ((long)(n_in + units) * 4 * units + 255) / 256);
-    hipLaunchKernelGGL(lstm_unpack_grads_consume_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, dwx_t, dwh_t, db_p, n_in, units, ld_in, dW, db);
+    dim3 grid(4 * units / 32, cdiv(n_in + units, 32));
+    hipLaunchKernelGGL(lstm_unpack_grads_kernel<true>, grid, dim3(256), 0, (hipStream_t)s, dwx_t, dwh_t, db_p, n_in, units, ld_in, dW, db);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
@@ -362,8 +368,9 @@ extern "C" int mnn_lstm_unpack_grads_consume(mnn_stream_t s, float* dwx_t, float
 extern "C" int mnn_lstm_unpack_grads(mnn_stream_t s, const float* dwx_t, const float* dwh_t, const float* db_p, int n_in, int units,
                                      int ld_in, float* dW, float* db) {
     MNN_REQUIRE(dwx_t && dwh_t && db_p && dW && db && units % 32 == 0 && ld_in >= n_in, "mnn_lstm_unpack_grads: bad arguments");
-    const int blocks = (int)min((long)1024, ((long)(n_in + units) * 4 * units + 255) / 256);
-    hipLaunchKernelGGL(lstm_unpack_grads_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, dwx_t, dwh_t, db_p, n_in, units, ld_in, dW, db);
+    dim3 grid(4 * units / 32, cdiv(n_in + units, 32));
+    hipLaunchKernelGGL(lstm_unpack_grads_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, const_cast<float*>(dwx_t), const_cast<float*>(dwh_t),
+                       const_cast<float*>(db_p), n_in, units, ld_in, dW, db);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
