@@ -524,9 +524,17 @@ __device__ __forceinline__ float block_sum_256(float v) {
     return part[0] + part[1] + part[2] + part[3];
 }
 
+// few workgroups, 16-byte loads: the partial sums all land on ONE word, and same-address float atomics serialise at ~12 ns each
+// (1024 of them were 12 of this kernel's 16 us)
 __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
     float acc = 0.f;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc = fmaf(x[i], x[i], acc);
+    const long n4 = (((uintptr_t)x & 15) == 0) ? n / 4 : 0;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 q = x4[i];
+        acc = fmaf(q.x, q.x, acc); acc = fmaf(q.y, q.y, acc); acc = fmaf(q.z, q.z, acc); acc = fmaf(q.w, q.w, acc);
+    }
+    for (long i = n4 * 4 + blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc = fmaf(x[i], x[i], acc);
     acc = block_sum_256(acc);
     if (threadIdx.x == 0) atomicAdd(out, acc);
 }
@@ -539,7 +547,7 @@ __global__ void __launch_bounds__(256) wsum_kernel(const float* __restrict__ x, 
 
 extern "C" int mnn_sumsq(mnn_stream_t s, const float* x, long n, float* out) {
     MNN_REQUIRE(x && out && n > 0, "mnn_sumsq: bad arguments");
-    hipLaunchKernelGGL(sumsq_kernel, dim3((int)min(1024L, (n + 255) / 256)), dim3(256), 0, (hipStream_t)s, x, n, out);
+    hipLaunchKernelGGL(sumsq_kernel, dim3((int)min(256L, (n + 1023) / 1024)), dim3(256), 0, (hipStream_t)s, x, n, out);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
@@ -554,15 +562,44 @@ __global__ void clip_adam_kernel(float* __restrict__ theta, const float* __restr
                                  long n, const float* __restrict__ sumsq, float clip, float lr_t, float lr, float b1, float b2, float eps,
                                  int sgd, const int32_t* __restrict__ step_dev) {
     if (step_dev != nullptr) {          // step counter lives on the device (hipGraph replay): t = *step_dev + 1
-        const double t = (double)(step_dev[0] + 1);
-        lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+        __shared__ float s_lr_t;        // two double-precision pow() once per workgroup, not once per thread
+        if (threadIdx.x == 0) {
+            const double t = (double)(step_dev[0] + 1);
+            s_lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+        }
+        __syncthreads();
+        lr_t = s_lr_t;
     }
     float scale = 1.f;
     if (clip > 0.f && sumsq != nullptr) {
         const float gn = sqrtf(sumsq[0]);
         scale = gn > 0.f ? clip * fminf(1.0f / gn, 1.0f / clip) : 1.f;   // tf.clip_by_global_norm
     }
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    // 16-byte accesses over the aligned body (seven streams of n floats: a memory-bound pass), scalar tail
+    const bool al = ((((uintptr_t)theta | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    const long n4 = al ? n / 4 : 0;
+    if (!sgd) {
+        float4* t4 = reinterpret_cast<float4*>(theta);
+        const float4* g4 = reinterpret_cast<const float4*>(grad);
+        float4* m4 = reinterpret_cast<float4*>(m);
+        float4* v4 = reinterpret_cast<float4*>(v);
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+            const float4 gq = g4[i];
+            float4 mq = m4[i], vq = v4[i], tq = t4[i];
+            const float ge[4] = {gq.x * scale, gq.y * scale, gq.z * scale, gq.w * scale};
+            float me[4] = {mq.x, mq.y, mq.z, mq.w}, ve[4] = {vq.x, vq.y, vq.z, vq.w}, te[4] = {tq.x, tq.y, tq.z, tq.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                me[e] = b1 * me[e] + (1.f - b1) * ge[e];
+                ve[e] = b2 * ve[e] + (1.f - b2) * ge[e] * ge[e];
+                te[e] -= lr_t * me[e] / (sqrtf(ve[e]) + eps);
+            }
+            m4[i] = make_float4(me[0], me[1], me[2], me[3]);
+            v4[i] = make_float4(ve[0], ve[1], ve[2], ve[3]);
+            t4[i] = make_float4(te[0], te[1], te[2], te[3]);
+        }
+    }
+    for (long i = (sgd ? 0 : n4 * 4) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float g = grad[i] * scale;
         if (sgd) {
             theta[i] -= lr * g;
