@@ -407,7 +407,8 @@ def test_fused_two_layer_wavefront_matches_sequential():
         assert np.allclose(la, lb, rtol=1e-3), (la, lb)
 
 
-@pytest.mark.parametrize("B,T,units,kp", [(6, 40, [128, 128], 0.9), (70, 9, [256, 128], 0.9), (33, 12, [128, 256], 1.0), (256, 24, [512, 256], 0.9)])
+@pytest.mark.parametrize("B,T,units,kp", [(6, 40, [128, 128], 0.9), (70, 9, [256, 128], 0.9), (33, 12, [128, 256], 1.0), (256, 24, [512, 256], 0.9),
+                                          (1024, 6, [512, 256], 0.9), (600, 5, [256, 256], 0.9)])     # the last two: several row tiles per workgroup
 def test_persistent_recurrence_matches_sequential(B, T, units, kp):
     """mnn_lstm2_persist_fwd/bwd (ONE launch for all T steps, register-resident weights, flag hand-offs between the
     workgroups of a row tile) vs the per-layer launch-per-step sequence: same step bodies, layer 2's projection summed
