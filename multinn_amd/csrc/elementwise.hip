@@ -249,32 +249,39 @@ extern "C" int mnn_pianoroll_split_tracks(mnn_stream_t s, const uint8_t* x, int 
 // ----------------------------------------------------------------------------------------------
 // LSTM weight packing: natural TF kernel W[(in+u), 4u] -> gate-interleaved K-contiguous copies
 // ----------------------------------------------------------------------------------------------
+// 32 packed columns (one gate of one 32-unit block = 32 consecutive natural columns) x 32 rows of W per workgroup; W is read along
+// the natural columns, wx_p / wh_p written along the packed columns and wx_t / wh_t (transposed) along k through an LDS tile: every
+// access coalesced (an element-per-thread form scattered the transposed copies with a stride of ld_in elements).
 template <typename T>
-__global__ void lstm_pack_kernel(const float* __restrict__ W, const float* __restrict__ bias, int n_in, int U, int ld_in,
-                                 T* __restrict__ wx_t, T* __restrict__ wh_t, T* __restrict__ wh_p, T* __restrict__ wx_p,
-                                 float* __restrict__ bias_p) {
-    const int N4 = 4 * U;
-    const long total = (long)(n_in + U) * N4;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(i / N4), nat = (int)(i % N4);
-        const int g = nat / U, unit = nat % U;
-        const int pc = gate_perm_col(g, unit);
-        const float w = W[i];
-        if (k < n_in) {
-            st_from_f32<T>(wx_t, (size_t)pc * ld_in + k, w);
-            if (wx_p != nullptr) st_from_f32<T>(wx_p, (size_t)k * N4 + pc, w);
-        } else {
-            const int kk = k - n_in;
-            st_from_f32<T>(wh_t, (size_t)pc * U + kk, w);
-            st_from_f32<T>(wh_p, (size_t)kk * N4 + pc, w);
-        }
-        if (k == 0) bias_p[pc] = bias[nat];
+__global__ void __launch_bounds__(256)
+lstm_pack_tiled_kernel(const float* __restrict__ W, const float* __restrict__ bias, int n_in, int U, int ld_in, T* __restrict__ wx_t,
+                       T* __restrict__ wh_t, T* __restrict__ wh_p, T* __restrict__ wx_p, float* __restrict__ bias_p) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int pc0 = blockIdx.x * 32, ub = blockIdx.x >> 2, g = blockIdx.x & 3;
+    const int nat0 = g * U + ub * 32, N4 = 4 * U, k0 = blockIdx.y * 32;
+    const int kmax = n_in + U;              // rows of W; k in [n_in, ld_in) of wx_t is zero padding (rows k0.. may cover it)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int k = k0 + ty + 8 * jj;
+        const float wv = k < kmax ? W[(size_t)k * N4 + nat0 + tx] : 0.f;
+        tile[ty + 8 * jj][tx] = wv;
+        if (k < n_in) { if (wx_p != nullptr) st_from_f32<T>(wx_p, (size_t)k * N4 + pc0 + tx, wv); }
+        else if (k < kmax) st_from_f32<T>(wh_p, (size_t)(k - n_in) * N4 + pc0 + tx, wv);
     }
-    // zero the K padding of wx_t
-    const long padtotal = (long)N4 * (ld_in - n_in);
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < padtotal; i += (long)gridDim.x * blockDim.x) {
-        const int r = (int)(i / (ld_in - n_in)), c = n_in + (int)(i % (ld_in - n_in));
-        st_from_f32<T>(wx_t, (size_t)r * ld_in + c, 0.f);
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int pc = pc0 + ty + 8 * jj, k = k0 + tx;
+        const float wv = tile[tx][ty + 8 * jj];
+        if (k < n_in) st_from_f32<T>(wx_t, (size_t)pc * ld_in + k, wv);
+        else if (k < kmax) st_from_f32<T>(wh_t, (size_t)pc * U + (k - n_in), wv);
+    }
+    if (blockIdx.y == 0) {
+        if (ty == 0) bias_p[pc0 + tx] = bias[nat0 + tx];
+        // zero the K padding of this workgroup's 32 rows of wx_t
+        const int pad = ld_in - n_in;
+        for (int i = threadIdx.x; i < 32 * pad; i += 256) st_from_f32<T>(wx_t, (size_t)(pc0 + i / pad) * ld_in + n_in + i % pad, 0.f);
     }
 }
 
@@ -283,12 +290,12 @@ extern "C" int mnn_lstm_pack_weights(mnn_stream_t s, const float* W, const float
     MNN_REQUIRE(W && bias && wx_t && wh_t && wh_p && bias_p, "mnn_lstm_pack_weights: null pointer");
     MNN_REQUIRE(units > 0 && units % 32 == 0 && n_in > 0 && ld_in >= n_in, "mnn_lstm_pack_weights: units %% 32 != 0 or bad n_in/ld_in");
     MNN_REQUIRE(dtype == MNN_F32 || dtype == MNN_BF16, "mnn_lstm_pack_weights: dtype must be f32/bf16");
-    const int blocks = (int)min((long)1024, ((long)(n_in + units) * 4 * units + 255) / 256);
+    dim3 grid(4 * units / 32, cdiv(n_in + units, 32));
     if (dtype == MNN_F32)
-        hipLaunchKernelGGL(lstm_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, W, bias, n_in, units, ld_in, (float*)wx_t,
+        hipLaunchKernelGGL(lstm_pack_tiled_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, W, bias, n_in, units, ld_in, (float*)wx_t,
                            (float*)wh_t, (float*)wh_p, (float*)wx_p, bias_p);
     else
-        hipLaunchKernelGGL(lstm_pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, W, bias, n_in, units, ld_in, (bf16_t*)wx_t,
+        hipLaunchKernelGGL(lstm_pack_tiled_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, W, bias, n_in, units, ld_in, (bf16_t*)wx_t,
                            (bf16_t*)wh_t, (bf16_t*)wh_p, (bf16_t*)wx_p, bias_p);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
