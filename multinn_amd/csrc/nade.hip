@@ -314,6 +314,10 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
                     }
                 }
             }
+            // The next chunk's staged weights go to LDS HERE (first half only): their global loads were issued at the top of the chunk
+            // and the only younger memory operations of this wave are none -- after the exchanges the wait for them would also sit
+            // behind this chunk's f32 atomics.  The other buffer of wl was last read in the previous chunk (barrier at its end).
+            if (half == 1) st.lstore(wl[(cc + 1) & 1][0], wl[(cc + 1) & 1][1]);
             // one cross-wave exchange per 4 visibles (the per-visible barrier was 60 % of the wave time)
             __syncthreads();                             // the previous exchange has been read
 #pragma unroll
@@ -335,7 +339,6 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
                 }
             }
         }
-        st.lstore(wl[(cc + 1) & 1][0], wl[(cc + 1) & 1][1]);
         vcur = vnext;
         dcur = dnext;
         __syncthreads();
