@@ -227,7 +227,7 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
                 float* __restrict__ d_bias, float* __restrict__ d_w_enc, float* __restrict__ d_w_dec) {
     constexpr int W = HQ * 64;
     __shared__ float wl[2][2][8 * W];
-    __shared__ float red[8][4][2][W];     // [wave][visible-in-half-chunk][d w_dec | d w_enc][hidden]: one exchange per 4 visibles
+    __shared__ __attribute__((aligned(16))) float red[8][4][2][W];     // [wave][visible-in-half-chunk][d w_dec | d w_enc][hidden]: one exchange per 4 visibles
     const int m = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -320,22 +320,51 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
             if (half == 1) st.lstore(wl[(cc + 1) & 1][0], wl[(cc + 1) & 1][1]);
             // one cross-wave exchange per 4 visibles (the per-visible barrier was 60 % of the wave time)
             __syncthreads();                             // the previous exchange has been read
+            if constexpr (HQ == 4) {
+                // exchange slots are LANE-major (the four hidden units lane, lane+64, lane+128, lane+192 of a lane side by side): one
+                // 16-byte LDS store per (visible, matrix) instead of four 4-byte ones, and the summing thread -- one per (visible,
+                // matrix, lane) -- reads 8 x 16 bytes instead of 32 x 4; its four atomics each still cover 256 contiguous bytes per wave
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int q = 0; q < HQ; ++q) {
-                    red[w][k][0][lane + 64 * q] = accd[k][q];
-                    red[w][k][1][lane + 64 * q] = acce[k][q];
+                for (int k = 0; k < 4; ++k) {
+                    *reinterpret_cast<float4*>(&red[w][k][0][4 * lane]) = make_float4(accd[k][0], accd[k][1], accd[k][2], accd[k][3]);
+                    *reinterpret_cast<float4*>(&red[w][k][1][4 * lane]) = make_float4(acce[k][0], acce[k][1], acce[k][2], acce[k][3]);
                 }
-            __syncthreads();
-            for (int e = threadIdx.x; e < 4 * 2 * W; e += 512) {
-                const int k = e / (2 * W), which = (e / W) & 1, j = e % W;
-                const int i = i0 + half * 4 + k;
-                if (j < Hn && i < D) {
-                    float sum = 0.f;
+                __syncthreads();
+                {
+                    const int k = threadIdx.x >> 7, which = (threadIdx.x >> 6) & 1;       // 4 visibles x 2 matrices x 64 lanes = 512 threads
+                    const int i = i0 + half * 4 + k;
+                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int ww = 0; ww < 8; ++ww) sum += red[ww][k][which][j];
-                    atomicAdd((which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * Hn + j, sum);
+                    for (int ww = 0; ww < 8; ++ww) {
+                        const float4 p = *reinterpret_cast<const float4*>(&red[ww][k][which][4 * lane]);
+                        sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+                    }
+                    if (i < D) {
+                        float* dst = (which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * Hn + lane;
+                        if (lane < Hn) atomicAdd(dst, sum.x);
+                        if (lane + 64 < Hn) atomicAdd(dst + 64, sum.y);
+                        if (lane + 128 < Hn) atomicAdd(dst + 128, sum.z);
+                        if (lane + 192 < Hn) atomicAdd(dst + 192, sum.w);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int q = 0; q < HQ; ++q) {
+                        red[w][k][0][lane + 64 * q] = accd[k][q];
+                        red[w][k][1][lane + 64 * q] = acce[k][q];
+                    }
+                __syncthreads();
+                for (int e = threadIdx.x; e < 4 * 2 * W; e += 512) {
+                    const int k = e / (2 * W), which = (e / W) & 1, j = e % W;
+                    const int i = i0 + half * 4 + k;
+                    if (j < Hn && i < D) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int ww = 0; ww < 8; ++ww) sum += red[ww][k][which][j];
+                        atomicAdd((which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * Hn + j, sum);
+                    }
                 }
             }
         }
