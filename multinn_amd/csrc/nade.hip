@@ -82,7 +82,7 @@ struct WStage {
             re[k] = ok ? we[(size_t)i * Hn + j] : 0.f;
         }
     }
-    __device__ __forceinline__ void lstore(float* __restrict__ sd, float* __restrict__ se) {
+    __device__ __forceinline__ void lstore(float* __restrict__ sd, float* __restrict__ se) const {
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             sd[threadIdx.x + k * 512] = rd[k];
@@ -220,13 +220,31 @@ extern "C" int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, in
 // backward: reverse scan over the visible order
 // ----------------------------------------------------------------------------------------------
 #define BWD_R 8   // rows per wave
+// Staged weights of a chunk into LDS.  HQ == 4: lane-major (the hidden units lane, lane+64, lane+128, lane+192 side by side), so the
+// scan reads the four values a lane needs with one 16-byte load per matrix.
+template <int HQ>
+__device__ __forceinline__ void bwd_lstore(const WStage<HQ>& st, float* __restrict__ sd, float* __restrict__ se) {
+    if constexpr (HQ == 4) {
+        constexpr int W = 256;
+#pragma unroll
+        for (int k = 0; k < WStage<HQ>::NE; ++k) {
+            const int e = threadIdx.x + k * 512, ii = e / W, j = e % W;
+            const int pos = ii * W + (j & 63) * 4 + (j >> 6);
+            sd[pos] = st.rd[k];
+            se[pos] = st.re[k];
+        }
+    } else {
+        st.lstore(sd, se);
+    }
+}
+
 template <int HQ>
 __global__ void __launch_bounds__(512)
 nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias,
                 int ld_bias, const float* __restrict__ w_enc, const float* __restrict__ w_dec, const float* __restrict__ a_final,
                 float* __restrict__ d_bias, float* __restrict__ d_w_enc, float* __restrict__ d_w_dec) {
     constexpr int W = HQ * 64;
-    __shared__ float wl[2][2][8 * W];
+    __shared__ __attribute__((aligned(16))) float wl[2][2][8 * W];
     __shared__ __attribute__((aligned(16))) float red[8][4][2][W];     // [wave][visible-in-half-chunk][d w_dec | d w_enc][hidden]: one exchange per 4 visibles
     const int m = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -257,7 +275,7 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
     const int nch = (D + 7) / 8;
     WStage<HQ> st;
     st.gload(wd, we, (nch - 1) * 8, D, Hn);
-    st.lstore(wl[0][0], wl[0][1]);
+    bwd_lstore<HQ>(st, wl[0][0], wl[0][1]);
     int icur = (nch - 1) * 8 + fi;
     bool vcur = fvalid && icur < D && vm[(size_t)frr * D + icur] != 0;
     float dcur = (fvalid && icur < D) ? d_bias[(size_t)frr * ld_bias + dl_off + icur] : 0.f;
@@ -282,10 +300,17 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
                 for (int q = 0; q < HQ; ++q) { accd[k][q] = 0.f; acce[k][q] = 0.f; }
                 if (i >= D) continue;                                           // block-uniform (tail chunk)
                 float wev[HQ], wdv[HQ];
+                if constexpr (HQ == 4) {                                        // lane-major staging: one 16-byte LDS load per matrix
+                    const float4 d4 = *reinterpret_cast<const float4*>(sd + ii * W + 4 * lane);
+                    const float4 e4 = *reinterpret_cast<const float4*>(se + ii * W + 4 * lane);
+                    wdv[0] = d4.x; wdv[1] = d4.y; wdv[2] = d4.z; wdv[3] = d4.w;
+                    wev[0] = e4.x; wev[1] = e4.y; wev[2] = e4.z; wev[3] = e4.w;
+                } else {
 #pragma unroll
-                for (int q = 0; q < HQ; ++q) {
-                    wdv[q] = sd[ii * W + lane + 64 * q];
-                    wev[q] = se[ii * W + lane + 64 * q];
+                    for (int q = 0; q < HQ; ++q) {
+                        wdv[q] = sd[ii * W + lane + 64 * q];
+                        wev[q] = se[ii * W + lane + 64 * q];
+                    }
                 }
                 // the rows are independent: first the (rare) state changes of the rows with v_i = 1 -- skipped with ONE scalar test when
                 // none of the wave's 8 rows has one (4 visibles in 5 at rho = 0.03) --, then the FMAs of all 8 rows, straight-line
@@ -317,7 +342,7 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
             // The next chunk's staged weights go to LDS HERE (first half only): their global loads were issued at the top of the chunk
             // and the only younger memory operations of this wave are none -- after the exchanges the wait for them would also sit
             // behind this chunk's f32 atomics.  The other buffer of wl was last read in the previous chunk (barrier at its end).
-            if (half == 1) st.lstore(wl[(cc + 1) & 1][0], wl[(cc + 1) & 1][1]);
+            if (half == 1) bwd_lstore<HQ>(st, wl[(cc + 1) & 1][0], wl[(cc + 1) & 1][1]);
             // one cross-wave exchange per 4 visibles (the per-visible barrier was 60 % of the wave time)
             __syncthreads();                             // the previous exchange has been read
             if constexpr (HQ == 4) {
