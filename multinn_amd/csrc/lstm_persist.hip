@@ -132,7 +132,7 @@ struct PFwdLayer {
 struct PFwdArgs { PFwdLayer l1, l2; int T, B, nrt, G, R; float kp; unsigned* sync; int xcc_off, allow_local, sticky_off; };
 
 struct FwdTiles {
-    float red[4][4][16][64];       // K-split partial tiles
+    __attribute__((aligned(16))) float red[4][4][16][64];       // K-split partial tiles, addressed as float4 [producer wave][gate][consumer wave][lane]
     bf16_t sH[32][40];             // h tile [row][unit] (+pad)
     bf16_t sY[32][40];             // dropped output tile
     bf16_t sT[32][40];             // h tile [unit][row] for the transposed copy (weight-gradient operand)
@@ -250,6 +250,7 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
     __syncthreads();
     if (!pst_same_xcd(A.sync + A.xcc_off + grp * 32, status, member, nm, &S.abort, &S.local, A.sticky_off)) return;
     const bool local = A.allow_local && S.local != 0;
+    float4* red4 = reinterpret_cast<float4*>(&S.red[0][0][0][0]);
     FwdTail tl;
     tl.valid = false;
 #pragma unroll
@@ -309,20 +310,26 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             for (int s = 0; s < KS1; ++s)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[g][s], acc[g], 0, 0, 0);
+            // K-split partials through LDS, 16 bytes per access: slot (producer wave, gate, consumer wave, lane) holds the four accumulator
+            // elements 4 w' .. 4 w' + 3 that consumer wave w' reduces (16 stores + 16 loads per thread and item instead of 64 + 64)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int k = 0; k < 16; ++k) S.red[w][g][k][lane] = acc[g][k];
+                for (int wc = 0; wc < 4; ++wc)
+                    red4[((w * 4 + g) * 4 + wc) * 64 + lane] = make_float4(acc[g][4 * wc], acc[g][4 * wc + 1], acc[g][4 * wc + 2], acc[g][4 * wc + 3]);
             lds_barrier();
             float z[4][4], cp[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = 4 * w + q;
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    z[q][g] = xp[q][g] + ((S.red[0][g][k][lane] + S.red[1][g][k][lane]) + (S.red[2][g][k][lane] + S.red[3][g][k][lane]));
-                cp[q] = (Rv == 1 && t > 0) ? tl.cv[q] : cl[q];
+            for (int g = 0; g < 4; ++g) {
+                const float4 p0 = red4[((0 * 4 + g) * 4 + w) * 64 + lane], p1 = red4[((1 * 4 + g) * 4 + w) * 64 + lane];
+                const float4 p2 = red4[((2 * 4 + g) * 4 + w) * 64 + lane], p3 = red4[((3 * 4 + g) * 4 + w) * 64 + lane];
+                z[0][g] = xp[0][g] + ((p0.x + p1.x) + (p2.x + p3.x));
+                z[1][g] = xp[1][g] + ((p0.y + p1.y) + (p2.y + p3.y));
+                z[2][g] = xp[2][g] + ((p0.z + p1.z) + (p2.z + p3.z));
+                z[3][g] = xp[3][g] + ((p0.w + p1.w) + (p2.w + p3.w));
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cp[q] = (Rv == 1 && t > 0) ? tl.cv[q] : cl[q];
             PST_TR(trc, 2);
             pf_finish(L, S, T, nrt, t, rt, nt, A.kp, z, cp, mk, tl, flags + rt * 32 + member, local, trc);
 #pragma unroll
@@ -384,20 +391,26 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             for (int s = 0; s < KS2; ++s)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s], bh[g][s], acc[g], 0, 0, 0);
+            // K-split partials through LDS, 16 bytes per access: slot (producer wave, gate, consumer wave, lane) holds the four accumulator
+            // elements 4 w' .. 4 w' + 3 that consumer wave w' reduces (16 stores + 16 loads per thread and item instead of 64 + 64)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int k = 0; k < 16; ++k) S.red[w][g][k][lane] = acc[g][k];
+                for (int wc = 0; wc < 4; ++wc)
+                    red4[((w * 4 + g) * 4 + wc) * 64 + lane] = make_float4(acc[g][4 * wc], acc[g][4 * wc + 1], acc[g][4 * wc + 2], acc[g][4 * wc + 3]);
             lds_barrier();
             float z[4][4], cp[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = 4 * w + q;
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    z[q][g] = bz[g] + ((S.red[0][g][k][lane] + S.red[1][g][k][lane]) + (S.red[2][g][k][lane] + S.red[3][g][k][lane]));
-                cp[q] = (Rv == 1 && t > 0) ? tl.cv[q] : cl[q];
+            for (int g = 0; g < 4; ++g) {
+                const float4 p0 = red4[((0 * 4 + g) * 4 + w) * 64 + lane], p1 = red4[((1 * 4 + g) * 4 + w) * 64 + lane];
+                const float4 p2 = red4[((2 * 4 + g) * 4 + w) * 64 + lane], p3 = red4[((3 * 4 + g) * 4 + w) * 64 + lane];
+                z[0][g] = bz[g] + ((p0.x + p1.x) + (p2.x + p3.x));
+                z[1][g] = bz[g] + ((p0.y + p1.y) + (p2.y + p3.y));
+                z[2][g] = bz[g] + ((p0.z + p1.z) + (p2.z + p3.z));
+                z[3][g] = bz[g] + ((p0.w + p1.w) + (p2.w + p3.w));
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cp[q] = (Rv == 1 && t > 0) ? tl.cv[q] : cl[q];
             PST_TR(trc, 2);
             pf_finish(L, S, T, nrt, t, rt, nt, A.kp, z, cp, mk, tl, flags + rt * 32 + member, local, trc);
             PST_TR(trc, 5);
@@ -432,7 +445,7 @@ struct PBwdLayer {
 struct PBwdArgs { PBwdLayer l1, l2; int T, B, nrt, G, R; float kp; unsigned* sync; int xcc_off, allow_local, sticky_off; };
 
 struct BwdTiles {
-    float red[2][8][16][64];
+    __attribute__((aligned(16))) float red[2][8][16][64];      // addressed as float2 [set][producer wave][consumer wave][lane]
     bf16_t sZ[32][136];            // dz tile [row][gate*32 + unit] (+pad)
     bf16_t sT[4][32][40];          // dz tile [gate][unit][row] for the transposed copy
     int abort, local;
@@ -553,6 +566,7 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
     __syncthreads();
     if (!pst_same_xcd(A.sync + A.xcc_off + grp * 32, status, member, nm, &S.abort, &S.local, A.sticky_off)) return;
     const bool local = A.allow_local && S.local != 0;
+    float2* red2 = reinterpret_cast<float2*>(&S.red[0][0][0][0]);
     BwdTail tl;
     tl.valid = false;
     tl.dcv[0] = tl.dcv[1] = 0.f;
@@ -594,17 +608,19 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
 #pragma unroll
             for (int s = 0; s < KB; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bw[s], acc, 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) S.red[0][w][j][lane] = acc[j];
+            for (int wc = 0; wc < 8; ++wc) red2[((0 * 8 + w) * 8 + wc) * 64 + lane] = make_float2(acc[2 * wc], acc[2 * wc + 1]);     // 8-byte slots: see the forward kernel
             lds_barrier();
             float dh[2], e_dc[2];
+            float sum2[2] = {0.f, 0.f};
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) {
+                const float2 p = red2[((0 * 8 + ww) * 8 + w) * 64 + lane];
+                sum2[0] += p.x; sum2[1] += p.y;
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int j = 2 * w + q;
-                float sum = 0.f;
-#pragma unroll
-                for (int ww = 0; ww < 8; ++ww) sum += S.red[0][ww][j][lane];
                 // layer 2's mask, when given, says dh_ext is the gradient wrt the DROPPED output: dropout backward happens here (dy / kp * keep)
-                dh[q] = (L.mask != nullptr ? e[q].dh / A.kp * (float)e[q].keep : e[q].dh) + sum;
+                dh[q] = (L.mask != nullptr ? e[q].dh / A.kp * (float)e[q].keep : e[q].dh) + sum2[q];
                 e_dc[q] = (Rv == 1 && k > 0) ? tl.dcv[q] : dcl[q];
             }
             PST_TR(trc, 2);
@@ -652,16 +668,21 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
 #pragma unroll
             for (int s = 0; s < KA; ++s) accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[s], bw[s], accw, 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { S.red[0][w][j][lane] = accq[j]; S.red[1][w][j][lane] = accw[j]; }
+            for (int wc = 0; wc < 8; ++wc) {
+                red2[((0 * 8 + w) * 8 + wc) * 64 + lane] = make_float2(accq[2 * wc], accq[2 * wc + 1]);
+                red2[((1 * 8 + w) * 8 + wc) * 64 + lane] = make_float2(accw[2 * wc], accw[2 * wc + 1]);
+            }
             lds_barrier();
             float dh[2], e_dc[2];
+            float sq2[2] = {0.f, 0.f}, sw2[2] = {0.f, 0.f};
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) {
+                const float2 pq = red2[((0 * 8 + ww) * 8 + w) * 64 + lane], pw = red2[((1 * 8 + ww) * 8 + w) * 64 + lane];
+                sq2[0] += pq.x; sq2[1] += pq.y; sw2[0] += pw.x; sw2[1] += pw.y;
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int j = 2 * w + q;
-                float sq = 0.f, sw = 0.f;
-#pragma unroll
-                for (int ww = 0; ww < 8; ++ww) { sq += S.red[0][ww][j][lane]; sw += S.red[1][ww][j][lane]; }
-                dh[q] = (L.mask != nullptr ? sq * ((float)e[q].keep / A.kp) : sq) + sw;
+                dh[q] = (L.mask != nullptr ? sq2[q] * ((float)e[q].keep / A.kp) : sq2[q]) + sw2[q];
                 e_dc[q] = (Rv == 1 && k > 0) ? tl.dcv[q] : dcl[q];
             }
             PST_TR(trc, 2);
