@@ -451,9 +451,9 @@ struct BwdTiles {
     int abort, local;
 };
 struct BwdEpi { float dh, g[4], c, cp; unsigned keep; };      // per fragment row: external gradient, gates, cell states, raw keep byte
-struct BwdTail { float dcv[2]; float dbv; int t, m0; bool valid; };      // dbv: threads 0..127: running column sum of the dz tiles (bias gradient)
+struct BwdTail { float dcv[2]; float dbv[4]; int t, m0; bool valid; };   // dbv[g]: this thread's running sum of dz (gate g, its unit, its rows): bias gradient
 
-__device__ __forceinline__ void pb_finish(const PBwdLayer& L, BwdTiles& S, int nrt, int t, int rt, int nt, const float (&dh)[2], const BwdEpi (&e)[2],
+__device__ __forceinline__ void pb_finish(const PBwdLayer& L, BwdTiles& S, int B, int nrt, int t, int rt, int nt, const float (&dh)[2], const BwdEpi (&e)[2],
                                           const float (&e_dc)[2], BwdTail& tl, unsigned* flag, unsigned epoch, bool local, long long* trc) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -467,11 +467,13 @@ __device__ __forceinline__ void pb_finish(const PBwdLayer& L, BwdTiles& S, int n
         const float d_c = dh[q] * go * (1.f - tc * tc) + e_dc[q];
         const float dzv[4] = {d_c * gg * gi * (1.f - gi), d_c * gi * (1.f - gg * gg), d_c * e[q].cp * gf * (1.f - gf), d_o * go * (1.f - go)};
         tl.dcv[q] = d_c * gf;
+        const bool rowok = rt * 32 + lr < B;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const bf16_t bv = f32_to_bf16(dzv[g]);
             S.sZ[lr][32 * g + r] = bv;
             if (L.dzTt != nullptr) S.sT[g][r][lr] = bv;
+            tl.dbv[g] += rowok ? bf16_to_f32(bv) : 0.f;          // the (bf16) values the weight-gradient GEMMs see, summed in registers
         }
     }
     tl.t = t; tl.m0 = rt * 32; tl.valid = true;
@@ -488,12 +490,6 @@ __device__ __forceinline__ void pb_finish(const PBwdLayer& L, BwdTiles& S, int n
 
 __device__ __forceinline__ void pb_tail(const PBwdLayer& L, const BwdTiles& S, int B, int Rv, int nt, BwdTail& tl) {
     if (!tl.valid) return;
-    if (L.db_p != nullptr && threadIdx.x < 128) {   // bias gradient: column sums of the (bf16) dz tile that is still in LDS
-        const int rows = min(32, B - tl.m0);
-        float sum = 0.f;
-        for (int rr = 0; rr < rows; ++rr) sum += bf16_to_f32(S.sZ[rr][threadIdx.x]);
-        tl.dbv += sum;
-    }
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int U = L.U, unit = nt * 32 + r, t = tl.t, m0 = tl.m0;
@@ -519,9 +515,24 @@ __device__ __forceinline__ void pb_tail(const PBwdLayer& L, const BwdTiles& S, i
     }
 }
 
-// End of the launch: one f32 atomic per gate column (the other row tiles' workgroups add to the same words).
-__device__ __forceinline__ void pb_flush_db(const PBwdLayer& L, int nt, const BwdTail& tl) {
-    if (L.db_p != nullptr && threadIdx.x < 128) atomicAdd(L.db_p + nt * 128 + threadIdx.x, tl.dbv);
+// End of the launch: the 16 per-thread partial sums of every gate column (8 waves x 2 lane halves) meet in LDS once, then one f32
+// atomic per column (the other row tiles' workgroups add to the same words).  Per item this costs four adds in registers; reading
+// the 32 rows of the dz tile back from LDS per item (32 2-byte loads for a quarter of the threads) sat in front of every MFMA chain.
+__device__ __forceinline__ void pb_flush_db(const PBwdLayer& L, BwdTiles& S, int nt, const BwdTail& tl) {
+    if (L.db_p == nullptr) return;                       // uniform
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    float* part = &S.red[0][0][0][0];                    // [16 (w, hh)][128 columns]: the K-split area is idle by now
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) part[(2 * w + hh) * 128 + 32 * g + r] = tl.dbv[g];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum += part[k * 128 + threadIdx.x];
+        atomicAdd(L.db_p + nt * 128 + threadIdx.x, sum);
+    }
 }
 
 // Epilogue operands of one (t, row tile) for this wave's 2 fragment rows: unconditional loads (see the rule above).
@@ -570,7 +581,7 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
     BwdTail tl;
     tl.valid = false;
     tl.dcv[0] = tl.dcv[1] = 0.f;
-    tl.dbv = 0.f;
+    tl.dbv[0] = tl.dbv[1] = tl.dbv[2] = tl.dbv[3] = 0.f;
     if (member < nb2) {
         // ---------------- layer 2 (leads) ----------------
         const PBwdLayer& L = A.l2;
@@ -624,12 +635,12 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
                 e_dc[q] = (Rv == 1 && k > 0) ? tl.dcv[q] : dcl[q];
             }
             PST_TR(trc, 2);
-            pb_finish(L, S, nrt, t, rt, nt, dh, e, e_dc, tl, flags + rt * 32 + member, (unsigned)(k + 1), local, trc);
+            pb_finish(L, S, B, nrt, t, rt, nt, dh, e, e_dc, tl, flags + rt * 32 + member, (unsigned)(k + 1), local, trc);
             e[0] = en[0]; e[1] = en[1];
             PST_TR(trc, 5);
         }
         pb_tail(L, S, B, Rv, nt, tl);
-        pb_flush_db(L, nt, tl);
+        pb_flush_db(L, S, nt, tl);
     } else {
         // ---------------- layer 1 ----------------
         const PBwdLayer& L = A.l1;
@@ -686,11 +697,11 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
                 e_dc[q] = (Rv == 1 && k > 0) ? tl.dcv[q] : dcl[q];
             }
             PST_TR(trc, 2);
-            pb_finish(L, S, nrt, t, rt, nt, dh, e, e_dc, tl, flags + rt * 32 + member, (unsigned)(k + 1), local, trc);
+            pb_finish(L, S, B, nrt, t, rt, nt, dh, e, e_dc, tl, flags + rt * 32 + member, (unsigned)(k + 1), local, trc);
             PST_TR(trc, 5);
         }
         pb_tail(L, S, B, Rv, nt, tl);
-        pb_flush_db(L, nt, tl);
+        pb_flush_db(L, S, nt, tl);
     }
 }
 
