@@ -591,8 +591,8 @@ class RnnNade(RnnEstimator):
             out[:, self.n_out:].zero_()
         ops.gemm_tn(y.view(N, -1), self._fc_t, out[:, :self.n_out], bias=self.store["dense/bias"])
         nll = torch.empty((M, N), device=dev)
-        cond_p = torch.empty((M, N, D), device=dev)
-        rw_m = rw / M if M > 1 else rw
+        cond_p = None if train else torch.empty((M, N, D), device=dev)     # the train step needs the loss only: 4 N D bytes less to write per
+        rw_m = rw / M if M > 1 else rw                                       # step; `cond_probs` fills it on demand (see the property)
         d_out = None
         if train:
             d_out = torch.empty((N, self.ldo), device=dev)
@@ -628,6 +628,17 @@ class RnnNade(RnnEstimator):
 
     @property
     def cond_probs(self):
+        if self._cond_tm is None:           # built in train mode: one more decoder pass over the saved Dense output, conditionals only
+            cx = self._ctx
+            M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
+            N = cx["B"] * cx["T"]
+            cp = torch.empty((M, N, D), device=cx["out"].device)
+            if self._nade_mfma():
+                ops.nade_logprob_fwd_mfma(cx["v"].view(M, N, D), cx["out"], self.store["nade/w_enc"], self._wdec_bf, M, D, Hn, None, None, cp, None, None)
+            else:
+                ops.nade_logprob_fwd(cx["v"].view(M, N, D), cx["out"], self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn, None, None, cp, None,
+                                     None)
+            self._cond_tm = cp
         r = [self._cond_tm[m][self._idx()] for m in range(self.num_tracks)]
         return r[0] if self.num_tracks == 1 else r
 

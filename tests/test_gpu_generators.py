@@ -538,6 +538,22 @@ def test_two_graph_data_parallel_step_matches_eager(monkeypatch):
     assert torch.allclose(a.store.theta, b.store.theta, atol=3e-3)
 
 
+def test_cond_probs_on_demand_after_a_train_mode_build():
+    """The train step does not store the conditionals (only the loss needs them); `cond_probs` then runs one more decoder pass over
+    the saved Dense output and must equal what an eval-mode build of the same batch returns."""
+    from multinn_amd import RnnNade
+    x = make_batch(6, 9, 8, 2, 11, rho=0.2)
+    for prec in ("fp32", "bf16"):
+        a = RnnNade(16, 256 if prec == "bf16" else 16, [128, 128], keep_prob=1.0, precision=prec, seed=3)
+        a.build_pianoroll(dev(x), None, is_train=True, mode="train")
+        assert a._cond_tm is None
+        cp_train = a.cond_probs
+        lp_train = a.log_probs
+        a.build_pianoroll(dev(x), None, is_train=False, mode="eval")
+        assert a._cond_tm is not None
+        assert torch.equal(cp_train, a.cond_probs) and torch.allclose(lp_train, a.log_probs, rtol=1e-6, atol=1e-6)
+
+
 def test_training_reduces_loss():
     from multinn_amd import RnnNade, AdamOptimizer
     x = make_batch(8, 8, 8, 2, 5, rho=0.1)
