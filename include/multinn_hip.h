@@ -262,7 +262,7 @@ int mnn_step_increment(mnn_stream_t s, int32_t* step_dev);
 int mnn_bias_grad(mnn_stream_t s, const float* dY, int rows, int cols, int ld, float* db, int accumulate);
 int mnn_fill_f32(mnn_stream_t s, float* x, long n, float value);
 /* One pass over the f32 gradient block dY[rows, cols_c] of the dense layer (rnn_estimator.py:205-215's tf.gradients through the
- * Dense layer): out_c = bf16 copy [rows, ld_c]; out_t = bf16 transpose of the first cols_t columns [cols_t, ld_t >= rows];
+ * Dense layer): out_c = bf16 copy [rows, ld_c] with the padding columns [cols_t, cols_c) written as zeros (dY's are not read); out_t = bf16 transpose of the first cols_t columns [cols_t, ld_t >= rows];
  * db[c] += column sums for c < cols_t.  Replaces convert2d + transpose + bias_grad (three reads of dY) in bf16 mode. */
 int mnn_grad_rows_fanout(mnn_stream_t s, const float* dY, int rows, int cols_c, int cols_t, int ld, void* out_c, int ld_c, void* out_t,
                          int ld_t, float* db);

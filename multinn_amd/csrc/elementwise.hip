@@ -654,7 +654,7 @@ extern "C" int mnn_bias_grad(mnn_stream_t s, const float* dY, int rows, int cols
 }
 
 // One pass over an f32 gradient block dY[rows, cols_c] that feeds three consumers (generators.py backward of the dense layer):
-//   out_c[r, c]  = bf16(dY[r, c])            c < cols_c   (A operand of the data-gradient GEMM)
+//   out_c[r, c]  = bf16(dY[r, c])            c < cols_t, 0 for cols_t <= c < cols_c   (A operand of the data-gradient GEMM, K padded)
 //   out_t[c, r]  = bf16(dY[r, c])            c < cols_t   (B operand of the weight-gradient GEMM, K-major)
 //   db[c]       += sum_r dY[r, c]            c < cols_t   (bias gradient)
 // instead of mnn_convert2d + mnn_transpose + mnn_bias_grad, each of which re-read the f32 block.
@@ -672,14 +672,14 @@ grad_rows_fanout_kernel(const float* __restrict__ dY, int rows, int cols_c, int 
         for (int k = 0; k < 4; ++k) {
             const int r = r0 + ty + 16 * k, c = c0 + 4 * tx;
             float x[4] = {0.f, 0.f, 0.f, 0.f};
-            if (r < rows) {
-                if (c + 3 < cols_c && (ld & 3) == 0) {
+            if (r < rows) {                 // columns [cols_t, cols_c) are padding: written as zeros, never read (dY's may be uninitialised)
+                if (c + 3 < cols_t && (ld & 3) == 0) {
                     const float4 q = *reinterpret_cast<const float4*>(dY + (size_t)r * ld + c);
                     x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (c + e < cols_c) x[e] = dY[(size_t)r * ld + c + e];
+                        if (c + e < cols_t) x[e] = dY[(size_t)r * ld + c + e];
                 }
             }
             bf16_t b[4];

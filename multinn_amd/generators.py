@@ -586,9 +586,7 @@ class RnnNade(RnnEstimator):
         y, ctx, _ = self._stack.forward(x_tm, kp, self.seed, self.row0, save=train, step_dev=self.store.step_dev)
         if ctx and x_tmT is not None:
             ctx[0]["inT"] = x_tmT
-        out = torch.empty((N, self.ldo), device=dev)
-        if self.ldo != self.n_out:
-            out[:, self.n_out:].zero_()
+        out = torch.empty((N, self.ldo), device=dev)      # columns >= n_out are padding of the row pitch: never read
         ops.gemm_tn(y.view(N, -1), self._fc_t, out[:, :self.n_out], bias=self.store["dense/bias"])
         nll = torch.empty((M, N), device=dev)
         cond_p = None if train else torch.empty((M, N, D), device=dev)     # the train step needs the loss only: 4 N D bytes less to write per
@@ -596,8 +594,8 @@ class RnnNade(RnnEstimator):
         d_out = None
         if train:
             d_out = torch.empty((N, self.ldo), device=dev)
-            if self.ldo != self.n_out:
-                d_out[:, self.n_out:].zero_()
+            if self.ldo != self.n_out and self.dtype == torch.float32:
+                d_out[:, self.n_out:].zero_()       # fp32: d_out itself is the dgrad operand; bf16: grad_rows_fanout writes the zero padding
         a_fin = torch.empty((M, N, Hn), device=dev) if train else None
         if self._nade_mfma():
             # bf16 compute mode: the decoder dot products run as a block-sparse bf16 GEMM over each row's hidden states
