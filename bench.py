@@ -184,13 +184,13 @@ def main():
     # fabric-side bytes per launch of that kernel: rocprofv3 PMC passes recorded under profiles/ (FETCH_SIZE and WRITE_SIZE cannot
     # be collected from inside this process); only for the workload they were measured on
     try:
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_h_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_o_pmc_traffic.json")))
         if a.workload == "c2" and a.precision == "bf16":
             hit = [v for k, v in pmc["kernels"].items() if k.startswith(roof["kernel"])]
             if hit:
                 roof["traffic"] = hit[0]["hbm_side_bytes_per_launch"]
                 roof["traffic_unit"] = "bytes/launch"
-                roof["traffic_source"] = "profiles/round1_h_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
+                roof["traffic_source"] = "profiles/round1_o_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
     except (OSError, ValueError, KeyError):
         pass
 
