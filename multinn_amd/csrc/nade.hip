@@ -220,19 +220,29 @@ extern "C" int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, in
 // backward: reverse scan over the visible order
 // ----------------------------------------------------------------------------------------------
 #define BWD_R 8   // rows per wave
-// Staged weights of a chunk into LDS.  HQ == 4: lane-major (the hidden units lane, lane+64, lane+128, lane+192 side by side), so the
-// scan reads the four values a lane needs with one 16-byte load per matrix.
+// Staging for the backward kernel.  HQ == 4: lane-major in LDS (the hidden units l, l+64, l+128, l+192 side by side), so the scan reads
+// the four values a lane needs with one 16-byte load per matrix.  Thread (visible t >> 6, slot l = t & 63) fetches exactly those four
+// values (four loads, each 256 contiguous bytes per wave) and stores them with ONE conflict-free 16-byte LDS store per matrix.
+template <int HQ>
+__device__ __forceinline__ void bwd_gload(WStage<HQ>& st, const float* __restrict__ wd, const float* __restrict__ we, int i0, int D, int Hn) {
+    if constexpr (HQ == 4) {
+        const int i = i0 + (int)(threadIdx.x >> 6), l = threadIdx.x & 63;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = i >= 0 && i < D && l + 64 * q < Hn;
+            st.rd[q] = ok ? wd[(size_t)i * Hn + l + 64 * q] : 0.f;
+            st.re[q] = ok ? we[(size_t)i * Hn + l + 64 * q] : 0.f;
+        }
+    } else {
+        st.gload(wd, we, i0, D, Hn);
+    }
+}
 template <int HQ>
 __device__ __forceinline__ void bwd_lstore(const WStage<HQ>& st, float* __restrict__ sd, float* __restrict__ se) {
     if constexpr (HQ == 4) {
-        constexpr int W = 256;
-#pragma unroll
-        for (int k = 0; k < WStage<HQ>::NE; ++k) {
-            const int e = threadIdx.x + k * 512, ii = e / W, j = e % W;
-            const int pos = ii * W + (j & 63) * 4 + (j >> 6);
-            sd[pos] = st.rd[k];
-            se[pos] = st.re[k];
-        }
+        const int pos = (int)(threadIdx.x >> 6) * 256 + 4 * (int)(threadIdx.x & 63);
+        *reinterpret_cast<float4*>(sd + pos) = make_float4(st.rd[0], st.rd[1], st.rd[2], st.rd[3]);
+        *reinterpret_cast<float4*>(se + pos) = make_float4(st.re[0], st.re[1], st.re[2], st.re[3]);
     } else {
         st.lstore(sd, se);
     }
@@ -274,7 +284,7 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
     const int frr = fvalid ? frow : N - 1;
     const int nch = (D + 7) / 8;
     WStage<HQ> st;
-    st.gload(wd, we, (nch - 1) * 8, D, Hn);
+    bwd_gload<HQ>(st, wd, we, (nch - 1) * 8, D, Hn);
     bwd_lstore<HQ>(st, wl[0][0], wl[0][1]);
     int icur = (nch - 1) * 8 + fi;
     bool vcur = fvalid && icur < D && vm[(size_t)frr * D + icur] != 0;
@@ -283,7 +293,7 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
     for (int cc = 0; cc < nch; ++cc) {
         const int i0 = (nch - 1 - cc) * 8;
         const int inext = i0 - 8 + fi;
-        st.gload(wd, we, i0 - 8, D, Hn);                                      // next (lower) chunk, zeros below 0
+        bwd_gload<HQ>(st, wd, we, i0 - 8, D, Hn);                             // next (lower) chunk, zeros below 0
         const bool vnext = fvalid && inext >= 0 && vm[(size_t)frr * D + inext] != 0;
         const float dnext = (fvalid && inext >= 0) ? d_bias[(size_t)frr * ld_bias + dl_off + inext] : 0.f;
         const unsigned long long mask = __ballot(vcur);
