@@ -47,3 +47,38 @@ def test_loss_accumulator_and_stats(tmp_path):
     t = TrainingStats()
     assert t.load(str(tmp_path / "steps")) and (t.steps, t.epoch, t.metric_best, t.run) == (1, 1, 1.5, 2)
     assert not TrainingStats().load(str(tmp_path / "missing"))
+
+
+def test_split_k_heuristic_targets_workgroup_counts():
+    """LstmStack._split_k: about 512 workgroups of 128 x 128 tiles below K = 64 k (every slice adds its tile with f32 atomics, which run
+    at one chip-wide rate), about 1024 above, never more slices than K / 1024, at least one."""
+    from multinn_amd.generators import LstmStack
+    sk = LstmStack._split_k
+    assert sk(2048, 448, 32768) == 8 and sk(2048, 512, 32768) == 8          # C2 layer 1: 64 tiles
+    assert sk(1024, 512, 32768) == 16 and sk(1024, 256, 32768) == 32        # C2 layer 2: 32 / 16 tiles
+    assert sk(2048, 448, 262144) == 16 and sk(1024, 256, 262144) == 64      # TGT: twice the slices
+    assert sk(2048, 448, 2048) == 2 and sk(64, 64, 512) == 1 and sk(128, 128, 100) == 1
+
+
+def test_data_parallel_switch_needs_a_process_group(monkeypatch):
+    """training.dp_active: false without an initialised process group, whatever the rehearsal variable says."""
+    from multinn_amd import training
+    monkeypatch.setenv("MULTINN_DP_REHEARSAL", "1")
+    assert training.dp_active() is False
+    import torch
+    g = torch.ones(4)
+    assert training.allreduce_flat(g) is g and float(g.sum()) == 4.0
+
+
+def test_bench_cli_contract():
+    """bench.py's flags as the driver passes them (no GPU touched: only the argument parser and the workload table)."""
+    import ast
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    tree = ast.parse(src)
+    flags = {a.value for n in ast.walk(tree) if isinstance(n, ast.Call) and getattr(n.func, "attr", "") == "add_argument"
+             for a in n.args if isinstance(a, ast.Constant)}
+    assert {"--gpus", "--steps", "--warmup"} <= flags
+    for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"', '"higher_is_better"', '"scaling"',
+                '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"'):
+        assert key in src, key
