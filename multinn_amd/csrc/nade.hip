@@ -226,12 +226,15 @@ extern "C" int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, in
 template <int HQ>
 __device__ __forceinline__ void bwd_gload(WStage<HQ>& st, const float* __restrict__ wd, const float* __restrict__ we, int i0, int D, int Hn) {
     if constexpr (HQ == 4) {
-        const int i = i0 + (int)(threadIdx.x >> 6), l = threadIdx.x & 63;
+        const int i = i0 + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;     // the visible is wave-uniform
+        const bool rowok = i >= 0 && i < D;                                                                  // scalar
+        const float* __restrict__ pd = wd + (size_t)(rowok ? i : 0) * Hn + l;                                // uniform row base + lane
+        const float* __restrict__ pe = we + (size_t)(rowok ? i : 0) * Hn + l;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const bool ok = i >= 0 && i < D && l + 64 * q < Hn;
-            st.rd[q] = ok ? wd[(size_t)i * Hn + l + 64 * q] : 0.f;
-            st.re[q] = ok ? we[(size_t)i * Hn + l + 64 * q] : 0.f;
+            const bool ok = rowok && l + 64 * q < Hn;
+            st.rd[q] = ok ? pd[64 * q] : 0.f;                // immediate offsets 0, 256, 512, 768 bytes
+            st.re[q] = ok ? pe[64 * q] : 0.f;
         }
     } else {
         st.gload(wd, we, i0, D, Hn);
