@@ -473,6 +473,32 @@ def test_persistent_recurrence_with_initial_state():
     assert float((yz.float() - y1.float()).abs().max()) > 5e-2
 
 
+def test_persistent_hand_offs_write_through_form_gives_the_same_bits(monkeypatch):
+    """The store policy of the hand-offs (write-back inside one XCD when a row tile's workgroups share it, device-scope write-through
+    otherwise) must not change a single bit: run one train-mode build + backward both ways (MNN_PERSIST_NO_LOCAL forces the second)."""
+    from multinn_amd import RnnNade
+    x = make_batch(96, 10, 8, 2, 13, rho=0.2)
+
+    def run():
+        g = RnnNade(16, 16, [256, 128], keep_prob=0.9, precision="bf16", seed=3)
+        g._materialize(16)
+        g._ensure_packed()
+        g._stack.keep_debug = True
+        g.build_pianoroll(dev(x), None, is_train=True, mode="train")
+        g.backward()
+        g._stack.check()
+        assert g._stack._persist(96)
+        return g._nll_tm.clone(), [t.clone() for t in g._stack._dbg_dzT]
+
+    nll_a, dz_a = run()
+    monkeypatch.setenv("MNN_PERSIST_NO_LOCAL", "1")
+    nll_b, dz_b = run()
+    monkeypatch.delenv("MNN_PERSIST_NO_LOCAL")
+    assert torch.equal(nll_a, nll_b)
+    for ta, tb in zip(dz_a, dz_b):
+        assert torch.equal(ta, tb)
+
+
 def test_persistent_launch_gives_up_loudly(monkeypatch):
     """A persistent launch whose status word is raised (here by the MNN_PERSIST_TEST_ABORT hook; in production by a workgroup whose
     bounded spin ran out) must drain -- every workgroup leaves at its next wait -- and the failure must stay visible to
