@@ -201,11 +201,14 @@ def test_bench_data_parallel_rehearsal_over_rccl():
     MULTINN_DP_REHEARSAL=1 so that the step takes the two-graph form with the eager all-reduce of the flat gradient between
     them.  With hipMemsetAsync nodes in the graphs this run failed on the second replay (stale 16-byte fill pattern over the
     hand-off flags -> 'persistent LSTM launch timed out'); the library now fills with its own kernels."""
-    import json, os, subprocess, sys
+    import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:                          # a free rendezvous port on the loopback
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, MULTINN_DP_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29653", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
