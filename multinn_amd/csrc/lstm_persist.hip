@@ -235,6 +235,72 @@ __device__ __forceinline__ void pf_tail(const PFwdLayer& L, const FwdTiles& S, i
     }
 }
 
+// Per-thread BYTE offsets of this thread's epilogue / tail accesses inside a 32-row tile, computed once per launch.  Every access of an
+// item is then  (wave-uniform 64-bit base of the (t, row tile))  +  (one of these 32-bit offsets): scalar address arithmetic and a
+// `global_* v_off, s[base]` instruction.  Forming `(size_t)t * 4 * B * U + (size_t)row * 4U + unit * 4` per lane and per access, under
+// per-row `row < B` masks, was ~20 instructions and three branches per store: the deferred stores of an item cost 1.0 us of the 4.4 us
+// step (scratch/persist_trace.hip with the tail removed: 3.34 us).
+struct FwdLane {
+    unsigned og[4], oc[4];         // gate-minor float4 (gates, xproj) / per-unit float (c) of fragment rows q = 0..3, full tile
+    unsigned ogl[4], ocl[4];       // the same with rows clamped to the LAST row tile (when B is not a multiple of 32)
+    unsigned om[4], oml[4];        // keep-mask bytes
+    unsigned oh, oyT, ohT;         // 16-byte pieces of the row-major h / y tile and of the transposed tiles
+    bool al8;                      // B, ld_yT, ld_hT multiples of 8: the 16-byte tile stores are aligned
+};
+__device__ __forceinline__ void fwd_lane_init(FwdLane& fl, const PFwdLayer& L, int B, int nrt, int nt) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5, U = L.U, unit = nt * 32 + r;
+    const int last_rows = B - (nrt - 1) * 32;               // rows of the last tile (1..32)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = 8 * w + q + 4 * hh, rowl = min(row, last_rows - 1);
+        fl.og[q] = (unsigned)(row * 4 * U + unit * 4) * 4u;  fl.ogl[q] = (unsigned)(rowl * 4 * U + unit * 4) * 4u;
+        fl.oc[q] = (unsigned)(row * U + unit) * 4u;          fl.ocl[q] = (unsigned)(rowl * U + unit) * 4u;
+        fl.om[q] = (unsigned)(row * U + unit);               fl.oml[q] = (unsigned)(rowl * U + unit);
+    }
+    const int tt = threadIdx.x & 127;
+    fl.oh = (unsigned)((tt >> 2) * U + (tt & 3) * 8) * 2u;
+    fl.oyT = (unsigned)((tt >> 2) * L.ld_yT + (tt & 3) * 8) * 2u;
+    fl.ohT = (unsigned)((tt >> 2) * L.ld_hT + (tt & 3) * 8) * 2u;
+    fl.al8 = (B & 7) == 0 && (L.ld_yT & 7) == 0 && (L.ld_hT & 7) == 0;
+}
+// Deferred plain stores of a finished item when its row tile is full and everything is 16-byte aligned: no per-row predicate, uniform bases.
+__device__ __forceinline__ void pf_tail_fast(const PFwdLayer& L, const FwdTiles& S, int T, int B, int nt, const FwdTail& tl, const FwdLane& fl) {
+    const int U = L.U, t = tl.t, m0 = tl.m0;
+    const size_t us = (size_t)B * U;
+    if (L.gates != nullptr) {                                // uniform
+        char* gb = reinterpret_cast<char*>(L.gates + (size_t)t * 4 * us + (size_t)m0 * 4 * U);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(gb + fl.og[q]) = make_float4(tl.gv[q][0], tl.gv[q][1], tl.gv[q][2], tl.gv[q][3]);
+    }
+    {
+        char* cb = reinterpret_cast<char*>(L.c + (size_t)t * us + (size_t)m0 * U);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float*>(cb + fl.oc[q]) = tl.cv[q];
+    }
+    const bool second = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)) != 0;     // waves 2, 3
+    const int tt = threadIdx.x & 127, row = tt >> 2, piece = tt & 3;
+    if (!second || L.mask != nullptr) {
+        char* hb = reinterpret_cast<char*>((second ? L.y : L.h) + (size_t)t * us + (size_t)m0 * U + nt * 32);
+        *reinterpret_cast<uint4*>(hb + fl.oh) = *reinterpret_cast<const uint4*>(second ? &S.sY[row][piece * 8] : &S.sH[row][piece * 8]);
+    }
+    if (second) {
+        if (L.yT != nullptr) {                               // yT[unit][t B + row]
+            char* yb = reinterpret_cast<char*>(L.yT + (size_t)(nt * 32) * L.ld_yT + (size_t)t * B + m0);
+            *reinterpret_cast<uint4*>(yb + fl.oyT) = *reinterpret_cast<const uint4*>(&S.sYT[row][piece * 8]);
+        }
+    } else if (L.hT != nullptr && t + 1 < T) {               // hT[unit][(t+1) B + row]
+        char* tb = reinterpret_cast<char*>(L.hT + (size_t)(nt * 32) * L.ld_hT + (size_t)(t + 1) * B + m0);
+        *reinterpret_cast<uint4*>(tb + fl.ohT) = *reinterpret_cast<const uint4*>(&S.sT[row][piece * 8]);
+    }
+}
+__device__ __forceinline__ void pf_tail_any(const PFwdLayer& L, const FwdTiles& S, int T, int B, int nt, const FwdTail& tl, const FwdLane& fl) {
+    if (!tl.valid) return;
+    if (fl.al8 && tl.m0 + 32 <= B) pf_tail_fast(L, S, T, B, nt, tl, fl);      // uniform
+    else pf_tail(L, S, T, B, nt, tl);
+}
+
 // Rule for the stretch between a hand-off's loads and its MFMAs: unconditional loads into registers only -- a load
 // under a branch feeds a phi, the phi's copy is a use, and the compiler then waits (vmcnt(0)) right behind the load.
 // So addresses are selected, never loads; `zero` points at always-zero words of the workspace.
@@ -272,14 +338,19 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
         for (int g = 0; g < 4; ++g) load_frags_plain<KS1>(L.wh_t + (size_t)(n0 + 32 * g + r) * U + kb, b[g]);
         float xp[4][4];
         unsigned mk[4];
+        FwdLane fl;
+        fwd_lane_init(fl, L, B, nrt, nt);
+        const bool has_mask = L.mask != nullptr;
         auto epi_load = [&](int t, int m0, float (&xp_)[4][4], unsigned (&mk_)[4]) {
+            // uniform bases of the (t, row tile) + this thread's offsets (rows clamped in a partial last tile); unconditional loads
+            const bool lastp = m0 + 32 > B;
+            const char* xb = reinterpret_cast<const char*>(L.xproj + (size_t)t * 4 * us + (size_t)m0 * N4);     // gate-minor xproj
+            const uint8_t* mb = has_mask ? L.mask + (size_t)t * us + (size_t)m0 * U : reinterpret_cast<const uint8_t*>(zero);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int rr = min(m0 + 8 * w + q + 4 * hh, B - 1);
-                const float4 xv = *reinterpret_cast<const float4*>(L.xproj + (size_t)t * 4 * us + (size_t)rr * N4 + unit * 4);     // gate-minor xproj
+                const float4 xv = *reinterpret_cast<const float4*>(xb + (lastp ? fl.ogl[q] : fl.og[q]));
                 xp_[q][0] = xv.x; xp_[q][1] = xv.y; xp_[q][2] = xv.z; xp_[q][3] = xv.w;
-                const uint8_t* mp = L.mask != nullptr ? L.mask + (size_t)t * us + (size_t)rr * U + unit : reinterpret_cast<const uint8_t*>(zero);
-                mk_[q] = *mp;
+                mk_[q] = mb[has_mask ? (lastp ? fl.oml[q] : fl.om[q]) : 0u];
             }
         };
         epi_load(0, grp * 32, xp, mk);
@@ -294,13 +365,16 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             PST_TR(trc, 1);
             bf16x8_t a[KS1];
             load_frags_xchg<KS1>(t > 0 ? L.hx + ((size_t)(t - 1) * nrt + rt) * slab : L.hx0 + (size_t)rt * slab, slab, w * KS1, a);
-            // behind the hand-off loads: this item's cell state, the next item's operands, the previous item's plain stores
+            // behind the hand-off loads: this item's cell state and the next item's operands (loads: their wait merges with the hand-off's;
+            // behind the MFMAs they would be waited for together with the plain stores)
             float cl[4];
+            {
+                const bool use = t == 0 ? L.c0 != nullptr : Rv != 1;        // uniform: otherwise an always-zero word is read (and not used)
+                const char* cb = reinterpret_cast<const char*>(t == 0 ? (L.c0 != nullptr ? L.c0 + (size_t)m0 * U : zero)
+                                                                    : (Rv == 1 ? zero : L.c + (size_t)(t - 1) * us + (size_t)m0 * U));
+                const bool lastp = m0 + 32 > B;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const size_t uo = (size_t)min(m0 + 8 * w + q + 4 * hh, B - 1) * U + unit;
-                const float* cptr = t == 0 ? (L.c0 != nullptr ? L.c0 + uo : zero) : (Rv == 1 ? zero : L.c + (size_t)(t - 1) * us + uo);
-                cl[q] = *cptr;
+                for (int q = 0; q < 4; ++q) cl[q] = *reinterpret_cast<const float*>(cb + (use ? (lastp ? fl.ocl[q] : fl.oc[q]) : 0u));
             }
             float xpn[4][4];
             unsigned mkn[4];
@@ -308,7 +382,6 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
                 const int i2 = min(i + 1, n_items - 1), t2 = i2 / Rv;
                 epi_load(t2, (grp + A.G * (i2 - t2 * Rv)) * 32, xpn, mkn);
             }
-            pf_tail(L, S, T, B, nt, tl);
             f32x16_t acc[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -318,6 +391,7 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             for (int s = 0; s < KS1; ++s)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[g][s], acc[g], 0, 0, 0);
+            pf_tail_any(L, S, T, B, nt, tl, fl);           // the previous item's plain stores issue while the MFMA chain runs
             // K-split partials through LDS, 16 bytes per access: slot (producer wave, gate, consumer wave, lane) holds the four accumulator
             // elements 4 w' .. 4 w' + 3 that consumer wave w' reduces (16 stores + 16 loads per thread and item instead of 64 + 64)
 #pragma unroll
@@ -354,7 +428,7 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             }
             PST_TR(trc, 5);
         }
-        pf_tail(L, S, T, B, nt, tl);
+        pf_tail_any(L, S, T, B, nt, tl, fl);
     } else {
         // ---------------- layer 2: z = bias + y1[t] . Wx^T + h[t-1] . Wh^T ----------------
         const PFwdLayer& L = A.l2;
@@ -371,6 +445,9 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             load_frags_plain<KS2>(L.wh_t + (size_t)(n0 + 32 * g + r) * U + kb2, bh[g]);
             bz[g] = L.bias_p[n0 + 32 * g + r];
         }
+        FwdLane fl;
+        fwd_lane_init(fl, L, B, nrt, nt);
+        const bool has_mask = L.mask != nullptr;
         const int n_items = T * Rv;
         bool have_peek = false;
         unsigned peek = 0u;
@@ -385,15 +462,18 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             load_frags_xchg<KS2>(t > 0 ? L.hx + ((size_t)(t - 1) * nrt + rt) * slab : L.hx0 + (size_t)rt * slab, slab, w * KS2, a2);
             float cl[4];
             unsigned mk[4];
+            {
+                const bool use = t == 0 ? L.c0 != nullptr : Rv != 1;        // uniform (see layer 1)
+                const char* cb = reinterpret_cast<const char*>(t == 0 ? (L.c0 != nullptr ? L.c0 + (size_t)m0 * U : zero)
+                                                                    : (Rv == 1 ? zero : L.c + (size_t)(t - 1) * us + (size_t)m0 * U));
+                const uint8_t* mb = has_mask ? L.mask + (size_t)t * us + (size_t)m0 * U : reinterpret_cast<const uint8_t*>(zero);
+                const bool lastp = m0 + 32 > B;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const size_t uo = (size_t)min(m0 + 8 * w + q + 4 * hh, B - 1) * U + unit;
-                const float* cptr = t == 0 ? (L.c0 != nullptr ? L.c0 + uo : zero) : (Rv == 1 ? zero : L.c + (size_t)(t - 1) * us + uo);
-                cl[q] = *cptr;
-                const uint8_t* mp = L.mask != nullptr ? L.mask + (size_t)t * us + uo : reinterpret_cast<const uint8_t*>(zero);
-                mk[q] = *mp;
+                for (int q = 0; q < 4; ++q) {
+                    cl[q] = *reinterpret_cast<const float*>(cb + (use ? (lastp ? fl.ocl[q] : fl.oc[q]) : 0u));
+                    mk[q] = mb[has_mask ? (lastp ? fl.oml[q] : fl.om[q]) : 0u];
+                }
             }
-            pf_tail(L, S, T, B, nt, tl);
             f32x16_t acc[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -407,6 +487,7 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             for (int s = 0; s < KS2; ++s)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s], bh[g][s], acc[g], 0, 0, 0);
+            pf_tail_any(L, S, T, B, nt, tl, fl);           // the previous item's plain stores issue while the MFMA chain runs
             // K-split partials through LDS, 16 bytes per access: slot (producer wave, gate, consumer wave, lane) holds the four accumulator
             // elements 4 w' .. 4 w' + 3 that consumer wave w' reduces (16 stores + 16 loads per thread and item instead of 64 + 64)
 #pragma unroll
@@ -436,7 +517,7 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             pf_finish(L, S, T, nrt, t, rt, nt, A.kp, z, cp, mk, tl, flags + rt * 32 + member, local, trc);
             PST_TR(trc, 5);
         }
-        pf_tail(L, S, T, B, nt, tl);
+        pf_tail_any(L, S, T, B, nt, tl, fl);
     }
 }
 
