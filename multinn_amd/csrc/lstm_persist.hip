@@ -714,12 +714,12 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
                 const int i2 = min(i + 1, n_items - 1), k2 = i2 / Rv;
                 pb_epi_load<false>(L, B, nt, T - 1 - k2, (grp + A.G * (i2 - k2 * Rv)) * 32, zero, en);
             }
-            pb_tail(L, S, B, Rv, nt, tl);
             f32x16_t acc;
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = 0.f;
 #pragma unroll
             for (int s = 0; s < KB; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bw[s], acc, 0, 0, 0);
+            pb_tail(L, S, B, Rv, nt, tl);                    // the previous item's plain stores issue while the MFMA chain runs
 #pragma unroll
             for (int wc = 0; wc < 8; ++wc) red2[((0 * 8 + w) * 8 + wc) * 64 + lane] = make_float2(acc[2 * wc], acc[2 * wc + 1]);     // 8-byte slots: see the forward kernel
             lds_barrier();
@@ -772,7 +772,6 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
             }
             BwdEpi e[2];
             pb_epi_load<true>(L, B, nt, t, m0, zero, e);      // same item, behind the hand-off loads: registers are scarce in this role
-            pb_tail(L, S, B, Rv, nt, tl);
             f32x16_t accq, accw;
 #pragma unroll
             for (int j = 0; j < 16; ++j) { accq[j] = 0.f; accw[j] = 0.f; }
@@ -780,6 +779,7 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
             for (int s = 0; s < KB; ++s) accq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[s], bq[s], accq, 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < KA; ++s) accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[s], bw[s], accw, 0, 0, 0);
+            pb_tail(L, S, B, Rv, nt, tl);                    // the previous item's plain stores issue while the MFMA chains run
 #pragma unroll
             for (int wc = 0; wc < 8; ++wc) {
                 red2[((0 * 8 + w) * 8 + wc) * 64 + lane] = make_float2(accq[2 * wc], accq[2 * wc + 1]);
