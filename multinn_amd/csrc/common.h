@@ -114,7 +114,7 @@ __device__ __forceinline__ float fast_tanh(float x) { return 2.0f * fast_rcp(1.0
 // ----------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ float det_exp(float x) {
     // exp(x) for x in [-87, 87]: n = floor(x*log2e + 0.5); r = x - n*ln2 (two-term); degree-6 Horner; scale by 2^n.
-    x = x < -87.0f ? -87.0f : (x > 87.0f ? 87.0f : x);
+    x = fminf(fmaxf(x, -87.0f), 87.0f);       // two instructions on the device; the same value as the two selects for every non-NaN x
     const float n = floorf(fmaf(x, 1.4426950408889634f, 0.5f));
     float r = fmaf(n, -0.693145751953125f, x);
     r = fmaf(n, -1.42860682030941723212e-6f, r);

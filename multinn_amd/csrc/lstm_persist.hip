@@ -521,9 +521,16 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
     }
 }
 
-// h0 [B,U] row-major -> one exchange slab per row tile (initial state of a stateful call); grid (nrt, U/16), 64 threads
-__global__ void __launch_bounds__(64) pst_fill_h0_kernel(const bf16_t* __restrict__ h0, int B, int U, char* __restrict__ slab0) {
-    const int rt = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+// h0 [B,U] row-major -> one exchange slab per row tile (initial state of a stateful call), both layers in one launch (a sampling scan
+// makes this call once per generated step); grid (nrt, U1/16 + U2/16), 64 threads; a layer without h0 keeps its zero slabs
+__global__ void __launch_bounds__(64) pst_fill_h0_kernel(const bf16_t* __restrict__ h0a, int Ua, char* __restrict__ slab_a,
+                                                         const bf16_t* __restrict__ h0b, int Ub, char* __restrict__ slab_b, int B) {
+    const bool first = (int)blockIdx.y < Ua / 16;
+    const bf16_t* __restrict__ h0 = first ? h0a : h0b;
+    if (h0 == nullptr) return;
+    const int U = first ? Ua : Ub;
+    char* __restrict__ slab0 = first ? slab_a : slab_b;
+    const int rt = blockIdx.x, f = first ? blockIdx.y : blockIdx.y - Ua / 16, lane = threadIdx.x;
     const int row = min(rt * 32 + (lane & 31), B - 1);
     const uint4 v = *reinterpret_cast<const uint4*>(h0 + (size_t)row * U + f * 16 + (lane >> 5) * 8);
     *reinterpret_cast<uint4*>(slab0 + ((size_t)rt * (U / 16) + f) * 1024 + lane * 16) = v;
@@ -919,8 +926,9 @@ extern "C" int mnn_lstm2_persist_fwd(mnn_stream_t s, int T, int B, const mnn_lst
     const int grid = a.G * (u1 / 32 + u2 / 32);
     MNN_HIP(mnn_zero_async(workspace, sync_words(a.nrt) * sizeof(unsigned) + edge_bytes(a.nrt, u1, u2, false), st));
     if (getenv("MNN_PERSIST_TEST_ABORT")) hipLaunchKernelGGL(pst_poison_kernel, dim3(1), dim3(1), 0, st, (unsigned*)workspace);   // tests: exercise the give-up path
-    if (L1->h0) hipLaunchKernelGGL(pst_fill_h0_kernel, dim3(a.nrt, u1 / 16), dim3(64), 0, st, (const bf16_t*)L1->h0, B, u1, edge);
-    if (L2->h0) hipLaunchKernelGGL(pst_fill_h0_kernel, dim3(a.nrt, u2 / 16), dim3(64), 0, st, (const bf16_t*)L2->h0, B, u2, edge + (size_t)a.nrt * 64 * u1);
+    if (L1->h0 || L2->h0)
+        hipLaunchKernelGGL(pst_fill_h0_kernel, dim3(a.nrt, u1 / 16 + u2 / 16), dim3(64), 0, st, (const bf16_t*)L1->h0, u1, edge,
+                           (const bf16_t*)L2->h0, u2, edge + (size_t)a.nrt * 64 * u1, B);
     hipError_t e;
     if (u1 == 512) e = launch_pfwd<8>(st, grid, a, u2);
     else if (u1 == 256) e = launch_pfwd<4>(st, grid, a, u2);

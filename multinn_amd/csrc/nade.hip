@@ -445,51 +445,134 @@ extern "C" int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, in
 // sampling: one wave per (row, track); deterministic order (DESIGN.md "Deterministic sampling"):
 //   lane l owns hidden j = l + 64 q, q = 0..3 ; acc_l = fma-chain over q ; xor-butterfly 32..1 ;
 //   logit = b_dec + acc ; p = det_sigmoid(logit) ; draw = u < det_sigmoid(logit / T)
+// The scan is a serial chain of D conditionals per row, so everything that does not depend on the previous draw is kept off it:
+//   * the hidden state h = det_sigmoid(a) is cached and recomputed only after a draw of 1 (the same value otherwise);
+//   * the two weight rows and b_dec of a visible are fetched FOUR visibles ahead into a register ring (a fetch per visible on the
+//     chain was an L2 round trip per conditional);
+//   * the uniforms: lane l evaluates the Philox block (first block of the chunk + l) once per 256 elements, the chain reads its
+//     word with one v_readlane (every lane used to run the ten rounds for every visible);
+//   * the xor butterfly runs on permlane swaps / DPP (each step adds the same two numbers as the shuffle form: same bits);
+//   * probabilities and draws are parked in LDS; the log terms are evaluated 64 at a time after the scan and added in visible order
+//     (the same sum as adding inside the loop), samples leave in one strided pass.
+// 487 -> see profiles/round1_d_notes.md (us per call at D = 440, Hn = 256).
 // ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_xor_sum(float x) {
+    {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);     // x[l] + x[l ^ 32]
+        x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);     // x[l] + x[l ^ 16]
+        x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    x = x + dpp_xor8(x);
+    x = x + swz_xor4(x);
+    x = x + dpp_xor2(x);
+    x = x + dpp_xor1(x);
+    return x;
+}
+
+// TMODE: 0 = threshold draws (temperature None / <= 0), 1 = temperature 1, 2 = any other temperature.  FULL: Hn == 256, no lane is idle.
+template <int TMODE, bool FULL>
 __global__ void __launch_bounds__(256)
 nade_sample_kernel(int tracks, int N, int D, int Hn, const float* __restrict__ bias, int ld_bias, const float* __restrict__ w_enc,
                    const float* __restrict__ w_dec, float temperature, uint64_t seed, uint32_t row0, uint32_t sub,
                    uint8_t* __restrict__ samples, long s_track_stride, int s_row_stride, int s_elem_stride, float* __restrict__ nll) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char nade_sample_smem[];       // per wave: p / log term [Dp] f32, b_dec [Dp] f32, draws [Dp] u8
     const int m = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= N) return;                                   // wave-uniform
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wv;
+    if (row >= N) return;                                   // wave-uniform; the kernel has no workgroup barrier
+    const int Dp = (D + 3) & ~3;
+    float* sp = reinterpret_cast<float*>(nade_sample_smem) + (size_t)wv * Dp;
+    float* sbd = reinterpret_cast<float*>(nade_sample_smem) + (size_t)(4 + wv) * Dp;
+    unsigned char* son = nade_sample_smem + (size_t)32 * Dp + (size_t)wv * Dp;
     const float* __restrict__ we = w_enc + (size_t)m * D * Hn;
     const float* __restrict__ wd = w_dec + (size_t)m * D * Hn;
     const float* __restrict__ bd = bias + (size_t)row * ld_bias + tracks * Hn + m * D;
-    float a[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) a[q] = (lane + 64 * q < Hn) ? bias[(size_t)row * ld_bias + m * Hn + lane + 64 * q] : 0.f;
-    float logp = 0.f;
-    for (int i = 0; i < D; ++i) {
-        float acc = 0.f, wev[4];
+    float a[4], h[4];
+    bool in[4];
+    int off[4];                                             // hidden index of (lane, q), 0 where there is none: loads are never predicated
+#pragma unroll                                              // (a load under a branch is waited for right behind it -- the ring would be no ring)
+    for (int q = 0; q < 4; ++q) {
+        in[q] = FULL || lane + 64 * q < Hn;
+        off[q] = in[q] ? lane + 64 * q : 0;
+        const float av = bias[(size_t)row * ld_bias + m * Hn + off[q]];
+        a[q] = in[q] ? av : 0.f;
+        h[q] = det_sigmoid(a[q]);
+    }
+    float wdr[4][4], wer[4][4];                             // ring: the weight rows of visibles i .. i + 3
+    auto fetch = [&](int k, int i) {
+        const int ii = min(i, D - 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const bool in = lane + 64 * q < Hn;
-            const float wdq = in ? wd[(size_t)i * Hn + lane + 64 * q] : 0.f;
-            wev[q] = in ? we[(size_t)i * Hn + lane + 64 * q] : 0.f;
-            acc = fmaf(det_sigmoid(a[q]), wdq, acc);
+            wdr[k][q] = wd[(size_t)ii * Hn + off[q]];
+            wer[k][q] = we[(size_t)ii * Hn + off[q]];
         }
+    };
+    for (int i = lane; i < D; i += 64) sbd[i] = bd[i];      // the row's b_dec: one coalesced pass into LDS, a broadcast read per visible
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc = acc + __shfl_xor(acc, o);
-        const float l = bd[i] + acc;
-        const float p = det_sigmoid(l);
-        bool on;
-        if (temperature > 0.f) {
-            const float ps = temperature == 1.0f ? p : det_sigmoid(l / temperature);
-            const float u = philox_uniform1(seed, MNN_STREAM_NADE, row0 + (uint32_t)row, sub, (uint32_t)(m * D + i));
-            on = u < ps;
-        } else {
-            on = p >= 0.5f;                                  // nade.py:278-279
-        }
-        logp += on ? logf(NADE_EPS + p) : logf(NADE_EPS + (1.0f - p));
-        if (on) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = a[q] + wev[q];
-        }
-        if (lane == 0) samples[(size_t)m * s_track_stride + (size_t)row * s_row_stride + (size_t)i * s_elem_stride] = on ? 1 : 0;
+    for (int k = 0; k < 4; ++k) {
+        fetch(k, k);
+        __builtin_amdgcn_sched_barrier(0);                  // issue order = ring order, in the prologue as in the loop (the waits count loads)
     }
-    if (lane == 0 && nll != nullptr) nll[(size_t)m * N + row] = -logp;
+    const uint32_t e0 = (uint32_t)(m * D);                  // element index of visible 0 (RNG contract: elem = m D + i)
+    uint32_t b0 = e0 >> 2;                                  // lane l holds the uniforms of Philox block b0 + l
+    float u4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (TMODE != 0) philox_uniform4(seed, MNN_STREAM_NADE, row0 + (uint32_t)row, sub, b0 + (uint32_t)lane, u4);
+    for (int i0 = 0; i0 < D; i0 += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k;
+            if (i < D) {                                    // uniform
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = fmaf(h[q], in[q] ? wdr[k][q] : 0.f, acc);
+                acc = wave_xor_sum(acc);
+                const float l = sbd[i] + acc;
+                const float p = det_sigmoid(l);
+                bool on;
+                if (TMODE != 0) {
+                    const float ps = TMODE == 1 ? p : det_sigmoid(l / temperature);
+                    const uint32_t e = e0 + (uint32_t)i;
+                    if ((e >> 2) >= b0 + 64u) {             // uniform: next 64 Philox blocks
+                        b0 += 64u;
+                        philox_uniform4(seed, MNN_STREAM_NADE, row0 + (uint32_t)row, sub, b0 + (uint32_t)lane, u4);
+                    }
+                    const uint32_t wsel = e & 3u;
+                    const float uw = wsel == 0u ? u4[0] : (wsel == 1u ? u4[1] : (wsel == 2u ? u4[2] : u4[3]));
+                    const float u = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), (int)((e >> 2) - b0)));
+                    on = __builtin_amdgcn_readfirstlane((int)(u < ps)) != 0;
+                } else {
+                    on = __builtin_amdgcn_readfirstlane((int)(p >= 0.5f)) != 0;        // nade.py:278-279
+                }
+                if (on) {                                   // uniform (every lane holds the same p and u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        a[q] = a[q] + (in[q] ? wer[k][q] : 0.f);
+                        h[q] = det_sigmoid(a[q]);
+                    }
+                }
+                sp[i] = p;                                  // every lane holds the same p and draw: one merged LDS write each
+                son[i] = on ? 1 : 0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(k, i + 4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // after the scan: samples out, log terms 64 at a time, then their sum in visible order (LDS operations of one wave execute in order)
+    for (int i = lane; i < D; i += 64) {
+        const float p = sp[i];
+        const bool on = son[i] != 0;
+        samples[(size_t)m * s_track_stride + (size_t)row * s_row_stride + (size_t)i * s_elem_stride] = on ? 1 : 0;
+        sp[i] = on ? logf(NADE_EPS + p) : logf(NADE_EPS + (1.0f - p));
+    }
+    if (nll != nullptr) {
+        float logp = 0.f;
+        for (int i = 0; i < D; ++i) logp += sp[i];
+        if (lane == 0) nll[(size_t)m * N + row] = -logp;
+    }
 }
 
 extern "C" int mnn_nade_sample(mnn_stream_t s, int tracks, int N, int D, int Hn, const float* bias, int ld_bias, const float* w_enc,
@@ -498,9 +581,15 @@ extern "C" int mnn_nade_sample(mnn_stream_t s, int tracks, int N, int D, int Hn,
     MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn > 0 && Hn <= 256, "mnn_nade_sample: need tracks,N,D>0 and 0<Hn<=256 (Hn=%d)", Hn);
     MNN_REQUIRE(bias && w_enc && w_dec && samples, "mnn_nade_sample: null pointer");
     MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_sample: ld_bias too small");
+    MNN_REQUIRE(D <= 3072, "mnn_nade_sample: D <= 3072 (probabilities and draws of a row are parked in LDS; D=%d)", D);
     dim3 grid(cdiv(N, 4), tracks);
-    hipLaunchKernelGGL(nade_sample_kernel, grid, dim3(256), 0, (hipStream_t)s, tracks, N, D, Hn, bias, ld_bias, w_enc, w_dec, temperature,
-                       seed, row0, sub, samples, s_track_stride, s_row_stride, s_elem_stride, nll);
+    const size_t lds = (size_t)36 * ((D + 3) & ~3);          // 4 waves x (2 f32 + u8) per visible
+    const int tmode = temperature > 0.f ? (temperature == 1.0f ? 1 : 2) : 0;
+#define SMP(TM, FU) hipLaunchKernelGGL((nade_sample_kernel<TM, FU>), grid, dim3(256), lds, (hipStream_t)s, tracks, N, D, Hn, bias, ld_bias, w_enc, \
+                                       w_dec, temperature, seed, row0, sub, samples, s_track_stride, s_row_stride, s_elem_stride, nll)
+    if (Hn == 256) { if (tmode == 0) SMP(0, true); else if (tmode == 1) SMP(1, true); else SMP(2, true); }
+    else { if (tmode == 0) SMP(0, false); else if (tmode == 1) SMP(1, false); else SMP(2, false); }
+#undef SMP
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

@@ -127,7 +127,28 @@ class FeedbackRnnSampler:
         self.num_tracks = len(generators)
 
     def generate(self, x_u8, num_steps):
-        """x_u8 [B,Ti,P,M] intro piano-rolls -> samples u8 [B,num_steps,P,M]."""
+        """x_u8 [B,Ti,P,M] intro piano-rolls -> samples u8 [B,num_steps,P,M].  One hipGraph replay per call on the
+        device (common.ScanGraphs): the M generators and the feedback module step inside the same captured scan."""
+        from .common import ScanGraphs
+        if not ScanGraphs.enabled(x_u8):
+            return self._generate_scan(x_u8, num_steps)
+        if getattr(self, "_scan_graphs", None) is None:
+            self._scan_graphs = ScanGraphs()
+        key = (tuple(x_u8.shape), int(num_steps), tuple((g.seed, g.row0) for g in self.generators))
+
+        def stale():
+            for g in self.generators:
+                g._packed_step = -1
+            if hasattr(self.feedback, "_packed_step"):
+                self.feedback._packed_step = -1
+
+        def scan(sx):
+            stale()                                    # pack inside the graph: a replay always sees the current weights
+            return self._generate_scan(sx, num_steps)
+
+        return self._scan_graphs.run(key, x_u8, scan, lambda sx: self._generate_scan(sx, min(int(num_steps), 2)), stale)
+
+    def _generate_scan(self, x_u8, num_steps):
         B, Ti, P, M = x_u8.shape
         assert M == self.num_tracks
         dev = x_u8.device

@@ -16,7 +16,7 @@ import os
 import torch
 
 from . import ops
-from .common import Model, RNN, NADE, RBM, ParamStore, glorot_uniform, zeros_init, default_device
+from .common import Model, RNN, NADE, RBM, ParamStore, ScanGraphs, glorot_uniform, zeros_init, default_device
 from .training import compute_gradients, world, dp_active, AdamOptimizer
 
 _RnnEstimatorStateTuple = collections.namedtuple("RnnEstimatorStateTuple", ("b_enc", "b_dec", "rnn_state"))
@@ -455,10 +455,37 @@ class RnnEstimator(Generator):
     def steps(self, inputs, initial_state=None):
         return self._get_state(inputs, initial_state=initial_state, last_outputs=True)
 
+    def _step_input(self, B, device):
+        """[B, ld0] staging row block of single_step: the zero padding beyond the input width is written once, every step converts its
+        input into the prefix (the step's GEMM has read the previous contents by then: same stream)."""
+        buf = getattr(self, "_xstep", None)
+        if buf is None or buf.shape[0] != B or buf.device != torch.device(device) or buf.shape[1] != self._stack.ld0 \
+                or torch.cuda.is_current_stream_capturing() != getattr(self, "_xstep_captured", False):
+            buf = self._xstep = torch.zeros((B, self._stack.ld0), device=device, dtype=self.dtype)
+            self._xstep_captured = torch.cuda.is_current_stream_capturing()
+        return buf
+
     # -- sampling -------------------------------------------------------------------------------
     def generate(self, x, num_steps):
         """rnn_estimator.py:271-298: intro pass, then num_steps x {sample_single, single_step}.
-        x [B,Ti,Din]; returns samples u8 [B,num_steps,num_output]."""
+        x [B,Ti,Din]; returns samples u8 [B,num_steps,num_output].  On the device the whole scan is ONE hipGraph
+        replay (captured per shape / num_steps / seed, see common.ScanGraphs); same kernels, same RNG counters, same bits."""
+        if not ScanGraphs.enabled(x):
+            return self._generate_scan(x, num_steps)
+        if getattr(self, "_scan_graphs", None) is None:
+            self._scan_graphs = ScanGraphs()
+        key = (tuple(x.shape), x.dtype, int(num_steps), self.seed, self.row0)
+
+        def scan(sx):
+            self._packed_step = -1                     # pack inside the graph: a replay always sees the current weights
+            return self._generate_scan(sx, num_steps)
+
+        def after():
+            self._packed_step = -1                     # the packed copies now live in the graph's pool
+
+        return self._scan_graphs.run(key, x, scan, lambda sx: self._generate_scan(sx, min(int(num_steps), 2)), after)
+
+    def _generate_scan(self, x, num_steps):
         self._materialize(x.shape[-1])
         self._rnn.build_cell(False)
         self._ensure_packed()
@@ -753,9 +780,7 @@ class RnnNade(RnnEstimator):
         return (be[0], bd[0]) if M == 1 else (be, bd)
 
     def _dense(self, h):
-        out = torch.empty((h.shape[0], self.ldo), device=h.device)
-        if self.ldo != self.n_out:
-            out[:, self.n_out:].zero_()
+        out = torch.empty((h.shape[0], self.ldo), device=h.device)        # columns [n_out, ldo) are alignment only: no kernel reads them
         ops.gemm_tn(h, self._fc_t, out[:, :self.n_out], bias=self.store["dense/bias"])
         return out
 
@@ -784,11 +809,11 @@ class RnnNade(RnnEstimator):
 
     def single_step(self, inputs, initial_state):
         """rnn_nade.py:253-277."""
-        x = torch.zeros((inputs.shape[0], self._stack.ld0), device=inputs.device, dtype=self.dtype)
+        x = self._step_input(inputs.shape[0], inputs.device)
         ops.convert2d(inputs.contiguous() if inputs.dtype in (torch.uint8, torch.float32, torch.bfloat16) else inputs.float(),
                       x[:, :inputs.shape[1]])
         h, new = self._stack.single_step(x, [(c, hh) for c, hh in initial_state.rnn_state])
-        return self._state_from_dense(self._dense(h.contiguous()), tuple((c.clone(), hh.clone()) for c, hh in new))
+        return self._state_from_dense(self._dense(h.contiguous()), tuple(new))       # views of buffers this step allocated: no copies
 
     def log_prob(self, inputs, targets_flat, lengths=None):
         """rnn_nade.py:279-302 (API-order outputs)."""
@@ -987,12 +1012,12 @@ class RnnRBM(RnnEstimator):
 
     def single_step(self, inputs, initial_state):
         """rnn_rbm.py:261-281."""
-        x = torch.zeros((inputs.shape[0], self._stack.ld0), device=inputs.device, dtype=self.dtype)
+        x = self._step_input(inputs.shape[0], inputs.device)
         ops.convert2d(inputs.contiguous(), x[:, :inputs.shape[1]])
         h, new = self._stack.single_step(x, [(c, hh) for c, hh in initial_state.rnn_state])
         out = self._biases(h.contiguous())
         Hn, D = self.num_hidden[-1], self.num_dims
-        return RnnEstimatorStateTuple(out[:, :Hn], out[:, Hn:Hn + D], tuple((c.clone(), hh.clone()) for c, hh in new))
+        return RnnEstimatorStateTuple(out[:, :Hn], out[:, Hn:Hn + D], tuple(new))
 
     def sample_single(self, inputs, state):
         """rnn_rbm.py:283-297 with k = rbm.k (R1): returns (sample u8, cond_prob)."""

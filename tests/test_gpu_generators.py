@@ -185,6 +185,42 @@ def test_generate_scan(tracks):
     assert torch.equal(sub, out[2:])
 
 
+@pytest.mark.parametrize("kind", ["nade", "multinade", "rbm"])
+def test_generate_graph_replay_equals_eager_scan(monkeypatch, kind):
+    """generate() replays ONE captured hipGraph of the whole scan (common.ScanGraphs); MULTINN_GENERATE_GRAPH=0 runs the eager loop.
+    Same kernels and RNG counters: the bits must agree -- also for a second input through the same graph, and after the weights
+    have changed (packing is part of the captured scan)."""
+    from multinn_amd import RnnNade, RnnMultiNADE, RnnRBM
+    B, Ti, E, Hn, units, steps = 40, 5, 16, 32, [128, 128], 7
+    tracks = 3 if kind == "multinade" else 1
+    Din = E * tracks
+    R = np.random.default_rng(11)
+    xa = dev((R.random((B, Ti, Din)) < .3).astype(np.uint8))
+    xb = dev((R.random((B, Ti, Din)) < .3).astype(np.uint8))
+    if kind == "nade":
+        gen = RnnNade(E, Hn, units, precision="bf16", seed=5)
+    elif kind == "multinade":
+        gen = RnnMultiNADE(E, Hn, units, tracks=list("abc"), precision="bf16", seed=5)
+    else:
+        gen = RnnRBM(E, Hn, units, k=3, precision="bf16", seed=5)
+    gen._materialize(Din)
+
+    def eager(x):
+        monkeypatch.setenv("MULTINN_GENERATE_GRAPH", "0")
+        out = gen.generate(x, steps)
+        monkeypatch.delenv("MULTINN_GENERATE_GRAPH")
+        return out
+
+    ga, gb = gen.generate(xa, steps), gen.generate(xb, steps)
+    assert len(gen._scan_graphs._cache) == 1                       # the second call replayed the first one's graph
+    assert torch.equal(ga, eager(xa)) and torch.equal(gb, eager(xb)) and not torch.equal(ga, gb)
+    gen.store.theta.mul_(1.5)                                      # "training happened": no recapture, the replay re-packs
+    gen.store.step += 1
+    gc = gen.generate(xa, steps)
+    assert len(gen._scan_graphs._cache) == 1
+    assert torch.equal(gc, eager(xa)) and not torch.equal(gc, ga)
+
+
 @pytest.mark.parametrize("bias_mode", ["conditional", "internal"])
 def test_rnn_rbm_train_step(bias_mode):
     from multinn_amd import RnnRBM
