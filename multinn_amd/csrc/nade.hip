@@ -447,7 +447,7 @@ extern "C" int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, in
 //   logit = b_dec + acc ; p = det_sigmoid(logit) ; draw = u < det_sigmoid(logit / T)
 // The scan is a serial chain of D conditionals per row, so everything that does not depend on the previous draw is kept off it:
 //   * the hidden state h = det_sigmoid(a) is cached and recomputed only after a draw of 1 (the same value otherwise);
-//   * the two weight rows and b_dec of a visible are fetched FOUR visibles ahead into a register ring (a fetch per visible on the
+//   * the two weight rows and b_dec of a visible are fetched EIGHT visibles ahead into a register ring (a fetch per visible on the
 //     chain was an L2 round trip per conditional);
 //   * the uniforms: lane l evaluates the Philox block (first block of the chunk + l) once per 256 elements, the chain reads its
 //     word with one v_readlane (every lane used to run the ten rounds for every visible);
@@ -472,13 +472,31 @@ __device__ __forceinline__ float wave_xor_sum(float x) {
     return x;
 }
 
+// The draw 1[u < det_sigmoid(x)] (or det_sigmoid(x) >= 1/2) decided WITHOUT the 35-operation deterministic sigmoid on the serial chain:
+// the hardware exp2 / rcp give the probability to ~1e-5 relative (argument scaling of exp2 included), which settles every draw
+// whose uniform is not within 1e-4 (relative) of it; the rare rest takes the exact comparison.  The outcome is the exact one always.
+__device__ __forceinline__ float sig_approx(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-x * 1.4426950408889634f));
+}
+__device__ __forceinline__ bool draw_below(float u, float x) {          // u < det_sigmoid(x); wave-uniform operands
+    const float r = sig_approx(x);
+    const float d = u - r;
+    if (__builtin_amdgcn_ballot_w64(fabsf(d) > 1e-4f * r + 1e-30f) != 0ull) return __builtin_amdgcn_ballot_w64(d < 0.f) != 0ull;
+    return __builtin_amdgcn_ballot_w64(u < det_sigmoid(x)) != 0ull;
+}
+__device__ __forceinline__ bool prob_at_least_half(float x) {           // det_sigmoid(x) >= 0.5f
+    const float d = sig_approx(x) - 0.5f;
+    if (__builtin_amdgcn_ballot_w64(fabsf(d) > 1e-4f) != 0ull) return __builtin_amdgcn_ballot_w64(d > 0.f) != 0ull;
+    return __builtin_amdgcn_ballot_w64(det_sigmoid(x) >= 0.5f) != 0ull;
+}
+
 // TMODE: 0 = threshold draws (temperature None / <= 0), 1 = temperature 1, 2 = any other temperature.  FULL: Hn == 256, no lane is idle.
-template <int TMODE, bool FULL>
+template <int TMODE, bool FULL, bool SPEC>
 __global__ void __launch_bounds__(256)
 nade_sample_kernel(int tracks, int N, int D, int Hn, const float* __restrict__ bias, int ld_bias, const float* __restrict__ w_enc,
                    const float* __restrict__ w_dec, float temperature, uint64_t seed, uint32_t row0, uint32_t sub,
                    uint8_t* __restrict__ samples, long s_track_stride, int s_row_stride, int s_elem_stride, float* __restrict__ nll) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char nade_sample_smem[];       // per wave: p / log term [Dp] f32, b_dec [Dp] f32, draws [Dp] u8
+    extern __shared__ __attribute__((aligned(16))) unsigned char nade_sample_smem[];       // per wave: logit / log term [Dp] f32, b_dec [Dp] f32, draws [Dp] u8, 256 uniforms
     const int m = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wv;
@@ -487,6 +505,7 @@ nade_sample_kernel(int tracks, int N, int D, int Hn, const float* __restrict__ b
     float* sp = reinterpret_cast<float*>(nade_sample_smem) + (size_t)wv * Dp;
     float* sbd = reinterpret_cast<float*>(nade_sample_smem) + (size_t)(4 + wv) * Dp;
     unsigned char* son = nade_sample_smem + (size_t)32 * Dp + (size_t)wv * Dp;
+    float* su = reinterpret_cast<float*>(nade_sample_smem + (size_t)36 * Dp) + wv * 256;    // uniforms of Philox blocks b0 .. b0 + 63
     const float* __restrict__ we = w_enc + (size_t)m * D * Hn;
     const float* __restrict__ wd = w_dec + (size_t)m * D * Hn;
     const float* __restrict__ bd = bias + (size_t)row * ld_bias + tracks * Hn + m * D;
@@ -501,7 +520,8 @@ nade_sample_kernel(int tracks, int N, int D, int Hn, const float* __restrict__ b
         a[q] = in[q] ? av : 0.f;
         h[q] = det_sigmoid(a[q]);
     }
-    float wdr[4][4], wer[4][4];                             // ring: the weight rows of visibles i .. i + 3
+    constexpr int RING = 8;                                 // visibles in flight: RING x (time per visible) must cover an L2 round trip
+    float wdr[RING][4], wer[RING][4];                       // ring: the weight rows of visibles i .. i + RING - 1
     auto fetch = [&](int k, int i) {
         const int ii = min(i, D - 1);
 #pragma unroll
@@ -512,39 +532,50 @@ nade_sample_kernel(int tracks, int N, int D, int Hn, const float* __restrict__ b
     };
     for (int i = lane; i < D; i += 64) sbd[i] = bd[i];      // the row's b_dec: one coalesced pass into LDS, a broadcast read per visible
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < RING; ++k) {
         fetch(k, k);
         __builtin_amdgcn_sched_barrier(0);                  // issue order = ring order, in the prologue as in the loop (the waits count loads)
     }
     const uint32_t e0 = (uint32_t)(m * D);                  // element index of visible 0 (RNG contract: elem = m D + i)
     uint32_t b0 = e0 >> 2;                                  // lane l holds the uniforms of Philox block b0 + l
-    float u4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (TMODE != 0) philox_uniform4(seed, MNN_STREAM_NADE, row0 + (uint32_t)row, sub, b0 + (uint32_t)lane, u4);
-    for (int i0 = 0; i0 < D; i0 += 4) {
+    auto refill = [&]() {                                   // lane l: the four uniforms of Philox block b0 + l, parked in LDS (one broadcast read per visible)
+        float u4[4];
+        philox_uniform4(seed, MNN_STREAM_NADE, row0 + (uint32_t)row, sub, b0 + (uint32_t)lane, u4);
+        *reinterpret_cast<float4*>(su + 4 * lane) = make_float4(u4[0], u4[1], u4[2], u4[3]);
+    };
+    if (TMODE != 0) refill();
+    auto dot = [&](int k) {                                 // sum_j h_j w_dec[visible of ring slot k][j], the contract's order
+        float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int q = 0; q < 4; ++q) acc = fmaf(h[q], in[q] ? wdr[k][q] : 0.f, acc);
+        return wave_xor_sum(acc);
+    };
+    // the uniform of visible i, fetched one visible ahead (with the rare Philox refill) so that the block below -- speculative dot
+    // product next to the draw -- stays one straight line the scheduler can interleave
+    auto uniform_of = [&](int i) {
+        const uint32_t e = e0 + (uint32_t)min(i, D - 1);
+        if ((e >> 2) >= b0 + 64u) {                         // uniform: next 64 Philox blocks (the previous ones have all been read)
+            b0 += 64u;
+            refill();
+        }
+        return su[e - 4u * b0];
+    };
+    float u_cur = TMODE != 0 ? uniform_of(0) : 0.f;
+    float acc = dot(0);
+    for (int i0 = 0; i0 < D; i0 += RING) {
+#pragma unroll
+        for (int k = 0; k < RING; ++k) {
             const int i = i0 + k;
             if (i < D) {                                    // uniform
-                float acc = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc = fmaf(h[q], in[q] ? wdr[k][q] : 0.f, acc);
-                acc = wave_xor_sum(acc);
+                // speculation: if this draw is 0 the hidden state does not change, and visible i + 1's dot product is this one -- it has
+                // no dependence on the sigmoid / draw chain below and fills its issue slots (a draw of 1 recomputes it)
+                const float spec = SPEC ? dot((k + 1) % RING) : 0.f;
                 const float l = sbd[i] + acc;
-                const float p = det_sigmoid(l);
                 bool on;
                 if (TMODE != 0) {
-                    const float ps = TMODE == 1 ? p : det_sigmoid(l / temperature);
-                    const uint32_t e = e0 + (uint32_t)i;
-                    if ((e >> 2) >= b0 + 64u) {             // uniform: next 64 Philox blocks
-                        b0 += 64u;
-                        philox_uniform4(seed, MNN_STREAM_NADE, row0 + (uint32_t)row, sub, b0 + (uint32_t)lane, u4);
-                    }
-                    const uint32_t wsel = e & 3u;
-                    const float uw = wsel == 0u ? u4[0] : (wsel == 1u ? u4[1] : (wsel == 2u ? u4[2] : u4[3]));
-                    const float u = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), (int)((e >> 2) - b0)));
-                    on = __builtin_amdgcn_readfirstlane((int)(u < ps)) != 0;
+                    on = draw_below(u_cur, TMODE == 1 ? l : l / temperature);
                 } else {
-                    on = __builtin_amdgcn_readfirstlane((int)(p >= 0.5f)) != 0;        // nade.py:278-279
+                    on = prob_at_least_half(l);              // nade.py:278-279
                 }
                 if (on) {                                   // uniform (every lane holds the same p and u)
 #pragma unroll
@@ -552,18 +583,22 @@ nade_sample_kernel(int tracks, int N, int D, int Hn, const float* __restrict__ b
                         a[q] = a[q] + (in[q] ? wer[k][q] : 0.f);
                         h[q] = det_sigmoid(a[q]);
                     }
+                    acc = dot((k + 1) % RING);
+                } else {
+                    acc = SPEC ? spec : dot((k + 1) % RING);
                 }
-                sp[i] = p;                                  // every lane holds the same p and draw: one merged LDS write each
-                son[i] = on ? 1 : 0;
+                sp[i] = l;                                  // every lane holds the same logit and draw: one merged LDS write each;
+                son[i] = on ? 1 : 0;                        // p = det_sigmoid(logit) is evaluated after the scan, 64 visibles at a time
+                if (TMODE != 0) u_cur = uniform_of(i + 1);
             }
             __builtin_amdgcn_sched_barrier(0);
-            fetch(k, i + 4);
+            fetch(k, i + RING);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     // after the scan: samples out, log terms 64 at a time, then their sum in visible order (LDS operations of one wave execute in order)
     for (int i = lane; i < D; i += 64) {
-        const float p = sp[i];
+        const float p = det_sigmoid(sp[i]);
         const bool on = son[i] != 0;
         samples[(size_t)m * s_track_stride + (size_t)row * s_row_stride + (size_t)i * s_elem_stride] = on ? 1 : 0;
         sp[i] = on ? logf(NADE_EPS + p) : logf(NADE_EPS + (1.0f - p));
@@ -583,12 +618,13 @@ extern "C" int mnn_nade_sample(mnn_stream_t s, int tracks, int N, int D, int Hn,
     MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_sample: ld_bias too small");
     MNN_REQUIRE(D <= 3072, "mnn_nade_sample: D <= 3072 (probabilities and draws of a row are parked in LDS; D=%d)", D);
     dim3 grid(cdiv(N, 4), tracks);
-    const size_t lds = (size_t)36 * ((D + 3) & ~3);          // 4 waves x (2 f32 + u8) per visible
+    const size_t lds = (size_t)36 * ((D + 3) & ~3) + 4096;   // 4 waves x ((2 f32 + u8) per visible + 256 uniforms)
     const int tmode = temperature > 0.f ? (temperature == 1.0f ? 1 : 2) : 0;
-#define SMP(TM, FU) hipLaunchKernelGGL((nade_sample_kernel<TM, FU>), grid, dim3(256), lds, (hipStream_t)s, tracks, N, D, Hn, bias, ld_bias, w_enc, \
-                                       w_dec, temperature, seed, row0, sub, samples, s_track_stride, s_row_stride, s_elem_stride, nll)
-    if (Hn == 256) { if (tmode == 0) SMP(0, true); else if (tmode == 1) SMP(1, true); else SMP(2, true); }
-    else { if (tmode == 0) SMP(0, false); else if (tmode == 1) SMP(1, false); else SMP(2, false); }
+#define SMP(TM, FU, SP) hipLaunchKernelGGL((nade_sample_kernel<TM, FU, SP>), grid, dim3(256), lds, (hipStream_t)s, tracks, N, D, Hn, bias, ld_bias, w_enc, \
+                                           w_dec, temperature, seed, row0, sub, samples, s_track_stride, s_row_stride, s_elem_stride, nll)
+    if (Hn == 256 && tmode == 1) { if (getenv("MNN_SAMPLE_NO_SPEC")) SMP(1, true, false); else SMP(1, true, true); }
+    else if (Hn == 256) { if (tmode == 0) SMP(0, true, false); else SMP(2, true, false); }
+    else { if (tmode == 0) SMP(0, false, false); else if (tmode == 1) SMP(1, false, false); else SMP(2, false, false); }
 #undef SMP
     MNN_LAUNCH_CHECK();
     return MNN_OK;

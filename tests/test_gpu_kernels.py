@@ -441,6 +441,27 @@ def test_nade_sample_bit_exact(ops, N, D, Hn, tracks, temp):
     assert np.array_equal(out2.cpu().numpy().reshape(N, D, tracks).transpose(0, 2, 1).reshape(N, tracks * D), got)
 
 
+def test_nade_sample_near_ties_take_the_exact_comparison(ops):
+    """The sampling kernel settles a draw from the hardware exp2 / rcp probability unless the decision is within 1e-4 of a tie and
+    then compares exactly.  Force the tie path: threshold draws (temperature None -> p >= 0.5, nade.py:278-279) with all-zero weights
+    and b_dec in {0, +-1e-7, +-3e-6, +-1}: the logit IS b_dec and det_sigmoid(+-tiny) rounds to exactly 0.5 or not -- the oracle's
+    float32 restatement decides, the kernel must agree on every visible (Hn = 256: the specialised kernel; Hn = 40: the generic one)."""
+    N, D = 6, 64
+    vals = np.array([0.0, 1e-7, -1e-7, 3e-6, -3e-6, 1.0, -1.0, 5.9e-8, -5.9e-8, 2e-5, -2e-5], np.float32)
+    R = np.random.default_rng(2)
+    for Hn in (256, 40):
+        bias = np.zeros((N, Hn + D), np.float32)
+        bias[:, Hn:] = vals[R.integers(0, len(vals), (N, D))]
+        we = np.zeros((1, D, Hn), np.float32)
+        wd = np.zeros((1, D, Hn), np.float32)
+        out = torch.zeros((N, D), device=DEV, dtype=torch.uint8)
+        ops.nade_sample(dev(bias), dev(we), dev(wd), 1, D, Hn, None, seed=1, row0=0, sub=0, samples=out)
+        u = np.zeros((N, D), np.float32)
+        s_ref, _ = det.nade_sample(bias, we[0], wd[0], 1, 0, D, Hn, None, u)
+        assert np.array_equal(out.cpu().numpy(), s_ref)
+        assert 0 < s_ref.mean() < 1
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,D,Hn,k,bcast", [(20, 88, 256, 10, False), (9, 30, 20, 3, True), (17, 440, 64, 2, False), (5, 12, 7, 0, False)])
 def test_rbm_gibbs_bit_exact(ops, N, D, Hn, k, bcast):
