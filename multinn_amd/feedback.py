@@ -125,6 +125,7 @@ class FeedbackRnnSampler:
     def __init__(self, generators, feedback):
         self.generators, self.feedback = generators, feedback
         self.num_tracks = len(generators)
+        self.concurrent = True       # the M generators of a step run on M streams (parallel branches of the captured scan)
 
     def generate(self, x_u8, num_steps):
         """x_u8 [B,Ti,P,M] intro piano-rolls -> samples u8 [B,num_steps,P,M].  One hipGraph replay per call on the
@@ -162,18 +163,48 @@ class FeedbackRnnSampler:
             g._ensure_packed()
             states.append(g.steps(torch.cat([enc[..., i].float(), x_fb], -1)))                      # multinn_feedback.py:143-149
         out = torch.empty((B, num_steps, P, M), device=dev, dtype=torch.uint8)
-        for s in range(num_steps):                                                                  # _feedback_recurrence (175-218)
-            samples = []
-            for i, g in enumerate(self.generators):
-                g._gen_step = s
-                g._last_dense = states[i].dense
-                smp, _ = g.sample_single(None, states[i])
-                samples.append(smp)
-            st = torch.stack(samples, -1)                                                           # [B,P,M]
-            out[:, s] = st
-            fb, fb_state = self.feedback.single(st.reshape(B, P * M), fb_state)
-            for i, g in enumerate(self.generators):
-                states[i] = g.single_step(torch.cat([samples[i].float(), fb], 1), states[i])
+        # Inside a step the tracks are independent: generator i's {sample | LSTM step, Dense} run on stream i, joined on
+        # the main stream around the feedback step.  Their single steps take the launch-per-step LSTM kernels: persistent launches
+        # spin on their own workgroups and must not share the device with one another (LstmStack.persist_single_step).
+        par = self.concurrent and x_u8.is_cuda and M > 1
+        main = torch.cuda.current_stream() if x_u8.is_cuda else None
+        if par:
+            if getattr(self, "_lanes", None) is None or len(self._lanes) != M:
+                self._lanes = [torch.cuda.Stream() for _ in range(M)]
+            lanes = self._lanes
+            for g in self.generators:
+                g._stack.persist_single_step = False
+        import contextlib
+        on = (lambda i: torch.cuda.stream(lanes[i])) if par else (lambda i: contextlib.nullcontext())
+        try:
+            for s in range(num_steps):                                                              # _feedback_recurrence (175-218)
+                samples = []
+                for i, g in enumerate(self.generators):
+                    if par and s == 0:
+                        lanes[i].wait_stream(main)
+                    with on(i):
+                        g._gen_step = s
+                        g._last_dense = states[i].dense
+                        smp, _ = g.sample_single(None, states[i])
+                    samples.append(smp)
+                if par:
+                    for ln in lanes:
+                        main.wait_stream(ln)
+                st = torch.stack(samples, -1)                                                       # [B,P,M]
+                out[:, s] = st
+                fb, fb_state = self.feedback.single(st.reshape(B, P * M), fb_state)
+                for i, g in enumerate(self.generators):
+                    if par:
+                        lanes[i].wait_stream(main)
+                    with on(i):
+                        states[i] = g.single_step(torch.cat([samples[i].float(), fb], 1), states[i])
+            if par:
+                for ln in lanes:
+                    main.wait_stream(ln)
+        finally:
+            if par:
+                for g in self.generators:
+                    g._stack.persist_single_step = True
         return out
 
 

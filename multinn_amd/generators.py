@@ -102,8 +102,15 @@ class LstmStack:
 
     persistent = os.environ.get("MULTINN_PERSIST", "1") != "0"   # one launch for all T steps (lstm_persist.hip) when the grid fits the device
 
-    def _persist(self, B):
+    # A persistent launch spins on its own workgroups and needs ALL of them resident: two such launches must never share the device.
+    # A caller that runs several stacks on concurrent streams (the feedback sampling scan) clears this for its single steps, which then
+    # take the launch-per-step kernels (T = 1: nothing to keep resident anyway).
+    persist_single_step = True
+
+    def _persist(self, B, T=2):
         if not (self.persistent and len(self.packed) == 2 and self.dtype == torch.bfloat16):
+            return False
+        if T == 1 and not self.persist_single_step:
             return False
         return ops.lstm2_persist_ok(B, self.packed[0]["u"], self.packed[1]["u"])
 
@@ -132,7 +139,7 @@ class LstmStack:
         T, B, _ = x_tm.shape
         dev = x_tm.device
         L = len(self.packed)
-        persist = self._persist(B)
+        persist = self._persist(B, T)
         bufs = []
         for l, p in enumerate(self.packed):
             u = p["u"]
