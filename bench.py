@@ -175,6 +175,7 @@ def main():
         dt = float(tt)
     if rank != 0:
         if world > 1 or rehearsal:
+            dist.barrier()              # rank 0 is still measuring the sampling scan: leave the process group together
             dist.destroy_process_group()
         return
 
@@ -249,6 +250,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(P, M, a.rho)
     print(json.dumps(out))
     if world > 1 or rehearsal:
+        dist.barrier()
         dist.destroy_process_group()
 
 

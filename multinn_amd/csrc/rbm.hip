@@ -101,6 +101,140 @@ rbm_gibbs_kernel(int N, int D, int Hn, int k, const uint8_t* __restrict__ v0, co
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// The same chain with W RESIDENT IN LDS (D (Hn + 1) floats fit: D = 88, Hn = 256 is 90 KB).  The streaming kernel above fetches every
+// W row from L2 inside the k loop, twice per Gibbs iteration, and waits for it: 33 us per iteration whatever the row count.  Here W is
+// read once per workgroup; the row stride Hn + 1 makes both walks conflict-free (hidden phase: consecutive threads, consecutive
+// columns; visible phase: thread d walks row d, bank (d + k) mod 32), so no transposed copy either.  R rows per workgroup (2 for a
+// sampling batch: many short workgroups; 8 for training batches); a phase with fewer outputs than threads splits the rows over the
+// spare threads (visible phase at D = 88: two or four row groups).  Biases stay in registers over the chain.  Arithmetic and order are
+// the streaming kernel's: ascending-index fma chain from 0, + bias, det_sigmoid, Philox draw -- bit-identical draws.
+// ----------------------------------------------------------------------------------------------
+template <int R, int RG, typename F>      // RG rows per thread; thread t -> (row group t / n_out, output t % n_out)
+__device__ __forceinline__ void rbm_phase_lds(const float* __restrict__ in_s, int Kpad, int K, const float* __restrict__ Ws, int w_k_stride,
+                                              int w_o_stride, int n_out, F&& fn) {
+    const int g = threadIdx.x / n_out, o = threadIdx.x - g * n_out;
+    if (g >= R / RG) return;
+    const float* __restrict__ wp = Ws + (size_t)o * w_o_stride;
+    const float* __restrict__ xp = in_s + (size_t)g * RG * Kpad;
+    float acc[RG];
+#pragma unroll
+    for (int r = 0; r < RG; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        float w[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) w[kk] = wp[(size_t)min(k0 + kk, K - 1) * w_k_stride];     // beyond K the input is the zero padding
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const float4 x = *reinterpret_cast<const float4*>(xp + r * Kpad + k0);
+            acc[r] = fmaf(x.x, w[0], acc[r]);
+            acc[r] = fmaf(x.y, w[1], acc[r]);
+            acc[r] = fmaf(x.z, w[2], acc[r]);
+            acc[r] = fmaf(x.w, w[3], acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RG; ++r) fn(g * RG + r, r, o, acc[r]);
+}
+
+template <int R, int RGH, int RGV>        // rows per thread in the hidden / visible phase (R / RG row groups of n_out threads each)
+__global__ void __launch_bounds__(256)
+rbm_gibbs_lds_kernel(int N, int D, int Hn, int k, const uint8_t* __restrict__ v0, const float* __restrict__ W, const float* __restrict__ bh,
+                     int ld_bh, const float* __restrict__ bv, int ld_bv, uint64_t seed, uint32_t row0, const uint32_t* __restrict__ row_ids,
+                     uint32_t sub0, float* __restrict__ p_v, uint8_t* __restrict__ v_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Dp = (D + 3) & ~3, Hp = (Hn + 3) & ~3, ldw = Hn + 1;
+    float* vs = smem;                 // [R][Dp]
+    float* hs = vs + R * Dp;          // [R][Hp]
+    float* Ws = hs + R * Hp;          // [D][ldw]
+    const int n0 = blockIdx.x * R;
+    for (int d = threadIdx.x >> 6; d < D; d += 4)            // one wave per row of W: coalesced, no index division
+        for (int j = threadIdx.x & 63; j < Hn; j += 64) Ws[d * ldw + j] = W[(size_t)d * Hn + j];
+    for (int e = threadIdx.x; e < R * Dp; e += blockDim.x) {
+        const int r = e / Dp, kx = e % Dp, n = n0 + r;
+        vs[e] = (n < N && kx < D) ? (float)v0[(size_t)n * D + kx] : 0.f;
+    }
+    for (int e = threadIdx.x; e < R * Hp; e += blockDim.x) hs[e] = 0.f;
+    // this thread's biases and row ids: constant over the chain
+    float bhr[RGH], bvr[RGV];
+    uint32_t idh[RGH], idv[RGV];
+    {
+        const int g = threadIdx.x / Hn, o = threadIdx.x - g * Hn;
+#pragma unroll
+        for (int r = 0; r < RGH; ++r) {
+            const int n = min(n0 + g * RGH + r, N - 1);
+            bhr[r] = bh[(size_t)n * ld_bh + min(o, Hn - 1)];
+            idh[r] = rbm_rowid(row_ids, row0, n);
+        }
+    }
+    {
+        const int g = threadIdx.x / D, o = threadIdx.x - g * D;
+#pragma unroll
+        for (int r = 0; r < RGV; ++r) {
+            const int n = min(n0 + min(g * RGV + r, R - 1), N - 1);
+            bvr[r] = bv[(size_t)n * ld_bv + min(o, D - 1)];
+            idv[r] = rbm_rowid(row_ids, row0, n);
+        }
+    }
+    __syncthreads();
+    if (k == 0) {                     // tf.while_loop with zero iterations returns (v, v)
+        for (int e = threadIdx.x; e < R * D; e += blockDim.x) {
+            const int r = e / D, d = e % D, n = n0 + r;
+            if (n < N) {
+                if (p_v) p_v[(size_t)n * D + d] = vs[r * Dp + d];
+                if (v_out) v_out[(size_t)n * D + d] = (uint8_t)vs[r * Dp + d];
+            }
+        }
+        return;
+    }
+    for (int it = 0; it < k; ++it) {
+        rbm_phase_lds<R, RGH>(vs, Dp, D, Ws, ldw, 1, Hn, [&](int r, int rl, int j, float acc) {
+            if (n0 + r >= N) return;
+            const float p = det_sigmoid(acc + bhr[rl]);
+            const float u = philox_uniform1(seed, MNN_STREAM_RBM_H, idh[rl], sub0 + (uint32_t)it, (uint32_t)j);
+            hs[r * Hp + j] = u < p ? 1.f : 0.f;
+        });
+        __syncthreads();
+        const bool last = it == k - 1;
+        rbm_phase_lds<R, RGV>(hs, Hp, Hn, Ws, 1, ldw, D, [&](int r, int rl, int d, float acc) {
+            const int n = n0 + r;
+            if (n >= N) return;
+            const float p = det_sigmoid(acc + bvr[rl]);
+            const float u = philox_uniform1(seed, MNN_STREAM_RBM_V, idv[rl], sub0 + (uint32_t)it, (uint32_t)d);
+            const float sv = u < p ? 1.f : 0.f;
+            vs[r * Dp + d] = sv;
+            if (last) {
+                if (p_v) p_v[(size_t)n * D + d] = p;
+                if (v_out) v_out[(size_t)n * D + d] = (uint8_t)sv;
+            }
+        });
+        __syncthreads();
+    }
+}
+
+static size_t rbm_lds_resident_bytes(int R, int D, int Hn) {
+    return ((size_t)R * (((D + 3) & ~3) + ((Hn + 3) & ~3)) + (size_t)D * (Hn + 1)) * sizeof(float);
+}
+
+// Launch the resident-W form when it applies (both phases fit 256 threads, W fits LDS); false: the caller streams.
+template <int R, int RGH, int RGV>
+static bool launch_gibbs_lds(hipStream_t st, int N, int D, int Hn, int k, const uint8_t* v0, const float* W, const float* bh, int ld_bh, const float* bv,
+                             int ld_bv, uint64_t seed, uint32_t row0, const uint32_t* row_ids, uint32_t sub0, float* p_v, uint8_t* v_out) {
+    const size_t lds = rbm_lds_resident_bytes(R, D, Hn);
+    static bool raised = false;                        // per instantiation: dynamic LDS above 64 KB has to be asked for once
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rbm_gibbs_lds_kernel<R, RGH, RGV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        raised = true;
+    }
+    hipLaunchKernelGGL((rbm_gibbs_lds_kernel<R, RGH, RGV>), dim3(cdiv(N, R)), dim3(256), lds, st, N, D, Hn, k, v0, W, bh, ld_bh, bv, ld_bv, seed,
+                       row0, row_ids, sub0, p_v, v_out);
+    return true;
+}
+
 extern "C" size_t mnn_rbm_workspace_bytes(int D, int Hn) { return (size_t)D * Hn * sizeof(float); }
 
 extern "C" int mnn_transpose(mnn_stream_t s, const void* in, int in_dtype, int R, int C, int ld_in, void* out, int out_dtype, int ld_out);
@@ -114,6 +248,21 @@ extern "C" int mnn_rbm_gibbs(mnn_stream_t s, int N, int D, int Hn, int k, const 
     MNN_REQUIRE(v0 && W && bh && bv && workspace, "mnn_rbm_gibbs: null pointer");
     MNN_REQUIRE((ld_bh == 0 || ld_bh >= Hn) && (ld_bv == 0 || ld_bv >= D), "mnn_rbm_gibbs: bad bias leading dimension");
     MNN_REQUIRE(rbm_lds_bytes(D, Hn) <= 160 * 1024, "mnn_rbm_gibbs: D+Hn too large for LDS");
+    if (Hn <= 256 && D <= 256 && getenv("MNN_RBM_STREAM_W") == nullptr) {
+        // W resident in LDS: rows per workgroup by batch size, rows per thread by how many row groups of n_out threads fit 256
+        hipStream_t st = (hipStream_t)s;
+        const int gh = 256 / Hn, gv = 256 / D;          // row groups available in the hidden / visible phase
+        bool done = false;
+#define TRY(R, RGH, RGV) (rbm_lds_resident_bytes(R, D, Hn) <= 158 * 1024 && \
+                          launch_gibbs_lds<R, RGH, RGV>(st, N, D, Hn, k, v0, W, bh, ld_bh, bv, ld_bv, seed, row0, row_ids, sub0, p_v, v_out))
+        if (N >= 2048) done = gv >= 2 ? (gh >= 2 ? TRY(8, 4, 4) : TRY(8, 8, 4)) : (gh >= 2 ? TRY(8, 4, 8) : TRY(8, 8, 8));
+        else done = gv >= 2 ? (gh >= 2 ? TRY(2, 1, 1) : TRY(2, 2, 1)) : (gh >= 2 ? TRY(2, 1, 2) : TRY(2, 2, 2));
+#undef TRY
+        if (done) {
+            MNN_LAUNCH_CHECK();
+            return MNN_OK;
+        }
+    }
     int rc = mnn_transpose(s, W, MNN_F32, D, Hn, Hn, workspace, MNN_F32, D);
     if (rc != MNN_OK) return rc;
     hipLaunchKernelGGL(rbm_gibbs_kernel, dim3(cdiv(N, RBM_R)), dim3(256), rbm_lds_bytes(D, Hn), (hipStream_t)s, N, D, Hn, k, v0, W,

@@ -214,3 +214,5 @@ def test_bench_data_parallel_rehearsal_over_rccl():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["launch"] == "hipgraph-replay" and out["value"] > 0
+    smp = out["sampling"]                      # the sampling scan runs on rank 0 after the timed region, process group still up
+    assert smp["unit"] == "generated timesteps/s" and smp["value"] > 0 and smp["launch"] == "hipgraph-replay"

@@ -463,8 +463,12 @@ def test_nade_sample_near_ties_take_the_exact_comparison(ops):
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("N,D,Hn,k,bcast", [(20, 88, 256, 10, False), (9, 30, 20, 3, True), (17, 440, 64, 2, False), (5, 12, 7, 0, False)])
+@pytest.mark.parametrize("N,D,Hn,k,bcast", [(20, 88, 256, 10, False), (9, 30, 20, 3, True), (17, 440, 64, 2, False), (5, 12, 7, 0, False),
+                                            (2101, 88, 256, 2, False), (2050, 40, 100, 2, True), (33, 200, 130, 2, False), (2049, 130, 200, 1, False),
+                                            (40, 200, 100, 2, False), (2060, 200, 100, 1, True)])
 def test_rbm_gibbs_bit_exact(ops, N, D, Hn, k, bcast):
+    """D, Hn <= 256: W resident in LDS (2 rows per workgroup below 2048 rows, 8 from there on; rows split over spare threads when a
+    phase has at most 128 outputs); D = 440: the streaming kernel.  Every form must reproduce the oracle's draws and probabilities."""
     R = np.random.default_rng(D)
     W = (R.standard_normal((D, Hn)) * .3).astype(np.float32)
     bh = (R.standard_normal((1 if bcast else N, Hn)) * .3).astype(np.float32)
@@ -477,8 +481,9 @@ def test_rbm_gibbs_bit_exact(ops, N, D, Hn, k, bcast):
     ops.rbm_gibbs(dev(v0), dev(W), dev(bh), dev(bv), k, seed=11, row0=500, sub0=3, p_v=p_v, v_out=v_out)
     assert np.array_equal(v_out.cpu().numpy(), v_ref), "Gibbs samples must be bit-exact"
     assert np.array_equal(p_v.cpu().numpy(), p_ref)
-    p64, v64 = orbm.gibbs(v0.astype(np.float64), W.astype(np.float64), bh.astype(np.float64), bv.astype(np.float64), k, u_h, u_v)
-    assert np.abs(p_v.cpu().numpy() - p64).max() < 1e-6 or not np.array_equal(v_ref, v64.astype(np.uint8))
+    if N <= 64:
+        p64, v64 = orbm.gibbs(v0.astype(np.float64), W.astype(np.float64), bh.astype(np.float64), bv.astype(np.float64), k, u_h, u_v)
+        assert np.abs(p_v.cpu().numpy() - p64).max() < 1e-6 or not np.array_equal(v_ref, v64.astype(np.uint8))
     # row_ids path
     ids = dev(rows.astype(np.int32))
     v2 = torch.zeros((N, D), device=DEV, dtype=torch.uint8)
