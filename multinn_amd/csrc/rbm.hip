@@ -105,9 +105,9 @@ rbm_gibbs_kernel(int N, int D, int Hn, int k, const uint8_t* __restrict__ v0, co
 // The same chain with W RESIDENT IN LDS (D (Hn + 1) floats fit: D = 88, Hn = 256 is 90 KB).  The streaming kernel above fetches every
 // W row from L2 inside the k loop, twice per Gibbs iteration, and waits for it: 33 us per iteration whatever the row count.  Here W is
 // read once per workgroup; the row stride Hn + 1 makes both walks conflict-free (hidden phase: consecutive threads, consecutive
-// columns; visible phase: thread d walks row d, bank (d + k) mod 32), so no transposed copy either.  R rows per workgroup (2 for a
-// sampling batch: many short workgroups; 8 for training batches); a phase with fewer outputs than threads splits the rows over the
-// spare threads (visible phase at D = 88: two or four row groups).  Biases stay in registers over the chain.  Arithmetic and order are
+// columns; visible phase: thread d walks row d, bank (d + k) mod 32), so no transposed copy either.  R = 2 rows per workgroup (many
+// short workgroups; used below 2048 rows, see mnn_rbm_gibbs); a phase with fewer outputs than threads splits the rows over the
+// spare threads (visible phase at D = 88: two row groups).  Biases stay in registers over the chain.  Arithmetic and order are
 // the streaming kernel's: ascending-index fma chain from 0, + bias, det_sigmoid, Philox draw -- bit-identical draws.
 // ----------------------------------------------------------------------------------------------
 template <int R, int RG, typename F>      // RG rows per thread; thread t -> (row group t / n_out, output t % n_out)
@@ -248,15 +248,16 @@ extern "C" int mnn_rbm_gibbs(mnn_stream_t s, int N, int D, int Hn, int k, const 
     MNN_REQUIRE(v0 && W && bh && bv && workspace, "mnn_rbm_gibbs: null pointer");
     MNN_REQUIRE((ld_bh == 0 || ld_bh >= Hn) && (ld_bv == 0 || ld_bv >= D), "mnn_rbm_gibbs: bad bias leading dimension");
     MNN_REQUIRE(rbm_lds_bytes(D, Hn) <= 160 * 1024, "mnn_rbm_gibbs: D+Hn too large for LDS");
-    if (Hn <= 256 && D <= 256 && getenv("MNN_RBM_STREAM_W") == nullptr) {
-        // W resident in LDS: rows per workgroup by batch size, rows per thread by how many row groups of n_out threads fit 256
+    if (N < 2048 && Hn <= 256 && D <= 256 && getenv("MNN_RBM_STREAM_W") == nullptr) {
+        // sampling-sized batches: W resident in LDS, two rows per workgroup (one workgroup per CU: at training sizes -- 32 768 rows --
+        // the streaming kernel's eight rows per workgroup and several workgroups per CU win, 1.5 vs 2.5 ms); rows per thread by how
+        // many row groups of n_out threads fit 256
         hipStream_t st = (hipStream_t)s;
         const int gh = 256 / Hn, gv = 256 / D;          // row groups available in the hidden / visible phase
         bool done = false;
 #define TRY(R, RGH, RGV) (rbm_lds_resident_bytes(R, D, Hn) <= 158 * 1024 && \
                           launch_gibbs_lds<R, RGH, RGV>(st, N, D, Hn, k, v0, W, bh, ld_bh, bv, ld_bv, seed, row0, row_ids, sub0, p_v, v_out))
-        if (N >= 2048) done = gv >= 2 ? (gh >= 2 ? TRY(8, 4, 4) : TRY(8, 8, 4)) : (gh >= 2 ? TRY(8, 4, 8) : TRY(8, 8, 8));
-        else done = gv >= 2 ? (gh >= 2 ? TRY(2, 1, 1) : TRY(2, 2, 1)) : (gh >= 2 ? TRY(2, 1, 2) : TRY(2, 2, 2));
+        done = gv >= 2 ? (gh >= 2 ? TRY(2, 1, 1) : TRY(2, 2, 1)) : (gh >= 2 ? TRY(2, 1, 2) : TRY(2, 2, 2));
 #undef TRY
         if (done) {
             MNN_LAUNCH_CHECK();

@@ -467,8 +467,8 @@ def test_nade_sample_near_ties_take_the_exact_comparison(ops):
                                             (2101, 88, 256, 2, False), (2050, 40, 100, 2, True), (33, 200, 130, 2, False), (2049, 130, 200, 1, False),
                                             (40, 200, 100, 2, False), (2060, 200, 100, 1, True)])
 def test_rbm_gibbs_bit_exact(ops, N, D, Hn, k, bcast):
-    """D, Hn <= 256: W resident in LDS (2 rows per workgroup below 2048 rows, 8 from there on; rows split over spare threads when a
-    phase has at most 128 outputs); D = 440: the streaming kernel.  Every form must reproduce the oracle's draws and probabilities."""
+    """Below 2048 rows with D, Hn <= 256: W resident in LDS, two rows per workgroup (rows split over spare threads when a phase has
+    at most 128 outputs); otherwise the streaming kernel.  Every form must reproduce the oracle's draws and probabilities."""
     R = np.random.default_rng(D)
     W = (R.standard_normal((D, Hn)) * .3).astype(np.float32)
     bh = (R.standard_normal((1 if bcast else N, Hn)) * .3).astype(np.float32)
