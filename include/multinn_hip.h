@@ -238,6 +238,12 @@ size_t mnn_rbm_workspace_bytes(int D, int Hn);
 int mnn_rbm_gibbs(mnn_stream_t s, int N, int D, int Hn, int k, const uint8_t* v0, const float* W, const float* bh, int ld_bh,
                   const float* bv, int ld_bv, uint64_t seed, uint32_t row0, const uint32_t* row_ids, uint32_t sub0,
                   float* p_v, uint8_t* v_out, void* workspace);
+/* The same chain with the step counter of the optimiser read ON THE DEVICE: effective seed = seed + *seed_step (NULL: seed).  A launch
+ * captured in a hipGraph then draws new uniforms at every replay, like the dropout masks (mnn_dropout_mask's step pointer); the
+ * reference re-runs its random ops at every sess.run (rbm.py:222-226). */
+int mnn_rbm_gibbs_stepped(mnn_stream_t s, int N, int D, int Hn, int k, const uint8_t* v0, const float* W, const float* bh, int ld_bh,
+                  const float* bv, int ld_bv, uint64_t seed, uint32_t row0, const uint32_t* row_ids, uint32_t sub0,
+                  float* p_v, uint8_t* v_out, void* workspace, const int* seed_step);
 int mnn_rbm_hidden(mnn_stream_t s, int N, int D, int Hn, const void* v, int v_dtype, const float* W, const float* bh,
                    int ld_bh, int stream_id, uint64_t seed, uint32_t row0, uint32_t sub, float* p_h, uint8_t* h);
 int mnn_rbm_visible(mnn_stream_t s, int N, int D, int Hn, const void* h, int h_dtype, const float* W, const float* bv,

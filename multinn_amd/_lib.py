@@ -38,6 +38,7 @@ SIGNATURES = {
     "mnn_nade_sample": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _f, _u64, _u32, _u32, _p, _l, _i, _i, _p]),
     "mnn_rbm_workspace_bytes": (_sz, [_i, _i]),
     "mnn_rbm_gibbs": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _u64, _u32, _p, _u32, _p, _p, _p]),
+    "mnn_rbm_gibbs_stepped": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _u64, _u32, _p, _u32, _p, _p, _p, _p]),
     "mnn_rbm_hidden": (_i, [_p, _i, _i, _i, _p, _i, _p, _p, _i, _i, _u64, _u32, _u32, _p, _p]),
     "mnn_rbm_visible": (_i, [_p, _i, _i, _i, _p, _i, _p, _p, _i, _i, _u64, _u32, _u32, _p, _p, _p]),
     "mnn_rbm_free_energy": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p]),

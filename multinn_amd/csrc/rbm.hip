@@ -56,8 +56,10 @@ __device__ __forceinline__ void rbm_load_rows(const TV* __restrict__ src, int N,
 __global__ void __launch_bounds__(256)
 rbm_gibbs_kernel(int N, int D, int Hn, int k, const uint8_t* __restrict__ v0, const float* __restrict__ W, const float* __restrict__ Wt,
                  const float* __restrict__ bh, int ld_bh, const float* __restrict__ bv, int ld_bv, uint64_t seed, uint32_t row0,
-                 const uint32_t* __restrict__ row_ids, uint32_t sub0, float* __restrict__ p_v, uint8_t* __restrict__ v_out) {
+                 const uint32_t* __restrict__ row_ids, uint32_t sub0, float* __restrict__ p_v, uint8_t* __restrict__ v_out,
+                 const int* __restrict__ seed_step) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (seed_step != nullptr) seed += (uint64_t)(int64_t)*seed_step;      // step counter on the device: a captured launch draws anew every replay
     const int Dp = (D + 3) & ~3, Hp = (Hn + 3) & ~3;
     float* vs = smem;                 // [RBM_R][Dp]
     float* hs = smem + RBM_R * Dp;    // [RBM_R][Hp]
@@ -141,8 +143,9 @@ template <int R, int RGH, int RGV>        // rows per thread in the hidden / vis
 __global__ void __launch_bounds__(256)
 rbm_gibbs_lds_kernel(int N, int D, int Hn, int k, const uint8_t* __restrict__ v0, const float* __restrict__ W, const float* __restrict__ bh,
                      int ld_bh, const float* __restrict__ bv, int ld_bv, uint64_t seed, uint32_t row0, const uint32_t* __restrict__ row_ids,
-                     uint32_t sub0, float* __restrict__ p_v, uint8_t* __restrict__ v_out) {
+                     uint32_t sub0, float* __restrict__ p_v, uint8_t* __restrict__ v_out, const int* __restrict__ seed_step) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (seed_step != nullptr) seed += (uint64_t)(int64_t)*seed_step;
     const int Dp = (D + 3) & ~3, Hp = (Hn + 3) & ~3, ldw = Hn + 1;
     float* vs = smem;                 // [R][Dp]
     float* hs = vs + R * Dp;          // [R][Hp]
@@ -219,7 +222,8 @@ static size_t rbm_lds_resident_bytes(int R, int D, int Hn) {
 // Launch the resident-W form when it applies (both phases fit 256 threads, W fits LDS); false: the caller streams.
 template <int R, int RGH, int RGV>
 static bool launch_gibbs_lds(hipStream_t st, int N, int D, int Hn, int k, const uint8_t* v0, const float* W, const float* bh, int ld_bh, const float* bv,
-                             int ld_bv, uint64_t seed, uint32_t row0, const uint32_t* row_ids, uint32_t sub0, float* p_v, uint8_t* v_out) {
+                             int ld_bv, uint64_t seed, uint32_t row0, const uint32_t* row_ids, uint32_t sub0, float* p_v, uint8_t* v_out,
+                             const int* seed_step) {
     const size_t lds = rbm_lds_resident_bytes(R, D, Hn);
     static bool raised = false;                        // per instantiation: dynamic LDS above 64 KB has to be asked for once
     if (!raised) {
@@ -231,7 +235,7 @@ static bool launch_gibbs_lds(hipStream_t st, int N, int D, int Hn, int k, const 
         raised = true;
     }
     hipLaunchKernelGGL((rbm_gibbs_lds_kernel<R, RGH, RGV>), dim3(cdiv(N, R)), dim3(256), lds, st, N, D, Hn, k, v0, W, bh, ld_bh, bv, ld_bv, seed,
-                       row0, row_ids, sub0, p_v, v_out);
+                       row0, row_ids, sub0, p_v, v_out, seed_step);
     return true;
 }
 
@@ -241,9 +245,9 @@ extern "C" int mnn_transpose(mnn_stream_t s, const void* in, int in_dtype, int R
 
 static size_t rbm_lds_bytes(int D, int Hn) { return (size_t)RBM_R * (((D + 3) & ~3) + ((Hn + 3) & ~3)) * sizeof(float); }
 
-extern "C" int mnn_rbm_gibbs(mnn_stream_t s, int N, int D, int Hn, int k, const uint8_t* v0, const float* W, const float* bh, int ld_bh,
-                             const float* bv, int ld_bv, uint64_t seed, uint32_t row0, const uint32_t* row_ids, uint32_t sub0, float* p_v,
-                             uint8_t* v_out, void* workspace) {
+extern "C" int mnn_rbm_gibbs_stepped(mnn_stream_t s, int N, int D, int Hn, int k, const uint8_t* v0, const float* W, const float* bh, int ld_bh,
+                                     const float* bv, int ld_bv, uint64_t seed, uint32_t row0, const uint32_t* row_ids, uint32_t sub0, float* p_v,
+                                     uint8_t* v_out, void* workspace, const int* seed_step) {
     MNN_REQUIRE(N > 0 && D > 0 && Hn > 0 && k >= 0, "mnn_rbm_gibbs: bad sizes N=%d D=%d Hn=%d k=%d", N, D, Hn, k);
     MNN_REQUIRE(v0 && W && bh && bv && workspace, "mnn_rbm_gibbs: null pointer");
     MNN_REQUIRE((ld_bh == 0 || ld_bh >= Hn) && (ld_bv == 0 || ld_bv >= D), "mnn_rbm_gibbs: bad bias leading dimension");
@@ -256,7 +260,7 @@ extern "C" int mnn_rbm_gibbs(mnn_stream_t s, int N, int D, int Hn, int k, const 
         const int gh = 256 / Hn, gv = 256 / D;          // row groups available in the hidden / visible phase
         bool done = false;
 #define TRY(R, RGH, RGV) (rbm_lds_resident_bytes(R, D, Hn) <= 158 * 1024 && \
-                          launch_gibbs_lds<R, RGH, RGV>(st, N, D, Hn, k, v0, W, bh, ld_bh, bv, ld_bv, seed, row0, row_ids, sub0, p_v, v_out))
+                          launch_gibbs_lds<R, RGH, RGV>(st, N, D, Hn, k, v0, W, bh, ld_bh, bv, ld_bv, seed, row0, row_ids, sub0, p_v, v_out, seed_step))
         done = gv >= 2 ? (gh >= 2 ? TRY(2, 1, 1) : TRY(2, 2, 1)) : (gh >= 2 ? TRY(2, 1, 2) : TRY(2, 2, 2));
 #undef TRY
         if (done) {
@@ -267,9 +271,15 @@ extern "C" int mnn_rbm_gibbs(mnn_stream_t s, int N, int D, int Hn, int k, const 
     int rc = mnn_transpose(s, W, MNN_F32, D, Hn, Hn, workspace, MNN_F32, D);
     if (rc != MNN_OK) return rc;
     hipLaunchKernelGGL(rbm_gibbs_kernel, dim3(cdiv(N, RBM_R)), dim3(256), rbm_lds_bytes(D, Hn), (hipStream_t)s, N, D, Hn, k, v0, W,
-                       (const float*)workspace, bh, ld_bh, bv, ld_bv, seed, row0, row_ids, sub0, p_v, v_out);
+                       (const float*)workspace, bh, ld_bh, bv, ld_bv, seed, row0, row_ids, sub0, p_v, v_out, seed_step);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
+}
+
+extern "C" int mnn_rbm_gibbs(mnn_stream_t s, int N, int D, int Hn, int k, const uint8_t* v0, const float* W, const float* bh, int ld_bh,
+                             const float* bv, int ld_bv, uint64_t seed, uint32_t row0, const uint32_t* row_ids, uint32_t sub0, float* p_v,
+                             uint8_t* v_out, void* workspace) {
+    return mnn_rbm_gibbs_stepped(s, N, D, Hn, k, v0, W, bh, ld_bh, bv, ld_bv, seed, row0, row_ids, sub0, p_v, v_out, workspace, nullptr);
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -449,18 +449,65 @@ class RnnEstimator(Generator):
     def _row_weight(self, lengths, B, T, device):
         """1/N_valid on valid rows (N_valid summed over ALL ranks), 0 on padding."""
         if lengths is None:
-            n_local = torch.tensor(float(B * T), device=device)
-            mask = torch.ones((T, B), device=device)
-        else:
-            mask = (torch.arange(T, device=device)[:, None] < lengths.to(device)[None, :]).float()
-            n_local = mask.sum()
-        n_tot = n_local.clone()
+            # full-length batches: every rank holds B*T valid rows, the total is known on the host -- no copy, no collective (this
+            # path runs inside captured steps)
+            n_ranks = torch.distributed.get_world_size() if (dp_active() and torch.distributed.is_initialized()) else 1
+            return torch.full((T * B,), 1.0 / float(B * T * n_ranks), device=device)
+        mask = (torch.arange(T, device=device)[:, None] < lengths.to(device)[None, :]).float()
+        n_tot = mask.sum()
         if dp_active():
             torch.distributed.all_reduce(n_tot)
         return (mask / n_tot).reshape(-1).contiguous()
 
     def steps(self, inputs, initial_state=None):
         return self._get_state(inputs, initial_state=initial_state, last_outputs=True)
+
+    def graphed_build_train(self, x, y, optimizer, lr=None, warmup=2):
+        """The generic captured optimiser step: build(x, y, None, True, 'train') + train(optimizer, lr) as hipGraph replays, for the
+        generators that train on encoder outputs rather than on a raw piano-roll batch (RnnRBM: jamming mode, RnnMultiNADE: composer
+        mode; RnnNade.graphed_train_step is the fused piano-roll form).  Eagerly such a step is host-bound (RnnRBM at [256,128,88]:
+        kernels 4 ms, wall 14 ms).  Returns run(x=None, y=None) -> loss.  Step-dependent values (dropout seed, Gibbs seed, Adam step)
+        are read from store.step_dev on the device; under data parallelism the gradient all-reduce stays an eager call between two
+        graphs.  Full-length batches only."""
+        from .training import allreduce_flat
+        sx, sy = x.clone(), y.clone()
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.build(sx, sy, None, True, "train")
+                self.train(optimizer, lr)
+        cur.wait_stream(side)
+        multi = dp_active()
+        g_fb, g_opt = torch.cuda.CUDAGraph(), None
+        with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
+            self.build(sx, sy, None, True, "train")
+            if multi:
+                self.backward()
+            else:
+                self.train(optimizer, lr)
+            loss = self._loss
+        if multi:
+            g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_opt, pool=g_fb.pool(), capture_error_mode="thread_local"):
+                self._grad_sumsq = compute_gradients(optimizer, self.store, self.clip_norm, lr, reduce=False)
+        self._packed_step = -1
+        self.store.step -= 1            # the captured step has not executed (host mirror of store.step_dev)
+
+        def run(x=None, y=None):
+            if x is not None:
+                sx.copy_(x)
+            if y is not None:
+                sy.copy_(y)
+            g_fb.replay()
+            if g_opt is not None:
+                allreduce_flat(self.store.grad)
+                g_opt.replay()
+            self.store.step += 1
+            return loss
+        run.graph = g_fb
+        return run
 
     def _step_input(self, B, device):
         """[B, ld0] staging row block of single_step: the zero padding beyond the input width is written once, every step converts its
@@ -920,7 +967,9 @@ class RnnRBM(RnnEstimator):
             rows = (torch.arange(T, device=dev)[:, None] * 65536 + (self.row0 + torch.arange(B, device=dev))[None, :]).reshape(-1).int()
             p_v = torch.empty((N, D), device=dev)
             v_s = torch.empty((N, D), device=dev, dtype=torch.uint8)
-            ops.rbm_gibbs(v0[:, :D].contiguous(), self._rbm.W, bh_t, bv_t, self._k, seed, 0, rows, 0, p_v, v_s)
+            # seed + step, the step read on the device (store.step_dev == store.step here): the same draws as passing seed + store.step,
+            # and a captured step (graphed_build_train) draws anew at every replay
+            ops.rbm_gibbs(v0[:, :D].contiguous(), self._rbm.W, bh_t, bv_t, self._k, self.seed, 0, rows, 0, p_v, v_s, seed_step=self.store.step_dev)
             if self.bias_mode == "conditional":
                 bh_u, bv_u = bh_t, bv_t
             else:

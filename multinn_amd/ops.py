@@ -421,7 +421,8 @@ def rbm_workspace(D, Hn, device):
     return torch.empty(_lib.load().mnn_rbm_workspace_bytes(D, Hn), dtype=torch.uint8, device=device)
 
 
-def rbm_gibbs(v0, W, bh, bv, k, seed, row0=0, row_ids=None, sub0=0, p_v=None, v_out=None):
+def rbm_gibbs(v0, W, bh, bv, k, seed, row0=0, row_ids=None, sub0=0, p_v=None, v_out=None, seed_step=None):
+    """seed_step (int32 device scalar, optional): added to `seed` on the device (graph-replay safe step-dependent draws)."""
     N, D = v0.shape
     Hn = W.shape[1]
     _req(v0.dtype == torch.uint8 and v0.is_contiguous(), "gibbs: v0 u8 [N,D]")
@@ -434,6 +435,11 @@ def rbm_gibbs(v0, W, bh, bv, k, seed, row0=0, row_ids=None, sub0=0, p_v=None, v_
     if row_ids is not None:
         _req(row_ids.dtype == torch.int32 and row_ids.numel() == N, "gibbs: row_ids int32 [N]")
     ws = rbm_workspace(D, Hn, v0.device)
+    if seed_step is not None:
+        _req(seed_step.dtype == torch.int32 and seed_step.numel() == 1, "gibbs: seed_step int32 [1]")
+        call("mnn_rbm_gibbs_stepped", _stream(), N, D, Hn, int(k), _ptr(v0), _ptr(W), _ptr(bh), _ldb(bh, Hn), _ptr(bv), _ldb(bv, D), int(seed),
+             int(row0), _ptr(row_ids), int(sub0), _ptr(p_v), _ptr(v_out), _ptr(ws), _ptr(seed_step))
+        return
     call("mnn_rbm_gibbs", _stream(), N, D, Hn, int(k), _ptr(v0), _ptr(W), _ptr(bh), _ldb(bh, Hn), _ptr(bv), _ldb(bv, D), int(seed), int(row0),
          _ptr(row_ids), int(sub0), _ptr(p_v), _ptr(v_out), _ptr(ws))
 

@@ -577,6 +577,43 @@ def test_graphed_train_step_matches_eager():
     assert torch.allclose(a.store.theta, b.store.theta, atol=2e-3)
 
 
+@pytest.mark.parametrize("kind", ["rbm", "multinade"])
+def test_graphed_build_train_matches_eager(kind):
+    """The generic captured step (build(x, y) + train as hipGraph replays) for the generators that train on encoder outputs: RnnRBM
+    (jamming) and RnnMultiNADE (composer).  Replays are steps 3, 4, 5 of the eager trajectory: dropout masks, the CD-k Gibbs uniforms
+    and the Adam step all follow the DEVICE step counter (a Gibbs seed baked into the graph would repeat the same chain -- and the
+    same loss -- at every replay)."""
+    from multinn_amd import RnnRBM, RnnMultiNADE, AdamOptimizer
+    B, T, E, tracks = 8, 6, 12, (3 if kind == "multinade" else 1)
+    D = E * tracks
+    R = np.random.default_rng(4)
+    seq = (R.random((B, T + 1, D)) < .25).astype(np.float32)
+    x, y = dev(seq[:, :-1]), dev(seq[:, 1:])
+
+    def make():
+        if kind == "rbm":
+            return RnnRBM(D, 20, [128, 128], keep_prob=0.9, k=3, precision="bf16", seed=3)
+        return RnnMultiNADE(E, 16, [128, 128], tracks=list("abc"), keep_prob=0.9, precision="bf16", seed=3)
+
+    a, b = make(), make()
+    a._materialize(D); b._materialize(D)
+    b.store.theta.copy_(a.store.theta)
+    opt = AdamOptimizer(0.01)
+
+    def eager_step():
+        a.build(x, y, None, True, "train")
+        a.train(opt, 0.01)
+        return float(a._loss)
+
+    run = b.graphed_build_train(x, y, opt, 0.01, warmup=2)
+    la = [eager_step() for _ in range(5)]
+    lb = [float(run()) for _ in range(3)]
+    assert np.allclose(lb, la[2:], rtol=5e-3, atol=1e-4), (la, lb)
+    assert len(set(np.round(lb, 6))) == 3                      # every replay is a different step
+    assert b.store.step == 5 and int(b.store.step_dev) == 5
+    assert torch.allclose(a.store.theta, b.store.theta, atol=3e-3)
+
+
 def test_two_graph_data_parallel_step_matches_eager(monkeypatch):
     """The N>1 form of the captured step: forward+backward graph | (all-reduce) | clip+Adam graph, replayed back to back.
     Regression: with hipMemsetAsync nodes the second replay of the first graph started from non-zero hand-off flags."""
