@@ -110,9 +110,37 @@ def train_epoch(generator, X, lengths, ids, batch_size, piece_size, optimizer, l
         song_ids, j, max_len, len_batch = w
         xb = torch.from_numpy(np.ascontiguousarray(X[song_ids, j:j + max_len])).to(device or "cuda")
         full = bool((len_batch == max_len).all())
-        loss = generator.train_step(xb, None if full else torch.from_numpy(len_batch).to(xb.device), optimizer, lr)
+        run = _captured_step(generator, xb, optimizer, lr) if full else None
+        if run is not None:
+            loss = run(xb)
+        else:
+            loss = generator.train_step(xb, None if full else torch.from_numpy(len_batch).to(xb.device), optimizer, lr)
         loss_accum.update(float(loss))
     return loss_accum.loss()
+
+
+def _captured_step(generator, xb, optimizer, lr, max_graphs=8):
+    """An eager optimiser step is host-bound (C2 shape: 7.2 ms eager, 2.85 ms as a hipGraph replay), so full-length windows of a shape
+    that keeps coming back -- batch_size x piece_size, i.e. nearly all of an epoch -- run as replays of RnnNade.graphed_train_step.
+    A shape is captured at its SECOND occurrence (the first one runs eagerly and creates every workspace; capturing executes nothing,
+    so the trajectory is the eager one), keyed by optimiser and learning rate (both are baked into the graph).  Only for the path the
+    captured step is tested on: the bf16 two-layer persistent recurrence.  MULTINN_TRAIN_GRAPH=0 keeps every step eager."""
+    import os
+    if os.environ.get("MULTINN_TRAIN_GRAPH", "1") == "0" or not xb.is_cuda or not hasattr(generator, "graphed_train_step"):
+        return None
+    stack = getattr(generator, "_stack", None)
+    if stack is None or getattr(stack, "packed", None) is None or not stack._persist(xb.shape[0]):
+        return None
+    key = (tuple(xb.shape), id(optimizer), lr)
+    graphs = generator.__dict__.setdefault("_step_graphs", {})
+    if key in graphs:
+        return graphs[key]
+    seen = generator.__dict__.setdefault("_step_shapes_seen", set())
+    if key not in seen or len(graphs) >= max_graphs:
+        seen.add(key)
+        return None
+    graphs[key] = generator.graphed_train_step(xb, optimizer, lr, warmup=0)
+    return graphs[key]
 
 
 def evaluate(generator, X, lengths, batch_size, piece_size, device=None):

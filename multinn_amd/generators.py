@@ -788,6 +788,7 @@ class RnnNade(RnnEstimator):
                 self.train_step(static_x, None, optimizer, lr)
         cur.wait_stream(side)
         multi = dp_active()
+        self._packed_step = -1          # the captured step packs the weights itself, whatever ran before (warmup = 0: a caller's own steps)
         g_fb, g_opt = torch.cuda.CUDAGraph(), None
         if not multi:
             with torch.cuda.graph(g_fb):

@@ -380,6 +380,40 @@ def test_driver_fit_and_checkpoints(tmp_path):
     assert stats.metric_best < float("inf")
 
 
+def test_driver_epoch_replays_captured_steps(monkeypatch):
+    """train_epoch runs full-length windows of a recurring shape as hipGraph replays (captured at the shape's second occurrence,
+    nothing executed by the capture): the loss trajectory must be the eager loop's (MULTINN_TRAIN_GRAPH=0) and ragged windows stay eager."""
+    from multinn_amd import RnnNade, AdamOptimizer
+    from multinn_amd.driver import train_epoch, LossAccumulator, TrainingStats
+    R = np.random.default_rng(5)
+    X = (R.random((24, 12, 8, 2)) < .2).astype(np.uint8)
+    lengths = np.full(24, 12)
+    lengths[5] = 7                                               # one ragged song: its late windows run eagerly
+    ids = np.arange(24)
+
+    def epoch_losses(graph):
+        if not graph:
+            monkeypatch.setenv("MULTINN_TRAIN_GRAPH", "0")
+        gen = RnnNade(16, 16, [128, 128], keep_prob=0.9, precision="bf16", seed=2)
+        gen._materialize(16)
+        opt = AdamOptimizer(0.01)
+        out = []
+        for _ in range(2):
+            acc = LossAccumulator()
+            train_epoch(gen, X, lengths, ids, 8, 4, opt, acc, TrainingStats(), lr=0.01, device=DEV)
+            out.append(acc.loss())
+        if not graph:
+            monkeypatch.delenv("MULTINN_TRAIN_GRAPH")
+        return out, gen
+
+    lg, gg = epoch_losses(True)
+    le, ge = epoch_losses(False)
+    assert len(gg.__dict__.get("_step_graphs", {})) >= 1 and "_step_graphs" not in ge.__dict__
+    assert np.allclose(lg, le, rtol=5e-3), (lg, le)
+    assert gg.store.step == ge.store.step
+    assert torch.allclose(gg.store.theta, ge.store.theta, atol=5e-3)
+
+
 def test_save_load_roundtrip(tmp_path):
     from multinn_amd import RnnNade, AdamOptimizer
     x = make_batch(4, 4, 4, 2, 3)
