@@ -207,7 +207,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // Epilogue of the LDS-DMA kernels: one wave's NI x NJ accumulator tiles -> C.  The store mode is resolved ONCE (template), the row
 // part of every address is wave-uniform (scalar arithmetic), the per-lane part is one offset computed once.  The per-element form
 // (64-bit row * ldc per lane, four run-time mode branches per element) cost ~40 instructions per stored value: at K = 448 the
-// 256 x 256 tile spent 21 of its 35 us issuing its 128 stores per thread (scratch/gemm_trace.hip) -- 150 -> 89 us for xproj1.
+// 256 x 256 tile spent 21 of its 35 us issuing its 128 stores per thread (profiles/tools/gemm_trace.hip) -- 150 -> 89 us for xproj1.
 enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_ACCUM = 2, EPI_BF16 = 3 };
 template <int MODE>
 __device__ __forceinline__ void epi_put(float* __restrict__ rowf, bf16_t* __restrict__ rowb, unsigned lane_off, float val) {
@@ -273,7 +273,7 @@ __device__ __forceinline__ int swz(int row) { return CPR == 8 ? ((row >> 1) & 7)
 
 // This thread's LDS-DMA slots of one operand tile (ROWS rows x CPR 16-byte chunks, NW waves): the global address of every slot at
 // k = 0 is computed ONCE per workgroup (row clamp, swizzle, 64-bit row * ld); staging a K tile is then one 64-bit add per slot.
-// Recomputing them per K tile cost ~0.5 us of address arithmetic per tile in front of the 8 DMA instructions (scratch/gemm_trace.hip).
+// Recomputing them per K tile cost ~0.5 us of address arithmetic per tile in front of the 8 DMA instructions (profiles/tools/gemm_trace.hip).
 template <int ROWS, int NW, int CPR>
 struct GldsSlots {
     static constexpr int NS = ROWS * CPR / (64 * NW);

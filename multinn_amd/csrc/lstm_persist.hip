@@ -26,7 +26,7 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned gu32;
 
-#ifdef PST_TRACE     // development only: per-stage timestamps of one workgroup per role (scratch/persist_trace.hip reads them)
+#ifdef PST_TRACE     // development only: per-stage timestamps of one workgroup per role (profiles/tools/persist_trace.hip reads them)
 __device__ long long pst_trace[4][512][8];
 #define PST_TR(ptr, k) do { if (ptr) (ptr)[k] = wall_clock64(); } while (0)
 #define PST_TRP(role, cond, step) ((cond) && threadIdx.x == 0 ? &pst_trace[role][step][0] : nullptr)
@@ -239,7 +239,7 @@ __device__ __forceinline__ void pf_tail(const PFwdLayer& L, const FwdTiles& S, i
 // item is then  (wave-uniform 64-bit base of the (t, row tile))  +  (one of these 32-bit offsets): scalar address arithmetic and a
 // `global_* v_off, s[base]` instruction.  Forming `(size_t)t * 4 * B * U + (size_t)row * 4U + unit * 4` per lane and per access, under
 // per-row `row < B` masks, was ~20 instructions and three branches per store: the deferred stores of an item cost 1.0 us of the 4.4 us
-// step (scratch/persist_trace.hip with the tail removed: 3.34 us).
+// step (profiles/tools/persist_trace.hip with the tail removed: 3.34 us).
 struct FwdLane {
     unsigned og[4], oc[4];         // gate-minor float4 (gates, xproj) / per-unit float (c) of fragment rows q = 0..3, full tile
     unsigned ogl[4], ocl[4];       // the same with rows clamped to the LAST row tile (when B is not a multiple of 32)

@@ -21,7 +21,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* gas_ptr_t;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-#ifdef NM_TRACE      // development only: per-phase clocks of one workgroup (scratch/nade_trace.hip)
+#ifdef NM_TRACE      // development only: per-phase clocks of one workgroup (profiles/tools/nade_trace.hip)
 __device__ long long nm_trace[16];
 #define NM_T(k) do { if (tid == 0 && blockIdx.x == NM_TRACE) { const long long now_ = wall_clock64(); nm_trace[k] += now_ - tprev_; tprev_ = now_; } } while (0)
 #else

@@ -225,7 +225,7 @@ class LstmStack:
     @staticmethod
     def _split_k(rows_out, cols_out, K):
         # about 512 workgroups of the 128 x 128 tile (two per CU): every slice adds its tile with f32 atomics, and those run at one
-        # chip-wide rate (~1.3 TB/s) -- 16 slices of dWh1 were 67 MB of adds, half of that GEMM's time (scratch/gemm_sweep.py)
+        # chip-wide rate (~1.3 TB/s) -- 16 slices of dWh1 were 67 MB of adds, half of that GEMM's time (profiles/tools/gemm_sweep.py)
         # (at K >= 64 k the adds are a small share again and more slices win: 1024 workgroups)
         tiles = -(-rows_out // 128) * -(-cols_out // 128)
         target = 512 if K < 65536 else 1024
