@@ -213,6 +213,7 @@ int mnn_nade_logprob_fwd_mfma(mnn_stream_t s, int tracks, int N, int D, int Hn, 
  *   recomputed only where v = 1.
  * mnn_nade_sample (nade.py:231-308): deterministic-order kernel, Bernoulli u < sigmoid(l/T);
  *   u = Philox(stream 1, row = row0+n, sub, elem = m*D+i); temperature <= 0 -> threshold 0.5.
+ *   D <= 1536 (a row's logits, b_dec and draws are parked in LDS during the scan); Hn <= 256.
  * ------------------------------------------------------------------------------------------ */
 int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                          const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* row_weight,

@@ -616,7 +616,7 @@ extern "C" int mnn_nade_sample(mnn_stream_t s, int tracks, int N, int D, int Hn,
     MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn > 0 && Hn <= 256, "mnn_nade_sample: need tracks,N,D>0 and 0<Hn<=256 (Hn=%d)", Hn);
     MNN_REQUIRE(bias && w_enc && w_dec && samples, "mnn_nade_sample: null pointer");
     MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_sample: ld_bias too small");
-    MNN_REQUIRE(D <= 3072, "mnn_nade_sample: D <= 3072 (probabilities and draws of a row are parked in LDS; D=%d)", D);
+    MNN_REQUIRE(D <= 1536, "mnn_nade_sample: D <= 1536 (logits, b_dec and draws of a row are parked in LDS, 36 B per visible and wave; D=%d)", D);
     dim3 grid(cdiv(N, 4), tracks);
     const size_t lds = (size_t)36 * ((D + 3) & ~3) + 4096;   // 4 waves x ((2 f32 + u8) per visible + 256 uniforms)
     const int tmode = temperature > 0.f ? (temperature == 1.0f ? 1 : 2) : 0;
