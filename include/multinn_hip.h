@@ -12,6 +12,16 @@
  *
  * Each entry cites the reference interface it replaces as file:line under
  * /root/reference/multinn (ilya16/MultINN).
+ *
+ * Two entries of SURVEY.md 8(b)'s proposed symbol list are deliberately NOT exported:
+ *   - mnn_generate_scan (rnn_estimator.py:271-323, multinn_feedback.py:120-218): the sampling scan is the sequence
+ *     {mnn_nade_sample | mnn_rbm_gibbs, mnn_lstm2_seq_fwd / mnn_lstm_seq_fwd, mnn_gemm_tn} per generated step, captured ONCE
+ *     into a hipGraph by the host (multinn_amd/common.py ScanGraphs) and replayed -- every step's RNG counter is a kernel
+ *     argument baked into its node, so one replay is one whole scan; a dedicated symbol would only repeat that loop in C.
+ *   - mnn_comm_init / mnn_allreduce_flat / mnn_comm_destroy: the single data-parallel exchange of a step is ONE
+ *     all-reduce of the flat f32 gradient buffer (or of the flat CD delta) issued by the host through torch.distributed,
+ *     backend "nccl" = RCCL over xGMI (multinn_amd/training.py allreduce_flat); the library never owns a communicator, so
+ *     it keeps "no global mutable state" and the buffer it hands over is a plain caller-owned device pointer.
  */
 #ifndef MULTINN_HIP_H
 #define MULTINN_HIP_H
@@ -252,6 +262,15 @@ int mnn_rbm_visible(mnn_stream_t s, int N, int D, int Hn, const void* h, int h_d
                     void* workspace);
 int mnn_rbm_free_energy(mnn_stream_t s, int N, int D, int Hn, const uint8_t* v, const float* W, const float* bh, int ld_bh,
                         const float* bv, int ld_bv, float* F);
+/* CD-k bias deltas (rbm.py:318-327): dbv[d] += scale * sum_n (v - p_v)[n,d], dbh[j] += scale * sum_n (h - p_h)[n,j] (f32 atomics: zero
+ * the outputs first).  The weight delta is two mnn_gemm_tn products combined by mnn_axpby_f32, which is also the `assign_add` of
+ * rbm.py:329-333: out[i] = a*x[i] + b*y[i] (out may alias x or y; y may be NULL when b == 0).  Under data parallelism the flat
+ * [dW | dbv | dbh] buffer is what the ranks all-reduce. */
+int mnn_rbm_cd_bias_delta(mnn_stream_t s, int N, int D, int Hn, const uint8_t* v, const float* p_v, const uint8_t* h, const float* p_h,
+                          float scale, float* dbv, float* dbh);
+int mnn_axpby_f32(mnn_stream_t s, long n, float a, const float* x, float b, const float* y, float* out);
+/* rbm.py:286-297 visible_bias_init_ops: bv[d] = log(1e-6 + p/(1-p)), p = colsum[d] / count (colsum: mnn_bias_grad over the batch). */
+int mnn_rbm_visible_bias_init(mnn_stream_t s, int D, const float* colsum, float count, float* bv);
 
 /* ------------------------------------------------------------------------------------------
  * Reductions / optimiser on the flat parameter buffer.
@@ -296,6 +315,13 @@ int mnn_musical_note_stats(mnn_stream_t s, const uint8_t* x, int B, int T, int P
  *   (tf.losses.log_loss, pass_encoder.py:81-86, rbm.py:124-129); probs f32 [N, ld_probs]. */
 int mnn_eval_counts(mnn_stream_t s, const uint8_t* targets, const uint8_t* predictions, long n, unsigned long long* counts);
 int mnn_log_loss_rows(mnn_stream_t s, const uint8_t* targets, const float* probs, int N, int D, int ld_probs, float* out);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement support (not on the product path).  mnn_probe_sigmoid: `blocks` x 256 threads x 8 independent chains x `iters`
+ * sigmoids (the NADE kernels' v_exp_f32 + v_rcp_f32 form), out f32 [blocks*256]: bench.py times it with HIP events to get the
+ * device's measured transcendental peak, the bound of the NADE phases in the step roofline.
+ * ------------------------------------------------------------------------------------------ */
+int mnn_probe_sigmoid(mnn_stream_t s, int blocks, int iters, float* out);
 
 #ifdef __cplusplus
 }

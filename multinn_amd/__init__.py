@@ -4,7 +4,8 @@ Host API mirrors ilya16/MultINN's Encoder/Generator plugin classes; compute is h
 behind the C ABI in include/multinn_hip.h (libmultinn_hip.so).  No CPU fallback.
 """
 __all__ = ["RnnNade", "RnnMultiNADE", "RnnRBM", "PassEncoder", "DBNEncoder", "NADE", "RBM", "RNN", "DBN",
-           "AdamOptimizer", "GradientDescentOptimizer"]
+           "AdamOptimizer", "GradientDescentOptimizer", "MultINN", "MultINNJoint", "MultINNComposer", "MultINNJamming",
+           "MultINNFeedback", "MultINNFeedbackRnn"]
 
 
 def __getattr__(name):
@@ -20,6 +21,10 @@ def __getattr__(name):
     if name in ("DNN", "FeedbackDnn", "FeedbackRnn", "FeedbackRnnSampler", "FeedbackSampler"):
         from . import feedback
         return getattr(feedback, name)
+    if name in ("MultINN", "MultINNJoint", "MultINNComposer", "MultINNJamming", "MultINNFeedback", "MultINNFeedbackRnn", "MultINNCore",
+                "MultIEncoderNN"):
+        from . import modes
+        return getattr(modes, name)
     if name in ("AdamOptimizer", "GradientDescentOptimizer", "compute_gradients"):
         from . import training
         return getattr(training, name)

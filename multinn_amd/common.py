@@ -403,39 +403,74 @@ class RBM(Model):
         return Fv - self.free_energy(v_sample, bh, bv), Fv
 
     def visible_bias_init_ops(self, v):
-        """rbm.py:286-297."""
-        p = v.float().mean(0)
-        self.bv.copy_(torch.log(1e-6 + p / (1 - p)).view(1, -1))
-        return []
+        """rbm.py:286-297: returns the (not yet executed) init ops -- call each to assign bv = log(1e-6 + p/(1-p)), p the mean
+        activation of every visible unit over the batch (over ALL ranks' batches under data parallelism)."""
+        from .training import dp_active
+        import torch.distributed as dist
+
+        def assign_bv():
+            N, D = v.shape
+            vf = torch.empty((N, D), device=v.device)
+            ops.convert2d(v if v.dtype in (torch.uint8, torch.float32) else v.float(), vf)
+            stat = torch.zeros(D + 1, device=v.device)         # [column sums | row count]: one buffer, one all-reduce
+            ops.bias_grad(vf, stat[:D], accumulate=True)
+            n_tot = float(N)
+            if dp_active():
+                ops.fill(stat[D:], float(N))
+                dist.all_reduce(stat)
+                n_tot = float(stat[D])
+            ops.rbm_visible_bias_init(stat[:D], n_tot, self.bv.view(-1))
+        return [assign_bv]
+
+    def _flat_delta(self):
+        """[W | bv | bh] are consecutive in the store (declare()): their flat slice and a delta buffer of the same layout."""
+        W, bh = self.W, self.bh
+        off = W.storage_offset() - self.store.theta.storage_offset()
+        n = self._num_dims * self._num_hidden + self._num_dims + self._num_hidden
+        assert bh.storage_offset() - W.storage_offset() == self._num_dims * self._num_hidden + self._num_dims
+        return self.store.theta[off:off + n]
 
     def _cd_update(self, v, lr, seed=None, row0=0, sub0=0):
-        """rbm.py:299-335: returns the deltas (dW, dbv, dbh) and applies them (assign_add)."""
+        """rbm.py:299-335: returns (update_ops, [dW, dbv, dbh]) and applies the deltas (assign_add).  Under data parallelism the flat
+        delta [dW | dbv | dbh] is summed over the ranks (ONE all-reduce) and N is the global row count, so every rank
+        applies the full-batch update."""
+        from .training import dp_active
+        import torch.distributed as dist
         seed = self.seed if seed is None else seed
         N = v.shape[0]
-        p_v_s, v_s = self.sample(v, self.bh, self.bv, self._k, seed, row0, None, sub0)
-        _, h = self.forward(v, None, seed, row0, sub0 + self._k)
+        D, Hn = self._num_dims, self._num_hidden
+        vu = v.to(torch.uint8).contiguous()
+        p_v_s, v_s = self.sample(vu, self.bh, self.bv, self._k, seed, row0, None, sub0)
+        _, h = self.forward(vu, None, seed, row0, sub0 + self._k)
         p_h_s, _ = self.forward(v_s, None, seed, row0, sub0 + self._k + 1)
-        lrn = lr / N
+        n_tot = N
+        if dp_active():
+            cnt = torch.full((1,), float(N), device=v.device)
+            dist.all_reduce(cnt)
+            n_tot = float(cnt)
+        lrn = lr / n_tot
         # outer-product sums on MFMA: [D,N] x [N,Hn]
         Np = ops.round_up(N, 4)
         def t_(x, rows):
-            out = torch.zeros((rows, Np), device=v.device)
-            return ops.transpose(x if x.dtype != torch.uint8 else x, out)
-        vT, hT = t_(v.to(torch.uint8).contiguous(), self._num_dims), t_(h, self._num_hidden)
-        pvT, phT = t_(p_v_s, self._num_dims), t_(p_h_s, self._num_hidden)
-        pos = torch.empty((self._num_dims, self._num_hidden), device=v.device)
-        neg = torch.empty_like(pos)
-        ops.gemm_tn(vT, hT, pos)
+            return ops.transpose(x, torch.zeros((rows, Np), device=v.device))
+        vT, hT = t_(vu, D), t_(h, Hn)
+        pvT, phT = t_(p_v_s, D), t_(p_h_s, Hn)
+        delta = torch.zeros(D * Hn + D + Hn, device=v.device)
+        dW, dbv, dbh = delta[:D * Hn].view(D, Hn), delta[D * Hn:D * Hn + D].view(1, D), delta[D * Hn + D:].view(1, Hn)
+        neg = torch.empty((D, Hn), device=v.device)
+        ops.gemm_tn(vT, hT, dW)
         ops.gemm_tn(pvT, phT, neg)
-        dW = lrn * (pos - neg)
-        dbv = lrn * (v.float() - p_v_s).sum(0, keepdim=True)
-        dbh = lrn * (h.float() - p_h_s).sum(0, keepdim=True)
-        self.W.add_(dW); self.bv.add_(dbv); self.bh.add_(dbh)
+        ops.axpby(lrn, dW.view(-1), -lrn, neg.view(-1), dW.view(-1))
+        ops.rbm_cd_bias_delta(vu, p_v_s, h, p_h_s, lrn, dbv.view(-1), dbh.view(-1))
+        if dp_active():
+            dist.all_reduce(delta)
+        theta = self._flat_delta()
+        ops.axpby(1.0, theta, 1.0, delta, theta)            # assign_add of W, bv, bh (rbm.py:329-333)
         return [], [dW, dbv, dbh]
 
     def train(self, v, lr, **kw):
         """rbm.py:265-284."""
-        init_ops = self.visible_bias_init_ops
+        init_ops = self.visible_bias_init_ops(v)
         update_ops, gradients = self._cd_update(v, lr, **kw)
         return init_ops, update_ops, gradients
 
@@ -465,6 +500,7 @@ class DBN(Model):
     num_hidden = property(lambda self: self._num_hidden)
     num_layers = property(lambda self: len(self._num_hidden))
     rbms = property(lambda self: self._rbms)
+    rbm_layers = property(lambda self: self._rbms)          # the reference's name (dbn.py:60)
 
     def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None):
         return self._rbms[0].build_metrics(targets, predictions, cond_probs, log_probs)

@@ -763,3 +763,29 @@ extern "C" int mnn_fill_f32(mnn_stream_t s, float* x, long n, float value) {
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
+
+// ----------------------------------------------------------------------------------------------
+// Measurement support ("the builder must measure the device's sigmoid (v_exp_f32 + v_rcp_f32) throughput with a
+// microbenchmark and use it as [the NADE] phase's peak").  Every thread runs 8 independent chains of the NADE kernels' own sigmoid
+// (fast_sigmoid: v_mul, v_exp_f32, v_add, v_rcp_f32), `iters` links each, 8 waves per SIMD resident; nothing touches memory until
+// the final store.  bench.py times the launch with HIP events: sigmoids/s = grid * 256 * 8 * iters / t.
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) probe_sigmoid_kernel(float* __restrict__ out, int iters) {
+    float x[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) x[c] = 1e-3f * (float)threadIdx.x + 0.125f * (float)c - 0.5f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x[c] = fast_sigmoid(x[c]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s += x[c];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+extern "C" int mnn_probe_sigmoid(mnn_stream_t s, int blocks, int iters, float* out) {
+    MNN_REQUIRE(blocks > 0 && iters > 0 && out, "mnn_probe_sigmoid: bad arguments");
+    hipLaunchKernelGGL(probe_sigmoid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, out, iters);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}

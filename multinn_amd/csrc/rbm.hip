@@ -385,3 +385,64 @@ extern "C" int mnn_rbm_free_energy(mnn_stream_t s, int N, int D, int Hn, const u
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
+
+// ----------------------------------------------------------------------------------------------
+// CD-k bias deltas (rbm.py:318-327):  dbv[d] += scale * sum_n (v[n,d] - p_v[n,d]),  dbh[j] += scale * sum_n (h[n,j] - p_h[n,j]).
+// One pass over the four [N, .] arrays; a workgroup owns 64 columns of one of the two outputs and a slab of rows, threads of a
+// wave read consecutive columns (coalesced), the 4 waves split the slab's rows; one f32 atomic per column and workgroup.
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+rbm_cd_bias_delta_kernel(int N, int D, int Hn, const uint8_t* __restrict__ v, const float* __restrict__ p_v, const uint8_t* __restrict__ h,
+                         const float* __restrict__ p_h, float scale, float* __restrict__ dbv, float* __restrict__ dbh) {
+    __shared__ float part[4][64];
+    const int nbv = (D + 63) / 64;
+    const bool vis = (int)blockIdx.x < nbv;
+    const int cols = vis ? D : Hn;
+    const int c = (vis ? blockIdx.x : blockIdx.x - nbv) * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const uint8_t* s = vis ? v : h;
+    const float* p = vis ? p_v : p_h;
+    float acc = 0.f;
+    if (c < cols)
+        for (int r = blockIdx.y * 4 + w; r < N; r += gridDim.y * 4) acc += (float)s[(size_t)r * cols + c] - p[(size_t)r * cols + c];
+    part[w][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (w == 0 && c < cols) atomicAdd((vis ? dbv : dbh) + c, scale * (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
+extern "C" int mnn_rbm_cd_bias_delta(mnn_stream_t s, int N, int D, int Hn, const uint8_t* v, const float* p_v, const uint8_t* h, const float* p_h,
+                                     float scale, float* dbv, float* dbh) {
+    MNN_REQUIRE(N > 0 && D > 0 && Hn > 0 && v && p_v && h && p_h && dbv && dbh, "mnn_rbm_cd_bias_delta: bad arguments");
+    const int slabs = N >= 4096 ? 64 : (N >= 256 ? 8 : 1);
+    hipLaunchKernelGGL(rbm_cd_bias_delta_kernel, dim3((D + 63) / 64 + (Hn + 63) / 64, slabs), dim3(256), 0, (hipStream_t)s, N, D, Hn, v, p_v, h, p_h,
+                       scale, dbv, dbh);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+// out[i] = a * x[i] + b * y[i]  (f32; out may alias x or y; y may be NULL when b == 0): the `assign_add` of the CD deltas
+// (rbm.py:329-333) and the combination of their positive / negative phase products.
+__global__ void __launch_bounds__(256) axpby_kernel(long n, float a, const float* x, float b, const float* y, float* out) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+extern "C" int mnn_axpby_f32(mnn_stream_t s, long n, float a, const float* x, float b, const float* y, float* out) {
+    MNN_REQUIRE(n > 0 && x && out && (y || b == 0.f), "mnn_axpby_f32: bad arguments");
+    hipLaunchKernelGGL(axpby_kernel, dim3((int)min(1024L, (n + 255) / 256)), dim3(256), 0, (hipStream_t)s, n, a, x, b, y, out);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+// rbm.py:286-297: bv[d] = log(1e-6 + p/(1-p)) with p = colsum[d] / count (utils/auxiliary.py:9-11 safe_log); colsum comes from
+// mnn_bias_grad over the f32 batch (summed over ranks by the caller under data parallelism).
+__global__ void __launch_bounds__(256) rbm_visible_bias_init_kernel(int D, const float* __restrict__ colsum, float count, float* __restrict__ bv) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d < D) {
+        const float p = colsum[d] / count;
+        bv[d] = logf(1e-6f + p / (1.f - p));
+    }
+}
+extern "C" int mnn_rbm_visible_bias_init(mnn_stream_t s, int D, const float* colsum, float count, float* bv) {
+    MNN_REQUIRE(D > 0 && colsum && bv && count > 0.f, "mnn_rbm_visible_bias_init: bad arguments");
+    hipLaunchKernelGGL(rbm_visible_bias_init_kernel, dim3(cdiv(D, 256)), dim3(256), 0, (hipStream_t)s, D, colsum, count, bv);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}

@@ -2,8 +2,9 @@
 best/last checkpoint policy and early stopping around ``Generator.train_step``.
 
 Same YAML keys as multinn/configs/default_config.yaml / default_params.yaml and the same CLI flags as
-train.py:287-329 (``python -m multinn_amd.driver -m NAME -c CONFIG -p PARAMS``).  Only the joint mode
-with a NADE generator is wired (the hot path); other modes raise NotImplementedError.
+train.py:287-329 (``python -m multinn_amd.driver -m NAME -c CONFIG -p PARAMS``).  Every mode of
+``params['mode']`` is wired through ``multinn_amd.modes`` (``build_model``); joint + PassEncoder + NADE takes the
+fused, hipGraph-replayed RnnNade step directly.
 """
 import argparse
 import math
@@ -156,7 +157,8 @@ def evaluate(generator, X, lengths, batch_size, piece_size, device=None):
         full = bool((len_batch == max_len).all())
         generator.build_pianoroll(xb, None if full else torch.from_numpy(len_batch).to(xb.device), is_train=False, mode="eval")
         n = int(len_batch.sum())
-        tot += float(generator.metrics["batch/loss"]) * n
+        loss = generator.generator_loss() if hasattr(generator, "generator_loss") else generator.metrics["batch/loss"]
+        tot += float(loss) * n
         cnt += n
     return tot / max(cnt, 1)
 
@@ -234,16 +236,21 @@ def pretrain_encoders(encoders, X_train, len_train, training_config, beat_size=4
 
 
 def build_generator(params, P, M, precision="bf16", seed=23):
-    """multinn_joint.py:41-74 for `mode: joint`, `encoder.type: Pass`, `generator.type: NADE|RBM`."""
+    """multinn_joint.py:41-74 for `mode: joint`, `encoder.type: Pass`, `generator.type: NADE|RBM`: the bare generator (kept for
+    callers that drive a Generator directly; `build_model` wires every mode)."""
     from .generators import RnnNade, RnnRBM
-    if params.get("mode", "joint") != "joint":
-        raise NotImplementedError("only `mode: joint` is wired into the driver (the hot path); the other modes are composed from the "
-                                  "same Generator/Encoder classes")
-    if (params.get("encoder") or {}).get("type", "Pass") != "Pass":
-        raise NotImplementedError("joint mode with a non-Pass encoder")
+    if params.get("mode", "joint") != "joint" or (params.get("encoder") or {}).get("type", "Pass") != "Pass":
+        raise ValueError("build_generator is the joint / PassEncoder shortcut: use build_model(config, params) for the other modes")
     g = params["generator"]
     cls = {"NADE": RnnNade, "RBM": RnnRBM}[g["type"]]
     return cls(P * M, g["num_hidden"], g["num_hidden_rnn"], keep_prob=params.get("keep_prob", 0.9), precision=precision, seed=seed)
+
+
+def build_model(config, params, precision="bf16", seed=None, device=None):
+    """train.py:50: `MultINN(config, params, mode=params['mode'], name=config['model_name'])` -- any of the five modes
+    (multinn_amd.modes), with the train_step / build_pianoroll / save / load surface `fit` drives."""
+    from .modes import MultINN
+    return MultINN(config, params, mode=params["mode"], name=config.get("model_name", "MultINN"), precision=precision, seed=seed, device=device)
 
 
 def main(argv=None):
@@ -283,8 +290,13 @@ def main(argv=None):
         X = X[:, :T // npx * npx].reshape(S, T // npx, npx, P, M).transpose(0, 1, 3, 2, 4).reshape(S, T // npx, P * npx, M)
     lengths = np.full(X.shape[0], X.shape[1], np.int64) if not d.get("sequence_lengths") else np.load(d["sequence_lengths"]) // npx
     nt, nv = d["split"]["num_train"], d["split"]["num_valid"]
-    gen = build_generator(params, X.shape[2], X.shape[3], a.precision, tr["random_seed"])
-    gen._materialize(X.shape[2] * X.shape[3])
+    if params.get("mode", "joint") == "joint" and (params.get("encoder") or {}).get("type", "Pass") == "Pass" \
+            and params["generator"]["type"] == "NADE":
+        gen = build_generator(params, X.shape[2], X.shape[3], a.precision, tr["random_seed"])     # the fused, hipGraph-replayed step
+        gen._materialize(X.shape[2] * X.shape[3])
+    else:
+        config.setdefault("data", {}).setdefault("pitch_range", {"lowest": 0, "highest": X.shape[2] // max(npx, 1)})
+        gen = build_model(config, params, a.precision, tr["random_seed"])
     stats = TrainingStats()
     if not a.from_init:
         src = dirs["model_last_dir"] if a.from_last else dirs["model_dir"]

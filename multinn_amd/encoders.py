@@ -3,7 +3,7 @@ import abc
 
 import torch
 
-from .common import Model, DBN
+from .common import Model, DBN, STREAM_DBN_ENC, STREAM_DBN_DEC
 
 
 class Encoder(Model):
@@ -14,7 +14,8 @@ class Encoder(Model):
         self._num_dims = num_dims
         self._num_hidden = [num_hidden] if isinstance(num_hidden, int) else list(num_hidden)
         self._track_name = track_name
-        self._encodings = self._decodings = self._enc_probs = self._dec_probs = None
+        self._lengths = None
+        self._enc_probs, self._encodings, self._dec_probs, self._decodings = [], [], [], []     # per layer (encoder.py:33-36)
 
     num_dims = property(lambda self: self._num_dims)
     num_hidden = property(lambda self: self._num_hidden)
@@ -40,30 +41,42 @@ class Encoder(Model):
 class PassEncoder(Encoder):
     """models/encoders/pass_encoder.py: identity encoder."""
 
-    def __init__(self, num_dims, name="pass-encoder", track_name="all"):
+    def __init__(self, num_dims, num_hidden=None, name="pass-encoder", track_name="all"):
+        """pass_encoder.py:12-29: `num_hidden` is accepted and unused (the encoder's hidden width IS `num_dims`)."""
         super().__init__(num_dims, num_dims, name=name, track_name=track_name)
 
     def build(self, x=None, y=None, lengths=None, is_train=None, mode="eval"):
         super().build(x, y, lengths, is_train, mode)
         self._inputs = x
-        if x is not None:
-            self._enc_probs, self._encodings = self.encode(x)
-            self._dec_probs, self._decodings = self.decode(self._encodings)
+        self._enc_probs, self._encodings = [x], [x]         # pass_encoder.py:52-53: per-layer lists of one entry
+        self._dec_probs, self._decodings = [x], [x]
         self._is_built = True
 
     def encode(self, x=None):
-        x = self._inputs if x is None else x
+        """pass_encoder.py:99-112."""
+        if x is None:
+            return self._enc_probs[-1], self._encodings[-1]
         return x, x
 
     def decode(self, h=None):
-        h = self._encodings if h is None else h
+        """pass_encoder.py:114-127."""
+        if h is None:
+            return self._dec_probs[-1], self._decodings[-1]
         return h, h
 
-    def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None):
+    def train(self, optimizer, lr, layer=0):
+        """pass_encoder.py:129-136: nothing to train."""
+        return [], [], {}, [], {}
+
+    def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None, layer=None):
         """pass_encoder.py:56-97: 'reconstruction cost' = sum_d tf.losses.log_loss(targets, cond_probs)."""
         from .metrics import base_metrics
-        lp = reconstruction_cost(targets, cond_probs)
-        return base_metrics(lp, targets, predictions, lp)
+        if log_probs is None and cond_probs is not None:
+            log_probs = reconstruction_cost(targets, cond_probs)
+        else:                                               # pass_encoder.py:86-88 (raised also when log_probs IS given, as written)
+            raise ValueError("Incorrect arguments. Either `cond_probs`, or `log_probs` should be provided on `encoder.build_metrics()` "
+                             "function call")
+        return base_metrics(log_probs, targets, predictions, log_probs)
 
 
 def reconstruction_cost(targets, cond_probs):
@@ -77,29 +90,46 @@ def reconstruction_cost(targets, cond_probs):
 
 
 class DBNEncoder(Encoder):
-    """models/encoders/dbn_encoder.py: DBN encode/decode with SAMPLED binary codes (52-106, 136-190)."""
+    """models/encoders/dbn_encoder.py: DBN encode/decode with SAMPLED binary codes (52-106, 136-190).
 
-    def __init__(self, num_dims, num_hidden, k=10, name="dbn-encoder", track_name="all", seed=23, device=None):
+    `encodings` / `enc_probs` / `decodings` / `dec_probs` are per-layer lists as in the reference (encoder.py:33-36,
+    dbn_encoder.py:83-97): entry i belongs to RBM layer i, `encodings[-1]` is the code the generators consume and
+    `decodings[0]` the reconstruction in input space."""
+
+    def __init__(self, num_dims, num_hidden, k=2, name="dbn-encoder", track_name="all", seed=23, device=None):
         super().__init__(num_dims, num_hidden, name=name, track_name=track_name)
         self._dbn = DBN(num_dims, self._num_hidden, k=k, name=f"{name}/{track_name}", seed=seed, device=device)
         self.store = self._dbn.store
         self.seed, self.row0, self._sub = seed, 0, 0
+        self._variables = dict(self.store.views)
+        self._trainable_variables = [self.store[n] for n in self.store.names()]
+        self._lengths = None
 
     dbn = property(lambda self: self._dbn)
 
     def build(self, x=None, y=None, lengths=None, is_train=None, mode="eval"):
+        """dbn_encoder.py:52-106: forward pass through every layer (sampled codes upward), then the reconstruction
+        pass back down, every layer's probabilities and samples kept."""
         super().build(x, y, lengths, is_train, mode)
-        self._inputs = x
-        if x is not None:
-            self._enc_probs, self._encodings = self.encode(x)
-            self._dec_probs, self._decodings = self.decode(self._encodings)
+        self._inputs, self._lengths = x, lengths
+        self._enc_probs, self._encodings, self._dec_probs, self._decodings = [], [], [], []
+        if x is not None and mode in ("train", "eval"):
+            f, lead = self._flat(x.to(torch.uint8) if x.dtype != torch.uint8 else x)
+            h = f
+            for i, r in enumerate(self._dbn.rbms):                      # same counters as DBN.forward: encode(x) == encodings[-1]
+                p, h = r.forward(h, None, self.seed, self.row0, (self._sub << 4) | i, STREAM_DBN_ENC)
+                self._enc_probs.append(p.view(*lead, -1)); self._encodings.append(h.view(*lead, -1))
+            v = h
+            for i in range(len(self._dbn.rbms) - 1, -1, -1):
+                p, v = self._dbn.rbms[i].reconstruct(v, None, self.seed, self.row0, (self._sub << 4) | i, STREAM_DBN_DEC)
+                self._dec_probs.insert(0, p.view(*lead, -1)); self._decodings.insert(0, v.view(*lead, -1))
         self._metrics = self._metrics_upd = None             # dbn_encoder.py:98-104: built on demand (see `metrics`)
         self._is_built = True
 
     def _ensure_metrics(self):
-        if self._metrics is None and self._inputs is not None:
+        if self._metrics is None and self._inputs is not None and self._decodings:
             self._metrics, self._metrics_upd, self._summaries["metrics"] = self.build_metrics(
-                targets=self._inputs, predictions=self._decodings, cond_probs=self._dec_probs)
+                targets=self._inputs, predictions=self._decodings[0], cond_probs=self._dec_probs[0])
         return self._metrics
 
     metrics = property(lambda self: self._ensure_metrics())
@@ -110,30 +140,41 @@ class DBNEncoder(Encoder):
 
     def encode(self, x=None):
         """dbn_encoder.py:136-162: [B,T,P] -> (p_h, h) with h sampled; the zero-padded step is encoded too."""
-        x = self._inputs if x is None else x
+        if x is None:
+            return self._enc_probs[-1], self._encodings[-1]
         f, lead = self._flat(x.to(torch.uint8) if x.dtype != torch.uint8 else x)
         p, h = self._dbn.forward(f, self.seed, self.row0, self._sub)
         return p.view(*lead, -1), h.view(*lead, -1)
 
     def decode(self, h=None):
         """dbn_encoder.py:164-190."""
-        h = self._encodings if h is None else h
+        if h is None:
+            return self._dec_probs[0], self._decodings[0]
         f, lead = self._flat(h.to(torch.uint8) if h.dtype != torch.uint8 else h)
         p, v = self._dbn.reconstruct(f, self.seed, self.row0, self._sub)
         return p.view(*lead, -1), v.view(*lead, -1)
 
-    def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None):
+    def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None, layer=None):
         return self._dbn.build_metrics(targets.reshape(-1, targets.shape[-1]), predictions.reshape(-1, predictions.shape[-1]),
                                        cond_probs.reshape(-1, cond_probs.shape[-1]) if cond_probs is not None else None, log_probs)
 
     def train(self, optimizer, lr, layer=0):
-        """dbn_encoder.py:192-240: CD-k on RBM ``layer`` fed with sampled codes of the layers below (R7 n/a)."""
+        """dbn_encoder.py:192-240: one CD-k update of RBM `layer` on its inputs (the batch for layer 0, the sampled codes of
+        layer-1 otherwise), flattened by `lengths`; metrics are that RBM's own reconstruction of its inputs (R7: the
+        reference reads a `track_name` the RBM lacks -- nothing here depends on it)."""
         assert 0 <= layer < self.num_layers                 # dbn_encoder.py:208
-        f, _ = self._flat(self._inputs.to(torch.uint8))
-        for i in range(layer):
-            _, f = self._dbn.rbms[i].forward(f, None, self.seed, self.row0, (self._sub << 4) | i, 4)
+        x = self._inputs if layer == 0 else self._encodings[layer - 1]
+        f, _ = self._flat(x.to(torch.uint8) if x.dtype != torch.uint8 else x)
+        if self._lengths is not None:                        # flatten_maybe_padded_sequences: b-major rows with t < lengths[b]
+            B, T = x.shape[0], x.shape[1]
+            m = torch.arange(T, device=x.device)[None, :] < self._lengths.to(x.device)[:, None]
+            f = f[m.reshape(-1)].contiguous()
         rbm = self._dbn.rbms[layer]
         rbm.seed = self.seed
         self._sub += 1
-        init_ops, update_ops, grads = rbm.train(f, lr, row0=self.row0, sub0=self._sub * 64)
-        return init_ops, update_ops, self.metrics, self.metrics_upd, self.summaries
+        sub0 = self._sub * 64
+        _, enc = rbm.forward(f, None, self.seed, self.row0, sub0 + 62)
+        dec_p, dec = rbm.reconstruct(enc, None, self.seed, self.row0, sub0 + 62)
+        metrics, metrics_upd, _ = rbm.build_metrics(targets=f, predictions=dec, cond_probs=dec_p)
+        init_ops, update_ops, grads = rbm.train(f, lr, row0=self.row0, sub0=sub0)
+        return init_ops, update_ops, metrics, metrics_upd, self.summaries

@@ -152,16 +152,25 @@ class FeedbackRnnSampler:
     def _generate_scan(self, x_u8, num_steps):
         B, Ti, P, M = x_u8.shape
         assert M == self.num_tracks
-        dev = x_u8.device
-        enc = torch.cat([torch.zeros((B, 1, P, M), device=dev, dtype=torch.uint8), x_u8], 1)      # multi_encoder_nn.py:73-76
-        stack = enc.reshape(B, Ti + 1, P * M)                                                       # feature p*M+m (stack axis 3 + reshape)
+        enc = torch.cat([torch.zeros((B, 1, P, M), device=x_u8.device, dtype=torch.uint8), x_u8], 1)      # multi_encoder_nn.py:73-76
+        return self.generate_encoded([enc[..., i] for i in range(M)], num_steps)
+
+    def generate_encoded(self, enc_tracks, num_steps):
+        """The scan on per-track ENCODED inputs (multinn_feedback.py:120-173 between the encoders): enc_tracks = M x u8
+        [B, Ti+1, E] (zero first step included) -> sampled codes u8 [B, num_steps, E, M]; the caller decodes them through
+        its encoders (identity for PassEncoder)."""
+        M = self.num_tracks
+        B, _, P = enc_tracks[0].shape
+        dev = enc_tracks[0].device
+        x_u8 = enc_tracks[0]
+        stack = torch.stack(enc_tracks, 3).reshape(B, -1, P * M)                                    # feature p*M+m (stack axis 3 + reshape)
         x_fb, fb_state = self.feedback.run(stack)
         states = []
         for i, g in enumerate(self.generators):
             g._materialize(P + x_fb.shape[-1])
             g._rnn.build_cell(False)
             g._ensure_packed()
-            states.append(g.steps(torch.cat([enc[..., i].float(), x_fb], -1)))                      # multinn_feedback.py:143-149
+            states.append(g.steps(torch.cat([enc_tracks[i].float(), x_fb], -1)))                    # multinn_feedback.py:143-149
         out = torch.empty((B, num_steps, P, M), device=dev, dtype=torch.uint8)
         # Inside a step the tracks are independent (SURVEY A19): generator i's {sample | LSTM step, Dense} run on stream i, joined on
         # the main stream around the feedback step.  Their single steps take the launch-per-step LSTM kernels: persistent launches

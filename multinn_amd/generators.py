@@ -404,6 +404,9 @@ class RnnEstimator(Generator):
         self.dtype = _compute_dtype(precision)
         self.seed, self.clip_norm = seed, clip_norm
         self.row0 = 0                     # global index of this rank's first sequence (data parallel)
+        # weight of this generator's loss in the optimised objective: a mode that trains M per-track generators on the MEAN track loss
+        # with one global-norm clip over all of them (multinn_jamming.py:235-241) sets 1/M; the generator's own metrics stay unscaled
+        self.grad_scale = 1.0
         self.store = ParamStore(device)
         self._gen = torch.Generator().manual_seed(seed)
         self._num_inputs = num_inputs
@@ -678,13 +681,14 @@ class RnnNade(RnnEstimator):
             if self.ldo != self.n_out and self.dtype == torch.float32:
                 d_out[:, self.n_out:].zero_()       # fp32: d_out itself is the dgrad operand; bf16: grad_rows_fanout writes the zero padding
         a_fin = torch.empty((M, N, Hn), device=dev) if train else None
+        rw_g = rw_m if self.grad_scale == 1.0 else rw_m * self.grad_scale      # gradient seed only: the reported loss stays unscaled
         if self._nade_mfma():
             # bf16 compute mode: the decoder dot products run as a block-sparse bf16 GEMM over each row's hidden states
             ops.nade_logprob_fwd_mfma(v.view(M, N, D), out, self.store["nade/w_enc"], self._wdec_bf, M, D, Hn,
-                                      rw_m if train else None, nll, cond_p, d_out, a_fin)
+                                      rw_g if train else None, nll, cond_p, d_out, a_fin)
         else:
             ops.nade_logprob_fwd(v.view(M, N, D), out, self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn,
-                                 rw_m if train else None, nll, cond_p, d_out, a_fin)
+                                 rw_g if train else None, nll, cond_p, d_out, a_fin)
         loss = torch.zeros(1, device=dev)
         ops.weighted_sum(nll.view(-1), rw_m.repeat(M) if M > 1 else rw_m, loss)      # statistical.py:34 / rnn_multinade.py:202-203
         self._ctx = dict(x_tm=x_tm, v=v, rw=rw_m, y=y, lstm=ctx, out=out, d_out=d_out, a_fin=a_fin, kp=kp, seed=self.seed, B=B, T=T)
@@ -984,9 +988,12 @@ class RnnRBM(RnnEstimator):
             self._ctx = dict(y=yy, lstm=ctx, out=out, tgt=tgt, v_s=v_s, rw=rw, kp=kp, seed=seed, B=B, T=T, bh_u=bh_u, bv_u=bv_u)
             self._cost_tm, self._F_tm, self._pv_tm, self._vs_tm, self._loss = cost, Fv, p_v, v_s, loss
             self._lengths, self._flat_idx = lengths, None
-            t = tgt.float()
-            self._recon_tm = (-t * torch.log(p_v + 1e-7) - (1 - t) * torch.log(1 - p_v + 1e-7)).sum(1)       # rbm.py:124-129
-            self._metrics = {"batch/loss": loss, "free_energy": (Fv * rw).sum(), "log_likelihood": (self._recon_tm * rw).sum()}
+            self._recon_tm = torch.empty(N, device=dev)
+            ops.log_loss_rows(tgt, p_v, self._recon_tm)                                                       # rbm.py:124-129
+            fe, ll = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+            ops.weighted_sum(Fv, rw, fe)
+            ops.weighted_sum(self._recon_tm, rw, ll)
+            self._metrics = {"batch/loss": loss, "free_energy": fe, "log_likelihood": ll}
             self._metrics_upd = []
         self._is_built = True
 
@@ -1014,7 +1021,7 @@ class RnnRBM(RnnEstimator):
         sv = torch.empty((N, Hn), device=dev); ss = torch.empty((N, Hn), device=dev)
         ops.rbm_hidden(cx["tgt"], self._rbm.W, cx["bh_u"], 0, 0, 0, 0, sv, None)
         ops.rbm_hidden(cx["v_s"], self._rbm.W, cx["bh_u"], 0, 0, 0, 0, ss, None)
-        rw = cx["rw"][:, None]
+        rw = cx["rw"][:, None] if self.grad_scale == 1.0 else (cx["rw"] * self.grad_scale)[:, None]
         # dF/dbh = -sigmoid(z), dF/dbv = -v, dF/dW = -v^T sigmoid(z); cost = F(v) - F(v_s), v_s constant (rbm.py:229)
         d_out = torch.zeros((N, self.ldo), device=dev)
         d_out[:, :Hn] = rw * (ss - sv)
@@ -1086,11 +1093,16 @@ class RnnRBM(RnnEstimator):
         return v, p_v
 
     def pretrain(self, optimizer, lr, run_optimizer=True):
-        """rnn_rbm.py:299-322: CD-k on the flattened inputs."""
+        """rnn_rbm.py:299-322: one CD-k update of the RBM module on the flattened inputs (`rbm.train`, no optimiser, no clipping).
+        Returns the documented 5-tuple (the reference returns `rbm.train`'s 3-tuple although its docstring and every caller --
+        multinn_jamming.py:219-221 -- expect five values)."""
         x = self._inputs
         B, T, _ = x.shape
         flat = x.to(torch.uint8)[:, :, :self.num_dims].reshape(B * T, self.num_dims)
         if self._lengths is not None:
             m = torch.arange(T, device=x.device)[None, :] < self._lengths.to(x.device)[:, None]
             flat = flat[m.reshape(-1)]
-        return self._rbm.train(flat.contiguous(), lr, seed=self.seed + self.store.step)
+        self._materialize(x.shape[-1])
+        init_ops, update_ops, self._cd_gradients = self._rbm.train(flat.contiguous(), lr, seed=self.seed + self.store.step, row0=self.row0 * T)
+        self._packed_step = -1                          # rbm.bh / rbm.bv feed the packed bias row
+        return init_ops, update_ops, self.metrics, self.metrics_upd, self.summaries

@@ -1,0 +1,629 @@
+"""The tensor plumbing of the five MultINN operation modes around the Encoder / Generator plugin classes
+(/root/reference/multinn/models/multinn): which slice of the `[batch, time, pitch, track]` piano-roll each encoder
+sees, how the encodings are stacked for the generators (inputs = enc[:, :-1], targets = enc[:, 1:]), how generator
+outputs are decoded back, how the per-track losses are combined and optimised, and how samples are put back together.
+
+    MultINNJoint        multinn_joint.py:41-215       one encoder over P*M features, one generator            (C1, C2, TGT)
+    MultINNJamming      multinn_jamming.py:31-250     M per-track encoders, M independent generators           (C3)
+    MultINNComposer     multinn_composer.py:33-204    M per-track encoders, ONE RnnMultiNADE over the stack    (C4)
+    MultINNFeedback     multinn_feedback.py:46-218    jamming + Dense feedback module
+    MultINNFeedbackRnn  multinn_feedback_rnn.py:30-79 jamming + recurrent feedback module                      (C5)
+    MultINN             multinn.py:24-53              facade choosing one of them by `params['mode']`
+
+Same constructor arguments (`config`, `params` dicts with the YAML keys of configs/*.yaml), method names and return
+arity as the reference.  The reference builds a TF1 graph once and feeds placeholders at every `sess.run`; here
+`build(x, lengths=..., is_train=..., mode=...)` takes the fed values and RUNS the forward pass on the device,
+`train_generators(optimizer, lr)` runs backward + the clipped optimiser step, `generate(num_steps)` runs the sampling
+scan.  The encoder-level ("global") metrics the reference adds to the graph but never evaluates in a training
+`sess.run` are computed on first access of `.metrics`.  Everything numeric goes through the Encoder / Generator classes
+(HIP kernels behind the C ABI); this file only slices, stacks and reshapes device tensors.
+"""
+import abc
+
+import torch
+
+from .common import Model
+from .encoders import PassEncoder, DBNEncoder
+from .generators import RnnNade, RnnRBM, RnnMultiNADE
+from .training import compute_gradients_multi, world
+
+
+def flatten_maybe_padded_sequences(x, lengths=None):
+    """utils/sequences.py:6-37: `[B,T,...]` -> `[N,...]`, rows (b,t) with t < lengths[b], b-major then t."""
+    B, T = x.shape[0], x.shape[1]
+    flat = x.reshape(B * T, *x.shape[2:])
+    if lengths is None:
+        return flat
+    m = torch.arange(T, device=x.device)[None, :] < lengths.to(x.device)[:, None]
+    return flat[m.reshape(-1)]
+
+
+class _LazyMetrics(dict):
+    """`metrics['global']` of train_generators (multinn_joint.py:286): the encoder-level metrics, evaluated when first read."""
+
+    def __init__(self, fn):
+        super().__init__()
+        self._fn, self._done = fn, False
+
+    def _fill(self):
+        if not self._done:
+            self._done = True
+            super().update(self._fn())
+
+    def __getitem__(self, k):
+        self._fill()
+        return super().__getitem__(k)
+
+    def __contains__(self, k):
+        self._fill()
+        return super().__contains__(k)
+
+    def keys(self):
+        self._fill()
+        return super().keys()
+
+    def items(self):
+        self._fill()
+        return super().items()
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __len__(self):
+        self._fill()
+        return super().__len__()
+
+
+class MultINNCore(Model):
+    """core/multinn_core.py:17-448 + core/multinn_interface.py."""
+
+    def __init__(self, config, params, name="MultINN", precision="bf16", seed=None, device=None):
+        super().__init__(name=name)
+        self._mode = "core"
+        self._config, self._params = config, params
+        self._encoder_type = params["encoder"]["type"]
+        self._generator_type = params["generator"]["type"]
+        if self._encoder_type == "Pass":
+            encoder_class = PassEncoder
+        elif self._encoder_type in ("RBM", "DBN"):
+            encoder_class = DBNEncoder
+        else:
+            raise ValueError("Incorrect encoder type, supported types are `Pass`, `RBM`, and `DBN`")
+        if self._generator_type == "RBM":
+            generator_class = RnnRBM
+        elif self._generator_type == "NADE":
+            generator_class = RnnNade
+        else:
+            raise ValueError("Incorrect generator type, supported types are `RBM`, and `NADE`")
+        num_dims = config["data"]["pitch_range"]["highest"] - config["data"]["pitch_range"]["lowest"]
+        self._num_dims = num_dims * config["training"]["num_pixels"]
+        self._tracks = list(config["data"]["instruments"])
+        self._feedback_module = False
+        self._keep_prob = params["keep_prob"]
+        self._tune_encoder = params["tune_encoder"]
+        if self._tune_encoder:
+            raise NotImplementedError("tune_encoder=True (gradients into the encoders, multinn_joint.py:117-122) is not built; the "
+                                      "reference default is False (default_params.yaml:2)")
+        self.precision, self.device = precision, device
+        self.seed = config["training"].get("random_seed", 23) if seed is None else seed
+        self.clip_norm = 5.0                               # utils/training.py:166 (hard-coded in the reference, R9)
+        self.separate_losses = False                       # jamming / composer default (multinn_jamming.py:156)
+        self._row0 = 0
+        self._x = self._lengths = self._is_train = None
+        self._placeholders = {"x": None, "lengths": None, "is_train": None}
+        self._encoders = self._init_encoders(encoder_class)
+        self._generators = self._init_generators(generator_class)
+        self._x_encoded = self._x_hidden = self._outputs_probs = self._outputs = self._inputs = None
+
+    # -- construction ---------------------------------------------------------------------------
+    def _encoder_kwargs(self, i=0):
+        """Build-only arguments next to the reference's (`num_dims`, `num_hidden`, `track_name`)."""
+        return {} if self._encoder_type == "Pass" else dict(seed=self.seed + 1000 + i, device=self.device)
+
+    def _generator_kwargs(self, i=0):
+        return dict(precision=self.precision, seed=self.seed + i, device=self.device, clip_norm=self.clip_norm)
+
+    @abc.abstractmethod
+    def _init_encoders(self, encoder_class):
+        ...
+
+    @abc.abstractmethod
+    def _init_generators(self, generator_class):
+        ...
+
+    mode = property(lambda self: self._mode)
+    num_dims = property(lambda self: self._num_dims)
+    tracks = property(lambda self: self._tracks)
+    num_tracks = property(lambda self: len(self._tracks))
+    encoder_type = property(lambda self: self._encoder_type)
+    generator_type = property(lambda self: self._generator_type)
+    encoders = property(lambda self: self._encoders)
+    generators = property(lambda self: self._generators)
+    feedback_module = property(lambda self: self._feedback_module)
+    keep_prob = property(lambda self: self._keep_prob)
+    tune_encoder = property(lambda self: self._tune_encoder)
+    trainable_feedback_variables = property(lambda self: [])
+
+    @property
+    def loss(self):
+        return self.metrics["batch/loss"]
+
+    @property
+    def row0(self):
+        return self._row0
+
+    @row0.setter
+    def row0(self, v):
+        """Global index of this rank's first sequence: every RNG counter is keyed by GLOBAL rows (data parallel)."""
+        self._row0 = int(v)
+        for g in self._generators:
+            g.row0 = self._row0
+
+    @property
+    def trainable_encoder_variables(self):
+        return [v for e in self._encoders for v in e.trainable_variables]
+
+    @property
+    def trainable_generator_variables(self):
+        return [v for g in self._generators for v in g.trainable_variables]
+
+    # -- build ----------------------------------------------------------------------------------
+    def build(self, x=None, y=None, lengths=None, is_train=None, mode="eval"):
+        """multinn_core.py:178-244.  x: u8 (or float 0/1) `[B,T,P,M]` piano-roll batch -- the value fed to the reference's `x`
+        placeholder; lengths int32 `[B]` or None; is_train bool."""
+        Model.build(self, mode=mode)
+        if x is None:
+            raise ValueError("build() needs the piano-roll batch x [B,T,P,M] (the reference feeds it through a placeholder)")
+        if x.dim() != 4 or x.shape[2] != self._num_dims or x.shape[3] != self.num_tracks:
+            raise ValueError(f"x must be [batch, time, {self._num_dims}, {self.num_tracks}], got {tuple(x.shape)}")
+        x = x if x.dtype == torch.uint8 else (x != 0).to(torch.uint8)
+        self._x, self._lengths, self._is_train, self._build_mode = x.contiguous(), lengths, bool(is_train), mode
+        self._placeholders = {"x": self._x, "lengths": lengths, "is_train": self._is_train}
+        T1 = x.shape[1] + 1
+        for e in self._encoders:                       # encoder draws: flat (b, t) rows of the padded batch, global ids
+            if hasattr(e, "row0"):
+                e.row0 = self._row0 * T1
+        self._inputs = self._x_encoded = None
+        self._metrics = self._metrics_upd = None
+        self._x_hidden = self._outputs_probs = self._outputs = None
+        self._build_all(mode)
+        self._variables = {"encoders": [e.variables for e in self._encoders], "generators": [g.variables for g in self._generators],
+                           "feedback": self.trainable_feedback_variables}
+        self._trainable_variables = self.trainable_encoder_variables + self.trainable_generator_variables + self.trainable_feedback_variables
+        self._is_built = True
+
+    def _build_all(self, mode):
+        self._inputs = self._build_inputs()
+        self._build_encoders("eval")
+        self._x_encoded = self._encode_inputs()
+        self._build_generators(mode)
+
+    def _ensure_global_metrics(self):
+        """multinn_core.py:226-241 (outputs, decodings, targets, encoder-level metrics), evaluated on demand."""
+        if self._metrics is None and self._is_built and getattr(self, "_build_mode", None) in ("train", "eval"):
+            self._x_hidden = self._build_generator_outputs()
+            self._outputs_probs, self._outputs = self._decode_generator_outputs()
+            targets = self._build_targets()
+            self._metrics, self._metrics_upd, self._summaries["metrics"] = self.build_metrics(
+                targets=targets, predictions=self._outputs, cond_probs=self._outputs_probs)
+        return self._metrics
+
+    metrics = property(lambda self: self._ensure_global_metrics())
+    metrics_upd = property(lambda self: (self._ensure_global_metrics(), self._metrics_upd)[1])
+
+    # -- sampling -------------------------------------------------------------------------------
+    def sampler(self, num_beats):
+        """multinn_core.py:324-341: number of model time steps in `num_beats` beats, then generate()."""
+        d = self._config["data"]
+        pitch_span = d["pitch_range"]["highest"] - d["pitch_range"]["lowest"]
+        return self.generate(num_beats * d["beat_resolution"] * pitch_span // self._num_dims)
+
+    def evaluator(self):
+        """multinn_core.py:343-362: musical metrics of the fed batch reshaped into bars `[B, bars, 4*beat_resolution, pitch_span, M]`."""
+        from . import metrics as MM
+        d = self._config["data"]
+        pitch_span = d["pitch_range"]["highest"] - d["pitch_range"]["lowest"]
+        bars = self._x.reshape(self._x.shape[0], -1, 4 * d["beat_resolution"], pitch_span, self.num_tracks)
+        return MM.compute_sample_metrics(bars)
+
+    def _combine_track_metrics(self, track_metrics, track_metrics_upd, track_summaries, global_scope=None):
+        """multinn_core.py:364-413: per-key lists over the tracks, averaged when a global scope is given."""
+        assert len(track_metrics) == self.num_tracks
+        metrics, metrics_upd = {}, []
+        for i in range(self.num_tracks):
+            for k, m in track_metrics[i].items():
+                metrics.setdefault(k, []).append(m)
+            metrics_upd += list(track_metrics_upd[i] or [])
+        if global_scope is not None:
+            for k, v in metrics.items():
+                if all(torch.is_tensor(t) for t in v):
+                    metrics[k] = torch.stack([t.reshape(()) for t in v]).mean()
+                else:
+                    metrics[k] = sum(float(t) for t in v) / len(v)
+        return metrics, metrics_upd, {"metrics": None, "weights": None, "gradients": None}
+
+    def load_encoders(self, sess=None, ckpt_dir=None):
+        """multinn_core.py:425-448."""
+        if self._encoder_type == "Pass":
+            return True
+        return all(e.load(None, ckpt_dir) for e in self._encoders)
+
+    def save(self, sess=None, ckpt_dir=None, global_step=None, write_meta_graph=False):
+        return [m.save(None, ckpt_dir) for m in self._generators + [e for e in self._encoders if e.store is not None]]
+
+    def load(self, sess=None, ckpt_dir=None):
+        return all(m.load(None, ckpt_dir) for m in self._generators + [e for e in self._encoders if e.store is not None])
+
+    # -- train.py:178-189: one `sess.run([update_ops, loss], feed_dict)` -----------------------------
+    def generator_loss(self):
+        """Mean over the generators of their `batch/loss` (the `loss` / `loglik` train.py:74-75 logs and validates on)."""
+        ls = [g.metrics["batch/loss"].reshape(()) for g in self._generators]
+        return ls[0] if len(ls) == 1 else torch.stack(ls).mean()
+
+    def train_step(self, x, lengths, optimizer, lr=None):
+        """build(x, lengths, is_train=True, mode='train') + train_generators(optimizer, lr): one optimiser step from a zero RNN state."""
+        self.build(x, lengths=lengths, is_train=True, mode="train")
+        self.train_generators(optimizer, lr)
+        return self.generator_loss()
+
+    def build_pianoroll(self, x, lengths=None, is_train=False, mode="eval"):
+        """The driver's evaluation entry (same name as RnnNade.build_pianoroll)."""
+        self.build(x, lengths=lengths, is_train=is_train, mode=mode)
+
+    # -- shared pieces of the train step ----------------------------------------------------------
+    def _with_global(self, out):
+        init_ops, update_ops, metrics, metrics_upd, summaries = out
+        metrics = dict(metrics)
+        metrics["global"] = _LazyMetrics(lambda: self.metrics)          # multinn_joint.py:284-286
+        return init_ops, update_ops, metrics, metrics_upd, summaries
+
+
+# ================================================================================================
+class MultINNJoint(MultINNCore):
+    """multinn_joint.py: one Encoder + one Generator over the stacked tracks (feature index p*M+m)."""
+
+    def __init__(self, config, params, name="MultINN-joint", **kw):
+        super().__init__(config, params, name=name, **kw)
+        self._mode = "joint"
+
+    def _init_encoders(self, encoder_class):
+        num_dims = self.num_dims * self.num_tracks                       # multinn_joint.py:41-52
+        encoders = [encoder_class(num_dims=num_dims, num_hidden=self._params["encoder"]["num_hidden"], track_name="all",
+                                  **self._encoder_kwargs())]
+        self._encoder = encoders[0]
+        self._num_dims_generator = self._encoder.num_hidden[-1]
+        return encoders
+
+    def _init_generators(self, generator_class):
+        generators = [generator_class(num_dims=self._num_dims_generator, num_hidden=self._params["generator"]["num_hidden"],
+                                      num_hidden_rnn=self._params["generator"]["num_hidden_rnn"], keep_prob=self.keep_prob,
+                                      **self._generator_kwargs())]          # multinn_joint.py:65-74
+        self._generator = generators[0]
+        return generators
+
+    def _fused(self):
+        """PassEncoder + RnnNade: zero-pad, shift, inputs / targets slicing fused into the generator's one plumbing kernel
+        (RnnNade.build_pianoroll: multinn_joint.py:83-89,132-139 in one pass over the uint8 batch)."""
+        return self._encoder_type == "Pass" and isinstance(self._generator, RnnNade)
+
+    def _build_all(self, mode):
+        if self._fused() and mode in ("train", "eval"):
+            self._generator.build_pianoroll(self._x, self._lengths, is_train=self._is_train, mode=mode)
+            return
+        super()._build_all(mode)
+
+    def _build_inputs(self):
+        B, T, P, M = self._x.shape
+        inputs = self._x.reshape(B, T, P * M)                             # multinn_joint.py:83-89
+        return torch.cat([torch.zeros((B, 1, P * M), device=inputs.device, dtype=inputs.dtype), inputs], 1)
+
+    def _build_targets(self):
+        return flatten_maybe_padded_sequences(self._x, self._lengths).reshape(-1, self.num_dims * self.num_tracks)
+
+    def _build_encoders(self, mode="eval"):
+        self._encoder.build(self._inputs, lengths=self._lengths, mode=mode)
+
+    def _encode_inputs(self):
+        _, x_encoded = self._encoder.encode()
+        return x_encoded                                                  # stop_gradient: nothing differentiates through it
+
+    def _build_generators(self, mode="eval"):
+        self._generator.build(x=self._x_encoded[:, :-1], y=self._x_encoded[:, 1:], lengths=self._lengths, is_train=self._is_train,
+                              mode=mode)                                  # multinn_joint.py:132-139
+
+    def _build_generator_outputs(self):
+        return self._generator.forward()
+
+    def _decode_generator_outputs(self):
+        return self._encoder.decode(self._x_hidden)
+
+    def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None):
+        """multinn_joint.py:159-186: encoder-level metrics, loss / NLL / perplexity divided by the number of tracks."""
+        metrics, metrics_upd, summaries = self._encoder.build_metrics(targets=targets, predictions=predictions, cond_probs=cond_probs)
+        for k in ("batch/loss", "log_likelihood", "perplexity"):
+            metrics[k] = metrics[k] / self.num_tracks
+        return metrics, metrics_upd, summaries
+
+    def generate(self, num_steps):
+        """multinn_joint.py:188-215 -> u8 `[B, num_steps, P, M]`."""
+        if self._x_encoded is None:
+            MultINNCore._build_all(self, "generate")
+        samples_h = self._generator.generate(self._x_encoded, num_steps)
+        _, samples = self._encoder.decode(samples_h)
+        return samples.reshape(-1, num_steps, self.num_dims, self.num_tracks).to(torch.uint8)
+
+    def train_encoders(self, optimizer, lr, layer=0):
+        if self._inputs is None:
+            self._inputs = self._build_inputs()
+            self._build_encoders("eval")
+        return self._encoder.train(optimizer, lr, layer=layer)
+
+    def pretrain_generators(self, optimizer, lr, separate_losses=True):
+        return self._with_global(self._generator.pretrain(optimizer, lr))
+
+    def train_generators(self, optimizer, lr, separate_losses=True):
+        return self._with_global(self._generator.train(optimizer, lr))
+
+
+# ================================================================================================
+class MultIEncoderNN(MultINNCore):
+    """core/multi_encoder_nn.py: one Encoder per track."""
+
+    def _init_encoders(self, encoder_class):
+        encoders = [encoder_class(num_dims=self.num_dims, num_hidden=self._params["encoder"]["num_hidden"], track_name=self.tracks[i],
+                                  **self._encoder_kwargs(i)) for i in range(self.num_tracks)]           # multi_encoder_nn.py:41-50
+        self._num_dims_generator = encoders[0].num_hidden[-1]
+        return encoders
+
+    def _build_inputs(self):
+        """multi_encoder_nn.py:66-76: zero first step, then one `[B,T+1,P]` sequence per track."""
+        B, T, P, M = self._x.shape
+        padded = torch.cat([torch.zeros((B, 1, P, M), device=self._x.device, dtype=self._x.dtype), self._x], 1)
+        return [t.contiguous() for t in padded.unbind(-1)]
+
+    def _build_targets(self):
+        return list(flatten_maybe_padded_sequences(self._x, self._lengths).unbind(-1))        # multi_encoder_nn.py:78-87
+
+    def _build_encoders(self, mode="eval"):
+        for i in range(self.num_tracks):
+            self.encoders[i].build(self._inputs[i], lengths=self._lengths, mode=mode)
+
+    def _encode_inputs(self):
+        return [self.encoders[i].encode()[1] for i in range(self.num_tracks)]
+
+    def _stack_encoded(self):
+        """multinn_composer.py:73-80 / multinn_feedback.py:85-91: stack on axis 3, reshape to `[B,T+1,E*M]` (feature e*M+m)."""
+        st = torch.stack(self._x_encoded, dim=3)
+        return st.reshape(st.shape[0], st.shape[1], self._num_dims_generator * self.num_tracks)
+
+    def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None):
+        """multi_encoder_nn.py:117-153: per-track encoder metrics, averaged over the tracks."""
+        tm, tu, ts = [], [], []
+        for i in range(self.num_tracks):
+            m, u, s = self.encoders[i].build_metrics(targets=targets[i], predictions=predictions[i], cond_probs=cond_probs[i])
+            tm.append(m); tu.append(u); ts.append({"metrics": s})
+        return self._combine_track_metrics(tm, tu, ts, global_scope=f"metrics/{self.encoders[0].name}/global/")
+
+    def train_encoders(self, optimizer, lr, layer=0):
+        """multi_encoder_nn.py:155-195."""
+        if self._inputs is None:
+            self._inputs = self._build_inputs()
+            self._build_encoders("eval")
+        init_ops, update_ops, tm, tu, ts = [], [], [], [], []
+        for i in range(self.num_tracks):
+            io, uo, m, mu, s = self.encoders[i].train(optimizer, lr, layer=layer)
+            init_ops += io; update_ops += uo
+            tm.append(m or {}); tu.append(mu); ts.append(s or {})
+        metrics, metrics_upd, summaries = self._combine_track_metrics(tm, tu, ts, global_scope="metrics/global/")
+        return init_ops, update_ops, metrics, metrics_upd, summaries
+
+    def _decode_tracks(self, hidden):
+        probs, outs = [], []
+        for i in range(self.num_tracks):
+            p, d = self.encoders[i].decode(hidden[i])
+            probs.append(p); outs.append(d)
+        return probs, outs
+
+
+class MultINNJamming(MultIEncoderNN):
+    """multinn_jamming.py: M independent per-track generators."""
+
+    def __init__(self, config, params, name="MultINN-jamming", **kw):
+        super().__init__(config, params, name=name, **kw)
+        self._mode = "jamming"
+
+    def _init_generators(self, generator_class):
+        return [generator_class(num_dims=self._num_dims_generator, num_hidden=self._params["generator"]["num_hidden"],
+                                num_hidden_rnn=self._params["generator"]["num_hidden_rnn"], keep_prob=self.keep_prob,
+                                track_name=self.tracks[i], **self._generator_kwargs(i)) for i in range(self.num_tracks)]    # :40-48
+
+    def _generator_io(self, i):
+        return self._x_encoded[i][:, :-1], self._x_encoded[i][:, 1:]                            # multinn_jamming.py:61-65
+
+    def _build_generators(self, mode="eval"):
+        scale = 1.0 if self.separate_losses else 1.0 / self.num_tracks
+        for i in range(self.num_tracks):
+            gi, gt = self._generator_io(i)
+            self.generators[i].grad_scale = scale          # mean track loss, one clip over all generators (multinn_jamming.py:235-241)
+            self.generators[i].build(x=gi, y=gt, lengths=self._lengths, is_train=self._is_train, mode=mode)
+
+    def _build_generator_outputs(self):
+        return [self.generators[i].forward() for i in range(self.num_tracks)]
+
+    def _decode_generator_outputs(self):
+        return self._decode_tracks(self._x_hidden)
+
+    def generate(self, num_steps):
+        """multinn_jamming.py:101-133 -> u8 `[B, num_steps, P, M]`."""
+        if self._x_encoded is None:
+            MultINNCore._build_all(self, "generate")
+        music = []
+        for i in range(self.num_tracks):
+            samples_h = self.generators[i].generate(self._x_encoded[i], num_steps)
+            music.append(self.encoders[i].decode(samples_h)[1].to(torch.uint8))
+        return torch.stack(music, dim=3)
+
+    def pretrain_generators(self, optimizer, lr, separate_losses=False):
+        return self._train_generators(optimizer, lr, pretrain=True, separate_losses=separate_losses)
+
+    def train_generators(self, optimizer, lr, separate_losses=False):
+        return self._with_global(self._train_generators(optimizer, lr, pretrain=False, separate_losses=separate_losses))
+
+    def _extra_stores(self):
+        return []
+
+    def _train_generators(self, optimizer, lr, pretrain=False, separate_losses=False):
+        """multinn_jamming.py:186-245."""
+        if not pretrain and separate_losses != self.separate_losses:
+            raise ValueError("set `model.separate_losses` before build(): the per-track gradient weight (1/num_tracks for the mean "
+                             "track loss) is applied in the forward pass")
+        init_ops, update_ops, tm, tu, ts = [], [], [], [], []
+        for i in range(self.num_tracks):
+            fn = self.generators[i].pretrain if pretrain else self.generators[i].train
+            io, uo, m, mu, s = fn(optimizer, lr, run_optimizer=separate_losses)
+            init_ops += io; update_ops += uo
+            tm.append(m); tu.append(mu); ts.append(s or {})
+        metrics, metrics_upd, summaries = self._combine_track_metrics(tm, tu, ts, global_scope=f"metrics/{self.generators[0].name}/global/")
+        if not separate_losses and not pretrain:
+            stores = [g.store for g in self.generators] + self._extra_stores()
+            self._grad_sumsq = compute_gradients_multi(optimizer, stores, self.clip_norm, lr)
+            for g in self.generators:
+                g._packed_step = -1
+        return init_ops, update_ops, metrics, metrics_upd, summaries
+
+
+class MultINNComposer(MultIEncoderNN):
+    """multinn_composer.py: per-track encoders, ONE generator with a shared LSTM and one NADE per track."""
+
+    def __init__(self, config, params, name="MultINN-composer", **kw):
+        super().__init__(config, params, name=name, **kw)
+        self._mode = "composer"
+
+    def _init_generators(self, generator_class):
+        if self.generator_type == "RBM":
+            raise NotImplementedError("MultiRNNRBM is not implemented yet :(")                 # multinn_composer.py:44-45
+        generators = [RnnMultiNADE(num_dims=self._num_dims_generator, num_hidden=self._params["generator"]["num_hidden"],
+                                   num_hidden_rnn=self._params["generator"]["num_hidden_rnn"], tracks=self.tracks,
+                                   keep_prob=self.keep_prob, **self._generator_kwargs())]       # multinn_composer.py:49-57
+        self._generator = generators[0]
+        return generators
+
+    def _build_generators(self, mode="eval"):
+        self._x_encoded_stack = self._stack_encoded()                                            # multinn_composer.py:73-87
+        self._generator.build(x=self._x_encoded_stack[:, :-1], y=self._x_encoded_stack[:, 1:], lengths=self._lengths,
+                              is_train=self._is_train, mode=mode)
+
+    def _build_generator_outputs(self):
+        return self._generator.forward()
+
+    def _decode_generator_outputs(self):
+        return self._decode_tracks(self._x_hidden)
+
+    def generate(self, num_steps):
+        """multinn_composer.py:114-151 -> u8 `[B, num_steps, P, M]`."""
+        if self._x_encoded is None:
+            MultINNCore._build_all(self, "generate")
+        samples_h = self._generator.generate(self._x_encoded_stack, num_steps)
+        samples_h = samples_h.reshape(samples_h.shape[0], num_steps, self._num_dims_generator, self.num_tracks).unbind(-1)
+        music = [self.encoders[i].decode(samples_h[i].contiguous())[1].to(torch.uint8) for i in range(self.num_tracks)]
+        return torch.stack(music, dim=3)
+
+    def pretrain_generators(self, optimizer, lr, separate_losses=False):
+        return self._generator.pretrain(optimizer, lr)
+
+    def train_generators(self, optimizer, lr, separate_losses=False):
+        return self._with_global(self._generator.train(optimizer, lr))
+
+
+class MultINNFeedback(MultINNJamming):
+    """multinn_feedback.py: jamming + a Dense feedback module over the stacked encodings of the step."""
+
+    def __init__(self, config, params, name="MultINN-feedback", **kw):
+        super().__init__(config, params, name=name, **kw)
+        self._mode = "feedback"
+        self._feedback_module = True
+        self._feedback_layer = None
+        self._x_encoded_stack = self._x_feedback = self._feedback_final_state = None
+
+    def _init_feedback(self, num_inputs):
+        from .feedback import FeedbackDnn
+        return FeedbackDnn(num_inputs, self._params["generator"]["feedback"], seed=self.seed + 500, device=self.device)   # :46-52
+
+    def _apply_feedback(self, inputs, initial_state=None, single_step=False):
+        if single_step:
+            return self._feedback_layer.single(inputs, initial_state)
+        return self._feedback_layer.run(inputs, initial_state)
+
+    def _build_generators(self, mode="eval"):
+        """multinn_feedback.py:54-101."""
+        if mode == "train":
+            raise NotImplementedError("training the feedback modes needs the gradient wrt the generator inputs (the feedback vector); "
+                                      "the feedback modes are built for evaluation and sampling (BASELINE config 5)")
+        self._x_encoded_stack = self._stack_encoded()
+        if self._feedback_layer is None:
+            self._feedback_layer = self._init_feedback(self._x_encoded_stack.shape[-1])
+        self._x_feedback, self._feedback_final_state = self._apply_feedback(self._x_encoded_stack, single_step=False)
+        super()._build_generators(mode)
+
+    def _generator_io(self, i):
+        inputs = torch.cat([self._x_encoded[i].float(), self._x_feedback], dim=-1)               # multinn_feedback.py:85-91
+        return inputs[:, :-1], self._x_encoded[i][:, 1:]
+
+    def generate(self, num_steps):
+        """multinn_feedback.py:120-173 -> u8 `[B, num_steps, P, M]`: one joint scan over the M generators and the feedback module."""
+        from .feedback import FeedbackRnnSampler
+        if self._x_encoded is None:
+            self._inputs = self._build_inputs()
+            self._build_encoders("eval")
+            self._x_encoded = self._encode_inputs()
+        if self._feedback_layer is None:
+            self._feedback_layer = self._init_feedback(self._num_dims_generator * self.num_tracks)
+        if getattr(self, "_sampler", None) is None:
+            self._sampler = FeedbackRnnSampler(self.generators, self._feedback_layer)
+        if self._encoder_type == "Pass":
+            samples_h = self._sampler.generate(self._x, num_steps)                                # whole scan = one hipGraph replay
+        else:
+            samples_h = self._sampler.generate_encoded([e.to(torch.uint8) for e in self._x_encoded], num_steps)
+        music = [self.encoders[i].decode(samples_h[..., i].contiguous())[1].to(torch.uint8) for i in range(self.num_tracks)]
+        return torch.stack(music, dim=3)
+
+    @property
+    def trainable_feedback_variables(self):
+        fl = self._feedback_layer
+        return [] if fl is None else [fl.store[n] for n in fl.store.names()]
+
+
+class MultINNFeedbackRnn(MultINNFeedback):
+    """multinn_feedback_rnn.py: the feedback module is an RNN over the stacked encodings (keeps history)."""
+
+    def __init__(self, config, params, name="MultINN-feedback-rnn", **kw):
+        super().__init__(config, params, name=name, **kw)
+        self._mode = "feedback-rnn"
+
+    def _init_feedback(self, num_inputs):
+        from .feedback import FeedbackRnn
+        return FeedbackRnn(num_inputs, self._params["generator"]["feedback"], keep_prob=self.keep_prob, precision=self.precision,
+                           seed=self.seed + 500, device=self.device)                              # multinn_feedback_rnn.py:30-39
+
+
+# ================================================================================================
+class MultINN:
+    """multinn.py:9-299: facade over the mode classes; every attribute and method is the chosen model's."""
+
+    _MODES = {"joint": MultINNJoint, "composer": MultINNComposer, "jamming": MultINNJamming, "feedback": MultINNFeedback,
+              "feedback-rnn": MultINNFeedbackRnn}
+
+    def __init__(self, config, params, mode="feedback-rnn", name="MultINN", **kw):
+        if mode not in self._MODES:
+            raise ValueError("Incorrect operation mode, choose from `joint`, `composer`, `jamming`, `feedback`, and `feddback-rnn`.")
+        self._model = self._MODES[mode](config, params, name=name, **kw)
+
+    def __getattr__(self, k):
+        return getattr(self.__dict__["_model"], k)
+
+    def __setattr__(self, k, v):
+        if k == "_model":
+            self.__dict__[k] = v
+        else:
+            setattr(self._model, k, v)

@@ -479,6 +479,36 @@ def rbm_free_energy(v, W, bh, bv, F):
     return F
 
 
+def rbm_cd_bias_delta(v, p_v, h, p_h, scale, dbv, dbh):
+    """dbv += scale * colsum(v - p_v), dbh += scale * colsum(h - p_h) (rbm.py:318-327); v/h u8, p_* f32, outputs f32 (zeroed by the caller)."""
+    N, D = v.shape
+    Hn = h.shape[1]
+    _req(v.dtype == torch.uint8 and h.dtype == torch.uint8 and v.is_contiguous() and h.is_contiguous() and h.shape[0] == N, "cd_bias_delta: v/h u8 [N,.]")
+    _req(p_v.dtype == torch.float32 and p_v.shape == (N, D) and p_v.is_contiguous() and p_h.dtype == torch.float32 and p_h.shape == (N, Hn)
+         and p_h.is_contiguous(), "cd_bias_delta: p_v / p_h f32 [N,.]")
+    _req(dbv.dtype == torch.float32 and dbv.numel() == D and dbv.is_contiguous() and dbh.dtype == torch.float32 and dbh.numel() == Hn
+         and dbh.is_contiguous(), "cd_bias_delta: outputs f32 [D] / [Hn]")
+    call("mnn_rbm_cd_bias_delta", _stream(), N, D, Hn, _ptr(v), _ptr(p_v), _ptr(h), _ptr(p_h), float(scale), _ptr(dbv), _ptr(dbh))
+
+
+def rbm_visible_bias_init(colsum, count, bv):
+    """bv[d] = log(1e-6 + p/(1-p)), p = colsum[d]/count (rbm.py:286-297)."""
+    D = colsum.numel()
+    _req(colsum.dtype == torch.float32 and colsum.is_contiguous() and bv.dtype == torch.float32 and bv.numel() == D and bv.is_contiguous(),
+         "visible_bias_init: f32 [D] buffers")
+    call("mnn_rbm_visible_bias_init", _stream(), D, _ptr(colsum), float(count), _ptr(bv))
+
+
+def axpby(a, x, b, y, out):
+    """out = a*x + b*y over flat f32 buffers (out may alias x or y; y None with b == 0)."""
+    n = x.numel()
+    for t in (x, out) + (() if y is None else (y,)):
+        _req(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n, "axpby: contiguous f32 buffers of equal size")
+    _req(y is not None or b == 0, "axpby: y missing")
+    call("mnn_axpby_f32", _stream(), n, float(a), _ptr(x), float(b), _ptr(y), _ptr(out))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 def sumsq(x, out):
     _req(x.dtype == torch.float32 and x.is_contiguous() and out.dtype == torch.float32, "sumsq: f32")

@@ -61,3 +61,22 @@ def compute_gradients(optimizer, store, clip_norm=5.0, lr=None, reduce=True):
                        optimizer.beta1, optimizer.beta2, optimizer.epsilon, store.step, optimizer.sgd, store.step_dev)
     ops.step_increment(store.step_dev)
     return sumsq
+
+
+def compute_gradients_multi(optimizer, stores, clip_norm=5.0, lr=None, reduce=True):
+    """The optimiser step of a mode that trains SEVERAL generators on one loss (multinn_jamming.py:235-241: `compute_gradients(optimizer,
+    mean track loss, all generators' + feedback variables)`): ONE global norm over every store's gradient (training.py:166 clips the
+    whole variable list together), then the clipped TF-Adam step per store.  Each store's flat gradient is summed over the ranks first
+    (data parallel).  Returns the device scalar holding the global sum of squares."""
+    if reduce:
+        for st in stores:
+            allreduce_flat(st.grad)
+    sumsq = torch.zeros(1, device=stores[0].grad.device)
+    for st in stores:
+        ops.sumsq(st.grad, sumsq)                       # accumulates (f32 atomic add into the one word)
+    for st in stores:
+        st.step += 1
+        ops.clip_adam_step(st.theta, st.grad, st.m, st.v, sumsq, clip_norm, optimizer.lr if lr is None else lr,
+                           optimizer.beta1, optimizer.beta2, optimizer.epsilon, st.step, optimizer.sgd, st.step_dev)
+        ops.step_increment(st.step_dev)
+    return sumsq

@@ -295,17 +295,23 @@ def test_rbm_cd_update_and_dbn_encoder():
     enc = DBNEncoder(D, [12, 8], seed=3)
     x = dev(v.reshape(4, 10, D))
     enc.build(x)
-    assert enc.encodings.shape == (4, 10, 8) and enc.encodings.dtype == torch.uint8
-    assert enc.dec_probs.shape == (4, 10, D) and float(enc.dec_probs.min()) > 0 and float(enc.dec_probs.max()) < 1
+    assert len(enc.encodings) == 2 and enc.encodings[0].shape == (4, 10, 12)               # per-layer lists (dbn_encoder.py:83-97)
+    assert enc.encodings[-1].shape == (4, 10, 8) and enc.encodings[-1].dtype == torch.uint8
+    assert enc.dec_probs[0].shape == (4, 10, D) and float(enc.dec_probs[0].min()) > 0 and float(enc.dec_probs[0].max()) < 1
+    assert enc.decodings[1].shape == (4, 10, 12) and torch.equal(enc.encode()[1], enc.encodings[-1])
     W1, W2 = [r.W.cpu().numpy() for r in enc.dbn.rbms]
     b1, b2 = [r.bh.cpu().numpy() for r in enc.dbn.rbms]
     ph1 = det.rbm_hidden(v, W1, b1)
     h1 = (philox.uniform_block(3, philox.STREAM_DBN_ENC, np.arange(N), 0, 12) < ph1).astype(np.uint8)
     ph2 = det.rbm_hidden(h1, W2, b2)
     h2 = (philox.uniform_block(3, philox.STREAM_DBN_ENC, np.arange(N), 1, 8) < ph2).astype(np.uint8)
-    assert np.array_equal(enc.encodings.cpu().numpy().reshape(N, 8), h2)
-    assert np.array_equal(enc.enc_probs.cpu().numpy().reshape(N, 8), ph2)
-    enc.train(None, 0.05, layer=1)
+    assert np.array_equal(enc.encodings[-1].cpu().numpy().reshape(N, 8), h2)
+    assert np.array_equal(enc.enc_probs[-1].cpu().numpy().reshape(N, 8), ph2)
+    assert np.array_equal(enc.encodings[0].cpu().numpy().reshape(N, 12), h1)
+    assert torch.equal(enc.encode(x)[1], enc.encodings[-1])                                  # explicit encode == the built encodings
+    W2_before = enc.dbn.rbms[1].W.clone()
+    io, uo, mt, mu, sm = enc.train(None, 0.05, layer=1)                                      # dbn_encoder.py:192-240
+    assert len(io) == 1 and {"batch/loss", "free_energy", "log_likelihood"} <= set(mt) and not torch.equal(W2_before, enc.dbn.rbms[1].W)
 
 
 def test_feedback_rnn_sampling_scan():

@@ -1,0 +1,385 @@
+"""BASELINE.json configurations run AS CONFIGURATIONS through the mode classes (multinn_amd/modes.py) against the CPU oracle:
+
+    C1  joint     PassEncoder + LSTM-RBM, 1 track
+    C2  joint     PassEncoder + LSTM-NADE (the fused piano-roll path) + the joint `/ num_tracks` metrics
+    C3  jamming   5 per-track LSTM-RBM generators, CD-10, mean track loss, ONE global-norm clip over all of them
+    C4  composer  5 DBNEncoders -> stacked codes -> RnnMultiNADE -> decode
+    C5  feedback-rnn sampling scan (per-track generators + recurrent feedback), incl. T = 512 generated steps
+
+fp32 mode: 1e-4 relative on losses / free energies / gradients (BASELINE.json gate); Bernoulli draws bit-exact against the
+deterministic C checker where the probabilities are computed by the deterministic kernels."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import generators as G, nade as onade, rbm as orbm, lstm as olstm, philox, det   # noqa: E402
+from oracle import tf_semantics as S   # noqa: E402
+
+DEV = "cuda:0"
+TRACKS5 = ["Drums", "Piano", "Guitar", "Bass", "Strings"]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(1e-30, np.abs(b).max())
+
+
+def config(P, tracks, num_pixels=1, beat_resolution=4):
+    return {"model_name": "t", "data": {"pitch_range": {"lowest": 0, "highest": P // num_pixels}, "instruments": list(tracks),
+                                         "beat_resolution": beat_resolution},
+            "training": {"num_pixels": num_pixels, "random_seed": 23}}
+
+
+def params(mode, enc="Pass", enc_hidden=None, gen="NADE", Hn=16, units=(32, 32), feedback=None, keep_prob=0.9):
+    return {"mode": mode, "tune_encoder": False, "keep_prob": keep_prob, "encoder": {"type": enc, "num_hidden": enc_hidden},
+            "generator": {"type": gen, "num_hidden": Hn, "num_hidden_rnn": list(units), "feedback": feedback}}
+
+
+def batch(B, T, P, M, seed, rho=0.25):
+    return (np.random.default_rng(seed).random((B, T, P, M)) < rho).astype(np.uint8)
+
+
+def load_rbm_params(gen, p):
+    s = gen.store
+    for l, (W, b) in enumerate(p['lstm']):
+        s[f"rnn/cell_{l}/kernel"].copy_(dev(W.astype(np.float32))); s[f"rnn/cell_{l}/bias"].copy_(dev(b.astype(np.float32)))
+    for kk in ("W", "bh", "bv"):
+        s[f"rbm/{kk}"].copy_(dev(p[kk].astype(np.float32)))
+    s["Wuh"].copy_(dev(p['Wuh'].astype(np.float32))); s["Wuv"].copy_(dev(p['Wuv'].astype(np.float32)))
+    gen._packed_step = -1
+
+
+def load_nade_params(gen, p):
+    s = gen.store
+    for l, (W, b) in enumerate(p['lstm']):
+        s[f"rnn/cell_{l}/kernel"].copy_(dev(W.astype(np.float32))); s[f"rnn/cell_{l}/bias"].copy_(dev(b.astype(np.float32)))
+    s["nade/w_enc"].copy_(dev(np.stack(p['w_enc']).astype(np.float32)))
+    s["nade/w_dec"].copy_(dev(np.stack(p['w_dec']).astype(np.float32)))
+    s["dense/kernel"].copy_(dev(p['fc_k'].astype(np.float32)))
+    s["dense/bias"].copy_(dev(p['fc_b'].astype(np.float32)))
+    gen._packed_step = -1
+
+
+def rbm_grad_list(g):
+    """Order of RnnRBM's variables: rbm [W, bv, bh], rnn, Wuh, Wuv (rnn_rbm.py:135-138)."""
+    out = [g['W'], g['bv'], g['bh']]
+    for W, b in g['lstm']:
+        out += [W, b]
+    return out + [g['Wuh'], g['Wuv']]
+
+
+def rbm_param_list(p):
+    out = [p['W'], p['bv'], p['bh']]
+    for W, b in p['lstm']:
+        out += [W, b]
+    return out + [p['Wuh'], p['Wuv']]
+
+
+def log_loss_rows(t, p):
+    return S.log_loss(t.astype(np.float64), p.astype(np.float64)).sum(1)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def test_c1_joint_pass_lstm_rbm_one_track():
+    """BASELINE configs[0]: Joint PassEncoder + LSTM-RBM, 1 track, batch 16, T 64 (feature width cut to keep the float64 oracle quick)."""
+    from multinn_amd import MultINN, AdamOptimizer
+    B, T, P, M, Hn, units, k = 16, 64, 20, 1, 24, [32, 32], 10
+    x = batch(B, T, P, M, 3, rho=0.15)
+    m = MultINN(config(P, ["Piano"]), params("joint", gen="RBM", Hn=Hn, units=units), mode="joint", precision="fp32")
+    gen = m.generators[0]
+    assert type(gen).__name__ == "RnnRBM" and gen.k == 10 and gen.num_dims == P
+    m.build(dev(x), None, True, "train")
+    p = G.init_rnn_rbm(5, P, P, Hn, units, np.float64)
+    p['bh'] += 0.1; p['bv'] -= 0.2
+    load_rbm_params(gen, p)
+    m.build(dev(x), None, True, "train")
+    inp, tgt = G.joint_inputs(x)
+    rows = np.array([t * 65536 + b for b in range(B) for t in range(T)])
+    du = G.dropout_uniforms(gen.seed, B, T, units)
+    fw = G.rnn_rbm_forward(inp.astype(np.float64), tgt.astype(np.float64), None, p, k, seed=gen.seed, keep_prob=0.9, drop_u=du, row_ids=rows)
+    vs = gen._outputs.cpu().numpy()
+    agree = (vs == fw['v_sample']).all(1).mean()
+    assert agree >= 0.9, agree
+    fw['v_sample'] = vs.astype(np.float64)                       # the device's own chain end: a rare u ~ p flip must not hide arithmetic errors
+    cost, F = orbm.free_energy_cost(fw['tgt'], fw['v_sample'], p['W'], fw['bh_t'], fw['bv_t'])
+    assert rel(gen.free_energy.cpu().numpy(), F) < 1e-4 and rel(gen.cost.cpu().numpy(), cost) < 1e-4
+    assert abs(float(m.generator_loss()) - cost.mean()) < 1e-4 * max(1.0, abs(cost.mean()))
+    pv = gen.cond_probs.cpu().numpy()
+    assert rel(gen.reconstruction_cost.cpu().numpy(), log_loss_rows(fw['tgt'], pv)) < 1e-5          # mnn_log_loss_rows (rbm.py:124-129)
+    # encoder-level ("global") metrics of the joint mode: log-loss of the DECODED hard outputs, / num_tracks (multinn_joint.py:177-184)
+    glob = m.metrics
+    ref = log_loss_rows(fw['tgt'], vs).mean() / M
+    assert abs(float(glob["batch/loss"]) - ref) < 1e-5 * ref and abs(float(glob["log_likelihood"]) - ref) < 1e-5 * ref
+    # backward + clip + TF-Adam through the mode's train_generators
+    g = G.rnn_rbm_backward(fw, p)
+    _, _, metrics, _, _ = m.train_generators(AdamOptimizer(0.01), 0.01)
+    assert "global" in metrics and float(metrics["global"]["batch/loss"]) == float(glob["batch/loss"])
+    opt = G.new_opt(rbm_param_list(p))
+    gn = G.apply_clip_adam(rbm_param_list(p), rbm_grad_list(g), opt, lr=0.01)
+    assert abs(float(gen._grad_sumsq.sqrt()) - gn) < 1e-4 * gn
+    for name, ref_p in zip(gen.store.names(), rbm_param_list(p)):
+        assert np.abs(gen.store[name].cpu().numpy().reshape(ref_p.shape) - ref_p).max() < 2e-4, name
+    out = m.generate(3)
+    assert out.shape == (B, 3, P, M) and out.dtype == torch.uint8
+
+
+def test_c2_joint_nade_global_metrics_divide_by_tracks():
+    """multinn_joint.py:159-186: the joint mode's encoder-level loss / NLL / perplexity are divided by the number of tracks; the
+    generator's own loss (statistical.py:34) is not."""
+    from multinn_amd import MultINN
+    B, T, P, M, Hn, units = 6, 5, 4, 3, 20, [32, 64]
+    x = batch(B, T, P, M, 1)
+    lengths = np.array([5, 2, 4, 5, 1, 3], np.int32)
+    m = MultINN(config(P, TRACKS5[:M]), params("joint", Hn=Hn, units=units), mode="joint", precision="fp32")
+    m.build(dev(x), dev(lengths), False, "eval")
+    gen = m.generators[0]
+    p = G.init_rnn_nade(3, P * M, P * M, Hn, units, np.float64)
+    load_nade_params(gen, p)
+    m.build(dev(x), dev(lengths), False, "eval")
+    inp, tgt = G.joint_inputs(x.astype(np.float64))
+    fw = G.rnn_nade_forward(inp, tgt, lengths, p, 1.0, None)
+    assert abs(float(m.generator_loss()) - fw['loss']) < 1e-4 * fw['loss']
+    hard = (fw['cond_p'][0] >= 0.5).astype(np.float64)
+    tflat = S.flatten_maybe_padded_sequences(tgt, lengths)
+    rows = log_loss_rows(tflat, hard)
+    glob = m.metrics
+    assert abs(float(glob["batch/loss"]) - rows.mean() / M) < 1e-5 * rows.mean()
+    assert abs(float(glob["log_likelihood"]) - rows.mean() / M) < 1e-5 * rows.mean()
+    assert abs(glob["accuracy"] - (hard == tflat).mean()) < 1e-6
+    assert float(m.loss) == float(glob["batch/loss"])
+    out = m.generate(2)
+    assert out.shape == (B, 2, P, M)
+    # the generic path (explicit encoder build / encode / slicing) gives the same numbers as the fused piano-roll kernel
+    m._fused = lambda: False
+    m.build(dev(x), dev(lengths), False, "eval")
+    assert abs(float(m.generator_loss()) - fw['loss']) < 1e-4 * fw['loss']
+    assert abs(float(m.metrics["batch/loss"]) - rows.mean() / M) < 1e-5 * rows.mean()
+
+
+def test_c3_jamming_five_lstm_rbm_cd10():
+    """BASELINE configs[2]: per-track LSTM-RBM generators (CD-10 Gibbs), 5 tracks; the optimised loss is the MEAN track loss with one
+    clip_by_global_norm over ALL generators' variables (multinn_jamming.py:186-245)."""
+    from multinn_amd import MultINN, AdamOptimizer
+    B, T, P, M, Hn, units, k = 4, 5, 12, 5, 16, [32, 32], 10
+    x = batch(B, T, P, M, 8)
+    m = MultINN(config(P, TRACKS5), params("jamming", gen="RBM", Hn=Hn, units=units), mode="jamming", precision="fp32")
+    assert [type(g).__name__ for g in m.generators] == ["RnnRBM"] * 5 and len({g.seed for g in m.generators}) == 5
+    m.build(dev(x), None, True, "train")
+    ps = [G.init_rnn_rbm(50 + i, P, P, Hn, units, np.float64) for i in range(M)]
+    for i, g in enumerate(m.generators):
+        ps[i]['bh'] += 0.05 * i
+        load_rbm_params(g, ps[i])
+    m.build(dev(x), None, True, "train")
+    tracks = G.per_track_inputs(x)                                       # multi_encoder_nn.py:66-76
+    rows = np.array([t * 65536 + b for b in range(B) for t in range(T)])
+    fws, grads, losses = [], [], []
+    for i, g in enumerate(m.generators):
+        assert g.grad_scale == 1.0 / M
+        inp, tgt = tracks[i][:, :-1].astype(np.float64), tracks[i][:, 1:].astype(np.float64)       # multinn_jamming.py:61-65
+        du = G.dropout_uniforms(g.seed, B, T, units)
+        fw = G.rnn_rbm_forward(inp, tgt, None, ps[i], k, seed=g.seed, keep_prob=0.9, drop_u=du, row_ids=rows)
+        vs = g._outputs.cpu().numpy()
+        assert (vs == fw['v_sample']).all(1).mean() >= 0.85
+        fw['v_sample'] = vs.astype(np.float64)
+        cost, F = orbm.free_energy_cost(fw['tgt'], fw['v_sample'], ps[i]['W'], fw['bh_t'], fw['bv_t'])
+        assert rel(g.free_energy.cpu().numpy(), F) < 1e-4
+        assert abs(float(g.metrics["batch/loss"]) - cost.mean()) < 1e-4 * max(1.0, abs(cost.mean()))
+        losses.append(cost.mean())
+        fws.append(fw)
+        grads.append(G.rnn_rbm_backward(fw, ps[i]))
+    assert abs(float(m.generator_loss()) - np.mean(losses)) < 1e-4 * max(1.0, abs(np.mean(losses)))
+    _, _, metrics, _, _ = m.train_generators(AdamOptimizer(0.01), 0.01)
+    assert abs(float(metrics["batch/loss"]) - np.mean(losses)) < 1e-4 * max(1.0, abs(np.mean(losses)))
+    # d(mean_i L_i)/d theta_i = g_i / M; ONE global norm over all five generators
+    all_p = [a for p in ps for a in rbm_param_list(p)]
+    all_g = [a / M for g in grads for a in rbm_grad_list(g)]
+    for i, g in enumerate(m.generators):
+        for name, ref in zip(g.store.names(), rbm_grad_list(grads[i])):
+            assert rel(g.store.gviews[name].cpu().numpy().reshape(ref.shape), ref / M) < 1e-4, (i, name)
+    gn = G.apply_clip_adam(all_p, all_g, G.new_opt(all_p), lr=0.01)
+    assert abs(float(m._grad_sumsq.sqrt()) - gn) < 1e-4 * gn
+    for i, g in enumerate(m.generators):
+        for name, ref in zip(g.store.names(), rbm_param_list(ps[i])):
+            assert np.abs(g.store[name].cpu().numpy().reshape(ref.shape) - ref).max() < 2e-4, (i, name)
+    glob = metrics["global"]
+    assert {"batch/loss", "log_likelihood", "accuracy"} <= set(glob.keys())
+    out = m.generate(3)
+    assert out.shape == (B, 3, P, M) and out.dtype == torch.uint8
+    with pytest.raises(ValueError):
+        m.train_generators(AdamOptimizer(0.01), 0.01, separate_losses=True)      # the track weight is applied in the forward pass
+
+
+def test_c4_composer_dbn_encoders_multinade():
+    """BASELINE configs[3]: per-track DBNEncoders -> stack on axis 3 -> [B,T+1,E*M] -> [:, :-1] / [:, 1:] -> RnnMultiNADE -> decode
+    (multinn_composer.py:73-87,114-151, multi_encoder_nn.py:66-115).  Codes are checked bit-exact against the deterministic checker,
+    the generator against the float64 oracle on those codes."""
+    from multinn_amd import MultINN, AdamOptimizer
+    B, T, P, M, Hn, units, E = 5, 4, 10, 5, 12, [32, 32], 6
+    x = batch(B, T, P, M, 4, rho=0.3)
+    m = MultINN(config(P, TRACKS5), params("composer", enc="DBN", enc_hidden=[8, E], Hn=Hn, units=units), mode="composer", precision="fp32")
+    gen = m.generators[0]
+    assert type(gen).__name__ == "RnnMultiNADE" and gen.num_dims == E and len(m.encoders) == 5
+    assert all(type(e).__name__ == "DBNEncoder" and e.dbn.rbms[0].k == 2 for e in m.encoders)
+    m.build(dev(x), None, True, "train")
+    p = G.init_rnn_nade(7, E * M, E, Hn, units, np.float64, tracks=M)
+    load_nade_params(gen, p)
+    m.build(dev(x), None, True, "train")
+    # encoders: sampled binary codes of the zero-padded per-track sequences (the padded step is encoded too)
+    tracks = G.per_track_inputs(x)
+    N1 = B * (T + 1)
+    codes = []
+    for i, e in enumerate(m.encoders):
+        h = tracks[i].reshape(N1, P)
+        for l, r in enumerate(e.dbn.rbms):
+            ph = det.rbm_hidden(h, r.W.cpu().numpy(), r.bh.cpu().numpy())
+            h = (philox.uniform_block(e.seed, philox.STREAM_DBN_ENC, np.arange(N1), (e._sub << 4) | l, ph.shape[1]) < ph).astype(np.uint8)
+        assert np.array_equal(e.encodings[-1].cpu().numpy().reshape(N1, E), h), i
+        codes.append(h.reshape(B, T + 1, E))
+    stack = np.stack(codes, axis=3).reshape(B, T + 1, E * M)             # multinn_composer.py:73-80: feature e*M+m
+    assert np.array_equal(m._x_encoded_stack.cpu().numpy(), stack)
+    inp, tgt = stack[:, :-1].astype(np.float64), stack[:, 1:].astype(np.float64)
+    du = G.dropout_uniforms(gen.seed, B, T, units)
+    fw = G.rnn_nade_forward(inp, tgt, None, p, 0.9, du, tracks=M)
+    g = G.rnn_nade_backward(fw, p, tracks=M)
+    assert abs(float(m.generator_loss()) - fw['loss']) < 1e-4 * fw['loss']
+    for t in range(M):
+        assert rel(gen.log_probs[t].cpu().numpy(), fw['nll'][t]) < 1e-4
+    # decode: hard generator outputs through each track's DBN, reconstruction cost against the raw targets
+    glob = m.metrics
+    hard = [(c >= 0.5).astype(np.uint8) for c in fw['cond_p']]
+    for t in range(M):
+        assert np.array_equal(m._x_hidden[t].cpu().numpy().astype(np.uint8), hard[t]), t
+        assert m._outputs_probs[t].shape == (B * T, P) and m._outputs[t].shape == (B * T, P)
+    assert {"batch/loss", "log_likelihood", "free_energy", "accuracy"} <= set(glob.keys())
+    _, _, metrics, _, _ = m.train_generators(AdamOptimizer(0.01), 0.01)
+    ref_g = []
+    for W, b in g['lstm']:
+        ref_g += [W, b]
+    ref_g += [np.stack(g['w_enc']), np.stack(g['w_dec']), g['fc_k'], g['fc_b']]
+    for name, ref in zip(gen.store.names(), ref_g):
+        assert rel(gen.store.gviews[name].cpu().numpy().reshape(ref.shape), ref) < 1e-4, name
+    assert float(metrics["global"]["batch/loss"]) == float(glob["batch/loss"])
+    out = m.generate(3)
+    assert out.shape == (B, 3, P, M) and out.dtype == torch.uint8 and torch.equal(out, m.generate(3))
+    # the encoders train through the mode too (multi_encoder_nn.py:155-195)
+    _, _, em, _, _ = m.train_encoders(None, 0.05, layer=1)
+    assert "batch/loss" in em and np.isfinite(float(em["batch/loss"]))
+
+
+def _feedback_model(P, M, Hn, units, fb_units, precision, B, Ti, seed=14):
+    from multinn_amd import MultINN
+    x = batch(B, Ti, P, M, seed, rho=0.3)
+    m = MultINN(config(P, TRACKS5[:M]), params("feedback-rnn", Hn=Hn, units=units, feedback=fb_units, keep_prob=0.9), mode="feedback-rnn",
+                precision=precision)
+    m.build(dev(x), None, False, "generate")
+    gparams = []
+    for i, g in enumerate(m.generators):
+        p = G.init_rnn_nade(60 + i, P + fb_units[-1], P, Hn, units, np.float64)
+        p['fc_b'][Hn:] = np.log(0.15 / 0.85)                        # piano-roll-like conditionals instead of coin flips
+        load_nade_params(g, p)
+        gparams.append(p)
+    fb = m._feedback_layer
+    fb_layers = [(fb.store[f"feedback/rnn/cell_{l}/kernel"].cpu().numpy().astype(np.float64),
+                  fb.store[f"feedback/rnn/cell_{l}/bias"].cpu().numpy().astype(np.float64)) for l in range(len(fb_units))]
+    return m, x, gparams, fb_layers, [g.seed for g in m.generators]
+
+
+def test_c5_feedback_rnn_mode_sampling_scan():
+    """BASELINE configs[4] through the mode class: intro pass, then per step M x NADE sample -> stack -> feedback LSTM step ->
+    M x {LSTM step on concat(sample_i, feedback) -> Dense} (multinn_feedback.py:120-218, multinn_feedback_rnn.py:41-79)."""
+    m, x, gparams, fb_layers, seeds = _feedback_model(8, 3, 16, [32, 32], [64, 32], "fp32", 4, 3)
+    steps = 6
+    out = m.generate(steps)
+    assert out.shape == (4, steps, 8, 3) and out.dtype == torch.uint8
+    got = out.cpu().numpy()
+    probs, us = G.feedback_rnn_teacher_forced(x, got, gparams, fb_layers, seeds)
+    bad = (us < probs) != (got > 0)
+    assert not (bad & (np.abs(us - probs) > 2e-5)).any()
+    ref, _ = G.feedback_rnn_generate(x, steps, gparams, fb_layers, seeds)
+    assert (ref == got).mean() > 0.99
+    assert torch.equal(out, m.generate(steps))
+    # eval build of the same mode: generator inputs = concat(track code, feedback vector)[:, :-1] (multinn_feedback.py:85-94)
+    m.build(dev(x), None, False, "eval")
+    enc = np.concatenate([np.zeros((4, 1, 8, 3)), x.astype(np.float64)], 1)
+    x_fb, _, _ = olstm.seq_fwd(enc.reshape(4, 4, 24), fb_layers)
+    for i, g in enumerate(m.generators):
+        inp = np.concatenate([enc[..., i], x_fb], -1)[:, :-1]
+        fw = G.rnn_nade_forward(inp, enc[..., i][:, 1:], None, gparams[i], 1.0, None)
+        assert abs(float(g.metrics["batch/loss"]) - fw['loss']) < 1e-4 * fw['loss'], i
+    with pytest.raises(NotImplementedError):
+        m.build(dev(x), None, True, "train")
+
+
+def test_c5_feedback_rnn_512_generated_steps():
+    """C5 at its real length and widths (default_feedback_rnn.yaml: generators [256,256], NADE 256, feedback LSTM [256,128], P = 88,
+    5 tracks): 512 generated steps in ONE captured scan (17.9 k graph nodes), every draw replayed teacher-forced by the float64
+    oracle (fp32 mode), and run-to-run reproducible; `sub` = the generated step in every RNG counter."""
+    P, M, B, Ti, steps = 88, 5, 4, 8, 512
+    m, x, gparams, fb_layers, seeds = _feedback_model(P, M, 256, [256, 256], [256, 128], "fp32", B, Ti, seed=21)
+    out = m.generate(steps)
+    assert out.shape == (B, steps, P, M)
+    got = out.cpu().numpy()
+    probs, us = G.feedback_rnn_teacher_forced(x, got, gparams, fb_layers, seeds)
+    bad = (us < probs) != (got > 0)
+    assert not (bad & (np.abs(us - probs) > 5e-5)).any(), int((bad & (np.abs(us - probs) > 5e-5)).sum())
+    dens = got.mean()
+    assert 0.01 < dens < 0.6, dens
+    late = got[:, 384:]
+    assert late.any() and not np.array_equal(got[:, 384:448], got[:, 448:512])      # still drawing new material at the end
+    assert torch.equal(out, m.generate(steps))
+    for g in m.generators:
+        g._stack.check()
+
+
+def test_c5_feedback_rnn_512_steps_bf16_reproducible():
+    """The benchmarked precision at the same length: two generate() calls give the same 512 x 5 x 88 draws, every step's draws differ
+    from the previous step's counters (no stale `sub`), and the persistent-launch status words stay clean."""
+    P, M, B, Ti, steps = 88, 5, 8, 8, 512
+    m, x, _, _, _ = _feedback_model(P, M, 256, [256, 256], [256, 128], "bf16", B, Ti, seed=22)
+    a = m.generate(steps)
+    b = m.generate(steps)
+    assert torch.equal(a, b) and a.shape == (B, steps, P, M)
+    got = a.cpu().numpy()
+    assert 0.01 < got.mean() < 0.6
+    same = [(got[:, s] == got[:, s - 1]).all() for s in range(1, steps)]
+    assert sum(same) < steps // 8
+    for g in m.generators:
+        g._stack.check()
+
+
+def test_rbm_visible_bias_init_and_rnn_rbm_pretrain():
+    """A17: visible_bias_init_ops (rbm.py:286-297) and RnnRBM.pretrain (rnn_rbm.py:299-322: one CD-k update of the RBM module on
+    the flattened inputs) against oracle/rbm.py."""
+    from multinn_amd import RnnRBM
+    B, T, D, Hn, units, k = 5, 6, 12, 10, [32, 32], 3
+    x = batch(B, T, D, 1, 11, rho=0.3)
+    inp, tgt = G.joint_inputs(x)
+    lengths = np.array([6, 3, 5, 6, 2], np.int32)
+    gen = RnnRBM(D, Hn, units, keep_prob=1.0, k=k, precision="fp32", seed=17)
+    gen.build(dev(inp), dev(tgt), dev(lengths), True, "train")
+    W0, bh0, bv0 = (gen._rbm.W.cpu().numpy().astype(np.float64), gen._rbm.bh.cpu().numpy().astype(np.float64),
+                    gen._rbm.bv.cpu().numpy().astype(np.float64))
+    flat = S.flatten_maybe_padded_sequences(inp, lengths).astype(np.float64)
+    N = flat.shape[0]
+    init_ops, update_ops, metrics, metrics_upd, summaries = gen.pretrain(None, 0.1)
+    assert update_ops == [] and len(init_ops) == 1 and "batch/loss" in metrics
+    rows = np.arange(N)
+    u_h, u_v = G.gibbs_uniforms(17, rows, k, Hn, D, 0)
+    u0 = philox.uniform_block(17, philox.STREAM_RBM_H, rows, k, Hn)
+    uk = philox.uniform_block(17, philox.STREAM_RBM_H, rows, k + 1, Hn)
+    dW, dbv, dbh = orbm.cd_update(flat, W0, bh0, bv0, k, 0.1, u_h, u_v, u0, uk)
+    gW, gbv, gbh = gen._cd_gradients
+    assert rel(gW.cpu().numpy(), dW) < 1e-4 and rel(gbv.cpu().numpy(), dbv) < 1e-4 and rel(gbh.cpu().numpy(), dbh) < 1e-4
+    assert rel(gen._rbm.W.cpu().numpy(), W0 + dW) < 1e-5 and rel(gen._rbm.bh.cpu().numpy(), bh0 + dbh) < 1e-5
+    assert np.abs(gen._rbm.bv.cpu().numpy() - (bv0 + dbv)).max() < 1e-6
+    # the init op is returned unexecuted (the reference runs init_ops once, train_encoders.py:150-153); running it assigns bv
+    init_ops[0]()
+    assert rel(gen._rbm.bv.cpu().numpy().reshape(-1), orbm.visible_bias_init(flat)) < 1e-5
+    pm = flat.mean(0)
+    assert np.allclose(gen._rbm.bv.cpu().numpy().reshape(-1), np.log(1e-6 + pm / (1 - pm)), rtol=1e-5, atol=1e-6)

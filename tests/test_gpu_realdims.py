@@ -1,0 +1,172 @@
+"""The BENCHMARKED configuration against the float64 oracle at its REAL widths (D = 440 visibles, 256 NADE hidden units, LSTM
+[512, 256]) -- not toy dims -- and a property test at the north-star shape [1024, 256, 88, 5].
+
+fp32 mode (the parity mode): loss, per-row NLL and every gradient within 1e-4 relative of oracle/generators.py.
+bf16 mode (the benchmarked one: persistent recurrence + matrix-core NADE forward, both asserted ON): its error against the same
+float64 oracle is printed and bounded (bf16 operands carry 8 significant bits)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import generators as G   # noqa: E402
+
+DEV = "cuda:0"
+P, M, HN, UNITS = 88, 5, 256, [512, 256]
+D = P * M
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(1e-30, np.abs(b).max())
+
+
+def cosine(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / max(1e-300, np.linalg.norm(a) * np.linalg.norm(b)))
+
+
+def synth(B, T, seed, rho):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return (rng.random((B, T, P, M)) < rho).astype(np.uint8)
+
+
+def load(gen, p):
+    s = gen.store
+    for l, (W, b) in enumerate(p['lstm']):
+        s[f"rnn/cell_{l}/kernel"].copy_(dev(W.astype(np.float32))); s[f"rnn/cell_{l}/bias"].copy_(dev(b.astype(np.float32)))
+    s["nade/w_enc"].copy_(dev(np.stack(p['w_enc']).astype(np.float32)))
+    s["nade/w_dec"].copy_(dev(np.stack(p['w_dec']).astype(np.float32)))
+    s["dense/kernel"].copy_(dev(p['fc_k'].astype(np.float32)))
+    s["dense/bias"].copy_(dev(p['fc_b'].astype(np.float32)))
+    gen._packed_step = -1
+
+
+def oracle_grads(g):
+    out = []
+    for W, b in g['lstm']:
+        out += [W, b]
+    return out + [np.stack(g['w_enc']), np.stack(g['w_dec']), g['fc_k'], g['fc_b']]
+
+
+_ORACLE = {}
+
+
+def oracle(B, T, rho):
+    """float64 forward + backward of the joint LSTM-NADE step at real widths (a few seconds), cached per input."""
+    key = (B, T, rho)
+    if key not in _ORACLE:
+        x = synth(B, T, 23, rho)
+        p = G.init_rnn_nade(23, D, D, HN, UNITS, np.float64)
+        for W, b in p['lstm']:
+            b += 0.05                                   # non-zero biases: a dropped bias add would otherwise be invisible
+        p['fc_b'] += 0.02
+        p['fc_b'][HN:] += np.log(max(rho, 1e-3) / (1 - min(rho, 0.999)))      # conditionals near the data density, as after training
+        inp, tgt = G.joint_inputs(x.astype(np.float64))
+        fw = G.rnn_nade_forward(inp, tgt, None, p, 0.9, G.dropout_uniforms(23, B, T, UNITS))
+        _ORACLE[key] = (x, p, fw, G.rnn_nade_backward(fw, p))
+    return _ORACLE[key]
+
+
+@pytest.mark.parametrize("rho", [0.03, 0.5])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_joint_lstm_nade_step_at_real_widths_vs_oracle(precision, rho):
+    from multinn_amd import RnnNade
+    B, T = 32, 8
+    x, p, fw, g = oracle(B, T, rho)
+    gen = RnnNade(D, HN, UNITS, keep_prob=0.9, precision=precision, seed=23)
+    gen._materialize(D)
+    load(gen, p)
+    gen.build_pianoroll(dev(x), None, is_train=True, mode="train")
+    if precision == "bf16":
+        assert gen._stack._persist(B, T) and gen._nade_mfma(), "the benchmarked kernels must be the ones under test"
+    loss = float(gen.metrics["batch/loss"])
+    nll = gen.log_probs.cpu().numpy()
+    gen.backward()
+    gen._stack.check()
+    errs = {"loss": abs(loss - fw['loss']) / abs(fw['loss']), "nll": rel(nll, fw['nll'][0])}
+    cosv = {}
+    for name, ref in zip(gen.store.names(), oracle_grads(g)):
+        got = gen.store.gviews[name].cpu().numpy().reshape(ref.shape)
+        errs[name] = rel(got, ref)
+        cosv[name] = cosine(got, ref)
+    print(f"\n[{precision} rho={rho}] relative error vs float64 oracle at D=440, Hn=256, [512,256], B={B}, T={T}:")
+    for k, v in errs.items():
+        print(f"    {k:24s} {v:.3e}" + (f"   cos {cosv[k]:.6f}" if k in cosv else ""))
+    if precision == "fp32":
+        assert all(v < 1e-4 for v in errs.values()), errs                  # BASELINE.json: 1e-4 relative
+    else:
+        assert errs["loss"] < 3e-3 and errs["nll"] < 2e-2, errs
+        assert all(v < 8e-2 for v in errs.values()), errs
+        assert all(c > 0.999 for c in cosv.values()), cosv
+    # eval build: conditionals against the oracle's
+    gen.build_pianoroll(dev(x), None, is_train=False, mode="eval")
+    cp = gen.cond_probs.cpu().numpy()
+    assert np.abs(cp - fw['cond_p'][0]).max() < (2e-5 if precision == "fp32" else 4e-2)
+
+
+def test_real_width_optimiser_step_fp32_vs_oracle():
+    """Clip 5.0 + TF-Adam on the oracle's gradients vs the device step at real widths: the UPDATE of every variable."""
+    from multinn_amd import RnnNade, AdamOptimizer
+    B, T = 32, 8
+    x, p, fw, g = oracle(B, T, 0.03)
+    gen = RnnNade(D, HN, UNITS, keep_prob=0.9, precision="fp32", seed=23)
+    gen._materialize(D)
+    load(gen, p)
+    before = {n: gen.store[n].clone() for n in gen.store.names()}
+    gen.train_step(dev(x), None, AdamOptimizer(0.01))
+    import copy
+    p2 = copy.deepcopy(p)
+    gn = G.apply_clip_adam(G.flat_params(p2), G.flat_grads(g), G.new_opt(G.flat_params(p2)), lr=0.01)
+    assert abs(float(gen._grad_sumsq.sqrt()) - gn) < 1e-4 * gn
+    ref_after = [a for pair in p2['lstm'] for a in pair] + [np.stack(p2['w_enc']), np.stack(p2['w_dec']), p2['fc_k'], p2['fc_b']]
+    ref_before = [a for pair in p['lstm'] for a in pair] + [np.stack(p['w_enc']), np.stack(p['w_dec']), p['fc_k'], p['fc_b']]
+    for name, ra, rb in zip(gen.store.names(), ref_after, ref_before):
+        upd = (gen.store[name] - before[name]).cpu().numpy().reshape(ra.shape)
+        # Adam's first step moves a weight by ~lr * g/(|g| + eps): compare the update where the gradient is not tiny against eps
+        assert np.abs(upd - (ra - rb)).max() < 2e-4, name
+
+
+def test_target_shape_train_step_properties():
+    """North-star shape [1024, 256, 88, 5] (BASELINE.json), bf16: the step runs on the persistent recurrence (four row tiles per
+    workgroup) and the matrix-core NADE forward; loss finite and in range, forward bit-deterministic, no persistent launch gave up,
+    gradients finite and aligned with the launch-per-step / f32-NADE kernels' on the same weights, and the captured step advances."""
+    from multinn_amd import RnnNade, AdamOptimizer
+    B, T = 1024, 256
+    x = dev(synth(B, T, 23, 0.03))
+    a = RnnNade(D, HN, UNITS, keep_prob=0.9, precision="bf16", seed=23)
+    a._materialize(D)
+    a.build_pianoroll(x, None, True, "train")
+    assert a._stack._persist(B, T) and a._nade_mfma()
+    la = float(a.metrics["batch/loss"])
+    assert np.isfinite(la) and 40 < la < 400, la
+    nll = a._nll_tm.clone()
+    a.backward()
+    a._stack.check()
+    ga = a.store.grad.clone()
+    assert bool(torch.isfinite(ga).all()) and float(ga.abs().max()) > 0
+    a.build_pianoroll(x, None, True, "train")
+    assert torch.equal(a._nll_tm, nll)                               # bit-deterministic forward at 262 144 rows
+    b = RnnNade(D, HN, UNITS, keep_prob=0.9, precision="bf16", seed=23)
+    b._materialize(D)
+    b.store.theta.copy_(a.store.theta)
+    b._stack.persistent = False
+    b.nade_mfma = False
+    b.build_pianoroll(x, None, True, "train")
+    lb = float(b.metrics["batch/loss"])
+    b.backward()
+    assert abs(la - lb) < 3e-3 * abs(lb), (la, lb)
+    cos = float(torch.nn.functional.cosine_similarity(ga, b.store.grad, dim=0))
+    assert cos > 0.999, cos
+    del b
+    torch.cuda.empty_cache()
+    opt = AdamOptimizer(0.01)
+    run = a.graphed_train_step(x, opt, warmup=1)
+    ls = [float(run()) for _ in range(3)]
+    a._stack.check()
+    assert all(np.isfinite(ls)) and ls[-1] < ls[0], ls
