@@ -94,11 +94,11 @@ def test_c1_joint_pass_lstm_rbm_one_track():
     m = MultINN(config(P, ["Piano"]), params("joint", gen="RBM", Hn=Hn, units=units), mode="joint", precision="fp32")
     gen = m.generators[0]
     assert type(gen).__name__ == "RnnRBM" and gen.k == 10 and gen.num_dims == P
-    m.build(dev(x), None, True, "train")
+    m.build(dev(x), lengths=None, is_train=True, mode="train")
     p = G.init_rnn_rbm(5, P, P, Hn, units, np.float64)
     p['bh'] += 0.1; p['bv'] -= 0.2
     load_rbm_params(gen, p)
-    m.build(dev(x), None, True, "train")
+    m.build(dev(x), lengths=None, is_train=True, mode="train")
     inp, tgt = G.joint_inputs(x)
     rows = np.array([t * 65536 + b for b in range(B) for t in range(T)])
     du = G.dropout_uniforms(gen.seed, B, T, units)
@@ -137,11 +137,11 @@ def test_c2_joint_nade_global_metrics_divide_by_tracks():
     x = batch(B, T, P, M, 1)
     lengths = np.array([5, 2, 4, 5, 1, 3], np.int32)
     m = MultINN(config(P, TRACKS5[:M]), params("joint", Hn=Hn, units=units), mode="joint", precision="fp32")
-    m.build(dev(x), dev(lengths), False, "eval")
+    m.build(dev(x), lengths=dev(lengths), is_train=False, mode="eval")
     gen = m.generators[0]
     p = G.init_rnn_nade(3, P * M, P * M, Hn, units, np.float64)
     load_nade_params(gen, p)
-    m.build(dev(x), dev(lengths), False, "eval")
+    m.build(dev(x), lengths=dev(lengths), is_train=False, mode="eval")
     inp, tgt = G.joint_inputs(x.astype(np.float64))
     fw = G.rnn_nade_forward(inp, tgt, lengths, p, 1.0, None)
     assert abs(float(m.generator_loss()) - fw['loss']) < 1e-4 * fw['loss']
@@ -157,7 +157,7 @@ def test_c2_joint_nade_global_metrics_divide_by_tracks():
     assert out.shape == (B, 2, P, M)
     # the generic path (explicit encoder build / encode / slicing) gives the same numbers as the fused piano-roll kernel
     m._fused = lambda: False
-    m.build(dev(x), dev(lengths), False, "eval")
+    m.build(dev(x), lengths=dev(lengths), is_train=False, mode="eval")
     assert abs(float(m.generator_loss()) - fw['loss']) < 1e-4 * fw['loss']
     assert abs(float(m.metrics["batch/loss"]) - rows.mean() / M) < 1e-5 * rows.mean()
 
@@ -170,12 +170,12 @@ def test_c3_jamming_five_lstm_rbm_cd10():
     x = batch(B, T, P, M, 8)
     m = MultINN(config(P, TRACKS5), params("jamming", gen="RBM", Hn=Hn, units=units), mode="jamming", precision="fp32")
     assert [type(g).__name__ for g in m.generators] == ["RnnRBM"] * 5 and len({g.seed for g in m.generators}) == 5
-    m.build(dev(x), None, True, "train")
+    m.build(dev(x), lengths=None, is_train=True, mode="train")
     ps = [G.init_rnn_rbm(50 + i, P, P, Hn, units, np.float64) for i in range(M)]
     for i, g in enumerate(m.generators):
         ps[i]['bh'] += 0.05 * i
         load_rbm_params(g, ps[i])
-    m.build(dev(x), None, True, "train")
+    m.build(dev(x), lengths=None, is_train=True, mode="train")
     tracks = G.per_track_inputs(x)                                       # multi_encoder_nn.py:66-76
     rows = np.array([t * 65536 + b for b in range(B) for t in range(T)])
     fws, grads, losses = [], [], []
@@ -226,10 +226,10 @@ def test_c4_composer_dbn_encoders_multinade():
     gen = m.generators[0]
     assert type(gen).__name__ == "RnnMultiNADE" and gen.num_dims == E and len(m.encoders) == 5
     assert all(type(e).__name__ == "DBNEncoder" and e.dbn.rbms[0].k == 2 for e in m.encoders)
-    m.build(dev(x), None, True, "train")
+    m.build(dev(x), lengths=None, is_train=True, mode="train")
     p = G.init_rnn_nade(7, E * M, E, Hn, units, np.float64, tracks=M)
     load_nade_params(gen, p)
-    m.build(dev(x), None, True, "train")
+    m.build(dev(x), lengths=None, is_train=True, mode="train")
     # encoders: sampled binary codes of the zero-padded per-track sequences (the padded step is encoded too)
     tracks = G.per_track_inputs(x)
     N1 = B * (T + 1)
@@ -277,7 +277,7 @@ def _feedback_model(P, M, Hn, units, fb_units, precision, B, Ti, seed=14):
     x = batch(B, Ti, P, M, seed, rho=0.3)
     m = MultINN(config(P, TRACKS5[:M]), params("feedback-rnn", Hn=Hn, units=units, feedback=fb_units, keep_prob=0.9), mode="feedback-rnn",
                 precision=precision)
-    m.build(dev(x), None, False, "generate")
+    m.build(dev(x), lengths=None, is_train=False, mode="generate")
     gparams = []
     for i, g in enumerate(m.generators):
         p = G.init_rnn_nade(60 + i, P + fb_units[-1], P, Hn, units, np.float64)
@@ -305,7 +305,7 @@ def test_c5_feedback_rnn_mode_sampling_scan():
     assert (ref == got).mean() > 0.99
     assert torch.equal(out, m.generate(steps))
     # eval build of the same mode: generator inputs = concat(track code, feedback vector)[:, :-1] (multinn_feedback.py:85-94)
-    m.build(dev(x), None, False, "eval")
+    m.build(dev(x), lengths=None, is_train=False, mode="eval")
     enc = np.concatenate([np.zeros((4, 1, 8, 3)), x.astype(np.float64)], 1)
     x_fb, _, _ = olstm.seq_fwd(enc.reshape(4, 4, 24), fb_layers)
     for i, g in enumerate(m.generators):
@@ -313,7 +313,7 @@ def test_c5_feedback_rnn_mode_sampling_scan():
         fw = G.rnn_nade_forward(inp, enc[..., i][:, 1:], None, gparams[i], 1.0, None)
         assert abs(float(g.metrics["batch/loss"]) - fw['loss']) < 1e-4 * fw['loss'], i
     with pytest.raises(NotImplementedError):
-        m.build(dev(x), None, True, "train")
+        m.build(dev(x), lengths=None, is_train=True, mode="train")
 
 
 def test_c5_feedback_rnn_512_generated_steps():

@@ -87,6 +87,7 @@ def test_joint_lstm_nade_step_at_real_widths_vs_oracle(precision, rho):
         assert gen._stack._persist(B, T) and gen._nade_mfma(), "the benchmarked kernels must be the ones under test"
     loss = float(gen.metrics["batch/loss"])
     nll = gen.log_probs.cpu().numpy()
+    cp = gen.cond_probs.cpu().numpy()                   # train-mode build: one more decoder pass over the saved Dense output
     gen.backward()
     gen._stack.check()
     errs = {"loss": abs(loss - fw['loss']) / abs(fw['loss']), "nll": rel(nll, fw['nll'][0])}
@@ -100,14 +101,13 @@ def test_joint_lstm_nade_step_at_real_widths_vs_oracle(precision, rho):
         print(f"    {k:24s} {v:.3e}" + (f"   cos {cosv[k]:.6f}" if k in cosv else ""))
     if precision == "fp32":
         assert all(v < 1e-4 for v in errs.values()), errs                  # BASELINE.json: 1e-4 relative
-    else:
-        assert errs["loss"] < 3e-3 and errs["nll"] < 2e-2, errs
-        assert all(v < 8e-2 for v in errs.values()), errs
-        assert all(c > 0.999 for c in cosv.values()), cosv
-    # eval build: conditionals against the oracle's
-    gen.build_pianoroll(dev(x), None, is_train=False, mode="eval")
-    cp = gen.cond_probs.cpu().numpy()
-    assert np.abs(cp - fw['cond_p'][0]).max() < (2e-5 if precision == "fp32" else 4e-2)
+    else:       # measured on MI355X (round 2): loss 6e-6, NLL 1.2e-4, gradients 4e-4 .. 4.3e-3, cosine >= 0.99999
+        assert errs["loss"] < 5e-4 and errs["nll"] < 2e-3, errs
+        assert all(v < 2e-2 for v in errs.values()), errs
+        assert all(c > 0.9999 for c in cosv.values()), cosv
+    cp_err = np.abs(cp - fw['cond_p'][0]).max()
+    print(f"    {'cond_probs (abs)':24s} {cp_err:.3e}")
+    assert cp_err < (2e-5 if precision == "fp32" else 2e-2)
 
 
 def test_real_width_optimiser_step_fp32_vs_oracle():
