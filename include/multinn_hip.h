@@ -187,6 +187,21 @@ int mnn_lstm2_persist_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer
                           void* workspace);
 int mnn_lstm2_persist_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L1, const mnn_lstm_bwd_layer* L2, float keep_prob,
                           void* workspace);
+/* Row-parallel persistent recurrence of ONE layer (multinn_amd/csrc/lstm_rowpar.hip), the form for B >= 512: a workgroup keeps its 32-unit
+ * slice of the recurrent weights in LDS, every WAVE owns one 32-row tile for the whole sequence (no K split, no workgroup barrier in the
+ * loop); the layers run as separate launches with the next layer's input projection (mnn_gemm_tn) between them.  Same layer descriptors as
+ * above, with: forward -- L->xproj GATE-MINOR f32 [T,B,4u] including the bias (mnn_lstm_rows_gate_minor), gates saved gate-minor, L->wx_t /
+ * bias_p unused, no initial state (h0 = c0 = NULL: a window starts from the zero state, train.py:165-173); backward -- L->dh_ext f32 [T,B,u]
+ * required (the gradient wrt the layer's output; with L->mask it is taken wrt the DROPPED output and dh_ext / keep_prob * mask is applied
+ * here), L->dz_T (optional) receives dz bf16 [T,B,4u] row-major in the gate-interleaved column order (the A operand of the input-gradient
+ * GEMM against wx_p), L->dzT_t / db_p as in the persistent form, L->workspace / wx_p / dz unused.  B must be a multiple of 32.
+ * workspace: mnn_lstm_rowpar_workspace_bytes(T,B,u) bytes, 256-byte aligned, zeroed ONCE at allocation; forward and backward calls of the
+ * same layer may share it.  mnn_lstm_rowpar_status: the sticky give-up word (non-zero: a bounded spin gave up, outputs are garbage). */
+int mnn_lstm_rowpar_ok(int B, int units);
+size_t mnn_lstm_rowpar_workspace_bytes(int T, int B, int units);
+int mnn_lstm_rowpar_status(const void* workspace, int* status);
+int mnn_lstm_rowpar_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L, float keep_prob, void* workspace);
+int mnn_lstm_rowpar_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L, float keep_prob, void* workspace);
 int mnn_dropout_mask(mnn_stream_t s, uint8_t* mask, int T, int B, int units, float keep_prob, uint64_t seed, const int32_t* step_dev,
                      uint32_t row0, int layer);
 
@@ -208,6 +223,18 @@ int mnn_nade_mfma_ok(int Hn);
 int mnn_nade_logprob_fwd_mfma(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride, const float* bias,
                               int ld_bias, const float* w_enc, const void* w_dec_bf16, const float* row_weight, float* nll, float* cond_p,
                               float* d_bias, float* a_final);
+/* Density-gated pair (bf16 compute mode, nade.py:155-229 unchanged): the matrix-core form's cost grows with the number of ACTIVE visibles
+ * (one hidden state per active visible and row), the f32 vector form's hardly does (MI355X, [1024,256,88,5]: 2.4 vs 3.6 ms at density 0.03,
+ * 19.7 vs 6.6 ms at 0.5).  mnn_density_gate counts the non-zero bytes of v ON THE DEVICE and writes gate[0] = (count > threshold) (count: a
+ * zeroed u32 scratch word, left zero); the two *_gated entries are then both launched and each returns at once unless gate[0] == run_if
+ * (gate NULL: always runs).  A captured step so takes the cheaper form at every replay, whatever batch it is fed. */
+int mnn_density_gate(mnn_stream_t s, const uint8_t* v, long n, long threshold, int* gate, unsigned* count);
+int mnn_nade_logprob_fwd_gated(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
+                               const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* row_weight,
+                               float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if);
+int mnn_nade_logprob_fwd_mfma_gated(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride, const float* bias,
+                                    int ld_bias, const float* w_enc, const void* w_dec_bf16, const float* row_weight, float* nll, float* cond_p,
+                                    float* d_bias, float* a_final, const int* gate, int run_if);
 
 /* ------------------------------------------------------------------------------------------
  * NADE (models/common/nade.py).  Weights w_enc,w_dec f32 [tracks,D,Hn].  Rows: v u8
@@ -231,6 +258,13 @@ int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const
 int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                          const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* a_final,
                          float* d_bias, float* d_w_enc, float* d_w_dec);
+/* The same backward with the weight-gradient sums over rows taken WITHOUT cross-workgroup atomics: every 64-row workgroup stores its
+ * partial d w_dec / d w_enc into its own slab of `workspace` (mnn_nade_logprob_bwd_workspace_bytes: cdiv(N,64) * tracks * 2 * D * Hn floats,
+ * 16-byte aligned; needs D * Hn % 4 == 0) and one pass sums the slabs into d_w_dec / d_w_enc (accumulating, as the atomic form does). */
+size_t mnn_nade_logprob_bwd_workspace_bytes(int tracks, int N, int D, int Hn);
+int mnn_nade_logprob_bwd_ws(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
+                            const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* a_final,
+                            float* d_bias, float* d_w_enc, float* d_w_dec, void* workspace, size_t workspace_bytes);
 int mnn_nade_sample(mnn_stream_t s, int tracks, int N, int D, int Hn, const float* bias, int ld_bias, const float* w_enc,
                     const float* w_dec, float temperature, uint64_t seed, uint32_t row0, uint32_t sub, uint8_t* samples,
                     long s_track_stride, int s_row_stride, int s_elem_stride, float* nll);

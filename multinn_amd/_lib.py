@@ -69,8 +69,18 @@ SIGNATURES["mnn_lstm2_persist_workspace_bytes"] = (_sz, [_i, _i, _i, _i])
 SIGNATURES["mnn_lstm2_persist_status"] = (_i, [_p, _i, _i, _i, C.POINTER(C.c_int)])
 SIGNATURES["mnn_lstm2_persist_fwd"] = (_i, [_p, _i, _i, C.POINTER(LstmFwdLayer), C.POINTER(LstmFwdLayer), _f, _p])
 SIGNATURES["mnn_lstm2_persist_bwd"] = (_i, [_p, _i, _i, C.POINTER(LstmBwdLayer), C.POINTER(LstmBwdLayer), _f, _p])
+SIGNATURES["mnn_lstm_rowpar_ok"] = (_i, [_i, _i])
+SIGNATURES["mnn_lstm_rowpar_workspace_bytes"] = (_sz, [_i, _i, _i])
+SIGNATURES["mnn_lstm_rowpar_status"] = (_i, [_p, C.POINTER(C.c_int)])
+SIGNATURES["mnn_lstm_rowpar_fwd"] = (_i, [_p, _i, _i, C.POINTER(LstmFwdLayer), _f, _p])
+SIGNATURES["mnn_lstm_rowpar_bwd"] = (_i, [_p, _i, _i, C.POINTER(LstmBwdLayer), _f, _p])
 SIGNATURES["mnn_nade_mfma_ok"] = (_i, [_i])
 SIGNATURES["mnn_nade_logprob_fwd_mfma"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p])
+SIGNATURES["mnn_nade_logprob_bwd_workspace_bytes"] = (_sz, [_i, _i, _i, _i])
+SIGNATURES["mnn_nade_logprob_bwd_ws"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _sz])
+SIGNATURES["mnn_density_gate"] = (_i, [_p, _p, _l, _l, _p, _p])
+SIGNATURES["mnn_nade_logprob_fwd_gated"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i])
+SIGNATURES["mnn_nade_logprob_fwd_mfma_gated"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i])
 SIGNATURES["mnn_musical_bar_stats"] = (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p])
 SIGNATURES["mnn_musical_note_stats"] = (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p])
 SIGNATURES["mnn_eval_counts"] = (_i, [_p, _p, _p, _l, _p])

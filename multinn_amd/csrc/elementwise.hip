@@ -789,3 +789,44 @@ extern "C" int mnn_probe_sigmoid(mnn_stream_t s, int blocks, int iters, float* o
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
+
+// ----------------------------------------------------------------------------------------------
+// Density gate: gate[0] = (number of non-zero bytes of v[0..n) > threshold) ? 1 : 0, decided ON THE DEVICE so that a captured step picks
+// per replay between the two forms of the NADE forward scan (matrix-core block-sparse form: cost grows with the number of active
+// visibles; f32 vector form: nearly flat) -- see mnn_nade_logprob_fwd_gated.  Two launches: count (one u32 atomic per workgroup),
+// decide.  count[0] must be zero on entry; the decide kernel re-zeroes it.
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) density_count_kernel(const uint8_t* __restrict__ v, long n, unsigned* __restrict__ count) {
+    unsigned acc = 0;
+    const long n16 = (((uintptr_t)v & 15) == 0) ? n / 16 : 0;
+    const uint4* v16 = reinterpret_cast<const uint4*>(v);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+        const uint4 q = v16[i];
+        // bytes are 0 / 1 piano-roll cells (any non-zero value counts once): fold each byte to its lowest bit, then popcount
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned x = w[k];
+            x |= x >> 4; x |= x >> 2; x |= x >> 1;
+            acc += __popc(x & 0x01010101u);
+        }
+    }
+    for (long i = n16 * 16 + blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += v[i] != 0;
+    __shared__ unsigned part[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(count, part[0] + part[1] + part[2] + part[3]);
+}
+__global__ void density_decide_kernel(unsigned* __restrict__ count, unsigned long long threshold, int* __restrict__ gate) {
+    gate[0] = (unsigned long long)count[0] > threshold ? 1 : 0;
+    count[0] = 0u;
+}
+extern "C" int mnn_density_gate(mnn_stream_t s, const uint8_t* v, long n, long threshold, int* gate, unsigned* count) {
+    MNN_REQUIRE(v && gate && count && n > 0 && threshold >= 0 && n < (1L << 32), "mnn_density_gate: bad arguments");
+    hipLaunchKernelGGL(density_count_kernel, dim3((int)min(1024L, (n + 4095) / 4096)), dim3(256), 0, (hipStream_t)s, v, n, count);
+    hipLaunchKernelGGL(density_decide_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, count, (unsigned long long)threshold, gate);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}

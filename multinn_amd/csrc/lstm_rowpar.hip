@@ -1,0 +1,484 @@
+// Row-parallel persistent LSTM recurrence for gfx950 (bf16 operands, f32 state): ONE launch runs all T steps of ONE layer.
+//
+// The two-layer persistent form of lstm_persist.hip splits K over the waves of a workgroup (weights in registers) and pays, per 32-row
+// item, a cross-wave reduction through LDS, three workgroup barriers and a poll: ~3.7 us whatever the item's height.  At B >= 512 a
+// workgroup walks several row tiles per timestep and that fixed cost is paid once per tile (TGT [1024,256,88,5]: 4 tiles -> 15.6 us per
+// timestep forward, 21.9 us backward, for 1.7 us of MFMA work).  Here the decomposition is turned round:
+//   * a workgroup owns one 32-unit tile (128 gate columns) of the layer and keeps that slice of the recurrent weights in LDS, stored in
+//     MFMA B-fragment order (one conflict-free 1-KiB ds_read_b128 per MFMA): 128 KiB for 512 units;
+//   * a WAVE owns one 32-row tile for the whole sequence and is an independent agent: it polls the progress flags of its row tile, pulls
+//     the previous step's state tile (A fragments, straight to registers), runs the full-K product for its 128 columns against the
+//     weights in LDS, does the gate pointwise IN REGISTERS (the four gates of a (row, unit) sit in the same lane: gate-interleaved
+//     columns), hands its h / dz tile on, and raises its own flag.  No K split, no cross-wave reduction, no workgroup barrier after
+//     the weights are loaded;
+//   * the layers run as separate launches (the input projection of the next layer is one large GEMM between them), which keeps K at
+//     the layer's own width: backward, 4U = 2048 columns of dz for 512 units fit LDS (128 KiB); the fused K = 4 U1 + 4 U2 does not.
+// Hand-off protocol: the one of lstm_persist.hip (cdna_hip_programming.md G16 R1; MI355X_MICROARCH.md "Valid forms", first table row)
+// with the workgroup replaced by the wave: 16-byte sc1 (write-through) stores of the tile in A-fragment order -> the storing wave's
+// `s_waitcnt vmcnt(0)` -> ONE sc1 flag store by that wave; the consumer wave polls the flags of its row tile with sc1 loads and only
+// then issues its sc1 loads of the tile.  Every spin is bounded and watches a status word; a give-up is sticky (mnn_lstm_rowpar_status).
+#include "common.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+#define RP_LIMIT 100000000LL       // spin bound: 1 s of wall_clock64() (100 MHz)
+#define RP_FLAGS_OFF 32            // words: [0] status, [1] sticky, [32 + 32 rt + member] progress flags
+#define RP_SC1 16                  // aux bit of raw buffer loads/stores: device scope (write-through / L1-bypassing)
+// The per-wave LDS tiles are written element-wise (bf16) and read back 16 bytes at a time by OTHER lanes of the same wave: the LDS serves a
+// wave's instructions in order, but the compiler must not move the differently-typed accesses across one another
+#define RP_LDS_FENCE() asm volatile("" ::: "memory")
+
+__device__ __forceinline__ unsigned rp_ld(const unsigned* p) { return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rp_st(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rp_rsrc(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// fragment row of C register k in lane half hh (v_mfma_f32_32x32x16_bf16): (k & 3) + 8 (k >> 2) + 4 hh
+__device__ __forceinline__ constexpr int rp_krow(int k) { return (k & 3) + 8 * (k >> 2); }
+
+// One wave waits until the first n words of `line` are all >= need; the other lanes watch the status word.  false: the launch is aborting.
+__device__ __forceinline__ bool rp_wait(const unsigned* line, unsigned* status, int n, unsigned need) {
+    const int lane = threadIdx.x & 63;
+    const bool mine = lane < n;
+    const unsigned* p = mine ? line + lane : status;
+    const long long t0 = wall_clock64();
+    for (unsigned spins = 1;; ++spins) {
+        const unsigned v = rp_ld(p);
+        if (__all(mine ? v >= need : v == 0u)) return true;
+        const bool dead = __any(!mine && v != 0u) || ((spins & 127u) == 0u && wall_clock64() - t0 > RP_LIMIT);
+        if (dead) {
+            if (lane == 0) { rp_st(status, 1u); rp_st(status + 1, 1u); }       // [1]: sticky, never re-zeroed by a launch
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+struct RFwdArgs {
+    const float* xproj; const bf16_t* wh_t; float* gates; float* c; bf16_t* h; bf16_t* y; const uint8_t* mask;
+    bf16_t* hT; int ld_hT; bf16_t* yT; int ld_yT;
+    char* hx; const char* hx0; unsigned* sync;
+    int T, B, nrt, G; float kp;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward:  z = xproj[t] (gate-minor, bias included) + h[t-1] . Wh^T ;  i,g,f,o ; c ; h
+// ------------------------------------------------------------------------------------------------------------------
+template <int U>
+__global__ void __launch_bounds__(256) lstm_rowpar_fwd_kernel(RFwdArgs A) {
+    constexpr int KS = U / 16;                      // k-steps of 16 over the recurrent width
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* wl = reinterpret_cast<uint4*>(smem);     // [gate][k-step][lane] 16-byte B fragments
+    const int grp = blockIdx.x % A.G, nt = blockIdx.x / A.G;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int T = A.T, B = A.B, nrt = A.nrt;
+    {   // this workgroup's 128 gate-interleaved rows of wh_t [4U, U] -> LDS, once
+        const int n0 = nt * 128;
+#pragma unroll 4
+        for (int i = 0; i < KS; ++i) {
+            const int e = i * 256 + (int)threadIdx.x;
+            const int g = e / (KS * 64), s = (e >> 6) % KS, ln = e & 63;
+            wl[e] = *reinterpret_cast<const uint4*>(A.wh_t + (size_t)(n0 + 32 * g + (ln & 31)) * U + 16 * s + 8 * (ln >> 5));
+        }
+    }
+    __syncthreads();
+    const int rt = grp + A.G * w;                   // this wave's row tile, for the whole sequence
+    if (rt >= nrt) return;
+    bf16_t (*sH)[40] = reinterpret_cast<bf16_t (*)[40]>(smem + (size_t)KS * 4096 + (size_t)w * 5120);          // tile [row][unit] (+pad)
+    bf16_t (*sT)[40] = reinterpret_cast<bf16_t (*)[40]>(smem + (size_t)KS * 4096 + (size_t)w * 5120 + 2560);   // tile [unit][row]
+    unsigned* status = A.sync;
+    unsigned* flags = A.sync + RP_FLAGS_OFF + rt * 32;
+    const int nb = U / 32, m0 = rt * 32, unit = nt * 32 + r;
+    const size_t us = (size_t)B * U, slab = (size_t)KS * 1024;
+    const bool drop = A.mask != nullptr;
+    // per-lane byte offsets inside the (t, row tile) block of each array; row of register k = rp_krow(k) + 4 hh
+    const unsigned og = (unsigned)((4 * hh) * 4 * U + unit * 4) * 4u;         // gates / xproj (gate-minor float4)
+    const unsigned oc = (unsigned)((4 * hh) * U + unit) * 4u;                 // c (float)
+    const unsigned om = (unsigned)((4 * hh) * U + unit);                      // keep mask (byte)
+    f32x16_t acc[4];
+    float creg[16];
+    unsigned mk[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { creg[k] = 0.f; mk[k] = 0u; }
+    auto prefetch = [&](int t) {     // xproj[t] straight into the accumulators (the MFMA chain then adds h . Wh^T), and the keep bytes
+        const char* xb = reinterpret_cast<const char*>(A.xproj + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og;
+        const uint8_t* mb = drop ? A.mask + (size_t)t * us + (size_t)m0 * U + om : nullptr;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float4 xv = *reinterpret_cast<const float4*>(xb + (size_t)rp_krow(k) * 16 * U);
+            acc[0][k] = xv.x; acc[1][k] = xv.y; acc[2][k] = xv.z; acc[3][k] = xv.w;
+            if (drop) mk[k] = mb[rp_krow(k) * U];
+        }
+    };
+    prefetch(0);
+    for (int t = 0; t < T; ++t) {
+        if (t > 0 && !rp_wait(flags, status, nb, (unsigned)t)) return;
+        bf16x8_t a[KS];
+        {
+            const __amdgpu_buffer_rsrc_t rs = rp_rsrc(t > 0 ? A.hx + ((size_t)(t - 1) * nrt + rt) * slab : A.hx0 + (size_t)rt * slab, slab);
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                a[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (s * 64 + lane) * 16, 0, RP_SC1));
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], __builtin_bit_cast(bf16x8_t, wl[(g * KS + s) * 64 + lane]), acc[g], 0, 0, 0);
+        // gate pointwise in registers; the activations replace the pre-activations in acc (they are what gets saved)
+        unsigned yb[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float gi = fast_sigmoid(acc[0][k]), gg = fast_tanh(acc[1][k]), gf = fast_sigmoid(acc[2][k]), go = fast_sigmoid(acc[3][k]);
+            const float cv = gg * gi + creg[k] * gf;
+            const float hv = fast_tanh(cv) * go;
+            acc[0][k] = gi; acc[1][k] = gg; acc[2][k] = gf; acc[3][k] = go;
+            creg[k] = cv;
+            const bf16_t hb = f32_to_bf16(hv);
+            const int lr = rp_krow(k) + 4 * hh;
+            sH[lr][r] = hb;
+            sT[r][lr] = hb;
+            yb[k] = drop ? (unsigned)f32_to_bf16(bf16_to_f32(hb) / A.kp * (float)mk[k]) : (unsigned)hb;
+        }
+        RP_LDS_FENCE();
+        {   // hand-off: k-steps 2 nt, 2 nt + 1 of the (t, row tile) slab, A-fragment order (row = lane & 31, 8 units per lane half)
+            const __amdgpu_buffer_rsrc_t rs = rp_rsrc(A.hx + ((size_t)t * nrt + rt) * slab, slab);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&sH[r][ks * 16 + hh * 8]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((2 * nt + ks) * 64 + lane) * 16, 0, RP_SC1);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's tile is out (and everything older)
+        if (lane == 0) rp_st(flags + nt, (unsigned)(t + 1));
+        // ---- off the chain: what the rest of the train step reads ----
+        if (A.gates != nullptr) {
+            char* gb = reinterpret_cast<char*>(A.gates + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                *reinterpret_cast<float4*>(gb + (size_t)rp_krow(k) * 16 * U) = make_float4(acc[0][k], acc[1][k], acc[2][k], acc[3][k]);
+        }
+        {
+            char* cb = reinterpret_cast<char*>(A.c + (size_t)t * us + (size_t)m0 * U) + oc;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) *reinterpret_cast<float*>(cb + (size_t)rp_krow(k) * 4 * U) = creg[k];
+        }
+        const int prow = lane >> 1, pp = (lane & 1) * 2;             // 32 rows x 4 pieces of 16 bytes: two pieces per lane
+        {
+            bf16_t* dst = A.h + (size_t)t * us + (size_t)(m0 + prow) * U + nt * 32 + pp * 8;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sH[prow][pp * 8]);
+            *reinterpret_cast<uint4*>(dst + 8) = *reinterpret_cast<const uint4*>(&sH[prow][pp * 8 + 8]);
+        }
+        if (A.hT != nullptr && t + 1 < T) {                          // hT[unit][(t+1) B + row]: the recurrent weight gradient's operand
+            bf16_t* dst = A.hT + (size_t)(nt * 32 + prow) * A.ld_hT + (size_t)(t + 1) * B + m0 + pp * 8;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sT[prow][pp * 8]);
+            *reinterpret_cast<uint4*>(dst + 8) = *reinterpret_cast<const uint4*>(&sT[prow][pp * 8 + 8]);
+        }
+        if (drop) {                                                   // the dropped output: the same two tiles again
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int lr = rp_krow(k) + 4 * hh;
+                sH[lr][r] = (bf16_t)yb[k];
+                sT[r][lr] = (bf16_t)yb[k];
+            }
+            RP_LDS_FENCE();
+            bf16_t* dst = A.y + (size_t)t * us + (size_t)(m0 + prow) * U + nt * 32 + pp * 8;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sH[prow][pp * 8]);
+            *reinterpret_cast<uint4*>(dst + 8) = *reinterpret_cast<const uint4*>(&sH[prow][pp * 8 + 8]);
+        }
+        if (A.yT != nullptr) {                                        // yT[unit][t B + row] (y, or h without dropout)
+            bf16_t* dst = A.yT + (size_t)(nt * 32 + prow) * A.ld_yT + (size_t)t * B + m0 + pp * 8;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sT[prow][pp * 8]);
+            *reinterpret_cast<uint4*>(dst + 8) = *reinterpret_cast<const uint4*>(&sT[prow][pp * 8 + 8]);
+        }
+        RP_LDS_FENCE();
+        if (t + 1 < T) prefetch(t + 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward:  dh = dh_ext[t] (/ kp * keep when a mask is given) + dz[t+1] . Wh ;  gate backward -> dz[t], dc
+// ------------------------------------------------------------------------------------------------------------------
+struct RBwdArgs {
+    const float* dh_ext; const bf16_t* wh_p; const float* gates; const float* c; const uint8_t* mask;
+    bf16_t* dzc; bf16_t* dzT; int ld_t; float* db_p;
+    char* dzx; const char* dzx0; unsigned* sync;
+    int T, B, nrt, G; float kp;
+};
+
+template <int U>
+__global__ void __launch_bounds__(256) lstm_rowpar_bwd_kernel(RBwdArgs A) {
+    constexpr int KS4 = U / 4;                      // k-steps of 16 over the 4U gate columns
+    constexpr int CH = KS4 < 32 ? KS4 : 32;         // k-steps per register chunk of the dz tile
+    constexpr int NCH = KS4 / CH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* wl = reinterpret_cast<uint4*>(smem);     // [k-step][lane] 16-byte B fragments of wh_p rows nt*32 .. nt*32+31
+    const int grp = blockIdx.x % A.G, nt = blockIdx.x / A.G;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int T = A.T, B = A.B, nrt = A.nrt;
+#pragma unroll 4
+    for (int i = 0; i < KS4 / 4; ++i) {
+        const int e = i * 256 + (int)threadIdx.x;
+        const int s = e >> 6, ln = e & 63;
+        wl[e] = *reinterpret_cast<const uint4*>(A.wh_p + (size_t)(nt * 32 + (ln & 31)) * 4 * U + 16 * s + 8 * (ln >> 5));
+    }
+    __syncthreads();
+    const int rt = grp + A.G * w;
+    if (rt >= nrt) return;
+    char* tile = smem + (size_t)KS4 * 1024 + (size_t)w * 10240;
+    bf16_t (*sZ)[136] = reinterpret_cast<bf16_t (*)[136]>(tile);               // dz tile [row][gate*32 + unit] (+pad): 8704 bytes
+    bf16_t (*sT)[32][40] = reinterpret_cast<bf16_t (*)[32][40]>(tile);         // dz tile [gate][unit][row]: 10240 bytes, AFTER sZ has been read
+    unsigned* status = A.sync;
+    unsigned* flags = A.sync + RP_FLAGS_OFF + rt * 32;
+    const int nb = U / 32, m0 = rt * 32, unit = nt * 32 + r;
+    const size_t us = (size_t)B * U, slab = (size_t)KS4 * 1024;
+    const bool drop = A.mask != nullptr;
+    const unsigned og = (unsigned)((4 * hh) * 4 * U + unit * 4) * 4u;
+    const unsigned oc = (unsigned)((4 * hh) * U + unit) * 4u;
+    const unsigned om = (unsigned)((4 * hh) * U + unit);
+    float dcreg[16], cnext[16], dbv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dcreg[k] = 0.f;
+    {   // c[T-1]: from then on an item's c is the previous item's c_prev
+        const char* cb = reinterpret_cast<const char*>(A.c + (size_t)(T - 1) * us + (size_t)m0 * U) + oc;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cnext[k] = *reinterpret_cast<const float*>(cb + (size_t)rp_krow(k) * 4 * U);
+    }
+    for (int kk = 0; kk < T; ++kk) {
+        const int t = T - 1 - kk;
+        // epilogue operands of (t, row tile): issued before the wait, consumed after the MFMA chain
+        float4 gv[16];
+        float cp[16], dhe[16];
+        unsigned mk[16];
+        {
+            const char* gb = reinterpret_cast<const char*>(A.gates + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og;
+            const char* pb = reinterpret_cast<const char*>(A.c + (size_t)(t > 0 ? t - 1 : 0) * us + (size_t)m0 * U) + oc;
+            const char* db = reinterpret_cast<const char*>(A.dh_ext + (size_t)t * us + (size_t)m0 * U) + oc;
+            const uint8_t* mb = drop ? A.mask + (size_t)t * us + (size_t)m0 * U + om : nullptr;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                gv[k] = *reinterpret_cast<const float4*>(gb + (size_t)rp_krow(k) * 16 * U);
+                cp[k] = *reinterpret_cast<const float*>(pb + (size_t)rp_krow(k) * 4 * U);
+                dhe[k] = *reinterpret_cast<const float*>(db + (size_t)rp_krow(k) * 4 * U);
+                mk[k] = drop ? (unsigned)mb[rp_krow(k) * U] : 1u;
+            }
+        }
+        if (kk > 0 && !rp_wait(flags, status, nb, (unsigned)kk)) return;
+        f32x16_t acc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        {
+            const __amdgpu_buffer_rsrc_t rs = rp_rsrc(kk > 0 ? A.dzx + ((size_t)(t + 1) * nrt + rt) * slab : A.dzx0 + (size_t)rt * slab, slab);
+            bf16x8_t a0[CH], a1[CH];
+#pragma unroll
+            for (int s = 0; s < CH; ++s) a0[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (s * 64 + lane) * 16, 0, RP_SC1));
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                if (ch + 1 < NCH) {             // the next chunk is in flight while this one feeds the MFMAs
+#pragma unroll
+                    for (int s = 0; s < CH; ++s) {
+                        const bf16x8_t v = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (((ch + 1) * CH + s) * 64 + lane) * 16, 0, RP_SC1));
+                        if ((ch & 1) == 0) a1[s] = v; else a0[s] = v;
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < CH; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16((ch & 1) == 0 ? a0[s] : a1[s],
+                                                                   __builtin_bit_cast(bf16x8_t, wl[(ch * CH + s) * 64 + lane]), acc, 0, 0, 0);
+            }
+        }
+        // gate backward in registers (rnn.py:124 LSTMBlockCell autodiff): dz = {d i, d g, d f, d o} pre-activation gradients
+        unsigned bvp[16][2];                     // the four bf16 values of a register row, packed (i | g << 16, f | o << 16)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float gi = gv[k].x, gg = gv[k].y, gf = gv[k].z, go = gv[k].w;
+            const float dh = (drop ? dhe[k] / A.kp * (float)mk[k] : dhe[k]) + acc[k];
+            const float tc = fast_tanh(cnext[k]);
+            const float d_o = dh * tc;
+            const float d_c = dh * go * (1.f - tc * tc) + dcreg[k];
+            const float cprev = t > 0 ? cp[k] : 0.f;
+            const float dzv[4] = {d_c * gg * gi * (1.f - gi), d_c * gi * (1.f - gg * gg), d_c * cprev * gf * (1.f - gf), d_o * go * (1.f - go)};
+            dcreg[k] = d_c * gf;
+            cnext[k] = cprev;
+            const int lr = rp_krow(k) + 4 * hh;
+            bf16_t b4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                b4[g] = f32_to_bf16(dzv[g]);
+                sZ[lr][32 * g + r] = b4[g];
+                dbv[g] += bf16_to_f32(b4[g]);             // the (bf16) values the weight-gradient GEMMs see
+            }
+            bvp[k][0] = (unsigned)b4[0] | ((unsigned)b4[1] << 16);
+            bvp[k][1] = (unsigned)b4[2] | ((unsigned)b4[3] << 16);
+        }
+        RP_LDS_FENCE();
+        {   // hand-off: k-steps 8 nt .. 8 nt + 7 of the (t, row tile) slab
+            const __amdgpu_buffer_rsrc_t rs = rp_rsrc(A.dzx + ((size_t)t * nrt + rt) * slab, slab);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&sZ[r][ks * 16 + hh * 8]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((8 * nt + ks) * 64 + lane) * 16, 0, RP_SC1);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) rp_st(flags + nt, (unsigned)(kk + 1));
+        // ---- off the chain ----
+        if (A.dzc != nullptr) {                  // row-major dz [t][row][4U] (gate-interleaved columns): the A operand of the input-gradient GEMM
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = j * 64 + lane, row = p >> 4, pc = p & 15;
+                *reinterpret_cast<uint4*>(A.dzc + ((size_t)t * B + m0 + row) * 4 * U + nt * 128 + pc * 8) = *reinterpret_cast<const uint4*>(&sZ[row][pc * 8]);
+            }
+        }
+        RP_LDS_FENCE();
+        if (A.dzT != nullptr) {                  // dzT[nt*128 + 32 g + unit][t B + row]: the K-contiguous operand of the weight-gradient GEMMs
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int lr = rp_krow(k) + 4 * hh;
+                sT[0][r][lr] = (bf16_t)(bvp[k][0] & 0xffffu); sT[1][r][lr] = (bf16_t)(bvp[k][0] >> 16);
+                sT[2][r][lr] = (bf16_t)(bvp[k][1] & 0xffffu); sT[3][r][lr] = (bf16_t)(bvp[k][1] >> 16);
+            }
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = j * 64 + lane, gu = p >> 2, piece = p & 3;
+                *reinterpret_cast<uint4*>(A.dzT + (size_t)(nt * 128 + gu) * A.ld_t + (size_t)t * B + m0 + piece * 8) =
+                    *reinterpret_cast<const uint4*>(&sT[gu >> 5][gu & 31][piece * 8]);
+            }
+        }
+        RP_LDS_FENCE();
+    }
+    if (A.db_p != nullptr) {                     // bias gradient: this wave's column sums over its rows and all steps
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float s2 = dbv[g] + __shfl_xor(dbv[g], 32);
+            if (hh == 0) atomicAdd(A.db_p + nt * 128 + 32 * g + r, s2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+static int rp_cu_count() {
+    static int n = -1;
+    if (n < 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+        n = p.multiProcessorCount;
+    }
+    return n;
+}
+static bool rp_units_ok(int u) { return u == 128 || u == 256 || u == 512; }
+// G row-tile groups x U/32 workgroups; every workgroup's waves own one row tile each (at most `maxw`): false when that does not cover B
+static bool rp_plan(int B, int U, bool bwd, int& nrt, int& G) {
+    if (!rp_units_ok(U) || B <= 0 || (B % 32) != 0) return false;
+    const int cus = rp_cu_count(), nb = U / 32;
+    if (cus < nb) return false;
+    nrt = B / 32;
+    G = cus / nb;
+    if (G > nrt) G = nrt;
+    const int tiles = (nrt + G - 1) / G;
+    const int maxw = (bwd && U == 512) ? 3 : 4;     // LDS: the backward tile buffers are 10 KiB per wave next to 128 KiB of weights
+    return tiles <= maxw;
+}
+static size_t rp_sync_bytes(int nrt) { return ((size_t)RP_FLAGS_OFF + 32 * (size_t)nrt) * sizeof(unsigned); }
+static size_t rp_edge_bytes(int nrt, int U) { return (size_t)nrt * (size_t)(U / 4) * 1024; }         // zero slabs standing for dz[T] (>= h[-1]'s)
+static size_t rp_xchg_off(int nrt, int U) { return (rp_sync_bytes(nrt) + rp_edge_bytes(nrt, U) + 255) / 256 * 256; }
+
+extern "C" int mnn_lstm_rowpar_ok(int B, int units) {
+    int nrt, G;
+    return (rp_plan(B, units, false, nrt, G) && rp_plan(B, units, true, nrt, G)) ? 1 : 0;
+}
+extern "C" size_t mnn_lstm_rowpar_workspace_bytes(int T, int B, int units) {
+    const size_t nrt = (size_t)((B + 31) / 32);
+    return rp_xchg_off((int)nrt, units) + (size_t)T * nrt * (size_t)(units / 4) * 1024;
+}
+extern "C" int mnn_lstm_rowpar_status(const void* workspace, int* status) {
+    MNN_REQUIRE(workspace && status, "mnn_lstm_rowpar_status: bad arguments");
+    unsigned v = 0;
+    MNN_HIP(hipMemcpy(&v, (const char*)workspace + sizeof(unsigned), sizeof(v), hipMemcpyDeviceToHost));
+    *status = (int)v;
+    return MNN_OK;
+}
+
+__global__ void rp_reset_kernel(unsigned* sync, int words) {          // progress words back to zero; [1] (sticky) is left alone
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x)
+        if (i != 1) sync[i] = 0u;
+}
+
+template <typename K, typename Arg>
+static hipError_t rp_launch(K kernel, bool& attr_set, int grid, size_t lds, hipStream_t st, const Arg& a) {
+    if (!attr_set) {                 // once per kernel (first call: an eager warm-up step, never under stream capture)
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+extern "C" int mnn_lstm_rowpar_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L, float keep_prob, void* workspace) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(L && workspace && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm_rowpar_fwd: bad arguments");
+    MNN_REQUIRE(((size_t)workspace & 255) == 0, "mnn_lstm_rowpar_fwd: workspace must be 256-byte aligned");
+    RFwdArgs a{};
+    const int U = L->units;
+    MNN_REQUIRE(rp_plan(B, U, false, a.nrt, a.G), "mnn_lstm_rowpar_fwd: units must be 128/256/512, B a multiple of 32 and the row tiles must fit the "
+                                                  "device's workgroups (B=%d u=%d)", B, U);
+    MNN_REQUIRE(L->xproj && L->wh_t && L->c && L->h, "mnn_lstm_rowpar_fwd: null pointer");
+    MNN_REQUIRE(L->h0 == nullptr && L->c0 == nullptr, "mnn_lstm_rowpar_fwd: an initial state is not supported by this form (zero state per window)");
+    MNN_REQUIRE(L->hT == nullptr || (L->ld_hT >= T * B && (L->ld_hT & 7) == 0), "mnn_lstm_rowpar_fwd: ld_hT too small / not a multiple of 8");
+    MNN_REQUIRE(L->yT == nullptr || (L->ld_yT >= T * B && (L->ld_yT & 7) == 0), "mnn_lstm_rowpar_fwd: ld_yT too small / not a multiple of 8");
+    MNN_REQUIRE((L->mask == nullptr) == (keep_prob >= 1.0f) && (L->mask == nullptr || L->y != nullptr),
+                "mnn_lstm_rowpar_fwd: a keep mask and a y buffer are needed exactly when keep_prob < 1");
+    a.xproj = L->xproj; a.wh_t = (const bf16_t*)L->wh_t; a.gates = L->gates; a.c = L->c; a.h = (bf16_t*)L->h; a.y = (bf16_t*)L->y; a.mask = L->mask;
+    a.hT = (bf16_t*)L->hT; a.ld_hT = L->ld_hT; a.yT = (bf16_t*)L->yT; a.ld_yT = L->ld_yT;
+    a.sync = (unsigned*)workspace; a.hx0 = (const char*)workspace + rp_sync_bytes(a.nrt); a.hx = (char*)workspace + rp_xchg_off(a.nrt, U);
+    a.T = T; a.B = B; a.kp = keep_prob;
+    hipLaunchKernelGGL(rp_reset_kernel, dim3(8), dim3(256), 0, st, (unsigned*)workspace, (int)(rp_sync_bytes(a.nrt) / sizeof(unsigned)));
+    MNN_HIP(mnn_zero_async((char*)workspace + rp_sync_bytes(a.nrt), rp_edge_bytes(a.nrt, U), st));
+    const int grid = a.G * (U / 32);
+    const size_t lds = (size_t)(U / 16) * 4096 + 4 * 5120;
+    static bool set512 = false, set256 = false, set128 = false;
+    hipError_t e;
+    if (U == 512) e = rp_launch(lstm_rowpar_fwd_kernel<512>, set512, grid, lds, st, a);
+    else if (U == 256) e = rp_launch(lstm_rowpar_fwd_kernel<256>, set256, grid, lds, st, a);
+    else e = rp_launch(lstm_rowpar_fwd_kernel<128>, set128, grid, lds, st, a);
+    MNN_HIP(e);
+    return MNN_OK;
+}
+
+extern "C" int mnn_lstm_rowpar_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L, float keep_prob, void* workspace) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(L && workspace && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm_rowpar_bwd: bad arguments");
+    MNN_REQUIRE(((size_t)workspace & 255) == 0, "mnn_lstm_rowpar_bwd: workspace must be 256-byte aligned");
+    RBwdArgs a{};
+    const int U = L->units;
+    MNN_REQUIRE(rp_plan(B, U, true, a.nrt, a.G), "mnn_lstm_rowpar_bwd: units must be 128/256/512, B a multiple of 32 and the row tiles must fit the "
+                                                 "device's workgroups (B=%d u=%d)", B, U);
+    MNN_REQUIRE(L->dh_ext && L->wh_p && L->gates && L->c, "mnn_lstm_rowpar_bwd: null pointer");
+    MNN_REQUIRE(L->c0 == nullptr && L->dz == nullptr, "mnn_lstm_rowpar_bwd: no initial state / f32 dz output in this form");
+    MNN_REQUIRE(L->dzT_t == nullptr || (L->ld_t >= T * B && (L->ld_t & 7) == 0), "mnn_lstm_rowpar_bwd: ld_t too small / not a multiple of 8");
+    a.dh_ext = L->dh_ext; a.wh_p = (const bf16_t*)L->wh_p; a.gates = L->gates; a.c = L->c; a.mask = L->mask;
+    a.dzc = (bf16_t*)L->dz_T; a.dzT = (bf16_t*)L->dzT_t; a.ld_t = L->ld_t; a.db_p = L->db_p;
+    a.sync = (unsigned*)workspace; a.dzx0 = (const char*)workspace + rp_sync_bytes(a.nrt); a.dzx = (char*)workspace + rp_xchg_off(a.nrt, U);
+    a.T = T; a.B = B; a.kp = keep_prob;
+    hipLaunchKernelGGL(rp_reset_kernel, dim3(8), dim3(256), 0, st, (unsigned*)workspace, (int)(rp_sync_bytes(a.nrt) / sizeof(unsigned)));
+    MNN_HIP(mnn_zero_async((char*)workspace + rp_sync_bytes(a.nrt), rp_edge_bytes(a.nrt, U), st));
+    const int grid = a.G * (U / 32);
+    const size_t lds = (size_t)(U / 4) * 1024 + (size_t)((U == 512) ? 3 : 4) * 10240;
+    static bool set512 = false, set256 = false, set128 = false;
+    hipError_t e;
+    if (U == 512) e = rp_launch(lstm_rowpar_bwd_kernel<512>, set512, grid, lds, st, a);
+    else if (U == 256) e = rp_launch(lstm_rowpar_bwd_kernel<256>, set256, grid, lds, st, a);
+    else e = rp_launch(lstm_rowpar_bwd_kernel<128>, set128, grid, lds, st, a);
+    MNN_HIP(e);
+    return MNN_OK;
+}

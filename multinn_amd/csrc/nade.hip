@@ -95,9 +95,11 @@ template <int HQ>
 __global__ void __launch_bounds__(512)
 nade_fwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias,
                 int ld_bias, const float* __restrict__ w_enc, const float* __restrict__ w_dec, const float* __restrict__ row_weight,
-                float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias, float* __restrict__ a_final) {
+                float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias, float* __restrict__ a_final,
+                const int* __restrict__ gate, int run_if) {
     constexpr int W = HQ * 64;
     __shared__ float wl[2][2][8 * W];            // [buffer][w_dec | w_enc][visible-in-chunk][hidden]
+    if (gate != nullptr && *gate != run_if) return;     // density-gated pair of launches (mnn_nade_logprob_fwd_gated): uniform exit
     const int m = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -200,6 +202,13 @@ nade_fwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
 extern "C" int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                     const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* row_weight,
                                     float* nll, float* cond_p, float* d_bias, float* a_final) {
+    return mnn_nade_logprob_fwd_gated(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec, row_weight, nll, cond_p, d_bias, a_final,
+                                      nullptr, 0);
+}
+
+extern "C" int mnn_nade_logprob_fwd_gated(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
+                                          const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* row_weight,
+                                          float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if) {
     MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn > 0 && Hn <= 256, "mnn_nade_logprob_fwd: need tracks,N,D>0 and 0<Hn<=256 (Hn=%d)", Hn);
     MNN_REQUIRE(v && bias && w_enc && w_dec, "mnn_nade_logprob_fwd: null pointer");
     MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_logprob_fwd: ld_bias %d < tracks*(Hn+D)", ld_bias);
@@ -207,7 +216,7 @@ extern "C" int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, in
     dim3 grid(cdiv(N, 64), tracks);
     hipStream_t st = (hipStream_t)s;
 #define FWD(HQ) hipLaunchKernelGGL(nade_fwd_kernel<HQ>, grid, dim3(512), 0, st, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, \
-                                   w_dec, row_weight, nll, cond_p, d_bias, a_final)
+                                   w_dec, row_weight, nll, cond_p, d_bias, a_final, gate, run_if)
     if (Hn <= 64) FWD(1);
     else if (Hn <= 128) FWD(2);
     else FWD(4);
@@ -255,7 +264,7 @@ template <int HQ>
 __global__ void __launch_bounds__(512)
 nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias,
                 int ld_bias, const float* __restrict__ w_enc, const float* __restrict__ w_dec, const float* __restrict__ a_final,
-                float* __restrict__ d_bias, float* __restrict__ d_w_enc, float* __restrict__ d_w_dec) {
+                float* __restrict__ d_bias, float* __restrict__ d_w_enc, float* __restrict__ d_w_dec, float* __restrict__ slab) {
     constexpr int W = HQ * 64;
     __shared__ __attribute__((aligned(16))) float wl[2][2][8 * W];
     __shared__ __attribute__((aligned(16))) float red[8][4][2][W];     // [wave][visible-in-half-chunk][d w_dec | d w_enc][hidden]: one exchange per 4 visibles
@@ -378,11 +387,23 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
                         sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
                     }
                     if (i < D) {
-                        float* dst = (which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * Hn + lane;
-                        if (lane < Hn) atomicAdd(dst, sum.x);
-                        if (lane + 64 < Hn) atomicAdd(dst + 64, sum.y);
-                        if (lane + 128 < Hn) atomicAdd(dst + 128, sum.z);
-                        if (lane + 192 < Hn) atomicAdd(dst + 192, sum.w);
+                        if (slab != nullptr) {
+                            // this workgroup's own partial-sum slab [workgroup][track][d w_dec | d w_enc][D][Hn]: plain stores (every (i < D, hidden)
+                            // word is written exactly once per workgroup), summed over the workgroups by nade_bwd_reduce_kernel.  The f32 atomics
+                            // of the other branch all land in the same 2 x D x Hn words from every 64-row workgroup: 3.7 GB of adds at TGT, at the
+                            // chip-wide ~1.3 TB/s atomic rate (MI355X_MICROARCH.md, Global float atomics)
+                            float* dst = slab + ((((size_t)blockIdx.x * tracks + m) * 2 + which) * D + i) * Hn + lane;
+                            if (lane < Hn) dst[0] = sum.x;
+                            if (lane + 64 < Hn) dst[64] = sum.y;
+                            if (lane + 128 < Hn) dst[128] = sum.z;
+                            if (lane + 192 < Hn) dst[192] = sum.w;
+                        } else {
+                            float* dst = (which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * Hn + lane;
+                            if (lane < Hn) atomicAdd(dst, sum.x);
+                            if (lane + 64 < Hn) atomicAdd(dst + 64, sum.y);
+                            if (lane + 128 < Hn) atomicAdd(dst + 128, sum.z);
+                            if (lane + 192 < Hn) atomicAdd(dst + 192, sum.w);
+                        }
                     }
                 }
             } else {
@@ -401,7 +422,8 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
                         float sum = 0.f;
 #pragma unroll
                         for (int ww = 0; ww < 8; ++ww) sum += red[ww][k][which][j];
-                        atomicAdd((which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * Hn + j, sum);
+                        if (slab != nullptr) slab[((((size_t)blockIdx.x * tracks + m) * 2 + which) * D + i) * Hn + j] = sum;
+                        else atomicAdd((which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * Hn + j, sum);
                     }
                 }
             }
@@ -423,21 +445,72 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
         }
 }
 
+// out[y][e] += sum over this z-slice's workgroup slabs of slab[b][y][e]   (y = track * 2 + {d w_dec, d w_enc}; e over D * Hn words, 16 bytes per
+// thread; the slices of z add with one f32 atomic per word -- 4 per word in all instead of one per 64 rows)
+__global__ void __launch_bounds__(256) nade_bwd_reduce_kernel(const float* __restrict__ slab, int nblk, int tracks, long dh, float* __restrict__ d_w_dec,
+                                                              float* __restrict__ d_w_enc) {
+    const long e4 = (long)blockIdx.x * 256 + threadIdx.x;                 // float4 index inside one [D, Hn] matrix
+    if (e4 * 4 >= dh) return;
+    const int y = blockIdx.y, m = y >> 1, which = y & 1;
+    const int per = (nblk + gridDim.z - 1) / gridDim.z, b0 = blockIdx.z * per, b1 = min(nblk, b0 + per);
+    const size_t stride = (size_t)tracks * 2 * dh;
+    const float* p = slab + (size_t)y * dh + e4 * 4;
+    float4 acc[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 q = *reinterpret_cast<const float4*>(p + (size_t)(b + u) * stride);
+            acc[u].x += q.x; acc[u].y += q.y; acc[u].z += q.z; acc[u].w += q.w;
+        }
+    }
+    for (; b < b1; ++b) {
+        const float4 q = *reinterpret_cast<const float4*>(p + (size_t)b * stride);
+        acc[0].x += q.x; acc[0].y += q.y; acc[0].z += q.z; acc[0].w += q.w;
+    }
+    float* out = (which == 0 ? d_w_dec : d_w_enc) + (size_t)m * dh + e4 * 4;
+    atomicAdd(out + 0, (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x));
+    atomicAdd(out + 1, (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y));
+    atomicAdd(out + 2, (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z));
+    atomicAdd(out + 3, (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w));
+}
+
+extern "C" size_t mnn_nade_logprob_bwd_workspace_bytes(int tracks, int N, int D, int Hn) {
+    if (tracks <= 0 || N <= 0 || D <= 0 || Hn <= 0 || ((long)D * Hn) % 4 != 0) return 0;
+    return (size_t)cdiv(N, 64) * tracks * 2 * D * Hn * sizeof(float);
+}
+
 extern "C" int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                     const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* a_final,
                                     float* d_bias, float* d_w_enc, float* d_w_dec) {
+    return mnn_nade_logprob_bwd_ws(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec, a_final, d_bias, d_w_enc, d_w_dec, nullptr, 0);
+}
+
+extern "C" int mnn_nade_logprob_bwd_ws(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
+                                       const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* a_final,
+                                       float* d_bias, float* d_w_enc, float* d_w_dec, void* workspace, size_t workspace_bytes) {
     MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn > 0 && Hn <= 256, "mnn_nade_logprob_bwd: need tracks,N,D>0 and 0<Hn<=256 (Hn=%d)", Hn);
     MNN_REQUIRE(v && bias && w_enc && w_dec && a_final && d_bias && d_w_enc && d_w_dec, "mnn_nade_logprob_bwd: null pointer");
     MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_logprob_bwd: ld_bias too small");
+    const size_t need = mnn_nade_logprob_bwd_workspace_bytes(tracks, N, D, Hn);
+    MNN_REQUIRE(workspace == nullptr || (need > 0 && workspace_bytes >= need && ((size_t)workspace & 15) == 0),
+                "mnn_nade_logprob_bwd_ws: workspace must be 16-byte aligned and hold mnn_nade_logprob_bwd_workspace_bytes() bytes (D*Hn %% 4 == 0)");
+    float* slab = (float*)workspace;
     dim3 grid(cdiv(N, 64), tracks);
     hipStream_t st = (hipStream_t)s;
 #define BWD(HQ) hipLaunchKernelGGL(nade_bwd_kernel<HQ>, grid, dim3(512), 0, st, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, \
-                                   w_dec, a_final, d_bias, d_w_enc, d_w_dec)
+                                   w_dec, a_final, d_bias, d_w_enc, d_w_dec, slab)
     if (Hn <= 64) BWD(1);
     else if (Hn <= 128) BWD(2);
     else BWD(4);
 #undef BWD
     MNN_LAUNCH_CHECK();
+    if (slab != nullptr) {
+        const long dh = (long)D * Hn;
+        const int nblk = cdiv(N, 64), split = nblk >= 64 ? 4 : 1;
+        hipLaunchKernelGGL(nade_bwd_reduce_kernel, dim3(cdiv(dh / 4, 256), tracks * 2, split), dim3(256), 0, st, slab, nblk, tracks, dh, d_w_dec, d_w_enc);
+        MNN_LAUNCH_CHECK();
+    }
     return MNN_OK;
 }
 

@@ -65,9 +65,11 @@ __device__ __forceinline__ void nm_load_a(const bf16_t (*tile)[NM_PITCH], int mi
 __global__ void __launch_bounds__(256)
 nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias, int ld_bias,
                      const float* __restrict__ w_enc, const bf16_t* __restrict__ w_dec_bf, const float* __restrict__ row_weight,
-                     float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias, float* __restrict__ a_final) {
+                     float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias, float* __restrict__ a_final,
+                     const int* __restrict__ gate, int run_if) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     NadeFwdSmem& S = *reinterpret_cast<NadeFwdSmem*>(smem_raw);
+    if (gate != nullptr && *gate != run_if) return;          // density-gated pair of launches: uniform exit
     constexpr int Hn = NM_H;
     const int m = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -318,6 +320,13 @@ extern "C" int mnn_nade_mfma_ok(int Hn) { return Hn == NM_H ? 1 : 0; }
 extern "C" int mnn_nade_logprob_fwd_mfma(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                          const float* bias, int ld_bias, const float* w_enc, const void* w_dec_bf16, const float* row_weight,
                                          float* nll, float* cond_p, float* d_bias, float* a_final) {
+    return mnn_nade_logprob_fwd_mfma_gated(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec_bf16, row_weight, nll, cond_p, d_bias,
+                                           a_final, nullptr, 0);
+}
+
+extern "C" int mnn_nade_logprob_fwd_mfma_gated(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
+                                               const float* bias, int ld_bias, const float* w_enc, const void* w_dec_bf16, const float* row_weight,
+                                               float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if) {
     MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn == NM_H, "mnn_nade_logprob_fwd_mfma: need tracks,N,D>0 and Hn == 256 (Hn=%d)", Hn);
     MNN_REQUIRE(v && bias && w_enc && w_dec_bf16, "mnn_nade_logprob_fwd_mfma: null pointer");
     MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_logprob_fwd_mfma: ld_bias %d < tracks*(Hn+D)", ld_bias);
@@ -329,7 +338,7 @@ extern "C" int mnn_nade_logprob_fwd_mfma(mnn_stream_t s, int tracks, int N, int 
     }
     dim3 grid(cdiv(N, 32), tracks);
     hipLaunchKernelGGL(nade_fwd_mfma_kernel, grid, dim3(256), sizeof(NadeFwdSmem), (hipStream_t)s, tracks, N, D, v, v_track_stride, bias, ld_bias,
-                       w_enc, (const bf16_t*)w_dec_bf16, row_weight, nll, cond_p, d_bias, a_final);
+                       w_enc, (const bf16_t*)w_dec_bf16, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

@@ -72,8 +72,9 @@ class LstmStack:
                      bias_p=torch.empty(4 * u, device=dev), n_in=n_in, u=u, ld=ld)
             ops.lstm_pack_weights(self.store[f"{self.rnn.prefix}/cell_{l}/kernel"], self.store[f"{self.rnn.prefix}/cell_{l}/bias"], n_in, u,
                                   p["wx_t"], p["wh_t"], p["wh_p"], p["wx_p"], p["bias_p"])
-            if l == 0 and self.dtype == torch.bfloat16 and len(self.rnn.num_units) == 2:
-                # the persistent recurrence reads layer 1's xproj gate-minor: the projection GEMM gets the rows in that order
+            if self.dtype == torch.bfloat16 and (l == 0 or self.rowpar):
+                # the persistent recurrences read xproj gate-minor: the projection GEMM gets the rows in that order (layer 1 of the two-layer
+                # form; every layer of the row-parallel form, whose layers each have their own projection GEMM)
                 p["wx_gm"], p["bias_gm"] = torch.empty_like(p["wx_t"]), torch.empty_like(p["bias_p"])
                 ops.lstm_rows_gate_minor(p["wx_t"], p["bias_p"], p["wx_gm"], p["bias_gm"])
             self.packed.append(p)
@@ -114,6 +115,88 @@ class LstmStack:
             return False
         return ops.lstm2_persist_ok(B, self.packed[0]["u"], self.packed[1]["u"])
 
+    # Row-parallel persistent form (lstm_rowpar.hip): one launch per LAYER for all T steps, weights in LDS, a wave per 32-row tile.  For
+    # large batches, where the two-layer form's fixed cost per 32-row item (K split over the waves, LDS reduction, workgroup barriers) is
+    # paid several times per timestep: TGT [1024,256,88,5] forward 15.6 us per timestep there.
+    rowpar = os.environ.get("MULTINN_ROWPAR", "1") != "0"
+    rowpar_min_batch = int(os.environ.get("MULTINN_ROWPAR_MIN_BATCH", "512"))
+
+    def _rowpar(self, B, T=2, state0=None):
+        if not (self.rowpar and self.dtype == torch.bfloat16 and state0 is None and T > 1 and B >= self.rowpar_min_batch and B % 32 == 0):
+            return False
+        return all("wx_gm" in p and ops.lstm_rowpar_ok(B, p["u"]) for p in self.packed)
+
+    def _rp_workspace(self, l, T, B, dev):
+        if not hasattr(self, "_rpws"):
+            self._rpws = {}
+        key = (l, T, B)
+        if key not in self._rpws:
+            self._rpws[key] = ops.lstm_rowpar_workspace(T, B, self.packed[l]["u"], dev)
+        return self._rpws[key]
+
+    def _forward_rowpar(self, x_tm, keep_prob, seed, row0, save, step_dev):
+        """Layer by layer: gate-minor input projection (one GEMM over all T*B rows), then the layer's whole recurrence in one launch."""
+        T, B, _ = x_tm.shape
+        dev, N = x_tm.device, T * B
+        Np = ops.round_up(N, 64)
+        zalloc = torch.zeros if Np != N else torch.empty
+        inp, ctx, final = x_tm, [], []
+        for l, p in enumerate(self.packed):
+            u = p["u"]
+            xproj = torch.empty((T, B, 4 * u), device=dev)
+            ops.gemm_tn(inp.view(N, -1), p["wx_gm"], xproj.view(N, -1), bias=p["bias_gm"])
+            h = torch.empty((T, B, u), device=dev, dtype=self.dtype)
+            mask = y = None
+            if keep_prob < 1.0:
+                mask = torch.empty((T, B, u), device=dev, dtype=torch.uint8)
+                ops.dropout_mask(mask, keep_prob, seed, row0, l, step_dev)
+                y = torch.empty_like(h)
+            gates = torch.empty((T, B, 4 * u), device=dev) if save else None
+            c = torch.empty((T, B, u), device=dev)
+            hT = yT = None
+            if save:
+                hT = torch.empty((u, Np), device=dev, dtype=self.dtype)
+                hT[:, :B].zero_()                      # h_{-1} = 0; columns [B, T*B) are written by the launch
+                if Np != N:
+                    hT[:, N:].zero_()
+                yT = zalloc((u, Np), device=dev, dtype=self.dtype)
+            d = ops.lstm2_fwd_layer(xproj, p["wh_t"], None, None, gates, c, h, hT, y, mask, yT=yT)
+            ops.lstm_rowpar_fwd(T, B, d, keep_prob, self._rp_workspace(l, T, B, dev))
+            out = y if y is not None else h
+            if save:
+                ctx.append(dict(inp=inp, gates=gates, c=c, h=h, c0=None, h0=None, hT=hT, mask=mask, yT=yT,
+                                inT=ctx[l - 1]["yT"] if l > 0 else None, persist=True, rowpar=True))
+            final.append((c[-1], h[-1]))
+            inp = out
+        return inp, ctx, final
+
+    def _backward_rowpar(self, dy, ctx, keep_prob):
+        """Top layer first: the layer's whole backward recurrence in one launch (dropout backward of its output folded in), then the
+        gradient wrt its input as one GEMM (dz row-major x Wx), which is the next layer's dh_ext."""
+        T, B, _ = dy.shape
+        dev, N = dy.device, T * B
+        Np = ops.round_up(N, 64)
+        zalloc = torch.zeros if Np != N else torch.empty
+        dh = dy.contiguous()
+        st = [None] * len(self.packed)
+        for l in range(len(self.packed) - 1, -1, -1):
+            p, cx = self.packed[l], ctx[l]
+            u = p["u"]
+            dzT = zalloc((4 * u, Np), device=dev, dtype=self.dtype)
+            dzc = torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype) if l > 0 else None
+            db_p = self._accum(l, dev)[2]
+            e = ops.lstm2_bwd_layer(dh.view(T, B, u), p["wh_p"], cx["gates"], cx["c"], None, dzc, ops.lstm_seq_bwd_workspace(B, u, dev), dzT, db_p,
+                                    cx["mask"] if keep_prob < 1.0 else None)
+            ops.lstm_rowpar_bwd(T, B, e, keep_prob, self._rp_workspace(l, T, B, dev))
+            st[l] = dict(dzT=dzT, db_p=db_p)
+            if l > 0:
+                dh = torch.empty((N, p["n_in"]), device=dev)
+                ops.gemm_tn(dzc.view(N, 4 * u), p["wx_p"], dh)
+        if getattr(self, "keep_debug", False):
+            self._dbg_dzT = [s_["dzT"] for s_ in st]
+        keep = [self._weight_grads(l, ctx[l], st[l]["dzT"], st[l]["db_p"], T, B) for l in range(len(self.packed) - 1, -1, -1)]
+        return None
+
     def _workspace(self, T, B, dev):
         """Flags + exchange area of the persistent launches, one per (T, B) (kept alive: captured graphs point at it)."""
         if not hasattr(self, "_pws"):
@@ -126,6 +209,8 @@ class LstmStack:
         """Raise if a persistent launch ever gave up waiting (synchronises the device)."""
         for (T, B), ws in getattr(self, "_pws", {}).items():
             ops.lstm2_persist_check(ws, B, self.packed[0]["u"], self.packed[1]["u"])
+        for ws in getattr(self, "_rpws", {}).values():
+            ops.lstm_rowpar_check(ws)
 
     @staticmethod
     def _chunks(T, step):
@@ -139,6 +224,8 @@ class LstmStack:
         T, B, _ = x_tm.shape
         dev = x_tm.device
         L = len(self.packed)
+        if self._rowpar(B, T, state0):
+            return self._forward_rowpar(x_tm, keep_prob, seed, row0, save, step_dev)
         persist = self._persist(B, T)
         bufs = []
         for l, p in enumerate(self.packed):
@@ -268,6 +355,8 @@ class LstmStack:
         each layer's weight-gradient GEMMs then run on that layer's stream."""
         if need_dx:
             raise NotImplementedError("gradient wrt the generator inputs (tune_encoder) is a 'next' row")
+        if ctx and ctx[0].get("rowpar"):
+            return self._backward_rowpar(dy, ctx, keep_prob)
         T, B, _ = dy.shape
         dev = dy.device
         L = len(self.packed)
@@ -612,6 +701,21 @@ class RnnNade(RnnEstimator):
 
     nade_mfma = os.environ.get("MULTINN_NADE_MFMA", "1") != "0"
 
+    # per-workgroup slabs + a reduction pass instead of f32 atomics for d w_enc / d w_dec: measured SLOWER on MI355X (TGT: 5.09 vs 3.99 ms --
+    # the atomics ride under the scan's VALU work, the slab stores + the 3.7 GB read-back do not), so it is opt-in (bit-reproducible sums)
+    nade_bwd_slabs = os.environ.get("MULTINN_NADE_BWD_SLABS", "0") != "0"
+
+    nade_dense_above = float(os.environ.get("MULTINN_NADE_DENSE_ABOVE", "0.07"))   # density above which the f32 scan replaces the matrix-core form
+
+    def _nade_fwd(self, v, out, rw, nll, cond_p, d_out, a_fin):
+        M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
+        if self.nade_dense_above >= 1.0:                 # gate off: always the matrix-core form
+            return ops.nade_logprob_fwd_mfma(v, out, self.store["nade/w_enc"], self._wdec_bf, M, D, Hn, rw, nll, cond_p, d_out, a_fin)
+        if getattr(self, "_gate", None) is None or self._gate.device != out.device:
+            self._gate = torch.zeros(2, device=out.device, dtype=torch.int32)            # [gate, count]
+        return ops.nade_logprob_fwd_auto(v, out, self.store["nade/w_enc"], self.store["nade/w_dec"], self._wdec_bf, M, D, Hn, self._gate[:1],
+                                         self._gate[1:], self.nade_dense_above, rw, nll, cond_p, d_out, a_fin)
+
     def _nade_mfma(self):
         """bf16 compute mode + a hidden width the matrix-core NADE kernels cover (the f32 VALU kernels remain the parity path)."""
         return self.nade_mfma and self.dtype == torch.bfloat16 and ops.nade_mfma_ok(self.num_hidden[-1])
@@ -683,9 +787,9 @@ class RnnNade(RnnEstimator):
         a_fin = torch.empty((M, N, Hn), device=dev) if train else None
         rw_g = rw_m if self.grad_scale == 1.0 else rw_m * self.grad_scale      # gradient seed only: the reported loss stays unscaled
         if self._nade_mfma():
-            # bf16 compute mode: the decoder dot products run as a block-sparse bf16 GEMM over each row's hidden states
-            ops.nade_logprob_fwd_mfma(v.view(M, N, D), out, self.store["nade/w_enc"], self._wdec_bf, M, D, Hn,
-                                      rw_g if train else None, nll, cond_p, d_out, a_fin)
+            # bf16 compute mode: the decoder dot products run as a block-sparse bf16 GEMM over each row's hidden states while the batch is
+            # piano-roll-sparse; a dense batch takes the f32 vector form (decided on the device, per launch: ops.nade_logprob_fwd_auto)
+            self._nade_fwd(v.view(M, N, D), out, rw_g if train else None, nll, cond_p, d_out, a_fin)
         else:
             ops.nade_logprob_fwd(v.view(M, N, D), out, self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn,
                                  rw_g if train else None, nll, cond_p, d_out, a_fin)
@@ -717,7 +821,7 @@ class RnnNade(RnnEstimator):
             N = cx["B"] * cx["T"]
             cp = torch.empty((M, N, D), device=cx["out"].device)
             if self._nade_mfma():
-                ops.nade_logprob_fwd_mfma(cx["v"].view(M, N, D), cx["out"], self.store["nade/w_enc"], self._wdec_bf, M, D, Hn, None, None, cp, None, None)
+                self._nade_fwd(cx["v"].view(M, N, D), cx["out"], None, None, cp, None, None)
             else:
                 ops.nade_logprob_fwd(cx["v"].view(M, N, D), cx["out"], self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn, None, None, cp, None,
                                      None)
@@ -746,8 +850,14 @@ class RnnNade(RnnEstimator):
         g = self.store.gviews
         self.store.grad.zero_()
         d_out = cx["d_out"]
+        # weight-gradient sums over rows through per-workgroup slabs + one reduction pass (no cross-workgroup f32 atomics) once there are
+        # enough 64-row workgroups for the atomics to be the bound (measured: from N = 4096 rows on)
+        ws = None
+        nb = ops.nade_bwd_workspace_bytes(M, N, D, Hn)
+        if self.nade_bwd_slabs and N >= 4096 and nb > 0:
+            ws = torch.empty(nb, device=dev, dtype=torch.uint8)
         ops.nade_logprob_bwd(cx["v"].view(M, N, D), cx["out"], self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn, cx["a_fin"],
-                             d_out, g["nade/w_enc"], g["nade/w_dec"])
+                             d_out, g["nade/w_enc"], g["nade/w_dec"], workspace=ws)
         # dense: dK[R,n_out] = y^T d_out ; db = sum d_out ; dy = d_out K^T
         Np = ops.round_up(N, 64)
         zalloc = torch.zeros if Np != N else torch.empty

@@ -309,6 +309,41 @@ def lstm2_persist_check(ws, B, u1, u2):
         raise _lib.MnnError("persistent LSTM launch timed out waiting for a neighbouring workgroup (grid not co-resident?)")
 
 
+def lstm_rowpar_ok(B, units):
+    """True when the row-parallel persistent recurrence (one layer per launch, weights in LDS, a wave per row tile) covers this shape."""
+    return bool(_lib.load().mnn_lstm_rowpar_ok(int(B), int(units)))
+
+
+def lstm_rowpar_workspace(T, B, units, device):
+    """Progress flags + exchange area of one layer's row-parallel launches (zeroed here, once; forward and backward share it)."""
+    return torch.zeros(_lib.load().mnn_lstm_rowpar_workspace_bytes(int(T), int(B), int(units)), dtype=torch.uint8, device=device)
+
+
+def _rp_ws_ok(ws, T, B, units):
+    _req(ws.dtype == torch.uint8 and ws.is_contiguous() and ws.data_ptr() % 256 == 0
+         and ws.numel() >= _lib.load().mnn_lstm_rowpar_workspace_bytes(int(T), int(B), int(units)),
+         "lstm rowpar: workspace must be the tensor of lstm_rowpar_workspace(T, B, units)")
+
+
+def lstm_rowpar_fwd(T, B, L, keep_prob, ws):
+    """L: descriptor of lstm2_fwd_layer (xproj gate-minor incl. bias; no h0 / c0)."""
+    _rp_ws_ok(ws, T, B, L.units)
+    call("mnn_lstm_rowpar_fwd", _stream(), T, B, C.byref(L), float(keep_prob), _ptr(ws))
+
+
+def lstm_rowpar_bwd(T, B, L, keep_prob, ws):
+    """L: descriptor of lstm2_bwd_layer (dh_ext required; dz_T = optional row-major bf16 dz for the input-gradient GEMM)."""
+    _rp_ws_ok(ws, T, B, L.units)
+    call("mnn_lstm_rowpar_bwd", _stream(), T, B, C.byref(L), float(keep_prob), _ptr(ws))
+
+
+def lstm_rowpar_check(ws):
+    st = C.c_int(0)
+    call("mnn_lstm_rowpar_status", _ptr(ws), C.byref(st))
+    if st.value != 0:
+        raise _lib.MnnError("row-parallel LSTM launch timed out waiting for a neighbouring wave (grid not co-resident?)")
+
+
 def dropout_mask(mask, keep_prob, seed, row0, layer, step_dev=None):
     T, B, u = mask.shape
     _req(mask.dtype == torch.uint8 and mask.is_contiguous() and u % 4 == 0 and 0 < keep_prob < 1, "dropout_mask: u8 [T,B,u], 0<kp<1")
@@ -386,13 +421,46 @@ def nade_logprob_fwd_mfma(v, bias, w_enc, w_dec_bf, tracks, D, Hn, row_weight=No
          _ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final))
 
 
-def nade_logprob_bwd(v, bias, w_enc, w_dec, tracks, D, Hn, a_final, d_bias, d_w_enc, d_w_dec):
+def nade_logprob_fwd_auto(v, bias, w_enc, w_dec, w_dec_bf, tracks, D, Hn, gate, count, dense_above=0.07, row_weight=None, nll=None,
+                          cond_p=None, d_bias=None, a_final=None):
+    """bf16 compute mode: the matrix-core form of the scan when at most `dense_above` of the cells of v are active, the f32 vector
+    form otherwise; decided on the device (mnn_density_gate), both launches issued (one returns at once).  gate int32[1], count: a zeroed
+    int32[1] scratch word (left zero)."""
+    N = bias.shape[0]
+    _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)
+    _req(w_dec_bf.dtype == torch.bfloat16 and w_dec_bf.is_contiguous() and w_dec_bf.numel() == tracks * D * Hn, "nade auto: w_dec_bf bf16 [tracks,D,Hn]")
+    _req(gate.dtype == torch.int32 and gate.numel() == 1 and count.dtype == torch.int32 and count.numel() == 1, "nade auto: gate / count int32[1]")
+    for t, n in ((nll, tracks * N), (cond_p, tracks * N * D), (a_final, tracks * N * Hn)):
+        _req(t is None or (t.dtype == torch.float32 and t.numel() == n and t.is_contiguous()), "nade auto: f32 outputs")
+    if d_bias is not None:
+        _req(row_weight is not None and d_bias.shape == bias.shape and d_bias.stride() == bias.stride() and d_bias.dtype == torch.float32,
+             "nade: d_bias must mirror bias and needs row_weight")
+    if row_weight is not None:
+        _req(row_weight.dtype == torch.float32 and row_weight.numel() == N, "nade: row_weight f32 [N]")
+    call("mnn_density_gate", _stream(), _ptr(v), v.numel(), int(dense_above * v.numel()), _ptr(gate), _ptr(count))
+    common = (tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc))
+    tail = (_ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final), _ptr(gate))
+    call("mnn_nade_logprob_fwd_mfma_gated", _stream(), *common, _ptr(w_dec_bf), *tail, 0)
+    call("mnn_nade_logprob_fwd_gated", _stream(), *common, _ptr(w_dec), *tail, 1)
+
+
+def nade_bwd_workspace_bytes(tracks, N, D, Hn):
+    return int(_lib.load().mnn_nade_logprob_bwd_workspace_bytes(int(tracks), int(N), int(D), int(Hn)))
+
+
+def nade_logprob_bwd(v, bias, w_enc, w_dec, tracks, D, Hn, a_final, d_bias, d_w_enc, d_w_dec, workspace=None):
     N = bias.shape[0]
     _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)
     _req(d_bias.shape == bias.shape and d_bias.stride() == bias.stride() and d_bias.dtype == torch.float32, "nade bwd: d_bias")
     for w in (d_w_enc, d_w_dec):
         _req(w.dtype == torch.float32 and w.is_contiguous() and w.numel() == tracks * D * Hn, "nade bwd: grad weights f32 [tracks,D,Hn]")
     _req(a_final.dtype == torch.float32 and a_final.numel() == tracks * N * Hn and a_final.is_contiguous(), "nade bwd: a_final f32 [tracks,N,Hn]")
+    if workspace is not None:
+        _req(workspace.dtype == torch.uint8 and workspace.is_contiguous() and workspace.numel() >= nade_bwd_workspace_bytes(tracks, N, D, Hn) > 0,
+             "nade bwd: workspace must be the tensor of nade_bwd_workspace(tracks, N, D, Hn)")
+        call("mnn_nade_logprob_bwd_ws", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
+             _ptr(a_final), _ptr(d_bias), _ptr(d_w_enc), _ptr(d_w_dec), _ptr(workspace), workspace.numel())
+        return
     call("mnn_nade_logprob_bwd", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
          _ptr(a_final), _ptr(d_bias), _ptr(d_w_enc), _ptr(d_w_dec))
 
