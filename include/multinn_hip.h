@@ -190,8 +190,9 @@ int mnn_lstm2_persist_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer
 /* Row-parallel persistent recurrence of ONE layer (multinn_amd/csrc/lstm_rowpar.hip), the form for B >= 512: a workgroup keeps its 32-unit
  * slice of the recurrent weights in LDS, every WAVE owns one 32-row tile for the whole sequence (no K split, no workgroup barrier in the
  * loop); the layers run as separate launches with the next layer's input projection (mnn_gemm_tn) between them.  Same layer descriptors as
- * above, with: forward -- L->xproj GATE-MINOR f32 [T,B,4u] including the bias (mnn_lstm_rows_gate_minor), gates saved gate-minor, L->wx_t /
- * bias_p unused, no initial state (h0 = c0 = NULL: a window starts from the zero state, train.py:165-173); backward -- L->dh_ext f32 [T,B,u]
+ * above, with: forward -- L->xproj GATE-MINOR f32 [T,B,4u] including the bias (mnn_lstm_rows_gate_minor); L->gates points at BF16 [T,B,4u]
+ * (gate-minor; half the bytes of the other forms' f32 copy: the saved activations only feed products that are rounded to bf16 anyway, and
+ * only mnn_lstm_rowpar_bwd reads them); L->wx_t / bias_p unused, no initial state (h0 = c0 = NULL: a window starts from the zero state, train.py:165-173); backward -- L->dh_ext f32 [T,B,u]
  * required (the gradient wrt the layer's output; with L->mask it is taken wrt the DROPPED output and dh_ext / keep_prob * mask is applied
  * here), L->dz_T (optional) receives dz bf16 [T,B,4u] row-major in the gate-interleaved column order (the A operand of the input-gradient
  * GEMM against wx_p), L->dzT_t / db_p as in the persistent form, L->workspace / wx_p / dz unused.  B must be a multiple of 32.

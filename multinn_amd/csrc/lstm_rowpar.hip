@@ -27,10 +27,23 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 
 #define RP_LIMIT 100000000LL       // spin bound: 1 s of wall_clock64() (100 MHz)
 #define RP_FLAGS_OFF 32            // words: [0] status, [1] sticky, [32 + 32 rt + member] progress flags
+#ifndef RP_RING
+#define RP_RING 3                  // backward: chunks of the dz tile in the register ring (8 KiB each)
+#endif
 #define RP_SC1 16                  // aux bit of raw buffer loads/stores: device scope (write-through / L1-bypassing)
 // The per-wave LDS tiles are written element-wise (bf16) and read back 16 bytes at a time by OTHER lanes of the same wave: the LDS serves a
 // wave's instructions in order, but the compiler must not move the differently-typed accesses across one another
 #define RP_LDS_FENCE() asm volatile("" ::: "memory")
+
+#ifdef RP_TRACE     // development only (profiles/tools/rowpar_trace.py): wall-clock stamps of one wave per kernel, [direction][step][stage]
+__device__ long long rp_trace[2][512][12];
+#define RP_TR(dir, cond, step, k) do { if ((cond) && (step) < 512 && (threadIdx.x & 63) == 0) rp_trace[dir][step][k] = wall_clock64(); } while (0)
+extern "C" int mnn_lstm_rowpar_trace(void* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rp_trace), sizeof(rp_trace)) == hipSuccess ? 0 : -2;
+}
+#else
+#define RP_TR(dir, cond, step, k) do { } while (0)
+#endif
 
 __device__ __forceinline__ unsigned rp_ld(const unsigned* p) { return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void rp_st(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -59,77 +72,174 @@ __device__ __forceinline__ bool rp_wait(const unsigned* line, unsigned* status, 
 }
 
 struct RFwdArgs {
-    const float* xproj; const bf16_t* wh_t; float* gates; float* c; bf16_t* h; bf16_t* y; const uint8_t* mask;
+    const float* xproj; const bf16_t* wh_t; bf16_t* gates; float* c; bf16_t* h; bf16_t* y; const uint8_t* mask;
     bf16_t* hT; int ld_hT; bf16_t* yT; int ld_yT;
     char* hx; const char* hx0; unsigned* sync;
-    int T, B, nrt, G; float kp;
+    int T, B, nrt, G, allow_local; float kp;
 };
+
+// Launch start: do the U/32 workgroups of this row-tile group share an XCD?  Each posts 0x100 | XCC_ID (device scope), wave 0 waits for the
+// others (bounded) and compares; the answer reaches the other waves through LDS at the barrier that follows the weight load.  It only
+// selects the store policy of the hand-offs (results never depend on it): on one XCD the tile and the flag are stored write-BACK -- they stay
+// in that XCD's L2, which the consumers' sc1 (L1-bypassing, L2-served) loads hit -- otherwise write-through (device scope).
+__device__ __forceinline__ void rp_probe_xcd(unsigned* xline, unsigned* status, int member, int nb, int* s_local) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) rp_st(xline + member, 0x100u | (xcc & 0xfu));
+    if (threadIdx.x < 64) {
+        bool same = false;
+        if (rp_wait(xline, status, nb, 1u)) {
+            const unsigned v = rp_ld(xline + (threadIdx.x < (unsigned)nb ? threadIdx.x : 0));
+            same = __all(v == __builtin_amdgcn_readfirstlane(v));
+        }
+        if (threadIdx.x == 0) *s_local = same ? 1 : 0;
+    }
+}
+__device__ __forceinline__ void rp_store_frag(const __amdgpu_buffer_rsrc_t rs, int f, int lane, u32x4_t v, bool local) {
+    if (local) __builtin_amdgcn_raw_buffer_store_b128(v, rs, (f * 64 + lane) * 16, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(v, rs, (f * 64 + lane) * 16, 0, RP_SC1);
+}
+__device__ __forceinline__ void rp_raise(unsigned* flag, unsigned value, bool local) {        // one lane, after the wave's vmcnt(0)
+    if (local) __hip_atomic_store((gu32*)flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // plain store: lands in the shared L2
+    else rp_st(flag, value);
+}
+
+// `s_waitcnt vmcnt(N)` with N a run-time count of the stores issued BEHIND the hand-off stores (loads, stores and atomics of a wave complete in
+// issue order: MI355X_MICROARCH.md, cycle constants): the hand-off tile is out, the younger row-major stores may still be in flight
+__device__ __forceinline__ void rp_wait_all_but(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+        case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+        case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+        case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+        case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+        case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
+        case 41: asm volatile("s_waitcnt vmcnt(41)" ::: "memory"); break;
+        case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
+        case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
+        case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+        case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+        case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // forward:  z = xproj[t] (gate-minor, bias included) + h[t-1] . Wh^T ;  i,g,f,o ; c ; h
+// One loop iteration of a wave:  wait for its row tile's flags | request the state tile (all k-steps at once) | xproj[t] into the accumulators |
+// MFMA chain, weights from LDS one k-step ahead | gate pointwise in registers | hand-off stores, then the row-major stores (gates, c, h, y,
+// h^T, y^T: 28 KB per tile) | wait for the hand-off stores only, raise the flag | request the next step's xproj and keep bytes.
 // ------------------------------------------------------------------------------------------------------------------
 template <int U>
-__global__ void __launch_bounds__(256) lstm_rowpar_fwd_kernel(RFwdArgs A) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_rowpar_fwd_kernel(RFwdArgs A) {
     constexpr int KS = U / 16;                      // k-steps of 16 over the recurrent width
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* wl = reinterpret_cast<uint4*>(smem);     // [gate][k-step][lane] 16-byte B fragments
+    int* s_local = reinterpret_cast<int*>(smem + (size_t)KS * 4096 + 4 * 5120);
     const int grp = blockIdx.x % A.G, nt = blockIdx.x / A.G;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int T = A.T, B = A.B, nrt = A.nrt;
-    {   // this workgroup's 128 gate-interleaved rows of wh_t [4U, U] -> LDS, once
+    const int nb = U / 32;
+    unsigned* status = A.sync;
+    rp_probe_xcd(A.sync + RP_FLAGS_OFF + 32 * nrt + 32 * grp, status, nt, nb, s_local);
+    const int rot = (2 * nt) & (KS - 1);           // rotation of this member's k-step order (speed only: the sum over k is taken in that order)
+    {   // this workgroup's 128 gate-interleaved rows of wh_t [4U, U] -> LDS, once, k-steps in the member's rotated order
         const int n0 = nt * 128;
 #pragma unroll 4
         for (int i = 0; i < KS; ++i) {
             const int e = i * 256 + (int)threadIdx.x;
             const int g = e / (KS * 64), s = (e >> 6) % KS, ln = e & 63;
-            wl[e] = *reinterpret_cast<const uint4*>(A.wh_t + (size_t)(n0 + 32 * g + (ln & 31)) * U + 16 * s + 8 * (ln >> 5));
+            wl[e] = *reinterpret_cast<const uint4*>(A.wh_t + (size_t)(n0 + 32 * g + (ln & 31)) * U + 16 * ((s + rot) & (KS - 1)) + 8 * (ln >> 5));
         }
     }
     __syncthreads();
+    const bool local = A.allow_local && *s_local != 0;
     const int rt = grp + A.G * w;                   // this wave's row tile, for the whole sequence
     if (rt >= nrt) return;
     bf16_t (*sH)[40] = reinterpret_cast<bf16_t (*)[40]>(smem + (size_t)KS * 4096 + (size_t)w * 5120);          // tile [row][unit] (+pad)
     bf16_t (*sT)[40] = reinterpret_cast<bf16_t (*)[40]>(smem + (size_t)KS * 4096 + (size_t)w * 5120 + 2560);   // tile [unit][row]
-    unsigned* status = A.sync;
     unsigned* flags = A.sync + RP_FLAGS_OFF + rt * 32;
-    const int nb = U / 32, m0 = rt * 32, unit = nt * 32 + r;
+    const int m0 = rt * 32, unit = nt * 32 + r;
     const size_t us = (size_t)B * U, slab = (size_t)KS * 1024;
     const bool drop = A.mask != nullptr;
+    const float ikp = 1.0f / A.kp;
     // per-lane byte offsets inside the (t, row tile) block of each array; row of register k = rp_krow(k) + 4 hh
     const unsigned og = (unsigned)((4 * hh) * 4 * U + unit * 4) * 4u;         // gates / xproj (gate-minor float4)
     const unsigned oc = (unsigned)((4 * hh) * U + unit) * 4u;                 // c (float)
     const unsigned om = (unsigned)((4 * hh) * U + unit);                      // keep mask (byte)
+    const int prow = lane >> 1, pp = (lane & 1) * 2;                          // tile stores: 32 rows x 4 pieces of 16 bytes, two pieces per lane
     f32x16_t acc[4];
+    float4 xv[16];                                  // the next step's xproj: requested behind the flag store, moved into acc behind the next wait
     float creg[16];
     unsigned mk[16];
+    uint4 mq = make_uint4(0u, 0u, 0u, 0u);          // the keep bytes of the next step: 16 of row (lane >> 1), units 16 (lane & 1) .. + 15
 #pragma unroll
     for (int k = 0; k < 16; ++k) { creg[k] = 0.f; mk[k] = 0u; }
-    auto prefetch = [&](int t) {     // xproj[t] straight into the accumulators (the MFMA chain then adds h . Wh^T), and the keep bytes
+    // xproj[t] and the keep bytes into VGPRs, nothing else: the accumulators live in AGPRs, and a copy there (v_accvgpr_write) needs the loaded
+    // value -- written here it made every request wait for its own HBM round trip (1.5 us per step in the stage trace).  The keep bytes
+    // come as ONE 16-byte load per lane and reach their (row, unit) lanes through the LDS tile at the top of the next item: a wave can
+    // have 63 vector-memory operations outstanding (vmcnt is 6 bits), and 40 stores + 16 + 16 loads made every request wait for stores
+    auto prefetch = [&](int t) {
         const char* xb = reinterpret_cast<const char*>(A.xproj + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og;
-        const uint8_t* mb = drop ? A.mask + (size_t)t * us + (size_t)m0 * U + om : nullptr;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float4 xv = *reinterpret_cast<const float4*>(xb + (size_t)rp_krow(k) * 16 * U);
-            acc[0][k] = xv.x; acc[1][k] = xv.y; acc[2][k] = xv.z; acc[3][k] = xv.w;
-            if (drop) mk[k] = mb[rp_krow(k) * U];
-        }
+        for (int k = 0; k < 16; ++k) xv[k] = *reinterpret_cast<const float4*>(xb + (size_t)rp_krow(k) * 16 * U);
+        if (drop) mq = *reinterpret_cast<const uint4*>(A.mask + (size_t)t * us + (size_t)(m0 + prow) * U + nt * 32 + (lane & 1) * 16);
     };
     prefetch(0);
+    const bool trc = nt == 0 && rt == 0;
     for (int t = 0; t < T; ++t) {
+        RP_TR(0, trc, t, 0);
         if (t > 0 && !rp_wait(flags, status, nb, (unsigned)t)) return;
+        RP_TR(0, trc, t, 1);
         bf16x8_t a[KS];
         {
             const __amdgpu_buffer_rsrc_t rs = rp_rsrc(t > 0 ? A.hx + ((size_t)(t - 1) * nrt + rt) * slab : A.hx0 + (size_t)rt * slab, slab);
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
-                a[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (s * 64 + lane) * 16, 0, RP_SC1));
+            for (int s = 0; s < KS; ++s)        // k-step s of this member is slab k-step (s + rot) % KS: the members of a row tile start at different lines
+                a[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ((((s + rot) & (KS - 1)) * 64 + lane) * 16), 0, RP_SC1));
         }
+        // all KS loads are in flight before anything else: left alone, the scheduler sinks every load next to its use and waits vmcnt(0) per MFMA
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
+        for (int k = 0; k < 16; ++k) { acc[0][k] = xv[k].x; acc[1][k] = xv[k].y; acc[2][k] = xv[k].z; acc[3][k] = xv[k].w; }   // z starts at xproj[t]
+        if (drop) {                                 // keep bytes: [row][32 units] through the (idle) h tile
+            uint8_t* mt = reinterpret_cast<uint8_t*>(&sH[0][0]);
+            RP_LDS_FENCE();
+            *reinterpret_cast<uint4*>(mt + prow * 32 + (lane & 1) * 16) = mq;
+            RP_LDS_FENCE();
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], __builtin_bit_cast(bf16x8_t, wl[(g * KS + s) * 64 + lane]), acc[g], 0, 0, 0);
+            for (int k = 0; k < 16; ++k) mk[k] = mt[(rp_krow(k) + 4 * hh) * 32 + r];
+            RP_LDS_FENCE();
+        }
+        // B fragments (weights in LDS) one k-step AHEAD of their MFMAs: an LDS read takes ~100 cycles to return, an MFMA issues every 32
+        bf16x8_t bq[2][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[0][g] = __builtin_bit_cast(bf16x8_t, wl[(g * KS + 0) * 64 + lane]);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bq[(s + 1) & 1][g] = __builtin_bit_cast(bf16x8_t, wl[(g * KS + s + 1) * 64 + lane]);
+            }
+            __builtin_amdgcn_sched_barrier(0);                        // ... and keep those reads in front of this k-step's MFMAs
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[s & 1][g], acc[g], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        RP_TR(0, trc, t, 2);
         // gate pointwise in registers; the activations replace the pre-activations in acc (they are what gets saved)
         unsigned yb[16];
 #pragma unroll
@@ -143,41 +253,42 @@ __global__ void __launch_bounds__(256) lstm_rowpar_fwd_kernel(RFwdArgs A) {
             const int lr = rp_krow(k) + 4 * hh;
             sH[lr][r] = hb;
             sT[r][lr] = hb;
-            yb[k] = drop ? (unsigned)f32_to_bf16(bf16_to_f32(hb) / A.kp * (float)mk[k]) : (unsigned)hb;
+            yb[k] = drop ? (unsigned)f32_to_bf16(bf16_to_f32(hb) * ikp * (float)mk[k]) : (unsigned)hb;
         }
         RP_LDS_FENCE();
+        RP_TR(0, trc, t, 3);
         {   // hand-off: k-steps 2 nt, 2 nt + 1 of the (t, row tile) slab, A-fragment order (row = lane & 31, 8 units per lane half)
             const __amdgpu_buffer_rsrc_t rs = rp_rsrc(A.hx + ((size_t)t * nrt + rt) * slab, slab);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&sH[r][ks * 16 + hh * 8]);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((2 * nt + ks) * 64 + lane) * 16, 0, RP_SC1);
+            for (int ks = 0; ks < 2; ++ks) rp_store_frag(rs, 2 * nt + ks, lane, *reinterpret_cast<const u32x4_t*>(&sH[r][ks * 16 + hh * 8]), local);
+        }
+        RP_TR(0, trc, t, 4);
+        // ---- issued BEHIND the hand-off stores, which alone the flag waits for: the next step's operands (first: they are needed soonest),
+        // then what the rest of the train step reads ----
+        int behind = 0;
+        if (t + 1 < T) { prefetch(t + 1); behind += drop ? 17 : 16; }
+        if (A.gates != nullptr) {                 // saved activations: bf16, gate-minor (8 bytes per (row, unit)) -- only mnn_lstm_rowpar_bwd reads them
+            char* gb = reinterpret_cast<char*>(A.gates + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og / 2;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                uint2 pk;
+                pk.x = (unsigned)f32_to_bf16(acc[0][k]) | ((unsigned)f32_to_bf16(acc[1][k]) << 16);
+                pk.y = (unsigned)f32_to_bf16(acc[2][k]) | ((unsigned)f32_to_bf16(acc[3][k]) << 16);
+                *reinterpret_cast<uint2*>(gb + (size_t)rp_krow(k) * 8 * U) = pk;
             }
+            behind += 16;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's tile is out (and everything older)
-        if (lane == 0) rp_st(flags + nt, (unsigned)(t + 1));
-        // ---- off the chain: what the rest of the train step reads ----
-        if (A.gates != nullptr) {
-            char* gb = reinterpret_cast<char*>(A.gates + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og;
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                *reinterpret_cast<float4*>(gb + (size_t)rp_krow(k) * 16 * U) = make_float4(acc[0][k], acc[1][k], acc[2][k], acc[3][k]);
-        }
-        {
-            char* cb = reinterpret_cast<char*>(A.c + (size_t)t * us + (size_t)m0 * U) + oc;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) *reinterpret_cast<float*>(cb + (size_t)rp_krow(k) * 4 * U) = creg[k];
-        }
-        const int prow = lane >> 1, pp = (lane & 1) * 2;             // 32 rows x 4 pieces of 16 bytes: two pieces per lane
         {
             bf16_t* dst = A.h + (size_t)t * us + (size_t)(m0 + prow) * U + nt * 32 + pp * 8;
             *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sH[prow][pp * 8]);
             *reinterpret_cast<uint4*>(dst + 8) = *reinterpret_cast<const uint4*>(&sH[prow][pp * 8 + 8]);
+            behind += 2;
         }
         if (A.hT != nullptr && t + 1 < T) {                          // hT[unit][(t+1) B + row]: the recurrent weight gradient's operand
             bf16_t* dst = A.hT + (size_t)(nt * 32 + prow) * A.ld_hT + (size_t)(t + 1) * B + m0 + pp * 8;
             *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sT[prow][pp * 8]);
             *reinterpret_cast<uint4*>(dst + 8) = *reinterpret_cast<const uint4*>(&sT[prow][pp * 8 + 8]);
+            behind += 2;
         }
         if (drop) {                                                   // the dropped output: the same two tiles again
             RP_LDS_FENCE();
@@ -191,14 +302,25 @@ __global__ void __launch_bounds__(256) lstm_rowpar_fwd_kernel(RFwdArgs A) {
             bf16_t* dst = A.y + (size_t)t * us + (size_t)(m0 + prow) * U + nt * 32 + pp * 8;
             *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sH[prow][pp * 8]);
             *reinterpret_cast<uint4*>(dst + 8) = *reinterpret_cast<const uint4*>(&sH[prow][pp * 8 + 8]);
+            behind += 2;
         }
         if (A.yT != nullptr) {                                        // yT[unit][t B + row] (y, or h without dropout)
             bf16_t* dst = A.yT + (size_t)(nt * 32 + prow) * A.ld_yT + (size_t)t * B + m0 + pp * 8;
             *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sT[prow][pp * 8]);
             *reinterpret_cast<uint4*>(dst + 8) = *reinterpret_cast<const uint4*>(&sT[prow][pp * 8 + 8]);
+            behind += 2;
         }
         RP_LDS_FENCE();
-        if (t + 1 < T) prefetch(t + 1);
+        RP_TR(0, trc, t, 5);
+        rp_wait_all_but(behind);                                      // the hand-off tile is out
+        if (lane == 0) rp_raise(flags + nt, (unsigned)(t + 1), local);
+        RP_TR(0, trc, t, 6);
+        {
+            char* cb = reinterpret_cast<char*>(A.c + (size_t)t * us + (size_t)m0 * U) + oc;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) *reinterpret_cast<float*>(cb + (size_t)rp_krow(k) * 4 * U) = creg[k];
+        }
+        RP_TR(0, trc, t, 7);
     }
 }
 
@@ -206,40 +328,47 @@ __global__ void __launch_bounds__(256) lstm_rowpar_fwd_kernel(RFwdArgs A) {
 // backward:  dh = dh_ext[t] (/ kp * keep when a mask is given) + dz[t+1] . Wh ;  gate backward -> dz[t], dc
 // ------------------------------------------------------------------------------------------------------------------
 struct RBwdArgs {
-    const float* dh_ext; const bf16_t* wh_p; const float* gates; const float* c; const uint8_t* mask;
+    const float* dh_ext; const bf16_t* wh_p; const bf16_t* gates; const float* c; const uint8_t* mask;
     bf16_t* dzc; bf16_t* dzT; int ld_t; float* db_p;
     char* dzx; const char* dzx0; unsigned* sync;
-    int T, B, nrt, G; float kp;
+    int T, B, nrt, G, allow_local; float kp;
 };
 
 template <int U>
-__global__ void __launch_bounds__(256) lstm_rowpar_bwd_kernel(RBwdArgs A) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_rowpar_bwd_kernel(RBwdArgs A) {
     constexpr int KS4 = U / 4;                      // k-steps of 16 over the 4U gate columns
-    constexpr int CH = KS4 < 32 ? KS4 : 32;         // k-steps per register chunk of the dz tile
+    constexpr int CH = 8;                           // k-steps per register chunk of the dz tile (ring of RP_RING chunks)
     constexpr int NCH = KS4 / CH;
+    constexpr int MAXW = U == 512 ? 3 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* wl = reinterpret_cast<uint4*>(smem);     // [k-step][lane] 16-byte B fragments of wh_p rows nt*32 .. nt*32+31
+    int* s_local = reinterpret_cast<int*>(smem + (size_t)KS4 * 1024 + (size_t)MAXW * 10240);
     const int grp = blockIdx.x % A.G, nt = blockIdx.x / A.G;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int T = A.T, B = A.B, nrt = A.nrt;
+    const int nb = U / 32;
+    unsigned* status = A.sync;
+    rp_probe_xcd(A.sync + RP_FLAGS_OFF + 32 * nrt + 32 * grp, status, nt, nb, s_local);
+    const int rot = (8 * nt) & (KS4 - 1);          // rotation of this member's k-step order, in whole chunks (speed only)
 #pragma unroll 4
     for (int i = 0; i < KS4 / 4; ++i) {
         const int e = i * 256 + (int)threadIdx.x;
         const int s = e >> 6, ln = e & 63;
-        wl[e] = *reinterpret_cast<const uint4*>(A.wh_p + (size_t)(nt * 32 + (ln & 31)) * 4 * U + 16 * s + 8 * (ln >> 5));
+        wl[e] = *reinterpret_cast<const uint4*>(A.wh_p + (size_t)(nt * 32 + (ln & 31)) * 4 * U + 16 * ((s + rot) & (KS4 - 1)) + 8 * (ln >> 5));
     }
     __syncthreads();
+    const bool local = A.allow_local && *s_local != 0;
     const int rt = grp + A.G * w;
     if (rt >= nrt) return;
     char* tile = smem + (size_t)KS4 * 1024 + (size_t)w * 10240;
     bf16_t (*sZ)[136] = reinterpret_cast<bf16_t (*)[136]>(tile);               // dz tile [row][gate*32 + unit] (+pad): 8704 bytes
     bf16_t (*sT)[32][40] = reinterpret_cast<bf16_t (*)[32][40]>(tile);         // dz tile [gate][unit][row]: 10240 bytes, AFTER sZ has been read
-    unsigned* status = A.sync;
     unsigned* flags = A.sync + RP_FLAGS_OFF + rt * 32;
-    const int nb = U / 32, m0 = rt * 32, unit = nt * 32 + r;
+    const int m0 = rt * 32, unit = nt * 32 + r;
     const size_t us = (size_t)B * U, slab = (size_t)KS4 * 1024;
     const bool drop = A.mask != nullptr;
+    const float ikp = 1.0f / A.kp;
     const unsigned og = (unsigned)((4 * hh) * 4 * U + unit * 4) * 4u;
     const unsigned oc = (unsigned)((4 * hh) * U + unit) * 4u;
     const unsigned om = (unsigned)((4 * hh) * U + unit);
@@ -251,55 +380,104 @@ __global__ void __launch_bounds__(256) lstm_rowpar_bwd_kernel(RBwdArgs A) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) cnext[k] = *reinterpret_cast<const float*>(cb + (size_t)rp_krow(k) * 4 * U);
     }
+    // epilogue operands of one (t, row tile): gates, c[t-1], the external gradient and the keep bytes.  Loaded one item AHEAD (issued
+    // right behind the flag store of the item before), so that they have landed when the hand-off of the next item arrives
+    // gates: one 16-byte load per (row, unit).  c[t-1], dh_ext and the keep bytes: whole 16-byte pieces of their 32 x 32 tiles (row lane >> 3
+    // + 8 j, units 4 (lane & 7) ..; keep bytes: row lane >> 1, units 16 (lane & 1) ..), 9 loads instead of 48 -- a wave can have 63 vector-memory
+    // operations outstanding (vmcnt is 6 bits) and 16 stores + 64 loads made every request wait for the stores; the pieces reach their (row, unit)
+    // lanes through the (idle) tile buffer at the top of the next item
+    uint2 gv[16];                                   // saved gate activations, bf16 x 4 (i | g << 16, f | o << 16)
+    float4 cq[4], dq[4];
+    uint4 mq = make_uint4(0u, 0u, 0u, 0u);
+    float cp[16];
+    const int srow = lane >> 3, spc = lane & 7, prow = lane >> 1;
+    auto prefetch = [&](int t) {
+        const float* pb = A.c + (size_t)(t > 0 ? t - 1 : 0) * us + (size_t)(m0 + srow) * U + nt * 32 + spc * 4;
+        const float* db = A.dh_ext + (size_t)t * us + (size_t)(m0 + srow) * U + nt * 32 + spc * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cq[j] = *reinterpret_cast<const float4*>(pb + (size_t)(8 * j) * U);
+            dq[j] = *reinterpret_cast<const float4*>(db + (size_t)(8 * j) * U);
+        }
+        if (drop) mq = *reinterpret_cast<const uint4*>(A.mask + (size_t)t * us + (size_t)(m0 + prow) * U + nt * 32 + (lane & 1) * 16);
+        const char* gb = reinterpret_cast<const char*>(A.gates + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og / 2;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) gv[k] = *reinterpret_cast<const uint2*>(gb + (size_t)rp_krow(k) * 8 * U);
+    };
+    prefetch(T - 1);
+    const bool trc = nt == 0 && rt == 0;
     for (int kk = 0; kk < T; ++kk) {
         const int t = T - 1 - kk;
-        // epilogue operands of (t, row tile): issued before the wait, consumed after the MFMA chain
-        float4 gv[16];
-        float cp[16], dhe[16];
-        unsigned mk[16];
-        {
-            const char* gb = reinterpret_cast<const char*>(A.gates + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og;
-            const char* pb = reinterpret_cast<const char*>(A.c + (size_t)(t > 0 ? t - 1 : 0) * us + (size_t)m0 * U) + oc;
-            const char* db = reinterpret_cast<const char*>(A.dh_ext + (size_t)t * us + (size_t)m0 * U) + oc;
-            const uint8_t* mb = drop ? A.mask + (size_t)t * us + (size_t)m0 * U + om : nullptr;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                gv[k] = *reinterpret_cast<const float4*>(gb + (size_t)rp_krow(k) * 16 * U);
-                cp[k] = *reinterpret_cast<const float*>(pb + (size_t)rp_krow(k) * 4 * U);
-                dhe[k] = *reinterpret_cast<const float*>(db + (size_t)rp_krow(k) * 4 * U);
-                mk[k] = drop ? (unsigned)mb[rp_krow(k) * U] : 1u;
-            }
-        }
+        RP_TR(1, trc, kk, 0);
         if (kk > 0 && !rp_wait(flags, status, nb, (unsigned)kk)) return;
+        RP_TR(1, trc, kk, 1);
         f32x16_t acc;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
         {
             const __amdgpu_buffer_rsrc_t rs = rp_rsrc(kk > 0 ? A.dzx + ((size_t)(t + 1) * nrt + rt) * slab : A.dzx0 + (size_t)rt * slab, slab);
-            bf16x8_t a0[CH], a1[CH];
-#pragma unroll
-            for (int s = 0; s < CH; ++s) a0[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (s * 64 + lane) * 16, 0, RP_SC1));
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                if (ch + 1 < NCH) {             // the next chunk is in flight while this one feeds the MFMAs
-#pragma unroll
-                    for (int s = 0; s < CH; ++s) {
-                        const bf16x8_t v = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (((ch + 1) * CH + s) * 64 + lane) * 16, 0, RP_SC1));
-                        if ((ch & 1) == 0) a1[s] = v; else a0[s] = v;
-                    }
-                }
+            bf16x8_t a[RP_RING][CH];            // ring of chunks of eight k-steps (8 KiB each), all but one in flight
+            auto issue = [&](int ch) {
 #pragma unroll
                 for (int s = 0; s < CH; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16((ch & 1) == 0 ? a0[s] : a1[s],
-                                                                   __builtin_bit_cast(bf16x8_t, wl[(ch * CH + s) * 64 + lane]), acc, 0, 0, 0);
+                    a[ch % RP_RING][s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ((((ch * CH + s + rot) & (KS4 - 1)) * 64 + lane) * 16), 0, RP_SC1));
+            };
+#pragma unroll
+            for (int ch = 0; ch < RP_RING - 1 && ch < NCH; ++ch) issue(ch);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+            // B fragments (weights in LDS) one chunk-half (four k-steps) AHEAD of their MFMAs
+            bf16x8_t bq[2][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[0][q] = __builtin_bit_cast(bf16x8_t, wl[q * 64 + lane]);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                if (ch + RP_RING - 1 < NCH) issue(ch + RP_RING - 1);     // the rest of the ring is in flight while this chunk feeds the MFMAs
+                __builtin_amdgcn_sched_barrier(0);           // (left alone, the scheduler sinks each load to its use and waits per MFMA)
+#pragma unroll
+                for (int s4 = 0; s4 < CH / 4; ++s4) {
+                    const int f4 = ch * (CH / 4) + s4;       // flattened group of four k-steps
+                    if (f4 + 1 < KS4 / 4) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bq[(f4 + 1) & 1][q] = __builtin_bit_cast(bf16x8_t, wl[((f4 + 1) * 4 + q) * 64 + lane]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ch % RP_RING][s4 * 4 + q], bq[f4 & 1][q], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+        }
+        RP_TR(1, trc, kk, 2);
+        float dhx[16];
+        {   // the item's staged operands -> their (row, unit) lanes, through the (idle) tile buffer: [32][36] f32 tiles of c[t-1] and dh_ext,
+            // [32][32] keep bytes.  Nothing before this point needed them: they were requested a whole item ago
+            float* st_c = reinterpret_cast<float*>(tile);
+            float* st_d = reinterpret_cast<float*>(tile + 4608);
+            uint8_t* st_m = reinterpret_cast<uint8_t*>(tile + 9216);
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {               // rows of 36 floats: 16-byte stores, conflict-free 4-byte column reads
+                *reinterpret_cast<float4*>(st_c + (srow + 8 * j) * 36 + spc * 4) = cq[j];
+                *reinterpret_cast<float4*>(st_d + (srow + 8 * j) * 36 + spc * 4) = dq[j];
+            }
+            if (drop) *reinterpret_cast<uint4*>(st_m + prow * 32 + (lane & 1) * 16) = mq;
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int lr = rp_krow(k) + 4 * hh;
+                cp[k] = st_c[lr * 36 + r];
+                const float dv = st_d[lr * 36 + r];
+                dhx[k] = drop ? dv * ikp * (float)st_m[lr * 32 + r] : dv;       // dropout backward of rnn.py:132 on the external gradient
+            }
+            RP_LDS_FENCE();
         }
         // gate backward in registers (rnn.py:124 LSTMBlockCell autodiff): dz = {d i, d g, d f, d o} pre-activation gradients
         unsigned bvp[16][2];                     // the four bf16 values of a register row, packed (i | g << 16, f | o << 16)
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const float gi = gv[k].x, gg = gv[k].y, gf = gv[k].z, go = gv[k].w;
-            const float dh = (drop ? dhe[k] / A.kp * (float)mk[k] : dhe[k]) + acc[k];
+            const float gi = __uint_as_float(gv[k].x << 16), gg = __uint_as_float(gv[k].x & 0xffff0000u);
+            const float gf = __uint_as_float(gv[k].y << 16), go = __uint_as_float(gv[k].y & 0xffff0000u);
+            const float dh = dhx[k] + acc[k];
             const float tc = fast_tanh(cnext[k]);
             const float d_o = dh * tc;
             const float d_c = dh * go * (1.f - tc * tc) + dcreg[k];
@@ -319,23 +497,23 @@ __global__ void __launch_bounds__(256) lstm_rowpar_bwd_kernel(RBwdArgs A) {
             bvp[k][1] = (unsigned)b4[2] | ((unsigned)b4[3] << 16);
         }
         RP_LDS_FENCE();
+        RP_TR(1, trc, kk, 3);
         {   // hand-off: k-steps 8 nt .. 8 nt + 7 of the (t, row tile) slab
             const __amdgpu_buffer_rsrc_t rs = rp_rsrc(A.dzx + ((size_t)t * nrt + rt) * slab, slab);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&sZ[r][ks * 16 + hh * 8]);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((8 * nt + ks) * 64 + lane) * 16, 0, RP_SC1);
-            }
+            for (int ks = 0; ks < 8; ++ks) rp_store_frag(rs, 8 * nt + ks, lane, *reinterpret_cast<const u32x4_t*>(&sZ[r][ks * 16 + hh * 8]), local);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) rp_st(flags + nt, (unsigned)(kk + 1));
-        // ---- off the chain ----
+        RP_TR(1, trc, kk, 4);
+        // ---- issued BEHIND the hand-off stores, which alone the flag waits for: the next item's operands, then what the rest of the step reads ----
+        int behind = 0;
+        if (kk + 1 < T) { prefetch(t - 1); behind += drop ? 25 : 24; }
         if (A.dzc != nullptr) {                  // row-major dz [t][row][4U] (gate-interleaved columns): the A operand of the input-gradient GEMM
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int p = j * 64 + lane, row = p >> 4, pc = p & 15;
                 *reinterpret_cast<uint4*>(A.dzc + ((size_t)t * B + m0 + row) * 4 * U + nt * 128 + pc * 8) = *reinterpret_cast<const uint4*>(&sZ[row][pc * 8]);
             }
+            behind += 8;
         }
         RP_LDS_FENCE();
         if (A.dzT != nullptr) {                  // dzT[nt*128 + 32 g + unit][t B + row]: the K-contiguous operand of the weight-gradient GEMMs
@@ -352,8 +530,14 @@ __global__ void __launch_bounds__(256) lstm_rowpar_bwd_kernel(RBwdArgs A) {
                 *reinterpret_cast<uint4*>(A.dzT + (size_t)(nt * 128 + gu) * A.ld_t + (size_t)t * B + m0 + piece * 8) =
                     *reinterpret_cast<const uint4*>(&sT[gu >> 5][gu & 31][piece * 8]);
             }
+            behind += 8;
         }
         RP_LDS_FENCE();
+        RP_TR(1, trc, kk, 5);
+        rp_wait_all_but(behind);
+        if (lane == 0) rp_raise(flags + nt, (unsigned)(kk + 1), local);
+        RP_TR(1, trc, kk, 6);
+        RP_TR(1, trc, kk, 7);
     }
     if (A.db_p != nullptr) {                     // bias gradient: this wave's column sums over its rows and all steps
 #pragma unroll
@@ -388,7 +572,7 @@ static bool rp_plan(int B, int U, bool bwd, int& nrt, int& G) {
     const int maxw = (bwd && U == 512) ? 3 : 4;     // LDS: the backward tile buffers are 10 KiB per wave next to 128 KiB of weights
     return tiles <= maxw;
 }
-static size_t rp_sync_bytes(int nrt) { return ((size_t)RP_FLAGS_OFF + 32 * (size_t)nrt) * sizeof(unsigned); }
+static size_t rp_sync_bytes(int nrt) { return ((size_t)RP_FLAGS_OFF + 64 * (size_t)nrt) * sizeof(unsigned); }      // flag lines, then one XCC-id line per row-tile group
 static size_t rp_edge_bytes(int nrt, int U) { return (size_t)nrt * (size_t)(U / 4) * 1024; }         // zero slabs standing for dz[T] (>= h[-1]'s)
 static size_t rp_xchg_off(int nrt, int U) { return (rp_sync_bytes(nrt) + rp_edge_bytes(nrt, U) + 255) / 256 * 256; }
 
@@ -438,14 +622,14 @@ extern "C" int mnn_lstm_rowpar_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_
     MNN_REQUIRE(L->yT == nullptr || (L->ld_yT >= T * B && (L->ld_yT & 7) == 0), "mnn_lstm_rowpar_fwd: ld_yT too small / not a multiple of 8");
     MNN_REQUIRE((L->mask == nullptr) == (keep_prob >= 1.0f) && (L->mask == nullptr || L->y != nullptr),
                 "mnn_lstm_rowpar_fwd: a keep mask and a y buffer are needed exactly when keep_prob < 1");
-    a.xproj = L->xproj; a.wh_t = (const bf16_t*)L->wh_t; a.gates = L->gates; a.c = L->c; a.h = (bf16_t*)L->h; a.y = (bf16_t*)L->y; a.mask = L->mask;
+    a.xproj = L->xproj; a.wh_t = (const bf16_t*)L->wh_t; a.gates = (bf16_t*)L->gates; a.c = L->c; a.h = (bf16_t*)L->h; a.y = (bf16_t*)L->y; a.mask = L->mask;
     a.hT = (bf16_t*)L->hT; a.ld_hT = L->ld_hT; a.yT = (bf16_t*)L->yT; a.ld_yT = L->ld_yT;
     a.sync = (unsigned*)workspace; a.hx0 = (const char*)workspace + rp_sync_bytes(a.nrt); a.hx = (char*)workspace + rp_xchg_off(a.nrt, U);
-    a.T = T; a.B = B; a.kp = keep_prob;
+    a.T = T; a.B = B; a.kp = keep_prob; a.allow_local = getenv("MNN_PERSIST_NO_LOCAL") == nullptr;
     hipLaunchKernelGGL(rp_reset_kernel, dim3(8), dim3(256), 0, st, (unsigned*)workspace, (int)(rp_sync_bytes(a.nrt) / sizeof(unsigned)));
     MNN_HIP(mnn_zero_async((char*)workspace + rp_sync_bytes(a.nrt), rp_edge_bytes(a.nrt, U), st));
     const int grid = a.G * (U / 32);
-    const size_t lds = (size_t)(U / 16) * 4096 + 4 * 5120;
+    const size_t lds = (size_t)(U / 16) * 4096 + 4 * 5120 + 16;
     static bool set512 = false, set256 = false, set128 = false;
     hipError_t e;
     if (U == 512) e = rp_launch(lstm_rowpar_fwd_kernel<512>, set512, grid, lds, st, a);
@@ -466,14 +650,14 @@ extern "C" int mnn_lstm_rowpar_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_
     MNN_REQUIRE(L->dh_ext && L->wh_p && L->gates && L->c, "mnn_lstm_rowpar_bwd: null pointer");
     MNN_REQUIRE(L->c0 == nullptr && L->dz == nullptr, "mnn_lstm_rowpar_bwd: no initial state / f32 dz output in this form");
     MNN_REQUIRE(L->dzT_t == nullptr || (L->ld_t >= T * B && (L->ld_t & 7) == 0), "mnn_lstm_rowpar_bwd: ld_t too small / not a multiple of 8");
-    a.dh_ext = L->dh_ext; a.wh_p = (const bf16_t*)L->wh_p; a.gates = L->gates; a.c = L->c; a.mask = L->mask;
+    a.dh_ext = L->dh_ext; a.wh_p = (const bf16_t*)L->wh_p; a.gates = (const bf16_t*)L->gates; a.c = L->c; a.mask = L->mask;
     a.dzc = (bf16_t*)L->dz_T; a.dzT = (bf16_t*)L->dzT_t; a.ld_t = L->ld_t; a.db_p = L->db_p;
     a.sync = (unsigned*)workspace; a.dzx0 = (const char*)workspace + rp_sync_bytes(a.nrt); a.dzx = (char*)workspace + rp_xchg_off(a.nrt, U);
-    a.T = T; a.B = B; a.kp = keep_prob;
+    a.T = T; a.B = B; a.kp = keep_prob; a.allow_local = getenv("MNN_PERSIST_NO_LOCAL") == nullptr;
     hipLaunchKernelGGL(rp_reset_kernel, dim3(8), dim3(256), 0, st, (unsigned*)workspace, (int)(rp_sync_bytes(a.nrt) / sizeof(unsigned)));
     MNN_HIP(mnn_zero_async((char*)workspace + rp_sync_bytes(a.nrt), rp_edge_bytes(a.nrt, U), st));
     const int grid = a.G * (U / 32);
-    const size_t lds = (size_t)(U / 4) * 1024 + (size_t)((U == 512) ? 3 : 4) * 10240;
+    const size_t lds = (size_t)(U / 4) * 1024 + (size_t)((U == 512) ? 3 : 4) * 10240 + 16;
     static bool set512 = false, set256 = false, set128 = false;
     hipError_t e;
     if (U == 512) e = rp_launch(lstm_rowpar_bwd_kernel<512>, set512, grid, lds, st, a);

@@ -151,7 +151,7 @@ class LstmStack:
                 mask = torch.empty((T, B, u), device=dev, dtype=torch.uint8)
                 ops.dropout_mask(mask, keep_prob, seed, row0, l, step_dev)
                 y = torch.empty_like(h)
-            gates = torch.empty((T, B, 4 * u), device=dev) if save else None
+            gates = torch.empty((T, B, 4 * u), device=dev, dtype=torch.bfloat16) if save else None      # this form saves its activations in bf16
             c = torch.empty((T, B, u), device=dev)
             hT = yT = None
             if save:
@@ -160,7 +160,7 @@ class LstmStack:
                 if Np != N:
                     hT[:, N:].zero_()
                 yT = zalloc((u, Np), device=dev, dtype=self.dtype)
-            d = ops.lstm2_fwd_layer(xproj, p["wh_t"], None, None, gates, c, h, hT, y, mask, yT=yT)
+            d = ops.lstm2_fwd_layer(xproj, p["wh_t"], None, None, gates, c, h, hT, y, mask, yT=yT, gates_dtype=torch.bfloat16)
             ops.lstm_rowpar_fwd(T, B, d, keep_prob, self._rp_workspace(l, T, B, dev))
             out = y if y is not None else h
             if save:
@@ -186,7 +186,7 @@ class LstmStack:
             dzc = torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype) if l > 0 else None
             db_p = self._accum(l, dev)[2]
             e = ops.lstm2_bwd_layer(dh.view(T, B, u), p["wh_p"], cx["gates"], cx["c"], None, dzc, ops.lstm_seq_bwd_workspace(B, u, dev), dzT, db_p,
-                                    cx["mask"] if keep_prob < 1.0 else None)
+                                    cx["mask"] if keep_prob < 1.0 else None, gates_dtype=torch.bfloat16)
             ops.lstm_rowpar_bwd(T, B, e, keep_prob, self._rp_workspace(l, T, B, dev))
             st[l] = dict(dzT=dzT, db_p=db_p)
             if l > 0:

@@ -212,7 +212,7 @@ def _p0(t):
     return t.data_ptr() if t is not None else None
 
 
-def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT, y=None, mask=None, wx_t=None, bias_p=None, yT=None):
+def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT, y=None, mask=None, wx_t=None, bias_p=None, yT=None, gates_dtype=torch.float32):
     """Descriptor of one layer for lstm2_seq_fwd (same tensors as lstm_seq_fwd; bf16, contiguous, time-major).
     y/mask: dropped output and u8 keep mask (keep_prob < 1); wx_t/bias_p: this layer's input projection (layer 2)."""
     _req(h.dim() == 3 and h.dtype == torch.bfloat16 and h.is_contiguous(), "lstm2: h bf16 [T,B,u]")
@@ -222,7 +222,7 @@ def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT, y=None, mask=None, wx_
     _req(xproj is None or (xproj.dtype == torch.float32 and xproj.is_contiguous() and xproj.shape == (T, B, N4)), "lstm2: xproj f32 [T,B,4u]")
     _req(wh_t.shape == (N4, u) and wh_t.is_contiguous() and wh_t.dtype == torch.bfloat16, "lstm2: wh_t bf16 [4u,u]")
     _req(c.dtype == torch.float32 and c.shape == (T, B, u) and c.is_contiguous(), "lstm2: c")
-    _req(gates is None or (gates.dtype == torch.float32 and gates.shape == (T, B, N4) and gates.is_contiguous()), "lstm2: gates")
+    _req(gates is None or (gates.dtype == gates_dtype and gates.shape == (T, B, N4) and gates.is_contiguous()), "lstm2: gates")
     _req(h0 is None or (h0.shape == (B, u) and h0.dtype == torch.bfloat16 and h0.is_contiguous()), "lstm2: h0")
     _req(c0 is None or (c0.shape == (B, u) and c0.dtype == torch.float32 and c0.is_contiguous()), "lstm2: c0")
     _req(hT is None or (hT.dim() == 2 and hT.shape[0] == u and hT.stride(1) == 1 and hT.shape[1] >= T * B and hT.dtype == torch.bfloat16), "lstm2: hT")
@@ -248,12 +248,12 @@ def lstm2_seq_fwd(T, B, L1, L2, keep_prob, s_begin=0, s_end=None):
     call("mnn_lstm2_seq_fwd", _stream(), T, B, C.byref(L1), C.byref(L2), float(keep_prob), int(s_begin), int(s_end))
 
 
-def lstm2_bwd_layer(dh_ext, wh_p, gates, c, c0, dz_T, ws, dzT_t, db_p, mask=None, wx_p=None):
+def lstm2_bwd_layer(dh_ext, wh_p, gates, c, c0, dz_T, ws, dzT_t, db_p, mask=None, wx_p=None, gates_dtype=torch.float32):
     T, B, u = c.shape
     N4 = 4 * u
     _req(dh_ext is None or (dh_ext.dtype == torch.float32 and dh_ext.is_contiguous() and dh_ext.shape == (T, B, u)), "lstm2 bwd: dh_ext f32 [T,B,u]")
     _req(wh_p.shape == (u, N4) and wh_p.is_contiguous() and wh_p.dtype == torch.bfloat16, "lstm2 bwd: wh_p bf16 [u,4u]")
-    _req(gates.shape == (T, B, N4) and gates.dtype == torch.float32 and gates.is_contiguous(), "lstm2 bwd: gates")
+    _req(gates.shape == (T, B, N4) and gates.dtype == gates_dtype and gates.is_contiguous(), "lstm2 bwd: gates")
     _req(c.shape == (T, B, u) and c.dtype == torch.float32 and c.is_contiguous(), "lstm2 bwd: c")
     _req(dz_T is None or (dz_T.shape == (T, B, N4) and dz_T.dtype == torch.bfloat16 and dz_T.is_contiguous()), "lstm2 bwd: dz_T bf16 [T,B,4u]")
     _req(dzT_t is None or (dzT_t.dim() == 2 and dzT_t.shape[0] == N4 and dzT_t.stride(1) == 1 and dzT_t.shape[1] >= T * B
