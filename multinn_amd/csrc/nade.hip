@@ -72,14 +72,15 @@ struct WStage {
     static constexpr int W = HQ * 64;            // padded hidden width
     static constexpr int NE = (8 * W) / 512;     // elements per thread per matrix
     float rd[NE], re[NE];
-    __device__ __forceinline__ void gload(const float* __restrict__ wd, const float* __restrict__ we, int i0, int D, int Hn) {
+    __device__ __forceinline__ void gload(const float* __restrict__ wd, const float* __restrict__ we, int i0, int D, int Hn, int ld = 0) {
+        if (ld == 0) ld = Hn;                    // row stride (a hidden slice of a wider matrix passes its width as Hn)
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             const int e = threadIdx.x + k * 512;
             const int ii = e / W, j = e - ii * W, i = i0 + ii;
             const bool ok = i >= 0 && i < D && j < Hn;
-            rd[k] = ok ? wd[(size_t)i * Hn + j] : 0.f;
-            re[k] = ok ? we[(size_t)i * Hn + j] : 0.f;
+            rd[k] = ok ? wd[(size_t)i * ld + j] : 0.f;
+            re[k] = ok ? we[(size_t)i * ld + j] : 0.f;
         }
     }
     __device__ __forceinline__ void lstore(float* __restrict__ sd, float* __restrict__ se) const {
@@ -232,29 +233,43 @@ extern "C" int mnn_nade_logprob_fwd_gated(mnn_stream_t s, int tracks, int N, int
 // Staging for the backward kernel.  HQ == 4: lane-major in LDS (the hidden units l, l+64, l+128, l+192 side by side), so the scan reads
 // the four values a lane needs with one 16-byte load per matrix.  Thread (visible t >> 6, slot l = t & 63) fetches exactly those four
 // values (four loads, each 256 contiguous bytes per wave) and stores them with ONE conflict-free 16-byte LDS store per matrix.
+// HQ consecutive floats as one LDS access (HQ = 2: 8 bytes, HQ = 4: 16 bytes)
+template <int HQ> struct LaneVec;
+template <> struct LaneVec<2> { typedef float2 T; };
+template <> struct LaneVec<4> { typedef float4 T; };
 template <int HQ>
-__device__ __forceinline__ void bwd_gload(WStage<HQ>& st, const float* __restrict__ wd, const float* __restrict__ we, int i0, int D, int Hn) {
-    if constexpr (HQ == 4) {
+__device__ __forceinline__ void lv_store(float* p, const float (&x)[HQ]) {
+    if constexpr (HQ == 4) *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
+    else *reinterpret_cast<float2*>(p) = make_float2(x[0], x[1]);
+}
+template <int HQ>
+__device__ __forceinline__ void lv_load(const float* p, float (&x)[HQ]) {
+    if constexpr (HQ == 4) { const float4 t = *reinterpret_cast<const float4*>(p); x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w; }
+    else { const float2 t = *reinterpret_cast<const float2*>(p); x[0] = t.x; x[1] = t.y; }
+}
+template <int HQ>
+__device__ __forceinline__ void bwd_gload(WStage<HQ>& st, const float* __restrict__ wd, const float* __restrict__ we, int i0, int D, int Hn, int ld) {
+    if constexpr (HQ >= 2) {
         const int i = i0 + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;     // the visible is wave-uniform
         const bool rowok = i >= 0 && i < D;                                                                  // scalar
-        const float* __restrict__ pd = wd + (size_t)(rowok ? i : 0) * Hn + l;                                // uniform row base + lane
-        const float* __restrict__ pe = we + (size_t)(rowok ? i : 0) * Hn + l;
+        const float* __restrict__ pd = wd + (size_t)(rowok ? i : 0) * ld + l;                                // uniform row base + lane
+        const float* __restrict__ pe = we + (size_t)(rowok ? i : 0) * ld + l;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < HQ; ++q) {
             const bool ok = rowok && l + 64 * q < Hn;
             st.rd[q] = ok ? pd[64 * q] : 0.f;                // immediate offsets 0, 256, 512, 768 bytes
             st.re[q] = ok ? pe[64 * q] : 0.f;
         }
     } else {
-        st.gload(wd, we, i0, D, Hn);
+        st.gload(wd, we, i0, D, Hn, ld);
     }
 }
 template <int HQ>
 __device__ __forceinline__ void bwd_lstore(const WStage<HQ>& st, float* __restrict__ sd, float* __restrict__ se) {
-    if constexpr (HQ == 4) {
-        const int pos = (int)(threadIdx.x >> 6) * 256 + 4 * (int)(threadIdx.x & 63);
-        *reinterpret_cast<float4*>(sd + pos) = make_float4(st.rd[0], st.rd[1], st.rd[2], st.rd[3]);
-        *reinterpret_cast<float4*>(se + pos) = make_float4(st.re[0], st.re[1], st.re[2], st.re[3]);
+    if constexpr (HQ >= 2) {
+        const int pos = (int)(threadIdx.x >> 6) * (64 * HQ) + HQ * (int)(threadIdx.x & 63);
+        lv_store<HQ>(sd + pos, st.rd);
+        lv_store<HQ>(se + pos, st.re);
     } else {
         st.lstore(sd, se);
     }
@@ -262,20 +277,23 @@ __device__ __forceinline__ void bwd_lstore(const WStage<HQ>& st, float* __restri
 
 template <int HQ>
 __global__ void __launch_bounds__(512)
-nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias,
+nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias,
                 int ld_bias, const float* __restrict__ w_enc, const float* __restrict__ w_dec, const float* __restrict__ a_final,
                 float* __restrict__ d_bias, float* __restrict__ d_w_enc, float* __restrict__ d_w_dec, float* __restrict__ slab) {
     constexpr int W = HQ * 64;
     __shared__ __attribute__((aligned(16))) float wl[2][2][8 * W];
     __shared__ __attribute__((aligned(16))) float red[8][4][2][W];     // [wave][visible-in-half-chunk][d w_dec | d w_enc][hidden]: one exchange per 4 visibles
-    const int m = blockIdx.y;
+    // blockIdx.y = track * nslice + hidden slice: the backward scan is separable over hidden units (only the forward logit sums over them), so a
+    // wide layer may run as nslice narrower workgroups (fewer registers and less LDS each: more of them resident per CU)
+    const int m = blockIdx.y / nslice, hb = (blockIdx.y - m * nslice) * W;
+    const int Hn = min(W, HnT - hb);                                           // hidden units of this slice
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rbase = blockIdx.x * 64 + w * BWD_R;
     const uint8_t* __restrict__ vm = v + (size_t)m * v_track_stride;
-    const float* __restrict__ we = w_enc + (size_t)m * D * Hn;
-    const float* __restrict__ wd = w_dec + (size_t)m * D * Hn;
-    const int dl_off = tracks * Hn + m * D;
+    const float* __restrict__ we = w_enc + (size_t)m * D * HnT + hb;
+    const float* __restrict__ wd = w_dec + (size_t)m * D * HnT + hb;
+    const int dl_off = tracks * HnT + m * D;
 
     // Sparsity (exact): `a` only changes at visibles with v = 1 (nade.py:219), so h = sigmoid(a) is cached
     // and recomputed only there, and sum_i dl_i * w_dec[i] is accumulated per constant-h segment (c) and
@@ -286,7 +304,7 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
             const int j = lane + 64 * q, row = rbase + r;
-            a[r][q] = (row < N && j < Hn) ? a_final[((size_t)m * N + row) * Hn + j] : 0.f;
+            a[r][q] = (row < N && j < Hn) ? a_final[((size_t)m * N + row) * HnT + hb + j] : 0.f;
             h[r][q] = fast_sigmoid(a[r][q]);
             G[r][q] = 0.f;
             c[r][q] = 0.f;
@@ -296,7 +314,7 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
     const int frr = fvalid ? frow : N - 1;
     const int nch = (D + 7) / 8;
     WStage<HQ> st;
-    bwd_gload<HQ>(st, wd, we, (nch - 1) * 8, D, Hn);
+    bwd_gload<HQ>(st, wd, we, (nch - 1) * 8, D, Hn, HnT);
     bwd_lstore<HQ>(st, wl[0][0], wl[0][1]);
     int icur = (nch - 1) * 8 + fi;
     bool vcur = fvalid && icur < D && vm[(size_t)frr * D + icur] != 0;
@@ -305,7 +323,7 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
     for (int cc = 0; cc < nch; ++cc) {
         const int i0 = (nch - 1 - cc) * 8;
         const int inext = i0 - 8 + fi;
-        bwd_gload<HQ>(st, wd, we, i0 - 8, D, Hn);                             // next (lower) chunk, zeros below 0
+        bwd_gload<HQ>(st, wd, we, i0 - 8, D, Hn, HnT);                             // next (lower) chunk, zeros below 0
         const bool vnext = fvalid && inext >= 0 && vm[(size_t)frr * D + inext] != 0;
         const float dnext = (fvalid && inext >= 0) ? d_bias[(size_t)frr * ld_bias + dl_off + inext] : 0.f;
         const unsigned long long mask = __ballot(vcur);
@@ -322,11 +340,9 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
                 for (int q = 0; q < HQ; ++q) { accd[k][q] = 0.f; acce[k][q] = 0.f; }
                 if (i >= D) continue;                                           // block-uniform (tail chunk)
                 float wev[HQ], wdv[HQ];
-                if constexpr (HQ == 4) {                                        // lane-major staging: one 16-byte LDS load per matrix
-                    const float4 d4 = *reinterpret_cast<const float4*>(sd + ii * W + 4 * lane);
-                    const float4 e4 = *reinterpret_cast<const float4*>(se + ii * W + 4 * lane);
-                    wdv[0] = d4.x; wdv[1] = d4.y; wdv[2] = d4.z; wdv[3] = d4.w;
-                    wev[0] = e4.x; wev[1] = e4.y; wev[2] = e4.z; wev[3] = e4.w;
+                if constexpr (HQ >= 2) {                                        // lane-major staging: one 8/16-byte LDS load per matrix
+                    lv_load<HQ>(sd + ii * W + HQ * lane, wdv);
+                    lv_load<HQ>(se + ii * W + HQ * lane, wev);
                 } else {
 #pragma unroll
                     for (int q = 0; q < HQ; ++q) {
@@ -367,24 +383,28 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
             if (half == 1) bwd_lstore<HQ>(st, wl[(cc + 1) & 1][0], wl[(cc + 1) & 1][1]);
             // one cross-wave exchange per 4 visibles (the per-visible barrier was 60 % of the wave time)
             __syncthreads();                             // the previous exchange has been read
-            if constexpr (HQ == 4) {
+            if constexpr (HQ >= 2) {
                 // exchange slots are LANE-major (the four hidden units lane, lane+64, lane+128, lane+192 of a lane side by side): one
                 // 16-byte LDS store per (visible, matrix) instead of four 4-byte ones, and the summing thread -- one per (visible,
                 // matrix, lane) -- reads 8 x 16 bytes instead of 32 x 4; its four atomics each still cover 256 contiguous bytes per wave
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    *reinterpret_cast<float4*>(&red[w][k][0][4 * lane]) = make_float4(accd[k][0], accd[k][1], accd[k][2], accd[k][3]);
-                    *reinterpret_cast<float4*>(&red[w][k][1][4 * lane]) = make_float4(acce[k][0], acce[k][1], acce[k][2], acce[k][3]);
+                    lv_store<HQ>(&red[w][k][0][HQ * lane], accd[k]);
+                    lv_store<HQ>(&red[w][k][1][HQ * lane], acce[k]);
                 }
                 __syncthreads();
                 {
                     const int k = threadIdx.x >> 7, which = (threadIdx.x >> 6) & 1;       // 4 visibles x 2 matrices x 64 lanes = 512 threads
                     const int i = i0 + half * 4 + k;
-                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float sum[HQ];
+#pragma unroll
+                    for (int q = 0; q < HQ; ++q) sum[q] = 0.f;
 #pragma unroll
                     for (int ww = 0; ww < 8; ++ww) {
-                        const float4 p = *reinterpret_cast<const float4*>(&red[ww][k][which][4 * lane]);
-                        sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+                        float pq[HQ];
+                        lv_load<HQ>(&red[ww][k][which][HQ * lane], pq);
+#pragma unroll
+                        for (int q = 0; q < HQ; ++q) sum[q] += pq[q];
                     }
                     if (i < D) {
                         if (slab != nullptr) {
@@ -392,17 +412,15 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
                             // word is written exactly once per workgroup), summed over the workgroups by nade_bwd_reduce_kernel.  The f32 atomics
                             // of the other branch all land in the same 2 x D x Hn words from every 64-row workgroup: 3.7 GB of adds at TGT, at the
                             // chip-wide ~1.3 TB/s atomic rate (MI355X_MICROARCH.md, Global float atomics)
-                            float* dst = slab + ((((size_t)blockIdx.x * tracks + m) * 2 + which) * D + i) * Hn + lane;
-                            if (lane < Hn) dst[0] = sum.x;
-                            if (lane + 64 < Hn) dst[64] = sum.y;
-                            if (lane + 128 < Hn) dst[128] = sum.z;
-                            if (lane + 192 < Hn) dst[192] = sum.w;
+                            float* dst = slab + ((((size_t)blockIdx.x * tracks + m) * 2 + which) * D + i) * HnT + hb + lane;
+#pragma unroll
+                            for (int q = 0; q < HQ; ++q)
+                                if (lane + 64 * q < Hn) dst[64 * q] = sum[q];
                         } else {
-                            float* dst = (which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * Hn + lane;
-                            if (lane < Hn) atomicAdd(dst, sum.x);
-                            if (lane + 64 < Hn) atomicAdd(dst + 64, sum.y);
-                            if (lane + 128 < Hn) atomicAdd(dst + 128, sum.z);
-                            if (lane + 192 < Hn) atomicAdd(dst + 192, sum.w);
+                            float* dst = (which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * HnT + hb + lane;
+#pragma unroll
+                            for (int q = 0; q < HQ; ++q)
+                                if (lane + 64 * q < Hn) atomicAdd(dst + 64 * q, sum[q]);
                         }
                     }
                 }
@@ -422,8 +440,8 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
                         float sum = 0.f;
 #pragma unroll
                         for (int ww = 0; ww < 8; ++ww) sum += red[ww][k][which][j];
-                        if (slab != nullptr) slab[((((size_t)blockIdx.x * tracks + m) * 2 + which) * D + i) * Hn + j] = sum;
-                        else atomicAdd((which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * Hn + j, sum);
+                        if (slab != nullptr) slab[((((size_t)blockIdx.x * tracks + m) * 2 + which) * D + i) * HnT + hb + j] = sum;
+                        else atomicAdd((which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * HnT + hb + j, sum);
                     }
                 }
             }
@@ -441,7 +459,7 @@ nade_bwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
             const int j = lane + 64 * q, row = rbase + r;
-            if (row < N && j < Hn) d_bias[(size_t)row * ld_bias + m * Hn + j] = G[r][q];
+            if (row < N && j < Hn) d_bias[(size_t)row * ld_bias + m * HnT + hb + j] = G[r][q];
         }
 }
 
@@ -496,13 +514,17 @@ extern "C" int mnn_nade_logprob_bwd_ws(mnn_stream_t s, int tracks, int N, int D,
     MNN_REQUIRE(workspace == nullptr || (need > 0 && workspace_bytes >= need && ((size_t)workspace & 15) == 0),
                 "mnn_nade_logprob_bwd_ws: workspace must be 16-byte aligned and hold mnn_nade_logprob_bwd_workspace_bytes() bytes (D*Hn %% 4 == 0)");
     float* slab = (float*)workspace;
-    dim3 grid(cdiv(N, 64), tracks);
     hipStream_t st = (hipStream_t)s;
-#define BWD(HQ) hipLaunchKernelGGL(nade_bwd_kernel<HQ>, grid, dim3(512), 0, st, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, \
-                                   w_dec, a_final, d_bias, d_w_enc, d_w_dec, slab)
-    if (Hn <= 64) BWD(1);
-    else if (Hn <= 128) BWD(2);
-    else BWD(4);
+    // hidden slices: Hn <= 256 in one workgroup of lane-major quads (HQ = 4), or as two 128-wide slices at twice the residency (HQ = 2)
+    static int split = -1;
+    if (split < 0) { const char* e = getenv("MULTINN_NADE_BWD_SLICES"); split = e ? atoi(e) : 2; }
+#define BWD(HQ, NS) hipLaunchKernelGGL(nade_bwd_kernel<HQ>, dim3(cdiv(N, 64), tracks * (NS)), dim3(512), 0, st, tracks, N, D, Hn, NS, v, v_track_stride, \
+                                       bias, ld_bias, w_enc, w_dec, a_final, d_bias, d_w_enc, d_w_dec, slab)
+    if (Hn <= 64) BWD(1, 1);
+    else if (Hn <= 128) { if (split == 4) BWD(1, cdiv(Hn, 64)); else BWD(2, 1); }
+    else if (split == 4) BWD(1, cdiv(Hn, 64));
+    else if (split == 2) BWD(2, cdiv(Hn, 128));
+    else BWD(4, 1);
 #undef BWD
     MNN_LAUNCH_CHECK();
     if (slab != nullptr) {
