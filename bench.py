@@ -354,8 +354,9 @@ def main(argv=None):
     if dom.startswith("mnn_nade_logprob"):
         bwd = dom.endswith("bwd")
         byts = N * (D + 4 * (HN + D) * (2 if bwd else 1) + 4 * (HN + D if bwd else D))
-        roof = dict(bound="hbm", achieved=byts / (dom_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", traffic=None, kernel=dom,
-                    launches_per_step=1, avg_launch_us=dom_ms * 1e3, algorithmic_bytes_per_launch=byts,
+        roof = dict(bound="hbm", achieved=byts / (dom_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", traffic=None,
+                    kernel="nade_bwd_kernel" if bwd else ("nade_fwd_mfma_kernel" if a.precision == "bf16" else "nade_fwd_kernel"),
+                    entry_point=dom, launches_per_step=1, avg_launch_us=dom_ms * 1e3, algorithmic_bytes_per_launch=byts,
                     note="transcendental / VALU-bound scan (SURVEY 8d): HBM is the contract's bound for a non-MFMA kernel; its "
                          "sigmoid-rate fraction is in roofline.step.phases")
     elif dom in ("mnn_lstm2_persist_fwd", "mnn_lstm2_persist_bwd"):
@@ -366,6 +367,14 @@ def main(argv=None):
                     avg_launch_us=dom_ms * 1e3, avg_timestep_us=dom_ms * 1e3 / T, algorithmic_flop_per_launch=flops,
                     note="latency-bound chain of T in-kernel tile hand-offs (flag + row tile through the fabric per timestep): "
                          "the number to watch is avg_timestep_us")
+    elif dom in ("mnn_lstm_rowpar_fwd", "mnn_lstm_rowpar_bwd"):
+        # one launch per LAYER: every wave carries one 32-row tile through all T steps against a 32-unit weight tile resident in LDS
+        roof = dict(bound="mfma", achieved=rec_flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
+                    kernel="lstm_rowpar_%s_kernel" % ("bwd" if dom.endswith("bwd") else "fwd"), entry_point=dom, launches_per_step=dom_calls,
+                    avg_launch_us=dom_ms * 1e3 / dom_calls, avg_timestep_us=dom_ms * 1e3 / dom_calls / T,
+                    algorithmic_flop_per_launch=rec_flops / dom_calls,
+                    note="latency-bound chain: per timestep every row tile exchanges its 32-row h (backward: dz) slice with the other unit "
+                         "tiles through L2 (flag per wave); the number to watch is avg_timestep_us")
     elif dom in ("mnn_lstm_seq_fwd", "mnn_lstm_seq_bwd", "mnn_lstm2_seq_fwd", "mnn_lstm2_seq_bwd"):
         fused = dom.startswith("mnn_lstm2")
         launches = (T + 2) if fused else 2 * T            # fused: one three-stage launch per timestep for both layers (lag 2)
@@ -387,7 +396,7 @@ def main(argv=None):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
             if a.precision == "bf16":
-                hit = [v for k, v in pmc["kernels"].items() if k.startswith(roof["kernel"].replace("mnn_", ""))]
+                hit = [v for k, v in pmc["kernels"].items() if k.startswith(roof["kernel"])]
                 if hit:
                     roof["traffic"] = hit[0]["hbm_side_bytes_per_launch"]
                     roof["traffic_unit"] = "bytes/launch"

@@ -27,6 +27,9 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 
 #define RP_LIMIT 100000000LL       // spin bound: 1 s of wall_clock64() (100 MHz)
 #define RP_FLAGS_OFF 32            // words: [0] status, [1] sticky, [32 + 32 rt + member] progress flags
+#ifndef RP_STG
+#define RP_STG 33   // f32 words per staged row (32 + pad)
+#endif
 #ifndef RP_RING
 #define RP_RING 3                  // backward: chunks of the dz tile in the register ring (8 KiB each)
 #endif
@@ -449,24 +452,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
         RP_TR(1, trc, kk, 2);
         float dhx[16];
-        {   // the item's staged operands -> their (row, unit) lanes, through the (idle) tile buffer: [32][36] f32 tiles of c[t-1] and dh_ext,
+        {   // the item's staged operands -> their (row, unit) lanes, through the (idle) tile buffer: [32][33] f32 tiles of c[t-1] and dh_ext,
             // [32][32] keep bytes.  Nothing before this point needed them: they were requested a whole item ago
             float* st_c = reinterpret_cast<float*>(tile);
-            float* st_d = reinterpret_cast<float*>(tile + 4608);
-            uint8_t* st_m = reinterpret_cast<uint8_t*>(tile + 9216);
+            float* st_d = reinterpret_cast<float*>(tile + 128 * RP_STG);
+            uint8_t* st_m = reinterpret_cast<uint8_t*>(tile + 256 * RP_STG);
             RP_LDS_FENCE();
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {               // rows of 36 floats: 16-byte stores, conflict-free 4-byte column reads
-                *reinterpret_cast<float4*>(st_c + (srow + 8 * j) * 36 + spc * 4) = cq[j];
-                *reinterpret_cast<float4*>(st_d + (srow + 8 * j) * 36 + spc * 4) = dq[j];
+            for (int j = 0; j < 4; ++j) {               // component stores: whole-float4 stores of cq / dq send the arrays to scratch memory
+                float* pc_ = st_c + (srow + 8 * j) * RP_STG + spc * 4;
+                float* pd_ = st_d + (srow + 8 * j) * RP_STG + spc * 4;
+                pc_[0] = cq[j].x; pc_[1] = cq[j].y; pc_[2] = cq[j].z; pc_[3] = cq[j].w;
+                pd_[0] = dq[j].x; pd_[1] = dq[j].y; pd_[2] = dq[j].z; pd_[3] = dq[j].w;
             }
             if (drop) *reinterpret_cast<uint4*>(st_m + prow * 32 + (lane & 1) * 16) = mq;
             RP_LDS_FENCE();
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int lr = rp_krow(k) + 4 * hh;
-                cp[k] = st_c[lr * 36 + r];
-                const float dv = st_d[lr * 36 + r];
+                cp[k] = st_c[lr * RP_STG + r];
+                const float dv = st_d[lr * RP_STG + r];
                 dhx[k] = drop ? dv * ikp * (float)st_m[lr * 32 + r] : dv;       // dropout backward of rnn.py:132 on the external gradient
             }
             RP_LDS_FENCE();

@@ -1,6 +1,6 @@
 """Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py --no-cpu-baseline --no-graph --steps 3 --warmup 1`
 into per-kernel HBM-side bytes per launch (MI355X_MICROARCH.md, HBM section: bytes = counter * 1024; FETCH_SIZE doubled on gfx950).
-Usage: python profiles/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json>"""
+Usage: python profiles/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> [workload label]"""
 import collections
 import csv
 import glob
@@ -23,7 +23,7 @@ def load(d, counter):
 
 def main():
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-    out = {"workload": "C2 [256,128,88,5] bf16, eager launches, 3 steps + 1 warm-up",
+    out = {"workload": sys.argv[4] if len(sys.argv) > 4 else "C2 [256,128,88,5] bf16, eager launches, 3 steps + 1 warm-up",
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (MI355X_MICROARCH.md HBM section): "
                      "bytes = counter * 1024; FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B)",
            "kernels": {}}
