@@ -192,12 +192,14 @@ int mnn_lstm2_persist_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer
  * loop); the layers run as separate launches with the next layer's input projection (mnn_gemm_tn) between them.  Same layer descriptors as
  * above, with: forward -- L->xproj GATE-MINOR f32 [T,B,4u] including the bias (mnn_lstm_rows_gate_minor); L->gates points at BF16 [T,B,4u]
  * (gate-minor; half the bytes of the other forms' f32 copy: the saved activations only feed products that are rounded to bf16 anyway, and
- * only mnn_lstm_rowpar_bwd reads them); L->wx_t / bias_p unused, no initial state (h0 = c0 = NULL: a window starts from the zero state, train.py:165-173); backward -- L->dh_ext f32 [T,B,u]
+ * only mnn_lstm_rowpar_bwd reads them); with a keep mask (L->mask, L->y) the layer's output is y and L->h receives ONLY its last timestep
+ * (the final state) -- the rows of h[0 .. T-2] are left untouched; L->wx_t / bias_p unused, no initial state (h0 = c0 = NULL: a window starts from the zero state, train.py:165-173); backward -- L->dh_ext f32 [T,B,u]
  * required (the gradient wrt the layer's output; with L->mask it is taken wrt the DROPPED output and dh_ext / keep_prob * mask is applied
  * here), L->dz_T (optional) receives dz bf16 [T,B,4u] row-major in the gate-interleaved column order (the A operand of the input-gradient
  * GEMM against wx_p), L->dzT_t / db_p as in the persistent form, L->workspace / wx_p / dz unused.  B must be a multiple of 32.
  * workspace: mnn_lstm_rowpar_workspace_bytes(T,B,u) bytes, 256-byte aligned, zeroed ONCE at allocation; forward and backward calls of the
- * same layer may share it.  mnn_lstm_rowpar_status: the sticky give-up word (non-zero: a bounded spin gave up, outputs are garbage). */
+ * same layer may share it.  Up to two row tiles per workgroup every (row tile, unit tile) item is worked by a PAIR of waves (forward: the
+ * gate columns split between them, backward: K split; MNN_ROWPAR_NO_PAIR=1 keeps one wave per item).  mnn_lstm_rowpar_status: the sticky give-up word (non-zero: a bounded spin gave up, outputs are garbage). */
 int mnn_lstm_rowpar_ok(int B, int units);
 size_t mnn_lstm_rowpar_workspace_bytes(int T, int B, int units);
 int mnn_lstm_rowpar_status(const void* workspace, int* status);

@@ -34,6 +34,9 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 #define RP_RING 3                  // backward: chunks of the dz tile in the register ring (8 KiB each)
 #endif
 #define RP_SC1 16                  // aux bit of raw buffer loads/stores: device scope (write-through / L1-bypassing)
+#ifndef RP_A_AUX
+#define RP_A_AUX 0                  // pair forward, same-XCD mode: state-tile loads through the L1
+#endif
 // The per-wave LDS tiles are written element-wise (bf16) and read back 16 bytes at a time by OTHER lanes of the same wave: the LDS serves a
 // wave's instructions in order, but the compiler must not move the differently-typed accesses across one another
 #define RP_LDS_FENCE() asm volatile("" ::: "memory")
@@ -109,33 +112,35 @@ __device__ __forceinline__ void rp_raise(unsigned* flag, unsigned value, bool lo
 
 // `s_waitcnt vmcnt(N)` with N a run-time count of the stores issued BEHIND the hand-off stores (loads, stores and atomics of a wave complete in
 // issue order: MI355X_MICROARCH.md, cycle constants): the hand-off tile is out, the younger row-major stores may still be in flight
+#define RP_VMC(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
 __device__ __forceinline__ void rp_wait_all_but(int n) {
     switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-        case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
-        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-        case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
-        case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
-        case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
-        case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
-        case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
-        case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
-        case 41: asm volatile("s_waitcnt vmcnt(41)" ::: "memory"); break;
-        case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
-        case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
-        case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
-        case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
-        case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
-        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
-        case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+        RP_VMC(0) RP_VMC(1) RP_VMC(2) RP_VMC(3) RP_VMC(4) RP_VMC(5) RP_VMC(6) RP_VMC(7) RP_VMC(8) RP_VMC(9) RP_VMC(10) RP_VMC(11) RP_VMC(12)
+        RP_VMC(13) RP_VMC(14) RP_VMC(15) RP_VMC(16) RP_VMC(17) RP_VMC(18) RP_VMC(19) RP_VMC(20) RP_VMC(21) RP_VMC(22) RP_VMC(23) RP_VMC(24)
+        RP_VMC(25) RP_VMC(26) RP_VMC(27) RP_VMC(28) RP_VMC(29) RP_VMC(30) RP_VMC(31) RP_VMC(32) RP_VMC(33) RP_VMC(34) RP_VMC(35) RP_VMC(36)
+        RP_VMC(37) RP_VMC(38) RP_VMC(39) RP_VMC(40) RP_VMC(41) RP_VMC(42) RP_VMC(43) RP_VMC(44) RP_VMC(45) RP_VMC(46) RP_VMC(47) RP_VMC(48)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// ---- wave pairs (the *2 kernels below): two waves of a workgroup share one (row tile, unit tile) and exchange through LDS ----
+// LDS serves one wave's instructions in order and is one memory for the whole workgroup, so "data words, then the step word" by the writer and
+// "step word, then data words" by the reader needs no hardware fence; RP_LDS_FENCE keeps the compiler from moving the accesses across each other.
+__device__ __forceinline__ unsigned rp_lds_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void rp_lds_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// wait (bounded) until the LDS word reaches `need`; false: the launch is aborting
+__device__ __forceinline__ bool rp_pair_wait(const unsigned* word, unsigned need, unsigned* status) {
+    if (rp_lds_ld(word) >= need) return true;
+    const long long t0 = wall_clock64();
+    for (unsigned spins = 1;; ++spins) {
+        if (rp_lds_ld(word) >= need) return true;
+        if ((spins & 255u) == 0u) {
+            if (rp_ld(status) != 0u) return false;
+            if (wall_clock64() - t0 > RP_LIMIT) {
+                if ((threadIdx.x & 63) == 0) { rp_st(status, 1u); rp_st(status + 1, 1u); }
+                return false;
+            }
+        }
     }
 }
 
@@ -281,7 +286,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             }
             behind += 16;
         }
-        {
+        if (!drop || t + 1 == T) {   // with dropout the layer's output is y, and only the final state reads h
             bf16_t* dst = A.h + (size_t)t * us + (size_t)(m0 + prow) * U + nt * 32 + pp * 8;
             *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sH[prow][pp * 8]);
             *reinterpret_cast<uint4*>(dst + 8) = *reinterpret_cast<const uint4*>(&sH[prow][pp * 8 + 8]);
@@ -553,6 +558,497 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Wave-pair forms (at most two row tiles per workgroup: every (row tile, unit tile) item gets TWO waves, so all four SIMDs of a CU work).
+// A single wave per item leaves the step a serial chain on one SIMD: 128 MFMAs (1.7 us at 32 cycles each) + the gate pointwise of 1024
+// (row, unit) pairs (1.6 us forward, 2.1 us backward) of the 6.2 / 8.4 us per timestep at U = 512 (profiles/tools/rowpar_trace.py).
+//   forward:  the pair splits the GATE columns (wave 0: i, g; wave 1: f, o -- each reads half of the weights in LDS and the whole h[t-1] tile),
+//             then the ROWS for the pointwise: wave h keeps C registers 8h .. 8h+7 (rows 16h .. 16h+15), sends the other eight of its two gate
+//             tiles to its partner through LDS (4 KiB each way) and receives the partner's gates for its own rows;
+//   backward: the pair splits K (wave h: dz columns of unit tiles h nb/2 .. -- half of the weights, half of the 4U-wide dz[t+1] tile: the
+//             load stream of a wave is bounded by its 63 outstanding requests), exchanges the partial dh of the other's rows (2 KiB each way).
+// Every wave hands on its own 16 rows and raises its own flag (member 2 nt + h): forward consumers wait for all 2 nb flags of the row tile,
+// backward consumers for the nb flags of their K half.  Transposed outputs (h^T, y^T, dz^T) leave as 8-byte stores straight from the registers
+// (a lane holds four consecutive rows of a unit), no LDS transpose.
+// ------------------------------------------------------------------------------------------------------------------
+template <int U>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_rowpar_fwd2_kernel(RFwdArgs A) {
+    constexpr int KS = U / 16;
+    constexpr size_t OFF_TILE = (size_t)KS * 4096, TILE_B = 2304, OFF_X = OFF_TILE + 4 * TILE_B, OFF_HS = OFF_X + 2 * 8192;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* wl = reinterpret_cast<uint4*>(smem);     // [gate][k-step][lane] 16-byte B fragments
+    unsigned* hs = reinterpret_cast<unsigned*>(smem + OFF_HS);      // [slot][ready 0, ready 1, taken 0, taken 1]
+    int* s_local = reinterpret_cast<int*>(smem + OFF_HS + 32);
+    const int grp = blockIdx.x % A.G, nt = blockIdx.x / A.G;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = w >> 1, half = w & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int T = A.T, B = A.B, nrt = A.nrt;
+    const int nb = U / 32;
+    unsigned* status = A.sync;
+    if (threadIdx.x < 8) hs[threadIdx.x] = 0u;
+    rp_probe_xcd(A.sync + RP_FLAGS_OFF + 32 * nrt + 32 * grp, status, nt, nb, s_local);
+    const int rot = (2 * nt) & (KS - 1);
+    {
+        const int n0 = nt * 128;
+#pragma unroll 4
+        for (int i = 0; i < KS; ++i) {
+            const int e = i * 256 + (int)threadIdx.x;
+            const int g = e / (KS * 64), s = (e >> 6) % KS, ln = e & 63;
+            wl[e] = *reinterpret_cast<const uint4*>(A.wh_t + (size_t)(n0 + 32 * g + (ln & 31)) * U + 16 * ((s + rot) & (KS - 1)) + 8 * (ln >> 5));
+        }
+    }
+    __syncthreads();
+    const bool local = A.allow_local && *s_local != 0;
+    const int rt = grp + A.G * slot;                // the pair's row tile, for the whole sequence
+    if (rt >= nrt) return;                          // both waves of the pair leave together
+    bf16_t (*sH)[40] = reinterpret_cast<bf16_t (*)[40]>(smem + OFF_TILE + (size_t)w * TILE_B);      // this wave's 16 rows [row][unit] (+pad)
+    unsigned* sT = reinterpret_cast<unsigned*>(smem + OFF_TILE + (size_t)w * TILE_B + 1280);        // [unit][8 row pairs]: the transposed tile
+    float4* xsend = reinterpret_cast<float4*>(smem + OFF_X + (size_t)slot * 8192 + (size_t)half * 4096);
+    const float4* xrecv = reinterpret_cast<const float4*>(smem + OFF_X + (size_t)slot * 8192 + (size_t)(half ^ 1) * 4096);
+    unsigned* my_ready = hs + slot * 4 + half;
+    const unsigned* peer_ready = hs + slot * 4 + (half ^ 1);
+    unsigned* my_taken = hs + slot * 4 + 2 + half;          // "I have read the partner's words of step .."
+    const unsigned* peer_taken = hs + slot * 4 + 2 + (half ^ 1);
+    unsigned* flags = A.sync + RP_FLAGS_OFF + rt * 32;
+    const int m0 = rt * 32, unit = nt * 32 + r;
+    const int rb = 16 * half + 4 * hh;              // global row (inside the tile) of local register row 0; register kl: rb + rp_krow(kl)
+    const size_t us = (size_t)B * U, slab = (size_t)KS * 1024;
+    const bool drop = A.mask != nullptr;
+    const float ikp = 1.0f / A.kp;
+    const unsigned og = (unsigned)(rb * 4 * U + unit * 4) * 4u;           // gates / xproj (gate-minor float4)
+    const unsigned oc = (unsigned)(rb * U + unit) * 4u;                   // c (float)
+    const int g0 = 2 * half;                        // this wave's two gate tiles: g0, g0 + 1
+    f32x16_t acc[2];
+    float4 xv[8];
+    float creg[8];
+    unsigned mk[8];
+    uint4 mq = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { creg[k] = 0.f; mk[k] = 0u; }
+    auto prefetch = [&](int t) {
+        const char* xb = reinterpret_cast<const char*>(A.xproj + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xv[k] = *reinterpret_cast<const float4*>(xb + (size_t)rp_krow(k) * 16 * U);
+        if (drop && lane < 32) mq = *reinterpret_cast<const uint4*>(A.mask + (size_t)t * us + (size_t)(m0 + 16 * half + (lane >> 1)) * U + nt * 32 + (lane & 1) * 16);
+    };
+    prefetch(0);
+    const bool trc = nt == 0 && rt == 0 && half == 0;
+    for (int t = 0; t < T; ++t) {
+        RP_TR(0, trc, t, 0);
+        if (t > 0 && !rp_wait(flags, status, 2 * nb, (unsigned)t)) return;
+        RP_TR(0, trc, t, 1);
+        bf16x8_t a[KS];
+        {
+            const __amdgpu_buffer_rsrc_t rs = rp_rsrc(t > 0 ? A.hx + ((size_t)(t - 1) * nrt + rt) * slab : A.hx0 + (size_t)rt * slab, slab);
+            // same-XCD mode: through the CU's L1 -- both waves of the pair (and the second pair) read the same 1-KiB lines within a microsecond,
+            // and a slab address is written once per launch before anybody reads it (the L1 starts the launch empty), so a hit is never stale
+            if (local) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    a[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ((((s + rot) & (KS - 1)) * 64 + lane) * 16), 0, RP_A_AUX));
+            } else {
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    a[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ((((s + rot) & (KS - 1)) * 64 + lane) * 16), 0, RP_SC1));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { acc[0][k] = 0.f; acc[1][k] = 0.f; }
+        if (drop) {                                 // keep bytes of this wave's 16 rows through its (idle) h tile
+            uint8_t* mt = reinterpret_cast<uint8_t*>(&sH[0][0]);
+            RP_LDS_FENCE();
+            if (lane < 32) *reinterpret_cast<uint4*>(mt + (lane >> 1) * 32 + (lane & 1) * 16) = mq;
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mk[k] = mt[(rp_krow(k) + 4 * hh) * 32 + r];
+            RP_LDS_FENCE();
+        }
+        bf16x8_t bq[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) bq[0][g] = __builtin_bit_cast(bf16x8_t, wl[((g0 + g) * KS + 0) * 64 + lane]);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) bq[(s + 1) & 1][g] = __builtin_bit_cast(bf16x8_t, wl[((g0 + g) * KS + s + 1) * 64 + lane]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[s & 1][g], acc[g], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        RP_TR(0, trc, t, 2);
+        // ---- pair exchange: the other wave's rows of my two gate tiles go out, its two gate tiles of my rows come in ----
+        float keep[2][8], recv[2][8];
+        {
+            if (t > 0 && !rp_pair_wait(peer_taken, (unsigned)t, status)) return;      // the partner has read my words of step t - 1
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float4 o4;
+                    o4.x = half ? acc[g][4 * q + 0] : acc[g][8 + 4 * q + 0];
+                    o4.y = half ? acc[g][4 * q + 1] : acc[g][8 + 4 * q + 1];
+                    o4.z = half ? acc[g][4 * q + 2] : acc[g][8 + 4 * q + 2];
+                    o4.w = half ? acc[g][4 * q + 3] : acc[g][8 + 4 * q + 3];
+                    xsend[(g * 2 + q) * 64 + lane] = o4;
+                }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) keep[g][k] = half ? acc[g][8 + k] : acc[g][k];
+            RP_LDS_FENCE();
+            if (lane == 0) rp_lds_st(my_ready, (unsigned)(t + 1));
+            if (!rp_pair_wait(peer_ready, (unsigned)(t + 1), status)) return;
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float4 i4 = xrecv[(g * 2 + q) * 64 + lane];
+                    recv[g][4 * q + 0] = i4.x; recv[g][4 * q + 1] = i4.y; recv[g][4 * q + 2] = i4.z; recv[g][4 * q + 3] = i4.w;
+                }
+            RP_LDS_FENCE();
+            if (lane == 0) rp_lds_st(my_taken, (unsigned)(t + 1));
+        }
+        // gate pointwise of this wave's 16 rows, in registers
+        float gact[4][8];
+        unsigned hbv[8], yb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float zi = (half ? recv[0][k] : keep[0][k]) + xv[k].x, zg = (half ? recv[1][k] : keep[1][k]) + xv[k].y;
+            const float zf = (half ? keep[0][k] : recv[0][k]) + xv[k].z, zo = (half ? keep[1][k] : recv[1][k]) + xv[k].w;
+            const float gi = fast_sigmoid(zi), gg = fast_tanh(zg), gf = fast_sigmoid(zf), go = fast_sigmoid(zo);
+            const float cv = gg * gi + creg[k] * gf;
+            const float hv = fast_tanh(cv) * go;
+            gact[0][k] = gi; gact[1][k] = gg; gact[2][k] = gf; gact[3][k] = go;
+            creg[k] = cv;
+            const bf16_t hb = f32_to_bf16(hv);
+            sH[rp_krow(k) + 4 * hh][r] = hb;
+            hbv[k] = (unsigned)hb;
+            yb[k] = drop ? (unsigned)f32_to_bf16(bf16_to_f32(hb) * ikp * (float)mk[k]) : (unsigned)hb;
+        }
+        RP_LDS_FENCE();
+        RP_TR(0, trc, t, 3);
+        {   // hand-off of this wave's 16 rows: k-steps 2 nt, 2 nt + 1 of the slab in ONE store (lane -> k-step, unit half, row)
+            const __amdgpu_buffer_rsrc_t rs = rp_rsrc(A.hx + ((size_t)t * nrt + rt) * slab, slab);
+            const int ks = lane >> 5, kh = (lane >> 4) & 1, rl = lane & 15;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&sH[rl][ks * 16 + kh * 8]);
+            const int off = (((2 * nt + ks) * 64) + kh * 32 + 16 * half + rl) * 16;
+            if (local) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, RP_SC1);
+        }
+        RP_TR(0, trc, t, 4);
+        int behind = 0;
+        if (t + 1 < T) { prefetch(t + 1); behind += drop ? 9 : 8; }
+        if (A.gates != nullptr) {
+            char* gb = reinterpret_cast<char*>(A.gates + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og / 2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint2 pk;
+                pk.x = (unsigned)f32_to_bf16(gact[0][k]) | ((unsigned)f32_to_bf16(gact[1][k]) << 16);
+                pk.y = (unsigned)f32_to_bf16(gact[2][k]) | ((unsigned)f32_to_bf16(gact[3][k]) << 16);
+                *reinterpret_cast<uint2*>(gb + (size_t)rp_krow(k) * 8 * U) = pk;
+            }
+            behind += 8;
+        }
+        if (!drop || t + 1 == T) {   // h rows (16 rows x 4 pieces of 16 bytes): with dropout the layer's output is y, and only the final state reads h
+            bf16_t* dst = A.h + (size_t)t * us + (size_t)(m0 + 16 * half + (lane >> 2)) * U + nt * 32 + (lane & 3) * 8;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sH[lane >> 2][(lane & 3) * 8]);
+            behind += 1;
+        }
+        if (A.hT != nullptr && t + 1 < T) {          // hT[unit][(t+1) B + row]: 16 rows = 32 bytes per unit, through the transposed tile
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sT[r * 8 + ((rp_krow(2 * j) + 4 * hh) >> 1)] = hbv[2 * j] | (hbv[2 * j + 1] << 16);
+            RP_LDS_FENCE();
+            bf16_t* dst = A.hT + (size_t)(nt * 32 + (lane >> 1)) * A.ld_hT + (size_t)(t + 1) * B + m0 + 16 * half + (lane & 1) * 8;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(sT + (lane >> 1) * 8 + (lane & 1) * 4);
+            behind += 1;
+        }
+        if (drop) {
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sH[rp_krow(k) + 4 * hh][r] = (bf16_t)yb[k];
+            RP_LDS_FENCE();
+            bf16_t* dst = A.y + (size_t)t * us + (size_t)(m0 + 16 * half + (lane >> 2)) * U + nt * 32 + (lane & 3) * 8;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sH[lane >> 2][(lane & 3) * 8]);
+            behind += 1;
+        }
+        if (A.yT != nullptr) {
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sT[r * 8 + ((rp_krow(2 * j) + 4 * hh) >> 1)] = yb[2 * j] | (yb[2 * j + 1] << 16);
+            RP_LDS_FENCE();
+            bf16_t* dst = A.yT + (size_t)(nt * 32 + (lane >> 1)) * A.ld_yT + (size_t)t * B + m0 + 16 * half + (lane & 1) * 8;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(sT + (lane >> 1) * 8 + (lane & 1) * 4);
+            behind += 1;
+        }
+        RP_LDS_FENCE();
+        RP_TR(0, trc, t, 5);
+        rp_wait_all_but(behind);
+        if (lane == 0) rp_raise(flags + 2 * nt + half, (unsigned)(t + 1), local);
+        RP_TR(0, trc, t, 6);
+        {
+            char* cb = reinterpret_cast<char*>(A.c + (size_t)t * us + (size_t)m0 * U) + oc;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) *reinterpret_cast<float*>(cb + (size_t)rp_krow(k) * 4 * U) = creg[k];
+        }
+        RP_TR(0, trc, t, 7);
+    }
+}
+
+template <int U>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_rowpar_bwd2_kernel(RBwdArgs A) {
+    constexpr int KS4 = U / 4, HK = KS4 / 2;        // k-steps of 16 over the 4U gate columns; per wave of the pair
+    constexpr int CH = 8, NCH = HK / CH;
+    constexpr size_t OFF_TILE = (size_t)KS4 * 1024, TILE_B = 4864, OFF_X = OFF_TILE + 4 * TILE_B, OFF_HS = OFF_X + 2 * 4096;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* wl = reinterpret_cast<uint4*>(smem);     // [position][lane] 16-byte B fragments of wh_p rows nt*32 .. +31, each half of K in its walk order
+    unsigned* hs = reinterpret_cast<unsigned*>(smem + OFF_HS);
+    int* s_local = reinterpret_cast<int*>(smem + OFF_HS + 32);
+    const int grp = blockIdx.x % A.G, nt = blockIdx.x / A.G;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = w >> 1, half = w & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int T = A.T, B = A.B, nrt = A.nrt;
+    const int nb = U / 32;
+    unsigned* status = A.sync;
+    if (threadIdx.x < 8) hs[threadIdx.x] = 0u;
+    rp_probe_xcd(A.sync + RP_FLAGS_OFF + 32 * nrt + 32 * grp, status, nt, nb, s_local);
+    const int rot = (8 * nt) & (HK - 1);            // rotation of the walk inside a K half, in whole chunks (speed only)
+#pragma unroll 4
+    for (int i = 0; i < KS4 / 4; ++i) {
+        const int e = i * 256 + (int)threadIdx.x;
+        const int p = e >> 6, ln = e & 63;
+        const int ks = (p / HK) * HK + ((p % HK + rot) & (HK - 1));
+        wl[e] = *reinterpret_cast<const uint4*>(A.wh_p + (size_t)(nt * 32 + (ln & 31)) * 4 * U + 16 * ks + 8 * (ln >> 5));
+    }
+    __syncthreads();
+    const bool local = A.allow_local && *s_local != 0;
+    const int rt = grp + A.G * slot;
+    if (rt >= nrt) return;
+    char* tile = smem + OFF_TILE + (size_t)w * TILE_B;
+    bf16_t (*sZ)[136] = reinterpret_cast<bf16_t (*)[136]>(tile);               // dz of this wave's 16 rows [row][gate*32 + unit] (+pad): 4352 bytes
+    float4* xsend = reinterpret_cast<float4*>(smem + OFF_X + (size_t)slot * 4096 + (size_t)half * 2048);
+    const float4* xrecv = reinterpret_cast<const float4*>(smem + OFF_X + (size_t)slot * 4096 + (size_t)(half ^ 1) * 2048);
+    unsigned* my_ready = hs + slot * 4 + half;
+    const unsigned* peer_ready = hs + slot * 4 + (half ^ 1);
+    unsigned* my_taken = hs + slot * 4 + 2 + half;
+    const unsigned* peer_taken = hs + slot * 4 + 2 + (half ^ 1);
+    unsigned* flags = A.sync + RP_FLAGS_OFF + rt * 32;
+    const int m0 = rt * 32, unit = nt * 32 + r;
+    const int rb = 16 * half + 4 * hh;
+    const size_t us = (size_t)B * U, slab = (size_t)KS4 * 1024;
+    const bool drop = A.mask != nullptr;
+    const float ikp = 1.0f / A.kp;
+    const unsigned og = (unsigned)(rb * 4 * U + unit * 4) * 4u;
+    const unsigned oc = (unsigned)(rb * U + unit) * 4u;
+    float dcreg[8], cnext[8], dbv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dcreg[k] = 0.f;
+    {
+        const char* cb = reinterpret_cast<const char*>(A.c + (size_t)(T - 1) * us + (size_t)m0 * U) + oc;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cnext[k] = *reinterpret_cast<const float*>(cb + (size_t)rp_krow(k) * 4 * U);
+    }
+    uint2 gv[8];
+    float4 cq[2], dq[2];
+    uint4 mq = make_uint4(0u, 0u, 0u, 0u);
+    float cp[8];
+    const int srow = lane >> 3, spc = lane & 7;
+    auto prefetch = [&](int t) {
+        const float* pb = A.c + (size_t)(t > 0 ? t - 1 : 0) * us + (size_t)(m0 + 16 * half + srow) * U + nt * 32 + spc * 4;
+        const float* db = A.dh_ext + (size_t)t * us + (size_t)(m0 + 16 * half + srow) * U + nt * 32 + spc * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            cq[j] = *reinterpret_cast<const float4*>(pb + (size_t)(8 * j) * U);
+            dq[j] = *reinterpret_cast<const float4*>(db + (size_t)(8 * j) * U);
+        }
+        if (drop && lane < 32) mq = *reinterpret_cast<const uint4*>(A.mask + (size_t)t * us + (size_t)(m0 + 16 * half + (lane >> 1)) * U + nt * 32 + (lane & 1) * 16);
+        const char* gb = reinterpret_cast<const char*>(A.gates + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og / 2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gv[k] = *reinterpret_cast<const uint2*>(gb + (size_t)rp_krow(k) * 8 * U);
+    };
+    prefetch(T - 1);
+    const bool trc = nt == 0 && rt == 0 && half == 0;
+    for (int kk = 0; kk < T; ++kk) {
+        const int t = T - 1 - kk;
+        RP_TR(1, trc, kk, 0);
+        if (kk > 0 && !rp_wait(flags + half * nb, status, nb, (unsigned)kk)) return;      // the producers of this wave's K half (both row halves)
+        RP_TR(1, trc, kk, 1);
+        f32x16_t acc;
+        {
+            const __amdgpu_buffer_rsrc_t rs = rp_rsrc(kk > 0 ? A.dzx + ((size_t)(t + 1) * nrt + rt) * slab : A.dzx0 + (size_t)rt * slab, slab);
+            bf16x8_t a[RP_RING][CH];
+            auto issue = [&](int ch) {
+#pragma unroll
+                for (int s = 0; s < CH; ++s)
+                    a[ch % RP_RING][s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(
+                        rs, (((half * HK + ((ch * CH + s + rot) & (HK - 1))) * 64 + lane) * 16), 0, RP_SC1));
+            };
+#pragma unroll
+            for (int ch = 0; ch < RP_RING - 1 && ch < NCH; ++ch) issue(ch);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+            const uint4* wlh = wl + (size_t)half * HK * 64;
+            bf16x8_t bq[2][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[0][q] = __builtin_bit_cast(bf16x8_t, wlh[q * 64 + lane]);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                if (ch + RP_RING - 1 < NCH) issue(ch + RP_RING - 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s4 = 0; s4 < CH / 4; ++s4) {
+                    const int f4 = ch * (CH / 4) + s4;
+                    if (f4 + 1 < HK / 4) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bq[(f4 + 1) & 1][q] = __builtin_bit_cast(bf16x8_t, wlh[((f4 + 1) * 4 + q) * 64 + lane]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ch % RP_RING][s4 * 4 + q], bq[f4 & 1][q], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        RP_TR(1, trc, kk, 2);
+        // ---- pair exchange: my partial dh of the partner's rows goes out, its partial of my rows comes in ----
+        float dhp[8];
+        {
+            if (kk > 0 && !rp_pair_wait(peer_taken, (unsigned)kk, status)) return;
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float4 o4;
+                o4.x = half ? acc[4 * q + 0] : acc[8 + 4 * q + 0];
+                o4.y = half ? acc[4 * q + 1] : acc[8 + 4 * q + 1];
+                o4.z = half ? acc[4 * q + 2] : acc[8 + 4 * q + 2];
+                o4.w = half ? acc[4 * q + 3] : acc[8 + 4 * q + 3];
+                xsend[q * 64 + lane] = o4;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dhp[k] = half ? acc[8 + k] : acc[k];
+            RP_LDS_FENCE();
+            if (lane == 0) rp_lds_st(my_ready, (unsigned)(kk + 1));
+            if (!rp_pair_wait(peer_ready, (unsigned)(kk + 1), status)) return;
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4 i4 = xrecv[q * 64 + lane];
+                dhp[4 * q + 0] += i4.x; dhp[4 * q + 1] += i4.y; dhp[4 * q + 2] += i4.z; dhp[4 * q + 3] += i4.w;
+            }
+            RP_LDS_FENCE();
+            if (lane == 0) rp_lds_st(my_taken, (unsigned)(kk + 1));
+        }
+        float dhx[8];
+        {   // staged operands of this wave's 16 rows -> their (row, unit) lanes through the (idle) tile buffer
+            float* st_c = reinterpret_cast<float*>(tile);
+            float* st_d = reinterpret_cast<float*>(tile + 64 * RP_STG);
+            uint8_t* st_m = reinterpret_cast<uint8_t*>(tile + 4224);
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {               // component stores: whole-float4 stores of cq / dq send the arrays to scratch memory
+                float* pc_ = st_c + (srow + 8 * j) * RP_STG + spc * 4;
+                float* pd_ = st_d + (srow + 8 * j) * RP_STG + spc * 4;
+                pc_[0] = cq[j].x; pc_[1] = cq[j].y; pc_[2] = cq[j].z; pc_[3] = cq[j].w;
+                pd_[0] = dq[j].x; pd_[1] = dq[j].y; pd_[2] = dq[j].z; pd_[3] = dq[j].w;
+            }
+            if (drop && lane < 32) *reinterpret_cast<uint4*>(st_m + (lane >> 1) * 32 + (lane & 1) * 16) = mq;
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int lr = rp_krow(k) + 4 * hh;
+                cp[k] = st_c[lr * RP_STG + r];
+                const float dv = st_d[lr * RP_STG + r];
+                dhx[k] = drop ? dv * ikp * (float)st_m[lr * 32 + r] : dv;
+            }
+            RP_LDS_FENCE();
+        }
+        unsigned bz[4][8];                        // bf16 dz by gate and register row
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float gi = __uint_as_float(gv[k].x << 16), gg = __uint_as_float(gv[k].x & 0xffff0000u);
+            const float gf = __uint_as_float(gv[k].y << 16), go = __uint_as_float(gv[k].y & 0xffff0000u);
+            const float dh = dhx[k] + dhp[k];
+            const float tc = fast_tanh(cnext[k]);
+            const float d_o = dh * tc;
+            const float d_c = dh * go * (1.f - tc * tc) + dcreg[k];
+            const float cprev = t > 0 ? cp[k] : 0.f;
+            const float dzv[4] = {d_c * gg * gi * (1.f - gi), d_c * gi * (1.f - gg * gg), d_c * cprev * gf * (1.f - gf), d_o * go * (1.f - go)};
+            dcreg[k] = d_c * gf;
+            cnext[k] = cprev;
+            const int lr = rp_krow(k) + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bf16_t b = f32_to_bf16(dzv[g]);
+                sZ[lr][32 * g + r] = b;
+                dbv[g] += bf16_to_f32(b);
+                bz[g][k] = (unsigned)b;
+            }
+        }
+        RP_LDS_FENCE();
+        RP_TR(1, trc, kk, 3);
+        {   // hand-off of this wave's 16 rows: k-steps 8 nt .. 8 nt + 7 of the slab, two k-steps per store
+            const __amdgpu_buffer_rsrc_t rs = rp_rsrc(A.dzx + ((size_t)t * nrt + rt) * slab, slab);
+            const int kh = (lane >> 4) & 1, rl = lane & 15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ks = 2 * j + (lane >> 5);
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&sZ[rl][ks * 16 + kh * 8]);
+                const int off = (((8 * nt + ks) * 64) + kh * 32 + 16 * half + rl) * 16;
+                if (local) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, RP_SC1);
+            }
+        }
+        RP_TR(1, trc, kk, 4);
+        int behind = 0;
+        if (kk + 1 < T) { prefetch(t - 1); behind += drop ? 13 : 12; }
+        if (A.dzc != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = j * 64 + lane, row = p >> 4, pc = p & 15;
+                *reinterpret_cast<uint4*>(A.dzc + ((size_t)t * B + m0 + 16 * half + row) * 4 * U + nt * 128 + pc * 8) = *reinterpret_cast<const uint4*>(&sZ[row][pc * 8]);
+            }
+            behind += 4;
+        }
+        if (A.dzT != nullptr) {                  // dzT[nt*128 + 32 g + unit][t B + row]: 16 rows = 32 bytes per (gate, unit), through the transposed tile
+            unsigned* sT = reinterpret_cast<unsigned*>(tile);        // [gate*32 + unit][8 row pairs], over the dz tile (read above)
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sT[(g * 32 + r) * 8 + ((rp_krow(2 * j) + 4 * hh) >> 1)] = bz[g][2 * j] | (bz[g][2 * j + 1] << 16);
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = j * 64 + lane, gu = p >> 1, piece = p & 1;
+                *reinterpret_cast<uint4*>(A.dzT + (size_t)(nt * 128 + gu) * A.ld_t + (size_t)t * B + m0 + 16 * half + piece * 8) =
+                    *reinterpret_cast<const uint4*>(sT + gu * 8 + piece * 4);
+            }
+            behind += 4;
+        }
+        RP_LDS_FENCE();
+        RP_TR(1, trc, kk, 5);
+        rp_wait_all_but(behind);
+        if (lane == 0) rp_raise(flags + 2 * nt + half, (unsigned)(kk + 1), local);
+        RP_TR(1, trc, kk, 6);
+        RP_TR(1, trc, kk, 7);
+    }
+    if (A.db_p != nullptr) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float s2 = dbv[g] + __shfl_xor(dbv[g], 32);
+            if (hh == 0) atomicAdd(A.db_p + nt * 128 + 32 * g + r, s2);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 static int rp_cu_count() {
     static int n = -1;
@@ -573,9 +1069,18 @@ static bool rp_plan(int B, int U, bool bwd, int& nrt, int& G) {
     nrt = B / 32;
     G = cus / nb;
     if (G > nrt) G = nrt;
+    if (const char* e = getenv("MNN_ROWPAR_MAX_G")) G = std::max(1, std::min(G, atoi(e)));      // test hook: several row tiles per workgroup at small B
     const int tiles = (nrt + G - 1) / G;
     const int maxw = (bwd && U == 512) ? 3 : 4;     // LDS: the backward tile buffers are 10 KiB per wave next to 128 KiB of weights
     return tiles <= maxw;
+}
+// wave-pair forms: at most two row tiles per workgroup (two waves per item, four waves per workgroup)
+static bool rp_pair(int B, int U) {
+    static int off = -1;
+    if (off < 0) off = getenv("MNN_ROWPAR_NO_PAIR") != nullptr ? 1 : 0;
+    int nrt, G;
+    if (off || !rp_plan(B, U, false, nrt, G)) return false;
+    return (nrt + G - 1) / G <= 2;
 }
 static size_t rp_sync_bytes(int nrt) { return ((size_t)RP_FLAGS_OFF + 64 * (size_t)nrt) * sizeof(unsigned); }      // flag lines, then one XCC-id line per row-tile group
 static size_t rp_edge_bytes(int nrt, int U) { return (size_t)nrt * (size_t)(U / 4) * 1024; }         // zero slabs standing for dz[T] (>= h[-1]'s)
@@ -634,6 +1139,16 @@ extern "C" int mnn_lstm_rowpar_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_
     hipLaunchKernelGGL(rp_reset_kernel, dim3(8), dim3(256), 0, st, (unsigned*)workspace, (int)(rp_sync_bytes(a.nrt) / sizeof(unsigned)));
     MNN_HIP(mnn_zero_async((char*)workspace + rp_sync_bytes(a.nrt), rp_edge_bytes(a.nrt, U), st));
     const int grid = a.G * (U / 32);
+    if (rp_pair(B, U)) {
+        const size_t lds2 = (size_t)(U / 16) * 4096 + 4 * 2304 + 2 * 8192 + 64;
+        static bool p512 = false, p256 = false, p128 = false;
+        hipError_t e2;
+        if (U == 512) e2 = rp_launch(lstm_rowpar_fwd2_kernel<512>, p512, grid, lds2, st, a);
+        else if (U == 256) e2 = rp_launch(lstm_rowpar_fwd2_kernel<256>, p256, grid, lds2, st, a);
+        else e2 = rp_launch(lstm_rowpar_fwd2_kernel<128>, p128, grid, lds2, st, a);
+        MNN_HIP(e2);
+        return MNN_OK;
+    }
     const size_t lds = (size_t)(U / 16) * 4096 + 4 * 5120 + 16;
     static bool set512 = false, set256 = false, set128 = false;
     hipError_t e;
@@ -662,6 +1177,16 @@ extern "C" int mnn_lstm_rowpar_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_
     hipLaunchKernelGGL(rp_reset_kernel, dim3(8), dim3(256), 0, st, (unsigned*)workspace, (int)(rp_sync_bytes(a.nrt) / sizeof(unsigned)));
     MNN_HIP(mnn_zero_async((char*)workspace + rp_sync_bytes(a.nrt), rp_edge_bytes(a.nrt, U), st));
     const int grid = a.G * (U / 32);
+    if (rp_pair(B, U)) {
+        const size_t lds2 = (size_t)(U / 4) * 1024 + 4 * 4864 + 2 * 4096 + 64;
+        static bool p512 = false, p256 = false, p128 = false;
+        hipError_t e2;
+        if (U == 512) e2 = rp_launch(lstm_rowpar_bwd2_kernel<512>, p512, grid, lds2, st, a);
+        else if (U == 256) e2 = rp_launch(lstm_rowpar_bwd2_kernel<256>, p256, grid, lds2, st, a);
+        else e2 = rp_launch(lstm_rowpar_bwd2_kernel<128>, p128, grid, lds2, st, a);
+        MNN_HIP(e2);
+        return MNN_OK;
+    }
     const size_t lds = (size_t)(U / 4) * 1024 + (size_t)((U == 512) ? 3 : 4) * 10240 + 16;
     static bool set512 = false, set256 = false, set128 = false;
     hipError_t e;

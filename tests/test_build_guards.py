@@ -22,6 +22,6 @@ def test_rowpar_kernels_use_no_scratch_memory(tmp_path):
     text = open(out).read()
     sizes = {m.group(1): int(m.group(2))
              for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text)}
-    kernels = {k: v for k, v in sizes.items() if "lstm_rowpar_fwd_kernel" in k or "lstm_rowpar_bwd_kernel" in k}
-    assert len(kernels) >= 6, sizes                       # three widths x forward / backward
+    kernels = {k: v for k, v in sizes.items() if "lstm_rowpar_" in k and "kernel" in k}
+    assert len(kernels) >= 12, sizes                      # three widths x forward / backward x (one wave | a wave pair) per item
     assert all(v == 0 for v in kernels.values()), kernels

@@ -173,12 +173,17 @@ def test_target_shape_train_step_properties():
     assert all(np.isfinite(ls)) and ls[-1] < ls[0], ls
 
 
-@pytest.mark.parametrize("units,B,T", [([512, 256], 64, 8), ([128, 128, 128], 96, 6), ([256], 32, 5)])
-def test_rowpar_recurrence_vs_oracle(units, B, T):
+@pytest.mark.parametrize("units,B,T,max_g", [([512, 256], 64, 8, None), ([128, 128, 128], 96, 6, None), ([256], 32, 5, None),
+                                             ([512, 256], 64, 6, 1), ([256], 128, 5, 1)])
+def test_rowpar_recurrence_vs_oracle(units, B, T, max_g, monkeypatch):
     """The row-parallel persistent recurrence (lstm_rowpar.hip: one launch per layer, weights in LDS, a wave per 32-row tile -- the form
     for B >= 512) against the float64 oracle, with its batch threshold lowered so the oracle stays quick: loss, NLL and every gradient
-    within the bf16 bounds of the two-layer persistent form; it must also agree with the launch-per-step kernels on the same weights."""
+    within the bf16 bounds of the two-layer persistent form; it must also agree with the launch-per-step kernels on the same weights.
+    Up to two row tiles per workgroup run as wave pairs (two waves per (row tile, unit tile) item); `max_g` = 1 (test hook MNN_ROWPAR_MAX_G)
+    puts all row tiles of the small batch on one workgroup per unit tile: two tiles = both pair slots, four tiles = the one-wave-per-tile form."""
     from multinn_amd import RnnNade
+    if max_g is not None:
+        monkeypatch.setenv("MNN_ROWPAR_MAX_G", str(max_g))
     rho = 0.05
     x = synth(B, T, 29, rho)
     p = G.init_rnn_nade(31, D, D, HN, units, np.float64)
