@@ -153,6 +153,7 @@ typedef struct { int units; const float* xproj; const void* wh_t; const void* h0
                  void* hT; int ld_hT; void* y; const uint8_t* mask; const void* wx_t; int ld_w; const float* bias_p;
                  void* yT; int ld_yT; /* persistent form only (else NULL): transposed copy of the layer's output (y, or h without
                                          dropout), yT[unit][t*B + row] -- the K-contiguous operand of the next weight gradient */
+                 int xproj_bf16;      /* mnn_lstm_rowpar_fwd only: xproj points at BF16 [T,B,4u] (gate-minor, bias included) instead of f32 */
                } mnn_lstm_fwd_layer;
 typedef struct { int units; const float* dh_ext; const void* wh_p; const float* gates; const float* c; const float* c0; float* dz;
                  void* dz_T; void* workspace; void* dzT_t; int ld_t; float* db_p; const uint8_t* mask; const void* wx_p; } mnn_lstm_bwd_layer;
@@ -190,7 +191,8 @@ int mnn_lstm2_persist_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer
 /* Row-parallel persistent recurrence of ONE layer (multinn_amd/csrc/lstm_rowpar.hip), the form for B >= 512: a workgroup keeps its 32-unit
  * slice of the recurrent weights in LDS, every WAVE owns one 32-row tile for the whole sequence (no K split, no workgroup barrier in the
  * loop); the layers run as separate launches with the next layer's input projection (mnn_gemm_tn) between them.  Same layer descriptors as
- * above, with: forward -- L->xproj GATE-MINOR f32 [T,B,4u] including the bias (mnn_lstm_rows_gate_minor); L->gates points at BF16 [T,B,4u]
+ * above, with: forward -- L->xproj GATE-MINOR f32 (or, with L->xproj_bf16, bf16: half the bytes of the step's largest tensor, written by
+ * mnn_gemm_tn with a bf16 C) [T,B,4u] including the bias (mnn_lstm_rows_gate_minor); L->gates points at BF16 [T,B,4u]
  * (gate-minor; half the bytes of the other forms' f32 copy: the saved activations only feed products that are rounded to bf16 anyway, and
  * only mnn_lstm_rowpar_bwd reads them); with a keep mask (L->mask, L->y) the layer's output is y and L->h receives ONLY its last timestep
  * (the final state) -- the rows of h[0 .. T-2] are left untouched; L->wx_t / bias_p unused, no initial state (h0 = c0 = NULL: a window starts from the zero state, train.py:165-173); backward -- L->dh_ext f32 [T,B,u]

@@ -53,7 +53,7 @@ SIGNATURES = {
 
 class LstmFwdLayer(C.Structure):
     _fields_ = [("units", _i), ("xproj", _p), ("wh_t", _p), ("h0", _p), ("c0", _p), ("gates", _p), ("c", _p), ("h", _p), ("hT", _p), ("ld_hT", _i), ("y", _p), ("mask", _p),
-                ("wx_t", _p), ("ld_w", _i), ("bias_p", _p), ("yT", _p), ("ld_yT", _i)]
+                ("wx_t", _p), ("ld_w", _i), ("bias_p", _p), ("yT", _p), ("ld_yT", _i), ("xproj_bf16", _i)]
 
 
 class LstmBwdLayer(C.Structure):

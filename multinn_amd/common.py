@@ -110,6 +110,15 @@ class ParamStore:
     def __getitem__(self, name):
         return self.views[name]
 
+    def offset(self, name):
+        """First word of variable `name` in the flat buffers (declaration order)."""
+        off = 0
+        for n, shape, _ in self._specs:
+            if n == name:
+                return off
+            off += math.prod(shape)
+        raise KeyError(name)
+
     def names(self):
         return [n for n, _, _ in self._specs]
 
@@ -265,7 +274,8 @@ class NADE(Model):
     def __init__(self, num_dims, num_hidden=128, internal_bias=False, name="nade"):
         super().__init__(name=name)
         if internal_bias:
-            raise NotImplementedError("internal_bias=True NADE is not used by the hot path (rnn_nade.py:28 default False)")
+            raise NotImplementedError("a standalone NADE with internal biases is not built: RnnNade / RnnMultiNADE(internal_bias=True) fold "
+                                      "them into the Dense bias (generators.py), which is the only place the reference uses them (rnn_nade.py:245-251)")
         if num_hidden > 256:
             raise ValueError("NADE hidden units > 256 are not supported by the HIP scan kernels")
         self._num_dims, self._num_hidden, self._internal_bias = num_dims, num_hidden, internal_bias

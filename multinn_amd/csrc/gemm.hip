@@ -1262,6 +1262,7 @@ static LstmFwdArgs make_fwd_args(const mnn_lstm_fwd_layer* L, int T, int B, int 
 
 extern "C" int mnn_lstm2_seq_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L1, const mnn_lstm_fwd_layer* L2, float keep_prob,
                                  int s_begin, int s_end) {
+    MNN_REQUIRE(L1 && L2 && !L1->xproj_bf16 && !L2->xproj_bf16, "this form reads f32 input projections (xproj_bf16 is for mnn_lstm_rowpar_fwd)");
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(L1 && L2 && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm2_seq_fwd: bad arguments");
     MNN_REQUIRE(lstm_v2_ok(MNN_BF16, L1->units) && lstm_v2_ok(MNN_BF16, L2->units), "mnn_lstm2_seq_fwd: units must be 128/256/512 (bf16)");

@@ -898,6 +898,7 @@ static PFwdLayer fwd_layer(const mnn_lstm_fwd_layer* L) {
 
 extern "C" int mnn_lstm2_persist_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L1, const mnn_lstm_fwd_layer* L2, float keep_prob,
                                      void* workspace) {
+    MNN_REQUIRE(L1 && L2 && !L1->xproj_bf16 && !L2->xproj_bf16, "this form reads f32 input projections (xproj_bf16 is for mnn_lstm_rowpar_fwd)");
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(L1 && L2 && workspace && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm2_persist_fwd: bad arguments");
     MNN_REQUIRE(((size_t)workspace & 255) == 0, "mnn_lstm2_persist_fwd: workspace must be 256-byte aligned");

@@ -83,6 +83,18 @@ struct RFwdArgs {
     char* hx; const char* hx0; unsigned* sync;
     int T, B, nrt, G, allow_local; float kp;
 };
+// xproj as stored: f32 float4 (i, g, f, o) per (row, unit), or four bf16 in 8 bytes (template parameter XB of the forward kernels)
+template <bool XB> struct RpX;
+template <> struct RpX<false> {
+    typedef float4 T;
+    static __device__ __forceinline__ float4 get(const float4& v) { return v; }
+};
+template <> struct RpX<true> {
+    typedef uint2 T;
+    static __device__ __forceinline__ float4 get(const uint2& v) {
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    }
+};
 
 // Launch start: do the U/32 workgroups of this row-tile group share an XCD?  Each posts 0x100 | XCC_ID (device scope), wave 0 waits for the
 // others (bounded) and compares; the answer reaches the other waves through LDS at the barrier that follows the weight load.  It only
@@ -150,7 +162,7 @@ __device__ __forceinline__ bool rp_pair_wait(const unsigned* word, unsigned need
 // MFMA chain, weights from LDS one k-step ahead | gate pointwise in registers | hand-off stores, then the row-major stores (gates, c, h, y,
 // h^T, y^T: 28 KB per tile) | wait for the hand-off stores only, raise the flag | request the next step's xproj and keep bytes.
 // ------------------------------------------------------------------------------------------------------------------
-template <int U>
+template <int U, bool XB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_rowpar_fwd_kernel(RFwdArgs A) {
     constexpr int KS = U / 16;                      // k-steps of 16 over the recurrent width
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -190,7 +202,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const unsigned om = (unsigned)((4 * hh) * U + unit);                      // keep mask (byte)
     const int prow = lane >> 1, pp = (lane & 1) * 2;                          // tile stores: 32 rows x 4 pieces of 16 bytes, two pieces per lane
     f32x16_t acc[4];
-    float4 xv[16];                                  // the next step's xproj: requested behind the flag store, moved into acc behind the next wait
+    typename RpX<XB>::T xv[16];                     // the next step's xproj: requested behind the flag store, moved into acc behind the next wait
     float creg[16];
     unsigned mk[16];
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);          // the keep bytes of the next step: 16 of row (lane >> 1), units 16 (lane & 1) .. + 15
@@ -201,9 +213,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // come as ONE 16-byte load per lane and reach their (row, unit) lanes through the LDS tile at the top of the next item: a wave can
     // have 63 vector-memory operations outstanding (vmcnt is 6 bits), and 40 stores + 16 + 16 loads made every request wait for stores
     auto prefetch = [&](int t) {
-        const char* xb = reinterpret_cast<const char*>(A.xproj + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og;
+        constexpr int XS = XB ? 2 : 4;              // bytes per stored value
+        const char* xb = reinterpret_cast<const char*>(A.xproj) + ((size_t)t * 4 * us + (size_t)m0 * 4 * U) * XS + og / (4 / XS);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) xv[k] = *reinterpret_cast<const float4*>(xb + (size_t)rp_krow(k) * 16 * U);
+        for (int k = 0; k < 16; ++k) xv[k] = *reinterpret_cast<const typename RpX<XB>::T*>(xb + (size_t)rp_krow(k) * 4 * XS * U);
         if (drop) mq = *reinterpret_cast<const uint4*>(A.mask + (size_t)t * us + (size_t)(m0 + prow) * U + nt * 32 + (lane & 1) * 16);
     };
     prefetch(0);
@@ -222,7 +235,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         // all KS loads are in flight before anything else: left alone, the scheduler sinks every load next to its use and waits vmcnt(0) per MFMA
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { acc[0][k] = xv[k].x; acc[1][k] = xv[k].y; acc[2][k] = xv[k].z; acc[3][k] = xv[k].w; }   // z starts at xproj[t]
+        for (int k = 0; k < 16; ++k) { const float4 x4 = RpX<XB>::get(xv[k]); acc[0][k] = x4.x; acc[1][k] = x4.y; acc[2][k] = x4.z; acc[3][k] = x4.w; }   // z starts at xproj[t]
         if (drop) {                                 // keep bytes: [row][32 units] through the (idle) h tile
             uint8_t* mt = reinterpret_cast<uint8_t*>(&sH[0][0]);
             RP_LDS_FENCE();
@@ -571,7 +584,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 // backward consumers for the nb flags of their K half.  Transposed outputs (h^T, y^T, dz^T) leave as 8-byte stores straight from the registers
 // (a lane holds four consecutive rows of a unit), no LDS transpose.
 // ------------------------------------------------------------------------------------------------------------------
-template <int U>
+template <int U, bool XB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_rowpar_fwd2_kernel(RFwdArgs A) {
     constexpr int KS = U / 16;
     constexpr size_t OFF_TILE = (size_t)KS * 4096, TILE_B = 2304, OFF_X = OFF_TILE + 4 * TILE_B, OFF_HS = OFF_X + 2 * 8192;
@@ -620,16 +633,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const unsigned oc = (unsigned)(rb * U + unit) * 4u;                   // c (float)
     const int g0 = 2 * half;                        // this wave's two gate tiles: g0, g0 + 1
     f32x16_t acc[2];
-    float4 xv[8];
+    typename RpX<XB>::T xv[8];
     float creg[8];
     unsigned mk[8];
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int k = 0; k < 8; ++k) { creg[k] = 0.f; mk[k] = 0u; }
     auto prefetch = [&](int t) {
-        const char* xb = reinterpret_cast<const char*>(A.xproj + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og;
+        constexpr int XS = XB ? 2 : 4;              // bytes per stored value
+        const char* xb = reinterpret_cast<const char*>(A.xproj) + ((size_t)t * 4 * us + (size_t)m0 * 4 * U) * XS + og / (4 / XS);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) xv[k] = *reinterpret_cast<const float4*>(xb + (size_t)rp_krow(k) * 16 * U);
+        for (int k = 0; k < 8; ++k) xv[k] = *reinterpret_cast<const typename RpX<XB>::T*>(xb + (size_t)rp_krow(k) * 4 * XS * U);
         if (drop && lane < 32) mq = *reinterpret_cast<const uint4*>(A.mask + (size_t)t * us + (size_t)(m0 + 16 * half + (lane >> 1)) * U + nt * 32 + (lane & 1) * 16);
     };
     prefetch(0);
@@ -719,8 +733,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         unsigned hbv[8], yb[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float zi = (half ? recv[0][k] : keep[0][k]) + xv[k].x, zg = (half ? recv[1][k] : keep[1][k]) + xv[k].y;
-            const float zf = (half ? keep[0][k] : recv[0][k]) + xv[k].z, zo = (half ? keep[1][k] : recv[1][k]) + xv[k].w;
+            const float4 x4 = RpX<XB>::get(xv[k]);
+            const float zi = (half ? recv[0][k] : keep[0][k]) + x4.x, zg = (half ? recv[1][k] : keep[1][k]) + x4.y;
+            const float zf = (half ? keep[0][k] : recv[0][k]) + x4.z, zo = (half ? keep[1][k] : recv[1][k]) + x4.w;
             const float gi = fast_sigmoid(zi), gg = fast_tanh(zg), gf = fast_sigmoid(zf), go = fast_sigmoid(zo);
             const float cv = gg * gi + creg[k] * gf;
             const float hv = fast_tanh(cv) * go;
@@ -1143,18 +1158,28 @@ extern "C" int mnn_lstm_rowpar_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_
         const size_t lds2 = (size_t)(U / 16) * 4096 + 4 * 2304 + 2 * 8192 + 64;
         static bool p512 = false, p256 = false, p128 = false;
         hipError_t e2;
-        if (U == 512) e2 = rp_launch(lstm_rowpar_fwd2_kernel<512>, p512, grid, lds2, st, a);
-        else if (U == 256) e2 = rp_launch(lstm_rowpar_fwd2_kernel<256>, p256, grid, lds2, st, a);
-        else e2 = rp_launch(lstm_rowpar_fwd2_kernel<128>, p128, grid, lds2, st, a);
+        static bool q512 = false, q256 = false, q128 = false;
+        if (L->xproj_bf16) {
+            if (U == 512) e2 = rp_launch(lstm_rowpar_fwd2_kernel<512, true>, q512, grid, lds2, st, a);
+            else if (U == 256) e2 = rp_launch(lstm_rowpar_fwd2_kernel<256, true>, q256, grid, lds2, st, a);
+            else e2 = rp_launch(lstm_rowpar_fwd2_kernel<128, true>, q128, grid, lds2, st, a);
+        } else if (U == 512) e2 = rp_launch(lstm_rowpar_fwd2_kernel<512, false>, p512, grid, lds2, st, a);
+        else if (U == 256) e2 = rp_launch(lstm_rowpar_fwd2_kernel<256, false>, p256, grid, lds2, st, a);
+        else e2 = rp_launch(lstm_rowpar_fwd2_kernel<128, false>, p128, grid, lds2, st, a);
         MNN_HIP(e2);
         return MNN_OK;
     }
     const size_t lds = (size_t)(U / 16) * 4096 + 4 * 5120 + 16;
     static bool set512 = false, set256 = false, set128 = false;
     hipError_t e;
-    if (U == 512) e = rp_launch(lstm_rowpar_fwd_kernel<512>, set512, grid, lds, st, a);
-    else if (U == 256) e = rp_launch(lstm_rowpar_fwd_kernel<256>, set256, grid, lds, st, a);
-    else e = rp_launch(lstm_rowpar_fwd_kernel<128>, set128, grid, lds, st, a);
+    static bool b512 = false, b256 = false, b128 = false;
+    if (L->xproj_bf16) {
+        if (U == 512) e = rp_launch(lstm_rowpar_fwd_kernel<512, true>, b512, grid, lds, st, a);
+        else if (U == 256) e = rp_launch(lstm_rowpar_fwd_kernel<256, true>, b256, grid, lds, st, a);
+        else e = rp_launch(lstm_rowpar_fwd_kernel<128, true>, b128, grid, lds, st, a);
+    } else if (U == 512) e = rp_launch(lstm_rowpar_fwd_kernel<512, false>, set512, grid, lds, st, a);
+    else if (U == 256) e = rp_launch(lstm_rowpar_fwd_kernel<256, false>, set256, grid, lds, st, a);
+    else e = rp_launch(lstm_rowpar_fwd_kernel<128, false>, set128, grid, lds, st, a);
     MNN_HIP(e);
     return MNN_OK;
 }

@@ -120,6 +120,8 @@ class LstmStack:
     # paid several times per timestep: TGT [1024,256,88,5] forward 15.6 us per timestep there.
     rowpar = os.environ.get("MULTINN_ROWPAR", "1") != "0"
     rowpar_min_batch = int(os.environ.get("MULTINN_ROWPAR_MIN_BATCH", "512"))
+    # dtype of the input projections the row-parallel form reads (bias included): bf16 halves the bytes of the step's largest tensor
+    rowpar_xproj_dtype = torch.float32 if os.environ.get("MULTINN_ROWPAR_XPROJ", "bf16") == "f32" else torch.bfloat16
 
     def _rowpar(self, B, T=2, state0=None):
         if not (self.rowpar and self.dtype == torch.bfloat16 and state0 is None and T > 1 and B >= self.rowpar_min_batch and B % 32 == 0):
@@ -143,7 +145,8 @@ class LstmStack:
         inp, ctx, final = x_tm, [], []
         for l, p in enumerate(self.packed):
             u = p["u"]
-            xproj = torch.empty((T, B, 4 * u), device=dev)
+            # the input projection is the step's largest tensor (TGT layer 1: 2.1 GB in f32): written and read once, in bf16 by default
+            xproj = torch.empty((T, B, 4 * u), device=dev, dtype=self.rowpar_xproj_dtype)
             ops.gemm_tn(inp.view(N, -1), p["wx_gm"], xproj.view(N, -1), bias=p["bias_gm"])
             h = torch.empty((T, B, u), device=dev, dtype=self.dtype)
             mask = y = None
@@ -160,7 +163,8 @@ class LstmStack:
                 if Np != N:
                     hT[:, N:].zero_()
                 yT = zalloc((u, Np), device=dev, dtype=self.dtype)
-            d = ops.lstm2_fwd_layer(xproj, p["wh_t"], None, None, gates, c, h, hT, y, mask, yT=yT, gates_dtype=torch.bfloat16)
+            d = ops.lstm2_fwd_layer(xproj, p["wh_t"], None, None, gates, c, h, hT, y, mask, yT=yT, gates_dtype=torch.bfloat16,
+                                    xproj_dtype=self.rowpar_xproj_dtype)
             ops.lstm_rowpar_fwd(T, B, d, keep_prob, self._rp_workspace(l, T, B, dev))
             out = y if y is not None else h
             if save:
@@ -354,7 +358,8 @@ class LstmStack:
         into the store's flat gradient buffer.  Same wavefront as forward, top layer first, chunks descending;
         each layer's weight-gradient GEMMs then run on that layer's stream."""
         if need_dx:
-            raise NotImplementedError("gradient wrt the generator inputs (tune_encoder) is a 'next' row")
+            raise NotImplementedError("the gradient wrt the generator's inputs is not built (nothing on the train path consumes it: "
+                                      "generator.py:201 differentiates wrt the generator's own variables; feedback-mode training would)")
         if ctx and ctx[0].get("rowpar"):
             return self._backward_rowpar(dy, ctx, keep_prob)
         T, B, _ = dy.shape
@@ -660,8 +665,9 @@ class RnnNade(RnnEstimator):
     num_tracks = property(lambda self: len(self._tracks))
 
     def _init_estimator(self):
-        if self.internal_bias:
-            raise NotImplementedError("internal_bias=True is not on the hot path (default False, rnn_nade.py:28)")
+        # internal_bias=True (nade.py:69-87, rnn_nade.py:245-251): the NADE's own b_enc / b_dec are ADDED to the Dense outputs.  A broadcast
+        # add in front of the scan is the same as adding them to the Dense layer's bias vector, so the kernels never see them: the forward GEMM
+        # takes dense/bias + [b_enc | b_dec] (one axpby over n_out words), and their gradient is the Dense bias gradient (same column sums).
         self._nades = [NADE(self.num_dims, self.num_hidden[-1], internal_bias=False, name=f"nade_{m}") for m in range(self.num_tracks)]
         self._nade = self._nades[0]
 
@@ -674,6 +680,9 @@ class RnnNade(RnnEstimator):
         std = 1.0 / (D ** 0.5)
         self.store.declare("nade/w_enc", (M, D, Hn), truncated_normal(self._gen, std))
         self.store.declare("nade/w_dec", (M, D, Hn), truncated_normal(self._gen, std))
+        if self.internal_bias:                          # adjacent in the flat buffer, in the Dense output's column order [tracks x Hn | tracks x D]
+            self.store.declare("nade/b_enc", (M, Hn), truncated_normal(self._gen, std))
+            self.store.declare("nade/b_dec", (M, D), truncated_normal(self._gen, std))
         n_out = M * (D + Hn)
         self.store.declare("dense/kernel", (R, n_out), glorot_uniform(self._gen, R, n_out))
         self.store.declare("dense/bias", (n_out,), zeros_init)
@@ -694,10 +703,20 @@ class RnnNade(RnnEstimator):
         ops.transpose(self.store["dense/kernel"], self._fc_t)
         self._fc_p = torch.zeros((R, self.ldo), device=dev, dtype=self.dtype)           # [R, n_out]: dgrad B operand
         ops.convert2d(self.store["dense/kernel"], self._fc_p[:, :self.n_out])
+        if self.internal_bias:
+            self._fc_bias = torch.empty(self.n_out, device=dev)
+            ops.axpby(1.0, self.store["dense/bias"], 1.0, self._internal_flat(self.store.theta), self._fc_bias)
+        else:
+            self._fc_bias = self.store["dense/bias"]
         if self._nade_mfma():                           # bf16 copy of the decoder weights for the matrix-core NADE kernels
             M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
             self._wdec_bf = torch.empty((M, D, Hn), device=dev, dtype=torch.bfloat16)
             ops.convert2d(self.store["nade/w_dec"].view(M * D, Hn), self._wdec_bf.view(M * D, Hn))
+
+    def _internal_flat(self, flat):
+        """[b_enc | b_dec] of all tracks as one n_out-long slice of a flat parameter-shaped buffer (theta or its gradient)."""
+        o = self.store.offset("nade/b_enc")
+        return flat[o:o + self.n_out]
 
     nade_mfma = os.environ.get("MULTINN_NADE_MFMA", "1") != "0"
 
@@ -775,7 +794,7 @@ class RnnNade(RnnEstimator):
         if ctx and x_tmT is not None:
             ctx[0]["inT"] = x_tmT
         out = torch.empty((N, self.ldo), device=dev)      # columns >= n_out are padding of the row pitch: never read
-        ops.gemm_tn(y.view(N, -1), self._fc_t, out[:, :self.n_out], bias=self.store["dense/bias"])
+        ops.gemm_tn(y.view(N, -1), self._fc_t, out[:, :self.n_out], bias=self._fc_bias)
         nll = torch.empty((M, N), device=dev)
         cond_p = None if train else torch.empty((M, N, D), device=dev)     # the train step needs the loss only: 4 N D bytes less to write per
         rw_m = rw / M if M > 1 else rw                                       # step; `cond_probs` fills it on demand (see the property)
@@ -873,6 +892,9 @@ class RnnNade(RnnEstimator):
         else:                               # one pass over d_out: bf16 copy, bf16 transpose, bias gradient
             do_c = torch.empty((N, self.ldo), device=dev, dtype=self.dtype)
             ops.grad_rows_fanout(d_out, self.n_out, do_c, doT, g["dense/bias"])
+        if self.internal_bias:              # d b_enc / d b_dec = the Dense bias gradient (same column sums of d_out)
+            gi = self._internal_flat(self.store.grad)
+            ops.axpby(1.0, gi, 1.0, g["dense/bias"], gi)
         ops.gemm_tn(yT, doT, g["dense/kernel"], accumulate=True, split_k=LstmStack._split_k(R, self.n_out, Np))
         del yT, doT
         dy = torch.empty((N, R), device=dev)
@@ -950,7 +972,7 @@ class RnnNade(RnnEstimator):
 
     def _dense(self, h):
         out = torch.empty((h.shape[0], self.ldo), device=h.device)        # columns [n_out, ldo) are alignment only: no kernel reads them
-        ops.gemm_tn(h, self._fc_t, out[:, :self.n_out], bias=self.store["dense/bias"])
+        ops.gemm_tn(h, self._fc_t, out[:, :self.n_out], bias=self._fc_bias)
         return out
 
     def _state_from_dense(self, out, rnn_state):

@@ -101,10 +101,11 @@ class MultINNCore(Model):
         self._tracks = list(config["data"]["instruments"])
         self._feedback_module = False
         self._keep_prob = params["keep_prob"]
-        self._tune_encoder = params["tune_encoder"]
-        if self._tune_encoder:
-            raise NotImplementedError("tune_encoder=True (gradients into the encoders, multinn_joint.py:117-122) is not built; the "
-                                      "reference default is False (default_params.yaml:2)")
+        # tune_encoder only removes a tf.stop_gradient on the encoded inputs (multinn_joint.py:117-122, multi_encoder_nn.py:110-113).  No
+        # optimiser in the reference ever applies that gradient: Generator.train differentiates wrt the GENERATOR's trainable_variables
+        # only (generator.py:201), the encoders train by contrastive divergence (dbn_encoder.py:192-240), PassEncoder has no variables and
+        # the DBN codes are floor(p + u) samples (zero gradient).  Both settings therefore give the same updates; the flag is kept and reported.
+        self._tune_encoder = bool(params["tune_encoder"])
         self.precision, self.device = precision, device
         self.seed = config["training"].get("random_seed", 23) if seed is None else seed
         self.clip_norm = 5.0                               # utils/training.py:166 (hard-coded in the reference, R9)

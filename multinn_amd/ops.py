@@ -212,14 +212,16 @@ def _p0(t):
     return t.data_ptr() if t is not None else None
 
 
-def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT, y=None, mask=None, wx_t=None, bias_p=None, yT=None, gates_dtype=torch.float32):
+def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT, y=None, mask=None, wx_t=None, bias_p=None, yT=None, gates_dtype=torch.float32,
+                    xproj_dtype=torch.float32):
     """Descriptor of one layer for lstm2_seq_fwd (same tensors as lstm_seq_fwd; bf16, contiguous, time-major).
     y/mask: dropped output and u8 keep mask (keep_prob < 1); wx_t/bias_p: this layer's input projection (layer 2)."""
     _req(h.dim() == 3 and h.dtype == torch.bfloat16 and h.is_contiguous(), "lstm2: h bf16 [T,B,u]")
     T, B, u = h.shape
     N4 = 4 * u
     _req(xproj is not None or wx_t is not None, "lstm2: xproj may be omitted only for a layer with its own input projection (persistent form)")
-    _req(xproj is None or (xproj.dtype == torch.float32 and xproj.is_contiguous() and xproj.shape == (T, B, N4)), "lstm2: xproj f32 [T,B,4u]")
+    _req(xproj is None or (xproj.dtype == xproj_dtype and xproj.is_contiguous() and xproj.shape == (T, B, N4)), "lstm2: xproj [T,B,4u] of the stated dtype")
+    _req(xproj_dtype in (torch.float32, torch.bfloat16), "lstm2: xproj f32 (or bf16: row-parallel form only)")
     _req(wh_t.shape == (N4, u) and wh_t.is_contiguous() and wh_t.dtype == torch.bfloat16, "lstm2: wh_t bf16 [4u,u]")
     _req(c.dtype == torch.float32 and c.shape == (T, B, u) and c.is_contiguous(), "lstm2: c")
     _req(gates is None or (gates.dtype == gates_dtype and gates.shape == (T, B, N4) and gates.is_contiguous()), "lstm2: gates")
@@ -239,7 +241,8 @@ def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT, y=None, mask=None, wx_
         _ptr(t)
     _req(yT is None or (yT.dim() == 2 and yT.shape[0] == u and yT.stride(1) == 1 and yT.shape[1] >= T * B and yT.dtype == torch.bfloat16), "lstm2: yT")
     return _lib.LstmFwdLayer(u, _p0(xproj), _p0(wh_t), _p0(h0), _p0(c0), _p0(gates), _p0(c), _p0(h), _p0(hT), hT.stride(0) if hT is not None else 0,
-                             _p0(y), _p0(mask), _p0(wx_t), ld_w, _p0(bias_p), _p0(yT), yT.stride(0) if yT is not None else 0)
+                             _p0(y), _p0(mask), _p0(wx_t), ld_w, _p0(bias_p), _p0(yT), yT.stride(0) if yT is not None else 0,
+                             1 if xproj_dtype == torch.bfloat16 else 0)
 
 
 def lstm2_seq_fwd(T, B, L1, L2, keep_prob, s_begin=0, s_end=None):

@@ -92,6 +92,61 @@ def test_rnn_nade_joint_train_step(precision, ragged, units):
             assert np.abs(gen.store[name].cpu().numpy().reshape(ref.shape) - ref).max() < 2e-4, name
 
 
+@pytest.mark.parametrize("tracks", [1, 3])
+def test_rnn_nade_internal_bias(tracks):
+    """internal_bias=True (nade.py:69-87, rnn_nade.py:245-251): b_enc / b_dec of the NADE(s) are added to the Dense outputs.  The oracle gets
+    the same model with the internal biases folded into its Dense bias: loss, NLL and every gradient must agree (fp32, 1e-4); the internal
+    biases' gradients are the Dense bias gradient's two blocks, they are variables of the model (order rnn, nade, dense) and they move."""
+    from multinn_amd import RnnNade, RnnMultiNADE, AdamOptimizer
+    B, T, Dm, Hn, units = 5, 4, 6, 12, [32, 32]
+    R = np.random.default_rng(7 + tracks)
+    names = [f"t{m}" for m in range(tracks)]
+    if tracks == 1:
+        x = make_batch(B, T, Dm, 1, 3)
+        inp, tgt = G.joint_inputs(x.astype(np.float64))
+        gen = RnnNade(Dm, Hn, units, keep_prob=1.0, internal_bias=True, precision="fp32", seed=23)
+        p = G.init_rnn_nade(5, Dm, Dm, Hn, units, np.float64)
+    else:
+        inp = (R.random((B, T, 10)) < 0.3).astype(np.float64)
+        tgt = (R.random((B, T, Dm * tracks)) < 0.3).astype(np.float64)
+        gen = RnnMultiNADE(Dm, Hn, units, names, keep_prob=1.0, internal_bias=True, precision="fp32", seed=23)
+        p = G.init_rnn_nade(5, 10, Dm, Hn, units, np.float64, tracks=tracks)
+    gen.build(dev(inp), dev(tgt), None, is_train=True, mode="train")
+    assert gen.store.names()[-4:] == ["nade/b_enc", "nade/b_dec", "dense/kernel", "dense/bias"]
+    load_nade_params(gen, p)
+    b_int = R.standard_normal(tracks * (Hn + Dm)) * 0.2
+    gen.store["nade/b_enc"].copy_(dev(b_int[:tracks * Hn].reshape(tracks, Hn).astype(np.float32)))
+    gen.store["nade/b_dec"].copy_(dev(b_int[tracks * Hn:].reshape(tracks, Dm).astype(np.float32)))
+    gen._packed_step = -1
+    gen.build(dev(inp), dev(tgt), None, is_train=True, mode="train")
+    import copy
+    pf = copy.deepcopy(p)
+    pf['fc_b'] = p['fc_b'] + b_int                                   # the same model, biases folded
+    fw = G.rnn_nade_forward(inp, tgt, None, pf, 1.0, None, tracks=tracks)
+    g = G.rnn_nade_backward(fw, pf, tracks=tracks)
+    assert abs(float(gen.metrics['batch/loss']) - fw['loss']) < 1e-4 * abs(fw['loss'])
+    gen.backward()
+    gv = gen.store.gviews
+    ref = oracle_grad_list(g)
+    plain = [n for n in gen.store.names() if n not in ("nade/b_enc", "nade/b_dec")]
+    for name, r_ in zip(plain, ref):
+        assert rel(gv[name].cpu().numpy().reshape(r_.shape), r_) < 1e-4, name
+    assert rel(gv["nade/b_enc"].cpu().numpy().ravel(), g['fc_b'][:tracks * Hn]) < 1e-4
+    assert rel(gv["nade/b_dec"].cpu().numpy().ravel(), g['fc_b'][tracks * Hn:]) < 1e-4
+    before = gen.store["nade/b_dec"].clone()
+    gen.train(AdamOptimizer(0.01), None)
+    assert float((gen.store["nade/b_dec"] - before).abs().max()) > 1e-3           # trained like every other variable
+    # the sampling path sees the folded bias too: one step from the zero state reproduces b_dec + internal part on a zero Dense kernel
+    gen.store["dense/kernel"].zero_()
+    gen._packed_step = -1
+    gen._ensure_packed()
+    st = gen.zero_state(2)
+    out = gen.single_step(torch.zeros((2, inp.shape[-1]), device=DEV), st)
+    bd = out.b_dec if tracks == 1 else out.b_dec[0]
+    want = gen.store["dense/bias"][tracks * Hn:tracks * Hn + Dm] + gen.store["nade/b_dec"][0]
+    assert torch.allclose(bd[0], want, atol=1e-6)
+
+
 def test_rnn_nade_generic_build_equals_pianoroll_path():
     from multinn_amd import RnnNade
     B, T, P, M, Hn, units = 4, 6, 4, 2, 16, [32, 32]

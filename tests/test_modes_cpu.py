@@ -93,9 +93,8 @@ def test_mode_argument_errors_follow_the_reference():
     with pytest.raises(NotImplementedError):
         modes.MultINNComposer(config(), params("composer", gen="RBM"))                                  # multinn_composer.py:44-45
     p = params("joint")
-    p["tune_encoder"] = True
-    with pytest.raises(NotImplementedError):
-        modes.MultINNJoint(config(), p)
+    p["tune_encoder"] = True                       # only lifts a stop_gradient nobody differentiates through (generator.py:201): accepted, same updates
+    assert modes.MultINNJoint(config(), p).tune_encoder is True
     m = modes.MultINNJoint(config(P=8, num_pixels=3), params("joint"))
     assert m.num_dims == 24                                                                             # multinn_core.py:57-59
     with pytest.raises(ValueError):
