@@ -310,6 +310,11 @@ int mnn_rbm_cd_bias_delta(mnn_stream_t s, int N, int D, int Hn, const uint8_t* v
 int mnn_axpby_f32(mnn_stream_t s, long n, float a, const float* x, float b, const float* y, float* out);
 /* rbm.py:286-297 visible_bias_init_ops: bv[d] = log(1e-6 + p/(1-p)), p = colsum[d] / count (colsum: mnn_bias_grad over the batch). */
 int mnn_rbm_visible_bias_init(mnn_stream_t s, int D, const float* colsum, float count, float* bv);
+/* Rows of the LSTM-RBM cost gradient (rnn_rbm.py:113-126 over rbm.py:229, cost = F(v) - F(v_s)): d_out[n, :Hn] = w (ss - sv), d_out[n, Hn:Hn+D] =
+ * w (v_s - v), zero padding up to ld, w = row_weight[n] * scale; pos = w ss and neg = -w sv [N,Hn] are the scaled hidden blocks of the two
+ * ACCUMULATING weight-gradient products v_s^T pos + v^T neg.  v / v_s u8 [N,D]; sv / ss = sigmoid(bh + v W), sigmoid(bh + v_s W) f32 [N,Hn]. */
+int mnn_rbm_cd_rows(mnn_stream_t s, int N, int D, int Hn, int ld, const uint8_t* v, const uint8_t* v_s, const float* sv, const float* ss,
+                    const float* row_weight, float scale, float* d_out, float* pos, float* neg);
 
 /* ------------------------------------------------------------------------------------------
  * Reductions / optimiser on the flat parameter buffer.

@@ -259,9 +259,63 @@ __device__ __forceinline__ void epi_store_tiles(void* __restrict__ Cv, int ldc, 
         }
     }
 }
+// Wide form for plain / bf16 stores of an interior wave tile: every 32 x 32 accumulator tile is turned round through a wave-private LDS
+// tile ([32][36] f32: the stage buffers are idle after the K loop) so that a lane holds consecutive COLUMNS, and leaves as 16-byte stores
+// covering whole 128-byte rows (f32: 4 stores of 8 rows x 128 B per tile; bf16: 2 stores of 16 rows x 64 B) instead of sixteen 4- / 2-byte
+// stores per lane.  A CU issues stores at a fixed instruction rate whatever their width (the element-wise epilogue of a 256 x 256 f32 tile:
+// 128 store instructions per lane, ~11 us at K = 448 next to ~12 us of K loop), so the bytes per instruction are what counts.
+#define EPI_SC_FLOATS 1152        // per-wave scratch: 32 rows x 36 floats
+#ifndef EPI_WIDE
+#define EPI_WIDE 1
+#endif
+template <int MODE, int NI, int NJ>
+__device__ __forceinline__ void epi_store_wide(void* __restrict__ Cv, int ldc, int row0, int col0, const f32x16_t (&acc)[NI][NJ],
+                                               const float* __restrict__ bias, int lane, float* __restrict__ sc) {
+    const int r = lane & 31, hh = lane >> 5;
+    float* Cf = reinterpret_cast<float*>(Cv);
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const float bv = bias != nullptr ? bias[col0 + j * 32 + r] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sc[((e & 3) + 8 * (e >> 2) + 4 * hh) * 36 + r] = acc[i][j][e] + bv;
+            asm volatile("" ::: "memory");
+            if (MODE == EPI_BF16) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int row = 16 * p + (lane >> 2), c8 = 8 * (lane & 3);
+                    const float4 v0 = *reinterpret_cast<const float4*>(sc + row * 36 + c8);
+                    const float4 v1 = *reinterpret_cast<const float4*>(sc + row * 36 + c8 + 4);
+                    uint4 pk;
+                    pk.x = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16);
+                    pk.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
+                    pk.z = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16);
+                    pk.w = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
+                    *reinterpret_cast<uint4*>(Cb + (size_t)(row0 + i * 32 + row) * ldc + col0 + j * 32 + c8) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int row = 8 * p + (lane >> 3), c4 = 4 * (lane & 7);
+                    *reinterpret_cast<float4*>(Cf + (size_t)(row0 + i * 32 + row) * ldc + col0 + j * 32 + c4) = *reinterpret_cast<const float4*>(sc + row * 36 + c4);
+                }
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+}
 template <int NI, int NJ>
 __device__ __forceinline__ void epi_dispatch(void* __restrict__ Cv, int ldc, int c_bf16, int flags, int M, int N, int row0, int col0,
-                                             const f32x16_t (&acc)[NI][NJ], const float* __restrict__ bias, int lane) {
+                                             const f32x16_t (&acc)[NI][NJ], const float* __restrict__ bias, int lane, float* __restrict__ sc = nullptr) {
+    if (sc != nullptr && !(flags & (MNN_GEMM_ATOMIC | MNN_GEMM_ACCUMULATE)) && row0 + NI * 32 <= M && col0 + NJ * 32 <= N &&
+        ((size_t)Cv & 15) == 0 && (ldc & (c_bf16 ? 7 : 3)) == 0) {               // all wave-uniform
+        if (c_bf16) epi_store_wide<EPI_BF16, NI, NJ>(Cv, ldc, row0, col0, acc, bias, lane, sc);
+        else epi_store_wide<EPI_STORE, NI, NJ>(Cv, ldc, row0, col0, acc, bias, lane, sc);
+        return;
+    }
     if (c_bf16) epi_store_tiles<EPI_BF16, NI, NJ>(Cv, ldc, M, N, row0, col0, acc, bias, lane);
     else if (flags & MNN_GEMM_ATOMIC) epi_store_tiles<EPI_ATOMIC, NI, NJ>(Cv, ldc, M, N, row0, col0, acc, bias, lane);
     else if (flags & MNN_GEMM_ACCUMULATE) epi_store_tiles<EPI_ACCUM, NI, NJ>(Cv, ldc, M, N, row0, col0, acc, bias, lane);
@@ -361,7 +415,8 @@ gemm_tn_glds_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restr
         __syncthreads();
         cur ^= 1;
     }
-    epi_dispatch<2, 2>(Cv, ldc, c_bf16, flags, M, N, m0 + wm * 64, n0 + wn * 64, acc, z == 0 ? bias : nullptr, lane);
+    epi_dispatch<2, 2>(Cv, ldc, c_bf16, flags, M, N, m0 + wm * 64, n0 + wn * 64, acc, z == 0 ? bias : nullptr, lane,
+                       EPI_WIDE ? reinterpret_cast<float*>(&smem[0][0][0]) + wave * EPI_SC_FLOATS : nullptr);      // the K loop ended with a barrier
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -431,7 +486,8 @@ gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
         __syncthreads();
         cur ^= 1;
     }
-    epi_dispatch<4, 2>(Cv, ldc, c_bf16, flags, M, N, m0 + wm * 128, n0 + wn * 64, acc, z == 0 ? bias : nullptr, lane);
+    epi_dispatch<4, 2>(Cv, ldc, c_bf16, flags, M, N, m0 + wm * 128, n0 + wn * 64, acc, z == 0 ? bias : nullptr, lane,
+                       EPI_WIDE ? reinterpret_cast<float*>(smem256) + wave * EPI_SC_FLOATS : nullptr);             // the K loop ended with a barrier
 }
 
 template <typename T>

@@ -446,3 +446,34 @@ extern "C" int mnn_rbm_visible_bias_init(mnn_stream_t s, int D, const float* col
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
+
+// Rows of the LSTM-RBM cost gradient (rnn_rbm.py:113-126 through rbm.py:229: cost = F(v) - F(v_s), v_s constant):
+//   d cost / d bh_t = w (sigmoid(z(v_s)) - sigmoid(z(v))),   d cost / d bv_t = w (v_s - v),   w = row_weight * scale
+// written into the Dense-output-shaped block d_out [N, ld] (columns [Hn + D, ld) zeroed), together with the two scaled hidden blocks whose
+// products with v_s^T and v^T give d cost / d W = v_s^T (w ss) - v^T (w sv):  pos = w ss,  neg = -w sv  (so that both GEMMs ACCUMULATE).
+__global__ void __launch_bounds__(256) rbm_cd_rows_kernel(int N, int D, int Hn, int ld, const uint8_t* __restrict__ v, const uint8_t* __restrict__ vs,
+                                                          const float* __restrict__ sv, const float* __restrict__ ss, const float* __restrict__ rw,
+                                                          float scale, float* __restrict__ d_out, float* __restrict__ pos, float* __restrict__ neg) {
+    const int n = blockIdx.x;
+    const float w = rw[n] * scale;
+    for (int j = threadIdx.x; j < ld; j += 256) {
+        float o = 0.f;
+        if (j < Hn) {
+            const float a = ss[(size_t)n * Hn + j], b = sv[(size_t)n * Hn + j];
+            o = w * (a - b);
+            pos[(size_t)n * Hn + j] = w * a;
+            neg[(size_t)n * Hn + j] = -(w * b);
+        } else if (j < Hn + D) {
+            const int i = j - Hn;
+            o = w * ((float)vs[(size_t)n * D + i] - (float)v[(size_t)n * D + i]);
+        }
+        d_out[(size_t)n * ld + j] = o;
+    }
+}
+extern "C" int mnn_rbm_cd_rows(mnn_stream_t s, int N, int D, int Hn, int ld, const uint8_t* v, const uint8_t* v_s, const float* sv, const float* ss,
+                               const float* row_weight, float scale, float* d_out, float* pos, float* neg) {
+    MNN_REQUIRE(N > 0 && D > 0 && Hn > 0 && ld >= Hn + D && v && v_s && sv && ss && row_weight && d_out && pos && neg, "mnn_rbm_cd_rows: bad arguments");
+    hipLaunchKernelGGL(rbm_cd_rows_kernel, dim3(N), dim3(256), 0, (hipStream_t)s, N, D, Hn, ld, v, v_s, sv, ss, row_weight, scale, d_out, pos, neg);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}

@@ -1153,25 +1153,24 @@ class RnnRBM(RnnEstimator):
         sv = torch.empty((N, Hn), device=dev); ss = torch.empty((N, Hn), device=dev)
         ops.rbm_hidden(cx["tgt"], self._rbm.W, cx["bh_u"], 0, 0, 0, 0, sv, None)
         ops.rbm_hidden(cx["v_s"], self._rbm.W, cx["bh_u"], 0, 0, 0, 0, ss, None)
-        rw = cx["rw"][:, None] if self.grad_scale == 1.0 else (cx["rw"] * self.grad_scale)[:, None]
-        # dF/dbh = -sigmoid(z), dF/dbv = -v, dF/dW = -v^T sigmoid(z); cost = F(v) - F(v_s), v_s constant (rbm.py:229)
-        d_out = torch.zeros((N, self.ldo), device=dev)
-        d_out[:, :Hn] = rw * (ss - sv)
-        d_out[:, Hn:Hn + D] = rw * (cx["v_s"].float() - cx["tgt"].float())
+        # dF/dbh = -sigmoid(z), dF/dbv = -v, dF/dW = -v^T sigmoid(z); cost = F(v) - F(v_s), v_s constant (rbm.py:229).  One pass writes the
+        # Dense-output-shaped gradient block and the two scaled hidden blocks of d cost / d W = v_s^T (w ss) - v^T (w sv)
+        d_out = torch.empty((N, self.ldo), device=dev)
+        pos = torch.empty((N, Hn), device=dev); neg = torch.empty((N, Hn), device=dev)
+        ops.rbm_cd_rows(cx["tgt"], cx["v_s"], sv, ss, cx["rw"], self.grad_scale, d_out, pos, neg)
         Np = ops.round_up(N, 4)
         def tr(xm, rows):
             o = torch.zeros((rows, Np), device=dev)
-            return ops.transpose(xm.contiguous(), o)
+            return ops.transpose(xm, o)
         # [D, N] . [N, Hn] in f32: two output tiles and K = N rows -- without split-K two workgroups walk the whole batch (6.7 ms of
         # a 19.6 ms step at N = 32 768); slices of >= 256 rows, up to one workgroup per CU
         sk = int(max(1, min(256 // (-(-D // 128) * -(-Hn // 128)), Np // 256)))
-        ops.gemm_tn(tr(cx["v_s"], D), tr(rw * ss, Hn), g[f"{self._rbm.prefix}/W"], accumulate=True, split_k=sk)
-        neg = torch.empty((D, Hn), device=dev)
-        ops.gemm_tn(tr(cx["tgt"], D), tr(rw * sv, Hn), neg, split_k=sk)
-        g[f"{self._rbm.prefix}/W"].sub_(neg)
+        gW = g[f"{self._rbm.prefix}/W"]
+        ops.gemm_tn(tr(cx["v_s"], D), tr(pos, Hn), gW, accumulate=True, split_k=sk)
+        ops.gemm_tn(tr(cx["tgt"], D), tr(neg, Hn), gW, accumulate=True, split_k=sk)
         if self.bias_mode != "conditional":
-            g[f"{self._rbm.prefix}/bh"].add_(d_out[:, :Hn].sum(0, keepdim=True))
-            g[f"{self._rbm.prefix}/bv"].add_(d_out[:, Hn:Hn + D].sum(0, keepdim=True))
+            ops.bias_grad(d_out[:, :Hn], g[f"{self._rbm.prefix}/bh"].view(-1), accumulate=True)
+            ops.bias_grad(d_out[:, Hn:Hn + D], g[f"{self._rbm.prefix}/bv"].view(-1), accumulate=True)
             return                                   # as written: no gradient reaches the LSTM / Wuh / Wuv (R3)
         if self.internal_bias:
             ops.bias_grad(d_out[:, :Hn], g[f"{self._rbm.prefix}/bh"].view(-1), accumulate=True)
@@ -1181,10 +1180,14 @@ class RnnRBM(RnnEstimator):
         ops.transpose(cx["y"].view(N, R), yT)
         doT = torch.zeros((self.n_out, Np8), device=dev, dtype=self.dtype)
         ops.transpose(d_out[:, :self.n_out], doT)
-        dwu = torch.empty((R, self.n_out), device=dev)
-        ops.gemm_tn(yT, doT, dwu, split_k=LstmStack._split_k(R, self.n_out, Np8))
-        g["Wuh"].add_(dwu[:, :Hn]); g["Wuv"].add_(dwu[:, Hn:])
-        do_c = d_out if self.dtype == torch.float32 else d_out.to(self.dtype)
+        # Wuh [R,Hn] and Wuv [R,D] are separate variables: one accumulating product per block of the transposed gradient
+        ops.gemm_tn(yT, doT[:Hn], g["Wuh"], accumulate=True, split_k=LstmStack._split_k(R, Hn, Np8))
+        ops.gemm_tn(yT, doT[Hn:Hn + D], g["Wuv"], accumulate=True, split_k=LstmStack._split_k(R, D, Np8))
+        if self.dtype == torch.float32:
+            do_c = d_out
+        else:
+            do_c = torch.empty((N, self.ldo), device=dev, dtype=self.dtype)
+            ops.convert2d(d_out, do_c)
         dy = torch.empty((N, R), device=dev)
         ops.gemm_tn(do_c, self._wu_p, dy)
         self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], self.seed, self.row0, step_dev=self.store.step_dev)

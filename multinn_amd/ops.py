@@ -562,6 +562,19 @@ def rbm_cd_bias_delta(v, p_v, h, p_h, scale, dbv, dbh):
     call("mnn_rbm_cd_bias_delta", _stream(), N, D, Hn, _ptr(v), _ptr(p_v), _ptr(h), _ptr(p_h), float(scale), _ptr(dbv), _ptr(dbh))
 
 
+def rbm_cd_rows(v, v_s, sv, ss, rw, scale, d_out, pos, neg):
+    """Rows of the LSTM-RBM cost gradient: d_out[:, :Hn] = w (ss - sv), d_out[:, Hn:Hn+D] = w (v_s - v), padding zeroed; pos = w ss, neg = -w sv
+    (w = rw * scale).  v / v_s u8 [N,D], sv / ss f32 [N,Hn], d_out f32 [N, ld >= Hn + D] (rnn_rbm.py:113-126, rbm.py:229)."""
+    N, D = v.shape
+    Hn = sv.shape[1]
+    _req(v.dtype == torch.uint8 and v_s.dtype == torch.uint8 and v.is_contiguous() and v_s.is_contiguous() and v_s.shape == (N, D), "cd_rows: v / v_s u8 [N,D]")
+    for t in (sv, ss, pos, neg):
+        _req(t.dtype == torch.float32 and t.shape == (N, Hn) and t.is_contiguous(), "cd_rows: sv / ss / pos / neg f32 [N,Hn]")
+    _req(rw.dtype == torch.float32 and rw.numel() == N and rw.is_contiguous(), "cd_rows: row weights f32 [N]")
+    _req(d_out.dtype == torch.float32 and d_out.dim() == 2 and d_out.shape[0] == N and d_out.is_contiguous() and d_out.shape[1] >= Hn + D, "cd_rows: d_out f32 [N, ld]")
+    call("mnn_rbm_cd_rows", _stream(), N, D, Hn, d_out.shape[1], _ptr(v), _ptr(v_s), _ptr(sv), _ptr(ss), _ptr(rw), float(scale), _ptr(d_out), _ptr(pos), _ptr(neg))
+
+
 def rbm_visible_bias_init(colsum, count, bv):
     """bv[d] = log(1e-6 + p/(1-p)), p = colsum[d]/count (rbm.py:286-297)."""
     D = colsum.numel()
