@@ -346,64 +346,76 @@ def main(argv=None):
     for k, (ms, n) in top:
         print(f"#   {k:32s} {ms:9.3f} ms/step  ({n} calls)", file=sys.stderr)
 
-    # ---- dominant entry point and its roofline (algorithmic counts: DESIGN.md "Roofline accounting") --------------------------
-    dom, (dom_ms, dom_calls) = top[0]
+    # ---- roofline per entry point (algorithmic counts: DESIGN.md "Roofline accounting"); `roofline` = the one with the largest share ----
     R1, R2 = UNITS
     peak_mfma = PEAK_MFMA_BF16_TFLOPS if a.precision == "bf16" else PEAK_MFMA_F32_TFLOPS
     rec_flops = 2.0 * N * (R1 * 4 * R1 + R2 * 4 * R2)          # the T sequential [B,u]x[u,4u] products of both layers, one direction
-    if dom.startswith("mnn_nade_logprob"):
-        bwd = dom.endswith("bwd")
-        byts = N * (D + 4 * (HN + D) * (2 if bwd else 1) + 4 * (HN + D if bwd else D))
-        roof = dict(bound="hbm", achieved=byts / (dom_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", traffic=None,
-                    kernel="nade_bwd_kernel" if bwd else ("nade_fwd_mfma_kernel" if a.precision == "bf16" else "nade_fwd_kernel"),
-                    entry_point=dom, launches_per_step=1, avg_launch_us=dom_ms * 1e3, algorithmic_bytes_per_launch=byts,
-                    note="transcendental / VALU-bound scan (SURVEY 8d): HBM is the contract's bound for a non-MFMA kernel; its "
-                         "sigmoid-rate fraction is in roofline.step.phases")
-    elif dom in ("mnn_lstm2_persist_fwd", "mnn_lstm2_persist_bwd"):
-        # ONE launch for the T-step recurrence of both layers; layer 2's input projection (its dgrad, backward) is folded in
-        flops = rec_flops + 2.0 * N * R1 * 4 * R2
-        roof = dict(bound="mfma", achieved=flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
-                    kernel="lstm2_persist_%s_kernel" % ("bwd" if dom.endswith("bwd") else "fwd"), launches_per_step=1,
-                    avg_launch_us=dom_ms * 1e3, avg_timestep_us=dom_ms * 1e3 / T, algorithmic_flop_per_launch=flops,
-                    note="latency-bound chain of T in-kernel tile hand-offs (flag + row tile through the fabric per timestep): "
-                         "the number to watch is avg_timestep_us")
-    elif dom in ("mnn_lstm_rowpar_fwd", "mnn_lstm_rowpar_bwd"):
-        # one launch per LAYER: every wave carries one 32-row tile through all T steps against a 32-unit weight tile resident in LDS
-        roof = dict(bound="mfma", achieved=rec_flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
-                    kernel="lstm_rowpar_%s_kernel" % ("bwd" if dom.endswith("bwd") else "fwd"), entry_point=dom, launches_per_step=dom_calls,
-                    avg_launch_us=dom_ms * 1e3 / dom_calls, avg_timestep_us=dom_ms * 1e3 / dom_calls / T,
-                    algorithmic_flop_per_launch=rec_flops / dom_calls,
-                    note="latency-bound chain: per timestep every row tile exchanges its 32-row h (backward: dz) slice with the other unit "
-                         "tiles through L2 (flag per wave); the number to watch is avg_timestep_us")
-    elif dom in ("mnn_lstm_seq_fwd", "mnn_lstm_seq_bwd", "mnn_lstm2_seq_fwd", "mnn_lstm2_seq_bwd"):
-        fused = dom.startswith("mnn_lstm2")
-        launches = (T + 2) if fused else 2 * T            # fused: one three-stage launch per timestep for both layers (lag 2)
-        roof = dict(bound="mfma", achieved=rec_flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
-                    kernel=("lstm3_%s_step" if fused else "lstm_%s_step_v2") % ("bwd" if dom.endswith("bwd") else "fwd"),
-                    launches_per_step=launches, avg_launch_us=dom_ms * 1e3 / launches, algorithmic_flop_per_launch=rec_flops / launches,
-                    note="latency-bound chain of T sequential launches: the number to watch is avg_launch_us")
-    else:   # all plain GEMMs of the step: input projections, dense, their dgrad + wgrad, recurrent wgrad
-        fwd = 2.0 * N * (D * 4 * R1 + R1 * 4 * R2 + R2 * (HN + D))
-        flops = 3.0 * fwd - 2.0 * N * D * 4 * R1 + rec_flops
-        roof = dict(bound="mfma", achieved=flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
-                    kernel="gemm_tn_glds_kernel", launches_per_step=dom_calls, avg_launch_us=dom_ms * 1e3 / dom_calls,
-                    algorithmic_flop_per_launch=flops / dom_calls)
-    roof["frac"] = roof["achieved"] / roof["peak"]
-    roof["timing"] = "HIP events around every C-ABI call of %d eager steps run right after the timed replays" % nb
-    # fabric-side bytes per launch of that kernel: rocprofv3 PMC passes recorded under profiles/ (FETCH_SIZE and WRITE_SIZE cannot be
+
+    def entry_roofline(dom, dom_ms, dom_calls):
+        if dom.startswith("mnn_nade_logprob"):
+            bwd = dom.endswith("bwd")
+            byts = N * (D + 4 * (HN + D) * (2 if bwd else 1) + 4 * (HN + D if bwd else D))
+            roof = dict(bound="hbm", achieved=byts / (dom_ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", traffic=None,
+                        kernel="nade_bwd_kernel" if bwd else ("nade_fwd_mfma_kernel" if a.precision == "bf16" else "nade_fwd_kernel"),
+                        entry_point=dom, launches_per_step=1, avg_launch_us=dom_ms * 1e3, algorithmic_bytes_per_launch=byts,
+                        note="transcendental / VALU-bound scan (SURVEY 8d): HBM is the contract's bound for a non-MFMA kernel; its "
+                             "sigmoid-rate fraction is in roofline.step.phases")
+        elif dom in ("mnn_lstm2_persist_fwd", "mnn_lstm2_persist_bwd"):
+            # ONE launch for the T-step recurrence of both layers; layer 2's input projection (its dgrad, backward) is folded in
+            flops = rec_flops + 2.0 * N * R1 * 4 * R2
+            roof = dict(bound="mfma", achieved=flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
+                        kernel="lstm2_persist_%s_kernel" % ("bwd" if dom.endswith("bwd") else "fwd"), launches_per_step=1,
+                        avg_launch_us=dom_ms * 1e3, avg_timestep_us=dom_ms * 1e3 / T, algorithmic_flop_per_launch=flops,
+                        note="latency-bound chain of T in-kernel tile hand-offs (flag + row tile through the fabric per timestep): "
+                             "the number to watch is avg_timestep_us")
+        elif dom in ("mnn_lstm_rowpar_fwd", "mnn_lstm_rowpar_bwd"):
+            # one launch per LAYER: every wave carries one 32-row tile through all T steps against a 32-unit weight tile resident in LDS
+            roof = dict(bound="mfma", achieved=rec_flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
+                        kernel="lstm_rowpar_%s" % ("bwd" if dom.endswith("bwd") else "fwd"), entry_point=dom, launches_per_step=dom_calls,
+                        avg_launch_us=dom_ms * 1e3 / dom_calls, avg_timestep_us=dom_ms * 1e3 / dom_calls / T,
+                        algorithmic_flop_per_launch=rec_flops / dom_calls,
+                        note="latency-bound chain: per timestep every row tile exchanges its 32-row h (backward: dz) slice with the other unit "
+                             "tiles through L2 (flag per wave); the number to watch is avg_timestep_us")
+        elif dom in ("mnn_lstm_seq_fwd", "mnn_lstm_seq_bwd", "mnn_lstm2_seq_fwd", "mnn_lstm2_seq_bwd"):
+            fused = dom.startswith("mnn_lstm2")
+            launches = (T + 2) if fused else 2 * T            # fused: one three-stage launch per timestep for both layers (lag 2)
+            roof = dict(bound="mfma", achieved=rec_flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
+                        kernel=("lstm3_%s_step" if fused else "lstm_%s_step_v2") % ("bwd" if dom.endswith("bwd") else "fwd"),
+                        launches_per_step=launches, avg_launch_us=dom_ms * 1e3 / launches, algorithmic_flop_per_launch=rec_flops / launches,
+                        note="latency-bound chain of T sequential launches: the number to watch is avg_launch_us")
+        else:   # all plain GEMMs of the step: input projections, dense, their dgrad + wgrad, recurrent wgrad
+            fwd = 2.0 * N * (D * 4 * R1 + R1 * 4 * R2 + R2 * (HN + D))
+            flops = 3.0 * fwd - 2.0 * N * D * 4 * R1 + rec_flops
+            roof = dict(bound="mfma", achieved=flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
+                        kernel="gemm_tn_glds", launches_per_step=dom_calls, avg_launch_us=dom_ms * 1e3 / dom_calls,
+                        algorithmic_flop_per_launch=flops / dom_calls)
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof.setdefault("entry_point", dom)
+        return roof
+
+    dom, (dom_ms, dom_calls) = top[0]
+    roof = entry_roofline(dom, dom_ms, dom_calls)
+    roof["others"] = [entry_roofline(k, ms, n) for k, (ms, n) in top[1:5] if ms > 0.05 * total_ms]
+    # fabric-side bytes per launch of each kernel: rocprofv3 PMC passes recorded under profiles/ (FETCH_SIZE and WRITE_SIZE cannot be
     # collected from inside this process); only for the workload they were measured on
-    for fn in ("round2_%s_pmc_traffic.json" % a.workload, "round1_o_pmc_traffic.json" if a.workload == "c2" else ""):
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
-            if a.precision == "bf16":
-                hit = [v for k, v in pmc["kernels"].items() if k.startswith(roof["kernel"])]
-                if hit:
-                    roof["traffic"] = hit[0]["hbm_side_bytes_per_launch"]
-                    roof["traffic_unit"] = "bytes/launch"
-                    roof["traffic_source"] = f"profiles/{fn} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
-                    break
-        except (OSError, ValueError, KeyError):
-            continue
+    def attach_traffic(rf):
+        for fn in ("round2_%s_pmc_traffic.json" % a.workload, "round1_o_pmc_traffic.json" if a.workload == "c2" else ""):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                if a.precision == "bf16":
+                    hit = [v for k, v in pmc["kernels"].items() if k.startswith(rf["kernel"])]
+                    if hit:
+                        rf["traffic"] = sum(h["hbm_side_bytes_per_launch"] * h["calls"] for h in hit) / sum(h["calls"] for h in hit)
+                        rf["traffic_unit"] = "bytes/launch"
+                        rf["traffic_source"] = f"profiles/{fn} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
+                        return
+            except (OSError, ValueError, KeyError):
+                continue
+
+    roof["timing"] = "HIP events around every C-ABI call of %d eager steps run right after the timed replays" % nb
+    attach_traffic(roof)
+    for rf in roof["others"]:
+        attach_traffic(rf)
 
     sig = sigmoid_peak(dev)
     roof["step"] = step_roofline(N, D, a.precision, sec, sig["sigmoids_per_s"])
