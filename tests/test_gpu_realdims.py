@@ -224,3 +224,30 @@ def test_rowpar_recurrence_vs_oracle(units, B, T, max_g, monkeypatch):
         gen.backward()
         assert torch.equal(gen._nll_tm, nll0) and all(torch.equal(a_, b_) for a_, b_ in zip(gen._stack._dbg_dzT, dz0))
     gen._stack.check()
+
+
+def test_persistent_forms_refuse_grids_that_cannot_be_resident():
+    """Co-residency is a construction, not an assumption: the host plans size every persistent grid to at most one workgroup per CU of THIS
+    device and refuse shapes whose row tiles do not fit (the caller then takes the launch-per-timestep kernels -- still device code); the C
+    entry points refuse them too instead of launching a grid that could wait for workgroups that are not resident."""
+    from multinn_amd import ops, RnnNade
+    from multinn_amd._lib import MnnError
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert ops.lstm_rowpar_ok(1024, 512) and ops.lstm_rowpar_ok(1024, 256)
+    big = 32 * (cus // 16) * 4                      # row tiles of U = 512: more than 3 per workgroup of the backward (one workgroup per CU)
+    assert not ops.lstm_rowpar_ok(big, 512)
+    assert not ops.lstm_rowpar_ok(1000, 512)        # not a multiple of the 32-row tile
+    assert not ops.lstm_rowpar_ok(1024, 96)         # unit widths: 128 / 256 / 512
+    gen = RnnNade(D, HN, UNITS, keep_prob=0.9, precision="bf16", seed=23)
+    gen._materialize(D)
+    gen._ensure_packed()
+    assert gen._stack._rowpar(1024, 8) and not gen._stack._rowpar(big, 8) and not gen._stack._rowpar(1024, 8, state0=[None])
+    # the C entry point itself refuses the shape (no launch): a fabricated descriptor never reaches a kernel
+    T, B, u = 2, 32 * (cus // 16) * 5, 512          # five row tiles per workgroup: more waves than a workgroup of either direction holds
+    xproj = torch.empty((T, B, 4 * u), device=DEV)
+    h = torch.empty((T, B, u), device=DEV, dtype=torch.bfloat16)
+    d = ops.lstm2_fwd_layer(xproj, gen._stack.packed[0]["wh_t"], None, None, None, torch.empty((T, B, u), device=DEV), h, None)
+    from multinn_amd import _lib
+    ws = torch.zeros(_lib.load().mnn_lstm_rowpar_workspace_bytes(T, B, u), device=DEV, dtype=torch.uint8)
+    with pytest.raises(MnnError):
+        ops.lstm_rowpar_fwd(T, B, d, 1.0, ws)
