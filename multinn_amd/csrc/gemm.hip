@@ -426,6 +426,14 @@ gemm_tn_glds_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restr
 // at two thirds of the MFMA rate before any latency.  Here 4 A + 2 B fragments feed 8 MFMAs and a stage carries 0.25 KiB
 // per MFMA: 1.0 KiB per MFMA, and one workgroup per CU holds two 64 KiB stages.
 // ----------------------------------------------------------------------------------------------
+#ifdef GM_TRACE      // development only (profiles/tools/gemm_trace.hip): phase clocks of workgroup GM_TRACE, accumulated in 10 ns units
+__device__ long long gm_trace[16];
+#define GM_T(k) do { if (threadIdx.x == 0 && blockIdx.x == GM_TRACE && blockIdx.y == 0) { const long long now_ = wall_clock64(); gm_trace[k] += now_ - gmprev_; gmprev_ = now_; } } while (0)
+#define GM_T0() long long gmprev_ = wall_clock64()
+#else
+#define GM_T(k) do { } while (0)
+#define GM_T0() do { } while (0)
+#endif
 __global__ void __launch_bounds__(512)
 gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c_bf16,
                        const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
@@ -458,11 +466,16 @@ gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
         slotA.stage(kt * BK, smem256 + (buf * 2 + 0) * TILE, wave);
         slotB.stage(kt * BK, smem256 + (buf * 2 + 1) * TILE, wave);
     };
+    GM_T0();
     stage(0, kt0);
     __syncthreads();                                        // hipcc drains vmcnt(0) before the barrier
+    GM_T(1);
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
+        // (spreading these 8 DMA instructions over the four k-steps was measured: the 0.6 us they hold the wave moves into the k-steps --
+        // 256 x 256 x 448 tile: issue 4.3 -> 1.4 us, LDS reads + MFMA 8.9 -> 10.2, barriers 1.8 -> 2.6: the K tile stays at ~2 us, LDS-bound)
         if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
+        GM_T(2);
         const char* sA = smem256 + (cur * 2 + 0) * TILE;
         const char* sB = smem256 + (cur * 2 + 1) * TILE;
 #pragma unroll
@@ -483,11 +496,18 @@ gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        GM_T(3);
         __syncthreads();
+        GM_T(4);
         cur ^= 1;
     }
     epi_dispatch<4, 2>(Cv, ldc, c_bf16, flags, M, N, m0 + wm * 128, n0 + wn * 64, acc, z == 0 ? bias : nullptr, lane,
                        EPI_WIDE ? reinterpret_cast<float*>(smem256) + wave * EPI_SC_FLOATS : nullptr);             // the K loop ended with a barrier
+    GM_T(5);
+#ifdef GM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GM_T(6);
+#endif
 }
 
 template <typename T>

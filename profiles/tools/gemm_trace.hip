@@ -7,7 +7,7 @@ extern "C" int mnn_bias_grad(mnn_stream_t, const float*, int, int, int, float*, 
 void mnn_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fprintf(stderr, "\n"); }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 int main(int argc, char** argv) {
-    const int M = argc > 1 ? atoi(argv[1]) : 32768, N = argc > 2 ? atoi(argv[2]) : 2048, K = argc > 3 ? atoi(argv[3]) : 448, sk = argc > 4 ? atoi(argv[4]) : 1;
+    const int M = argc > 1 ? atoi(argv[1]) : 262144, N = argc > 2 ? atoi(argv[2]) : 2048, K = argc > 3 ? atoi(argv[3]) : 448, sk = argc > 4 ? atoi(argv[4]) : 1;
     bf16_t *A, *B; float* C;
     CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 4));
     CK(hipMemset(A, 0, (size_t)M * K * 2)); CK(hipMemset(B, 0, (size_t)N * K * 2));
@@ -20,8 +20,8 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(gm_trace), sizeof(z)));
-        printf("gemm %.1f us; one workgroup (us): setup %.2f | first stage+sync %.2f | issue next %.2f | compute %.2f | sync %.2f | epilogue issue %.2f | stores drain %.2f\n",
-               ms * 1e3, z[0] * 0.01, z[1] * 0.01, z[2] * 0.01, z[3] * 0.01, z[4] * 0.01, z[5] * 0.01, z[6] * 0.01);
+        printf("gemm %.1f us; workgroup %d of the 256 x 256 kernel (us): first stage+sync %.2f | issue next stages %.2f | LDS reads + MFMA %.2f | barriers %.2f | epilogue issue %.2f | stores drain %.2f\n",
+               ms * 1e3, GM_TRACE, z[1] * 0.01, z[2] * 0.01, z[3] * 0.01, z[4] * 0.01, z[5] * 0.01, z[6] * 0.01);
     }
     return 0;
 }
