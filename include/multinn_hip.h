@@ -316,6 +316,9 @@ int mnn_rbm_visible_bias_init(mnn_stream_t s, int D, const float* colsum, float 
 int mnn_rbm_cd_rows(mnn_stream_t s, int N, int D, int Hn, int ld, const uint8_t* v, const uint8_t* v_s, const float* sv, const float* ss,
                     const float* row_weight, float scale, float* d_out, float* pos, float* neg);
 
+/* dz = dy * y * (1 - y) over n f32 words (dz may alias dy): backward of the sigmoid Dense layers of the feedback module (dnn.py:60-76). */
+int mnn_sigmoid_grad_f32(mnn_stream_t s, long n, const float* dy, const float* y, float* dz);
+
 /* ------------------------------------------------------------------------------------------
  * Reductions / optimiser on the flat parameter buffer.
  * mnn_sumsq: out[0] += sum(x^2) (f32 atomic; zero first).  mnn_weighted_sum: out[0] += sum w*x.

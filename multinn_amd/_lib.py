@@ -87,6 +87,7 @@ SIGNATURES["mnn_eval_counts"] = (_i, [_p, _p, _p, _l, _p])
 SIGNATURES["mnn_log_loss_rows"] = (_i, [_p, _p, _p, _i, _i, _i, _p])
 SIGNATURES["mnn_rbm_cd_bias_delta"] = (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _f, _p, _p])
 SIGNATURES["mnn_rbm_visible_bias_init"] = (_i, [_p, _i, _p, _f, _p])
+SIGNATURES["mnn_sigmoid_grad_f32"] = (_i, [_p, _l, _p, _p, _p])
 SIGNATURES["mnn_rbm_cd_rows"] = (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p])
 SIGNATURES["mnn_probe_sigmoid"] = (_i, [_p, _i, _i, _p])
 SIGNATURES["mnn_axpby_f32"] = (_i, [_p, _l, _f, _p, _f, _p, _p])

@@ -477,3 +477,18 @@ extern "C" int mnn_rbm_cd_rows(mnn_stream_t s, int N, int D, int Hn, int ld, con
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
+
+// dz[i] = dy[i] * y[i] * (1 - y[i])  (f32; dz may alias dy): backward of y = sigmoid(z), the activation of the Dense feedback module
+// (dnn.py:60-76 / multinn_feedback.py:48-52)
+__global__ void __launch_bounds__(256) sigmoid_grad_kernel(long n, const float* __restrict__ dy, const float* __restrict__ y, float* dz) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float yy = y[i];
+        dz[i] = dy[i] * (yy - yy * yy);
+    }
+}
+extern "C" int mnn_sigmoid_grad_f32(mnn_stream_t s, long n, const float* dy, const float* y, float* dz) {
+    MNN_REQUIRE(n > 0 && dy && y && dz, "mnn_sigmoid_grad_f32: bad arguments");
+    hipLaunchKernelGGL(sigmoid_grad_kernel, dim3((int)min(2048L, (n + 255) / 256)), dim3(256), 0, (hipStream_t)s, n, dy, y, dz);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}

@@ -21,6 +21,7 @@ class FeedbackRnn(Model):
         self._stack = LstmStack(self._rnn, self.store, self.dtype)
         self._rnn.build_cell(False)
         self.num_inputs, self.num_units = num_inputs, list(self._rnn.num_units)
+        self.seed, self.row0, self._ctx = seed, 0, None
         self._is_built = True
 
     def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None):
@@ -32,11 +33,24 @@ class FeedbackRnn(Model):
         out[:, :, :Din] = x.transpose(0, 1).to(self.dtype)
         return out
 
-    def run(self, x, initial_state=None):
-        """_apply_feedback(single_step=False): x [B,T,Din] -> (outputs [B,T,F] f32, final_state)."""
+    def run(self, x, initial_state=None, train=False):
+        """_apply_feedback(single_step=False): x [B,T,Din] -> (outputs [B,T,F] f32, final_state).  train=True keeps what backward() needs
+        and applies the module's output dropout (multinn_feedback_rnn.py:56-57: built with is_train)."""
         self._stack.pack()
-        y, _, final = self._stack.forward(self._tm(x), 1.0, save=False, state0=initial_state)
+        self._rnn.build_cell(bool(train))
+        kp = self._rnn.effective_keep_prob() if train else 1.0
+        y, ctx, final = self._stack.forward(self._tm(x), kp, self.seed, self.row0, save=bool(train), state0=initial_state,
+                                            step_dev=self.store.step_dev)
+        self._ctx = dict(lstm=ctx, kp=kp) if train else None
         return y.transpose(0, 1).float(), [(c.clone(), h.clone()) for c, h in final]
+
+    def backward(self, d_out):
+        """d_out f32 [B,T,F]: gradient wrt the feedback vectors -> the module's kernel / bias gradients (its inputs are codes: no gradient)."""
+        if self._ctx is None:
+            raise RuntimeError("FeedbackRnn.backward: run(..., train=True) first")
+        self.store.grad.zero_()
+        dy = d_out.transpose(0, 1).contiguous()
+        self._stack.backward(dy, self._ctx["lstm"], self._ctx["kp"], self.seed, self.row0, step_dev=self.store.step_dev)
 
     def single(self, x, state):
         """_apply_feedback(single_step=True): x [B,Din] -> (output [B,F] f32, new_state)."""
@@ -84,15 +98,43 @@ class DNN(Model):
     def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None):
         return [], [], None                                  # dnn.py:96-110: a base block without metrics of its own
 
-    def __call__(self, x):
-        """x [..., n_in] (any float / u8 tensor) -> [..., units[-1]] f32."""
+    def __call__(self, x, save=False):
+        """x [..., n_in] (any float / u8 tensor) -> [..., units[-1]] f32.  save=True keeps every layer's input and output for backward()."""
         self._materialize(x.shape[-1])
         h = x.reshape(-1, x.shape[-1]).float().contiguous()
+        acts = [h]
         for l, u in enumerate(self._num_units):
             out = torch.empty((h.shape[0], u), device=h.device)
             ops.rbm_hidden(h, self.store[f"{self.name}/dense_{l}/kernel"], self.store[f"{self.name}/dense_{l}/bias"].view(1, u), 0, 0, 0, 0, p_h=out)
             h = out
+            acts.append(h)
+        self._acts = acts if save else None
         return h.reshape(x.shape[:-1] + (self._num_units[-1],))
+
+    def backward(self, d_out):
+        """d_out f32 [..., units[-1]]: gradient wrt the outputs of the last call(save=True) -> kernel / bias gradients of every layer
+        (dW = x^T dz, db = sum dz, dz = dy y (1 - y), dy_below = dz W^T: dnn.py:60-76 by hand).  No gradient wrt the module's inputs (codes)."""
+        if getattr(self, "_acts", None) is None:
+            raise RuntimeError("DNN.backward: call the module with save=True first")
+        g = self.store.gviews
+        self.store.grad.zero_()
+        dy = d_out.reshape(-1, d_out.shape[-1]).float().contiguous()
+        N = dy.shape[0]
+        Np = ops.round_up(N, 4)
+
+        def tr(xm):
+            o = torch.zeros((xm.shape[1], Np), device=xm.device)
+            return ops.transpose(xm, o)
+        for l in range(len(self._num_units) - 1, -1, -1):
+            x_in, y = self._acts[l], self._acts[l + 1]
+            dz = ops.sigmoid_grad(dy, y, torch.empty_like(y))
+            sk = int(max(1, min(256, Np // 256)))
+            ops.gemm_tn(tr(x_in), tr(dz), g[f"{self.name}/dense_{l}/kernel"], accumulate=True, split_k=sk)      # [n_in, N] . [N, u]
+            ops.bias_grad(dz, g[f"{self.name}/dense_{l}/bias"], accumulate=True)
+            if l > 0:
+                W = self.store[f"{self.name}/dense_{l}/kernel"]                 # [n_in, u]: K = u contiguous, the B operand as stored
+                dy = torch.empty((N, W.shape[0]), device=dz.device)
+                ops.gemm_tn(dz, W, dy)
 
 
 class FeedbackDnn(Model):
@@ -109,9 +151,13 @@ class FeedbackDnn(Model):
     def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None):
         return [], [], None
 
-    def run(self, x, initial_state=None):
+    def run(self, x, initial_state=None, train=False):
         """_apply_feedback(single_step=False): x [B,T,Din] -> (outputs [B,T,F] f32, state placeholder)."""
-        return self._dnn(x), None
+        return self._dnn(x, save=bool(train)), None
+
+    def backward(self, d_out):
+        """d_out f32 [B,T,F]: gradient wrt the feedback vectors -> the Dense layers' gradients."""
+        self._dnn.backward(d_out)
 
     def single(self, x, state):
         """_apply_feedback(single_step=True): x [B,Din] -> (output [B,F] f32, state placeholder)."""

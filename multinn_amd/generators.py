@@ -174,7 +174,7 @@ class LstmStack:
             inp = out
         return inp, ctx, final
 
-    def _backward_rowpar(self, dy, ctx, keep_prob):
+    def _backward_rowpar(self, dy, ctx, keep_prob, need_dx=False):
         """Top layer first: the layer's whole backward recurrence in one launch (dropout backward of its output folded in), then the
         gradient wrt its input as one GEMM (dz row-major x Wx), which is the next layer's dh_ext."""
         T, B, _ = dy.shape
@@ -199,7 +199,7 @@ class LstmStack:
         if getattr(self, "keep_debug", False):
             self._dbg_dzT = [s_["dzT"] for s_ in st]
         keep = [self._weight_grads(l, ctx[l], st[l]["dzT"], st[l]["db_p"], T, B) for l in range(len(self.packed) - 1, -1, -1)]
-        return None
+        return self._input_grad(st[0]["dzT"], T, B) if need_dx else None
 
     def _workspace(self, T, B, dev):
         """Flags + exchange area of the persistent launches, one per (T, B) (kept alive: captured graphs point at it)."""
@@ -357,11 +357,8 @@ class LstmStack:
         """dy f32 [T,B,u_last]: gradient wrt the (dropped) top output.  Accumulates the kernel / bias gradients
         into the store's flat gradient buffer.  Same wavefront as forward, top layer first, chunks descending;
         each layer's weight-gradient GEMMs then run on that layer's stream."""
-        if need_dx:
-            raise NotImplementedError("the gradient wrt the generator's inputs is not built (nothing on the train path consumes it: "
-                                      "generator.py:201 differentiates wrt the generator's own variables; feedback-mode training would)")
         if ctx and ctx[0].get("rowpar"):
-            return self._backward_rowpar(dy, ctx, keep_prob)
+            return self._backward_rowpar(dy, ctx, keep_prob, need_dx)
         T, B, _ = dy.shape
         dev = dy.device
         L = len(self.packed)
@@ -433,7 +430,22 @@ class LstmStack:
                 keep.append(self._weight_grads(l, ctx[l], st[l]["dzT"], st[l]["db_p"], T, B))
         for s in lanes[1:]:
             main.wait_stream(s)
-        return None
+        return self._input_grad(st[0]["dzT"], T, B) if need_dx else None
+
+    def _input_grad(self, dzT0, T, B):
+        """Gradient wrt the stack's inputs, f32 [T,B,n_in] = dz_0 . Wx_0^T (only the feedback modes consume it: the feedback vector is part of
+        every per-track generator's input, multinn_feedback.py:85-91).  Every form of the recurrence leaves layer 0's dz as dz^T [4u, N]
+        (the weight-gradient operand): one transpose pass makes the K-contiguous A operand."""
+        p = self.packed[0]
+        N = T * B
+        if p.get("wx_p0") is None:          # [ld0, 4u]: the packed (gate-interleaved) input weights with K = 4u contiguous, once per pack
+            p["wx_p0"] = torch.empty((p["ld"], 4 * p["u"]), device=dzT0.device, dtype=self.dtype)
+            ops.transpose(p["wx_t"], p["wx_p0"])
+        dz = torch.empty((N, 4 * p["u"]), device=dzT0.device, dtype=self.dtype)
+        ops.transpose(dzT0[:, :N], dz)
+        dx = torch.empty((N, p["n_in"]), device=dzT0.device)
+        ops.gemm_tn(dz, p["wx_p0"][:p["n_in"]], dx)
+        return dx.view(T, B, p["n_in"])
 
     def single_step(self, x, state):
         """One time step (rnn_nade.py:268): x [B,ld0] compute dtype, state [(c,h)...] -> (h_top, new_state)."""
@@ -481,7 +493,7 @@ class Generator(Model):
 
     def train(self, optimizer, lr, run_optimizer=True):
         """generator.py:176-205: backward of metrics['batch/loss'] + clipped optimiser step."""
-        self.backward()
+        self.backward()                     # leaves self._dx (f32 [T,B,n_in], time-major) when self.need_dx is set by the mode
         summaries = dict(self.summaries)
         if run_optimizer:
             self._grad_sumsq = compute_gradients(optimizer, self.store, self.clip_norm, lr)
@@ -501,6 +513,8 @@ class RnnEstimator(Generator):
         # weight of this generator's loss in the optimised objective: a mode that trains M per-track generators on the MEAN track loss
         # with one global-norm clip over all of them (multinn_jamming.py:235-241) sets 1/M; the generator's own metrics stay unscaled
         self.grad_scale = 1.0
+        self.need_dx = False              # a feedback mode sets it: backward() then also leaves d loss / d inputs in self._dx (f32 [T,B,n_in])
+        self._dx = None
         self.store = ParamStore(device)
         self._gen = torch.Generator().manual_seed(seed)
         self._num_inputs = num_inputs
@@ -899,7 +913,7 @@ class RnnNade(RnnEstimator):
         del yT, doT
         dy = torch.empty((N, R), device=dev)
         ops.gemm_tn(do_c, self._fc_p, dy)
-        self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], cx["seed"], self.row0, step_dev=self.store.step_dev)
+        self._dx = self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], cx["seed"], self.row0, need_dx=self.need_dx, step_dev=self.store.step_dev)
 
     def train_step(self, x_u8, lengths, optimizer, lr=None):
         """One optimiser step on a piano-roll batch (train.py:178-189's sess.run)."""
@@ -1190,7 +1204,7 @@ class RnnRBM(RnnEstimator):
             ops.convert2d(d_out, do_c)
         dy = torch.empty((N, R), device=dev)
         ops.gemm_tn(do_c, self._wu_p, dy)
-        self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], self.seed, self.row0, step_dev=self.store.step_dev)
+        self._dx = self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], self.seed, self.row0, need_dx=self.need_dx, step_dev=self.store.step_dev)
 
     def zero_state(self, batch_size):
         self._materialize(self._num_inputs)

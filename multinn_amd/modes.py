@@ -25,6 +25,7 @@ import torch
 from .common import Model
 from .encoders import PassEncoder, DBNEncoder
 from .generators import RnnNade, RnnRBM, RnnMultiNADE
+from . import ops
 from .training import compute_gradients_multi, world
 
 
@@ -474,6 +475,9 @@ class MultINNJamming(MultIEncoderNN):
     def _extra_stores(self):
         return []
 
+    def _backward_extra(self):
+        """Hook between the generators' backward passes and the joint optimiser step (the feedback modes back-propagate into their module)."""
+
     def _train_generators(self, optimizer, lr, pretrain=False, separate_losses=False):
         """multinn_jamming.py:186-245."""
         if not pretrain and separate_losses != self.separate_losses:
@@ -487,6 +491,7 @@ class MultINNJamming(MultIEncoderNN):
             tm.append(m); tu.append(mu); ts.append(s or {})
         metrics, metrics_upd, summaries = self._combine_track_metrics(tm, tu, ts, global_scope=f"metrics/{self.generators[0].name}/global/")
         if not separate_losses and not pretrain:
+            self._backward_extra()
             stores = [g.store for g in self.generators] + self._extra_stores()
             self._grad_sumsq = compute_gradients_multi(optimizer, stores, self.clip_norm, lr)
             for g in self.generators:
@@ -551,21 +556,43 @@ class MultINNFeedback(MultINNJamming):
         from .feedback import FeedbackDnn
         return FeedbackDnn(num_inputs, self._params["generator"]["feedback"], seed=self.seed + 500, device=self.device)   # :46-52
 
-    def _apply_feedback(self, inputs, initial_state=None, single_step=False):
+    def _apply_feedback(self, inputs, initial_state=None, single_step=False, train=False):
         if single_step:
             return self._feedback_layer.single(inputs, initial_state)
-        return self._feedback_layer.run(inputs, initial_state)
+        return self._feedback_layer.run(inputs, initial_state, train=train)
 
     def _build_generators(self, mode="eval"):
-        """multinn_feedback.py:54-101."""
-        if mode == "train":
-            raise NotImplementedError("training the feedback modes needs the gradient wrt the generator inputs (the feedback vector); "
-                                      "the feedback modes are built for evaluation and sampling (BASELINE config 5)")
+        """multinn_feedback.py:54-101.  In train mode the feedback module keeps what its backward needs and every generator is asked for the
+        gradient wrt its inputs: the feedback vector is columns [E, E + F) of each generator's input (:85-91), and the mean track loss is
+        minimised over the generators' AND the module's variables (multinn_jamming.py:235-241 with trainable_feedback_variables, :97)."""
+        train = mode == "train"
         self._x_encoded_stack = self._stack_encoded()
         if self._feedback_layer is None:
             self._feedback_layer = self._init_feedback(self._x_encoded_stack.shape[-1])
-        self._x_feedback, self._feedback_final_state = self._apply_feedback(self._x_encoded_stack, single_step=False)
+        self._feedback_layer.row0 = self._row0
+        self._x_feedback, self._feedback_final_state = self._apply_feedback(self._x_encoded_stack, single_step=False, train=train)
+        for g in self.generators:
+            g.need_dx = train and not self.separate_losses
         super()._build_generators(mode)
+
+    def _extra_stores(self):
+        return [] if self._feedback_layer is None else [self._feedback_layer.store]
+
+    def _backward_extra(self):
+        """d mean-track-loss / d feedback vectors = the feedback columns of every generator's input gradient, summed over the tracks (each
+        generator's backward already carries the 1/M of the mean), zero for the last step (inputs are [:, :-1]); then the module's backward."""
+        E, F = self._num_dims_generator, self._x_feedback.shape[-1]
+        B, T1, _ = self._x_feedback.shape
+        T = T1 - 1
+        dev = self._x_feedback.device
+        acc = torch.zeros((T1, B, F), device=dev)                    # time-major like the generators' dx
+        tmp = torch.empty((T * B, F), device=dev)
+        for g in self.generators:
+            dx = g._dx                                               # f32 [T, B, E + F]
+            ops.convert2d(dx.view(T * B, E + F)[:, E:], tmp)
+            flat = acc.view(-1)[:T * B * F]
+            ops.axpby(1.0, flat, 1.0, tmp.view(-1), flat)
+        self._feedback_layer.backward(acc.transpose(0, 1).contiguous())       # [B, T+1, F], the row order of the forward call
 
     def _generator_io(self, i):
         inputs = torch.cat([self._x_encoded[i].float(), self._x_feedback], dim=-1)               # multinn_feedback.py:85-91

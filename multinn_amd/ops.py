@@ -562,6 +562,15 @@ def rbm_cd_bias_delta(v, p_v, h, p_h, scale, dbv, dbh):
     call("mnn_rbm_cd_bias_delta", _stream(), N, D, Hn, _ptr(v), _ptr(p_v), _ptr(h), _ptr(p_h), float(scale), _ptr(dbv), _ptr(dbh))
 
 
+def sigmoid_grad(dy, y, dz):
+    """dz = dy * y * (1 - y) (f32, same shapes; dz may alias dy)."""
+    n = y.numel()
+    for t in (dy, y, dz):
+        _req(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n, "sigmoid_grad: contiguous f32 buffers of equal size")
+    call("mnn_sigmoid_grad_f32", _stream(), n, _ptr(dy), _ptr(y), _ptr(dz))
+    return dz
+
+
 def rbm_cd_rows(v, v_s, sv, ss, rw, scale, d_out, pos, neg):
     """Rows of the LSTM-RBM cost gradient: d_out[:, :Hn] = w (ss - sv), d_out[:, Hn:Hn+D] = w (v_s - v), padding zeroed; pos = w ss, neg = -w sv
     (w = rw * scale).  v / v_s u8 [N,D], sv / ss f32 [N,Hn], d_out f32 [N, ld >= Hn + D] (rnn_rbm.py:113-126, rbm.py:229)."""

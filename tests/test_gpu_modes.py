@@ -312,8 +312,7 @@ def test_c5_feedback_rnn_mode_sampling_scan():
         inp = np.concatenate([enc[..., i], x_fb], -1)[:, :-1]
         fw = G.rnn_nade_forward(inp, enc[..., i][:, 1:], None, gparams[i], 1.0, None)
         assert abs(float(g.metrics["batch/loss"]) - fw['loss']) < 1e-4 * fw['loss'], i
-    with pytest.raises(NotImplementedError):
-        m.build(dev(x), lengths=None, is_train=True, mode="train")
+    m.build(dev(x), lengths=None, is_train=True, mode="train")          # trainable too: test_feedback_modes_train_step_vs_oracle
 
 
 def test_c5_feedback_rnn_512_generated_steps():
@@ -383,3 +382,74 @@ def test_rbm_visible_bias_init_and_rnn_rbm_pretrain():
     assert rel(gen._rbm.bv.cpu().numpy().reshape(-1), orbm.visible_bias_init(flat)) < 1e-5
     pm = flat.mean(0)
     assert np.allclose(gen._rbm.bv.cpu().numpy().reshape(-1), np.log(1e-6 + pm / (1 - pm)), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["feedback", "feedback-rnn"])
+def test_feedback_modes_train_step_vs_oracle(mode):
+    """Training the feedback modes (multinn_feedback.py:54-101 + multinn_jamming.py:186-245): the mean track loss is minimised over the M
+    generators AND the feedback module, whose output is columns [E, E + F) of every generator's input -- so each generator hands back the
+    gradient wrt its inputs and the module back-propagates their sum.  fp32, keep_prob = 1: every gradient (generators / M, Dense or LSTM
+    feedback module) and the joint global norm against the oracle composed from its LSTM / NADE pieces."""
+    from multinn_amd import MultINN, AdamOptimizer
+    P, M, Hn, units, B, Ti = 8, 3, 12, [32, 32], 4, 5
+    fb_units = [24] if mode == "feedback" else [64, 32]
+    F = fb_units[-1]
+    x = batch(B, Ti, P, M, 31, rho=0.3)
+    m = MultINN(config(P, TRACKS5[:M]), params(mode, Hn=Hn, units=units, feedback=fb_units, keep_prob=1.0), mode=mode, precision="fp32")
+    m.build(dev(x), lengths=None, is_train=True, mode="train")
+    gparams = []
+    for i, g in enumerate(m.generators):
+        p = G.init_rnn_nade(80 + i, P + F, P, Hn, units, np.float64)
+        load_nade_params(g, p)
+        gparams.append(p)
+    fb = m._feedback_layer
+    f64 = lambda t: t.cpu().numpy().astype(np.float64)
+    m.build(dev(x), lengths=None, is_train=True, mode="train")          # with the loaded weights
+    enc = np.concatenate([np.zeros((B, 1, P, M)), x.astype(np.float64)], 1)            # PassEncoder codes, zero first step
+    stack = enc.reshape(B, Ti + 1, P * M)
+    if mode == "feedback":
+        Ws = [(f64(fb.store[f"feedback/dnn/dense_{l}/kernel"]), f64(fb.store[f"feedback/dnn/dense_{l}/bias"])) for l in range(len(fb_units))]
+        acts = [stack.reshape(-1, P * M)]
+        for W, b in Ws:
+            acts.append(1.0 / (1.0 + np.exp(-(acts[-1] @ W + b))))
+        x_fb = acts[-1].reshape(B, Ti + 1, F)
+    else:
+        fb_layers = [(f64(fb.store[f"feedback/rnn/cell_{l}/kernel"]), f64(fb.store[f"feedback/rnn/cell_{l}/bias"])) for l in range(len(fb_units))]
+        x_fb, _, fcache = olstm.seq_fwd(stack, fb_layers)
+    d_fb = np.zeros((B, Ti + 1, F))
+    refs, loss = [], 0.0
+    for i in range(M):
+        inp = np.concatenate([enc[..., i], x_fb], -1)[:, :-1]
+        fw = G.rnn_nade_forward(inp, enc[..., i][:, 1:], None, gparams[i], 1.0, None)
+        gi = G.rnn_nade_backward(fw, gparams[i])
+        loss += fw['loss'] / M
+        d_fb[:, :-1] += gi['dx'][..., P:] / M
+        refs.append([a / M for a in ([w_ for pair in gi['lstm'] for w_ in pair] + [np.stack(gi['w_enc']), np.stack(gi['w_dec']), gi['fc_k'], gi['fc_b']])])
+    if mode == "feedback":
+        fb_ref, dy = [], d_fb.reshape(-1, F)
+        for l in range(len(Ws) - 1, -1, -1):
+            dz = dy * acts[l + 1] * (1 - acts[l + 1])
+            fb_ref = [acts[l].T @ dz, dz.sum(0)] + fb_ref
+            dy = dz @ Ws[l][0].T
+    else:
+        _, lg = olstm.seq_bwd(d_fb, fcache)
+        fb_ref = [a for pair in lg for a in pair]
+    _, _, metrics, _, _ = m.train_generators(AdamOptimizer(0.01), 0.01)
+    assert abs(float(metrics["batch/loss"]) - loss) < 1e-4 * abs(loss)
+    sq = 0.0
+    for i, g in enumerate(m.generators):
+        for name, r_ in zip(g.store.names(), refs[i]):
+            got = g.store.gviews[name].cpu().numpy().reshape(r_.shape)
+            assert rel(got, r_) < 1e-4, (i, name)
+            sq += float((r_ ** 2).sum())
+    for name, r_ in zip(fb.store.names(), fb_ref):
+        got = fb.store.gviews[name].cpu().numpy().reshape(r_.shape)
+        assert rel(got, r_) < 1e-4, name
+        assert np.abs(r_).max() > 0                                                     # the module really receives a gradient
+        sq += float((r_ ** 2).sum())
+    assert abs(float(m._grad_sumsq.sqrt()) - np.sqrt(sq)) < 1e-4 * np.sqrt(sq)         # ONE global norm over generators + feedback module
+    before = float(metrics["batch/loss"])
+    for _ in range(5):
+        m.build(dev(x), lengths=None, is_train=True, mode="train")
+        _, _, metrics, _, _ = m.train_generators(AdamOptimizer(0.01), 0.01)
+    assert float(metrics["batch/loss"]) < before
