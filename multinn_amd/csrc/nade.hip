@@ -229,7 +229,6 @@ extern "C" int mnn_nade_logprob_fwd_gated(mnn_stream_t s, int tracks, int N, int
 // ----------------------------------------------------------------------------------------------
 // backward: reverse scan over the visible order
 // ----------------------------------------------------------------------------------------------
-#define BWD_R 8   // rows per wave
 // Staging for the backward kernel.  HQ == 4: lane-major in LDS (the hidden units l, l+64, l+128, l+192 side by side), so the scan reads
 // the four values a lane needs with one 16-byte load per matrix.  Thread (visible t >> 6, slot l = t & 63) fetches exactly those four
 // values (four loads, each 256 contiguous bytes per wave) and stores them with ONE conflict-free 16-byte LDS store per matrix.
@@ -275,7 +274,9 @@ __device__ __forceinline__ void bwd_lstore(const WStage<HQ>& st, float* __restri
     }
 }
 
-template <int HQ>
+// RG = groups of 8 rows per wave (rows per workgroup: 64 RG).  RG = 2 halves the f32 atomics per row (one add per visible and hidden unit
+// per 128 rows) and the LDS reads / exchanges per FMA, at twice the state registers (HQ = 2: 4 x 16 x 2 = 128): two waves per SIMD.
+template <int HQ, int RG>
 __global__ void __launch_bounds__(512)
 nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias,
                 int ld_bias, const float* __restrict__ w_enc, const float* __restrict__ w_dec, const float* __restrict__ a_final,
@@ -289,7 +290,8 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
     const int Hn = min(W, HnT - hb);                                           // hidden units of this slice
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rbase = blockIdx.x * 64 + w * BWD_R;
+    constexpr int BWD_R = 8 * RG;                                              // rows per wave
+    const int rbase = blockIdx.x * (64 * RG) + w * BWD_R;
     const uint8_t* __restrict__ vm = v + (size_t)m * v_track_stride;
     const float* __restrict__ we = w_enc + (size_t)m * D * HnT + hb;
     const float* __restrict__ wd = w_dec + (size_t)m * D * HnT + hb;
@@ -309,24 +311,42 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
             G[r][q] = 0.f;
             c[r][q] = 0.f;
         }
-    const int frow = rbase + (lane >> 3), fi = lane & 7;
-    const bool fvalid = frow < N;
-    const int frr = fvalid ? frow : N - 1;
+    const int fi = lane & 7;
+    int frr[RG];
+    bool fvalid[RG];
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+        const int frow = rbase + 8 * g + (lane >> 3);
+        fvalid[g] = frow < N;
+        frr[g] = fvalid[g] ? frow : N - 1;
+    }
     const int nch = (D + 7) / 8;
     WStage<HQ> st;
     bwd_gload<HQ>(st, wd, we, (nch - 1) * 8, D, Hn, HnT);
     bwd_lstore<HQ>(st, wl[0][0], wl[0][1]);
-    int icur = (nch - 1) * 8 + fi;
-    bool vcur = fvalid && icur < D && vm[(size_t)frr * D + icur] != 0;
-    float dcur = (fvalid && icur < D) ? d_bias[(size_t)frr * ld_bias + dl_off + icur] : 0.f;
+    const int icur = (nch - 1) * 8 + fi;
+    bool vcur[RG];
+    float dcur[RG];
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+        vcur[g] = fvalid[g] && icur < D && vm[(size_t)frr[g] * D + icur] != 0;
+        dcur[g] = (fvalid[g] && icur < D) ? d_bias[(size_t)frr[g] * ld_bias + dl_off + icur] : 0.f;
+    }
     __syncthreads();
     for (int cc = 0; cc < nch; ++cc) {
         const int i0 = (nch - 1 - cc) * 8;
         const int inext = i0 - 8 + fi;
         bwd_gload<HQ>(st, wd, we, i0 - 8, D, Hn, HnT);                             // next (lower) chunk, zeros below 0
-        const bool vnext = fvalid && inext >= 0 && vm[(size_t)frr * D + inext] != 0;
-        const float dnext = (fvalid && inext >= 0) ? d_bias[(size_t)frr * ld_bias + dl_off + inext] : 0.f;
-        const unsigned long long mask = __ballot(vcur);
+        bool vnext[RG];
+        float dnext[RG];
+        unsigned long long mask[RG], many = 0ull;
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            vnext[g] = fvalid[g] && inext >= 0 && vm[(size_t)frr[g] * D + inext] != 0;
+            dnext[g] = (fvalid[g] && inext >= 0) ? d_bias[(size_t)frr[g] * ld_bias + dl_off + inext] : 0.f;
+            mask[g] = __ballot(vcur[g]);
+            many |= mask[g];
+        }
         const float* __restrict__ sd = wl[cc & 1][0];
         const float* __restrict__ se = wl[cc & 1][1];
 #pragma unroll
@@ -352,10 +372,10 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
                 }
                 // the rows are independent: first the (rare) state changes of the rows with v_i = 1 -- skipped with ONE scalar test when
                 // none of the wave's 8 rows has one (4 visibles in 5 at rho = 0.03) --, then the FMAs of all 8 rows, straight-line
-                if ((mask & (0x0101010101010101ull << ii)) != 0ull) {
+                if ((many & (0x0101010101010101ull << ii)) != 0ull) {
 #pragma unroll
                     for (int r = 0; r < BWD_R; ++r) {
-                        if ((mask >> (r * 8 + ii)) & 1ull) {
+                        if ((mask[r >> 3] >> ((r & 7) * 8 + ii)) & 1ull) {
 #pragma unroll
                             for (int q = 0; q < HQ; ++q) {
                                 G[r][q] = fmaf(c[r][q], fmaf(-h[r][q], h[r][q], h[r][q]), G[r][q]);   // close the segment that used a_{i+1}
@@ -369,7 +389,7 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
                 }
 #pragma unroll
                 for (int r = 0; r < BWD_R; ++r) {
-                    const float dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dcur), r * 8 + ii));
+                    const float dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dcur[r >> 3]), (r & 7) * 8 + ii));
 #pragma unroll
                     for (int q = 0; q < HQ; ++q) {
                         accd[k][q] = fmaf(dl, h[r][q], accd[k][q]);
@@ -446,8 +466,8 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
                 }
             }
         }
-        vcur = vnext;
-        dcur = dnext;
+#pragma unroll
+        for (int g = 0; g < RG; ++g) { vcur[g] = vnext[g]; dcur[g] = dnext[g]; }
         __syncthreads();
     }
 #pragma unroll
@@ -518,13 +538,19 @@ extern "C" int mnn_nade_logprob_bwd_ws(mnn_stream_t s, int tracks, int N, int D,
     // hidden slices: Hn <= 256 in one workgroup of lane-major quads (HQ = 4), or as two 128-wide slices at twice the residency (HQ = 2)
     static int split = -1;
     if (split < 0) { const char* e = getenv("MULTINN_NADE_BWD_SLICES"); split = e ? atoi(e) : 2; }
-#define BWD(HQ, NS) hipLaunchKernelGGL(nade_bwd_kernel<HQ>, dim3(cdiv(N, 64), tracks * (NS)), dim3(512), 0, st, tracks, N, D, Hn, NS, v, v_track_stride, \
-                                       bias, ld_bias, w_enc, w_dec, a_final, d_bias, d_w_enc, d_w_dec, slab)
-    if (Hn <= 64) BWD(1, 1);
-    else if (Hn <= 128) { if (split == 4) BWD(1, cdiv(Hn, 64)); else BWD(2, 1); }
-    else if (split == 4) BWD(1, cdiv(Hn, 64));
-    else if (split == 2) BWD(2, cdiv(Hn, 128));
-    else BWD(4, 1);
+    // rows per workgroup: 64, or with MULTINN_NADE_BWD_ROWS=128 two groups of 8 rows per wave (half the f32 atomics per row, a quarter fewer LDS
+    // reads per FMA).  Measured SLOWER at the bench shape (4.98 vs 3.94 ms, rho = 0.5: 8.6 vs 6.5): 187 registers leave two waves per SIMD
+    // instead of four -- the scan is bound by issue / latency at that occupancy, its atomics ride along
+    static int rows2 = -1;
+    if (rows2 < 0) { const char* e = getenv("MULTINN_NADE_BWD_ROWS"); rows2 = (e && atoi(e) == 128) ? 2 : 0; }
+#define BWD(HQ, RG, NS) hipLaunchKernelGGL((nade_bwd_kernel<HQ, RG>), dim3(cdiv(N, 64 * (RG)), tracks * (NS)), dim3(512), 0, st, tracks, N, D, Hn, NS, v, \
+                                           v_track_stride, bias, ld_bias, w_enc, w_dec, a_final, d_bias, d_w_enc, d_w_dec, slab)
+    const bool r2 = slab == nullptr && rows2 == 2;
+    if (Hn <= 64) BWD(1, 1, 1);
+    else if (Hn <= 128) { if (split == 4) BWD(1, 1, cdiv(Hn, 64)); else if (r2) BWD(2, 2, 1); else BWD(2, 1, 1); }
+    else if (split == 4) BWD(1, 1, cdiv(Hn, 64));
+    else if (split == 2) { if (r2) BWD(2, 2, cdiv(Hn, 128)); else BWD(2, 1, cdiv(Hn, 128)); }
+    else BWD(4, 1, 1);
 #undef BWD
     MNN_LAUNCH_CHECK();
     if (slab != nullptr) {
