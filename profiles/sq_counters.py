@@ -17,7 +17,7 @@ def main():
             name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
             acc[name][r["Counter_Name"]] += float(r["Counter_Value"])
             calls[name].add(r["Dispatch_Id"])
-    out = {"workload": "C2 [256,128,88,5] bf16, eager launches, 3 steps + 1 warm-up", "kernels": {}}
+    out = {"workload": sys.argv[3] if len(sys.argv) > 3 else "C2 [256,128,88,5] bf16, eager launches, 3 steps + 1 warm-up", "kernels": {}}
     for name, c in sorted(acc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0.0)):
         n = len(calls[name])
         if n == 0 or name.startswith("at::") or "rocclr" in name:
