@@ -47,7 +47,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="tgt", choices=sorted(WORKLOADS))
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--rho", type=float, default=0.03)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampling", action="store_true", help="skip the sampling-scan measurement (rank 0, after the timed region)")
@@ -193,8 +193,8 @@ def step_roofline(N, D, precision, t_measured_s, sig_peak):
     R1, R2 = UNITS
     fwd_flop = 2.0 * ((D + R1) * 4 * R1 + (R1 + R2) * 4 * R2 + R2 * (D + HN))
     flops = 3.0 * fwd_flop * N
-    peak_mfma = (PEAK_MFMA_BF16_TFLOPS if precision == "bf16" else PEAK_MFMA_F32_TFLOPS) * 1e12
-    act = 2 if precision == "bf16" else 4
+    peak_mfma = (PEAK_MFMA_F32_TFLOPS if precision == "fp32" else PEAK_MFMA_BF16_TFLOPS) * 1e12      # f16 and bf16 MFMA: the same dense rate
+    act = 4 if precision == "fp32" else 2
     bytes_dense = N * D + 2.0 * N * (4 * R1 + 4 * R2) * 4 + 2.0 * N * (2 * R1 + 2 * R2) * act + 7 * 4 * 3143352
     sig = N * (2.0 * D * HN + D)
     bytes_nade = N * (3 * 4 * (HN + D) + 2 * 4 * (HN + D) + D)
@@ -348,7 +348,7 @@ def main(argv=None):
 
     # ---- roofline per entry point (algorithmic counts: DESIGN.md "Roofline accounting"); `roofline` = the one with the largest share ----
     R1, R2 = UNITS
-    peak_mfma = PEAK_MFMA_BF16_TFLOPS if a.precision == "bf16" else PEAK_MFMA_F32_TFLOPS
+    peak_mfma = PEAK_MFMA_F32_TFLOPS if a.precision == "fp32" else PEAK_MFMA_BF16_TFLOPS
     rec_flops = 2.0 * N * (R1 * 4 * R1 + R2 * 4 * R2)          # the T sequential [B,u]x[u,4u] products of both layers, one direction
 
     def entry_roofline(dom, dom_ms, dom_calls):
@@ -425,7 +425,7 @@ def main(argv=None):
     out = {
         "metric": "piano-roll timesteps/sec (train step), 5-track LSTM-NADE", "value": world * B * T / sec,
         "unit": "timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": sec * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.precision == "bf16" else "f32",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp16": "fp16", "bf16": "bf16", "fp32": "f32"}[a.precision],
         "data": "synthetic",
         "config": {"workload": w["name"], "global_batch": world * B, "per_gpu_batch": B, "seq_len": T, "pitches": P, "tracks": M, "rho": a.rho,
                    "nade_hidden": HN, "lstm_units": UNITS, "keep_prob": 0.9, "optimizer": "TF-Adam lr 0.01 eps 1e-4 clip 5.0",

@@ -8,7 +8,7 @@
  *     comes from the matching *_workspace_bytes() query;
  *   - every call takes a hipStream_t (as void*) and is asynchronous on that stream;
  *   - no global mutable state; RNG is passed as (seed, row0, sub) -- never global;
- *   - dtypes are explicit enums; "T" operands are bf16 or f32 (mnn_dtype).
+ *   - dtypes are explicit enums; "T" operands are bf16, f16 (IEEE half) or f32 (mnn_dtype).
  *
  * Each entry cites the reference interface it replaces as file:line under
  * /root/reference/multinn (ilya16/MultINN).
@@ -39,7 +39,7 @@ extern "C" {
 
 typedef void* mnn_stream_t; /* hipStream_t */
 
-typedef enum { MNN_F32 = 0, MNN_BF16 = 1, MNN_U8 = 2 } mnn_dtype;
+typedef enum { MNN_F32 = 0, MNN_BF16 = 1, MNN_U8 = 2, MNN_F16 = 3 } mnn_dtype;   /* MNN_F16: IEEE half (precision "fp16"), accepted wherever the 16-bit "T" is */
 
 /* RNG streams of the build's Philox4x32-10 contract (DESIGN.md "RNG contract") */
 enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_STREAM_RBM_V = 3,
@@ -62,11 +62,11 @@ const char* mnn_last_error(void);
 int mnn_gemm_tn(mnn_stream_t s, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                 void* C, int ldc, int c_dtype, const float* bias, int flags, int split_k);
 
-/* out[C,R] = in[R,C]^T with dtype conversion (in_dtype -> out_dtype in {f32,bf16,u8->f32/bf16});
+/* out[C,R] = in[R,C]^T with dtype conversion (in_dtype in {f32,bf16,f16,u8} -> out_dtype in {f32,bf16,f16});
  * used to build K-contiguous operands for weight-gradient GEMMs and transposed weight copies. */
 int mnn_transpose(mnn_stream_t s, const void* in, int in_dtype, int R, int C, int ld_in, void* out, int out_dtype, int ld_out);
 
-/* dst[r, c] = convert(src[r, c]) (2-D strided copy/convert; f32<->bf16, u8->f32/bf16) */
+/* dst[r, c] = convert(src[r, c]) (2-D strided copy/convert; f32<->bf16/f16, u8->f32/bf16/f16) */
 int mnn_convert2d(mnn_stream_t s, const void* src, int src_dtype, int ld_src, void* dst, int dst_dtype, int ld_dst, int R, int C);
 
 /* ------------------------------------------------------------------------------------------
@@ -85,7 +85,8 @@ int mnn_pianoroll_shift_timemajor(mnn_stream_t s, const uint8_t* x, int B, int T
 /* Same plumbing for the bf16 train step, plus inputs_t[ld_in, ld_t >= B*T]: the transposed copy of `inputs` (feature-major,
  * column t*B+b), the K-major operand of layer 1's weight-gradient GEMM (saves a transpose pass over `inputs`). */
 int mnn_pianoroll_shift_timemajor_t(mnn_stream_t s, const uint8_t* x, int B, int T, int D, const int32_t* lengths, void* inputs,
-                                    int ld_in, void* inputs_t, int ld_t, uint8_t* targets, float* row_weight, long n_valid_total);
+                                    int ld_in, void* inputs_t, int ld_t, uint8_t* targets, float* row_weight, long n_valid_total,
+                                    int dtype /* MNN_BF16 or MNN_F16: the flavour of inputs / inputs_t */);
 
 /* per-track variant: targets_tracks u8 [M,T,B,P] from x u8 [B,T,P,M]  (multi_encoder_nn.py:66-76) */
 int mnn_pianoroll_split_tracks(mnn_stream_t s, const uint8_t* x, int B, int T, int P, int M, uint8_t* targets_tracks);
@@ -153,10 +154,14 @@ typedef struct { int units; const float* xproj; const void* wh_t; const void* h0
                  void* hT; int ld_hT; void* y; const uint8_t* mask; const void* wx_t; int ld_w; const float* bias_p;
                  void* yT; int ld_yT; /* persistent form only (else NULL): transposed copy of the layer's output (y, or h without
                                          dropout), yT[unit][t*B + row] -- the K-contiguous operand of the next weight gradient */
-                 int xproj_bf16;      /* mnn_lstm_rowpar_fwd only: xproj points at BF16 [T,B,4u] (gate-minor, bias included) instead of f32 */
+                 int xproj_bf16;      /* mnn_lstm_rowpar_fwd only: xproj points at 16-bit values [T,B,4u] (gate-minor, bias included) instead of f32 */
+                 int f16;             /* persistent forms (mnn_lstm2_persist_*, mnn_lstm_rowpar_*): every 16-bit tensor of this layer (weights, h, y, hT, yT,
+                                         16-bit xproj / saved gates) is IEEE half instead of bfloat16 */
                } mnn_lstm_fwd_layer;
 typedef struct { int units; const float* dh_ext; const void* wh_p; const float* gates; const float* c; const float* c0; float* dz;
-                 void* dz_T; void* workspace; void* dzT_t; int ld_t; float* db_p; const uint8_t* mask; const void* wx_p; } mnn_lstm_bwd_layer;
+                 void* dz_T; void* workspace; void* dzT_t; int ld_t; float* db_p; const uint8_t* mask; const void* wx_p;
+                 int f16;             /* as in mnn_lstm_fwd_layer */
+               } mnn_lstm_bwd_layer;
 int mnn_lstm2_seq_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L1, const mnn_lstm_fwd_layer* L2, float keep_prob,
                       int s_begin, int s_end);
 int mnn_lstm2_seq_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L1, const mnn_lstm_bwd_layer* L2, float keep_prob,
@@ -338,7 +343,7 @@ int mnn_fill_f32(mnn_stream_t s, float* x, long n, float value);
  * Dense layer): out_c = bf16 copy [rows, ld_c] with the padding columns [cols_t, cols_c) written as zeros (dY's are not read); out_t = bf16 transpose of the first cols_t columns [cols_t, ld_t >= rows];
  * db[c] += column sums for c < cols_t.  Replaces convert2d + transpose + bias_grad (three reads of dY) in bf16 mode. */
 int mnn_grad_rows_fanout(mnn_stream_t s, const float* dY, int rows, int cols_c, int cols_t, int ld, void* out_c, int ld_c, void* out_t,
-                         int ld_t, float* db);
+                         int ld_t, float* db, int dtype /* MNN_BF16 or MNN_F16: the flavour of out_c / out_t */);
 
 /* ------------------------------------------------------------------------------------------
  * Musical sample metrics (metrics/musical.py:45-275): integer passes over a sampled piano-roll

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MULTINN_HIP_LIB", os.path.join(HERE, "libmultinn_hip.so"))   # override: A/B builds of the same ABI
 
-F32, BF16, U8 = 0, 1, 2
+F32, BF16, U8, F16 = 0, 1, 2, 3
 GEMM_ACCUMULATE, GEMM_ATOMIC = 1, 2
 
 _p, _i, _l, _f, _u64, _u32, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_uint32, C.c_size_t
@@ -22,7 +22,7 @@ SIGNATURES = {
     "mnn_transpose": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _i]),
     "mnn_convert2d": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i]),
     "mnn_pianoroll_shift_timemajor": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _l]),
-    "mnn_pianoroll_shift_timemajor_t": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p, _l]),
+    "mnn_pianoroll_shift_timemajor_t": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p, _l, _i]),
     "mnn_pianoroll_split_tracks": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mnn_lstm_pack_weights": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "mnn_lstm_unpack_grads": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
@@ -47,18 +47,18 @@ SIGNATURES = {
     "mnn_clip_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _f, _i, _p, _i]),
     "mnn_step_increment": (_i, [_p, _p]),
     "mnn_bias_grad": (_i, [_p, _p, _i, _i, _i, _p, _i]),
-    "mnn_grad_rows_fanout": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
+    "mnn_grad_rows_fanout": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i]),
     "mnn_fill_f32": (_i, [_p, _p, _l, _f]),
 }
 
 class LstmFwdLayer(C.Structure):
     _fields_ = [("units", _i), ("xproj", _p), ("wh_t", _p), ("h0", _p), ("c0", _p), ("gates", _p), ("c", _p), ("h", _p), ("hT", _p), ("ld_hT", _i), ("y", _p), ("mask", _p),
-                ("wx_t", _p), ("ld_w", _i), ("bias_p", _p), ("yT", _p), ("ld_yT", _i), ("xproj_bf16", _i)]
+                ("wx_t", _p), ("ld_w", _i), ("bias_p", _p), ("yT", _p), ("ld_yT", _i), ("xproj_bf16", _i), ("f16", _i)]
 
 
 class LstmBwdLayer(C.Structure):
     _fields_ = [("units", _i), ("dh_ext", _p), ("wh_p", _p), ("gates", _p), ("c", _p), ("c0", _p), ("dz", _p), ("dz_T", _p), ("workspace", _p),
-                ("dzT_t", _p), ("ld_t", _i), ("db_p", _p), ("mask", _p), ("wx_p", _p)]
+                ("dzT_t", _p), ("ld_t", _i), ("db_p", _p), ("mask", _p), ("wx_p", _p), ("f16", _i)]
 
 
 SIGNATURES["mnn_lstm2_seq_fwd"] = (_i, [_p, _i, _i, C.POINTER(LstmFwdLayer), C.POINTER(LstmFwdLayer), _f, _i, _i])

@@ -89,6 +89,15 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return __builtin_bit_cast(uint16_t, b);
 }
 
+// IEEE half: the second 16-bit operand flavour (precision "fp16": 11 significant bits instead of bf16's 8 at the same MFMA rate and the
+// same bytes; the operands of this path -- {0,1} inputs, |h| <= 1, |w| < 1, loss-scaled gradients -- sit inside its range).  Kernels templated
+// on an element type take f16_t; kernels that move raw 16-bit words (h16_t) take a flavour struct (Bf16F / Fp16F) for the conversions and
+// the matrix-core instruction.
+typedef _Float16 f16_t;
+typedef uint16_t h16_t;
+__device__ __forceinline__ float f16_to_f32(h16_t x) { return (float)__builtin_bit_cast(_Float16, x); }
+__device__ __forceinline__ h16_t f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }    // v_cvt_f16_f32: round to nearest even
+
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {
     __device__ static __forceinline__ float load(float x) { return x; }
@@ -98,6 +107,39 @@ template <> struct Cvt<bf16_t> {
     __device__ static __forceinline__ float load(bf16_t x) { return bf16_to_f32(x); }
     __device__ static __forceinline__ bf16_t store(float x) { return f32_to_bf16(x); }
 };
+template <> struct Cvt<f16_t> {
+    __device__ static __forceinline__ float load(f16_t x) { return (float)x; }
+    __device__ static __forceinline__ f16_t store(float x) { return (f16_t)x; }
+};
+
+typedef float mnn_f32x16 __attribute__((ext_vector_type(16)));
+typedef float mnn_f32x4 __attribute__((ext_vector_type(4)));
+struct Bf16F {
+    typedef __bf16 x8 __attribute__((ext_vector_type(8)));
+    typedef bf16_t elem;
+    static constexpr int DTYPE = MNN_BF16;
+    __device__ static __forceinline__ float f32(h16_t x) { return bf16_to_f32(x); }
+    __device__ static __forceinline__ h16_t cvt(float f) { return f32_to_bf16(f); }
+    __device__ static __forceinline__ float lo(uint32_t v) { return __uint_as_float(v << 16); }            // low / high half of a packed pair
+    __device__ static __forceinline__ float hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+    __device__ static __forceinline__ mnn_f32x16 mfma32(x8 a, x8 b, mnn_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ mnn_f32x4 mfma16(x8 a, x8 b, mnn_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+struct Fp16F {
+    typedef _Float16 x8 __attribute__((ext_vector_type(8)));
+    typedef f16_t elem;
+    static constexpr int DTYPE = MNN_F16;
+    __device__ static __forceinline__ float f32(h16_t x) { return f16_to_f32(x); }
+    __device__ static __forceinline__ h16_t cvt(float f) { return f32_to_f16(f); }
+    __device__ static __forceinline__ float lo(uint32_t v) { return f16_to_f32((h16_t)(v & 0xffffu)); }
+    __device__ static __forceinline__ float hi(uint32_t v) { return f16_to_f32((h16_t)(v >> 16)); }
+    __device__ static __forceinline__ mnn_f32x16 mfma32(x8 a, x8 b, mnn_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ mnn_f32x4 mfma16(x8 a, x8 b, mnn_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <typename T> struct FlavorOf;
+template <> struct FlavorOf<bf16_t> { typedef Bf16F type; };
+template <> struct FlavorOf<f16_t> { typedef Fp16F type; };
+template <typename F> __device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)F::cvt(a) | ((uint32_t)F::cvt(b) << 16); }
 
 // ----------------------------------------------------------------------------------------------
 // fast math (throughput paths; tolerance-checked against the oracle)

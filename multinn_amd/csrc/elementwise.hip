@@ -20,10 +20,12 @@ extern "C" int mnn_version(void) { return 100; }
 template <typename T> __device__ __forceinline__ float ld_as_f32(const T* p, size_t i);
 template <> __device__ __forceinline__ float ld_as_f32<float>(const float* p, size_t i) { return p[i]; }
 template <> __device__ __forceinline__ float ld_as_f32<bf16_t>(const bf16_t* p, size_t i) { return bf16_to_f32(p[i]); }
+template <> __device__ __forceinline__ float ld_as_f32<f16_t>(const f16_t* p, size_t i) { return (float)p[i]; }
 template <> __device__ __forceinline__ float ld_as_f32<uint8_t>(const uint8_t* p, size_t i) { return (float)p[i]; }
 template <typename T> __device__ __forceinline__ void st_from_f32(T* p, size_t i, float v);
 template <> __device__ __forceinline__ void st_from_f32<float>(float* p, size_t i, float v) { p[i] = v; }
 template <> __device__ __forceinline__ void st_from_f32<bf16_t>(bf16_t* p, size_t i, float v) { p[i] = f32_to_bf16(v); }
+template <> __device__ __forceinline__ void st_from_f32<f16_t>(f16_t* p, size_t i, float v) { p[i] = (f16_t)v; }
 
 // ----------------------------------------------------------------------------------------------
 // transpose with conversion: out[c, r] = in[r, c]; 32x32 tiles through LDS (+1 pad)
@@ -58,11 +60,13 @@ extern "C" int mnn_transpose(mnn_stream_t s, const void* in, int in_dtype, int R
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(in && out && R > 0 && C > 0 && ld_in >= C && ld_out >= R, "mnn_transpose: bad arguments R=%d C=%d ld_in=%d ld_out=%d", R, C,
                 ld_in, ld_out);
-    MNN_REQUIRE(out_dtype == MNN_F32 || out_dtype == MNN_BF16, "mnn_transpose: out dtype must be f32/bf16");
-#define TR(TI) (out_dtype == MNN_F32 ? launch_transpose<TI, float>(st, in, R, C, ld_in, out, ld_out) \
-                                      : launch_transpose<TI, bf16_t>(st, in, R, C, ld_in, out, ld_out))
+    MNN_REQUIRE(out_dtype == MNN_F32 || out_dtype == MNN_BF16 || out_dtype == MNN_F16, "mnn_transpose: out dtype must be f32/bf16/f16");
+#define TR(TI) (out_dtype == MNN_F32 ? launch_transpose<TI, float>(st, in, R, C, ld_in, out, ld_out)          \
+                : out_dtype == MNN_F16 ? launch_transpose<TI, f16_t>(st, in, R, C, ld_in, out, ld_out)         \
+                                       : launch_transpose<TI, bf16_t>(st, in, R, C, ld_in, out, ld_out))
     if (in_dtype == MNN_F32) return TR(float);
     if (in_dtype == MNN_BF16) return TR(bf16_t);
+    if (in_dtype == MNN_F16) return TR(f16_t);
     if (in_dtype == MNN_U8) return TR(uint8_t);
 #undef TR
     mnn_set_error("mnn_transpose: unknown in dtype %d", in_dtype);
@@ -81,17 +85,20 @@ __global__ void convert2d_kernel(const TI* __restrict__ src, int ld_src, TO* __r
 extern "C" int mnn_convert2d(mnn_stream_t s, const void* src, int src_dtype, int ld_src, void* dst, int dst_dtype, int ld_dst, int R, int C) {
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(src && dst && R > 0 && C > 0 && ld_src >= C && ld_dst >= C, "mnn_convert2d: bad arguments");
-    MNN_REQUIRE(dst_dtype == MNN_F32 || dst_dtype == MNN_BF16, "mnn_convert2d: dst dtype must be f32/bf16");
+    MNN_REQUIRE(dst_dtype == MNN_F32 || dst_dtype == MNN_BF16 || dst_dtype == MNN_F16, "mnn_convert2d: dst dtype must be f32/bf16/f16");
     const int blocks = (int)min((long)2048, ((long)R * C + 255) / 256);
 #define CV(TI)                                                                                                              \
     do {                                                                                                                    \
         if (dst_dtype == MNN_F32)                                                                                           \
             hipLaunchKernelGGL((convert2d_kernel<TI, float>), dim3(blocks), dim3(256), 0, st, (const TI*)src, ld_src, (float*)dst, ld_dst, R, C); \
+        else if (dst_dtype == MNN_F16)                                                                                      \
+            hipLaunchKernelGGL((convert2d_kernel<TI, f16_t>), dim3(blocks), dim3(256), 0, st, (const TI*)src, ld_src, (f16_t*)dst, ld_dst, R, C); \
         else                                                                                                                \
             hipLaunchKernelGGL((convert2d_kernel<TI, bf16_t>), dim3(blocks), dim3(256), 0, st, (const TI*)src, ld_src, (bf16_t*)dst, ld_dst, R, C); \
     } while (0)
     if (src_dtype == MNN_F32) CV(float);
     else if (src_dtype == MNN_BF16) CV(bf16_t);
+    else if (src_dtype == MNN_F16) CV(f16_t);
     else if (src_dtype == MNN_U8) CV(uint8_t);
     else { mnn_set_error("mnn_convert2d: unknown src dtype %d", src_dtype); return MNN_ERR_INVALID; }
 #undef CV
@@ -125,11 +132,14 @@ extern "C" int mnn_pianoroll_shift_timemajor(mnn_stream_t s, const uint8_t* x, i
                                              int in_dtype, int ld_in, uint8_t* targets, float* row_weight, long n_valid_total) {
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(x && inputs && B > 0 && T > 0 && D > 0 && ld_in >= D, "mnn_pianoroll_shift_timemajor: bad arguments");
-    MNN_REQUIRE(in_dtype == MNN_F32 || in_dtype == MNN_BF16, "mnn_pianoroll_shift_timemajor: inputs dtype must be f32/bf16");
+    MNN_REQUIRE(in_dtype == MNN_F32 || in_dtype == MNN_BF16 || in_dtype == MNN_F16, "mnn_pianoroll_shift_timemajor: inputs dtype must be f32/bf16/f16");
     MNN_REQUIRE(lengths == nullptr || n_valid_total > 0, "mnn_pianoroll_shift_timemajor: n_valid_total required with lengths");
     const float inv_n = 1.0f / (float)(n_valid_total > 0 ? n_valid_total : (long)B * T);
     if (in_dtype == MNN_F32)
         hipLaunchKernelGGL(pianoroll_shift_kernel<float>, dim3(B * T), dim3(128), 0, st, x, B, T, D, lengths, (float*)inputs, ld_in, targets,
+                           row_weight, inv_n);
+    else if (in_dtype == MNN_F16)
+        hipLaunchKernelGGL(pianoroll_shift_kernel<f16_t>, dim3(B * T), dim3(128), 0, st, x, B, T, D, lengths, (f16_t*)inputs, ld_in, targets,
                            row_weight, inv_n);
     else
         hipLaunchKernelGGL(pianoroll_shift_kernel<bf16_t>, dim3(B * T), dim3(128), 0, st, x, B, T, D, lengths, (bf16_t*)inputs, ld_in, targets,
@@ -141,6 +151,7 @@ extern "C" int mnn_pianoroll_shift_timemajor(mnn_stream_t s, const uint8_t* x, i
 // Tiled form for the bf16 train step: 64 (t, b) rows x 64 features per workgroup, 8-byte loads of the piano-roll, 16-byte
 // stores of the shifted inputs, and ALSO the transposed copy inputs_t[feature][t B + b] (the K-major operand of layer 1's
 // weight-gradient GEMM) through an LDS tile -- instead of a second pass (mnn_transpose) over the 29 MB of inputs.
+template <typename F>
 __global__ void __launch_bounds__(256)
 pianoroll_shift_tiled_kernel(const uint8_t* __restrict__ x, int B, int Tn, int D, const int32_t* __restrict__ lengths,
                              bf16_t* __restrict__ inputs, int ld_in, bf16_t* __restrict__ inputs_t, int ld_t,
@@ -169,7 +180,7 @@ pianoroll_shift_tiled_kernel(const uint8_t* __restrict__ x, int B, int Tn, int D
         bf16_t o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            o[e] = f32_to_bf16((float)pv[e]);              // 0..255 are exact in bf16
+            o[e] = F::cvt((float)pv[e]);                    // 0..255 are exact in bf16 and in f16
             tile[rr][8 * fq + e] = o[e];
         }
         if (n < N) {
@@ -216,7 +227,8 @@ pianoroll_shift_tiled_kernel(const uint8_t* __restrict__ x, int B, int Tn, int D
 }
 
 extern "C" int mnn_pianoroll_shift_timemajor_t(mnn_stream_t s, const uint8_t* x, int B, int T, int D, const int32_t* lengths, void* inputs,
-                                               int ld_in, void* inputs_t, int ld_t, uint8_t* targets, float* row_weight, long n_valid_total) {
+                                               int ld_in, void* inputs_t, int ld_t, uint8_t* targets, float* row_weight, long n_valid_total, int dtype) {
+    MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F16, "mnn_pianoroll_shift_timemajor_t: dtype must be bf16 or f16");
     MNN_REQUIRE(x && inputs && inputs_t && B > 0 && T > 0 && D > 0 && ld_in >= D, "mnn_pianoroll_shift_timemajor_t: bad arguments");
     MNN_REQUIRE(ld_in % 8 == 0 && ld_t % 8 == 0 && ld_t >= B * T, "mnn_pianoroll_shift_timemajor_t: ld_in, ld_t must be multiples of 8, ld_t >= B*T");
     MNN_REQUIRE(((uintptr_t)inputs & 15) == 0 && ((uintptr_t)inputs_t & 15) == 0 && ((uintptr_t)x & 7) == 0 && (targets == nullptr || ((uintptr_t)targets & 7) == 0),
@@ -224,8 +236,12 @@ extern "C" int mnn_pianoroll_shift_timemajor_t(mnn_stream_t s, const uint8_t* x,
     MNN_REQUIRE(lengths == nullptr || n_valid_total > 0, "mnn_pianoroll_shift_timemajor_t: n_valid_total required with lengths");
     const float inv_n = 1.0f / (float)(n_valid_total > 0 ? n_valid_total : (long)B * T);
     dim3 grid(cdiv(ld_in, 64), cdiv((long)B * T, 64));
-    hipLaunchKernelGGL(pianoroll_shift_tiled_kernel, grid, dim3(256), 0, (hipStream_t)s, x, B, T, D, lengths, (bf16_t*)inputs, ld_in,
-                       (bf16_t*)inputs_t, ld_t, targets, row_weight, inv_n);
+    if (dtype == MNN_F16)
+        hipLaunchKernelGGL(pianoroll_shift_tiled_kernel<Fp16F>, grid, dim3(256), 0, (hipStream_t)s, x, B, T, D, lengths, (bf16_t*)inputs, ld_in,
+                           (bf16_t*)inputs_t, ld_t, targets, row_weight, inv_n);
+    else
+        hipLaunchKernelGGL(pianoroll_shift_tiled_kernel<Bf16F>, grid, dim3(256), 0, (hipStream_t)s, x, B, T, D, lengths, (bf16_t*)inputs, ld_in,
+                           (bf16_t*)inputs_t, ld_t, targets, row_weight, inv_n);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
@@ -289,11 +305,14 @@ extern "C" int mnn_lstm_pack_weights(mnn_stream_t s, const float* W, const float
                                      void* wx_t, void* wh_t, void* wh_p, void* wx_p, float* bias_p) {
     MNN_REQUIRE(W && bias && wx_t && wh_t && wh_p && bias_p, "mnn_lstm_pack_weights: null pointer");
     MNN_REQUIRE(units > 0 && units % 32 == 0 && n_in > 0 && ld_in >= n_in, "mnn_lstm_pack_weights: units %% 32 != 0 or bad n_in/ld_in");
-    MNN_REQUIRE(dtype == MNN_F32 || dtype == MNN_BF16, "mnn_lstm_pack_weights: dtype must be f32/bf16");
+    MNN_REQUIRE(dtype == MNN_F32 || dtype == MNN_BF16 || dtype == MNN_F16, "mnn_lstm_pack_weights: dtype must be f32/bf16/f16");
     dim3 grid(4 * units / 32, cdiv(n_in + units, 32));
     if (dtype == MNN_F32)
         hipLaunchKernelGGL(lstm_pack_tiled_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, W, bias, n_in, units, ld_in, (float*)wx_t,
                            (float*)wh_t, (float*)wh_p, (float*)wx_p, bias_p);
+    else if (dtype == MNN_F16)
+        hipLaunchKernelGGL(lstm_pack_tiled_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)s, W, bias, n_in, units, ld_in, (f16_t*)wx_t,
+                           (f16_t*)wh_t, (f16_t*)wh_p, (f16_t*)wx_p, bias_p);
     else
         hipLaunchKernelGGL(lstm_pack_tiled_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, W, bias, n_in, units, ld_in, (bf16_t*)wx_t,
                            (bf16_t*)wh_t, (bf16_t*)wh_p, (bf16_t*)wx_p, bias_p);
@@ -317,7 +336,7 @@ __global__ void lstm_rows_gate_minor_kernel(const T* __restrict__ src, const flo
 extern "C" int mnn_lstm_rows_gate_minor(mnn_stream_t s, int dtype, int units, int ld, const void* wx_t, const float* bias_p, void* wx_gm,
                                         float* bias_gm) {
     MNN_REQUIRE(wx_t && bias_p && wx_gm && bias_gm && units > 0 && units % 32 == 0 && ld > 0, "mnn_lstm_rows_gate_minor: bad arguments");
-    MNN_REQUIRE(dtype == MNN_F32 || dtype == MNN_BF16, "mnn_lstm_rows_gate_minor: dtype must be f32/bf16");
+    MNN_REQUIRE(dtype == MNN_F32 || dtype == MNN_BF16 || dtype == MNN_F16, "mnn_lstm_rows_gate_minor: dtype must be f32/bf16/f16");   // 16-bit rows move as raw words
     if (dtype == MNN_F32)
         hipLaunchKernelGGL(lstm_rows_gate_minor_kernel<float>, dim3(4 * units), dim3(128), 0, (hipStream_t)s, (const float*)wx_t, bias_p, units, ld,
                            (float*)wx_gm, bias_gm);
@@ -410,9 +429,9 @@ extern "C" int mnn_dropout_fwd(mnn_stream_t s, int dtype, const void* h, void* y
                                const int32_t* step_dev, uint32_t row0, int layer, int t_offset) {
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(h && y && T > 0 && B > 0 && units > 0 && units % 4 == 0, "mnn_dropout_fwd: bad arguments");
-    MNN_REQUIRE(dtype == MNN_F32 || dtype == MNN_BF16, "mnn_dropout_fwd: dtype must be f32/bf16");
+    MNN_REQUIRE(dtype == MNN_F32 || dtype == MNN_BF16 || dtype == MNN_F16, "mnn_dropout_fwd: dtype must be f32/bf16/f16");
     MNN_REQUIRE(keep_prob > 0.f, "mnn_dropout_fwd: keep_prob must be > 0");
-    const size_t bytes = (size_t)T * B * units * (dtype == MNN_BF16 ? 2 : 4);
+    const size_t bytes = (size_t)T * B * units * (dtype == MNN_F32 ? 4 : 2);
     if (keep_prob >= 1.0f) {
         if (h != y) MNN_HIP(mnn_copy_async(y, h, bytes, st));
         return MNN_OK;
@@ -421,6 +440,9 @@ extern "C" int mnn_dropout_fwd(mnn_stream_t s, int dtype, const void* h, void* y
     if (dtype == MNN_F32)
         hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)h, (float*)y, T, B, units, keep_prob, seed,
                            step_dev, row0, layer, t_offset);
+    else if (dtype == MNN_F16)
+        hipLaunchKernelGGL(dropout_fwd_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const f16_t*)h, (f16_t*)y, T, B, units, keep_prob,
+                           seed, step_dev, row0, layer, t_offset);
     else
         hipLaunchKernelGGL(dropout_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)h, (bf16_t*)y, T, B, units, keep_prob,
                            seed, step_dev, row0, layer, t_offset);
@@ -659,6 +681,7 @@ extern "C" int mnn_bias_grad(mnn_stream_t s, const float* dY, int rows, int cols
 //   db[c]       += sum_r dY[r, c]            c < cols_t   (bias gradient)
 // instead of mnn_convert2d + mnn_transpose + mnn_bias_grad, each of which re-read the f32 block.
 // 64 x 64 tiles, 256 threads: thread (ty = tid / 16, tx = tid % 16) loads float4 at rows ty + 16 k, columns 4 tx.
+template <typename F>
 __global__ void __launch_bounds__(256)
 grad_rows_fanout_kernel(const float* __restrict__ dY, int rows, int cols_c, int cols_t, int ld, bf16_t* __restrict__ out_c, int ld_c,
                         bf16_t* __restrict__ out_t, int ld_t, float* __restrict__ db) {
@@ -685,7 +708,7 @@ grad_rows_fanout_kernel(const float* __restrict__ dY, int rows, int cols_c, int 
             bf16_t b[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                b[e] = f32_to_bf16(x[e]);
+                b[e] = F::cvt(x[e]);
                 acc[e] += x[e];
                 tile[ty + 16 * k][4 * tx + e] = b[e];
             }
@@ -735,13 +758,18 @@ grad_rows_fanout_kernel(const float* __restrict__ dY, int rows, int cols_c, int 
 }
 
 extern "C" int mnn_grad_rows_fanout(mnn_stream_t s, const float* dY, int rows, int cols_c, int cols_t, int ld, void* out_c, int ld_c,
-                                    void* out_t, int ld_t, float* db) {
+                                    void* out_t, int ld_t, float* db, int dtype) {
+    MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F16, "mnn_grad_rows_fanout: dtype must be bf16 or f16");
     MNN_REQUIRE(dY && out_c && out_t && db && rows > 0 && cols_c > 0 && cols_t > 0 && cols_t <= cols_c, "mnn_grad_rows_fanout: bad arguments");
     MNN_REQUIRE(ld >= cols_c && ld_c >= cols_c && ld_t >= rows, "mnn_grad_rows_fanout: leading dimension too small");
     MNN_REQUIRE(((uintptr_t)dY & 15) == 0 && ((uintptr_t)out_c & 7) == 0 && ((uintptr_t)out_t & 15) == 0, "mnn_grad_rows_fanout: misaligned buffer");
     dim3 grid(cdiv(cols_c, 64), min(256, cdiv(rows, 64)));
-    hipLaunchKernelGGL(grad_rows_fanout_kernel, grid, dim3(256), 0, (hipStream_t)s, dY, rows, cols_c, cols_t, ld, (bf16_t*)out_c, ld_c,
-                       (bf16_t*)out_t, ld_t, db);
+    if (dtype == MNN_F16)
+        hipLaunchKernelGGL(grad_rows_fanout_kernel<Fp16F>, grid, dim3(256), 0, (hipStream_t)s, dY, rows, cols_c, cols_t, ld, (bf16_t*)out_c, ld_c,
+                           (bf16_t*)out_t, ld_t, db);
+    else
+        hipLaunchKernelGGL(grad_rows_fanout_kernel<Bf16F>, grid, dim3(256), 0, (hipStream_t)s, dY, rows, cols_c, cols_t, ld, (bf16_t*)out_c, ld_c,
+                           (bf16_t*)out_t, ld_t, db);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

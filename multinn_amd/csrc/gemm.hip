@@ -8,6 +8,7 @@
 // touches fall on 16 distinct 16-byte slots (conflict-free, MI355X_MICROARCH "LDS").
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
@@ -18,7 +19,10 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <typename T> struct Elem;
 template <> struct Elem<bf16_t> { static constexpr int PER16 = 8; static constexpr int PER_CHUNK = 32; };
+template <> struct Elem<f16_t>  { static constexpr int PER16 = 8; static constexpr int PER_CHUNK = 32; };
 template <> struct Elem<float>  { static constexpr int PER16 = 4; static constexpr int PER_CHUNK = 16; };
+// 16-bit C outputs: the mnn_dtype code of C (MNN_F32 = plain f32) travels as `c16`; a 16-bit value is converted by its own flavour
+__device__ __forceinline__ h16_t cvt_c16(float v, int c16) { return c16 == MNN_F16 ? f32_to_f16(v) : f32_to_bf16(v); }
 
 template <typename T, int BM, int BN, int WM, int WN>
 struct GemmCore {
@@ -66,17 +70,19 @@ struct GemmCore {
         const char* pa = sA + (wm * (BM / WM) + r) * LDS_ROW;
         const char* pb = sB + (wn * (BN / WN) + r) * LDS_ROW;
         if constexpr (sizeof(T) == 2) {
+            using F = typename FlavorOf<T>::type;
+            using V8 = typename F::x8;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8_t a[TM], b[TN];
+                V8 a[TM], b[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(pa + i * 32 * LDS_ROW + ks * 32 + h * 16);
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const V8*>(pa + i * 32 * LDS_ROW + ks * 32 + h * 16);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(pb + j * 32 * LDS_ROW + ks * 32 + h * 16);
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const V8*>(pb + j * 32 * LDS_ROW + ks * 32 + h * 16);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = F::mfma32(a[i], b[j], acc[i][j]);
             }
         } else {
             // K order inside the chunk is permuted (lane half h owns k = 8h..8h+7) so each lane reads
@@ -177,7 +183,7 @@ gemm_tn_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ld
                 const float val = acc[i][j][r] + bv;
                 const size_t o = (size_t)row * ldc + col;
                 if (c_bf16) {
-                    Cb[o] = f32_to_bf16(val);
+                    Cb[o] = cvt_c16(val, c_bf16);
                 } else if (flags & MNN_GEMM_ATOMIC) {
                     atomicAdd(Cf + o, val);
                 } else if (flags & MNN_GEMM_ACCUMULATE) {
@@ -208,11 +214,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // part of every address is wave-uniform (scalar arithmetic), the per-lane part is one offset computed once.  The per-element form
 // (64-bit row * ldc per lane, four run-time mode branches per element) cost ~40 instructions per stored value: at K = 448 the
 // 256 x 256 tile spent 21 of its 35 us issuing its 128 stores per thread (profiles/tools/gemm_trace.hip) -- 150 -> 89 us for xproj1.
-enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_ACCUM = 2, EPI_BF16 = 3 };
+enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_ACCUM = 2, EPI_BF16 = 3, EPI_F16 = 4 };
 template <int MODE>
 __device__ __forceinline__ void epi_put(float* __restrict__ rowf, bf16_t* __restrict__ rowb, unsigned lane_off, float val) {
     // rowf / rowb are wave-uniform pointers (SGPR base), lane_off the one per-lane offset: the store needs no vector address arithmetic
     if (MODE == EPI_BF16) rowb[lane_off] = f32_to_bf16(val);
+    else if (MODE == EPI_F16) rowb[lane_off] = f32_to_f16(val);
     else if (MODE == EPI_ATOMIC) atomicAdd(rowf + lane_off, val);
     else if (MODE == EPI_ACCUM) rowf[lane_off] += val;
     else rowf[lane_off] = val;
@@ -283,17 +290,18 @@ __device__ __forceinline__ void epi_store_wide(void* __restrict__ Cv, int ldc, i
 #pragma unroll
             for (int e = 0; e < 16; ++e) sc[((e & 3) + 8 * (e >> 2) + 4 * hh) * 36 + r] = acc[i][j][e] + bv;
             asm volatile("" ::: "memory");
-            if (MODE == EPI_BF16) {
+            if (MODE == EPI_BF16 || MODE == EPI_F16) {
+                using CF = typename std::conditional<MODE == EPI_F16, Fp16F, Bf16F>::type;
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int row = 16 * p + (lane >> 2), c8 = 8 * (lane & 3);
                     const float4 v0 = *reinterpret_cast<const float4*>(sc + row * 36 + c8);
                     const float4 v1 = *reinterpret_cast<const float4*>(sc + row * 36 + c8 + 4);
                     uint4 pk;
-                    pk.x = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16);
-                    pk.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
-                    pk.z = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16);
-                    pk.w = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
+                    pk.x = pack2<CF>(v0.x, v0.y);
+                    pk.y = pack2<CF>(v0.z, v0.w);
+                    pk.z = pack2<CF>(v1.x, v1.y);
+                    pk.w = pack2<CF>(v1.z, v1.w);
                     *reinterpret_cast<uint4*>(Cb + (size_t)(row0 + i * 32 + row) * ldc + col0 + j * 32 + c8) = pk;
                 }
             } else {
@@ -312,11 +320,13 @@ __device__ __forceinline__ void epi_dispatch(void* __restrict__ Cv, int ldc, int
                                              const f32x16_t (&acc)[NI][NJ], const float* __restrict__ bias, int lane, float* __restrict__ sc = nullptr) {
     if (sc != nullptr && !(flags & (MNN_GEMM_ATOMIC | MNN_GEMM_ACCUMULATE)) && row0 + NI * 32 <= M && col0 + NJ * 32 <= N &&
         ((size_t)Cv & 15) == 0 && (ldc & (c_bf16 ? 7 : 3)) == 0) {               // all wave-uniform
-        if (c_bf16) epi_store_wide<EPI_BF16, NI, NJ>(Cv, ldc, row0, col0, acc, bias, lane, sc);
+        if (c_bf16 == MNN_F16) epi_store_wide<EPI_F16, NI, NJ>(Cv, ldc, row0, col0, acc, bias, lane, sc);
+        else if (c_bf16) epi_store_wide<EPI_BF16, NI, NJ>(Cv, ldc, row0, col0, acc, bias, lane, sc);
         else epi_store_wide<EPI_STORE, NI, NJ>(Cv, ldc, row0, col0, acc, bias, lane, sc);
         return;
     }
-    if (c_bf16) epi_store_tiles<EPI_BF16, NI, NJ>(Cv, ldc, M, N, row0, col0, acc, bias, lane);
+    if (c_bf16 == MNN_F16) epi_store_tiles<EPI_F16, NI, NJ>(Cv, ldc, M, N, row0, col0, acc, bias, lane);
+    else if (c_bf16) epi_store_tiles<EPI_BF16, NI, NJ>(Cv, ldc, M, N, row0, col0, acc, bias, lane);
     else if (flags & MNN_GEMM_ATOMIC) epi_store_tiles<EPI_ATOMIC, NI, NJ>(Cv, ldc, M, N, row0, col0, acc, bias, lane);
     else if (flags & MNN_GEMM_ACCUMULATE) epi_store_tiles<EPI_ACCUM, NI, NJ>(Cv, ldc, M, N, row0, col0, acc, bias, lane);
     else epi_store_tiles<EPI_STORE, NI, NJ>(Cv, ldc, M, N, row0, col0, acc, bias, lane);
@@ -351,7 +361,7 @@ struct GldsSlots {
     }
 };
 
-template <int BK>
+template <int BK, typename F>
 __global__ void __launch_bounds__(256)
 gemm_tn_glds_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c_bf16,
                     const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
@@ -396,21 +406,21 @@ gemm_tn_glds_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restr
         const char* sB = smem[cur][1];
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8_t a[2], b[2];
+            typename F::x8 a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = wm * 64 + i * 32 + r;
-                a[i] = *reinterpret_cast<const bf16x8_t*>(sA + row * ROWB + (((ks * 2 + h) ^ swz<CPR>(row)) << 4));
+                a[i] = *reinterpret_cast<const typename F::x8*>(sA + row * ROWB + (((ks * 2 + h) ^ swz<CPR>(row)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int row = wn * 64 + j * 32 + r;
-                b[j] = *reinterpret_cast<const bf16x8_t*>(sB + row * ROWB + (((ks * 2 + h) ^ swz<CPR>(row)) << 4));
+                b[j] = *reinterpret_cast<const typename F::x8*>(sB + row * ROWB + (((ks * 2 + h) ^ swz<CPR>(row)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = F::mfma32(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
         cur ^= 1;
@@ -434,6 +444,7 @@ __device__ long long gm_trace[16];
 #define GM_T(k) do { } while (0)
 #define GM_T0() do { } while (0)
 #endif
+template <typename F>
 __global__ void __launch_bounds__(512)
 gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c_bf16,
                        const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
@@ -480,21 +491,21 @@ gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
         const char* sB = smem256 + (cur * 2 + 1) * TILE;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8_t a[4], b[2];
+            typename F::x8 a[4], b[2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = wm * 128 + i * 32 + r;
-                a[i] = *reinterpret_cast<const bf16x8_t*>(sA + row * ROWB + (((ks * 2 + h) ^ swz<CPR>(row)) << 4));
+                a[i] = *reinterpret_cast<const typename F::x8*>(sA + row * ROWB + (((ks * 2 + h) ^ swz<CPR>(row)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int row = wn * 64 + j * 32 + r;
-                b[j] = *reinterpret_cast<const bf16x8_t*>(sB + row * ROWB + (((ks * 2 + h) ^ swz<CPR>(row)) << 4));
+                b[j] = *reinterpret_cast<const typename F::x8*>(sB + row * ROWB + (((ks * 2 + h) ^ swz<CPR>(row)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = F::mfma32(a[i], b[j], acc[i][j]);
         }
         GM_T(3);
         __syncthreads();
@@ -522,20 +533,23 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
         const int ntm2 = cdiv(M, 256), ntn2 = cdiv(N, 256);
         static const bool no256 = getenv("MNN_GEMM_NO256") != nullptr;
         if (!no256 && K % 64 == 0 && M >= 256 && N >= 192 && (long)ntm2 * ntn2 * split_k >= 192 && K / 64 / split_k >= 6) {     // measured per shape: profiles/round1_f_gemm_shapes.md
-            static bool attr_set = false;
-            if (!attr_set) {
-                MNN_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128));
-                attr_set = true;
+            using F = typename FlavorOf<T>::type;
+            static bool attr_set[64];
+            int dev = 0;
+            MNN_HIP(hipGetDevice(&dev));
+            if (dev >= 0 && dev < 64 && !attr_set[dev]) {       // per device and per flavour (this function is instantiated once per T)
+                MNN_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds256_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128));
+                attr_set[dev] = true;
             }
             dim3 grid2(cdiv(ntm2, 8) * 8 * ntn2, split_k);
-            hipLaunchKernelGGL(gemm_tn_glds256_kernel, grid2, dim3(512), 4 * 256 * 128, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, c_bf16,
+            hipLaunchKernelGGL(gemm_tn_glds256_kernel<F>, grid2, dim3(512), 4 * 256 * 128, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, c_bf16,
                                bias, M, N, K, flags, split_k, ntm2, ntn2);
             MNN_LAUNCH_CHECK();
             return MNN_OK;
         }
         // (BK = 128 for the tall-K weight-gradient GEMMs was measured slower: C2 1.28 -> 1.54 ms, 1 block/CU at 128 KiB LDS)
         if (K % 64 == 0) {
-            hipLaunchKernelGGL(gemm_tn_glds_kernel<64>, grid, dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, c_bf16, bias, M,
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<64, typename FlavorOf<T>::type>), grid, dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, c_bf16, bias, M,
                                N, K, flags, split_k, ntm, ntn);
             MNN_LAUNCH_CHECK();
             return MNN_OK;
@@ -550,10 +564,10 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
 extern "C" int mnn_gemm_tn(mnn_stream_t s, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                            int ldc, int c_dtype, const float* bias, int flags, int split_k) {
     hipStream_t st = (hipStream_t)s;
-    MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F32, "mnn_gemm_tn: dtype must be bf16 or f32 (got %d)", dtype);
-    MNN_REQUIRE(c_dtype == MNN_F32 || c_dtype == MNN_BF16, "mnn_gemm_tn: c_dtype must be f32 or bf16");
+    MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F16 || dtype == MNN_F32, "mnn_gemm_tn: dtype must be bf16, f16 or f32 (got %d)", dtype);
+    MNN_REQUIRE(c_dtype == MNN_F32 || c_dtype == MNN_BF16 || c_dtype == MNN_F16, "mnn_gemm_tn: c_dtype must be f32, bf16 or f16");
     MNN_REQUIRE(M > 0 && N > 0 && K > 0, "mnn_gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
-    const int al = dtype == MNN_BF16 ? 8 : 4;
+    const int al = dtype == MNN_F32 ? 4 : 8;
     MNN_REQUIRE(K % al == 0 && lda % al == 0 && ldb % al == 0, "mnn_gemm_tn: K/lda/ldb must be multiples of %d (K=%d lda=%d ldb=%d)",
                 al, K, lda, ldb);
     MNN_REQUIRE(lda >= K && ldb >= K && ldc >= N, "mnn_gemm_tn: leading dimension too small");
@@ -566,9 +580,11 @@ extern "C" int mnn_gemm_tn(mnn_stream_t s, int dtype, int M, int N, int K, const
         }
         flags |= MNN_GEMM_ATOMIC | MNN_GEMM_ACCUMULATE;
     }
-    MNN_REQUIRE(!(c_dtype == MNN_BF16 && (flags & (MNN_GEMM_ACCUMULATE | MNN_GEMM_ATOMIC))), "mnn_gemm_tn: bf16 C cannot accumulate");
-    if (dtype == MNN_BF16) return launch_gemm<bf16_t>(st, M, N, K, A, lda, B, ldb, C, ldc, c_dtype == MNN_BF16, bias, flags, split_k);
-    return launch_gemm<float>(st, M, N, K, A, lda, B, ldb, C, ldc, c_dtype == MNN_BF16, bias, flags, split_k);
+    MNN_REQUIRE(!(c_dtype != MNN_F32 && (flags & (MNN_GEMM_ACCUMULATE | MNN_GEMM_ATOMIC))), "mnn_gemm_tn: a 16-bit C cannot accumulate");
+    const int c16 = c_dtype == MNN_F32 ? 0 : c_dtype;      // 0: f32 C; else the mnn_dtype code of the 16-bit C
+    if (dtype == MNN_BF16) return launch_gemm<bf16_t>(st, M, N, K, A, lda, B, ldb, C, ldc, c16, bias, flags, split_k);
+    if (dtype == MNN_F16) return launch_gemm<f16_t>(st, M, N, K, A, lda, B, ldb, C, ldc, c16, bias, flags, split_k);
+    return launch_gemm<float>(st, M, N, K, A, lda, B, ldb, C, ldc, c16, bias, flags, split_k);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1124,13 +1140,13 @@ extern "C" int mnn_lstm_fused_outputs(int dtype, int units) { return lstm_v2_ok(
 extern "C" int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int units, int t_begin, int t_end, const float* xproj,
                                 const void* wh_t, const void* h0, const float* c0, float* gates, float* c, void* h, void* hT, int ld_hT) {
     hipStream_t st = (hipStream_t)s;
-    MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F32, "mnn_lstm_seq_fwd: dtype must be bf16 or f32");
+    MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F16 || dtype == MNN_F32, "mnn_lstm_seq_fwd: dtype must be bf16, f16 or f32");
     MNN_REQUIRE(T > 0 && B > 0 && units > 0 && units % 32 == 0, "mnn_lstm_seq_fwd: units must be a positive multiple of 32 (T=%d B=%d u=%d)",
                 T, B, units);
     MNN_REQUIRE(xproj && wh_t && c && h, "mnn_lstm_seq_fwd: null pointer");
     MNN_REQUIRE(0 <= t_begin && t_begin < t_end && t_end <= T, "mnn_lstm_seq_fwd: bad step range [%d,%d) of %d", t_begin, t_end, T);
     MNN_REQUIRE(hT == nullptr || ld_hT >= T * B, "mnn_lstm_seq_fwd: ld_hT %d < T*B", ld_hT);
-    const size_t esz = dtype == MNN_BF16 ? 2 : 4;
+    const size_t esz = dtype == MNN_F32 ? 4 : 2;
     dim3 grid(units / 32, cdiv(B, 64));
     const bool v2 = lstm_v2_ok(dtype, units);
     for (int t = t_begin; t < t_end; ++t) {
@@ -1151,6 +1167,9 @@ extern "C" int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int uni
         } else if (dtype == MNN_BF16)
             hipLaunchKernelGGL(lstm_fwd_step_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)hp, (const bf16_t*)wh_t, xp, cp, gt, ct,
                                (bf16_t*)ht, B, units);
+        else if (dtype == MNN_F16)
+            hipLaunchKernelGGL(lstm_fwd_step_kernel<f16_t>, grid, dim3(128), 0, st, (const f16_t*)hp, (const f16_t*)wh_t, xp, cp, gt, ct,
+                               (f16_t*)ht, B, units);
         else
             hipLaunchKernelGGL(lstm_fwd_step_kernel<float>, grid, dim3(128), 0, st, (const float*)hp, (const float*)wh_t, xp, cp, gt, ct,
                                (float*)ht, B, units);
@@ -1233,7 +1252,7 @@ extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int uni
                                 const void* wh_p, const float* gates, const float* c, const float* c0, float* dz, void* dz_T, float* dh0,
                                 float* dc0, void* workspace, void* dzT_t, int ld_t, float* db_p) {
     hipStream_t st = (hipStream_t)s;
-    MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F32, "mnn_lstm_seq_bwd: dtype must be bf16 or f32");
+    MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F16 || dtype == MNN_F32, "mnn_lstm_seq_bwd: dtype must be bf16, f16 or f32");
     MNN_REQUIRE(T > 0 && B > 0 && units > 0 && units % 32 == 0, "mnn_lstm_seq_bwd: units must be a positive multiple of 32");
     MNN_REQUIRE(dh_ext && wh_p && gates && c && workspace, "mnn_lstm_seq_bwd: null pointer");
     MNN_REQUIRE(dtype == MNN_F32 ? (dz != nullptr) : (dz_T != nullptr), "mnn_lstm_seq_bwd: dz (f32) / dz_T (bf16) output required");
@@ -1242,7 +1261,7 @@ extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int uni
     const bool v2 = lstm_v2_ok(dtype, units);
     MNN_REQUIRE(v2 || db_p == nullptr || dz != nullptr, "mnn_lstm_seq_bwd: the generic path needs the f32 dz for the bias gradient");
     if (dtype == MNN_F32) dz_T = dz;
-    const size_t esz = dtype == MNN_BF16 ? 2 : 4;
+    const size_t esz = dtype == MNN_F32 ? 4 : 2;
     float* dc = (float*)workspace;        // carried d c between calls: process [t_begin,t_end) from the top range downwards
     dim3 grid(cdiv(units, 64), cdiv(B, 64));
     const size_t zs = (size_t)B * 4 * units, us = (size_t)B * units;
@@ -1266,6 +1285,10 @@ extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int uni
         } else if (dtype == MNN_BF16)
             hipLaunchKernelGGL(lstm_bwd_step_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)dzn, (const bf16_t*)wh_p,
                                dh_ext + (size_t)tt * us, gates + (size_t)tt * zs, c + (size_t)tt * us, cp, dc, dzt, (bf16_t*)dzTt, dho, B,
+                               units, t == T - 1 ? 1 : 0);
+        else if (dtype == MNN_F16)
+            hipLaunchKernelGGL(lstm_bwd_step_kernel<f16_t>, grid, dim3(128), 0, st, (const f16_t*)dzn, (const f16_t*)wh_p,
+                               dh_ext + (size_t)tt * us, gates + (size_t)tt * zs, c + (size_t)tt * us, cp, dc, dzt, (f16_t*)dzTt, dho, B,
                                units, t == T - 1 ? 1 : 0);
         else
             hipLaunchKernelGGL(lstm_bwd_step_kernel<float>, grid, dim3(128), 0, st, (const float*)dzn, (const float*)wh_p,
@@ -1342,6 +1365,7 @@ extern "C" int mnn_lstm2_seq_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fw
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(L1 && L2 && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm2_seq_fwd: bad arguments");
     MNN_REQUIRE(lstm_v2_ok(MNN_BF16, L1->units) && lstm_v2_ok(MNN_BF16, L2->units), "mnn_lstm2_seq_fwd: units must be 128/256/512 (bf16)");
+    MNN_REQUIRE(!L1->f16 && !L2->f16, "mnn_lstm2_seq_fwd: bf16 only (f16 layers run mnn_lstm2_persist_* / mnn_lstm_rowpar_* / mnn_lstm_seq_*)");
     MNN_REQUIRE(0 <= s_begin && s_begin < s_end && s_end <= T + 2, "mnn_lstm2_seq_fwd: bad launch range [%d,%d) of %d", s_begin, s_end, T + 2);
     for (const mnn_lstm_fwd_layer* L : {L1, L2}) {
         MNN_REQUIRE(L->xproj && L->wh_t && L->c && L->h, "mnn_lstm2_seq_fwd: null pointer");
@@ -1400,6 +1424,7 @@ extern "C" int mnn_lstm2_seq_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bw
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(L1 && L2 && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm2_seq_bwd: bad arguments");
     MNN_REQUIRE(lstm_v2_ok(MNN_BF16, L1->units) && lstm_v2_ok(MNN_BF16, L2->units), "mnn_lstm2_seq_bwd: units must be 128/256/512 (bf16)");
+    MNN_REQUIRE(!L1->f16 && !L2->f16, "mnn_lstm2_seq_bwd: bf16 only");
     MNN_REQUIRE(0 <= k_begin && k_begin < k_end && k_end <= T + 2, "mnn_lstm2_seq_bwd: bad launch range [%d,%d) of %d", k_begin, k_end, T + 2);
     for (const mnn_lstm_bwd_layer* L : {L1, L2}) {
         MNN_REQUIRE(L->dh_ext && L->wh_p && L->gates && L->c && L->dz_T && L->workspace, "mnn_lstm2_seq_bwd: null pointer");

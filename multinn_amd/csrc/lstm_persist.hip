@@ -45,12 +45,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const void* base, s
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 // k-steps [f0, f0+KS) of one exchange slab ([k-step][lane][16 B]): one contiguous KiB per instruction
-template <int KS>
-__device__ __forceinline__ void load_frags_xchg(const void* slab, size_t slab_bytes, int f0, bf16x8_t (&f)[KS]) {
+template <int KS, typename V>
+__device__ __forceinline__ void load_frags_xchg(const void* slab, size_t slab_bytes, int f0, V (&f)[KS]) {
     const __amdgpu_buffer_rsrc_t rs = slice_rsrc(slab, slab_bytes);
     const int off = (f0 * 64 + (int)(threadIdx.x & 63)) * 16;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) f[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024 * s, 0, PST_SC1));
+    for (int s = 0; s < KS; ++s) f[s] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024 * s, 0, PST_SC1));
 }
 // `local`: every workgroup of this row tile sits on ONE XCD (checked at launch start, pst_same_xcd): then the tile is stored
 // write-BACK -- it stays in that XCD's L2, which all of them share, and the consumers' sc1 (L1-bypassing, L2-served) loads hit
@@ -59,10 +59,10 @@ __device__ __forceinline__ void store_frag_xchg(void* slab, size_t slab_bytes, i
     if (local) __builtin_amdgcn_raw_buffer_store_b128(v, slice_rsrc(slab, slab_bytes), (f * 64 + lane) * 16, 0, 0);
     else __builtin_amdgcn_raw_buffer_store_b128(v, slice_rsrc(slab, slab_bytes), (f * 64 + lane) * 16, 0, PST_SC1);
 }
-template <int KS>
-__device__ __forceinline__ void load_frags_plain(const bf16_t* __restrict__ p, bf16x8_t (&f)[KS]) {
+template <int KS, typename V>
+__device__ __forceinline__ void load_frags_plain(const bf16_t* __restrict__ p, V (&f)[KS]) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) f[s] = *reinterpret_cast<const bf16x8_t*>(p + 16 * s);
+    for (int s = 0; s < KS; ++s) f[s] = *reinterpret_cast<const V*>(p + 16 * s);
 }
 
 // Workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt(0), which would make
@@ -150,6 +150,7 @@ struct FwdTiles {
 struct FwdTail { float gv[4][4], cv[4]; int t, m0; bool valid; };
 
 // Gate pointwise of this wave's 4 fragment rows -> tiles in LDS, then the hand-off of the h (and y) tile.
+template <typename F>
 __device__ __forceinline__ void pf_finish(const PFwdLayer& L, FwdTiles& S, int T, int nrt, int t, int rt, int nt, float kp, const float (&z)[4][4],
                                           const float (&cp)[4], const unsigned (&mk)[4], FwdTail& tl, unsigned* flag, bool local, long long* trc) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -162,11 +163,11 @@ __device__ __forceinline__ void pf_finish(const PFwdLayer& L, FwdTiles& S, int T
         const float c = gg * gi + cp[q] * gf;
         const float h = fast_tanh(c) * go;
         tl.gv[q][0] = gi; tl.gv[q][1] = gg; tl.gv[q][2] = gf; tl.gv[q][3] = go; tl.cv[q] = c;
-        const bf16_t hb = f32_to_bf16(h);
+        const bf16_t hb = F::cvt(h);
         const int lr = 8 * w + q + 4 * hh;
         S.sH[lr][r] = hb;
         bf16_t yb = hb;
-        if (drop) { yb = f32_to_bf16(bf16_to_f32(hb) / kp * (float)mk[q]); S.sY[lr][r] = yb; }     // mk: raw keep byte, converted here (not at the load)
+        if (drop) { yb = F::cvt(F::f32(hb) / kp * (float)mk[q]); S.sY[lr][r] = yb; }     // mk: raw keep byte, converted here (not at the load)
         if (wantT) S.sT[r][lr] = hb;
         if (L.yT != nullptr) S.sYT[r][lr] = yb;
     }
@@ -306,7 +307,7 @@ __device__ __forceinline__ void pf_tail_any(const PFwdLayer& L, const FwdTiles& 
 // So addresses are selected, never loads; `zero` points at always-zero words of the workspace.
 
 // KS1 = U1 / 64, KS2 = U2 / 64 (k-steps of 16 per wave, 4 waves).
-template <int KS1, int KS2>
+template <int KS1, int KS2, typename F>
 __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
     __shared__ FwdTiles S;
     const int nb1 = A.l1.U / 32, nb2 = A.l2.U / 32, nm = nb1 + nb2;
@@ -333,9 +334,9 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
         const int nt = member, U = L.U, N4 = 4 * U, n0 = nt * 128, unit = nt * 32 + r;
         const int kb = w * 16 * KS1 + hh * 8;
         const size_t us = (size_t)B * U, slab = (size_t)(U / 16) * 1024;
-        bf16x8_t b[4][KS1];
+        typename F::x8 b[4][KS1];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) load_frags_plain<KS1>(L.wh_t + (size_t)(n0 + 32 * g + r) * U + kb, b[g]);
+        for (int g = 0; g < 4; ++g) load_frags_plain(L.wh_t + (size_t)(n0 + 32 * g + r) * U + kb, b[g]);
         float xp[4][4];
         unsigned mk[4];
         FwdLane fl;
@@ -363,8 +364,8 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             PST_TR(trc, 0);
             if (t > 0 && !pst_wait(flags + rt * 32, status, nb1, (unsigned)t, nb1, 0u, &S.abort, A.sticky_off, have_peek, peek)) return;
             PST_TR(trc, 1);
-            bf16x8_t a[KS1];
-            load_frags_xchg<KS1>(t > 0 ? L.hx + ((size_t)(t - 1) * nrt + rt) * slab : L.hx0 + (size_t)rt * slab, slab, w * KS1, a);
+            typename F::x8 a[KS1];
+            load_frags_xchg(t > 0 ? L.hx + ((size_t)(t - 1) * nrt + rt) * slab : L.hx0 + (size_t)rt * slab, slab, w * KS1, a);
             // behind the hand-off loads: this item's cell state and the next item's operands (loads: their wait merges with the hand-off's;
             // behind the MFMAs they would be waited for together with the plain stores)
             float cl[4];
@@ -390,7 +391,7 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
 #pragma unroll
             for (int s = 0; s < KS1; ++s)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[g][s], acc[g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) acc[g] = F::mfma32(a[s], b[g][s], acc[g]);
             pf_tail_any(L, S, T, B, nt, tl, fl);           // the previous item's plain stores issue while the MFMA chain runs
             // K-split partials through LDS, 16 bytes per access: slot (producer wave, gate, consumer wave, lane) holds the four accumulator
             // elements 4 w' .. 4 w' + 3 that consumer wave w' reduces (16 stores + 16 loads per thread and item instead of 64 + 64)
@@ -419,7 +420,7 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
                 have_peek = Rv > 1 && i + 1 < n_items;
                 peek = pst_peek(flags + (grp + A.G * (i2 - t2 * Rv)) * 32, status, nb1);
             }
-            pf_finish(L, S, T, nrt, t, rt, nt, A.kp, z, cp, mk, tl, flags + rt * 32 + member, local, trc);
+            pf_finish<F>(L, S, T, nrt, t, rt, nt, A.kp, z, cp, mk, tl, flags + rt * 32 + member, local, trc);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 mk[q] = mkn[q];
@@ -437,12 +438,12 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
         const int kb1 = w * 16 * KS1 + hh * 8, kb2 = w * 16 * KS2 + hh * 8;
         const size_t us = (size_t)B * U, slab = (size_t)(U / 16) * 1024, slab1 = (size_t)(U1 / 16) * 1024;
         const char* y1x = L1.mask != nullptr ? L1.yx : L1.hx;
-        bf16x8_t bx[4][KS1], bh[4][KS2];
+        typename F::x8 bx[4][KS1], bh[4][KS2];
         float bz[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            load_frags_plain<KS1>(L.wx_t + (size_t)(n0 + 32 * g + r) * L.ld_w + kb1, bx[g]);
-            load_frags_plain<KS2>(L.wh_t + (size_t)(n0 + 32 * g + r) * U + kb2, bh[g]);
+            load_frags_plain(L.wx_t + (size_t)(n0 + 32 * g + r) * L.ld_w + kb1, bx[g]);
+            load_frags_plain(L.wh_t + (size_t)(n0 + 32 * g + r) * U + kb2, bh[g]);
             bz[g] = L.bias_p[n0 + 32 * g + r];
         }
         FwdLane fl;
@@ -457,9 +458,9 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
             PST_TR(trc, 0);
             if (!pst_wait(flags + rt * 32, status, nb1, (unsigned)(t + 1), nm, (unsigned)t, &S.abort, A.sticky_off, have_peek, peek)) return;
             PST_TR(trc, 1);
-            bf16x8_t a1[KS1], a2[KS2];
-            load_frags_xchg<KS1>(y1x + ((size_t)t * nrt + rt) * slab1, slab1, w * KS1, a1);
-            load_frags_xchg<KS2>(t > 0 ? L.hx + ((size_t)(t - 1) * nrt + rt) * slab : L.hx0 + (size_t)rt * slab, slab, w * KS2, a2);
+            typename F::x8 a1[KS1], a2[KS2];
+            load_frags_xchg(y1x + ((size_t)t * nrt + rt) * slab1, slab1, w * KS1, a1);
+            load_frags_xchg(t > 0 ? L.hx + ((size_t)(t - 1) * nrt + rt) * slab : L.hx0 + (size_t)rt * slab, slab, w * KS2, a2);
             float cl[4];
             unsigned mk[4];
             {
@@ -482,11 +483,11 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
 #pragma unroll
             for (int s = 0; s < KS1; ++s)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s], bx[g][s], acc[g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) acc[g] = F::mfma32(a1[s], bx[g][s], acc[g]);
 #pragma unroll
             for (int s = 0; s < KS2; ++s)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s], bh[g][s], acc[g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) acc[g] = F::mfma32(a2[s], bh[g][s], acc[g]);
             pf_tail_any(L, S, T, B, nt, tl, fl);           // the previous item's plain stores issue while the MFMA chain runs
             // K-split partials through LDS, 16 bytes per access: slot (producer wave, gate, consumer wave, lane) holds the four accumulator
             // elements 4 w' .. 4 w' + 3 that consumer wave w' reduces (16 stores + 16 loads per thread and item instead of 64 + 64)
@@ -514,7 +515,7 @@ __global__ void __launch_bounds__(256) lstm2_persist_fwd_kernel(PFwdArgs A) {
                 have_peek = Rv > 1 && i + 1 < n_items;
                 peek = pst_peek(flags + (grp + A.G * (i2 - t2 * Rv)) * 32, status, nm);
             }
-            pf_finish(L, S, T, nrt, t, rt, nt, A.kp, z, cp, mk, tl, flags + rt * 32 + member, local, trc);
+            pf_finish<F>(L, S, T, nrt, t, rt, nt, A.kp, z, cp, mk, tl, flags + rt * 32 + member, local, trc);
             PST_TR(trc, 5);
         }
         pf_tail_any(L, S, T, B, nt, tl, fl);
@@ -562,6 +563,7 @@ struct BwdTiles {
 struct BwdEpi { float dh, g[4], c, cp; unsigned keep; };      // per fragment row: external gradient, gates, cell states, raw keep byte
 struct BwdTail { float dcv[2]; float dbv[4]; int t, m0; bool valid; };   // dbv[g]: this thread's running sum of dz (gate g, its unit, its rows): bias gradient
 
+template <typename F>
 __device__ __forceinline__ void pb_finish(const PBwdLayer& L, BwdTiles& S, int B, int nrt, int t, int rt, int nt, const float (&dh)[2], const BwdEpi (&e)[2],
                                           const float (&e_dc)[2], BwdTail& tl, unsigned* flag, unsigned epoch, bool local, long long* trc) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -579,10 +581,10 @@ __device__ __forceinline__ void pb_finish(const PBwdLayer& L, BwdTiles& S, int B
         const bool rowok = rt * 32 + lr < B;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const bf16_t bv = f32_to_bf16(dzv[g]);
+            const bf16_t bv = F::cvt(dzv[g]);
             S.sZ[lr][32 * g + r] = bv;
             if (L.dzTt != nullptr) S.sT[g][r][lr] = bv;
-            tl.dbv[g] += rowok ? bf16_to_f32(bv) : 0.f;          // the (bf16) values the weight-gradient GEMMs see, summed in registers
+            tl.dbv[g] += rowok ? F::f32(bv) : 0.f;          // the (bf16) values the weight-gradient GEMMs see, summed in registers
         }
     }
     tl.t = t; tl.m0 = rt * 32; tl.valid = true;
@@ -669,7 +671,7 @@ __device__ __forceinline__ void pb_epi_load(const PBwdLayer& L, int B, int nt, i
 }
 
 // KA = 4 U1 / 128, KB = 4 U2 / 128 (k-steps of 16 per wave, 8 waves).
-template <int KA, int KB>
+template <int KA, int KB, typename F>
 __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
     __shared__ BwdTiles S;
     const int nb1 = A.l1.U / 32, nb2 = A.l2.U / 32, nm = nb1 + nb2;
@@ -697,8 +699,8 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
         const int nt = member, U = L.U, N4 = 4 * U, unit = nt * 32 + r;
         const size_t slab = (size_t)(N4 / 16) * 1024;
         const int kb = w * 16 * KB + hh * 8;
-        bf16x8_t bw[KB];
-        load_frags_plain<KB>(L.wh_p + (size_t)unit * N4 + kb, bw);
+        typename F::x8 bw[KB];
+        load_frags_plain(L.wh_p + (size_t)unit * N4 + kb, bw);
         BwdEpi e[2], en[2];
         pb_epi_load<false>(L, B, nt, T - 1, grp * 32, zero, e);
         for (int i = 0; i < n_items; ++i) {
@@ -707,8 +709,8 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
             PST_TR(trc, 0);
             if (k > 0 && !pst_wait(flags + rt * 32, status, nb2, (unsigned)k, nb2, 0u, &S.abort, A.sticky_off)) return;
             PST_TR(trc, 1);
-            bf16x8_t a[KB];
-            load_frags_xchg<KB>(k > 0 ? L.dzx + ((size_t)(t + 1) * nrt + rt) * slab : L.dzxT + (size_t)rt * slab, slab, w * KB, a);
+            typename F::x8 a[KB];
+            load_frags_xchg(k > 0 ? L.dzx + ((size_t)(t + 1) * nrt + rt) * slab : L.dzxT + (size_t)rt * slab, slab, w * KB, a);
             float dcl[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -725,7 +727,7 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = 0.f;
 #pragma unroll
-            for (int s = 0; s < KB; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bw[s], acc, 0, 0, 0);
+            for (int s = 0; s < KB; ++s) acc = F::mfma32(a[s], bw[s], acc);
             pb_tail(L, S, B, Rv, nt, tl);                    // the previous item's plain stores issue while the MFMA chain runs
 #pragma unroll
             for (int wc = 0; wc < 8; ++wc) red2[((0 * 8 + w) * 8 + wc) * 64 + lane] = make_float2(acc[2 * wc], acc[2 * wc + 1]);     // 8-byte slots: see the forward kernel
@@ -744,7 +746,7 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
                 e_dc[q] = (Rv == 1 && k > 0) ? tl.dcv[q] : dcl[q];
             }
             PST_TR(trc, 2);
-            pb_finish(L, S, B, nrt, t, rt, nt, dh, e, e_dc, tl, flags + rt * 32 + member, (unsigned)(k + 1), local, trc);
+            pb_finish<F>(L, S, B, nrt, t, rt, nt, dh, e, e_dc, tl, flags + rt * 32 + member, (unsigned)(k + 1), local, trc);
             e[0] = en[0]; e[1] = en[1];
             PST_TR(trc, 5);
         }
@@ -757,18 +759,18 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
         const int nt = member - nb2, U = L.U, N4 = 4 * U, K2 = 4 * L2.U, unit = nt * 32 + r;
         const size_t slab = (size_t)(N4 / 16) * 1024, slab2 = (size_t)(K2 / 16) * 1024;
         const int kba = w * 16 * KA + hh * 8, kbb = w * 16 * KB + hh * 8;
-        bf16x8_t bw[KA], bq[KB];
-        load_frags_plain<KA>(L.wh_p + (size_t)unit * N4 + kba, bw);
-        load_frags_plain<KB>(L2.wx_p + (size_t)unit * K2 + kbb, bq);
+        typename F::x8 bw[KA], bq[KB];
+        load_frags_plain(L.wh_p + (size_t)unit * N4 + kba, bw);
+        load_frags_plain(L2.wx_p + (size_t)unit * K2 + kbb, bq);
         for (int i = 0; i < n_items; ++i) {
             const int k = i / Rv, t = T - 1 - k, rt = grp + A.G * (i - k * Rv), m0 = rt * 32;
             long long* trc = PST_TRP(3, member == nb2 && rt == 0, k);
             PST_TR(trc, 0);
             if (!pst_wait(flags + rt * 32, status, nb2, (unsigned)(k + 1), nm, (unsigned)k, &S.abort, A.sticky_off)) return;
             PST_TR(trc, 1);
-            bf16x8_t aq[KB], aw[KA];
-            load_frags_xchg<KB>(L2.dzx + ((size_t)t * nrt + rt) * slab2, slab2, w * KB, aq);
-            load_frags_xchg<KA>(k > 0 ? L.dzx + ((size_t)(t + 1) * nrt + rt) * slab : L.dzxT + (size_t)rt * slab, slab, w * KA, aw);
+            typename F::x8 aq[KB], aw[KA];
+            load_frags_xchg(L2.dzx + ((size_t)t * nrt + rt) * slab2, slab2, w * KB, aq);
+            load_frags_xchg(k > 0 ? L.dzx + ((size_t)(t + 1) * nrt + rt) * slab : L.dzxT + (size_t)rt * slab, slab, w * KA, aw);
             float dcl[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -783,9 +785,9 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) { accq[j] = 0.f; accw[j] = 0.f; }
 #pragma unroll
-            for (int s = 0; s < KB; ++s) accq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[s], bq[s], accq, 0, 0, 0);
+            for (int s = 0; s < KB; ++s) accq = F::mfma32(aq[s], bq[s], accq);
 #pragma unroll
-            for (int s = 0; s < KA; ++s) accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[s], bw[s], accw, 0, 0, 0);
+            for (int s = 0; s < KA; ++s) accw = F::mfma32(aw[s], bw[s], accw);
             pb_tail(L, S, B, Rv, nt, tl);                    // the previous item's plain stores issue while the MFMA chains run
 #pragma unroll
             for (int wc = 0; wc < 8; ++wc) {
@@ -806,7 +808,7 @@ __global__ void __launch_bounds__(512) lstm2_persist_bwd_kernel(PBwdArgs A) {
                 e_dc[q] = (Rv == 1 && k > 0) ? tl.dcv[q] : dcl[q];
             }
             PST_TR(trc, 2);
-            pb_finish(L, S, B, nrt, t, rt, nt, dh, e, e_dc, tl, flags + rt * 32 + member, (unsigned)(k + 1), local, trc);
+            pb_finish<F>(L, S, B, nrt, t, rt, nt, dh, e, e_dc, tl, flags + rt * 32 + member, (unsigned)(k + 1), local, trc);
             PST_TR(trc, 5);
         }
         pb_tail(L, S, B, Rv, nt, tl);
@@ -820,15 +822,16 @@ __global__ void pst_poison_kernel(unsigned* sync) { sync[0] = 1u; }
 // ---------------------------------------------------------------------------------------------- host side
 static bool units_ok(int u) { return u == 128 || u == 256 || u == 512; }
 
-static int cu_count() {
-    static int n = -1;
-    if (n < 0) {
-        int dev = 0;
+static int cu_count() {             // of the CURRENT device
+    static int n[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (n[dev] <= 0) {
         hipDeviceProp_t p;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
-        n = p.multiProcessorCount;
+        if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+        n[dev] = p.multiProcessorCount;
     }
-    return n;
+    return n[dev];
 }
 
 // G row-tile groups x (nb1 + nb2) members, R row tiles per workgroup; false when the grid cannot be resident at once.
@@ -872,18 +875,18 @@ extern "C" int mnn_lstm2_persist_status(const void* workspace, int B, int u1, in
     return MNN_OK;
 }
 
-template <int K1>
+template <int K1, typename F>
 static hipError_t launch_pfwd(hipStream_t st, int grid, const PFwdArgs& a, int u2) {
-    if (u2 == 512) hipLaunchKernelGGL((lstm2_persist_fwd_kernel<K1, 8>), dim3(grid), dim3(256), 0, st, a);
-    else if (u2 == 256) hipLaunchKernelGGL((lstm2_persist_fwd_kernel<K1, 4>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((lstm2_persist_fwd_kernel<K1, 2>), dim3(grid), dim3(256), 0, st, a);
+    if (u2 == 512) hipLaunchKernelGGL((lstm2_persist_fwd_kernel<K1, 8, F>), dim3(grid), dim3(256), 0, st, a);
+    else if (u2 == 256) hipLaunchKernelGGL((lstm2_persist_fwd_kernel<K1, 4, F>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((lstm2_persist_fwd_kernel<K1, 2, F>), dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError();
 }
-template <int KA>
+template <int KA, typename F>
 static hipError_t launch_pbwd(hipStream_t st, int grid, const PBwdArgs& a, int u2) {
-    if (u2 == 512) hipLaunchKernelGGL((lstm2_persist_bwd_kernel<KA, 16>), dim3(grid), dim3(512), 0, st, a);
-    else if (u2 == 256) hipLaunchKernelGGL((lstm2_persist_bwd_kernel<KA, 8>), dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((lstm2_persist_bwd_kernel<KA, 4>), dim3(grid), dim3(512), 0, st, a);
+    if (u2 == 512) hipLaunchKernelGGL((lstm2_persist_bwd_kernel<KA, 16, F>), dim3(grid), dim3(512), 0, st, a);
+    else if (u2 == 256) hipLaunchKernelGGL((lstm2_persist_bwd_kernel<KA, 8, F>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((lstm2_persist_bwd_kernel<KA, 4, F>), dim3(grid), dim3(512), 0, st, a);
     return hipGetLastError();
 }
 
@@ -930,10 +933,15 @@ extern "C" int mnn_lstm2_persist_fwd(mnn_stream_t s, int T, int B, const mnn_lst
     if (L1->h0 || L2->h0)
         hipLaunchKernelGGL(pst_fill_h0_kernel, dim3(a.nrt, u1 / 16 + u2 / 16), dim3(64), 0, st, (const bf16_t*)L1->h0, u1, edge,
                            (const bf16_t*)L2->h0, u2, edge + (size_t)a.nrt * 64 * u1, B);
+    MNN_REQUIRE((L1->f16 != 0) == (L2->f16 != 0), "mnn_lstm2_persist_fwd: both layers must use the same 16-bit flavour");
     hipError_t e;
-    if (u1 == 512) e = launch_pfwd<8>(st, grid, a, u2);
-    else if (u1 == 256) e = launch_pfwd<4>(st, grid, a, u2);
-    else e = launch_pfwd<2>(st, grid, a, u2);
+    if (L1->f16) {
+        if (u1 == 512) e = launch_pfwd<8, Fp16F>(st, grid, a, u2);
+        else if (u1 == 256) e = launch_pfwd<4, Fp16F>(st, grid, a, u2);
+        else e = launch_pfwd<2, Fp16F>(st, grid, a, u2);
+    } else if (u1 == 512) e = launch_pfwd<8, Bf16F>(st, grid, a, u2);
+    else if (u1 == 256) e = launch_pfwd<4, Bf16F>(st, grid, a, u2);
+    else e = launch_pfwd<2, Bf16F>(st, grid, a, u2);
     MNN_HIP(e);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
@@ -975,10 +983,15 @@ extern "C" int mnn_lstm2_persist_bwd(mnn_stream_t s, int T, int B, const mnn_lst
     a.l1.dzx = x; a.l2.dzx = x + per * 256 * u1;
     const int grid = a.G * (u1 / 32 + u2 / 32);
     MNN_HIP(mnn_zero_async(workspace, sync_words(a.nrt) * sizeof(unsigned) + edge_bytes(a.nrt, u1, u2, true), st));
+    MNN_REQUIRE((L1->f16 != 0) == (L2->f16 != 0), "mnn_lstm2_persist_bwd: both layers must use the same 16-bit flavour");
     hipError_t e;
-    if (u1 == 512) e = launch_pbwd<16>(st, grid, a, u2);
-    else if (u1 == 256) e = launch_pbwd<8>(st, grid, a, u2);
-    else e = launch_pbwd<4>(st, grid, a, u2);
+    if (L1->f16) {
+        if (u1 == 512) e = launch_pbwd<16, Fp16F>(st, grid, a, u2);
+        else if (u1 == 256) e = launch_pbwd<8, Fp16F>(st, grid, a, u2);
+        else e = launch_pbwd<4, Fp16F>(st, grid, a, u2);
+    } else if (u1 == 512) e = launch_pbwd<16, Bf16F>(st, grid, a, u2);
+    else if (u1 == 256) e = launch_pbwd<8, Bf16F>(st, grid, a, u2);
+    else e = launch_pbwd<4, Bf16F>(st, grid, a, u2);
     MNN_HIP(e);
     MNN_LAUNCH_CHECK();
     return MNN_OK;

@@ -40,6 +40,9 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 // The per-wave LDS tiles are written element-wise (bf16) and read back 16 bytes at a time by OTHER lanes of the same wave: the LDS serves a
 // wave's instructions in order, but the compiler must not move the differently-typed accesses across one another
 #define RP_LDS_FENCE() asm volatile("" ::: "memory")
+// Behind the hand-off stores: rp_wait_all_but(N) counts the vector-memory operations written AFTER them in the source, so neither the
+// scheduler nor the memory-dependence analysis may move one of those above the hand-off (vmcnt retires in issue order)
+#define RP_HANDOFF_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
 
 #ifdef RP_TRACE     // development only (profiles/tools/rowpar_trace.py): wall-clock stamps of one wave per kernel, [direction][step][stage]
 __device__ long long rp_trace[2][512][12];
@@ -84,16 +87,14 @@ struct RFwdArgs {
     int T, B, nrt, G, allow_local; float kp;
 };
 // xproj as stored: f32 float4 (i, g, f, o) per (row, unit), or four bf16 in 8 bytes (template parameter XB of the forward kernels)
-template <bool XB> struct RpX;
-template <> struct RpX<false> {
+template <bool XB, typename F> struct RpX;
+template <typename F> struct RpX<false, F> {
     typedef float4 T;
     static __device__ __forceinline__ float4 get(const float4& v) { return v; }
 };
-template <> struct RpX<true> {
+template <typename F> struct RpX<true, F> {
     typedef uint2 T;
-    static __device__ __forceinline__ float4 get(const uint2& v) {
-        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
-    }
+    static __device__ __forceinline__ float4 get(const uint2& v) { return make_float4(F::lo(v.x), F::hi(v.x), F::lo(v.y), F::hi(v.y)); }
 };
 
 // Launch start: do the U/32 workgroups of this row-tile group share an XCD?  Each posts 0x100 | XCC_ID (device scope), wave 0 waits for the
@@ -162,7 +163,7 @@ __device__ __forceinline__ bool rp_pair_wait(const unsigned* word, unsigned need
 // MFMA chain, weights from LDS one k-step ahead | gate pointwise in registers | hand-off stores, then the row-major stores (gates, c, h, y,
 // h^T, y^T: 28 KB per tile) | wait for the hand-off stores only, raise the flag | request the next step's xproj and keep bytes.
 // ------------------------------------------------------------------------------------------------------------------
-template <int U, bool XB>
+template <int U, bool XB, typename F>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_rowpar_fwd_kernel(RFwdArgs A) {
     constexpr int KS = U / 16;                      // k-steps of 16 over the recurrent width
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const unsigned om = (unsigned)((4 * hh) * U + unit);                      // keep mask (byte)
     const int prow = lane >> 1, pp = (lane & 1) * 2;                          // tile stores: 32 rows x 4 pieces of 16 bytes, two pieces per lane
     f32x16_t acc[4];
-    typename RpX<XB>::T xv[16];                     // the next step's xproj: requested behind the flag store, moved into acc behind the next wait
+    typename RpX<XB, F>::T xv[16];                     // the next step's xproj: requested behind the flag store, moved into acc behind the next wait
     float creg[16];
     unsigned mk[16];
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);          // the keep bytes of the next step: 16 of row (lane >> 1), units 16 (lane & 1) .. + 15
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         constexpr int XS = XB ? 2 : 4;              // bytes per stored value
         const char* xb = reinterpret_cast<const char*>(A.xproj) + ((size_t)t * 4 * us + (size_t)m0 * 4 * U) * XS + og / (4 / XS);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) xv[k] = *reinterpret_cast<const typename RpX<XB>::T*>(xb + (size_t)rp_krow(k) * 4 * XS * U);
+        for (int k = 0; k < 16; ++k) xv[k] = *reinterpret_cast<const typename RpX<XB, F>::T*>(xb + (size_t)rp_krow(k) * 4 * XS * U);
         if (drop) mq = *reinterpret_cast<const uint4*>(A.mask + (size_t)t * us + (size_t)(m0 + prow) * U + nt * 32 + (lane & 1) * 16);
     };
     prefetch(0);
@@ -225,17 +226,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         RP_TR(0, trc, t, 0);
         if (t > 0 && !rp_wait(flags, status, nb, (unsigned)t)) return;
         RP_TR(0, trc, t, 1);
-        bf16x8_t a[KS];
+        typename F::x8 a[KS];
         {
             const __amdgpu_buffer_rsrc_t rs = rp_rsrc(t > 0 ? A.hx + ((size_t)(t - 1) * nrt + rt) * slab : A.hx0 + (size_t)rt * slab, slab);
 #pragma unroll
             for (int s = 0; s < KS; ++s)        // k-step s of this member is slab k-step (s + rot) % KS: the members of a row tile start at different lines
-                a[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ((((s + rot) & (KS - 1)) * 64 + lane) * 16), 0, RP_SC1));
+                a[s] = __builtin_bit_cast(typename F::x8, __builtin_amdgcn_raw_buffer_load_b128(rs, ((((s + rot) & (KS - 1)) * 64 + lane) * 16), 0, RP_SC1));
         }
         // all KS loads are in flight before anything else: left alone, the scheduler sinks every load next to its use and waits vmcnt(0) per MFMA
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { const float4 x4 = RpX<XB>::get(xv[k]); acc[0][k] = x4.x; acc[1][k] = x4.y; acc[2][k] = x4.z; acc[3][k] = x4.w; }   // z starts at xproj[t]
+        for (int k = 0; k < 16; ++k) { const float4 x4 = RpX<XB, F>::get(xv[k]); acc[0][k] = x4.x; acc[1][k] = x4.y; acc[2][k] = x4.z; acc[3][k] = x4.w; }   // z starts at xproj[t]
         if (drop) {                                 // keep bytes: [row][32 units] through the (idle) h tile
             uint8_t* mt = reinterpret_cast<uint8_t*>(&sH[0][0]);
             RP_LDS_FENCE();
@@ -246,18 +247,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             RP_LDS_FENCE();
         }
         // B fragments (weights in LDS) one k-step AHEAD of their MFMAs: an LDS read takes ~100 cycles to return, an MFMA issues every 32
-        bf16x8_t bq[2][4];
+        typename F::x8 bq[2][4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bq[0][g] = __builtin_bit_cast(bf16x8_t, wl[(g * KS + 0) * 64 + lane]);
+        for (int g = 0; g < 4; ++g) bq[0][g] = __builtin_bit_cast(typename F::x8, wl[(g * KS + 0) * 64 + lane]);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             if (s + 1 < KS) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) bq[(s + 1) & 1][g] = __builtin_bit_cast(bf16x8_t, wl[(g * KS + s + 1) * 64 + lane]);
+                for (int g = 0; g < 4; ++g) bq[(s + 1) & 1][g] = __builtin_bit_cast(typename F::x8, wl[(g * KS + s + 1) * 64 + lane]);
             }
             __builtin_amdgcn_sched_barrier(0);                        // ... and keep those reads in front of this k-step's MFMAs
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[s & 1][g], acc[g], 0, 0, 0);
+            for (int g = 0; g < 4; ++g) acc[g] = F::mfma32(a[s], bq[s & 1][g], acc[g]);
         }
         __builtin_amdgcn_sched_barrier(0);
         RP_TR(0, trc, t, 2);
@@ -270,11 +271,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             const float hv = fast_tanh(cv) * go;
             acc[0][k] = gi; acc[1][k] = gg; acc[2][k] = gf; acc[3][k] = go;
             creg[k] = cv;
-            const bf16_t hb = f32_to_bf16(hv);
+            const bf16_t hb = F::cvt(hv);
             const int lr = rp_krow(k) + 4 * hh;
             sH[lr][r] = hb;
             sT[r][lr] = hb;
-            yb[k] = drop ? (unsigned)f32_to_bf16(bf16_to_f32(hb) * ikp * (float)mk[k]) : (unsigned)hb;
+            yb[k] = drop ? (unsigned)F::cvt(F::f32(hb) * ikp * (float)mk[k]) : (unsigned)hb;
         }
         RP_LDS_FENCE();
         RP_TR(0, trc, t, 3);
@@ -283,6 +284,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) rp_store_frag(rs, 2 * nt + ks, lane, *reinterpret_cast<const u32x4_t*>(&sH[r][ks * 16 + hh * 8]), local);
         }
+        RP_HANDOFF_FENCE();
         RP_TR(0, trc, t, 4);
         // ---- issued BEHIND the hand-off stores, which alone the flag waits for: the next step's operands (first: they are needed soonest),
         // then what the rest of the train step reads ----
@@ -293,8 +295,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 uint2 pk;
-                pk.x = (unsigned)f32_to_bf16(acc[0][k]) | ((unsigned)f32_to_bf16(acc[1][k]) << 16);
-                pk.y = (unsigned)f32_to_bf16(acc[2][k]) | ((unsigned)f32_to_bf16(acc[3][k]) << 16);
+                pk.x = (unsigned)F::cvt(acc[0][k]) | ((unsigned)F::cvt(acc[1][k]) << 16);
+                pk.y = (unsigned)F::cvt(acc[2][k]) | ((unsigned)F::cvt(acc[3][k]) << 16);
                 *reinterpret_cast<uint2*>(gb + (size_t)rp_krow(k) * 8 * U) = pk;
             }
             behind += 16;
@@ -355,7 +357,7 @@ struct RBwdArgs {
     int T, B, nrt, G, allow_local; float kp;
 };
 
-template <int U>
+template <int U, typename F>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_rowpar_bwd_kernel(RBwdArgs A) {
     constexpr int KS4 = U / 4;                      // k-steps of 16 over the 4U gate columns
     constexpr int CH = 8;                           // k-steps per register chunk of the dz tile (ring of RP_RING chunks)
@@ -435,11 +437,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         f32x16_t acc;
         {
             const __amdgpu_buffer_rsrc_t rs = rp_rsrc(kk > 0 ? A.dzx + ((size_t)(t + 1) * nrt + rt) * slab : A.dzx0 + (size_t)rt * slab, slab);
-            bf16x8_t a[RP_RING][CH];            // ring of chunks of eight k-steps (8 KiB each), all but one in flight
+            typename F::x8 a[RP_RING][CH];            // ring of chunks of eight k-steps (8 KiB each), all but one in flight
             auto issue = [&](int ch) {
 #pragma unroll
                 for (int s = 0; s < CH; ++s)
-                    a[ch % RP_RING][s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ((((ch * CH + s + rot) & (KS4 - 1)) * 64 + lane) * 16), 0, RP_SC1));
+                    a[ch % RP_RING][s] = __builtin_bit_cast(typename F::x8, __builtin_amdgcn_raw_buffer_load_b128(rs, ((((ch * CH + s + rot) & (KS4 - 1)) * 64 + lane) * 16), 0, RP_SC1));
             };
 #pragma unroll
             for (int ch = 0; ch < RP_RING - 1 && ch < NCH; ++ch) issue(ch);
@@ -447,9 +449,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[k] = 0.f;
             // B fragments (weights in LDS) one chunk-half (four k-steps) AHEAD of their MFMAs
-            bf16x8_t bq[2][4];
+            typename F::x8 bq[2][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bq[0][q] = __builtin_bit_cast(bf16x8_t, wl[q * 64 + lane]);
+            for (int q = 0; q < 4; ++q) bq[0][q] = __builtin_bit_cast(typename F::x8, wl[q * 64 + lane]);
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 if (ch + RP_RING - 1 < NCH) issue(ch + RP_RING - 1);     // the rest of the ring is in flight while this chunk feeds the MFMAs
@@ -459,11 +461,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     const int f4 = ch * (CH / 4) + s4;       // flattened group of four k-steps
                     if (f4 + 1 < KS4 / 4) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) bq[(f4 + 1) & 1][q] = __builtin_bit_cast(bf16x8_t, wl[((f4 + 1) * 4 + q) * 64 + lane]);
+                        for (int q = 0; q < 4; ++q) bq[(f4 + 1) & 1][q] = __builtin_bit_cast(typename F::x8, wl[((f4 + 1) * 4 + q) * 64 + lane]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ch % RP_RING][s4 * 4 + q], bq[f4 & 1][q], acc, 0, 0, 0);
+                    for (int q = 0; q < 4; ++q) acc = F::mfma32(a[ch % RP_RING][s4 * 4 + q], bq[f4 & 1][q], acc);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -498,8 +500,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         unsigned bvp[16][2];                     // the four bf16 values of a register row, packed (i | g << 16, f | o << 16)
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const float gi = __uint_as_float(gv[k].x << 16), gg = __uint_as_float(gv[k].x & 0xffff0000u);
-            const float gf = __uint_as_float(gv[k].y << 16), go = __uint_as_float(gv[k].y & 0xffff0000u);
+            const float gi = F::lo(gv[k].x), gg = F::hi(gv[k].x);
+            const float gf = F::lo(gv[k].y), go = F::hi(gv[k].y);
             const float dh = dhx[k] + acc[k];
             const float tc = fast_tanh(cnext[k]);
             const float d_o = dh * tc;
@@ -512,9 +514,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             bf16_t b4[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                b4[g] = f32_to_bf16(dzv[g]);
+                b4[g] = F::cvt(dzv[g]);
                 sZ[lr][32 * g + r] = b4[g];
-                dbv[g] += bf16_to_f32(b4[g]);             // the (bf16) values the weight-gradient GEMMs see
+                dbv[g] += F::f32(b4[g]);             // the (bf16) values the weight-gradient GEMMs see
             }
             bvp[k][0] = (unsigned)b4[0] | ((unsigned)b4[1] << 16);
             bvp[k][1] = (unsigned)b4[2] | ((unsigned)b4[3] << 16);
@@ -526,6 +528,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) rp_store_frag(rs, 8 * nt + ks, lane, *reinterpret_cast<const u32x4_t*>(&sZ[r][ks * 16 + hh * 8]), local);
         }
+        RP_HANDOFF_FENCE();
         RP_TR(1, trc, kk, 4);
         // ---- issued BEHIND the hand-off stores, which alone the flag waits for: the next item's operands, then what the rest of the step reads ----
         int behind = 0;
@@ -584,7 +587,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 // backward consumers for the nb flags of their K half.  Transposed outputs (h^T, y^T, dz^T) leave as 8-byte stores straight from the registers
 // (a lane holds four consecutive rows of a unit), no LDS transpose.
 // ------------------------------------------------------------------------------------------------------------------
-template <int U, bool XB>
+template <int U, bool XB, typename F>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_rowpar_fwd2_kernel(RFwdArgs A) {
     constexpr int KS = U / 16;
     constexpr size_t OFF_TILE = (size_t)KS * 4096, TILE_B = 2304, OFF_X = OFF_TILE + 4 * TILE_B, OFF_HS = OFF_X + 2 * 8192;
@@ -633,7 +636,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const unsigned oc = (unsigned)(rb * U + unit) * 4u;                   // c (float)
     const int g0 = 2 * half;                        // this wave's two gate tiles: g0, g0 + 1
     f32x16_t acc[2];
-    typename RpX<XB>::T xv[8];
+    typename RpX<XB, F>::T xv[8];
     float creg[8];
     unsigned mk[8];
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);
@@ -643,7 +646,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         constexpr int XS = XB ? 2 : 4;              // bytes per stored value
         const char* xb = reinterpret_cast<const char*>(A.xproj) + ((size_t)t * 4 * us + (size_t)m0 * 4 * U) * XS + og / (4 / XS);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) xv[k] = *reinterpret_cast<const typename RpX<XB>::T*>(xb + (size_t)rp_krow(k) * 4 * XS * U);
+        for (int k = 0; k < 8; ++k) xv[k] = *reinterpret_cast<const typename RpX<XB, F>::T*>(xb + (size_t)rp_krow(k) * 4 * XS * U);
         if (drop && lane < 32) mq = *reinterpret_cast<const uint4*>(A.mask + (size_t)t * us + (size_t)(m0 + 16 * half + (lane >> 1)) * U + nt * 32 + (lane & 1) * 16);
     };
     prefetch(0);
@@ -652,7 +655,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         RP_TR(0, trc, t, 0);
         if (t > 0 && !rp_wait(flags, status, 2 * nb, (unsigned)t)) return;
         RP_TR(0, trc, t, 1);
-        bf16x8_t a[KS];
+        typename F::x8 a[KS];
         {
             const __amdgpu_buffer_rsrc_t rs = rp_rsrc(t > 0 ? A.hx + ((size_t)(t - 1) * nrt + rt) * slab : A.hx0 + (size_t)rt * slab, slab);
             // same-XCD mode: through the CU's L1 -- both waves of the pair (and the second pair) read the same 1-KiB lines within a microsecond,
@@ -660,11 +663,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             if (local) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s)
-                    a[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ((((s + rot) & (KS - 1)) * 64 + lane) * 16), 0, RP_A_AUX));
+                    a[s] = __builtin_bit_cast(typename F::x8, __builtin_amdgcn_raw_buffer_load_b128(rs, ((((s + rot) & (KS - 1)) * 64 + lane) * 16), 0, RP_A_AUX));
             } else {
 #pragma unroll
                 for (int s = 0; s < KS; ++s)
-                    a[s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ((((s + rot) & (KS - 1)) * 64 + lane) * 16), 0, RP_SC1));
+                    a[s] = __builtin_bit_cast(typename F::x8, __builtin_amdgcn_raw_buffer_load_b128(rs, ((((s + rot) & (KS - 1)) * 64 + lane) * 16), 0, RP_SC1));
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -679,18 +682,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             for (int k = 0; k < 8; ++k) mk[k] = mt[(rp_krow(k) + 4 * hh) * 32 + r];
             RP_LDS_FENCE();
         }
-        bf16x8_t bq[2][2];
+        typename F::x8 bq[2][2];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) bq[0][g] = __builtin_bit_cast(bf16x8_t, wl[((g0 + g) * KS + 0) * 64 + lane]);
+        for (int g = 0; g < 2; ++g) bq[0][g] = __builtin_bit_cast(typename F::x8, wl[((g0 + g) * KS + 0) * 64 + lane]);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             if (s + 1 < KS) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g) bq[(s + 1) & 1][g] = __builtin_bit_cast(bf16x8_t, wl[((g0 + g) * KS + s + 1) * 64 + lane]);
+                for (int g = 0; g < 2; ++g) bq[(s + 1) & 1][g] = __builtin_bit_cast(typename F::x8, wl[((g0 + g) * KS + s + 1) * 64 + lane]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[s & 1][g], acc[g], 0, 0, 0);
+            for (int g = 0; g < 2; ++g) acc[g] = F::mfma32(a[s], bq[s & 1][g], acc[g]);
         }
         __builtin_amdgcn_sched_barrier(0);
         RP_TR(0, trc, t, 2);
@@ -733,7 +736,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         unsigned hbv[8], yb[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float4 x4 = RpX<XB>::get(xv[k]);
+            const float4 x4 = RpX<XB, F>::get(xv[k]);
             const float zi = (half ? recv[0][k] : keep[0][k]) + x4.x, zg = (half ? recv[1][k] : keep[1][k]) + x4.y;
             const float zf = (half ? keep[0][k] : recv[0][k]) + x4.z, zo = (half ? keep[1][k] : recv[1][k]) + x4.w;
             const float gi = fast_sigmoid(zi), gg = fast_tanh(zg), gf = fast_sigmoid(zf), go = fast_sigmoid(zo);
@@ -741,10 +744,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             const float hv = fast_tanh(cv) * go;
             gact[0][k] = gi; gact[1][k] = gg; gact[2][k] = gf; gact[3][k] = go;
             creg[k] = cv;
-            const bf16_t hb = f32_to_bf16(hv);
+            const bf16_t hb = F::cvt(hv);
             sH[rp_krow(k) + 4 * hh][r] = hb;
             hbv[k] = (unsigned)hb;
-            yb[k] = drop ? (unsigned)f32_to_bf16(bf16_to_f32(hb) * ikp * (float)mk[k]) : (unsigned)hb;
+            yb[k] = drop ? (unsigned)F::cvt(F::f32(hb) * ikp * (float)mk[k]) : (unsigned)hb;
         }
         RP_LDS_FENCE();
         RP_TR(0, trc, t, 3);
@@ -756,6 +759,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             if (local) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
             else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, RP_SC1);
         }
+        RP_HANDOFF_FENCE();
         RP_TR(0, trc, t, 4);
         int behind = 0;
         if (t + 1 < T) { prefetch(t + 1); behind += drop ? 9 : 8; }
@@ -764,8 +768,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 uint2 pk;
-                pk.x = (unsigned)f32_to_bf16(gact[0][k]) | ((unsigned)f32_to_bf16(gact[1][k]) << 16);
-                pk.y = (unsigned)f32_to_bf16(gact[2][k]) | ((unsigned)f32_to_bf16(gact[3][k]) << 16);
+                pk.x = (unsigned)F::cvt(gact[0][k]) | ((unsigned)F::cvt(gact[1][k]) << 16);
+                pk.y = (unsigned)F::cvt(gact[2][k]) | ((unsigned)F::cvt(gact[3][k]) << 16);
                 *reinterpret_cast<uint2*>(gb + (size_t)rp_krow(k) * 8 * U) = pk;
             }
             behind += 8;
@@ -816,7 +820,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 }
 
-template <int U>
+template <int U, typename F>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_rowpar_bwd2_kernel(RBwdArgs A) {
     constexpr int KS4 = U / 4, HK = KS4 / 2;        // k-steps of 16 over the 4U gate columns; per wave of the pair
     constexpr int CH = 8, NCH = HK / CH;
@@ -898,11 +902,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         f32x16_t acc;
         {
             const __amdgpu_buffer_rsrc_t rs = rp_rsrc(kk > 0 ? A.dzx + ((size_t)(t + 1) * nrt + rt) * slab : A.dzx0 + (size_t)rt * slab, slab);
-            bf16x8_t a[RP_RING][CH];
+            typename F::x8 a[RP_RING][CH];
             auto issue = [&](int ch) {
 #pragma unroll
                 for (int s = 0; s < CH; ++s)
-                    a[ch % RP_RING][s] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(
+                    a[ch % RP_RING][s] = __builtin_bit_cast(typename F::x8, __builtin_amdgcn_raw_buffer_load_b128(
                         rs, (((half * HK + ((ch * CH + s + rot) & (HK - 1))) * 64 + lane) * 16), 0, RP_SC1));
             };
 #pragma unroll
@@ -911,9 +915,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[k] = 0.f;
             const uint4* wlh = wl + (size_t)half * HK * 64;
-            bf16x8_t bq[2][4];
+            typename F::x8 bq[2][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bq[0][q] = __builtin_bit_cast(bf16x8_t, wlh[q * 64 + lane]);
+            for (int q = 0; q < 4; ++q) bq[0][q] = __builtin_bit_cast(typename F::x8, wlh[q * 64 + lane]);
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 if (ch + RP_RING - 1 < NCH) issue(ch + RP_RING - 1);
@@ -923,11 +927,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     const int f4 = ch * (CH / 4) + s4;
                     if (f4 + 1 < HK / 4) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) bq[(f4 + 1) & 1][q] = __builtin_bit_cast(bf16x8_t, wlh[((f4 + 1) * 4 + q) * 64 + lane]);
+                        for (int q = 0; q < 4; ++q) bq[(f4 + 1) & 1][q] = __builtin_bit_cast(typename F::x8, wlh[((f4 + 1) * 4 + q) * 64 + lane]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ch % RP_RING][s4 * 4 + q], bq[f4 & 1][q], acc, 0, 0, 0);
+                    for (int q = 0; q < 4; ++q) acc = F::mfma32(a[ch % RP_RING][s4 * 4 + q], bq[f4 & 1][q], acc);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -988,8 +992,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         unsigned bz[4][8];                        // bf16 dz by gate and register row
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float gi = __uint_as_float(gv[k].x << 16), gg = __uint_as_float(gv[k].x & 0xffff0000u);
-            const float gf = __uint_as_float(gv[k].y << 16), go = __uint_as_float(gv[k].y & 0xffff0000u);
+            const float gi = F::lo(gv[k].x), gg = F::hi(gv[k].x);
+            const float gf = F::lo(gv[k].y), go = F::hi(gv[k].y);
             const float dh = dhx[k] + dhp[k];
             const float tc = fast_tanh(cnext[k]);
             const float d_o = dh * tc;
@@ -1001,9 +1005,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             const int lr = rp_krow(k) + 4 * hh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const bf16_t b = f32_to_bf16(dzv[g]);
+                const bf16_t b = F::cvt(dzv[g]);
                 sZ[lr][32 * g + r] = b;
-                dbv[g] += bf16_to_f32(b);
+                dbv[g] += F::f32(b);
                 bz[g][k] = (unsigned)b;
             }
         }
@@ -1021,6 +1025,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, RP_SC1);
             }
         }
+        RP_HANDOFF_FENCE();
         RP_TR(1, trc, kk, 4);
         int behind = 0;
         if (kk + 1 < T) { prefetch(t - 1); behind += drop ? 13 : 12; }
@@ -1065,16 +1070,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-static int rp_cu_count() {
-    static int n = -1;
-    if (n < 0) {
-        int dev = 0;
+static int rp_cu_count() {          // of the CURRENT device (a process may drive several)
+    static int n[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (n[dev] <= 0) {
         hipDeviceProp_t p;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
-        n = p.multiProcessorCount;
+        if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+        n[dev] = p.multiProcessorCount;
     }
-    return n;
+    return n[dev];
 }
+static hipError_t rp_prepare_device();
 static bool rp_units_ok(int u) { return u == 128 || u == 256 || u == 512; }
 // G row-tile groups x U/32 workgroups; every workgroup's waves own one row tile each (at most `maxw`): false when that does not cover B
 static bool rp_plan(int B, int U, bool bwd, int& nrt, int& G) {
@@ -1103,7 +1110,8 @@ static size_t rp_xchg_off(int nrt, int U) { return (rp_sync_bytes(nrt) + rp_edge
 
 extern "C" int mnn_lstm_rowpar_ok(int B, int units) {
     int nrt, G;
-    return (rp_plan(B, units, false, nrt, G) && rp_plan(B, units, true, nrt, G)) ? 1 : 0;
+    if (!(rp_plan(B, units, false, nrt, G) && rp_plan(B, units, true, nrt, G))) return 0;
+    return rp_prepare_device() == hipSuccess ? 1 : 0;
 }
 extern "C" size_t mnn_lstm_rowpar_workspace_bytes(int T, int B, int units) {
     const size_t nrt = (size_t)((B + 31) / 32);
@@ -1122,15 +1130,47 @@ __global__ void rp_reset_kernel(unsigned* sync, int words) {          // progres
         if (i != 1) sync[i] = 0u;
 }
 
-template <typename K, typename Arg>
-static hipError_t rp_launch(K kernel, bool& attr_set, int grid, size_t lds, hipStream_t st, const Arg& a) {
-    if (!attr_set) {                 // once per kernel (first call: an eager warm-up step, never under stream capture)
-        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, st, a);
-    return hipGetLastError();
+// Every instantiation with its dynamic-LDS size.  The MaxDynamicSharedMemorySize attribute is per device: it is set for ALL of them the first
+// time a device asks mnn_lstm_rowpar_ok / launches (the host calls _ok before every use, so never for the first time under stream capture).
+static size_t rp_lds_fwd(int U, bool pair) { return pair ? (size_t)(U / 16) * 4096 + 4 * 2304 + 2 * 8192 + 64 : (size_t)(U / 16) * 4096 + 4 * 5120 + 16; }
+static size_t rp_lds_bwd(int U, bool pair) {
+    return pair ? (size_t)(U / 4) * 1024 + 4 * 4864 + 2 * 4096 + 64 : (size_t)(U / 4) * 1024 + (size_t)((U == 512) ? 3 : 4) * 10240 + 16;
+}
+typedef void (*rp_fwd_fn)(RFwdArgs);
+typedef void (*rp_bwd_fn)(RBwdArgs);
+template <typename F, bool XB> static rp_fwd_fn rp_fwd_kernel_x(int U, bool pair) {
+    if (pair) return U == 512 ? lstm_rowpar_fwd2_kernel<512, XB, F> : (U == 256 ? lstm_rowpar_fwd2_kernel<256, XB, F> : lstm_rowpar_fwd2_kernel<128, XB, F>);
+    return U == 512 ? lstm_rowpar_fwd_kernel<512, XB, F> : (U == 256 ? lstm_rowpar_fwd_kernel<256, XB, F> : lstm_rowpar_fwd_kernel<128, XB, F>);
+}
+static rp_fwd_fn rp_fwd_kernel(int U, bool pair, bool xb, bool f16) {
+    if (f16) return xb ? rp_fwd_kernel_x<Fp16F, true>(U, pair) : rp_fwd_kernel_x<Fp16F, false>(U, pair);
+    return xb ? rp_fwd_kernel_x<Bf16F, true>(U, pair) : rp_fwd_kernel_x<Bf16F, false>(U, pair);
+}
+template <typename F> static rp_bwd_fn rp_bwd_kernel_x(int U, bool pair) {
+    if (pair) return U == 512 ? lstm_rowpar_bwd2_kernel<512, F> : (U == 256 ? lstm_rowpar_bwd2_kernel<256, F> : lstm_rowpar_bwd2_kernel<128, F>);
+    return U == 512 ? lstm_rowpar_bwd_kernel<512, F> : (U == 256 ? lstm_rowpar_bwd_kernel<256, F> : lstm_rowpar_bwd_kernel<128, F>);
+}
+static rp_bwd_fn rp_bwd_kernel(int U, bool pair, bool f16) { return f16 ? rp_bwd_kernel_x<Fp16F>(U, pair) : rp_bwd_kernel_x<Bf16F>(U, pair); }
+static hipError_t rp_prepare_device() {
+    static bool done[64];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (done[dev]) return hipSuccess;
+    const int us[3] = {128, 256, 512};
+    for (int ui = 0; ui < 3; ++ui)
+        for (int pair = 0; pair < 2; ++pair)
+            for (int f16 = 0; f16 < 2; ++f16) {
+                for (int xb = 0; xb < 2; ++xb) {
+                    e = hipFuncSetAttribute((const void*)rp_fwd_kernel(us[ui], pair, xb, f16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rp_lds_fwd(us[ui], pair));
+                    if (e != hipSuccess) return e;
+                }
+                e = hipFuncSetAttribute((const void*)rp_bwd_kernel(us[ui], pair, f16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rp_lds_bwd(us[ui], pair));
+                if (e != hipSuccess) return e;
+            }
+    done[dev] = true;
+    return hipSuccess;
 }
 
 extern "C" int mnn_lstm_rowpar_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L, float keep_prob, void* workspace) {
@@ -1154,33 +1194,10 @@ extern "C" int mnn_lstm_rowpar_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_
     hipLaunchKernelGGL(rp_reset_kernel, dim3(8), dim3(256), 0, st, (unsigned*)workspace, (int)(rp_sync_bytes(a.nrt) / sizeof(unsigned)));
     MNN_HIP(mnn_zero_async((char*)workspace + rp_sync_bytes(a.nrt), rp_edge_bytes(a.nrt, U), st));
     const int grid = a.G * (U / 32);
-    if (rp_pair(B, U)) {
-        const size_t lds2 = (size_t)(U / 16) * 4096 + 4 * 2304 + 2 * 8192 + 64;
-        static bool p512 = false, p256 = false, p128 = false;
-        hipError_t e2;
-        static bool q512 = false, q256 = false, q128 = false;
-        if (L->xproj_bf16) {
-            if (U == 512) e2 = rp_launch(lstm_rowpar_fwd2_kernel<512, true>, q512, grid, lds2, st, a);
-            else if (U == 256) e2 = rp_launch(lstm_rowpar_fwd2_kernel<256, true>, q256, grid, lds2, st, a);
-            else e2 = rp_launch(lstm_rowpar_fwd2_kernel<128, true>, q128, grid, lds2, st, a);
-        } else if (U == 512) e2 = rp_launch(lstm_rowpar_fwd2_kernel<512, false>, p512, grid, lds2, st, a);
-        else if (U == 256) e2 = rp_launch(lstm_rowpar_fwd2_kernel<256, false>, p256, grid, lds2, st, a);
-        else e2 = rp_launch(lstm_rowpar_fwd2_kernel<128, false>, p128, grid, lds2, st, a);
-        MNN_HIP(e2);
-        return MNN_OK;
-    }
-    const size_t lds = (size_t)(U / 16) * 4096 + 4 * 5120 + 16;
-    static bool set512 = false, set256 = false, set128 = false;
-    hipError_t e;
-    static bool b512 = false, b256 = false, b128 = false;
-    if (L->xproj_bf16) {
-        if (U == 512) e = rp_launch(lstm_rowpar_fwd_kernel<512, true>, b512, grid, lds, st, a);
-        else if (U == 256) e = rp_launch(lstm_rowpar_fwd_kernel<256, true>, b256, grid, lds, st, a);
-        else e = rp_launch(lstm_rowpar_fwd_kernel<128, true>, b128, grid, lds, st, a);
-    } else if (U == 512) e = rp_launch(lstm_rowpar_fwd_kernel<512, false>, set512, grid, lds, st, a);
-    else if (U == 256) e = rp_launch(lstm_rowpar_fwd_kernel<256, false>, set256, grid, lds, st, a);
-    else e = rp_launch(lstm_rowpar_fwd_kernel<128, false>, set128, grid, lds, st, a);
-    MNN_HIP(e);
+    const bool pair = rp_pair(B, U);
+    MNN_HIP(rp_prepare_device());
+    hipLaunchKernelGGL(rp_fwd_kernel(U, pair, L->xproj_bf16 != 0, L->f16 != 0), dim3(grid), dim3(256), rp_lds_fwd(U, pair), st, a);
+    MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
 
@@ -1202,22 +1219,9 @@ extern "C" int mnn_lstm_rowpar_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_
     hipLaunchKernelGGL(rp_reset_kernel, dim3(8), dim3(256), 0, st, (unsigned*)workspace, (int)(rp_sync_bytes(a.nrt) / sizeof(unsigned)));
     MNN_HIP(mnn_zero_async((char*)workspace + rp_sync_bytes(a.nrt), rp_edge_bytes(a.nrt, U), st));
     const int grid = a.G * (U / 32);
-    if (rp_pair(B, U)) {
-        const size_t lds2 = (size_t)(U / 4) * 1024 + 4 * 4864 + 2 * 4096 + 64;
-        static bool p512 = false, p256 = false, p128 = false;
-        hipError_t e2;
-        if (U == 512) e2 = rp_launch(lstm_rowpar_bwd2_kernel<512>, p512, grid, lds2, st, a);
-        else if (U == 256) e2 = rp_launch(lstm_rowpar_bwd2_kernel<256>, p256, grid, lds2, st, a);
-        else e2 = rp_launch(lstm_rowpar_bwd2_kernel<128>, p128, grid, lds2, st, a);
-        MNN_HIP(e2);
-        return MNN_OK;
-    }
-    const size_t lds = (size_t)(U / 4) * 1024 + (size_t)((U == 512) ? 3 : 4) * 10240 + 16;
-    static bool set512 = false, set256 = false, set128 = false;
-    hipError_t e;
-    if (U == 512) e = rp_launch(lstm_rowpar_bwd_kernel<512>, set512, grid, lds, st, a);
-    else if (U == 256) e = rp_launch(lstm_rowpar_bwd_kernel<256>, set256, grid, lds, st, a);
-    else e = rp_launch(lstm_rowpar_bwd_kernel<128>, set128, grid, lds, st, a);
-    MNN_HIP(e);
+    const bool pair = rp_pair(B, U);
+    MNN_HIP(rp_prepare_device());
+    hipLaunchKernelGGL(rp_bwd_kernel(U, pair, L->f16 != 0), dim3(grid), dim3(256), rp_lds_bwd(U, pair), st, a);
+    MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

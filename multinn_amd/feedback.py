@@ -50,7 +50,13 @@ class FeedbackRnn(Model):
             raise RuntimeError("FeedbackRnn.backward: run(..., train=True) first")
         self.store.grad.zero_()
         dy = d_out.transpose(0, 1).contiguous()
+        # f16 operands: the pass runs on loss-scaled values (LstmStack.loss_scale); d_out comes from mean-over-rows losses, ~1/(B T) per element
+        ls = self._stack.loss_scale(dy.shape[0] * dy.shape[1])
+        if ls != 1.0:
+            dy = dy * ls
         self._stack.backward(dy, self._ctx["lstm"], self._ctx["kp"], self.seed, self.row0, step_dev=self.store.step_dev)
+        if ls != 1.0:
+            ops.axpby(1.0 / ls, self.store.grad, 0.0, None, self.store.grad)
 
     def single(self, x, state):
         """_apply_feedback(single_step=True): x [B,Din] -> (output [B,F] f32, new_state)."""

@@ -11,6 +11,7 @@ rows past ``lengths`` are masked by a zero row weight instead of being gathered 
 """
 import abc
 import collections
+import math
 import os
 
 import torch
@@ -35,9 +36,11 @@ class RnnEstimatorStateTuple(_RnnEstimatorStateTuple):
 def _compute_dtype(precision):
     if precision in ("bf16", torch.bfloat16):
         return torch.bfloat16
+    if precision in ("fp16", "f16", torch.float16):
+        return torch.float16
     if precision in ("fp32", "f32", torch.float32):
         return torch.float32
-    raise ValueError("precision must be 'bf16' or 'fp32'")
+    raise ValueError("precision must be 'fp16', 'bf16' or 'fp32'")
 
 
 def flat_index(lengths, B, T, device):
@@ -57,9 +60,21 @@ class LstmStack:
 
     def __init__(self, rnn, store, dtype):
         self.rnn, self.store, self.dtype = rnn, store, dtype
-        self.al = 8 if dtype == torch.bfloat16 else 4
+        self.al = 8 if dtype in ops.H16 else 4
+        self.h16 = dtype in ops.H16                     # 16-bit operands (bf16 or IEEE half): the persistent / matrix-core forms apply
         self.ld0 = ops.round_up(rnn.n_in, 64)          # K of the input projection: multiple of 64 selects the LDS-DMA GEMM
         self.packed = None
+
+    # IEEE half has 5 exponent bits: the backward pass of a mean-over-rows loss (seeds of 1/N ~ 4e-6 at the bench shape) would sit in its
+    # subnormals.  The owner of a backward pass (RnnNade / RnnRBM / FeedbackRnn) multiplies its gradient seed by loss_scale(N) -- a power of
+    # two, so every f32 result is the unscaled one times 2^k exactly -- and multiplies store.grad (and d loss / d inputs) by 1/scale at its
+    # end: callers always see unscaled gradients.  256 / N keeps |d logits| <= 256 and typical dz around 1..100 (f16: 6e-5 .. 65504).
+    loss_scale_rows = 256.0
+
+    def loss_scale(self, n_rows):
+        if self.dtype != torch.float16:
+            return 1.0
+        return float(2.0 ** round(math.log2(self.loss_scale_rows * max(int(n_rows), 1))))
 
     def pack(self):
         dev = self.store.theta.device
@@ -72,7 +87,7 @@ class LstmStack:
                      bias_p=torch.empty(4 * u, device=dev), n_in=n_in, u=u, ld=ld)
             ops.lstm_pack_weights(self.store[f"{self.rnn.prefix}/cell_{l}/kernel"], self.store[f"{self.rnn.prefix}/cell_{l}/bias"], n_in, u,
                                   p["wx_t"], p["wh_t"], p["wh_p"], p["wx_p"], p["bias_p"])
-            if self.dtype == torch.bfloat16 and (l == 0 or self.rowpar):
+            if self.h16 and (l == 0 or self.rowpar):
                 # the persistent recurrences read xproj gate-minor: the projection GEMM gets the rows in that order (layer 1 of the two-layer
                 # form; every layer of the row-parallel form, whose layers each have their own projection GEMM)
                 p["wx_gm"], p["bias_gm"] = torch.empty_like(p["wx_t"]), torch.empty_like(p["bias_p"])
@@ -109,7 +124,7 @@ class LstmStack:
     persist_single_step = True
 
     def _persist(self, B, T=2):
-        if not (self.persistent and len(self.packed) == 2 and self.dtype == torch.bfloat16):
+        if not (self.persistent and len(self.packed) == 2 and self.h16):
             return False
         if T == 1 and not self.persist_single_step:
             return False
@@ -120,11 +135,16 @@ class LstmStack:
     # paid several times per timestep: TGT [1024,256,88,5] forward 15.6 us per timestep there.
     rowpar = os.environ.get("MULTINN_ROWPAR", "1") != "0"
     rowpar_min_batch = int(os.environ.get("MULTINN_ROWPAR_MIN_BATCH", "512"))
-    # dtype of the input projections the row-parallel form reads (bias included): bf16 halves the bytes of the step's largest tensor
-    rowpar_xproj_dtype = torch.float32 if os.environ.get("MULTINN_ROWPAR_XPROJ", "bf16") == "f32" else torch.bfloat16
+    # input projections the row-parallel form reads (bias included): stored in the 16-bit compute type by default (half the bytes of the
+    # step's largest tensor), f32 with MULTINN_ROWPAR_XPROJ=f32
+    rowpar_xproj_f32 = os.environ.get("MULTINN_ROWPAR_XPROJ", "16") == "f32"
+
+    @property
+    def rowpar_xproj_dtype(self):
+        return torch.float32 if self.rowpar_xproj_f32 else self.dtype
 
     def _rowpar(self, B, T=2, state0=None):
-        if not (self.rowpar and self.dtype == torch.bfloat16 and state0 is None and T > 1 and B >= self.rowpar_min_batch and B % 32 == 0):
+        if not (self.rowpar and self.h16 and state0 is None and T > 1 and B >= self.rowpar_min_batch and B % 32 == 0):
             return False
         return all("wx_gm" in p and ops.lstm_rowpar_ok(B, p["u"]) for p in self.packed)
 
@@ -154,7 +174,7 @@ class LstmStack:
                 mask = torch.empty((T, B, u), device=dev, dtype=torch.uint8)
                 ops.dropout_mask(mask, keep_prob, seed, row0, l, step_dev)
                 y = torch.empty_like(h)
-            gates = torch.empty((T, B, 4 * u), device=dev, dtype=torch.bfloat16) if save else None      # this form saves its activations in bf16
+            gates = torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype) if save else None         # this form saves its activations in 16 bits
             c = torch.empty((T, B, u), device=dev)
             hT = yT = None
             if save:
@@ -163,7 +183,7 @@ class LstmStack:
                 if Np != N:
                     hT[:, N:].zero_()
                 yT = zalloc((u, Np), device=dev, dtype=self.dtype)
-            d = ops.lstm2_fwd_layer(xproj, p["wh_t"], None, None, gates, c, h, hT, y, mask, yT=yT, gates_dtype=torch.bfloat16,
+            d = ops.lstm2_fwd_layer(xproj, p["wh_t"], None, None, gates, c, h, hT, y, mask, yT=yT, gates_dtype=self.dtype,
                                     xproj_dtype=self.rowpar_xproj_dtype)
             ops.lstm_rowpar_fwd(T, B, d, keep_prob, self._rp_workspace(l, T, B, dev))
             out = y if y is not None else h
@@ -190,7 +210,7 @@ class LstmStack:
             dzc = torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype) if l > 0 else None
             db_p = self._accum(l, dev)[2]
             e = ops.lstm2_bwd_layer(dh.view(T, B, u), p["wh_p"], cx["gates"], cx["c"], None, dzc, ops.lstm_seq_bwd_workspace(B, u, dev), dzT, db_p,
-                                    cx["mask"] if keep_prob < 1.0 else None, gates_dtype=torch.bfloat16)
+                                    cx["mask"] if keep_prob < 1.0 else None, gates_dtype=self.dtype)
             ops.lstm_rowpar_bwd(T, B, e, keep_prob, self._rp_workspace(l, T, B, dev))
             st[l] = dict(dzT=dzT, db_p=db_p)
             if l > 0:
@@ -573,6 +593,14 @@ class RnnEstimator(Generator):
     def steps(self, inputs, initial_state=None):
         return self._get_state(inputs, initial_state=initial_state, last_outputs=True)
 
+    def _unscale(self, ls):
+        """End of a loss-scaled backward pass (LstmStack.loss_scale): gradients and d loss / d inputs back to their true scale."""
+        if ls != 1.0:
+            ops.axpby(1.0 / ls, self.store.grad, 0.0, None, self.store.grad)
+            if self._dx is not None:
+                flat = self._dx.view(-1)
+                ops.axpby(1.0 / ls, flat, 0.0, None, flat)
+
     def graphed_build_train(self, x, y, optimizer, lr=None, warmup=2):
         """The generic captured optimiser step: build(x, y, None, True, 'train') + train(optimizer, lr) as hipGraph replays, for the
         generators that train on encoder outputs rather than on a raw piano-roll batch (RnnRBM: jamming mode, RnnMultiNADE: composer
@@ -724,7 +752,7 @@ class RnnNade(RnnEstimator):
             self._fc_bias = self.store["dense/bias"]
         if self._nade_mfma():                           # bf16 copy of the decoder weights for the matrix-core NADE kernels
             M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
-            self._wdec_bf = torch.empty((M, D, Hn), device=dev, dtype=torch.bfloat16)
+            self._wdec_bf = torch.empty((M, D, Hn), device=dev, dtype=torch.bfloat16)       # this kernel's own operand type, whatever the mode's
             ops.convert2d(self.store["nade/w_dec"].view(M * D, Hn), self._wdec_bf.view(M * D, Hn))
 
     def _internal_flat(self, flat):
@@ -792,7 +820,7 @@ class RnnNade(RnnEstimator):
         else:
             n_valid = B * T * world()[1]
         x_tmT = None
-        if mode == "train" and self.dtype == torch.bfloat16:       # the same pass also writes x^T, layer 1's weight-gradient operand
+        if mode == "train" and self.dtype in ops.H16:              # the same pass also writes x^T, layer 1's weight-gradient operand
             Np = ops.round_up(T * B, 64)
             x_tmT = (torch.zeros if Np != T * B else torch.empty)((self._stack.ld0, Np), device=dev, dtype=self.dtype)
         ops.pianoroll_shift_timemajor(x_u8.view(B, T, D), lengths, x_tm, v, rw, n_valid, inputs_t=x_tmT)
@@ -818,7 +846,10 @@ class RnnNade(RnnEstimator):
             if self.ldo != self.n_out and self.dtype == torch.float32:
                 d_out[:, self.n_out:].zero_()       # fp32: d_out itself is the dgrad operand; bf16: grad_rows_fanout writes the zero padding
         a_fin = torch.empty((M, N, Hn), device=dev) if train else None
-        rw_g = rw_m if self.grad_scale == 1.0 else rw_m * self.grad_scale      # gradient seed only: the reported loss stays unscaled
+        # gradient seed only (the reported loss stays unscaled): the mode's weight of this generator's loss, and the f16 loss scale
+        ls = self._stack.loss_scale(N * world()[1]) if train else 1.0
+        gs = self.grad_scale * ls
+        rw_g = rw_m if gs == 1.0 else rw_m * gs
         if self._nade_mfma():
             # bf16 compute mode: the decoder dot products run as a block-sparse bf16 GEMM over each row's hidden states while the batch is
             # piano-roll-sparse; a dense batch takes the f32 vector form (decided on the device, per launch: ops.nade_logprob_fwd_auto)
@@ -828,7 +859,7 @@ class RnnNade(RnnEstimator):
                                  rw_g if train else None, nll, cond_p, d_out, a_fin)
         loss = torch.zeros(1, device=dev)
         ops.weighted_sum(nll.view(-1), rw_m.repeat(M) if M > 1 else rw_m, loss)      # statistical.py:34 / rnn_multinade.py:202-203
-        self._ctx = dict(x_tm=x_tm, v=v, rw=rw_m, y=y, lstm=ctx, out=out, d_out=d_out, a_fin=a_fin, kp=kp, seed=self.seed, B=B, T=T)
+        self._ctx = dict(x_tm=x_tm, v=v, rw=rw_m, y=y, lstm=ctx, out=out, d_out=d_out, a_fin=a_fin, kp=kp, seed=self.seed, B=B, T=T, ls=ls)
         self._nll_tm, self._cond_tm, self._loss = nll, cond_p, loss
         self._flat_idx = None
         self._lengths = lengths
@@ -914,6 +945,7 @@ class RnnNade(RnnEstimator):
         dy = torch.empty((N, R), device=dev)
         ops.gemm_tn(do_c, self._fc_p, dy)
         self._dx = self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], cx["seed"], self.row0, need_dx=self.need_dx, step_dev=self.store.step_dev)
+        self._unscale(cx.get("ls", 1.0))
 
     def train_step(self, x_u8, lengths, optimizer, lr=None):
         """One optimiser step on a piano-roll batch (train.py:178-189's sess.run)."""
@@ -1015,7 +1047,7 @@ class RnnNade(RnnEstimator):
     def single_step(self, inputs, initial_state):
         """rnn_nade.py:253-277."""
         x = self._step_input(inputs.shape[0], inputs.device)
-        ops.convert2d(inputs.contiguous() if inputs.dtype in (torch.uint8, torch.float32, torch.bfloat16) else inputs.float(),
+        ops.convert2d(inputs.contiguous() if inputs.dtype in (torch.uint8, torch.float32, torch.bfloat16, torch.float16) else inputs.float(),
                       x[:, :inputs.shape[1]])
         h, new = self._stack.single_step(x, [(c, hh) for c, hh in initial_state.rnn_state])
         return self._state_from_dense(self._dense(h.contiguous()), tuple(new))       # views of buffers this step allocated: no copies
@@ -1171,7 +1203,8 @@ class RnnRBM(RnnEstimator):
         # Dense-output-shaped gradient block and the two scaled hidden blocks of d cost / d W = v_s^T (w ss) - v^T (w sv)
         d_out = torch.empty((N, self.ldo), device=dev)
         pos = torch.empty((N, Hn), device=dev); neg = torch.empty((N, Hn), device=dev)
-        ops.rbm_cd_rows(cx["tgt"], cx["v_s"], sv, ss, cx["rw"], self.grad_scale, d_out, pos, neg)
+        ls = self._stack.loss_scale(N * world()[1])
+        ops.rbm_cd_rows(cx["tgt"], cx["v_s"], sv, ss, cx["rw"], self.grad_scale * ls, d_out, pos, neg)
         Np = ops.round_up(N, 4)
         def tr(xm, rows):
             o = torch.zeros((rows, Np), device=dev)
@@ -1185,6 +1218,8 @@ class RnnRBM(RnnEstimator):
         if self.bias_mode != "conditional":
             ops.bias_grad(d_out[:, :Hn], g[f"{self._rbm.prefix}/bh"].view(-1), accumulate=True)
             ops.bias_grad(d_out[:, Hn:Hn + D], g[f"{self._rbm.prefix}/bv"].view(-1), accumulate=True)
+            self._dx = None
+            self._unscale(ls)
             return                                   # as written: no gradient reaches the LSTM / Wuh / Wuv (R3)
         if self.internal_bias:
             ops.bias_grad(d_out[:, :Hn], g[f"{self._rbm.prefix}/bh"].view(-1), accumulate=True)
@@ -1205,6 +1240,7 @@ class RnnRBM(RnnEstimator):
         dy = torch.empty((N, R), device=dev)
         ops.gemm_tn(do_c, self._wu_p, dy)
         self._dx = self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], self.seed, self.row0, need_dx=self.need_dx, step_dev=self.store.step_dev)
+        self._unscale(ls)
 
     def zero_state(self, batch_size):
         self._materialize(self._num_inputs)

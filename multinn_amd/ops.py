@@ -9,13 +9,14 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, U8, GEMM_ACCUMULATE
+from ._lib import F32, BF16, U8, F16, GEMM_ACCUMULATE
 
 
 def call(name, *args):
     return _lib.call(name, *args)
 
-_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.uint8: U8}
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.uint8: U8, torch.float16: F16}
+H16 = (torch.bfloat16, torch.float16)          # the two 16-bit operand flavours (precision "bf16" / "fp16")
 
 
 def dtype_code(t):
@@ -53,11 +54,11 @@ def round_up(x, m):
 def gemm_tn(A, B, C_out, bias=None, accumulate=False, split_k=1):
     """C[M,N] (+)= A[M,K] . B[N,K]^T (+bias).  A,B same dtype (f32/bf16), K-contiguous views."""
     _rowmajor(A, "gemm A"); _rowmajor(B, "gemm B"); _rowmajor(C_out, "gemm C")
-    _req(A.dtype == B.dtype and A.dtype in (torch.float32, torch.bfloat16), "gemm: A/B must both be f32 or bf16")
+    _req(A.dtype == B.dtype and A.dtype in (torch.float32,) + H16, "gemm: A/B must both be f32, bf16 or f16")
     M, K = A.shape
     N, K2 = B.shape
     _req(K == K2 and C_out.shape == (M, N), f"gemm: shape mismatch A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(C_out.shape)}")
-    _req(C_out.dtype in (torch.float32, torch.bfloat16), "gemm: C must be f32/bf16")
+    _req(C_out.dtype in (torch.float32,) + H16, "gemm: C must be f32/bf16/f16")
     if bias is not None:
         _req(bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous(), "gemm: bias must be f32[N]")
     call("mnn_gemm_tn", _stream(), dtype_code(A), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C_out), C_out.stride(0),
@@ -96,10 +97,10 @@ def pianoroll_shift_timemajor(x, lengths, inputs, targets, row_weight, n_valid_t
         _req(lengths.dtype == torch.int32 and lengths.numel() == B, "pianoroll: lengths int32 [B]")
         _req(n_valid_total > 0, "pianoroll: n_valid_total required with lengths")
     if inputs_t is not None:
-        _req(inputs.dtype == torch.bfloat16 and inputs_t.dtype == torch.bfloat16 and inputs_t.dim() == 2 and inputs_t.stride(1) == 1
-             and inputs_t.shape[0] == inputs.shape[2] and inputs_t.shape[1] >= T * B, "pianoroll: inputs_t must be bf16 [ld, >=T*B]")
+        _req(inputs.dtype in H16 and inputs_t.dtype == inputs.dtype and inputs_t.dim() == 2 and inputs_t.stride(1) == 1
+             and inputs_t.shape[0] == inputs.shape[2] and inputs_t.shape[1] >= T * B, "pianoroll: inputs_t must be 16-bit [ld, >=T*B] like inputs")
         call("mnn_pianoroll_shift_timemajor_t", _stream(), _ptr(x), B, T, D, _ptr(lengths), _ptr(inputs), inputs.shape[2], _ptr(inputs_t),
-             inputs_t.stride(0), _ptr(targets), _ptr(row_weight), int(n_valid_total))
+             inputs_t.stride(0), _ptr(targets), _ptr(row_weight), int(n_valid_total), dtype_code(inputs))
         return
     call("mnn_pianoroll_shift_timemajor", _stream(), _ptr(x), B, T, D, _ptr(lengths), _ptr(inputs), dtype_code(inputs), inputs.shape[2],
          _ptr(targets), _ptr(row_weight), int(n_valid_total))
@@ -216,33 +217,35 @@ def lstm2_fwd_layer(xproj, wh_t, h0, c0, gates, c, h, hT, y=None, mask=None, wx_
                     xproj_dtype=torch.float32):
     """Descriptor of one layer for lstm2_seq_fwd (same tensors as lstm_seq_fwd; bf16, contiguous, time-major).
     y/mask: dropped output and u8 keep mask (keep_prob < 1); wx_t/bias_p: this layer's input projection (layer 2)."""
-    _req(h.dim() == 3 and h.dtype == torch.bfloat16 and h.is_contiguous(), "lstm2: h bf16 [T,B,u]")
+    _req(h.dim() == 3 and h.dtype in H16 and h.is_contiguous(), "lstm2: h bf16 / f16 [T,B,u]")
+    dt = h.dtype                                    # the layer's 16-bit flavour: every 16-bit tensor of the layer has it
     T, B, u = h.shape
     N4 = 4 * u
     _req(xproj is not None or wx_t is not None, "lstm2: xproj may be omitted only for a layer with its own input projection (persistent form)")
     _req(xproj is None or (xproj.dtype == xproj_dtype and xproj.is_contiguous() and xproj.shape == (T, B, N4)), "lstm2: xproj [T,B,4u] of the stated dtype")
-    _req(xproj_dtype in (torch.float32, torch.bfloat16), "lstm2: xproj f32 (or bf16: row-parallel form only)")
-    _req(wh_t.shape == (N4, u) and wh_t.is_contiguous() and wh_t.dtype == torch.bfloat16, "lstm2: wh_t bf16 [4u,u]")
+    _req(xproj_dtype in (torch.float32, dt), "lstm2: xproj f32 (or the layer's 16-bit type: row-parallel form only)")
+    _req(gates_dtype in (torch.float32, dt), "lstm2: gates f32 (or the layer's 16-bit type: row-parallel form)")
+    _req(wh_t.shape == (N4, u) and wh_t.is_contiguous() and wh_t.dtype == dt, "lstm2: wh_t [4u,u] in the layer's 16-bit type")
     _req(c.dtype == torch.float32 and c.shape == (T, B, u) and c.is_contiguous(), "lstm2: c")
     _req(gates is None or (gates.dtype == gates_dtype and gates.shape == (T, B, N4) and gates.is_contiguous()), "lstm2: gates")
-    _req(h0 is None or (h0.shape == (B, u) and h0.dtype == torch.bfloat16 and h0.is_contiguous()), "lstm2: h0")
+    _req(h0 is None or (h0.shape == (B, u) and h0.dtype == dt and h0.is_contiguous()), "lstm2: h0")
     _req(c0 is None or (c0.shape == (B, u) and c0.dtype == torch.float32 and c0.is_contiguous()), "lstm2: c0")
-    _req(hT is None or (hT.dim() == 2 and hT.shape[0] == u and hT.stride(1) == 1 and hT.shape[1] >= T * B and hT.dtype == torch.bfloat16), "lstm2: hT")
+    _req(hT is None or (hT.dim() == 2 and hT.shape[0] == u and hT.stride(1) == 1 and hT.shape[1] >= T * B and hT.dtype == dt), "lstm2: hT")
     _req((y is None) == (mask is None), "lstm2: y and mask come together")
     if mask is not None:
         _req(mask.dtype == torch.uint8 and mask.shape == (T, B, u) and mask.is_contiguous(), "lstm2: mask u8 [T,B,u]")
-        _req(y.dtype == torch.bfloat16 and y.shape == (T, B, u) and y.is_contiguous(), "lstm2: y bf16 [T,B,u]")
+        _req(y.dtype == dt and y.shape == (T, B, u) and y.is_contiguous(), "lstm2: y [T,B,u] in the layer's 16-bit type")
     ld_w = 0
     if wx_t is not None:
-        _req(wx_t.dim() == 2 and wx_t.shape[0] == N4 and wx_t.stride(1) == 1 and wx_t.dtype == torch.bfloat16, "lstm2: wx_t bf16 [4u, ld]")
+        _req(wx_t.dim() == 2 and wx_t.shape[0] == N4 and wx_t.stride(1) == 1 and wx_t.dtype == dt, "lstm2: wx_t [4u, ld] in the layer's 16-bit type")
         _req(bias_p is not None and bias_p.dtype == torch.float32 and bias_p.numel() == N4, "lstm2: bias_p f32 [4u]")
         ld_w = wx_t.stride(0)
     for t in (wh_t, c, h):
         _ptr(t)
-    _req(yT is None or (yT.dim() == 2 and yT.shape[0] == u and yT.stride(1) == 1 and yT.shape[1] >= T * B and yT.dtype == torch.bfloat16), "lstm2: yT")
+    _req(yT is None or (yT.dim() == 2 and yT.shape[0] == u and yT.stride(1) == 1 and yT.shape[1] >= T * B and yT.dtype == dt), "lstm2: yT")
     return _lib.LstmFwdLayer(u, _p0(xproj), _p0(wh_t), _p0(h0), _p0(c0), _p0(gates), _p0(c), _p0(h), _p0(hT), hT.stride(0) if hT is not None else 0,
                              _p0(y), _p0(mask), _p0(wx_t), ld_w, _p0(bias_p), _p0(yT), yT.stride(0) if yT is not None else 0,
-                             1 if xproj_dtype == torch.bfloat16 else 0)
+                             1 if xproj_dtype != torch.float32 else 0, 1 if dt == torch.float16 else 0)
 
 
 def lstm2_seq_fwd(T, B, L1, L2, keep_prob, s_begin=0, s_end=None):
@@ -255,20 +258,22 @@ def lstm2_bwd_layer(dh_ext, wh_p, gates, c, c0, dz_T, ws, dzT_t, db_p, mask=None
     T, B, u = c.shape
     N4 = 4 * u
     _req(dh_ext is None or (dh_ext.dtype == torch.float32 and dh_ext.is_contiguous() and dh_ext.shape == (T, B, u)), "lstm2 bwd: dh_ext f32 [T,B,u]")
-    _req(wh_p.shape == (u, N4) and wh_p.is_contiguous() and wh_p.dtype == torch.bfloat16, "lstm2 bwd: wh_p bf16 [u,4u]")
+    _req(wh_p.shape == (u, N4) and wh_p.is_contiguous() and wh_p.dtype in H16, "lstm2 bwd: wh_p bf16 / f16 [u,4u]")
+    dt = wh_p.dtype
+    _req(gates_dtype in (torch.float32, dt), "lstm2 bwd: gates f32 (or the layer's 16-bit type: row-parallel form)")
     _req(gates.shape == (T, B, N4) and gates.dtype == gates_dtype and gates.is_contiguous(), "lstm2 bwd: gates")
     _req(c.shape == (T, B, u) and c.dtype == torch.float32 and c.is_contiguous(), "lstm2 bwd: c")
-    _req(dz_T is None or (dz_T.shape == (T, B, N4) and dz_T.dtype == torch.bfloat16 and dz_T.is_contiguous()), "lstm2 bwd: dz_T bf16 [T,B,4u]")
+    _req(dz_T is None or (dz_T.shape == (T, B, N4) and dz_T.dtype == dt and dz_T.is_contiguous()), "lstm2 bwd: dz_T [T,B,4u] in the layer's 16-bit type")
     _req(dzT_t is None or (dzT_t.dim() == 2 and dzT_t.shape[0] == N4 and dzT_t.stride(1) == 1 and dzT_t.shape[1] >= T * B
-                           and dzT_t.dtype == torch.bfloat16), "lstm2 bwd: dzT_t")
+                           and dzT_t.dtype == dt), "lstm2 bwd: dzT_t")
     _req(db_p is None or (db_p.dtype == torch.float32 and db_p.numel() == N4 and dzT_t is not None), "lstm2 bwd: db_p")
     _req(ws.numel() >= B * u * 4, "lstm2 bwd: workspace too small")
     _req(mask is None or (mask.dtype == torch.uint8 and mask.shape == (T, B, u) and mask.is_contiguous()), "lstm2 bwd: mask u8 [T,B,u]")
-    _req(wx_p is None or (wx_p.dim() == 2 and wx_p.shape[1] == N4 and wx_p.is_contiguous() and wx_p.dtype == torch.bfloat16), "lstm2 bwd: wx_p [n_in,4u]")
+    _req(wx_p is None or (wx_p.dim() == 2 and wx_p.shape[1] == N4 and wx_p.is_contiguous() and wx_p.dtype == dt), "lstm2 bwd: wx_p [n_in,4u]")
     for t in (wh_p, gates, c, ws):
         _ptr(t)
     return _lib.LstmBwdLayer(u, _p0(dh_ext), _p0(wh_p), _p0(gates), _p0(c), _p0(c0), None, _p0(dz_T), _p0(ws), _p0(dzT_t),
-                             dzT_t.stride(0) if dzT_t is not None else 0, _p0(db_p), _p0(mask), _p0(wx_p))
+                             dzT_t.stride(0) if dzT_t is not None else 0, _p0(db_p), _p0(mask), _p0(wx_p), 1 if dt == torch.float16 else 0)
 
 
 def lstm2_seq_bwd(T, B, L1, L2, keep_prob, k_begin=0, k_end=None):
@@ -636,12 +641,12 @@ def grad_rows_fanout(dY, cols_t, out_c, out_t, db):
     """One pass over dY f32 [rows, cols_c]: out_c = bf16 copy, out_t[:cols_t, :rows] = bf16 transpose, db[:cols_t] += column sums."""
     _rowmajor(dY, "fanout dY"); _rowmajor(out_c, "fanout out_c"); _rowmajor(out_t, "fanout out_t")
     rows, cols_c = dY.shape
-    _req(dY.dtype == torch.float32 and out_c.dtype == torch.bfloat16 and out_t.dtype == torch.bfloat16 and db.dtype == torch.float32,
-         "fanout: dY/db f32, outputs bf16")
+    _req(dY.dtype == torch.float32 and out_c.dtype in H16 and out_t.dtype == out_c.dtype and db.dtype == torch.float32,
+         "fanout: dY/db f32, outputs bf16 / f16")
     _req(out_c.shape == dY.shape and out_t.shape[0] == cols_t and out_t.shape[1] >= rows and 0 < cols_t <= cols_c and db.numel() == cols_t
          and db.is_contiguous(), "fanout: shapes")
     call("mnn_grad_rows_fanout", _stream(), _ptr(dY), rows, cols_c, cols_t, dY.stride(0), _ptr(out_c), out_c.stride(0), _ptr(out_t),
-         out_t.stride(0), _ptr(db))
+         out_t.stride(0), _ptr(db), dtype_code(out_c))
 
 
 def fill(x, value):

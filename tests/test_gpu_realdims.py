@@ -74,7 +74,7 @@ def oracle(B, T, rho):
 
 
 @pytest.mark.parametrize("rho", [0.03, 0.5])
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16"])
 def test_joint_lstm_nade_step_at_real_widths_vs_oracle(precision, rho):
     from multinn_amd import RnnNade
     B, T = 32, 8
@@ -83,7 +83,7 @@ def test_joint_lstm_nade_step_at_real_widths_vs_oracle(precision, rho):
     gen._materialize(D)
     load(gen, p)
     gen.build_pianoroll(dev(x), None, is_train=True, mode="train")
-    if precision == "bf16":
+    if precision in ("bf16", "fp16"):
         assert gen._stack._persist(B, T) and gen._nade_mfma(), "the benchmarked kernels must be the ones under test"
     loss = float(gen.metrics["batch/loss"])
     nll = gen.log_probs.cpu().numpy()
@@ -101,13 +101,17 @@ def test_joint_lstm_nade_step_at_real_widths_vs_oracle(precision, rho):
         print(f"    {k:24s} {v:.3e}" + (f"   cos {cosv[k]:.6f}" if k in cosv else ""))
     if precision == "fp32":
         assert all(v < 1e-4 for v in errs.values()), errs                  # BASELINE.json: 1e-4 relative
+    elif precision == "fp16":   # the BENCHMARKED mode: the quantities BASELINE.json names within 1e-4; gradients (f16 operands, 11 bits) bounded
+        assert errs["loss"] < 1e-4 and errs["nll"] < 1e-4, errs
+        assert all(v < 3e-3 for v in errs.values()), errs
+        assert all(c > 0.999999 for c in cosv.values()), cosv
     else:       # measured on MI355X (round 2): loss 6e-6, NLL 1.2e-4, gradients 4e-4 .. 4.3e-3, cosine >= 0.99999
         assert errs["loss"] < 5e-4 and errs["nll"] < 2e-3, errs
         assert all(v < 2e-2 for v in errs.values()), errs
         assert all(c > 0.9999 for c in cosv.values()), cosv
     cp_err = np.abs(cp - fw['cond_p'][0]).max()
     print(f"    {'cond_probs (abs)':24s} {cp_err:.3e}")
-    assert cp_err < (2e-5 if precision == "fp32" else 2e-2)
+    assert cp_err < {"fp32": 2e-5, "fp16": 1e-4, "bf16": 2e-2}[precision]
 
 
 def test_real_width_optimiser_step_fp32_vs_oracle():
@@ -173,9 +177,10 @@ def test_target_shape_train_step_properties():
     assert all(np.isfinite(ls)) and ls[-1] < ls[0], ls
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("units,B,T,max_g", [([512, 256], 64, 8, None), ([128, 128, 128], 96, 6, None), ([256], 32, 5, None),
                                              ([512, 256], 64, 6, 1), ([256], 128, 5, 1)])
-def test_rowpar_recurrence_vs_oracle(units, B, T, max_g, monkeypatch):
+def test_rowpar_recurrence_vs_oracle(units, B, T, max_g, precision, monkeypatch):
     """The row-parallel persistent recurrence (lstm_rowpar.hip: one launch per layer, weights in LDS, a wave per 32-row tile -- the form
     for B >= 512) against the float64 oracle, with its batch threshold lowered so the oracle stays quick: loss, NLL and every gradient
     within the bf16 bounds of the two-layer persistent form; it must also agree with the launch-per-step kernels on the same weights.
@@ -193,7 +198,7 @@ def test_rowpar_recurrence_vs_oracle(units, B, T, max_g, monkeypatch):
     inp, tgt = G.joint_inputs(x.astype(np.float64))
     fw = G.rnn_nade_forward(inp, tgt, None, p, 0.9, G.dropout_uniforms(23, B, T, units))
     g = G.rnn_nade_backward(fw, p)
-    gen = RnnNade(D, HN, units, keep_prob=0.9, precision="bf16", seed=23)
+    gen = RnnNade(D, HN, units, keep_prob=0.9, precision=precision, seed=23)
     gen._materialize(D)
     load(gen, p)
     gen._stack.rowpar_min_batch = 32
@@ -210,12 +215,20 @@ def test_rowpar_recurrence_vs_oracle(units, B, T, max_g, monkeypatch):
         got = gen.store.gviews[name].cpu().numpy().reshape(ref.shape)
         errs[name] = rel(got, ref)
         cosv[name] = cosine(got, ref)
-    print(f"\n[rowpar units={units} B={B} T={T}] relative error vs float64 oracle:")
+    print(f"\n[rowpar {precision} units={units} B={B} T={T}] relative error vs float64 oracle:")
     for k, v in errs.items():
         print(f"    {k:24s} {v:.3e}" + (f"   cos {cosv[k]:.6f}" if k in cosv else ""))
-    assert errs["loss"] < 5e-4 and errs["nll"] < 2e-3, errs
-    assert all(v < 2e-2 for v in errs.values()), errs
-    assert all(c > 0.9999 for c in cosv.values()), cosv
+    if precision == "fp16":     # the benchmarked mode and form: BASELINE.json's 1e-4 on the loss and every row's NLL
+        assert errs["loss"] < 1e-4 and errs["nll"] < 1e-4, errs
+        assert all(v < 3e-3 for v in errs.values()), errs
+        assert all(c > 0.999999 for c in cosv.values()), cosv
+        cp_err = np.abs(gen.cond_probs.cpu().numpy() - fw['cond_p'][0]).max()
+        print(f"    {'cond_probs (abs)':24s} {cp_err:.3e}")
+        assert cp_err < 1e-4
+    else:
+        assert errs["loss"] < 5e-4 and errs["nll"] < 2e-3, errs
+        assert all(v < 2e-2 for v in errs.values()), errs
+        assert all(c > 0.9999 for c in cosv.values()), cosv
     # run-to-run: the recurrence's own outputs (no atomics upstream of them) are bit-stable
     nll0 = gen._nll_tm.clone()
     dz0 = [d.clone() for d in gen._stack._dbg_dzT]
