@@ -15,6 +15,8 @@
 // adds, one sigmoid per state element and the per-(row, d) pointwise.  w_enc stays f32 (a is exact up to f32
 // summation order and is handed to the backward pass as a_final); w_dec is read as a bf16 copy.
 #include "common.h"
+#include <algorithm>
+#include <type_traits>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -39,10 +41,21 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 __device__ __forceinline__ float nm_ln(float x) { return __builtin_amdgcn_logf(x) * LN2F; }
 
-struct NadeFwdSmem {
+// SPLIT (precision "fp16": BASELINE.json's 1e-4 on every conditional): both operands of the decoder dot products carry 16 significant
+// bits as a bf16 pair hi + lo (hi = bf16(x), lo = bf16(x - hi)).  A state element is ONE 32-bit LDS word (hi | lo << 16), so the flip pass
+// still writes one word per (state, hidden unit); a 16-byte A-fragment read is then 4 hidden units x (hi, lo) = 8 k-slots, and it meets
+//   B1 = (w_hi, w_hi) per unit:  (h_hi + h_lo) . w_hi          B2 = (w_lo, w_lo) per unit:  (h_hi + h_lo) . w_lo
+// on v_mfma_f32_16x16x32_bf16: 16 k-steps x 2 MFMAs per 16 x 16 tile instead of 8.  The matrix cores are ~2 % busy in this kernel, so the
+// extra passes are free; what is paid is twice the LDS bytes per A fragment.  w_dec comes pre-split ([d][4-unit group][hi x4 | lo x4]).
+template <bool SPLIT> struct NmState;
+template <> struct NmState<false> { typedef bf16_t T; static constexpr int PITCH = NM_PITCH; static constexpr int KS = 8; };
+template <> struct NmState<true> { typedef uint32_t T; static constexpr int PITCH = 260; static constexpr int KS = 16; };    // 260 words: rows 4 banks apart
+
+template <bool SPLIT>
+struct NadeFwdSmemT {
     float sA[32][NM_H];                 // pre-activations a[row][hidden] (f32; thread = hidden unit owns a column)
-    bf16_t sH[32][NM_PITCH];            // current state of every row (as of the tile being processed)
-    bf16_t sF[32][NM_PITCH];            // states created by the flips of the tile (one chunk of 32 slots)
+    typename NmState<SPLIT>::T sH[32][NmState<SPLIT>::PITCH];            // current state of every row (as of the tile being processed)
+    typename NmState<SPLIT>::T sF[32][NmState<SPLIT>::PITCH];            // states created by the flips of the tile (one chunk of 32 slots)
     float sLb[32][NM_LP];               // logits of the base states  [row][column]
     float sLf[32][NM_LP];               // logits of the flip states  [slot][column]
     unsigned sMask[2][32];              // v bits of the tile, per row (double buffered: tile c, tile c+1)
@@ -58,16 +71,57 @@ __device__ __forceinline__ void nm_load_a(const bf16_t (*tile)[NM_PITCH], int mi
 #pragma unroll
     for (int s = 0; s < 8; ++s) a[s] = *reinterpret_cast<const bf16x8_t*>(p + 32 * s);
 }
+// split form: k-step s covers hidden units 16 s + 4 (l >> 4) .. + 3, each as the (hi, lo) pair of its state word
+__device__ __forceinline__ void nm_load_a(const uint32_t (*tile)[260], int mi, int lane, bf16x8_t (&a)[16]) {
+    const uint32_t* p = &tile[16 * mi + (lane & 15)][4 * (lane >> 4)];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) a[s] = *reinterpret_cast<const bf16x8_t*>(p + 16 * s);
+}
+__device__ __forceinline__ uint32_t nm_split(float x) {           // hi | lo << 16
+    const uint32_t hi = (uint32_t)f32_to_bf16(x);
+    return hi | ((uint32_t)f32_to_bf16(x - __uint_as_float(hi << 16)) << 16);
+}
+template <bool SPLIT> __device__ __forceinline__ typename NmState<SPLIT>::T nm_state(float h) {
+    if constexpr (SPLIT) return nm_split(h);
+    else return f32_to_bf16(h);
+}
+// 16 x 16 logits of one state tile against the tile's decoder rows
+__device__ __forceinline__ f32x4_t nm_dot(const bf16x8_t (&af)[8], const bf16x8_t (&bfr)[8]) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], bfr[s], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ f32x4_t nm_dot(const bf16x8_t (&af)[16], const uint4 (&bw)[16]) {
+    // bw[s] = hi(u0,u1) hi(u2,u3) lo(u0,u1) lo(u2,u3) of the step's four units: every 16-bit weight doubled into the slot pair of its unit
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        uint4 b1, b2;
+        b1.x = __builtin_amdgcn_perm(bw[s].x, bw[s].x, 0x01000100u); b1.y = __builtin_amdgcn_perm(bw[s].x, bw[s].x, 0x03020302u);
+        b1.z = __builtin_amdgcn_perm(bw[s].y, bw[s].y, 0x01000100u); b1.w = __builtin_amdgcn_perm(bw[s].y, bw[s].y, 0x03020302u);
+        b2.x = __builtin_amdgcn_perm(bw[s].z, bw[s].z, 0x01000100u); b2.y = __builtin_amdgcn_perm(bw[s].z, bw[s].z, 0x03020302u);
+        b2.z = __builtin_amdgcn_perm(bw[s].w, bw[s].w, 0x01000100u); b2.w = __builtin_amdgcn_perm(bw[s].w, bw[s].w, 0x03020302u);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], __builtin_bit_cast(bf16x8_t, b1), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], __builtin_bit_cast(bf16x8_t, b2), acc, 0, 0, 0);
+    }
+    return acc;
+}
 
 // thread = hidden unit: the 32 rows' pre-activations a[32] live in registers and are indexed by the (wave-uniform) row of
 // each flip -- the compiler lowers that to s_set_gpr_idx, no scratch.  Per flip the VALU does one add, one sigmoid,
 // one bf16 convert and two LDS writes; everything it needs (the flip list, the flips' w_enc values) was fetched a tile ahead.
+template <bool SPLIT>
 __global__ void __launch_bounds__(256)
 nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias, int ld_bias,
                      const float* __restrict__ w_enc, const bf16_t* __restrict__ w_dec_bf, const float* __restrict__ row_weight,
                      float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias, float* __restrict__ a_final,
                      const int* __restrict__ gate, int run_if) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    typedef NadeFwdSmemT<SPLIT> NadeFwdSmem;
+    typedef typename NmState<SPLIT>::T state_t;
+    typedef typename std::conditional<SPLIT, uint4, bf16x8_t>::type bfrag_t;
+    constexpr int KS = NmState<SPLIT>::KS;
     NadeFwdSmem& S = *reinterpret_cast<NadeFwdSmem*>(smem_raw);
     if (gate != nullptr && *gate != run_if) return;          // density-gated pair of launches: uniform exit
     constexpr int Hn = NM_H;
@@ -77,7 +131,7 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
     const int rb = blockIdx.x * 32;
     const uint8_t* __restrict__ vm = v + (size_t)m * v_track_stride;
     const float* __restrict__ we = w_enc + (size_t)m * D * Hn;
-    const bf16_t* __restrict__ wd = w_dec_bf + (size_t)m * D * Hn;
+    const bf16_t* __restrict__ wd = w_dec_bf + (size_t)m * D * Hn * (SPLIT ? 2 : 1);
     const int bd_off = tracks * Hn + m * D;
     const int ntile = (D + 31) / 32;
 
@@ -86,7 +140,7 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
         const int row = rb + n;
         const float av = row < N ? bias[(size_t)row * ld_bias + m * Hn + tid] : 0.f;
         S.sA[n][tid] = av;
-        S.sH[n][tid] = f32_to_bf16(fast_sigmoid(av));
+        S.sH[n][tid] = nm_state<SPLIT>(fast_sigmoid(av));
     }
     // v bytes of rows 8w .. 8w+7 of a tile: lane -> (row 8w + 2i + (lane >> 5), column lane & 31)
     auto load_v = [&](int c, unsigned char (&vb)[4]) {
@@ -128,11 +182,17 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
             if (lane == 0) S.sSb[buf][32] = (unsigned)base;
         }
     };
-    auto load_b = [&](int c, bf16x8_t (&b)[8]) {            // lane: column l & 15 of the wave's column half, k = 32 s + 8 (l >> 4) + j
+    auto load_b = [&](int c, bfrag_t (&b)[KS]) {            // lane: column l & 15 of the wave's column half, k = 32 s + 8 (l >> 4) + j
         const int d = min(32 * c + 16 * ni + (lane & 15), D - 1);
-        const bf16_t* p = wd + (size_t)d * Hn + 8 * (lane >> 4);
+        if constexpr (SPLIT) {                                // [d][4-unit group 4 s + (l >> 4)][hi x4 | lo x4]: 16 bytes per k-step
+            const bf16_t* p = wd + (size_t)d * 2 * Hn + 8 * (lane >> 4);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) b[s] = *reinterpret_cast<const bf16x8_t*>(p + 32 * s);
+            for (int s = 0; s < KS; ++s) b[s] = *reinterpret_cast<const uint4*>(p + 32 * s);
+        } else {
+            const bf16_t* p = wd + (size_t)d * Hn + 8 * (lane >> 4);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) b[s] = *reinterpret_cast<const bf16x8_t*>(p + 32 * s);
+        }
     };
     // w_enc[column of flip k0+u][this hidden unit] for the 32 flips of a chunk (entries past the tile's count re-read flip 0's row)
     auto load_we = [&](int c, int buf, int k0, float (&wv)[32]) {
@@ -147,7 +207,7 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
         }
     };
     unsigned char vb[4];
-    bf16x8_t bfr[8];
+    bfrag_t bfr[KS];
     float wev[32];
     load_v(0, vb);
     load_b(0, bfr);
@@ -174,11 +234,9 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
 #pragma unroll
         for (int k = 0; k < 4; ++k) bdec[k] = bias[(size_t)err * ld_bias + bd_off + min(32 * c + ed0 + k, D - 1)];
         {
-            bf16x8_t af[8];
+            bf16x8_t af[KS];
             nm_load_a(S.sH, mi, lane, af);
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], bfr[s], acc, 0, 0, 0);
+            const f32x4_t acc = nm_dot(af, bfr);
 #pragma unroll
             for (int i = 0; i < 4; ++i) S.sLb[16 * mi + 4 * (lane >> 4) + i][16 * ni + (lane & 15)] = acc[i];
         }
@@ -225,9 +283,9 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
                         for (int i = 0; i < 8; ++i) x[i] = S.sA[n[i]][tid];
 #pragma unroll
                         for (int i = 0; i < 8; ++i) x[i] += wev[u0 + i];
-                        bf16_t hb[8];
+                        state_t hb[8];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) hb[i] = f32_to_bf16(fast_sigmoid(x[i]));
+                        for (int i = 0; i < 8; ++i) hb[i] = nm_state<SPLIT>(fast_sigmoid(x[i]));
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             if (u0 + i < cnt) {
@@ -242,7 +300,7 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
                             if (u0 + i < cnt) {
                                 const float av = S.sA[n[i]][tid] + wev[u0 + i];
                                 S.sA[n[i]][tid] = av;
-                                const bf16_t hb1 = f32_to_bf16(fast_sigmoid(av));
+                                const state_t hb1 = nm_state<SPLIT>(fast_sigmoid(av));
                                 S.sF[u0 + i][tid] = hb1;
                                 S.sH[n[i]][tid] = hb1;
                             }
@@ -257,11 +315,9 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
             NM_T(4);
             // ---- S2: flip logits; each pair whose state sits in this chunk picks its logit ----
             {
-                bf16x8_t af[8];
+                bf16x8_t af[KS];
                 nm_load_a(S.sF, mi, lane, af);
-                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], bfr[s], acc, 0, 0, 0);
+                const f32x4_t acc = nm_dot(af, bfr);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) S.sLf[16 * mi + 4 * (lane >> 4) + i][16 * ni + (lane & 15)] = acc[i];
             }
@@ -324,21 +380,58 @@ extern "C" int mnn_nade_logprob_fwd_mfma(mnn_stream_t s, int tracks, int N, int 
                                            a_final, nullptr, 0);
 }
 
+template <bool SPLIT>
+static int nm_launch(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride, const float* bias, int ld_bias,
+                     const float* w_enc, const void* w_dec16, const float* row_weight, float* nll, float* cond_p, float* d_bias, float* a_final,
+                     const int* gate, int run_if) {
+    MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn == NM_H, "mnn_nade_logprob_fwd_mfma: need tracks,N,D>0 and Hn == 256 (Hn=%d)", Hn);
+    MNN_REQUIRE(v && bias && w_enc && w_dec16, "mnn_nade_logprob_fwd_mfma: null pointer");
+    MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_logprob_fwd_mfma: ld_bias %d < tracks*(Hn+D)", ld_bias);
+    MNN_REQUIRE(d_bias == nullptr || row_weight != nullptr, "mnn_nade_logprob_fwd_mfma: d_bias needs row_weight");
+    MNN_REQUIRE(((uintptr_t)w_dec16 & 15) == 0, "mnn_nade_logprob_fwd_mfma: the 16-bit decoder weights must be 16-byte aligned");
+    static bool attr_set[64];
+    int dev = 0;
+    MNN_HIP(hipGetDevice(&dev));
+    MNN_REQUIRE(dev >= 0 && dev < 64, "mnn_nade_logprob_fwd_mfma: device index %d", dev);
+    if (!attr_set[dev]) {
+        MNN_HIP(hipFuncSetAttribute((const void*)nade_fwd_mfma_kernel<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(NadeFwdSmemT<SPLIT>)));
+        attr_set[dev] = true;
+    }
+    dim3 grid(cdiv(N, 32), tracks);
+    hipLaunchKernelGGL(nade_fwd_mfma_kernel<SPLIT>, grid, dim3(256), sizeof(NadeFwdSmemT<SPLIT>), (hipStream_t)s, tracks, N, D, v, v_track_stride, bias,
+                       ld_bias, w_enc, (const bf16_t*)w_dec16, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
 extern "C" int mnn_nade_logprob_fwd_mfma_gated(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                                const float* bias, int ld_bias, const float* w_enc, const void* w_dec_bf16, const float* row_weight,
                                                float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if) {
-    MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn == NM_H, "mnn_nade_logprob_fwd_mfma: need tracks,N,D>0 and Hn == 256 (Hn=%d)", Hn);
-    MNN_REQUIRE(v && bias && w_enc && w_dec_bf16, "mnn_nade_logprob_fwd_mfma: null pointer");
-    MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_logprob_fwd_mfma: ld_bias %d < tracks*(Hn+D)", ld_bias);
-    MNN_REQUIRE(d_bias == nullptr || row_weight != nullptr, "mnn_nade_logprob_fwd_mfma: d_bias needs row_weight");
-    static bool attr_set = false;
-    if (!attr_set) {
-        MNN_HIP(hipFuncSetAttribute((const void*)nade_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(NadeFwdSmem)));
-        attr_set = true;
+    return nm_launch<false>(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec_bf16, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
+}
+
+extern "C" int mnn_nade_logprob_fwd_mfma_split(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
+                                               const float* bias, int ld_bias, const float* w_enc, const void* w_dec_split, const float* row_weight,
+                                               float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if) {
+    return nm_launch<true>(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec_split, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
+}
+
+// w_dec f32 [rows, Hn] -> [rows][Hn / 4][hi x4 | lo x4] bf16 (16 bytes per group of four hidden units): the B operand of the split form
+__global__ void __launch_bounds__(256) nade_split_pack_kernel(const float* __restrict__ w, long groups, uint4* __restrict__ out) {
+    for (long g = blockIdx.x * 256L + threadIdx.x; g < groups; g += (long)gridDim.x * 256) {
+        const float4 x = *reinterpret_cast<const float4*>(w + 4 * g);
+        const uint32_t s0 = nm_split(x.x), s1 = nm_split(x.y), s2 = nm_split(x.z), s3 = nm_split(x.w);
+        uint4 o;
+        o.x = (s0 & 0xffffu) | (s1 << 16); o.y = (s2 & 0xffffu) | (s3 << 16);
+        o.z = (s0 >> 16) | (s1 & 0xffff0000u); o.w = (s2 >> 16) | (s3 & 0xffff0000u);
+        out[g] = o;
     }
-    dim3 grid(cdiv(N, 32), tracks);
-    hipLaunchKernelGGL(nade_fwd_mfma_kernel, grid, dim3(256), sizeof(NadeFwdSmem), (hipStream_t)s, tracks, N, D, v, v_track_stride, bias, ld_bias,
-                       w_enc, (const bf16_t*)w_dec_bf16, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
+}
+extern "C" int mnn_nade_split_pack(mnn_stream_t s, const float* w_dec, long rows, int Hn, void* out) {
+    MNN_REQUIRE(w_dec && out && rows > 0 && Hn > 0 && Hn % 4 == 0, "mnn_nade_split_pack: bad arguments");
+    MNN_REQUIRE(((uintptr_t)w_dec & 15) == 0 && ((uintptr_t)out & 15) == 0, "mnn_nade_split_pack: buffers must be 16-byte aligned");
+    const long groups = rows * (Hn / 4);
+    hipLaunchKernelGGL(nade_split_pack_kernel, dim3((int)std::min(2048L, (groups + 255) / 256)), dim3(256), 0, (hipStream_t)s, w_dec, groups, (uint4*)out);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
