@@ -163,6 +163,16 @@ def evaluate(generator, X, lengths, batch_size, piece_size, device=None):
     return tot / max(cnt, 1)
 
 
+def check_recurrences(model):
+    """Raise if any persistent-recurrence launch of the model's LSTM stacks timed out on a bounded spin since the last check (its sticky
+    status word: LstmStack.check / MultINNCore.check; synchronises the device).  The launches of lstm_persist.hip / lstm_rowpar.hip need
+    their whole grid resident at once; one that could not become resident returns garbage and only sets that word."""
+    if hasattr(model, "check"):
+        model.check()
+    elif getattr(model, "_stack", None) is not None:
+        model._stack.check()
+
+
 def fit(generator, optimizer, X_train, len_train, X_valid, len_valid, training_config, logs_config, dirs, stats=None, beat_size=4,
         save_best_only=False, log=print):
     """train.py:150-282: epochs, shuffling (np.random.seed(epoch)), evaluation, best / last checkpoints,
@@ -180,6 +190,7 @@ def fit(generator, optimizer, X_train, len_train, X_valid, len_valid, training_c
         np.random.shuffle(ids)
         acc.clear()
         train_epoch(generator, X_train, len_train, ids, batch_size, piece_size, optimizer, acc, stats, training_config.get("learning_rate"))
+        check_recurrences(generator)            # a persistent launch that gave up would have trained on garbage: raise before validating / saving
         loglik_val = evaluate(generator, X_valid, len_valid, batch_size, piece_size) if logs_config.get("evaluate_epochs", 1) else acc.loss()
         log(f" epoch: {epoch:3d} (steps: {stats.steps:5d}) time: {time.time() - t0:.2f}s{acc} valid nll: {loglik_val:.4f}")
         if loglik_val < stats.metric_best:
@@ -193,6 +204,7 @@ def fit(generator, optimizer, X_train, len_train, X_valid, len_valid, training_c
             if stats.idle_epochs >= training_config["early_stopping"]:
                 log(f"[WARN]  No improvement after {training_config['early_stopping']} epochs, quiting")
                 break
+    check_recurrences(generator)
     if not save_best_only:
         generator.save(None, dirs["model_last_dir"], global_step=stats.steps)
         stats.save(os.path.join(dirs["model_last_dir"], "steps"))
@@ -266,7 +278,8 @@ def main(argv=None):
     ap.add_argument("--encoders", default=None)
     ap.add_argument("--save-best-only", action="store_true")
     ap.add_argument("--reuse-config", action="store_true")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32"],
+                    help="fp16: IEEE-half operands, the mode that meets the 1e-4 parity gate at full speed; bf16; fp32: v_mfma_f32 GEMMs, launch-per-step recurrence")
     a = ap.parse_args(argv)
     from .training import AdamOptimizer
     root = os.path.join("..", "results", a.model_name)                  # utils/setup.py:50

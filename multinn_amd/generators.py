@@ -593,6 +593,11 @@ class RnnEstimator(Generator):
     def steps(self, inputs, initial_state=None):
         return self._get_state(inputs, initial_state=initial_state, last_outputs=True)
 
+    def check(self):
+        """Raise if a persistent recurrence launch of this generator ever gave up on a bounded spin (LstmStack.check)."""
+        if getattr(self, "_stack", None) is not None:
+            self._stack.check()
+
     def _unscale(self, ls):
         """End of a loss-scaled backward pass (LstmStack.loss_scale): gradients and d loss / d inputs back to their true scale."""
         if ls != 1.0:
@@ -1307,6 +1312,13 @@ class RnnRBM(RnnEstimator):
             m = torch.arange(T, device=x.device)[None, :] < self._lengths.to(x.device)[:, None]
             flat = flat[m.reshape(-1)]
         self._materialize(x.shape[-1])
+        if not run_optimizer:
+            # the only caller that passes False (multinn_jamming.py:219-241 without separate losses) discards the CD update ops in favour of
+            # its joint gradient step and keeps the init ops: nothing is applied here
+            return self._rbm.visible_bias_init_ops(flat.contiguous()), [], self.metrics, self.metrics_upd, self.summaries
+        # eager semantics: the CD-k update is APPLIED by this call and update_ops comes back empty, while init_ops are
+        # returned unexecuted (the reference runs them once, before the first update: train_encoders.py:150-153) -- run them BEFORE the first
+        # pretrain() call, not after it, or the first update's visible-bias delta is overwritten
         init_ops, update_ops, self._cd_gradients = self._rbm.train(flat.contiguous(), lr, seed=self.seed + self.store.step, row0=self.row0 * T)
         self._packed_step = -1                          # rbm.bh / rbm.bv feed the packed bias row
         return init_ops, update_ops, self.metrics, self.metrics_upd, self.summaries

@@ -19,6 +19,7 @@ scan.  The encoder-level ("global") metrics the reference adds to the graph but 
 (HIP kernels behind the C ABI); this file only slices, stacks and reshapes device tensors.
 """
 import abc
+import os
 
 import torch
 
@@ -251,11 +252,78 @@ class MultINNCore(Model):
             return True
         return all(e.load(None, ckpt_dir) for e in self._encoders)
 
+    # -- checkpoints (model.py:180-234: ONE tf Saver over uniquely scoped variables) ------------------------------------------------
+    # One file per mode, `{name}.pt`: every generator / encoder / feedback store under its own index (the M per-track generators of the
+    # jamming and feedback modes all carry the default name 'rnn-nade' / 'rnn-rbm': per-model files keyed by name overwrote one another),
+    # parameters AND Adam slots and step counts (R12).  Stores that are only created at the first build (a generator's variables need its
+    # input width, the feedback module is built from the stacked codes) are materialised from the checkpoint's own shapes before loading.
+    def _ckpt_path(self, ckpt_dir):
+        return os.path.join(ckpt_dir, f"{self.name}.pt")
+
+    def _feedback_state(self):
+        fl = getattr(self, "_feedback_layer", None)
+        return None if fl is None or fl.store.theta is None else fl.store.state_dict()
+
     def save(self, sess=None, ckpt_dir=None, global_step=None, write_meta_graph=False):
-        return [m.save(None, ckpt_dir) for m in self._generators + [e for e in self._encoders if e.store is not None]]
+        os.makedirs(ckpt_dir, exist_ok=True)
+        sd = lambda m: None if m.store is None or m.store.theta is None else m.store.state_dict()
+        blob = dict(mode=self._mode, tracks=list(self._tracks), generators=[sd(g) for g in self._generators],
+                    encoders=[sd(e) for e in self._encoders], feedback=self._feedback_state(), global_step=global_step)
+        path = self._ckpt_path(ckpt_dir)
+        torch.save(blob, path)
+        return path
+
+    @staticmethod
+    def _first_kernel_rows(sd, suffix="cell_0/kernel"):
+        for n, shp in zip(sd["names"], sd["shapes"]):
+            if n.endswith(suffix):
+                return int(shp[0]), int(shp[1])
+        raise ValueError("checkpoint holds no variable ending in " + suffix)
 
     def load(self, sess=None, ckpt_dir=None):
-        return all(m.load(None, ckpt_dir) for m in self._generators + [e for e in self._encoders if e.store is not None])
+        path = self._ckpt_path(ckpt_dir)
+        if not os.path.exists(path):
+            return False
+        blob = torch.load(path)
+        if blob.get("mode") != self._mode or list(blob.get("tracks", [])) != list(self._tracks):
+            raise ValueError(f"checkpoint {path} was written by mode {blob.get('mode')!r} / tracks {blob.get('tracks')}, "
+                             f"this model is {self._mode!r} / {self._tracks}")
+        if len(blob["generators"]) != len(self._generators) or len(blob["encoders"]) != len(self._encoders):
+            raise ValueError("checkpoint does not match the model's generators / encoders")
+        for g, sd in zip(self._generators, blob["generators"]):
+            if sd is None:
+                continue
+            if g.store.theta is None:                   # variables are declared at the first build: take the input width from the checkpoint
+                rows, cols = self._first_kernel_rows(sd)
+                g._materialize(rows - cols // 4)
+            g.store.load_state_dict(sd)
+            g._packed_step = -1
+        for e, sd in zip(self._encoders, blob["encoders"]):
+            if sd is not None:
+                e.store.load_state_dict(sd)
+        fb = blob.get("feedback")
+        if fb is not None:
+            if not self._feedback_module:
+                raise ValueError("checkpoint holds a feedback module, this mode has none")
+            if self._feedback_layer is None:
+                rows, cols = self._first_kernel_rows(fb) if any(n.endswith("cell_0/kernel") for n in fb["names"]) \
+                    else self._first_kernel_rows(fb, "dense_0/kernel")
+                n_in = rows - cols // 4 if any(n.endswith("cell_0/kernel") for n in fb["names"]) else rows
+                self._feedback_layer = self._init_feedback(n_in)
+            self._feedback_layer.store.load_state_dict(fb)
+            if hasattr(self._feedback_layer, "_packed_step"):
+                self._feedback_layer._packed_step = -1
+        return True
+
+    def check(self):
+        """Raise if a persistent recurrence launch of any generator (or of the feedback module) ever gave up on a bounded spin: its outputs
+        were garbage (LstmStack.check; synchronises the device).  The driver calls it before every validation pass and checkpoint."""
+        for g in self._generators:
+            if getattr(g, "_stack", None) is not None:
+                g._stack.check()
+        fl = getattr(self, "_feedback_layer", None)
+        if fl is not None and getattr(fl, "_stack", None) is not None:
+            fl._stack.check()
 
     # -- train.py:178-189: one `sess.run([update_ops, loss], feed_dict)` -----------------------------
     def generator_loss(self):
@@ -479,23 +547,42 @@ class MultINNJamming(MultIEncoderNN):
         """Hook between the generators' backward passes and the joint optimiser step (the feedback modes back-propagate into their module)."""
 
     def _train_generators(self, optimizer, lr, pretrain=False, separate_losses=False):
-        """multinn_jamming.py:186-245."""
-        if not pretrain and separate_losses != self.separate_losses:
-            raise ValueError("set `model.separate_losses` before build(): the per-track gradient weight (1/num_tracks for the mean "
-                             "track loss) is applied in the forward pass")
+        """multinn_jamming.py:186-245.  Per generator: `pretrain` / `train` with run_optimizer = separate_losses; then, whenever NOT
+        separate_losses -- pre-training included (:235: the reference replaces the collected update ops by the joint gradient step, so a
+        pre-training call without separate losses is the visible-bias init ops plus an ordinary step on the mean track loss) -- ONE clipped
+        step on the mean track loss over all generators' (and the feedback module's) variables.  The per-track weight of that mean (1/M) is
+        applied to the gradient seed at build time from `self.separate_losses`; an argument that differs from the attribute is honoured by
+        rescaling the finished gradients (everything downstream of the seed is linear in it)."""
+        M = self.num_tracks
+        built_scale = 1.0 if self.separate_losses else 1.0 / M
+        want_scale = 1.0 if separate_losses else 1.0 / M
         init_ops, update_ops, tm, tu, ts = [], [], [], [], []
-        for i in range(self.num_tracks):
-            fn = self.generators[i].pretrain if pretrain else self.generators[i].train
-            io, uo, m, mu, s = fn(optimizer, lr, run_optimizer=separate_losses)
+        for i, g in enumerate(self.generators):
+            if pretrain:
+                io, uo, m, mu, s = g.pretrain(optimizer, lr, run_optimizer=separate_losses)
+                if not separate_losses:
+                    g.backward()                    # the joint step below differentiates the same batch/loss
+            else:
+                io, uo, m, mu, s = g.train(optimizer, lr, run_optimizer=False)           # backward only
+            if (not pretrain or not separate_losses) and want_scale != built_scale:
+                r = want_scale / built_scale
+                ops.axpby(r, g.store.grad, 0.0, None, g.store.grad)
+                if g._dx is not None:
+                    ops.axpby(r, g._dx.view(-1), 0.0, None, g._dx.view(-1))
+            if separate_losses and not pretrain:        # generator.py:199-205: each generator's own clipped step
+                from .training import compute_gradients
+                g._grad_sumsq = compute_gradients(optimizer, g.store, g.clip_norm, lr)
+                g._packed_step = -1
             init_ops += io; update_ops += uo
             tm.append(m); tu.append(mu); ts.append(s or {})
         metrics, metrics_upd, summaries = self._combine_track_metrics(tm, tu, ts, global_scope=f"metrics/{self.generators[0].name}/global/")
-        if not separate_losses and not pretrain:
+        if not separate_losses:
             self._backward_extra()
             stores = [g.store for g in self.generators] + self._extra_stores()
             self._grad_sumsq = compute_gradients_multi(optimizer, stores, self.clip_norm, lr)
             for g in self.generators:
                 g._packed_step = -1
+            update_ops = []                         # multinn_jamming.py:237: the joint step REPLACES the collected update ops (it has run)
         return init_ops, update_ops, metrics, metrics_upd, summaries
 
 

@@ -211,8 +211,22 @@ def test_c3_jamming_five_lstm_rbm_cd10():
     assert {"batch/loss", "log_likelihood", "accuracy"} <= set(glob.keys())
     out = m.generate(3)
     assert out.shape == (B, 3, P, M) and out.dtype == torch.uint8
-    with pytest.raises(ValueError):
-        m.train_generators(AdamOptimizer(0.01), 0.01, separate_losses=True)      # the track weight is applied in the forward pass
+    # `separate_losses` passed to train_generators is honoured even when it differs from the attribute the batch was built with
+    # (multinn_jamming.py:213-221: run_optimizer = separate_losses): every generator then steps on ITS OWN loss, gradient g_i instead of g_i / M
+    m.build(dev(x), lengths=None, is_train=True, mode="train")
+    opt0 = AdamOptimizer(0.0)                                            # zero step size: the weights stay put between the two calls
+    mean_grads = []
+    for g in m.generators:                                               # built for the mean track loss: d (L_i / M)
+        g.backward()
+        mean_grads.append(g.store.grad.clone())
+    m.train_generators(opt0, 0.0, separate_losses=True)
+    for g, r in zip(m.generators, mean_grads):
+        assert float((g.store.grad - M * r).abs().max()) <= 1e-4 * float((M * r).abs().max())
+    # pre-training without separate losses = init ops + the joint step on the mean track loss (multinn_jamming.py:235-241 runs for both)
+    m.build(dev(x), lengths=None, is_train=True, mode="train")
+    steps = [g.store.step for g in m.generators]
+    init_ops, update_ops, _, _, _ = m.pretrain_generators(opt0, 0.0)
+    assert len(init_ops) == M and update_ops == [] and [g.store.step for g in m.generators] == [s_ + 1 for s_ in steps]
 
 
 def test_c4_composer_dbn_encoders_multinade():
@@ -453,3 +467,47 @@ def test_feedback_modes_train_step_vs_oracle(mode):
         m.build(dev(x), lengths=None, is_train=True, mode="train")
         _, _, metrics, _, _ = m.train_generators(AdamOptimizer(0.01), 0.01)
     assert float(metrics["batch/loss"]) < before
+
+
+@pytest.mark.parametrize("mode,enc,gen", [("jamming", "DBN", "RBM"), ("feedback-rnn", "Pass", "NADE"), ("feedback", "DBN", "NADE"),
+                                          ("composer", "DBN", "NADE"), ("joint", "Pass", "NADE")])
+def test_mode_checkpoint_round_trip(mode, enc, gen, tmp_path):
+    """model.py:180-234 through a MODE: save after a few optimiser steps, load into a FRESH model before it has seen a batch (the driver's
+    resume order: build_model, load, fit), and find every store bit-equal -- parameters, both Adam slots and the step count of every
+    per-track generator (they all carry the same default name), of every per-track DBN encoder and of the feedback module, whose variables
+    only exist after the first build.  Then the two models take the same next step."""
+    from multinn_amd import MultINN, AdamOptimizer
+    B, T, P, M = 4, 5, 12, 5
+    x = dev(batch(B, T, P, M, 12))
+    kw = dict(enc=enc, enc_hidden=[10, 8] if enc == "DBN" else None, gen=gen, Hn=16, units=[32, 32],
+              feedback=[32] if mode.startswith("feedback") else None)
+    a = MultINN(config(P, TRACKS5), params(mode, **kw), mode=mode, precision="fp32")
+    opt = AdamOptimizer(0.01)
+    for _ in range(2):
+        a.train_step(x, None, opt)
+    path = a.save(None, str(tmp_path), global_step=2)
+    assert path.endswith(".pt") and len(list(tmp_path.iterdir())) == 1          # ONE file: no per-model files overwriting one another
+    b = MultINN(config(P, TRACKS5), params(mode, **kw), mode=mode, precision="fp32")
+    for e in b.encoders:                            # the stores that exist before the first build must really be overwritten by load()
+        if getattr(e, "store", None) is not None and e.store.theta is not None:
+            e.store.theta.add_(1.0)
+    assert all(g.store.theta is None for g in b.generators)          # the generators' variables do not exist yet: load() declares them
+    assert b.load(None, str(tmp_path)) is True
+    assert MultINN(config(P, TRACKS5), params(mode, **kw), mode=mode, precision="fp32").load(None, str(tmp_path / "nowhere")) is False
+
+    def stores(m):
+        out = [g.store for g in m.generators] + [e.store for e in m.encoders if getattr(e, "store", None) is not None and e.store.theta is not None]
+        fl = getattr(m, "_feedback_layer", None)
+        return out + ([fl.store] if fl is not None else [])
+    sa, sb = stores(a), stores(b)
+    assert len(sa) == len(sb) and len(sa) >= len(a.generators) + (1 if mode.startswith("feedback") else 0)
+    for p_, q_ in zip(sa, sb):
+        assert p_.names() == q_.names() and p_.step == q_.step and int(q_.step_dev) == q_.step
+        assert torch.equal(p_.theta, q_.theta) and torch.equal(p_.m, q_.m) and torch.equal(p_.v, q_.v)
+    la = float(a.train_step(x, None, opt))
+    lb = float(b.train_step(x, None, opt))
+    assert abs(la - lb) <= 1e-4 * max(1.0, abs(la)), (la, lb)
+    b.check()
+    with pytest.raises(ValueError):
+        other = "joint" if mode != "joint" else "jamming"
+        MultINN(config(P, TRACKS5), params(other, gen="NADE", Hn=16, units=[32, 32]), mode=other, precision="fp32").load(None, str(tmp_path))
