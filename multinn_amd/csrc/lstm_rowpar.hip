@@ -42,7 +42,8 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 #define RP_LDS_FENCE() asm volatile("" ::: "memory")
 // Behind the hand-off stores: rp_wait_all_but(N) counts the vector-memory operations written AFTER them in the source, so neither the
 // scheduler nor the memory-dependence analysis may move one of those above the hand-off (vmcnt retires in issue order)
-#define RP_HANDOFF_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
+// (the marker comment lets tests/test_build_guards.py find the fence in the compiler's output)
+#define RP_HANDOFF_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("; RP_HANDOFF_FENCE" ::: "memory"); } while (0)
 
 #ifdef RP_TRACE     // development only (profiles/tools/rowpar_trace.py): wall-clock stamps of one wave per kernel, [direction][step][stage]
 __device__ long long rp_trace[2][512][12];

@@ -337,6 +337,45 @@ class MultINNCore(Model):
         self.train_generators(optimizer, lr)
         return self.generator_loss()
 
+    def _all_stores(self):
+        out = [g.store for g in self._generators]
+        fl = getattr(self, "_feedback_layer", None)
+        return out + ([fl.store] if fl is not None else [])
+
+    def graphed_train_step(self, x, optimizer, lr=None, warmup=2):
+        """`train_step` on full-length batches as ONE hipGraph replay (single rank): encoders, every generator's build and backward, the
+        feedback module and the joint clipped step -- eagerly a mode's step is host-bound (five generators: ~200 launches and the Python
+        between them).  Step-dependent values (dropout / Gibbs seeds, Adam's step) are read from each store's device-side counter, so every
+        replay is the next step.  Returns run(x=None) -> loss."""
+        from .training import dp_active
+        if dp_active():
+            raise NotImplementedError("graphed_train_step of a mode is single-rank (the generators' own captured steps handle data parallelism)")
+        sx = x.clone()
+        cur, side = torch.cuda.current_stream(), torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(max(int(warmup), 1)):        # >= 1: variables, persistent-kernel attributes and workspaces exist before the capture
+                self.train_step(sx, None, optimizer, lr)
+        cur.wait_stream(side)
+        for g in self._generators:
+            g._packed_step = -1
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = self.train_step(sx, None, optimizer, lr)
+        stores = self._all_stores()
+        for st in stores:
+            st.step -= 1                                # the captured step has not executed (host mirror of step_dev)
+
+        def run(x=None):
+            if x is not None:
+                sx.copy_(x)
+            graph.replay()
+            for st in stores:
+                st.step += 1
+            return loss
+        run.graph = graph
+        return run
+
     def build_pianoroll(self, x, lengths=None, is_train=False, mode="eval"):
         """The driver's evaluation entry (same name as RnnNade.build_pianoroll)."""
         self.build(x, lengths=lengths, is_train=is_train, mode=mode)

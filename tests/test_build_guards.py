@@ -23,5 +23,24 @@ def test_rowpar_kernels_use_no_scratch_memory(tmp_path):
     sizes = {m.group(1): int(m.group(2))
              for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text)}
     kernels = {k: v for k, v in sizes.items() if "lstm_rowpar_" in k and "kernel" in k}
-    assert len(kernels) >= 12, sizes                      # three widths x forward / backward x (one wave | a wave pair) per item
+    assert len(kernels) >= 36, sizes        # three widths x forward (f32 | 16-bit xproj) / backward x (one wave | a wave pair) x (bf16 | f16)
     assert all(v == 0 for v in kernels.values()), kernels
+    # The flag of a hand-off waits with `s_waitcnt vmcnt(N)`, N = the vector-memory operations WRITTEN BEHIND the hand-off stores in the
+    # source.  That only covers the tile if the compiler keeps them behind: RP_HANDOFF_FENCE (sched_barrier + memory clobber) sits right
+    # behind the hand-off stores and leaves a marker.  In every kernel, between the marker and the closest vector-memory instruction in
+    # front of it there must be nothing but the hand-off's own 16-byte buffer stores.
+    bodies = re.split(r"\n(?=_Z\w*lstm_rowpar_\w+:)", text)
+    checked = 0
+    for body in bodies:
+        if not re.match(r"_Z\w*lstm_rowpar_(fwd|bwd)", body):
+            continue
+        lines = body.split("\n")
+        marks = [i for i, ln in enumerate(lines) if "RP_HANDOFF_FENCE" in ln]
+        assert len(marks) >= 1, body[:80]
+        for i in marks:
+            j = i - 1
+            while j >= 0 and not re.search(r"\b(global_load|global_store|global_atomic|buffer_load|buffer_store|flat_load|flat_store|scratch_)", lines[j]):
+                j -= 1
+            assert j >= 0 and "buffer_store_dwordx4" in lines[j], (body[:60], lines[j] if j >= 0 else None)
+            checked += 1
+    assert checked >= 36, checked
