@@ -438,9 +438,13 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
                                 if (lane + 64 * q < Hn) dst[64 * q] = sum[q];
                         } else {
                             float* dst = (which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * HnT + hb + lane;
+#ifdef NADE_BWD_NO_ATOMIC       // development only (timing the scan without its f32 atomics: results are wrong)
+                            if (sum[0] == 1.2345e30f) dst[0] = sum[0];
+#else
 #pragma unroll
                             for (int q = 0; q < HQ; ++q)
                                 if (lane + 64 * q < Hn) atomicAdd(dst + 64 * q, sum[q]);
+#endif
                         }
                     }
                 }

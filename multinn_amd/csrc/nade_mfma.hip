@@ -49,11 +49,11 @@ __device__ __forceinline__ float nm_ln(float x) { return __builtin_amdgcn_logf(x
 // extra passes are free; what is paid is twice the LDS bytes per A fragment.  w_dec comes pre-split ([d][4-unit group][hi x4 | lo x4]).
 template <bool SPLIT> struct NmState;
 template <> struct NmState<false> { typedef bf16_t T; static constexpr int PITCH = NM_PITCH; static constexpr int KS = 8; };
-template <> struct NmState<true> { typedef uint32_t T; static constexpr int PITCH = 260; static constexpr int KS = 16; };    // 260 words: rows 4 banks apart
+template <> struct NmState<true> { typedef uint32_t T; static constexpr int PITCH = 260; static constexpr int KS = 8; };    // 260 words: rows 4 banks apart
 
 template <bool SPLIT>
 struct NadeFwdSmemT {
-    float sA[32][NM_H];                 // pre-activations a[row][hidden] (f32; thread = hidden unit owns a column)
+    float sA[SPLIT ? 1 : 32][NM_H];     // pre-activations a[row][hidden] (f32; thread = hidden unit owns a column); split form: in registers
     typename NmState<SPLIT>::T sH[32][NmState<SPLIT>::PITCH];            // current state of every row (as of the tile being processed)
     typename NmState<SPLIT>::T sF[32][NmState<SPLIT>::PITCH];            // states created by the flips of the tile (one chunk of 32 slots)
     float sLb[32][NM_LP];               // logits of the base states  [row][column]
@@ -71,12 +71,6 @@ __device__ __forceinline__ void nm_load_a(const bf16_t (*tile)[NM_PITCH], int mi
 #pragma unroll
     for (int s = 0; s < 8; ++s) a[s] = *reinterpret_cast<const bf16x8_t*>(p + 32 * s);
 }
-// split form: k-step s covers hidden units 16 s + 4 (l >> 4) .. + 3, each as the (hi, lo) pair of its state word
-__device__ __forceinline__ void nm_load_a(const uint32_t (*tile)[260], int mi, int lane, bf16x8_t (&a)[16]) {
-    const uint32_t* p = &tile[16 * mi + (lane & 15)][4 * (lane >> 4)];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) a[s] = *reinterpret_cast<const bf16x8_t*>(p + 16 * s);
-}
 __device__ __forceinline__ uint32_t nm_split(float x) {           // hi | lo << 16
     const uint32_t hi = (uint32_t)f32_to_bf16(x);
     return hi | ((uint32_t)f32_to_bf16(x - __uint_as_float(hi << 16)) << 16);
@@ -92,28 +86,70 @@ __device__ __forceinline__ f32x4_t nm_dot(const bf16x8_t (&af)[8], const bf16x8_
     for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], bfr[s], acc, 0, 0, 0);
     return acc;
 }
-__device__ __forceinline__ f32x4_t nm_dot(const bf16x8_t (&af)[16], const uint4 (&bw)[16]) {
-    // bw[s] = hi(u0,u1) hi(u2,u3) lo(u0,u1) lo(u2,u3) of the step's four units: every 16-bit weight doubled into the slot pair of its unit
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+// split form: a wave owns 16 columns x ONE HALF of K (hidden units 128 kh .. 128 kh + 127) for BOTH 16-row tiles -- its decoder fragments are then
+// 32 registers instead of 64 (the kernel must stay under 256 to run two workgroups per CU); the two K halves of a logit meet in LDS (two
+// partial tiles, summed by the thread that reads them: a fixed order, so the result stays bit-deterministic).  The A fragments come from LDS
+// in groups of four k-steps; each 16-bit weight is doubled into the slot pair (hi, lo) of its hidden unit.
+__device__ __forceinline__ void nm_dot_split(const uint32_t (*tile)[260], int kh, int lane, const uint4 (&bw)[8], f32x4_t& acc0, f32x4_t& acc1) {
+    // both 16-row tiles at once: the doubled weight fragments are built once per k-step and feed two independent accumulator chains
+    const uint32_t* p0 = &tile[(lane & 15)][128 * kh + 4 * (lane >> 4)];
+    const uint32_t* p1 = &tile[16 + (lane & 15)][128 * kh + 4 * (lane >> 4)];
+    acc0 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    acc1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        uint4 b1, b2;
-        b1.x = __builtin_amdgcn_perm(bw[s].x, bw[s].x, 0x01000100u); b1.y = __builtin_amdgcn_perm(bw[s].x, bw[s].x, 0x03020302u);
-        b1.z = __builtin_amdgcn_perm(bw[s].y, bw[s].y, 0x01000100u); b1.w = __builtin_amdgcn_perm(bw[s].y, bw[s].y, 0x03020302u);
-        b2.x = __builtin_amdgcn_perm(bw[s].z, bw[s].z, 0x01000100u); b2.y = __builtin_amdgcn_perm(bw[s].z, bw[s].z, 0x03020302u);
-        b2.z = __builtin_amdgcn_perm(bw[s].w, bw[s].w, 0x01000100u); b2.w = __builtin_amdgcn_perm(bw[s].w, bw[s].w, 0x03020302u);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], __builtin_bit_cast(bf16x8_t, b1), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], __builtin_bit_cast(bf16x8_t, b2), acc, 0, 0, 0);
+    for (int g = 0; g < 4; ++g) {
+        bf16x8_t a0[2], a1[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            a0[s] = *reinterpret_cast<const bf16x8_t*>(p0 + 16 * (2 * g + s));
+            a1[s] = *reinterpret_cast<const bf16x8_t*>(p1 + 16 * (2 * g + s));
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int s = 2 * g + s2;
+            uint4 b1, b2;       // bw[s] = hi(u0,u1) hi(u2,u3) lo(u0,u1) lo(u2,u3) of the step's four units
+            b1.x = __builtin_amdgcn_perm(bw[s].x, bw[s].x, 0x01000100u); b1.y = __builtin_amdgcn_perm(bw[s].x, bw[s].x, 0x03020302u);
+            b1.z = __builtin_amdgcn_perm(bw[s].y, bw[s].y, 0x01000100u); b1.w = __builtin_amdgcn_perm(bw[s].y, bw[s].y, 0x03020302u);
+            b2.x = __builtin_amdgcn_perm(bw[s].z, bw[s].z, 0x01000100u); b2.y = __builtin_amdgcn_perm(bw[s].z, bw[s].z, 0x03020302u);
+            b2.z = __builtin_amdgcn_perm(bw[s].w, bw[s].w, 0x01000100u); b2.w = __builtin_amdgcn_perm(bw[s].w, bw[s].w, 0x03020302u);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[s2], __builtin_bit_cast(bf16x8_t, b1), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[s2], __builtin_bit_cast(bf16x8_t, b1), acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[s2], __builtin_bit_cast(bf16x8_t, b2), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[s2], __builtin_bit_cast(bf16x8_t, b2), acc1, 0, 0, 0);
+        }
     }
-    return acc;
+}
+// One 32 x 32 logit tile of a state tile.  Non-split: wave (mi, ni) = w & 1, w >> 1 writes its 16 x 16 quadrant to out0.  Split: wave
+// (kh, ni) = w & 1, w >> 1 writes its K half of both 16-row tiles to out0 (kh = 0) / out1 (kh = 1).
+template <bool SPLIT, typename Tile, typename B>
+__device__ __forceinline__ void nm_logit_tile(const Tile& tile, int w, int lane, const B& bfr, float (*out0)[NM_LP], float (*out1)[NM_LP]) {
+    const int ni = w >> 1;
+    if constexpr (SPLIT) {
+        const int kh = w & 1;
+        float (*out)[NM_LP] = kh ? out1 : out0;
+        f32x4_t acc0, acc1;
+        nm_dot_split(tile, kh, lane, bfr, acc0, acc1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            out[4 * (lane >> 4) + i][16 * ni + (lane & 15)] = acc0[i];
+            out[16 + 4 * (lane >> 4) + i][16 * ni + (lane & 15)] = acc1[i];
+        }
+    } else {
+        const int mi = w & 1;
+        bf16x8_t af[8];
+        nm_load_a(tile, mi, lane, af);
+        const f32x4_t acc = nm_dot(af, bfr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out0[16 * mi + 4 * (lane >> 4) + i][16 * ni + (lane & 15)] = acc[i];
+    }
 }
 
 // thread = hidden unit: the 32 rows' pre-activations a[32] live in registers and are indexed by the (wave-uniform) row of
 // each flip -- the compiler lowers that to s_set_gpr_idx, no scratch.  Per flip the VALU does one add, one sigmoid,
 // one bf16 convert and two LDS writes; everything it needs (the flip list, the flips' w_enc values) was fetched a tile ahead.
 template <bool SPLIT>
-__global__ void __launch_bounds__(256)
-nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias, int ld_bias,
+__device__ __forceinline__ void
+nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias, int ld_bias,
                      const float* __restrict__ w_enc, const bf16_t* __restrict__ w_dec_bf, const float* __restrict__ row_weight,
                      float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias, float* __restrict__ a_final,
                      const int* __restrict__ gate, int run_if) {
@@ -127,7 +163,7 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
     constexpr int Hn = NM_H;
     const int m = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mi = w & 1, ni = w >> 1;                       // this wave's 16 x 16 quadrant of a 32 x 32 logit tile
+    const int ni = w >> 1;                                   // this wave's column half of a 32 x 32 logit tile (w & 1: its row half / K half)
     const int rb = blockIdx.x * 32;
     const uint8_t* __restrict__ vm = v + (size_t)m * v_track_stride;
     const float* __restrict__ we = w_enc + (size_t)m * D * Hn;
@@ -135,11 +171,16 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
     const int bd_off = tracks * Hn + m * D;
     const int ntile = (D + 31) / 32;
 
-#pragma unroll 4
+    // split form: the pre-activations of this thread's hidden unit for the 32 rows live in REGISTERS, indexed by the wave-uniform row of each
+    // flip (indirect register addressing); that frees 32 KiB of LDS (two workgroups per CU with the doubled state tiles) and takes the
+    // LDS round trip out of every flip's read-modify-write
+    float areg[SPLIT ? 32 : 1];
+#pragma unroll
     for (int n = 0; n < 32; ++n) {
         const int row = rb + n;
         const float av = row < N ? bias[(size_t)row * ld_bias + m * Hn + tid] : 0.f;
-        S.sA[n][tid] = av;
+        if constexpr (SPLIT) areg[n] = av;
+        else S.sA[n][tid] = av;
         S.sH[n][tid] = nm_state<SPLIT>(fast_sigmoid(av));
     }
     // v bytes of rows 8w .. 8w+7 of a tile: lane -> (row 8w + 2i + (lane >> 5), column lane & 31)
@@ -184,8 +225,8 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
     };
     auto load_b = [&](int c, bfrag_t (&b)[KS]) {            // lane: column l & 15 of the wave's column half, k = 32 s + 8 (l >> 4) + j
         const int d = min(32 * c + 16 * ni + (lane & 15), D - 1);
-        if constexpr (SPLIT) {                                // [d][4-unit group 4 s + (l >> 4)][hi x4 | lo x4]: 16 bytes per k-step
-            const bf16_t* p = wd + (size_t)d * 2 * Hn + 8 * (lane >> 4);
+        if constexpr (SPLIT) {                                // [d][4-unit group][hi x4 | lo x4]: 16 bytes per k-step; this wave's K half (w & 1)
+            const bf16_t* p = wd + (size_t)d * 2 * Hn + 256 * (w & 1) + 8 * (lane >> 4);
 #pragma unroll
             for (int s = 0; s < KS; ++s) b[s] = *reinterpret_cast<const uint4*>(p + 32 * s);
         } else {
@@ -197,13 +238,17 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
     // w_enc[column of flip k0+u][this hidden unit] for the 32 flips of a chunk (entries past the tile's count re-read flip 0's row)
     auto load_we = [&](int c, int buf, int k0, float (&wv)[32]) {
         const int F = (int)S.sSb[buf][32];
-        int ent[32];                                         // all list reads first, then all global loads: nothing serialises on LDS latency
+        constexpr int GR = SPLIT ? 8 : 32;                   // list reads first, then the global loads, per group: nothing serialises on LDS latency
+#pragma unroll                                               // (split form: groups of 8 -- 32 list entries at once do not fit its register budget)
+        for (int u0 = 0; u0 < 32; u0 += GR) {
+            int ent[GR];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) ent[u] = S.sFl[buf][(k0 + u < F) ? k0 + u : 0];
+            for (int u = 0; u < GR; ++u) ent[u] = S.sFl[buf][(k0 + u0 + u < F) ? k0 + u0 + u : 0];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int e = __builtin_amdgcn_readfirstlane(ent[u]);
-            wv[u] = we[(size_t)min(32 * c + (e & 31), D - 1) * Hn + tid];
+            for (int u = 0; u < GR; ++u) {
+                const int e = __builtin_amdgcn_readfirstlane(ent[u]);
+                wv[u0 + u] = we[(size_t)min(32 * c + (e & 31), D - 1) * Hn + tid];
+            }
         }
     };
     unsigned char vb[4];
@@ -233,13 +278,10 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
         float bdec[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) bdec[k] = bias[(size_t)err * ld_bias + bd_off + min(32 * c + ed0 + k, D - 1)];
-        {
-            bf16x8_t af[KS];
-            nm_load_a(S.sH, mi, lane, af);
-            const f32x4_t acc = nm_dot(af, bfr);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) S.sLb[16 * mi + 4 * (lane >> 4) + i][16 * ni + (lane & 15)] = acc[i];
-        }
+        // split form: the two K halves of the base logits go to two partial tiles laid over the (idle) flip-state tile
+        float (*pb0)[NM_LP] = SPLIT ? reinterpret_cast<float (*)[NM_LP]>(&S.sF[0][0]) : S.sLb;
+        float (*pb1)[NM_LP] = SPLIT ? pb0 + 32 : S.sLb;
+        nm_logit_tile<SPLIT>(S.sH, w, lane, bfr, pb0, pb1);
         if (c + 1 < ntile) {
             ballots(c + 1, vb, S.sMask[nbuf]);               // v bytes requested one tile ago
             if (c + 2 < ntile) load_v(c + 2, vb);
@@ -254,7 +296,7 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             jj[k] = __popc(mk & ((1u << (ed0 + k)) - 1u));   // flips of this row strictly before the column
-            lsel[k] = S.sLb[en][ed0 + k];
+            lsel[k] = SPLIT ? pb0[en][ed0 + k] + pb1[en][ed0 + k] : S.sLb[en][ed0 + k];
         }
         int slot_of[4];                                      // slot of the state each pair uses: pass jj-1, rank of the row among that pass's rows
 #pragma unroll
@@ -262,6 +304,7 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
             const int pj = max(jj[k] - 1, 0);
             slot_of[k] = jj[k] > 0 ? (int)S.sPs[buf][pj] + __popc(S.sAct[buf][pj] & ((1u << en) - 1u)) : -1;
         }
+        if (SPLIT && F > 0) lds_barrier();                   // the partial base logits (laid over sF) have been read: the flips may write sF
         for (int k0 = 0; k0 < F; k0 += 32) {
             // ---- S1: the chunk's flips in pass order: a[row] += w_enc[d]; new state -> sF[slot] and the row's current state.
             //      Eight at a time: within a pass the rows are distinct (and ascending), so the eight read-modify-writes of
@@ -280,7 +323,10 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
                     if (indep) {
                         float x[8];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) x[i] = S.sA[n[i]][tid];
+                        for (int i = 0; i < 8; ++i) {
+                            if constexpr (SPLIT) x[i] = areg[n[i]];
+                            else x[i] = S.sA[n[i]][tid];
+                        }
 #pragma unroll
                         for (int i = 0; i < 8; ++i) x[i] += wev[u0 + i];
                         state_t hb[8];
@@ -289,7 +335,8 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             if (u0 + i < cnt) {
-                                S.sA[n[i]][tid] = x[i];
+                                if constexpr (SPLIT) areg[n[i]] = x[i];
+                                else S.sA[n[i]][tid] = x[i];
                                 S.sF[u0 + i][tid] = hb[i];
                                 S.sH[n[i]][tid] = hb[i];
                             }
@@ -298,8 +345,9 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             if (u0 + i < cnt) {
-                                const float av = S.sA[n[i]][tid] + wev[u0 + i];
-                                S.sA[n[i]][tid] = av;
+                                float av;
+                                if constexpr (SPLIT) { av = areg[n[i]] + wev[u0 + i]; areg[n[i]] = av; }
+                                else { av = S.sA[n[i]][tid] + wev[u0 + i]; S.sA[n[i]][tid] = av; }
                                 const state_t hb1 = nm_state<SPLIT>(fast_sigmoid(av));
                                 S.sF[u0 + i][tid] = hb1;
                                 S.sH[n[i]][tid] = hb1;
@@ -314,13 +362,7 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
             lds_barrier();                                 // B2: sF complete (and the next tile's list)
             NM_T(4);
             // ---- S2: flip logits; each pair whose state sits in this chunk picks its logit ----
-            {
-                bf16x8_t af[KS];
-                nm_load_a(S.sF, mi, lane, af);
-                const f32x4_t acc = nm_dot(af, bfr);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) S.sLf[16 * mi + 4 * (lane >> 4) + i][16 * ni + (lane & 15)] = acc[i];
-            }
+            nm_logit_tile<SPLIT>(S.sF, w, lane, bfr, S.sLf, S.sLb);     // split form: K halves in sLf and in sLb (idle: its base logits were read above)
             if (k0 == 0 && F <= 32 && c + 1 < ntile) load_we(c + 1, nbuf, 0, wev);     // behind the MFMAs: the next tile's encoder rows
             NM_T(5);
             lds_barrier();                                 // B3: sLf ready
@@ -328,7 +370,7 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int slot = slot_of[k] - k0;
-                if (slot_of[k] >= 0 && slot >= 0 && slot < 32) lsel[k] = S.sLf[slot][ed0 + k];
+                if (slot_of[k] >= 0 && slot >= 0 && slot < 32) lsel[k] = SPLIT ? S.sLf[slot][ed0 + k] + S.sLb[slot][ed0 + k] : S.sLf[slot][ed0 + k];
             }
         }
         if (F == 0 && c + 1 < ntile) {                       // no flip in this tile: the bookkeeping of the loop body still has to happen
@@ -365,10 +407,30 @@ nade_fwd_mfma_kernel(int tracks, int N, int D, const uint8_t* __restrict__ v, lo
     lp += __shfl_xor(lp, 4);
     if ((tid & 7) == 0 && evalid && nll != nullptr) nll[(size_t)m * N + erow] = -lp;
     if (a_final != nullptr) {
-#pragma unroll 4
+#pragma unroll
         for (int n = 0; n < 32; ++n)
-            if (rb + n < N) a_final[((size_t)m * N + rb + n) * Hn + tid] = S.sA[n][tid];
+            if (rb + n < N) a_final[((size_t)m * N + rb + n) * Hn + tid] = SPLIT ? areg[SPLIT ? n : 0] : S.sA[SPLIT ? 0 : n][tid];
     }
+}
+
+// two entry points over the one body: the split form is held to 256 registers (two workgroups per CU), the bf16 form keeps its own allocation
+template <bool SPLIT> __global__ void nade_fwd_mfma_kernel(int, int, int, const uint8_t*, long, const float*, int, const float*, const bf16_t*, const float*,
+                                                           float*, float*, float*, float*, const int*, int);
+template <>
+__global__ void __launch_bounds__(256)
+nade_fwd_mfma_kernel<false>(int tracks, int N, int D, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias, int ld_bias,
+                            const float* __restrict__ w_enc, const bf16_t* __restrict__ w_dec_bf, const float* __restrict__ row_weight,
+                            float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias, float* __restrict__ a_final,
+                            const int* __restrict__ gate, int run_if) {
+    nade_fwd_mfma_body<false>(tracks, N, D, v, v_track_stride, bias, ld_bias, w_enc, w_dec_bf, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
+}
+template <>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+nade_fwd_mfma_kernel<true>(int tracks, int N, int D, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias, int ld_bias,
+                           const float* __restrict__ w_enc, const bf16_t* __restrict__ w_dec_bf, const float* __restrict__ row_weight,
+                           float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias, float* __restrict__ a_final,
+                           const int* __restrict__ gate, int run_if) {
+    nade_fwd_mfma_body<true>(tracks, N, D, v, v_track_stride, bias, ld_bias, w_enc, w_dec_bf, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
 }
 
 extern "C" int mnn_nade_mfma_ok(int Hn) { return Hn == NM_H ? 1 : 0; }
