@@ -81,8 +81,8 @@ SIGNATURES["mnn_nade_logprob_bwd_ws"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i
 SIGNATURES["mnn_density_gate"] = (_i, [_p, _p, _l, _l, _p, _p])
 SIGNATURES["mnn_nade_logprob_fwd_gated"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i])
 SIGNATURES["mnn_nade_logprob_fwd_mfma_gated"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i])
-SIGNATURES["mnn_nade_logprob_fwd_mfma_split"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i])
-SIGNATURES["mnn_nade_split_pack"] = (_i, [_p, _p, _l, _i, _p])
+SIGNATURES["mnn_nade_logprob_fwd_mfma_f32"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i])
+SIGNATURES["mnn_nade_f32_pack"] = (_i, [_p, _p, _l, _i, _p])
 SIGNATURES["mnn_musical_bar_stats"] = (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p])
 SIGNATURES["mnn_musical_note_stats"] = (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p])
 SIGNATURES["mnn_eval_counts"] = (_i, [_p, _p, _p, _l, _p])

@@ -41,15 +41,16 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 __device__ __forceinline__ float nm_ln(float x) { return __builtin_amdgcn_logf(x) * LN2F; }
 
-// SPLIT (precision "fp16": BASELINE.json's 1e-4 on every conditional): both operands of the decoder dot products carry 16 significant
-// bits as a bf16 pair hi + lo (hi = bf16(x), lo = bf16(x - hi)).  A state element is ONE 32-bit LDS word (hi | lo << 16), so the flip pass
-// still writes one word per (state, hidden unit); a 16-byte A-fragment read is then 4 hidden units x (hi, lo) = 8 k-slots, and it meets
-//   B1 = (w_hi, w_hi) per unit:  (h_hi + h_lo) . w_hi          B2 = (w_lo, w_lo) per unit:  (h_hi + h_lo) . w_lo
-// on v_mfma_f32_16x16x32_bf16: 16 k-steps x 2 MFMAs per 16 x 16 tile instead of 8.  The matrix cores are ~2 % busy in this kernel, so the
-// extra passes are free; what is paid is twice the LDS bytes per A fragment.  w_dec comes pre-split ([d][4-unit group][hi x4 | lo x4]).
+// SPLIT = the EXACT-PRODUCT form (precision "fp16": BASELINE.json's 1e-4 on every conditional, which 8- or 11-bit operands of the decoder dot
+// products miss): hidden states and decoder weights stay f32 and meet on v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulation: the
+// arithmetic of the vector scan, summation order aside).  That instruction runs at 1/16 of the 16-bit rate -- 2 x 2 D Hn flops per row at
+// 157 TFLOP/s are ~0.8 ms of matrix-core time per launch at [1024,256,88,5], overlapped with the other workgroup of the CU -- and a state
+// element is a 32-bit LDS word: the pre-activations move to registers (indirect register addressing) so that two workgroups still fit a CU,
+// a wave owns ONE HALF of K for both 16-row tiles (32 registers of decoder weights instead of 64), the two K halves of a logit meet in LDS.
+// w_dec comes k-permuted from mnn_nade_f32_pack: [d][K half][lane group g][step s] = w_dec[d][128 half + 4 s + g].
 template <bool SPLIT> struct NmState;
-template <> struct NmState<false> { typedef bf16_t T; static constexpr int PITCH = NM_PITCH; static constexpr int KS = 8; };
-template <> struct NmState<true> { typedef uint32_t T; static constexpr int PITCH = 260; static constexpr int KS = 8; };    // 260 words: rows 4 banks apart
+template <> struct NmState<false> { typedef bf16_t T; static constexpr int PITCH = NM_PITCH; };
+template <> struct NmState<true> { typedef float T; static constexpr int PITCH = 260; };     // 260 words: rows 4 banks apart
 
 template <bool SPLIT>
 struct NadeFwdSmemT {
@@ -71,12 +72,8 @@ __device__ __forceinline__ void nm_load_a(const bf16_t (*tile)[NM_PITCH], int mi
 #pragma unroll
     for (int s = 0; s < 8; ++s) a[s] = *reinterpret_cast<const bf16x8_t*>(p + 32 * s);
 }
-__device__ __forceinline__ uint32_t nm_split(float x) {           // hi | lo << 16
-    const uint32_t hi = (uint32_t)f32_to_bf16(x);
-    return hi | ((uint32_t)f32_to_bf16(x - __uint_as_float(hi << 16)) << 16);
-}
 template <bool SPLIT> __device__ __forceinline__ typename NmState<SPLIT>::T nm_state(float h) {
-    if constexpr (SPLIT) return nm_split(h);
+    if constexpr (SPLIT) return h;
     else return f32_to_bf16(h);
 }
 // 16 x 16 logits of one state tile against the tile's decoder rows
@@ -86,36 +83,23 @@ __device__ __forceinline__ f32x4_t nm_dot(const bf16x8_t (&af)[8], const bf16x8_
     for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], bfr[s], acc, 0, 0, 0);
     return acc;
 }
-// split form: a wave owns 16 columns x ONE HALF of K (hidden units 128 kh .. 128 kh + 127) for BOTH 16-row tiles -- its decoder fragments are then
-// 32 registers instead of 64 (the kernel must stay under 256 to run two workgroups per CU); the two K halves of a logit meet in LDS (two
-// partial tiles, summed by the thread that reads them: a fixed order, so the result stays bit-deterministic).  The A fragments come from LDS
-// in groups of four k-steps; each 16-bit weight is doubled into the slot pair (hi, lo) of its hidden unit.
-__device__ __forceinline__ void nm_dot_split(const uint32_t (*tile)[260], int kh, int lane, const uint4 (&bw)[8], f32x4_t& acc0, f32x4_t& acc1) {
-    // both 16-row tiles at once: the doubled weight fragments are built once per k-step and feed two independent accumulator chains
-    const uint32_t* p0 = &tile[(lane & 15)][128 * kh + 4 * (lane >> 4)];
-    const uint32_t* p1 = &tile[16 + (lane & 15)][128 * kh + 4 * (lane >> 4)];
+// exact form: a wave owns 16 columns x ONE HALF of K (hidden units 128 kh .. 128 kh + 127) for BOTH 16-row tiles; k-step s covers hidden units
+// 128 kh + 4 s + (lane >> 4): one f32 per lane and operand.  Two independent accumulator chains (the two row tiles) share the weight registers.
+__device__ __forceinline__ void nm_dot_f32(const float (*tile)[260], int kh, int lane, const float4 (&bw)[8], f32x4_t& acc0, f32x4_t& acc1) {
+    const float* p0 = &tile[(lane & 15)][128 * kh + (lane >> 4)];
+    const float* p1 = &tile[16 + (lane & 15)][128 * kh + (lane >> 4)];
     acc0 = f32x4_t{0.f, 0.f, 0.f, 0.f};
     acc1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        bf16x8_t a0[2], a1[2];
+    for (int g = 0; g < 8; ++g) {
+        float a0[4], a1[4];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            a0[s] = *reinterpret_cast<const bf16x8_t*>(p0 + 16 * (2 * g + s));
-            a1[s] = *reinterpret_cast<const bf16x8_t*>(p1 + 16 * (2 * g + s));
-        }
+        for (int s = 0; s < 4; ++s) { a0[s] = p0[4 * (4 * g + s)]; a1[s] = p1[4 * (4 * g + s)]; }
+        const float b[4] = {bw[g].x, bw[g].y, bw[g].z, bw[g].w};
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int s = 2 * g + s2;
-            uint4 b1, b2;       // bw[s] = hi(u0,u1) hi(u2,u3) lo(u0,u1) lo(u2,u3) of the step's four units
-            b1.x = __builtin_amdgcn_perm(bw[s].x, bw[s].x, 0x01000100u); b1.y = __builtin_amdgcn_perm(bw[s].x, bw[s].x, 0x03020302u);
-            b1.z = __builtin_amdgcn_perm(bw[s].y, bw[s].y, 0x01000100u); b1.w = __builtin_amdgcn_perm(bw[s].y, bw[s].y, 0x03020302u);
-            b2.x = __builtin_amdgcn_perm(bw[s].z, bw[s].z, 0x01000100u); b2.y = __builtin_amdgcn_perm(bw[s].z, bw[s].z, 0x03020302u);
-            b2.z = __builtin_amdgcn_perm(bw[s].w, bw[s].w, 0x01000100u); b2.w = __builtin_amdgcn_perm(bw[s].w, bw[s].w, 0x03020302u);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[s2], __builtin_bit_cast(bf16x8_t, b1), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[s2], __builtin_bit_cast(bf16x8_t, b1), acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[s2], __builtin_bit_cast(bf16x8_t, b2), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[s2], __builtin_bit_cast(bf16x8_t, b2), acc1, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b[s], acc1, 0, 0, 0);
         }
     }
 }
@@ -128,7 +112,7 @@ __device__ __forceinline__ void nm_logit_tile(const Tile& tile, int w, int lane,
         const int kh = w & 1;
         float (*out)[NM_LP] = kh ? out1 : out0;
         f32x4_t acc0, acc1;
-        nm_dot_split(tile, kh, lane, bfr, acc0, acc1);
+        nm_dot_f32(tile, kh, lane, bfr, acc0, acc1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             out[4 * (lane >> 4) + i][16 * ni + (lane & 15)] = acc0[i];
@@ -156,8 +140,8 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     typedef NadeFwdSmemT<SPLIT> NadeFwdSmem;
     typedef typename NmState<SPLIT>::T state_t;
-    typedef typename std::conditional<SPLIT, uint4, bf16x8_t>::type bfrag_t;
-    constexpr int KS = NmState<SPLIT>::KS;
+    typedef typename std::conditional<SPLIT, float4, bf16x8_t>::type bfrag_t;
+    constexpr int KS = 8;                                    // decoder fragments per lane: 8 x 16 bytes in both forms
     NadeFwdSmem& S = *reinterpret_cast<NadeFwdSmem*>(smem_raw);
     if (gate != nullptr && *gate != run_if) return;          // density-gated pair of launches: uniform exit
     constexpr int Hn = NM_H;
@@ -167,7 +151,7 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
     const int rb = blockIdx.x * 32;
     const uint8_t* __restrict__ vm = v + (size_t)m * v_track_stride;
     const float* __restrict__ we = w_enc + (size_t)m * D * Hn;
-    const bf16_t* __restrict__ wd = w_dec_bf + (size_t)m * D * Hn * (SPLIT ? 2 : 1);
+    const bf16_t* __restrict__ wd = w_dec_bf + (size_t)m * D * Hn * (SPLIT ? 2 : 1);        // (exact form: f32 words behind the 16-bit pointer type)
     const int bd_off = tracks * Hn + m * D;
     const int ntile = (D + 31) / 32;
 
@@ -225,10 +209,10 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
     };
     auto load_b = [&](int c, bfrag_t (&b)[KS]) {            // lane: column l & 15 of the wave's column half, k = 32 s + 8 (l >> 4) + j
         const int d = min(32 * c + 16 * ni + (lane & 15), D - 1);
-        if constexpr (SPLIT) {                                // [d][4-unit group][hi x4 | lo x4]: 16 bytes per k-step; this wave's K half (w & 1)
-            const bf16_t* p = wd + (size_t)d * 2 * Hn + 256 * (w & 1) + 8 * (lane >> 4);
+        if constexpr (SPLIT) {                                // [d][K half w & 1][lane group][32 steps]: this lane's 32 weights are 128 contiguous bytes
+            const float* p = reinterpret_cast<const float*>(wd) + (((size_t)d * 2 + (w & 1)) * 4 + (lane >> 4)) * 32;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) b[s] = *reinterpret_cast<const uint4*>(p + 32 * s);
+            for (int s = 0; s < KS; ++s) b[s] = *reinterpret_cast<const float4*>(p + 4 * s);
         } else {
             const bf16_t* p = wd + (size_t)d * Hn + 8 * (lane >> 4);
 #pragma unroll
@@ -472,28 +456,27 @@ extern "C" int mnn_nade_logprob_fwd_mfma_gated(mnn_stream_t s, int tracks, int N
     return nm_launch<false>(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec_bf16, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
 }
 
-extern "C" int mnn_nade_logprob_fwd_mfma_split(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
-                                               const float* bias, int ld_bias, const float* w_enc, const void* w_dec_split, const float* row_weight,
-                                               float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if) {
-    return nm_launch<true>(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec_split, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
+extern "C" int mnn_nade_logprob_fwd_mfma_f32(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
+                                             const float* bias, int ld_bias, const float* w_enc, const void* w_dec_packed, const float* row_weight,
+                                             float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if) {
+    return nm_launch<true>(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec_packed, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
 }
 
-// w_dec f32 [rows, Hn] -> [rows][Hn / 4][hi x4 | lo x4] bf16 (16 bytes per group of four hidden units): the B operand of the split form
-__global__ void __launch_bounds__(256) nade_split_pack_kernel(const float* __restrict__ w, long groups, uint4* __restrict__ out) {
-    for (long g = blockIdx.x * 256L + threadIdx.x; g < groups; g += (long)gridDim.x * 256) {
-        const float4 x = *reinterpret_cast<const float4*>(w + 4 * g);
-        const uint32_t s0 = nm_split(x.x), s1 = nm_split(x.y), s2 = nm_split(x.z), s3 = nm_split(x.w);
-        uint4 o;
-        o.x = (s0 & 0xffffu) | (s1 << 16); o.y = (s2 & 0xffffu) | (s3 << 16);
-        o.z = (s0 >> 16) | (s1 & 0xffff0000u); o.w = (s2 >> 16) | (s3 & 0xffff0000u);
-        out[g] = o;
+// w_dec f32 [rows, Hn] -> [rows][K half][lane group g = 0..3][step s] = w_dec[row][half * Hn / 2 + 4 s + g]: the B operand of the exact form,
+// every lane's Hn / 8 weights of a column contiguous
+__global__ void __launch_bounds__(256) nade_f32_pack_kernel(const float* __restrict__ w, long n, int Hn, float* __restrict__ out) {
+    const int steps = Hn / 8;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const long row = e / Hn;
+        const int o = (int)(e - row * Hn), s = o % steps, g = (o / steps) & 3, half = o / (4 * steps);
+        out[e] = w[row * Hn + half * (Hn / 2) + 4 * s + g];
     }
 }
-extern "C" int mnn_nade_split_pack(mnn_stream_t s, const float* w_dec, long rows, int Hn, void* out) {
-    MNN_REQUIRE(w_dec && out && rows > 0 && Hn > 0 && Hn % 4 == 0, "mnn_nade_split_pack: bad arguments");
-    MNN_REQUIRE(((uintptr_t)w_dec & 15) == 0 && ((uintptr_t)out & 15) == 0, "mnn_nade_split_pack: buffers must be 16-byte aligned");
-    const long groups = rows * (Hn / 4);
-    hipLaunchKernelGGL(nade_split_pack_kernel, dim3((int)std::min(2048L, (groups + 255) / 256)), dim3(256), 0, (hipStream_t)s, w_dec, groups, (uint4*)out);
+extern "C" int mnn_nade_f32_pack(mnn_stream_t s, const float* w_dec, long rows, int Hn, float* out) {
+    MNN_REQUIRE(w_dec && out && rows > 0 && Hn > 0 && Hn % 8 == 0, "mnn_nade_f32_pack: bad arguments (Hn must be a multiple of 8)");
+    MNN_REQUIRE(((uintptr_t)out & 15) == 0, "mnn_nade_f32_pack: the packed buffer must be 16-byte aligned");
+    const long n = rows * Hn;
+    hipLaunchKernelGGL(nade_f32_pack_kernel, dim3((int)std::min(2048L, (n + 255) / 256)), dim3(256), 0, (hipStream_t)s, w_dec, n, Hn, out);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

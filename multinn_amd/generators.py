@@ -757,9 +757,9 @@ class RnnNade(RnnEstimator):
             self._fc_bias = self.store["dense/bias"]
         if self._nade_mfma():                           # 16-bit copy of the decoder weights for the matrix-core NADE kernels
             M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
-            if self._nade_split():                      # fp16 mode: bf16 pairs hi + lo, [hi x4 | lo x4] per group of four hidden units
-                self._wdec_bf = torch.empty((M, D, 2 * Hn), device=dev, dtype=torch.bfloat16)
-                ops.nade_split_pack(self.store["nade/w_dec"].view(M * D, Hn), self._wdec_bf.view(M * D, 2 * Hn))
+            if self._nade_exact():                      # fp16 mode: f32 weights, k-permuted for the exact-product MFMA form
+                self._wdec_bf = torch.empty((M, D, Hn), device=dev, dtype=torch.float32)
+                ops.nade_f32_pack(self.store["nade/w_dec"].view(M * D, Hn), self._wdec_bf.view(M * D, Hn))
             else:
                 self._wdec_bf = torch.empty((M, D, Hn), device=dev, dtype=torch.bfloat16)
                 ops.convert2d(self.store["nade/w_dec"].view(M * D, Hn), self._wdec_bf.view(M * D, Hn))
@@ -779,30 +779,28 @@ class RnnNade(RnnEstimator):
 
     def _nade_fwd(self, v, out, rw, nll, cond_p, d_out, a_fin):
         M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
-        split = self._nade_split()
+        exact = self._nade_exact()
         if self.nade_dense_above >= 1.0:                 # gate off: always the matrix-core form
             return ops.nade_logprob_fwd_auto(v, out, self.store["nade/w_enc"], self.store["nade/w_dec"], self._wdec_bf, M, D, Hn, None, None,
-                                             1.0, rw, nll, cond_p, d_out, a_fin, split=split)
+                                             1.0, rw, nll, cond_p, d_out, a_fin, exact=exact)
         if getattr(self, "_gate", None) is None or self._gate.device != out.device:
             self._gate = torch.zeros(2, device=out.device, dtype=torch.int32)            # [gate, count]
         return ops.nade_logprob_fwd_auto(v, out, self.store["nade/w_enc"], self.store["nade/w_dec"], self._wdec_bf, M, D, Hn, self._gate[:1],
-                                         self._gate[1:], self.nade_dense_above, rw, nll, cond_p, d_out, a_fin, split=split)
+                                         self._gate[1:], self.nade_dense_above, rw, nll, cond_p, d_out, a_fin, exact=exact)
 
-    # fp16 mode: the split-operand matrix-core scan (nade_mfma.hip, SPLIT) needs 113 KB of LDS and 327 registers -- one workgroup per CU, where
-    # the bf16 form runs two: measured 5.4 ms at [1024,256,88,5] against 3.5 ms of the f32 vector scan (and 2.4 ms of the bf16 form).  Until it
-    # fits twice per CU the fp16 mode takes the f32 scan (exact f32 dot products); MULTINN_NADE_SPLIT=1 selects the split form.
-    nade_split = os.environ.get("MULTINN_NADE_SPLIT", "0") != "0"
+    # fp16 mode: the exact-product matrix-core scan (nade_mfma.hip, SPLIT: f32 operands on v_mfma_f32_16x16x4_f32) or the f32 vector scan
+    nade_exact = os.environ.get("MULTINN_NADE_EXACT_MFMA", "1") != "0"
 
     def _nade_mfma(self):
-        """The matrix-core NADE forward is in use: bf16 mode (or fp16 mode with the split form enabled) and a hidden width it covers;
+        """The matrix-core NADE forward is in use: bf16 mode (16-bit operands) or fp16 mode (exact f32 products), and a hidden width it covers;
         otherwise the f32 VALU kernels."""
         if not (self.nade_mfma and ops.nade_mfma_ok(self.num_hidden[-1])):
             return False
-        return self.dtype == torch.bfloat16 or (self.dtype == torch.float16 and self.nade_split)
+        return self.dtype == torch.bfloat16 or (self.dtype == torch.float16 and self.nade_exact)
 
-    def _nade_split(self):
-        """fp16 mode: the matrix-core scan takes both operands as bf16 pairs hi + lo (16 significant bits; BASELINE.json's 1e-4 on every
-        conditional needs more than the 8 / 11 bits of a single bf16 / f16 operand there -- the LSTM / Dense operands do not)."""
+    def _nade_exact(self):
+        """fp16 mode: BASELINE.json's 1e-4 on every conditional needs more than the 8 / 11 bits of a single bf16 / f16 operand in the decoder
+        dot products (the LSTM / Dense operands do not): the matrix-core scan runs on f32 operands there."""
         return self.dtype == torch.float16
 
     # -- forward --------------------------------------------------------------------------------

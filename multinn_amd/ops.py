@@ -429,26 +429,26 @@ def nade_logprob_fwd_mfma(v, bias, w_enc, w_dec_bf, tracks, D, Hn, row_weight=No
          _ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final))
 
 
-def nade_split_pack(w_dec, out):
-    """w_dec f32 [rows, Hn] -> out bf16 [rows, 2*Hn]: per group of four hidden units (hi x4 | lo x4), the decoder operand of the split
-    matrix-core NADE forward (precision "fp16")."""
-    _rowmajor(w_dec, "split_pack w_dec"); _rowmajor(out, "split_pack out")
+def nade_f32_pack(w_dec, out):
+    """w_dec f32 [rows, Hn] -> out f32 [rows, Hn], k-permuted ([K half][lane group][step] = w_dec[row][half Hn/2 + 4 step + group]): the decoder
+    operand of the exact-product matrix-core NADE forward (precision "fp16")."""
+    _rowmajor(w_dec, "f32_pack w_dec"); _rowmajor(out, "f32_pack out")
     rows, Hn = w_dec.shape
-    _req(w_dec.dtype == torch.float32 and w_dec.is_contiguous() and out.dtype == torch.bfloat16 and out.is_contiguous()
-         and out.shape == (rows, 2 * Hn) and Hn % 4 == 0, "split_pack: w_dec f32 [rows,Hn] -> out bf16 [rows,2 Hn]")
-    call("mnn_nade_split_pack", _stream(), _ptr(w_dec), rows, Hn, _ptr(out))
+    _req(w_dec.dtype == torch.float32 and w_dec.is_contiguous() and out.dtype == torch.float32 and out.is_contiguous()
+         and out.shape == (rows, Hn) and Hn % 8 == 0, "f32_pack: w_dec f32 [rows,Hn] -> out f32 [rows,Hn], Hn % 8 == 0")
+    call("mnn_nade_f32_pack", _stream(), _ptr(w_dec), rows, Hn, _ptr(out))
     return out
 
 
 def nade_logprob_fwd_auto(v, bias, w_enc, w_dec, w_dec_bf, tracks, D, Hn, gate, count, dense_above=0.07, row_weight=None, nll=None,
-                          cond_p=None, d_bias=None, a_final=None, split=False):
-    """bf16 compute mode: the matrix-core form of the scan when at most `dense_above` of the cells of v are active, the f32 vector
+                          cond_p=None, d_bias=None, a_final=None, exact=False):
+    """16-bit compute modes (exact=True: the exact-product f32 MFMA form of fp16 mode): the matrix-core form of the scan when at most `dense_above` of the cells of v are active, the f32 vector
     form otherwise; decided on the device (mnn_density_gate), both launches issued (one returns at once).  gate int32[1], count: a zeroed
     int32[1] scratch word (left zero)."""
     N = bias.shape[0]
     _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)
-    _req(w_dec_bf.dtype == torch.bfloat16 and w_dec_bf.is_contiguous() and w_dec_bf.numel() == tracks * D * Hn * (2 if split else 1),
-         "nade auto: w_dec_bf bf16 [tracks,D,Hn] (split: the [tracks,D,2 Hn] output of nade_split_pack)")
+    _req(w_dec_bf.dtype == (torch.float32 if exact else torch.bfloat16) and w_dec_bf.is_contiguous() and w_dec_bf.numel() == tracks * D * Hn,
+         "nade auto: w_dec_bf bf16 [tracks,D,Hn] (exact form: the f32 [tracks,D,Hn] output of nade_f32_pack)")
     _req(gate is None or (gate.dtype == torch.int32 and gate.numel() == 1 and count.dtype == torch.int32 and count.numel() == 1), "nade auto: gate / count int32[1]")
     for t, n in ((nll, tracks * N), (cond_p, tracks * N * D), (a_final, tracks * N * Hn)):
         _req(t is None or (t.dtype == torch.float32 and t.numel() == n and t.is_contiguous()), "nade auto: f32 outputs")
@@ -459,7 +459,7 @@ def nade_logprob_fwd_auto(v, bias, w_enc, w_dec, w_dec_bf, tracks, D, Hn, gate, 
         _req(row_weight.dtype == torch.float32 and row_weight.numel() == N, "nade: row_weight f32 [N]")
     common = (tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc))
     tail = (_ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final), _ptr(gate))
-    mfma = "mnn_nade_logprob_fwd_mfma_split" if split else "mnn_nade_logprob_fwd_mfma_gated"
+    mfma = "mnn_nade_logprob_fwd_mfma_f32" if exact else "mnn_nade_logprob_fwd_mfma_gated"
     if gate is None:                                # gate off: always the matrix-core form
         call(mfma, _stream(), *common, _ptr(w_dec_bf), *tail, 0)
         return

@@ -403,10 +403,10 @@ def test_nade_mfma_forward_matches_f32_kernel(ops, N, D, tracks, rho):
 
 
 @pytest.mark.parametrize("N,D,tracks,rho", [(70, 100, 1, 0.05), (96, 440, 1, 0.03), (64, 440, 1, 0.5), (33, 31, 2, 0.5), (40, 65, 1, 1.0), (5, 440, 1, 0.0)])
-def test_nade_mfma_split_forward_vs_oracle(ops, N, D, tracks, rho):
-    """Split-operand matrix-core NADE forward (precision "fp16": states and decoder weights as bf16 pairs hi + lo, 16 significant bits)
-    against the float64 oracle (nade.py:155-229): every conditional within 1e-4 absolute (measured ~1e-6), per-row NLL within 1e-4 relative,
-    d nll / d b_dec within 1e-4 of its scale; a_final as exact as the f32 kernel's; the pack kernel's pairs reconstruct w_dec to 2^-16."""
+def test_nade_mfma_exact_forward_vs_oracle(ops, N, D, tracks, rho):
+    """Exact-product matrix-core NADE forward (precision "fp16": f32 states and decoder weights on v_mfma_f32_16x16x4_f32) against the float64
+    oracle (nade.py:155-229): every conditional within 1e-5 absolute, per-row NLL within 1e-5 relative (the f32 vector scan's own level),
+    d nll / d b_dec within 1e-4 of its scale, a_final as exact as the f32 kernel's; the pack kernel is a pure permutation of w_dec."""
     Hn = 256
     R = np.random.default_rng(N + D)
     ld = tracks * (Hn + D)
@@ -415,15 +415,15 @@ def test_nade_mfma_split_forward_vs_oracle(ops, N, D, tracks, rho):
     wd = (R.standard_normal((tracks, D, Hn)) * .1).astype(np.float32)
     v = (R.random((tracks, N, D)) < rho).astype(np.uint8)
     rw = (R.random(N) / N).astype(np.float32)
-    wsp = torch.empty((tracks * D, 2 * Hn), device=DEV, dtype=torch.bfloat16)
-    ops.nade_split_pack(dev(wd).view(tracks * D, Hn), wsp)
-    q = wsp.float().view(tracks * D, Hn // 4, 2, 4)
-    rec = (q[:, :, 0] + q[:, :, 1]).reshape(tracks, D, Hn).cpu().numpy()
-    assert np.abs(rec - wd).max() <= 2.0 ** -16 * np.abs(wd).max()
+    wpk = torch.empty((tracks * D, Hn), device=DEV)
+    ops.nade_f32_pack(dev(wd).view(tracks * D, Hn), wpk)
+    q = wpk.view(tracks * D, 2, 4, Hn // 8).cpu().numpy()              # [row][K half][lane group][step] = w[row][half * Hn/2 + 4 step + group]
+    rec = q.transpose(0, 1, 3, 2).reshape(tracks, D, Hn)
+    assert np.array_equal(rec, wd)
     z = lambda *s_: torch.zeros(s_, device=DEV)
     nll, cp, db, af = z(tracks, N), z(tracks, N, D), z(N, ld), z(tracks, N, Hn)
-    ops.nade_logprob_fwd_auto(dev(v), dev(bias), dev(we), dev(wd), wsp.view(tracks, D, 2 * Hn), tracks, D, Hn, None, None, 1.0, dev(rw), nll, cp, db, af,
-                              split=True)
+    ops.nade_logprob_fwd_auto(dev(v), dev(bias), dev(we), dev(wd), wpk.view(tracks, D, Hn), tracks, D, Hn, None, None, 1.0, dev(rw), nll, cp, db, af,
+                              exact=True)
     f8 = np.float64
     for m in range(tracks):
         be = bias[:, m * Hn:(m + 1) * Hn].astype(f8)
@@ -431,15 +431,15 @@ def test_nade_mfma_split_forward_vs_oracle(ops, N, D, tracks, rho):
         n_ref, c_ref = onade.log_prob(v[m].astype(f8), be, bd, we[m].astype(f8), wd[m].astype(f8))
         e_cp = np.abs(cp[m].cpu().numpy() - c_ref).max()
         e_nll = np.abs(nll[m].cpu().numpy() - n_ref).max() / np.abs(n_ref).max()
-        print(f"\n[split N={N} D={D} rho={rho} track {m}] cond_p abs {e_cp:.2e}  nll rel {e_nll:.2e}")
-        assert e_cp < 1e-4 and e_nll < 1e-4
+        print(f"\n[exact N={N} D={D} rho={rho} track {m}] cond_p abs {e_cp:.2e}  nll rel {e_nll:.2e}")
+        assert e_cp < 1e-5 and e_nll < 2e-5
         g = onade.log_prob_bwd(v[m].astype(f8), be, bd, we[m].astype(f8), wd[m].astype(f8), rw.astype(f8))
         assert rel(db.cpu().numpy()[:, tracks * Hn + m * D: tracks * Hn + (m + 1) * D], g[1]) < 1e-4
         a_ref = be + (v[m].astype(f8) @ we[m].astype(f8))
         assert np.abs(af[m].cpu().numpy() - a_ref).max() < 1e-4
     nll2, cp2 = z(tracks, N), z(tracks, N, D)
-    ops.nade_logprob_fwd_auto(dev(v), dev(bias), dev(we), dev(wd), wsp.view(tracks, D, 2 * Hn), tracks, D, Hn, None, None, 1.0, None, nll2, cp2, None, None,
-                              split=True)
+    ops.nade_logprob_fwd_auto(dev(v), dev(bias), dev(we), dev(wd), wpk.view(tracks, D, Hn), tracks, D, Hn, None, None, 1.0, None, nll2, cp2, None, None,
+                              exact=True)
     assert torch.equal(nll, nll2) and torch.equal(cp, cp2)              # deterministic
 
 

@@ -83,8 +83,8 @@ def test_joint_lstm_nade_step_at_real_widths_vs_oracle(precision, rho):
     gen._materialize(D)
     load(gen, p)
     gen.build_pianoroll(dev(x), None, is_train=True, mode="train")
-    if precision in ("bf16", "fp16"):   # fp16: the NADE forward of the benchmarked mode is whatever RnnNade._nade_fwd dispatches (f32 scan or split MFMA)
-        assert gen._stack._persist(B, T) and (gen._nade_mfma() or precision == "fp16"), "the benchmarked kernels must be the ones under test"
+    if precision in ("bf16", "fp16"):
+        assert gen._stack._persist(B, T) and gen._nade_mfma(), "the benchmarked kernels must be the ones under test"
     loss = float(gen.metrics["batch/loss"])
     nll = gen.log_probs.cpu().numpy()
     cp = gen.cond_probs.cpu().numpy()                   # train-mode build: one more decoder pass over the saved Dense output
