@@ -486,7 +486,9 @@ gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
     for (int kt = kt0; kt < kt1; ++kt) {
         // (spreading these 8 DMA instructions over the four k-steps was measured: the 0.6 us they hold the wave moves into the k-steps --
         // 256 x 256 x 448 tile: issue 4.3 -> 1.4 us, LDS reads + MFMA 8.9 -> 10.2, barriers 1.8 -> 2.6: the K tile stays at ~2 us, LDS-bound)
+#ifndef ABL_NODMA
         if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
+#endif
         GM_T(2);
         const char* sA = smem256 + (cur * 2 + 0) * TILE;
         const char* sB = smem256 + (cur * 2 + 1) * TILE;
@@ -506,7 +508,13 @@ gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = F::mfma32(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < 2; ++j) {
+#ifndef ABL_NOMFMA
+                    acc[i][j] = F::mfma32(a[i], b[j], acc[i][j]);
+#else
+                    asm volatile("" :: "v"(a[i]), "v"(b[j]));
+#endif
+                }
         }
         GM_T(3);
         __syncthreads();
@@ -607,30 +615,33 @@ __device__ __forceinline__ RingItem ring_item(int lin, int split_k, int ntn, int
     return it;
 }
 
-template <typename F>
+template <typename F, int BK, int NS>
 __global__ void __launch_bounds__(512)
 gemm_tn_ring256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c16,
                        const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn, int n_items) {
-    constexpr int SLOT = 32768;
-    extern __shared__ __attribute__((aligned(16))) char ring[];          // 4 slots x [A 256 x 64 B | B 256 x 64 B]
+    // BK = 32, NS = 4: the ring described above.  BK = 64, NS = 2: the K loop of gemm_tn_glds256_kernel (one 64-deep sub-tile in flight) inside the
+    // same persistent scaffold -- the operand stream is served at ~34 GB/s per CU whatever is in flight (profiles/round3_b_gemm_ablation.md), so
+    // depth buys nothing on long K, but the next tile's first sub-tile travels under this tile's epilogue stores.
+    constexpr int ROWB = 2 * BK, CPR = BK / 8, HALF = 256 * ROWB, SLOT = 2 * HALF, NP = CPR / 2;     // NP: DMA pieces per thread and operand
+    extern __shared__ __attribute__((aligned(16))) char ring[];          // NS slots x [A 256 rows | B 256 rows], then the epilogue scratch
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int r = lane & 31, h = lane >> 5;
-    const int nks = K / 32;
+    const int nks = K / BK;
     const unsigned ring0 = rg_lds_addr(ring);
     auto item_ok = [&](const RingItem& it) { return it.ks0 < it.ks1 && it.m0 < ntm * 256; };
-    // ---- producer side: this thread's four 16-byte DMA slots of a sub-tile (two of A, two of B): linear position p = 512 j + tid, row p >> 2
-    const int prow0 = (int)threadIdx.x >> 2, prow1 = prow0 + 128;
-    const int pch0 = (int)(threadIdx.x & 3) ^ ((prow0 >> 2) & 3), pch1 = (int)(threadIdx.x & 3) ^ ((prow1 >> 2) & 3);   // logical chunk held by the slot
+    // ---- producer side: piece j of this thread covers linear 16-byte position p = 512 j + tid of the operand image: row p / CPR, chunk p % CPR
     int p_lin = blockIdx.x;                                   // item being staged
     RingItem pit = ring_item(p_lin < n_items ? p_lin : 0, split_k, ntn, nks);
     int p_ks = pit.ks0;
-    const bf16_t *pa0, *pa1, *pb0, *pb1;
+    const bf16_t *pa[NP], *pb[NP];
     auto p_setup = [&]() {                                    // rows past the edge replicate the last row (never stored)
-        pa0 = A + (size_t)min(pit.m0 + prow0, M - 1) * lda + pch0 * 8;
-        pa1 = A + (size_t)min(pit.m0 + prow1, M - 1) * lda + pch1 * 8;
-        pb0 = B + (size_t)min(pit.n0 + prow0, N - 1) * ldb + pch0 * 8;
-        pb1 = B + (size_t)min(pit.n0 + prow1, N - 1) * ldb + pch1 * 8;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int p = 512 * j + (int)threadIdx.x, row = p / CPR, ch = (p % CPR) ^ swz<CPR>(row);
+            pa[j] = A + (size_t)min(pit.m0 + row, M - 1) * lda + ch * 8;
+            pb[j] = B + (size_t)min(pit.n0 + row, N - 1) * ldb + ch * 8;
+        }
     };
     auto p_next_item = [&]() {                                // an item whose K slice is empty or whose tile row lies past ntm is skipped on both sides
         do {
@@ -640,17 +651,14 @@ gemm_tn_ring256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
         if (p_lin < n_items) { p_ks = pit.ks0; p_setup(); }
     };
     if (p_lin < n_items && !item_ok(pit)) p_next_item(); else if (p_lin < n_items) p_setup();
-    // one of the four DMA pieces of the sub-tile being staged (q = 0, 1: A; 2, 3: B); the cursor moves on behind the last one
-    auto stage_piece = [&](int slot, int q) {
+    auto stage = [&](int slot) {                              // the 2 NP DMA pieces of the next sub-tile of the stream; the cursor moves on behind them
         const unsigned base = ring0 + slot * SLOT + wave * 1024;
-        const int k0 = p_ks * 32;
-        if (q == 0) rg_dma16(pa0 + k0, base);
-        else if (q == 1) rg_dma16(pa1 + k0, base + 8192);
-        else if (q == 2) rg_dma16(pb0 + k0, base + 16384);
-        else {
-            rg_dma16(pb1 + k0, base + 16384 + 8192);
-            if (++p_ks == pit.ks1) p_next_item();
-        }
+        const int k0 = p_ks * BK;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) rg_dma16(pa[j] + k0, base + j * 8192);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) rg_dma16(pb[j] + k0, base + HALF + j * 8192);
+        if (++p_ks == pit.ks1) p_next_item();
     };
     // ---- consumer side: number of sub-tiles of this workgroup's stream, and the cursor of the MFMAs
     int S = 0;
@@ -670,58 +678,38 @@ gemm_tn_ring256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     int staged = 0;                                           // sub-tiles whose DMAs have been issued
-    for (int s0 = 0; s0 < 3 && staged < S; ++s0, ++staged)
+    for (int s0 = 0; s0 < NS - 1 && staged < S; ++s0, ++staged) stage(s0);
+    // fragment byte offsets inside a slot for k-step 0 (logical chunk h); k-step ks adds 2 ks to the chunk before the swizzle
+    int rowA[4], rowB[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) stage_piece(s0, q);
-    // fragment byte offsets inside a slot (k-step ks, logical chunk 2 ks + h), constant over the loop
-    unsigned offA[4][2], offB[2][2];
+    for (int i = 0; i < 4; ++i) rowA[i] = wm * 128 + i * 32 + r;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const int row = wm * 128 + i * 32 + r; offA[i][ks] = row * 64 + (((2 * ks + h) ^ ((row >> 2) & 3)) << 4); }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { const int row = wn * 64 + j * 32 + r; offB[j][ks] = 16384 + row * 64 + (((2 * ks + h) ^ ((row >> 2) & 3)) << 4); }
-    }
-    // Step n: wait for sub-tile n | barrier (it is in LDS for everybody; the slot of sub-tile n - 1 is free) | fragments of k-step 0 | MFMAs of
-    // k-step 0 with the fragment reads of k-step 1 and the first two DMA pieces of sub-tile n + 3 between them | MFMAs of k-step 1 with the other
-    // two pieces.  An LDS-DMA costs 60-180 cycles of issue: among the MFMAs it hides, in front of them it delays both waves of the SIMD (the
-    // barrier keeps them in step, so nothing else would fill the pipe).
+    for (int j = 0; j < 2; ++j) rowB[j] = wn * 64 + j * 32 + r;
     GM_T0();
     for (int n = 0; n < S; ++n) {
-        rg_wait_all_but(4 * (staged - n - 1));               // sub-tile n has landed once only the younger staged ones are outstanding
+        rg_wait_all_but(2 * NP * (staged - n - 1));           // sub-tile n has landed once only the younger staged ones are outstanding
         GM_T(1);
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();                         // it is in LDS for everybody; the slot of sub-tile n - 1 is free
         GM_T(2);
-        const char* slot = ring + (n & 3) * SLOT;
-        typename F::x8 a0[4], b0[2], a1[4], b1[2];
+        if (staged < S) { stage((n + NS - 1) % NS); ++staged; }
+        GM_T(3);
+        const char* slot = ring + (n % NS) * SLOT;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b0[j] = *reinterpret_cast<const typename F::x8*>(slot + offB[j][0]);
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            typename F::x8 a[4], b[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a0[i] = *reinterpret_cast<const typename F::x8*>(slot + offA[i][0]);
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const typename F::x8*>(slot + HALF + rowB[j] * ROWB + (((2 * ks + h) ^ swz<CPR>(rowB[j])) << 4));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b1[j] = *reinterpret_cast<const typename F::x8*>(slot + offB[j][1]);
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const typename F::x8*>(slot + rowA[i] * ROWB + (((2 * ks + h) ^ swz<CPR>(rowA[i])) << 4));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a1[i] = *reinterpret_cast<const typename F::x8*>(slot + offA[i][1]);
-        const bool st = staged < S;                          // a sub-tile left to stage: into the slot of sub-tile n - 1
-        __builtin_amdgcn_s_setprio(1);
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = F::mfma32(a0[i], b0[j], acc[i][j]);
-            if ((i & 1) == 1 && st) stage_piece((n + 3) & 3, i >> 1);
+                for (int j = 0; j < 2; ++j) acc[i][j] = F::mfma32(a[i], b[j], acc[i][j]);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = F::mfma32(a1[i], b1[j], acc[i][j]);
-            if ((i & 1) == 1 && st) stage_piece((n + 3) & 3, 2 + (i >> 1));
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (st) ++staged;
         GM_T(4);
         if (++c_ks == cit.ks1) {
             // ---- the tile (or its K slice) is complete: epilogue (wide form through a per-wave 16-row scratch behind the ring), next item
-            float* sc = reinterpret_cast<float*>(ring + 4 * SLOT) + wave * (16 * 36);
+            float* sc = reinterpret_cast<float*>(ring + NS * SLOT) + wave * (16 * 36);
             const int row0 = cit.m0 + wm * 128, col0 = cit.n0 + wn * 64;
             const float* bz = cit.z == 0 ? bias : nullptr;
             const bool wide = !(flags & (MNN_GEMM_ATOMIC | MNN_GEMM_ACCUMULATE)) && row0 + 128 <= M && col0 + 64 <= N && ((size_t)Cv & 15) == 0 &&
@@ -762,28 +750,30 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
         const int ntm2 = cdiv(M, 256), ntn2 = cdiv(N, 256);
         static const bool no256 = getenv("MNN_GEMM_NO256") != nullptr;
         static const bool no_ring = getenv("MNN_GEMM_NO_RING") != nullptr;
-        // the ring form wins where an output tile has few K tiles and the prologue / epilogue bubbles of the one-tile-per-workgroup kernel are a large
-        // share (dense forward, K = 256: 349 -> 246 us at [262144, 696]); its 32-deep steps (a barrier and four DMA pieces per 16 MFMAs) lose to the
-        // 64-deep loop on longer K (xproj1 K = 448: 813 -> 899 us; the K = 262144 weight gradients 570 -> 690 us), with the DMA pieces in front of
-        // the MFMAs or among them
-        if (!no_ring && !no256 && K % 32 == 0 && K <= 256 && split_k == 1 && M >= 256 && N >= 192 && (long)ntm2 * ntn2 >= 128 && K / 32 >= 4) {
+        // persistent ring form of the 256 x 256 tile: only where an output tile has at most four 64-deep K tiles (the Dense forward of the step,
+        // K = 256: 349 -> 250-300 us at [262144, 696]).  Measured and NOT used elsewhere (profiles/round3_b_gemm_ablation.md): on K = 448 .. 1024
+        // both the 4-slot ring (xproj1 813 -> 899 us) and a persistent two-slot form with 64-deep sub-tiles (905 us) lose to the plain
+        // one-tile-per-workgroup kernel, on the K = 262144 weight gradients the ring takes 690 instead of 570 us: the operand stream arrives at
+        // ~34 GB/s per CU whatever is in flight, and the hardware's own workgroup turnover overlaps prologues and epilogues at least as well.
+        if (!no_ring && !no256 && K % 32 == 0 && K <= 256 && split_k == 1 && M >= 256 && N >= 192 && (long)ntm2 * ntn2 >= 512 && K / 32 >= 4) {
             using F = typename FlavorOf<T>::type;
+            constexpr int LDS_RING = 4 * 32768 + 8 * 16 * 36 * 4;
             static bool attr_set[64];
             static int cus[64];
             int dev = 0;
             MNN_HIP(hipGetDevice(&dev));
             MNN_REQUIRE(dev >= 0 && dev < 64, "mnn_gemm_tn: device index %d", dev);
             if (!attr_set[dev]) {
-                MNN_HIP(hipFuncSetAttribute((const void*)gemm_tn_ring256_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8 * 16 * 36 * 4));
+                MNN_HIP(hipFuncSetAttribute((const void*)gemm_tn_ring256_kernel<F, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_RING));
                 hipDeviceProp_t pr;
                 MNN_HIP(hipGetDeviceProperties(&pr, dev));
                 cus[dev] = pr.multiProcessorCount;
                 attr_set[dev] = true;
             }
-            const int n_items = cdiv(ntm2, 8) * 8 * ntn2 * split_k;
+            const int n_items = cdiv(ntm2, 8) * 8 * ntn2;
             const int gridp = std::min(n_items, std::max(8, cus[dev] / 8 * 8));          // one workgroup per CU, a multiple of the 8 XCDs
-            hipLaunchKernelGGL(gemm_tn_ring256_kernel<F>, dim3(gridp), dim3(512), 4 * 32768 + 8 * 16 * 36 * 4, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc,
-                               c_bf16, bias, M, N, K, flags, split_k, ntm2, ntn2, n_items);
+            hipLaunchKernelGGL((gemm_tn_ring256_kernel<F, 32, 4>), dim3(gridp), dim3(512), LDS_RING, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C,
+                               ldc, c_bf16, bias, M, N, K, flags, 1, ntm2, ntn2, n_items);
             MNN_LAUNCH_CHECK();
             return MNN_OK;
         }
