@@ -366,7 +366,7 @@ def mode_params(w):
 def main(argv=None):
     a = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        return launch_ranks(a.gpus, sys.argv[1:] if argv is None else argv, need_devices=not a.collective_only)
+        return launch_ranks(a.gpus, sys.argv[1:] if argv is None else argv, need_devices=not a.collective_only and a.backend == "nccl")
     if a.collective_only:
         return collective_only(a)
 

@@ -530,214 +530,6 @@ gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
 #endif
 }
 
-// ----------------------------------------------------------------------------------------------
-// Ring variant of the 256 x 256 tile (round 3): the K loop of gemm_tn_glds256_kernel keeps ONE K tile (64 KiB) in flight and meets it at a
-// barrier that drains vmcnt(0): measured ~2.0 us per K tile for 0.85 us of MFMAs -- it runs at the latency of its own prefetch.  Here
-//   * the operand stream is cut into sub-tiles of 32 k (A 256 x 32 + B 256 x 32 = 32 KiB) that circulate through a ring of FOUR LDS slots:
-//     three sub-tiles (96 KiB) are in flight while the fourth feeds the MFMAs;
-//   * the LDS-DMA is issued from inline assembly, so the compiler's own wait bookkeeping never sees it (it would wait vmcnt(0) at the next
-//     barrier): the wait for sub-tile g is a counted `s_waitcnt vmcnt(8)` (the two younger sub-tiles, four 16-byte DMAs per thread each, stay
-//     in flight; a wave's vector-memory operations complete in issue order) followed by a raw s_barrier (cdna_hip_programming.md, "Pipelining
-//     across barriers"); that barrier is also what frees the slot consumed one step earlier for the next stage -- one barrier per sub-tile;
-//   * the workgroups are PERSISTENT (one per CU, items b, b + grid, ...): the ring does not care about tile boundaries, so while a tile's
-//     epilogue stores run the first three sub-tiles of the next tile are already on their way (the short-K forward GEMMs of the step -- 7 to
-//     16 K tiles per output tile -- spent a third of their time in unoverlapped prologues and epilogues);
-//   * epilogue: the wide (16-byte) form through a per-wave 16-row scratch laid over the slot that was consumed last (free until the next
-//     stage), or the element-wise / atomic forms without scratch.
-// LDS image of a sub-tile: 64-byte rows, 16-byte chunk c of row r at chunk c ^ ((r >> 2) & 3): the 16 rows of a ds_read_b128 lane group fall
-// on 16 distinct 16-byte granules; the DMA writes linearly, so the swizzle is applied to each lane's SOURCE address and again on the read.
-// ----------------------------------------------------------------------------------------------
-#define RG_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-__device__ __forceinline__ void rg_wait_all_but(int n) {          // n: vector-memory operations issued after the ones waited for
-    switch (n) {
-        RG_VM(0) RG_VM(4) RG_VM(8)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-__device__ __forceinline__ unsigned rg_lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
-__device__ __forceinline__ void rg_dma16(const void* gsrc, unsigned lds_dst) {     // one LDS-DMA: 64 lanes x 16 B -> 1 KiB at the wave-uniform lds_dst
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-// wide epilogue of one wave's NI x NJ accumulator tiles through a 16-row scratch ([16][36] f32 per wave)
-template <int MODE, int NI, int NJ>
-__device__ __forceinline__ void epi_store_wide16(void* __restrict__ Cv, int ldc, int row0, int col0, const f32x16_t (&acc)[NI][NJ],
-                                                 const float* __restrict__ bias, int lane, float* __restrict__ sc) {
-    const int r = lane & 31, hh = lane >> 5;
-    float* Cf = reinterpret_cast<float*>(Cv);
-    bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const float bv = bias != nullptr ? bias[col0 + j * 32 + r] : 0.f;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {             // rows 16 half .. 16 half + 15 of the tile: registers e = 8 half .. 8 half + 7
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sc[((e & 3) + 8 * (e >> 2) + 4 * hh) * 36 + r] = acc[i][j][8 * half + e] + bv;
-                asm volatile("" ::: "memory");
-                if (MODE == EPI_BF16 || MODE == EPI_F16) {
-                    using CF = typename std::conditional<MODE == EPI_F16, Fp16F, Bf16F>::type;
-                    const int row = lane >> 2, c8 = 8 * (lane & 3);
-                    const float4 v0 = *reinterpret_cast<const float4*>(sc + row * 36 + c8);
-                    const float4 v1 = *reinterpret_cast<const float4*>(sc + row * 36 + c8 + 4);
-                    uint4 pk;
-                    pk.x = pack2<CF>(v0.x, v0.y); pk.y = pack2<CF>(v0.z, v0.w); pk.z = pack2<CF>(v1.x, v1.y); pk.w = pack2<CF>(v1.z, v1.w);
-                    *reinterpret_cast<uint4*>(Cb + (size_t)(row0 + i * 32 + 16 * half + row) * ldc + col0 + j * 32 + c8) = pk;
-                } else {
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const int row = 8 * p + (lane >> 3), c4 = 4 * (lane & 7);
-                        *reinterpret_cast<float4*>(Cf + (size_t)(row0 + i * 32 + 16 * half + row) * ldc + col0 + j * 32 + c4) =
-                            *reinterpret_cast<const float4*>(sc + row * 36 + c4);
-                    }
-                }
-                asm volatile("" ::: "memory");
-            }
-        }
-    }
-}
-
-struct RingItem { int m0, n0, ks0, ks1, z; };           // output tile origin, sub-tile range [ks0, ks1) of its K slice, slice index
-__device__ __forceinline__ RingItem ring_item(int lin, int split_k, int ntn, int nks) {
-    // same map as the non-persistent kernels: the split-K slices of one tile on consecutive ids (consecutive XCDs), an m-panel per XCD
-    RingItem it;
-    it.z = lin % split_k;
-    const int bid = lin / split_k;
-    const int grp = bid / (8 * ntn), within = bid % (8 * ntn);
-    it.m0 = (grp * 8 + (within & 7)) * 256;
-    it.n0 = (within >> 3) * 256;
-    const int per = (nks + split_k - 1) / split_k;
-    it.ks0 = it.z * per;
-    it.ks1 = min(nks, it.ks0 + per);
-    return it;
-}
-
-template <typename F, int BK, int NS>
-__global__ void __launch_bounds__(512)
-gemm_tn_ring256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c16,
-                       const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn, int n_items) {
-    // BK = 32, NS = 4: the ring described above.  BK = 64, NS = 2: the K loop of gemm_tn_glds256_kernel (one 64-deep sub-tile in flight) inside the
-    // same persistent scaffold -- the operand stream is served at ~34 GB/s per CU whatever is in flight (profiles/round3_b_gemm_ablation.md), so
-    // depth buys nothing on long K, but the next tile's first sub-tile travels under this tile's epilogue stores.
-    constexpr int ROWB = 2 * BK, CPR = BK / 8, HALF = 256 * ROWB, SLOT = 2 * HALF, NP = CPR / 2;     // NP: DMA pieces per thread and operand
-    extern __shared__ __attribute__((aligned(16))) char ring[];          // NS slots x [A 256 rows | B 256 rows], then the epilogue scratch
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int r = lane & 31, h = lane >> 5;
-    const int nks = K / BK;
-    const unsigned ring0 = rg_lds_addr(ring);
-    auto item_ok = [&](const RingItem& it) { return it.ks0 < it.ks1 && it.m0 < ntm * 256; };
-    // ---- producer side: piece j of this thread covers linear 16-byte position p = 512 j + tid of the operand image: row p / CPR, chunk p % CPR
-    int p_lin = blockIdx.x;                                   // item being staged
-    RingItem pit = ring_item(p_lin < n_items ? p_lin : 0, split_k, ntn, nks);
-    int p_ks = pit.ks0;
-    const bf16_t *pa[NP], *pb[NP];
-    auto p_setup = [&]() {                                    // rows past the edge replicate the last row (never stored)
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int p = 512 * j + (int)threadIdx.x, row = p / CPR, ch = (p % CPR) ^ swz<CPR>(row);
-            pa[j] = A + (size_t)min(pit.m0 + row, M - 1) * lda + ch * 8;
-            pb[j] = B + (size_t)min(pit.n0 + row, N - 1) * ldb + ch * 8;
-        }
-    };
-    auto p_next_item = [&]() {                                // an item whose K slice is empty or whose tile row lies past ntm is skipped on both sides
-        do {
-            p_lin += gridDim.x;
-            if (p_lin < n_items) pit = ring_item(p_lin, split_k, ntn, nks);
-        } while (p_lin < n_items && !item_ok(pit));
-        if (p_lin < n_items) { p_ks = pit.ks0; p_setup(); }
-    };
-    if (p_lin < n_items && !item_ok(pit)) p_next_item(); else if (p_lin < n_items) p_setup();
-    auto stage = [&](int slot) {                              // the 2 NP DMA pieces of the next sub-tile of the stream; the cursor moves on behind them
-        const unsigned base = ring0 + slot * SLOT + wave * 1024;
-        const int k0 = p_ks * BK;
-#pragma unroll
-        for (int j = 0; j < NP; ++j) rg_dma16(pa[j] + k0, base + j * 8192);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) rg_dma16(pb[j] + k0, base + HALF + j * 8192);
-        if (++p_ks == pit.ks1) p_next_item();
-    };
-    // ---- consumer side: number of sub-tiles of this workgroup's stream, and the cursor of the MFMAs
-    int S = 0;
-    for (int l = blockIdx.x; l < n_items; l += gridDim.x) {
-        const RingItem it = ring_item(l, split_k, ntn, nks);
-        if (item_ok(it)) S += it.ks1 - it.ks0;
-    }
-    int c_lin = blockIdx.x;
-    RingItem cit = ring_item(c_lin < n_items ? c_lin : 0, split_k, ntn, nks);
-    while (c_lin < n_items && !item_ok(cit)) { c_lin += gridDim.x; if (c_lin < n_items) cit = ring_item(c_lin, split_k, ntn, nks); }
-    int c_ks = cit.ks0;
-    f32x16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    int staged = 0;                                           // sub-tiles whose DMAs have been issued
-    for (int s0 = 0; s0 < NS - 1 && staged < S; ++s0, ++staged) stage(s0);
-    // fragment byte offsets inside a slot for k-step 0 (logical chunk h); k-step ks adds 2 ks to the chunk before the swizzle
-    int rowA[4], rowB[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rowA[i] = wm * 128 + i * 32 + r;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) rowB[j] = wn * 64 + j * 32 + r;
-    GM_T0();
-    for (int n = 0; n < S; ++n) {
-        rg_wait_all_but(2 * NP * (staged - n - 1));           // sub-tile n has landed once only the younger staged ones are outstanding
-        GM_T(1);
-        __builtin_amdgcn_s_barrier();                         // it is in LDS for everybody; the slot of sub-tile n - 1 is free
-        GM_T(2);
-        if (staged < S) { stage((n + NS - 1) % NS); ++staged; }
-        GM_T(3);
-        const char* slot = ring + (n % NS) * SLOT;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            typename F::x8 a[4], b[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const typename F::x8*>(slot + HALF + rowB[j] * ROWB + (((2 * ks + h) ^ swz<CPR>(rowB[j])) << 4));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const typename F::x8*>(slot + rowA[i] * ROWB + (((2 * ks + h) ^ swz<CPR>(rowA[i])) << 4));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = F::mfma32(a[i], b[j], acc[i][j]);
-        }
-        GM_T(4);
-        if (++c_ks == cit.ks1) {
-            // ---- the tile (or its K slice) is complete: epilogue (wide form through a per-wave 16-row scratch behind the ring), next item
-            float* sc = reinterpret_cast<float*>(ring + NS * SLOT) + wave * (16 * 36);
-            const int row0 = cit.m0 + wm * 128, col0 = cit.n0 + wn * 64;
-            const float* bz = cit.z == 0 ? bias : nullptr;
-            const bool wide = !(flags & (MNN_GEMM_ATOMIC | MNN_GEMM_ACCUMULATE)) && row0 + 128 <= M && col0 + 64 <= N && ((size_t)Cv & 15) == 0 &&
-                              (ldc & (c16 ? 7 : 3)) == 0;
-            if (wide) {
-                if (c16 == MNN_F16) epi_store_wide16<EPI_F16, 4, 2>(Cv, ldc, row0, col0, acc, bz, lane, sc);
-                else if (c16) epi_store_wide16<EPI_BF16, 4, 2>(Cv, ldc, row0, col0, acc, bz, lane, sc);
-                else epi_store_wide16<EPI_STORE, 4, 2>(Cv, ldc, row0, col0, acc, bz, lane, sc);
-            } else {
-                epi_dispatch<4, 2>(Cv, ldc, c16, flags, M, N, row0, col0, acc, bz, lane, nullptr);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-            do {
-                c_lin += gridDim.x;
-                if (c_lin < n_items) cit = ring_item(c_lin, split_k, ntn, nks);
-            } while (c_lin < n_items && !item_ok(cit));
-            c_ks = cit.ks0;
-            GM_T(5);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 template <typename T>
 static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                        int c_bf16, const float* bias, int flags, int split_k) {
@@ -749,34 +541,9 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
         // large problems: 256 x 256 tiles (enough of them to occupy the chip, each with enough K tiles to amortise its prologue)
         const int ntm2 = cdiv(M, 256), ntn2 = cdiv(N, 256);
         static const bool no256 = getenv("MNN_GEMM_NO256") != nullptr;
-        static const bool no_ring = getenv("MNN_GEMM_NO_RING") != nullptr;
-        // persistent ring form of the 256 x 256 tile: only where an output tile has at most four 64-deep K tiles (the Dense forward of the step,
-        // K = 256: 349 -> 250-300 us at [262144, 696]).  Measured and NOT used elsewhere (profiles/round3_b_gemm_ablation.md): on K = 448 .. 1024
-        // both the 4-slot ring (xproj1 813 -> 899 us) and a persistent two-slot form with 64-deep sub-tiles (905 us) lose to the plain
-        // one-tile-per-workgroup kernel, on the K = 262144 weight gradients the ring takes 690 instead of 570 us: the operand stream arrives at
-        // ~34 GB/s per CU whatever is in flight, and the hardware's own workgroup turnover overlaps prologues and epilogues at least as well.
-        if (!no_ring && !no256 && K % 32 == 0 && K <= 256 && split_k == 1 && M >= 256 && N >= 192 && (long)ntm2 * ntn2 >= 512 && K / 32 >= 4) {
-            using F = typename FlavorOf<T>::type;
-            constexpr int LDS_RING = 4 * 32768 + 8 * 16 * 36 * 4;
-            static bool attr_set[64];
-            static int cus[64];
-            int dev = 0;
-            MNN_HIP(hipGetDevice(&dev));
-            MNN_REQUIRE(dev >= 0 && dev < 64, "mnn_gemm_tn: device index %d", dev);
-            if (!attr_set[dev]) {
-                MNN_HIP(hipFuncSetAttribute((const void*)gemm_tn_ring256_kernel<F, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_RING));
-                hipDeviceProp_t pr;
-                MNN_HIP(hipGetDeviceProperties(&pr, dev));
-                cus[dev] = pr.multiProcessorCount;
-                attr_set[dev] = true;
-            }
-            const int n_items = cdiv(ntm2, 8) * 8 * ntn2;
-            const int gridp = std::min(n_items, std::max(8, cus[dev] / 8 * 8));          // one workgroup per CU, a multiple of the 8 XCDs
-            hipLaunchKernelGGL((gemm_tn_ring256_kernel<F, 32, 4>), dim3(gridp), dim3(512), LDS_RING, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C,
-                               ldc, c_bf16, bias, M, N, K, flags, 1, ntm2, ntn2, n_items);
-            MNN_LAUNCH_CHECK();
-            return MNN_OK;
-        }
+        // A persistent ring form of this tile (4 LDS slots of 32-deep sub-tiles, counted vmcnt, raw barriers) was measured in round 3 and is NOT
+        // shipped (profiles/round3_b_gemm_ablation.md): slower on K = 448 .. 1024 and on the K = 262144 weight gradients, because the operand
+        // stream arrives at ~34 GB/s per CU whatever is in flight; its one win (K = 256, the Dense forward) needs an N-edge epilogue at N = 704.
         if (!no256 && K % 64 == 0 && M >= 256 && N >= 192 && (long)ntm2 * ntn2 * split_k >= 192 && K / 64 / split_k >= 6) {     // measured per shape: profiles/round1_f_gemm_shapes.md
             using F = typename FlavorOf<T>::type;
             static bool attr_set[64];

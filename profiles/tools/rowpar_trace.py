@@ -15,7 +15,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 UNITS = [int(u) for u in sys.argv[3].split(",")] if len(sys.argv) > 3 else [512, 256]
 x = torch.from_numpy((np.random.default_rng(0).random((B, T, 88, 5)) < 0.03).astype(np.uint8)).cuda()
-gen = RnnNade(440, 256, UNITS, keep_prob=0.9, precision="bf16", seed=23)
+gen = RnnNade(440, 256, UNITS, keep_prob=0.9, precision=(sys.argv[4] if len(sys.argv) > 4 else "fp16"), seed=23)
 opt = AdamOptimizer(0.01)
 for _ in range(3):
     gen.train_step(x, None, opt)

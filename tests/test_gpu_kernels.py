@@ -62,6 +62,36 @@ def test_gemm_tn(ops, M, N, K, dt):
     assert rel(Cb.float().cpu().numpy(), Ar @ Br.T) < 1e-2
 
 
+@pytest.mark.parametrize("M,N,K,split_k", [(16384, 704, 256, 1), (16400, 2048, 448, 1), (16384, 704, 512, 1), (16384, 256, 704, 1),
+                                          (2048, 512, 16384, 16), (704, 256, 16384, 8), (65536, 704, 256, 1)])
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_gemm_tn_step_shapes(ops, M, N, K, split_k, dt):
+    """The GEMM shapes of the train step (Dense forward N = 704 with its ragged last column tile, input projection, dX, weight gradients with
+    split-K) at a reduced row count, both 16-bit flavours, f32 and 16-bit C: every element against torch's f32 product of the same operands.
+    (Round 3: a tile form without N-edge handling stored past the row end at N = 704 and only showed at the target shape.)"""
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    At = (torch.randn((M, K), device=DEV, generator=g) * 0.5).to(tdt)
+    Bt = (torch.randn((N, K), device=DEV, generator=g) * 0.5).to(tdt)
+    bias = torch.randn(N, device=DEV, generator=g)
+    ref = At.float() @ Bt.float().T
+    scale = float(ref.abs().max())
+    C = torch.full((M + 1, N), 7.0, device=DEV)                     # a guard row behind the matrix
+    if split_k == 1:
+        ops.gemm_tn(At, Bt, C[:M], bias=bias)
+        assert float((C[:M] - (ref + bias)).abs().max()) < 2e-5 * scale * max(1, K // 1024)
+    else:
+        C[:M].zero_()
+        ops.gemm_tn(At, Bt, C[:M], accumulate=True, split_k=split_k)
+        assert float((C[:M] - ref).abs().max()) < 2e-5 * scale * max(1, K // 1024)
+    assert bool((C[M] == 7.0).all())
+    if split_k == 1:
+        Cb = torch.full((M + 1, N), 7.0, device=DEV, dtype=tdt)
+        ops.gemm_tn(At, Bt, Cb[:M])
+        assert float((Cb[:M].float() - ref).abs().max()) < (2e-3 if dt == "f16" else 1e-2) * scale
+        assert bool((Cb[M] == 7.0).all())
+
+
 def test_gemm_strided_views_and_errors(ops):
     R = np.random.default_rng(0)
     A = dev(R.standard_normal((50, 96)).astype(np.float32))

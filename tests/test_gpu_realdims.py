@@ -136,14 +136,15 @@ def test_real_width_optimiser_step_fp32_vs_oracle():
         assert np.abs(upd - (ra - rb)).max() < 2e-4, name
 
 
-def test_target_shape_train_step_properties():
-    """North-star shape [1024, 256, 88, 5] (BASELINE.json), bf16: the step runs on the persistent recurrence (four row tiles per
-    workgroup) and the matrix-core NADE forward; loss finite and in range, forward bit-deterministic, no persistent launch gave up,
-    gradients finite and aligned with the launch-per-step / f32-NADE kernels' on the same weights, and the captured step advances."""
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_target_shape_train_step_properties(precision):
+    """North-star shape [1024, 256, 88, 5] (BASELINE.json) in the benchmarked mode (fp16) and in bf16: the step runs on the row-parallel
+    persistent recurrence and the matrix-core NADE forward; loss finite and in range, forward bit-deterministic, no persistent launch gave
+    up, gradients finite and aligned with the launch-per-step / f32-NADE kernels' on the same weights, and the captured step advances."""
     from multinn_amd import RnnNade, AdamOptimizer
     B, T = 1024, 256
     x = dev(synth(B, T, 23, 0.03))
-    a = RnnNade(D, HN, UNITS, keep_prob=0.9, precision="bf16", seed=23)
+    a = RnnNade(D, HN, UNITS, keep_prob=0.9, precision=precision, seed=23)
     a._materialize(D)
     a.build_pianoroll(x, None, True, "train")
     assert (a._stack._rowpar(B, T) or a._stack._persist(B, T)) and a._nade_mfma()
@@ -156,7 +157,7 @@ def test_target_shape_train_step_properties():
     assert bool(torch.isfinite(ga).all()) and float(ga.abs().max()) > 0
     a.build_pianoroll(x, None, True, "train")
     assert torch.equal(a._nll_tm, nll)                               # bit-deterministic forward at 262 144 rows
-    b = RnnNade(D, HN, UNITS, keep_prob=0.9, precision="bf16", seed=23)
+    b = RnnNade(D, HN, UNITS, keep_prob=0.9, precision=precision, seed=23)
     b._materialize(D)
     b.store.theta.copy_(a.store.theta)
     b._stack.persistent = False
@@ -165,9 +166,9 @@ def test_target_shape_train_step_properties():
     b.build_pianoroll(x, None, True, "train")
     lb = float(b.metrics["batch/loss"])
     b.backward()
-    assert abs(la - lb) < 3e-3 * abs(lb), (la, lb)
+    assert abs(la - lb) < (1e-4 if precision == "fp16" else 3e-3) * abs(lb), (la, lb)
     cos = float(torch.nn.functional.cosine_similarity(ga, b.store.grad, dim=0))
-    assert cos > 0.999, cos
+    assert cos > (0.99999 if precision == "fp16" else 0.999), cos
     del b
     torch.cuda.empty_cache()
     opt = AdamOptimizer(0.01)
