@@ -222,17 +222,13 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
     // w_enc[column of flip k0+u][this hidden unit] for the 32 flips of a chunk (entries past the tile's count re-read flip 0's row)
     auto load_we = [&](int c, int buf, int k0, float (&wv)[32]) {
         const int F = (int)S.sSb[buf][32];
-        constexpr int GR = SPLIT ? 8 : 32;                   // list reads first, then the global loads, per group: nothing serialises on LDS latency
-#pragma unroll                                               // (split form: groups of 8 -- 32 list entries at once do not fit its register budget)
-        for (int u0 = 0; u0 < 32; u0 += GR) {
-            int ent[GR];
+        // ONE list read per lane (lane u holds entry k0 + u), the entries then come out of the lanes with v_readlane: a uniform LDS read per
+        // entry followed by v_readfirstlane is compiled into one LDS round trip per entry, 32 in a row
+        const int entv = (int)S.sFl[buf][(k0 + (lane & 31) < F) ? k0 + (lane & 31) : 0];
 #pragma unroll
-            for (int u = 0; u < GR; ++u) ent[u] = S.sFl[buf][(k0 + u0 + u < F) ? k0 + u0 + u : 0];
-#pragma unroll
-            for (int u = 0; u < GR; ++u) {
-                const int e = __builtin_amdgcn_readfirstlane(ent[u]);
-                wv[u0 + u] = we[(size_t)min(32 * c + (e & 31), D - 1) * Hn + tid];
-            }
+        for (int u = 0; u < 32; ++u) {
+            const int e = __builtin_amdgcn_readlane(entv, u);
+            wv[u] = we[(size_t)min(32 * c + (e & 31), D - 1) * Hn + tid];
         }
     };
     unsigned char vb[4];
@@ -295,46 +291,63 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
             //      sA are issued together and the in-order VALU sees eight independent chains.
             if (k0 > 0) load_we(c, buf, k0, wev);            // rare: more than 32 flips in one tile
             const int cnt = min(32, F - k0);
+            const int flv = (int)S.sFl[buf][min(k0 + (lane & 31), F - 1)];       // the chunk's list entries, one per lane (see load_we)
 #pragma unroll
             for (int u0 = 0; u0 < 32; u0 += 8) {
                 if (u0 < cnt) {
                     int n[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) n[i] = __builtin_amdgcn_readfirstlane((int)S.sFl[buf][min(k0 + u0 + i, F - 1)]) >> 5;
-                    bool indep = u0 + 8 <= cnt;              // a full batch inside one pass: rows strictly ascending, hence distinct
-#pragma unroll
-                    for (int i = 0; i < 7; ++i) indep = indep && n[i] < n[i + 1];
-                    if (indep) {
+                    for (int i = 0; i < 8; ++i) n[i] = __builtin_amdgcn_readlane(flv, u0 + i) >> 5;
+                    if constexpr (SPLIT) {
+                        // pre-activations in registers: the read-modify-writes of the batch run in list order (a row may appear twice in a
+                        // batch that straddles two passes), each a register move with a wave-uniform index and one add; the eight sigmoids
+                        // are independent of each other; entries past the count add 0 to the row of the last flip.  Kept free of branches
+                        // so that the indexed writes happen in place (a conditional write made the compiler copy all 32 registers per flip)
                         float x[8];
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
-                            if constexpr (SPLIT) x[i] = areg[n[i]];
-                            else x[i] = S.sA[n[i]][tid];
+                            x[i] = areg[n[i]] + ((u0 + i < cnt) ? wev[u0 + i] : 0.f);
+                            areg[n[i]] = x[i];
                         }
+                        float hb[8];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) x[i] += wev[u0 + i];
-                        state_t hb[8];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) hb[i] = nm_state<SPLIT>(fast_sigmoid(x[i]));
+                        for (int i = 0; i < 8; ++i) hb[i] = fast_sigmoid(x[i]);
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             if (u0 + i < cnt) {
-                                if constexpr (SPLIT) areg[n[i]] = x[i];
-                                else S.sA[n[i]][tid] = x[i];
                                 S.sF[u0 + i][tid] = hb[i];
                                 S.sH[n[i]][tid] = hb[i];
                             }
                         }
                     } else {
+                        bool indep = u0 + 8 <= cnt;          // a full batch inside one pass: rows strictly ascending, hence distinct
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            if (u0 + i < cnt) {
-                                float av;
-                                if constexpr (SPLIT) { av = areg[n[i]] + wev[u0 + i]; areg[n[i]] = av; }
-                                else { av = S.sA[n[i]][tid] + wev[u0 + i]; S.sA[n[i]][tid] = av; }
-                                const state_t hb1 = nm_state<SPLIT>(fast_sigmoid(av));
-                                S.sF[u0 + i][tid] = hb1;
-                                S.sH[n[i]][tid] = hb1;
+                        for (int i = 0; i < 7; ++i) indep = indep && n[i] < n[i + 1];
+                        if (indep) {
+                            float x[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) x[i] = S.sA[n[i]][tid];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) x[i] += wev[u0 + i];
+                            state_t hb[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) hb[i] = nm_state<SPLIT>(fast_sigmoid(x[i]));
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                S.sA[n[i]][tid] = x[i];
+                                S.sF[u0 + i][tid] = hb[i];
+                                S.sH[n[i]][tid] = hb[i];
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                if (u0 + i < cnt) {
+                                    const float av = S.sA[n[i]][tid] + wev[u0 + i];
+                                    S.sA[n[i]][tid] = av;
+                                    const state_t hb1 = nm_state<SPLIT>(fast_sigmoid(av));
+                                    S.sF[u0 + i][tid] = hb1;
+                                    S.sH[n[i]][tid] = hb1;
+                                }
                             }
                         }
                     }
