@@ -245,11 +245,11 @@ int mnn_nade_logprob_fwd_gated(mnn_stream_t s, int tracks, int N, int D, int Hn,
 int mnn_nade_logprob_fwd_mfma_gated(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride, const float* bias,
                                     int ld_bias, const float* w_enc, const void* w_dec_bf16, const float* row_weight, float* nll, float* cond_p,
                                     float* d_bias, float* a_final, const int* gate, int run_if);
-/* Exact-product form of the matrix-core scan (precision "fp16": nade.py:199-221 within 1e-4 on every conditional, which 8- or 11-bit operands
- * of the decoder dot products miss by 2-10x): hidden states and decoder weights stay f32 and meet on v_mfma_f32_16x16x4_f32 (exact f32
- * products, f32 accumulation).  w_dec_packed: mnn_nade_f32_pack's output, f32 [tracks*D][2 K halves][4 lane groups][Hn/8 steps] (the same
- * Hn values per row, k-permuted so that every lane's weights are contiguous).  Same arguments and gate convention as
- * mnn_nade_logprob_fwd_mfma_gated (gate NULL: always runs). */
+/* Split-operand form of the matrix-core scan (precision "fp16": nade.py:199-221 within 1e-4 on every conditional, which 8- or 11-bit operands
+ * of the decoder dot products miss by 2-10x): every hidden state and decoder weight is carried as an IEEE-half pair hi + lo (22 significant
+ * bits) and a logit is the f32 sum of the three 16-bit MFMA products hi.hi + hi.lo + lo.hi (~1e-6 of the f32 vector scan).  w_dec_packed:
+ * mnn_nade_f32_pack's output, f16 [tracks*D][hi | lo][Hn] in a buffer of the f32 original's size (rows * Hn * 4 bytes, 16-byte aligned).
+ * Same arguments and gate convention as mnn_nade_logprob_fwd_mfma_gated (gate NULL: always runs). */
 int mnn_nade_f32_pack(mnn_stream_t s, const float* w_dec, long rows, int Hn, float* w_dec_packed);
 int mnn_nade_logprob_fwd_mfma_f32(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride, const float* bias,
                                   int ld_bias, const float* w_enc, const void* w_dec_packed, const float* row_weight, float* nll, float* cond_p,

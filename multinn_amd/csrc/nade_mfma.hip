@@ -41,16 +41,25 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 __device__ __forceinline__ float nm_ln(float x) { return __builtin_amdgcn_logf(x) * LN2F; }
 
-// SPLIT = the EXACT-PRODUCT form (precision "fp16": BASELINE.json's 1e-4 on every conditional, which 8- or 11-bit operands of the decoder dot
-// products miss): hidden states and decoder weights stay f32 and meet on v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulation: the
-// arithmetic of the vector scan, summation order aside).  That instruction runs at 1/16 of the 16-bit rate -- 2 x 2 D Hn flops per row at
-// 157 TFLOP/s are ~0.8 ms of matrix-core time per launch at [1024,256,88,5], overlapped with the other workgroup of the CU -- and a state
-// element is a 32-bit LDS word: the pre-activations move to registers (indirect register addressing) so that two workgroups still fit a CU,
-// a wave owns ONE HALF of K for both 16-row tiles (32 registers of decoder weights instead of 64), the two K halves of a logit meet in LDS.
-// w_dec comes k-permuted from mnn_nade_f32_pack: [d][K half][lane group g][step s] = w_dec[d][128 half + 4 s + g].
+// SPLIT = the SPLIT-OPERAND form (precision "fp16": BASELINE.json's 1e-4 on every conditional, which 8- or 11-bit operands of the decoder dot
+// products miss).  Every hidden state h and every decoder weight w is carried as TWO IEEE halves, x = hi + lo with hi = f16(x) and
+// lo = f16(x - hi) (22 significant bits), and a logit is the f32 sum of three 16-bit matrix-core products  hi.hi + hi.lo + lo.hi  (the
+// dropped lo.lo term is 2^-22 of a product): ~1e-6 of the vector scan's f32 arithmetic at the 16-bit MFMA rate.  (Round 3 first shipped
+// this form on v_mfma_f32_16x16x4_f32 -- exact f32 products at 1/16 of the 16-bit rate: its two logit phases cost 0.9 of the launch's
+// 2.8 ms at [1024,256,88,5]; measured by ablation, profiles/round3_d_nade_fwd_ablation.md.)  A state element is ONE 32-bit LDS word
+// (hi in the low half, lo in the high half), unpacked into the two A fragments with v_perm_b32; the pre-activations live in registers
+// (indirect register addressing), which keeps two workgroups on a CU.  w_dec comes from mnn_nade_f32_pack as f16 [d][hi | lo][Hn].
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+struct NmPairB { f16x8_t hi, lo; };                       // decoder fragment of one k-step: the weights' high and low halves
 template <bool SPLIT> struct NmState;
 template <> struct NmState<false> { typedef bf16_t T; static constexpr int PITCH = NM_PITCH; };
-template <> struct NmState<true> { typedef float T; static constexpr int PITCH = 260; };     // 260 words: rows 4 banks apart
+template <> struct NmState<true> { typedef unsigned T; static constexpr int PITCH = 260; };  // 260 words: rows 4 banks apart
+// state word of x in (0, 1): hi = x truncated to f16's 11 significant bits (a mask: exact), lo = x - hi (exact in f32, at most 13 significant
+// bits) rounded toward zero to f16 -- one v_and, one v_sub, one v_cvt_pkrtz; |x - (hi + lo)| < 2^-21 x (f16 subnormals: 2^-24 absolute)
+__device__ __forceinline__ unsigned nm_pack_hl(float x) {
+    const float hi = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hi, x - hi));
+}
 
 template <bool SPLIT>
 struct NadeFwdSmemT {
@@ -73,7 +82,7 @@ __device__ __forceinline__ void nm_load_a(const bf16_t (*tile)[NM_PITCH], int mi
     for (int s = 0; s < 8; ++s) a[s] = *reinterpret_cast<const bf16x8_t*>(p + 32 * s);
 }
 template <bool SPLIT> __device__ __forceinline__ typename NmState<SPLIT>::T nm_state(float h) {
-    if constexpr (SPLIT) return h;
+    if constexpr (SPLIT) return nm_pack_hl(h);
     else return f32_to_bf16(h);
 }
 // 16 x 16 logits of one state tile against the tile's decoder rows
@@ -83,49 +92,40 @@ __device__ __forceinline__ f32x4_t nm_dot(const bf16x8_t (&af)[8], const bf16x8_
     for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], bfr[s], acc, 0, 0, 0);
     return acc;
 }
-// exact form: a wave owns 16 columns x ONE HALF of K (hidden units 128 kh .. 128 kh + 127) for BOTH 16-row tiles; k-step s covers hidden units
-// 128 kh + 4 s + (lane >> 4): one f32 per lane and operand.  Two independent accumulator chains (the two row tiles) share the weight registers.
-__device__ __forceinline__ void nm_dot_f32(const float (*tile)[260], int kh, int lane, const float4 (&bw)[8], f32x4_t& acc0, f32x4_t& acc1) {
-    const float* p0 = &tile[(lane & 15)][128 * kh + (lane >> 4)];
-    const float* p1 = &tile[16 + (lane & 15)][128 * kh + (lane >> 4)];
-    acc0 = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    acc1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+// split-operand form: 16 rows x K = 256 of a packed state tile against the wave's 16 decoder columns.  Lane (row l & 15, k group l >> 4) reads
+// its 8 packed words of a k-step with two 16-byte LDS loads (rows 4 banks apart: conflict-free) and splits them into the hi and lo fragments.
+__device__ __forceinline__ f32x4_t nm_dot_hl(const unsigned (*tile)[260], int mi, int lane, const NmPairB (&bw)[8]) {
+    const unsigned* p = &tile[16 * mi + (lane & 15)][8 * (lane >> 4)];
+    f32x4_t accm = {0.f, 0.f, 0.f, 0.f}, accs = {0.f, 0.f, 0.f, 0.f};     // main term | the two small terms: two independent chains
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        float a0[4], a1[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) { a0[s] = p0[4 * (4 * g + s)]; a1[s] = p1[4 * (4 * g + s)]; }
-        const float b[4] = {bw[g].x, bw[g].y, bw[g].z, bw[g].w};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b[s], acc1, 0, 0, 0);
-        }
+    for (int s = 0; s < 8; ++s) {
+        const uint4 q0 = *reinterpret_cast<const uint4*>(p + 32 * s), q1 = *reinterpret_cast<const uint4*>(p + 32 * s + 4);
+        uint4 uh, ul;
+        uh.x = __builtin_amdgcn_perm(q0.y, q0.x, 0x05040100u); ul.x = __builtin_amdgcn_perm(q0.y, q0.x, 0x07060302u);
+        uh.y = __builtin_amdgcn_perm(q0.w, q0.z, 0x05040100u); ul.y = __builtin_amdgcn_perm(q0.w, q0.z, 0x07060302u);
+        uh.z = __builtin_amdgcn_perm(q1.y, q1.x, 0x05040100u); ul.z = __builtin_amdgcn_perm(q1.y, q1.x, 0x07060302u);
+        uh.w = __builtin_amdgcn_perm(q1.w, q1.z, 0x05040100u); ul.w = __builtin_amdgcn_perm(q1.w, q1.z, 0x07060302u);
+        const f16x8_t ah = __builtin_bit_cast(f16x8_t, uh), al = __builtin_bit_cast(f16x8_t, ul);
+        accs = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bw[s].lo, accs, 0, 0, 0);
+        accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bw[s].hi, accm, 0, 0, 0);
+        accs = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bw[s].hi, accs, 0, 0, 0);
     }
+    return accm + accs;
 }
-// One 32 x 32 logit tile of a state tile.  Non-split: wave (mi, ni) = w & 1, w >> 1 writes its 16 x 16 quadrant to out0.  Split: wave
-// (kh, ni) = w & 1, w >> 1 writes its K half of both 16-row tiles to out0 (kh = 0) / out1 (kh = 1).
+// One 32 x 32 logit tile of a state tile: wave (mi, ni) = w & 1, w >> 1 writes its 16 x 16 quadrant.
 template <bool SPLIT, typename Tile, typename B>
-__device__ __forceinline__ void nm_logit_tile(const Tile& tile, int w, int lane, const B& bfr, float (*out0)[NM_LP], float (*out1)[NM_LP]) {
-    const int ni = w >> 1;
+__device__ __forceinline__ void nm_logit_tile(const Tile& tile, int w, int lane, const B& bfr, float (*out)[NM_LP]) {
+    const int ni = w >> 1, mi = w & 1;
+    f32x4_t acc;
     if constexpr (SPLIT) {
-        const int kh = w & 1;
-        float (*out)[NM_LP] = kh ? out1 : out0;
-        f32x4_t acc0, acc1;
-        nm_dot_f32(tile, kh, lane, bfr, acc0, acc1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            out[4 * (lane >> 4) + i][16 * ni + (lane & 15)] = acc0[i];
-            out[16 + 4 * (lane >> 4) + i][16 * ni + (lane & 15)] = acc1[i];
-        }
+        acc = nm_dot_hl(tile, mi, lane, bfr);
     } else {
-        const int mi = w & 1;
         bf16x8_t af[8];
         nm_load_a(tile, mi, lane, af);
-        const f32x4_t acc = nm_dot(af, bfr);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) out0[16 * mi + 4 * (lane >> 4) + i][16 * ni + (lane & 15)] = acc[i];
+        acc = nm_dot(af, bfr);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[16 * mi + 4 * (lane >> 4) + i][16 * ni + (lane & 15)] = acc[i];
 }
 
 // thread = hidden unit: the 32 rows' pre-activations a[32] live in registers and are indexed by the (wave-uniform) row of
@@ -140,8 +140,8 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     typedef NadeFwdSmemT<SPLIT> NadeFwdSmem;
     typedef typename NmState<SPLIT>::T state_t;
-    typedef typename std::conditional<SPLIT, float4, bf16x8_t>::type bfrag_t;
-    constexpr int KS = 8;                                    // decoder fragments per lane: 8 x 16 bytes in both forms
+    typedef typename std::conditional<SPLIT, NmPairB, bf16x8_t>::type bfrag_t;
+    constexpr int KS = 8;                                    // k-steps of 32 hidden units
     NadeFwdSmem& S = *reinterpret_cast<NadeFwdSmem*>(smem_raw);
     if (gate != nullptr && *gate != run_if) return;          // density-gated pair of launches: uniform exit
     constexpr int Hn = NM_H;
@@ -151,7 +151,7 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
     const int rb = blockIdx.x * 32;
     const uint8_t* __restrict__ vm = v + (size_t)m * v_track_stride;
     const float* __restrict__ we = w_enc + (size_t)m * D * Hn;
-    const bf16_t* __restrict__ wd = w_dec_bf + (size_t)m * D * Hn * (SPLIT ? 2 : 1);        // (exact form: f32 words behind the 16-bit pointer type)
+    const bf16_t* __restrict__ wd = w_dec_bf + (size_t)m * D * Hn * (SPLIT ? 2 : 1);        // (split form: f16 [d][hi | lo][Hn] behind the 16-bit pointer type)
     const int bd_off = tracks * Hn + m * D;
     const int ntile = (D + 31) / 32;
 
@@ -209,10 +209,13 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
     };
     auto load_b = [&](int c, bfrag_t (&b)[KS]) {            // lane: column l & 15 of the wave's column half, k = 32 s + 8 (l >> 4) + j
         const int d = min(32 * c + 16 * ni + (lane & 15), D - 1);
-        if constexpr (SPLIT) {                                // [d][K half w & 1][lane group][32 steps]: this lane's 32 weights are 128 contiguous bytes
-            const float* p = reinterpret_cast<const float*>(wd) + (((size_t)d * 2 + (w & 1)) * 4 + (lane >> 4)) * 32;
+        if constexpr (SPLIT) {                                // [d][hi | lo][Hn] f16
+            const f16_t* p = reinterpret_cast<const f16_t*>(wd) + (size_t)d * 2 * Hn + 8 * (lane >> 4);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) b[s] = *reinterpret_cast<const float4*>(p + 4 * s);
+            for (int s = 0; s < KS; ++s) {
+                b[s].hi = *reinterpret_cast<const f16x8_t*>(p + 32 * s);
+                b[s].lo = *reinterpret_cast<const f16x8_t*>(p + Hn + 32 * s);
+            }
         } else {
             const bf16_t* p = wd + (size_t)d * Hn + 8 * (lane >> 4);
 #pragma unroll
@@ -258,10 +261,7 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
         float bdec[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) bdec[k] = bias[(size_t)err * ld_bias + bd_off + min(32 * c + ed0 + k, D - 1)];
-        // split form: the two K halves of the base logits go to two partial tiles laid over the (idle) flip-state tile
-        float (*pb0)[NM_LP] = SPLIT ? reinterpret_cast<float (*)[NM_LP]>(&S.sF[0][0]) : S.sLb;
-        float (*pb1)[NM_LP] = SPLIT ? pb0 + 32 : S.sLb;
-        nm_logit_tile<SPLIT>(S.sH, w, lane, bfr, pb0, pb1);
+        nm_logit_tile<SPLIT>(S.sH, w, lane, bfr, S.sLb);
         if (c + 1 < ntile) {
             ballots(c + 1, vb, S.sMask[nbuf]);               // v bytes requested one tile ago
             if (c + 2 < ntile) load_v(c + 2, vb);
@@ -276,7 +276,7 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             jj[k] = __popc(mk & ((1u << (ed0 + k)) - 1u));   // flips of this row strictly before the column
-            lsel[k] = SPLIT ? pb0[en][ed0 + k] + pb1[en][ed0 + k] : S.sLb[en][ed0 + k];
+            lsel[k] = S.sLb[en][ed0 + k];
         }
         int slot_of[4];                                      // slot of the state each pair uses: pass jj-1, rank of the row among that pass's rows
 #pragma unroll
@@ -284,7 +284,6 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
             const int pj = max(jj[k] - 1, 0);
             slot_of[k] = jj[k] > 0 ? (int)S.sPs[buf][pj] + __popc(S.sAct[buf][pj] & ((1u << en) - 1u)) : -1;
         }
-        if (SPLIT && F > 0) lds_barrier();                   // the partial base logits (laid over sF) have been read: the flips may write sF
         for (int k0 = 0; k0 < F; k0 += 32) {
             // ---- S1: the chunk's flips in pass order: a[row] += w_enc[d]; new state -> sF[slot] and the row's current state.
             //      Eight at a time: within a pass the rows are distinct (and ascending), so the eight read-modify-writes of
@@ -309,9 +308,9 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
                             x[i] = areg[n[i]] + ((u0 + i < cnt) ? wev[u0 + i] : 0.f);
                             areg[n[i]] = x[i];
                         }
-                        float hb[8];
+                        state_t hb[8];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) hb[i] = fast_sigmoid(x[i]);
+                        for (int i = 0; i < 8; ++i) hb[i] = nm_state<SPLIT>(fast_sigmoid(x[i]));
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             if (u0 + i < cnt) {
@@ -359,7 +358,7 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
             lds_barrier();                                 // B2: sF complete (and the next tile's list)
             NM_T(4);
             // ---- S2: flip logits; each pair whose state sits in this chunk picks its logit ----
-            nm_logit_tile<SPLIT>(S.sF, w, lane, bfr, S.sLf, S.sLb);     // split form: K halves in sLf and in sLb (idle: its base logits were read above)
+            nm_logit_tile<SPLIT>(S.sF, w, lane, bfr, S.sLf);
             if (k0 == 0 && F <= 32 && c + 1 < ntile) load_we(c + 1, nbuf, 0, wev);     // behind the MFMAs: the next tile's encoder rows
             NM_T(5);
             lds_barrier();                                 // B3: sLf ready
@@ -367,7 +366,7 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int slot = slot_of[k] - k0;
-                if (slot_of[k] >= 0 && slot >= 0 && slot < 32) lsel[k] = SPLIT ? S.sLf[slot][ed0 + k] + S.sLb[slot][ed0 + k] : S.sLf[slot][ed0 + k];
+                if (slot_of[k] >= 0 && slot >= 0 && slot < 32) lsel[k] = S.sLf[slot][ed0 + k];
             }
         }
         if (F == 0 && c + 1 < ntile) {                       // no flip in this tile: the bookkeeping of the loop body still has to happen
@@ -475,14 +474,16 @@ extern "C" int mnn_nade_logprob_fwd_mfma_f32(mnn_stream_t s, int tracks, int N, 
     return nm_launch<true>(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec_packed, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
 }
 
-// w_dec f32 [rows, Hn] -> [rows][K half][lane group g = 0..3][step s] = w_dec[row][half * Hn / 2 + 4 s + g]: the B operand of the exact form,
-// every lane's Hn / 8 weights of a column contiguous
+// w_dec f32 [rows, Hn] -> f16 [rows][hi | lo][Hn]: the B operand of the split-operand form (4 bytes per weight, as the f32 original)
 __global__ void __launch_bounds__(256) nade_f32_pack_kernel(const float* __restrict__ w, long n, int Hn, float* __restrict__ out) {
-    const int steps = Hn / 8;
+    f16_t* o = reinterpret_cast<f16_t*>(out);
     for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
         const long row = e / Hn;
-        const int o = (int)(e - row * Hn), s = o % steps, g = (o / steps) & 3, half = o / (4 * steps);
-        out[e] = w[row * Hn + half * (Hn / 2) + 4 * s + g];
+        const int k = (int)(e - row * Hn);
+        const float x = w[e];
+        const f16_t hi = (f16_t)x;
+        o[row * 2 * Hn + k] = hi;
+        o[row * 2 * Hn + Hn + k] = (f16_t)(x - (float)hi);
     }
 }
 extern "C" int mnn_nade_f32_pack(mnn_stream_t s, const float* w_dec, long rows, int Hn, float* out) {

@@ -757,7 +757,7 @@ class RnnNade(RnnEstimator):
             self._fc_bias = self.store["dense/bias"]
         if self._nade_mfma():                           # 16-bit copy of the decoder weights for the matrix-core NADE kernels
             M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
-            if self._nade_exact():                      # fp16 mode: f32 weights, k-permuted for the exact-product MFMA form
+            if self._nade_exact():                      # fp16 mode: the weights as f16 hi | lo pairs for the split-operand MFMA form
                 self._wdec_bf = torch.empty((M, D, Hn), device=dev, dtype=torch.float32)
                 ops.nade_f32_pack(self.store["nade/w_dec"].view(M * D, Hn), self._wdec_bf.view(M * D, Hn))
             else:
@@ -788,11 +788,11 @@ class RnnNade(RnnEstimator):
         return ops.nade_logprob_fwd_auto(v, out, self.store["nade/w_enc"], self.store["nade/w_dec"], self._wdec_bf, M, D, Hn, self._gate[:1],
                                          self._gate[1:], self.nade_dense_above, rw, nll, cond_p, d_out, a_fin, exact=exact)
 
-    # fp16 mode: the exact-product matrix-core scan (nade_mfma.hip, SPLIT: f32 operands on v_mfma_f32_16x16x4_f32) or the f32 vector scan
+    # fp16 mode: the split-operand matrix-core scan (nade_mfma.hip, SPLIT: f16 hi + lo pairs, three 16-bit MFMA products) or the f32 vector scan
     nade_exact = os.environ.get("MULTINN_NADE_EXACT_MFMA", "1") != "0"
 
     def _nade_mfma(self):
-        """The matrix-core NADE forward is in use: bf16 mode (16-bit operands) or fp16 mode (exact f32 products), and a hidden width it covers;
+        """The matrix-core NADE forward is in use: bf16 mode (16-bit operands) or fp16 mode (hi + lo operand pairs, 22 bits), and a hidden width it covers;
         otherwise the f32 VALU kernels."""
         if not (self.nade_mfma and ops.nade_mfma_ok(self.num_hidden[-1])):
             return False
@@ -800,7 +800,7 @@ class RnnNade(RnnEstimator):
 
     def _nade_exact(self):
         """fp16 mode: BASELINE.json's 1e-4 on every conditional needs more than the 8 / 11 bits of a single bf16 / f16 operand in the decoder
-        dot products (the LSTM / Dense operands do not): the matrix-core scan runs on f32 operands there."""
+        dot products (the LSTM / Dense operands do not): the matrix-core scan carries them as f16 hi + lo pairs there."""
         return self.dtype == torch.float16
 
     # -- forward --------------------------------------------------------------------------------

@@ -430,8 +430,8 @@ def nade_logprob_fwd_mfma(v, bias, w_enc, w_dec_bf, tracks, D, Hn, row_weight=No
 
 
 def nade_f32_pack(w_dec, out):
-    """w_dec f32 [rows, Hn] -> out f32 [rows, Hn], k-permuted ([K half][lane group][step] = w_dec[row][half Hn/2 + 4 step + group]): the decoder
-    operand of the exact-product matrix-core NADE forward (precision "fp16")."""
+    """w_dec f32 [rows, Hn] -> out (an f32 [rows, Hn] buffer holding f16 [rows][hi | lo][Hn], hi = f16(w), lo = f16(w - hi)): the decoder
+    operand of the split-operand matrix-core NADE forward (precision "fp16")."""
     _rowmajor(w_dec, "f32_pack w_dec"); _rowmajor(out, "f32_pack out")
     rows, Hn = w_dec.shape
     _req(w_dec.dtype == torch.float32 and w_dec.is_contiguous() and out.dtype == torch.float32 and out.is_contiguous()
@@ -442,13 +442,13 @@ def nade_f32_pack(w_dec, out):
 
 def nade_logprob_fwd_auto(v, bias, w_enc, w_dec, w_dec_bf, tracks, D, Hn, gate, count, dense_above=0.07, row_weight=None, nll=None,
                           cond_p=None, d_bias=None, a_final=None, exact=False):
-    """16-bit compute modes (exact=True: the exact-product f32 MFMA form of fp16 mode): the matrix-core form of the scan when at most `dense_above` of the cells of v are active, the f32 vector
+    """16-bit compute modes (exact=True: the split-operand hi + lo form of fp16 mode): the matrix-core form of the scan when at most `dense_above` of the cells of v are active, the f32 vector
     form otherwise; decided on the device (mnn_density_gate), both launches issued (one returns at once).  gate int32[1], count: a zeroed
     int32[1] scratch word (left zero)."""
     N = bias.shape[0]
     _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)
     _req(w_dec_bf.dtype == (torch.float32 if exact else torch.bfloat16) and w_dec_bf.is_contiguous() and w_dec_bf.numel() == tracks * D * Hn,
-         "nade auto: w_dec_bf bf16 [tracks,D,Hn] (exact form: the f32 [tracks,D,Hn] output of nade_f32_pack)")
+         "nade auto: w_dec_bf bf16 [tracks,D,Hn] (exact form: the f32-sized [tracks,D,Hn] output of nade_f32_pack)")
     _req(gate is None or (gate.dtype == torch.int32 and gate.numel() == 1 and count.dtype == torch.int32 and count.numel() == 1), "nade auto: gate / count int32[1]")
     for t, n in ((nll, tracks * N), (cond_p, tracks * N * D), (a_final, tracks * N * Hn)):
         _req(t is None or (t.dtype == torch.float32 and t.numel() == n and t.is_contiguous()), "nade auto: f32 outputs")
