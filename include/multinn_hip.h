@@ -114,6 +114,10 @@ int mnn_lstm_unpack_grads(mnn_stream_t s, const float* dwx_t, const float* dwh_t
  * for the split-K weight-gradient GEMMs (MNN_GEMM_ACCUMULATE) and the recurrence's bias sums, no zero fill per step. */
 int mnn_lstm_unpack_grads_consume(mnn_stream_t s, float* dwx_t, float* dwh_t, float* db_p, int n_in, int units, int ld_in, float* dW,
                                   float* db);
+/* Consuming form for ONE packed matrix dw_cat f32 [4u, ld_in + u] = [dWx^T | dWh^T]: the output of a single weight-gradient GEMM
+ * dz^T . [x^T ; h_prev^T]^T over the concatenated operand (dz^T is then streamed once for both gradients; rnn.py:60-62's kernel is
+ * [(in + u), 4u], i.e. the two blocks are rows of one variable). */
+int mnn_lstm_unpack_grads_cat(mnn_stream_t s, float* dw_cat, float* db_p, int n_in, int units, int ld_in, float* dW, float* db);
 
 /* One layer over steps [t_begin, t_end) of a sequence, time-major (chunked calls let the layers of a
  * stack run as a wavefront on separate streams).  xproj f32 [T,B,4u] = inputs . Wx + b (already

@@ -27,6 +27,7 @@ SIGNATURES = {
     "mnn_lstm_pack_weights": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "mnn_lstm_unpack_grads": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "mnn_lstm_unpack_grads_consume": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "mnn_lstm_unpack_grads_cat": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "mnn_lstm_seq_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i]),
     "mnn_lstm_fused_outputs": (_i, [_i, _i]),
     "mnn_lstm_seq_bwd_workspace_bytes": (_sz, [_i, _i]),

@@ -353,7 +353,7 @@ extern "C" int mnn_lstm_rows_gate_minor(mnn_stream_t s, int dtype, int units, in
 // is set back to zero by the thread that read it -- the packed buffers are then persistent accumulators for the split-K GEMMs.
 template <bool CONSUME>
 __global__ void __launch_bounds__(256)
-lstm_unpack_grads_kernel(float* __restrict__ dwx_t, float* __restrict__ dwh_t, float* __restrict__ db_p, int n_in, int U, int ld_in,
+lstm_unpack_grads_kernel(float* __restrict__ dwx_t, float* __restrict__ dwh_t, float* __restrict__ db_p, int n_in, int U, int ld_in, int ld_h,
                          float* __restrict__ dW, float* __restrict__ db) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -364,7 +364,7 @@ lstm_unpack_grads_kernel(float* __restrict__ dwx_t, float* __restrict__ dwh_t, f
         const int pc = pc0 + ty + 8 * jj, k = k0 + tx;
         float val = 0.f;
         if (k < K) {
-            float* src = k < n_in ? dwx_t + (size_t)pc * ld_in + k : dwh_t + (size_t)pc * U + (k - n_in);
+            float* src = k < n_in ? dwx_t + (size_t)pc * ld_in + k : dwh_t + (size_t)pc * ld_h + (k - n_in);
             val = *src;
             if (CONSUME) *src = 0.f;
         }
@@ -386,7 +386,18 @@ extern "C" int mnn_lstm_unpack_grads_consume(mnn_stream_t s, float* dwx_t, float
                                              float* db) {
     MNN_REQUIRE(dwx_t && dwh_t && db_p && dW && db && units % 32 == 0 && ld_in >= n_in, "mnn_lstm_unpack_grads_consume: bad arguments");
     dim3 grid(4 * units / 32, cdiv(n_in + units, 32));
-    hipLaunchKernelGGL(lstm_unpack_grads_kernel<true>, grid, dim3(256), 0, (hipStream_t)s, dwx_t, dwh_t, db_p, n_in, units, ld_in, dW, db);
+    hipLaunchKernelGGL(lstm_unpack_grads_kernel<true>, grid, dim3(256), 0, (hipStream_t)s, dwx_t, dwh_t, db_p, n_in, units, ld_in, units, dW, db);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+// the two packed gradients side by side in one matrix dw_cat [4u, ld_in + u] (columns [0, ld_in): dWx^T, [ld_in, ld_in + u): dWh^T) -- the
+// output of ONE weight-gradient GEMM over the concatenated operand [x^T ; h_prev^T]; consuming form
+extern "C" int mnn_lstm_unpack_grads_cat(mnn_stream_t s, float* dw_cat, float* db_p, int n_in, int units, int ld_in, float* dW, float* db) {
+    MNN_REQUIRE(dw_cat && db_p && dW && db && units % 32 == 0 && ld_in >= n_in, "mnn_lstm_unpack_grads_cat: bad arguments");
+    dim3 grid(4 * units / 32, cdiv(n_in + units, 32));
+    hipLaunchKernelGGL(lstm_unpack_grads_kernel<true>, grid, dim3(256), 0, (hipStream_t)s, dw_cat, dw_cat + ld_in, db_p, n_in, units, ld_in + units,
+                       ld_in + units, dW, db);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
@@ -396,7 +407,7 @@ extern "C" int mnn_lstm_unpack_grads(mnn_stream_t s, const float* dwx_t, const f
     MNN_REQUIRE(dwx_t && dwh_t && db_p && dW && db && units % 32 == 0 && ld_in >= n_in, "mnn_lstm_unpack_grads: bad arguments");
     dim3 grid(4 * units / 32, cdiv(n_in + units, 32));
     hipLaunchKernelGGL(lstm_unpack_grads_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, const_cast<float*>(dwx_t), const_cast<float*>(dwh_t),
-                       const_cast<float*>(db_p), n_in, units, ld_in, dW, db);
+                       const_cast<float*>(db_p), n_in, units, ld_in, units, dW, db);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

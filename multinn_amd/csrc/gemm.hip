@@ -362,16 +362,30 @@ struct GldsSlots {
     }
 };
 
+// Split-K work mapping.  The hardware deals consecutive workgroup ids round-robin over the 8 XCDs (xcd = id % 8).  All tiles that read the same
+// K slice should run on ONE XCD, so that the slice's A and B panels are fetched into that L2 once and the other tiles hit.  `z = id % split_k`
+// achieves that when split_k is a multiple of 8 (or the real tiles sit at multiples of 8 in the slot order: a single row group).  For other
+// slice counts XCD x owns the CONTIGUOUS range [x T / 8, (x + 1) T / 8) of the slice-major order (item = z * slots + tile); the grid's x
+// extent is a multiple of 8 workgroups, so T % 8 == 0.  Measured, [1024 x 768] weight gradient, K = 262144, split 20: 708 -> 399 us (split
+// 16: 456 either way).  Not used for multiples of 8: [256 x 704] at split 64 takes 159 us with id % split_k and 349 us contiguous.
+#define GEMM_SPLITK_CONTIG 0x100         // internal flag bit (set by the launcher): the mapping below; clear: z = id % split_k
+__device__ __forceinline__ void splitk_item(int split_k, int flags, int& z, int& bid) {
+    const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+    if (!(flags & GEMM_SPLITK_CONTIG)) { z = lin % split_k; bid = lin / split_k; return; }
+    const int slots = gridDim.x, per_xcd = (slots * split_k) >> 3;
+    const int item = (lin & 7) * per_xcd + (lin >> 3);
+    z = item / slots;
+    bid = item - z * slots;
+}
+
 template <int BK, typename F>
 __global__ void __launch_bounds__(256)
 gemm_tn_glds_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c_bf16,
                     const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
     constexpr int CPR = BK / 8, ROWB = BK * 2, TILE = 128 * ROWB;
     __shared__ __attribute__((aligned(16))) char smem[2][2][TILE];
-    // split-K: consecutive workgroup ids (= consecutive XCDs) take different K slices of the SAME output tile, so the tiles
-    // that share an XCD read the same K slice of A and B at the same time and the re-reads hit that XCD's L2
-    const int lin = blockIdx.x + blockIdx.y * gridDim.x;
-    const int z = lin % split_k, bid = lin / split_k;
+    int z, bid;
+    splitk_item(split_k, flags, z, bid);               // the tiles that share an XCD read the same K slice of A and B: the re-reads hit that XCD's L2
     const int grp = bid / (8 * ntn), within = bid % (8 * ntn);
     const int mt = grp * 8 + (within & 7), nt = within >> 3;
     if (mt >= ntm) return;
@@ -451,8 +465,8 @@ gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
                        const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
     constexpr int BK = 64, CPR = 8, ROWB = 128, TILE = 256 * ROWB;
     extern __shared__ __attribute__((aligned(16))) char smem256[];        // [stage][A | B][256 rows x 128 B]
-    const int lin = blockIdx.x + blockIdx.y * gridDim.x;   // split-K slices of one tile on consecutive ids / XCDs (see the 128 x 128 kernel)
-    const int z = lin % split_k, bid = lin / split_k;
+    int z, bid;
+    splitk_item(split_k, flags, z, bid);
     const int grp = bid / (8 * ntn), within = bid % (8 * ntn);
     const int mt = grp * 8 + (within & 7), nt = within >> 3;
     if (mt >= ntm) return;
@@ -591,6 +605,9 @@ extern "C" int mnn_gemm_tn(mnn_stream_t s, int dtype, int M, int N, int K, const
             MNN_HIP(mnn_zero_async(C, (size_t)N * 4, (size_t)ldc * 4, M, st));
         }
         flags |= MNN_GEMM_ATOMIC | MNN_GEMM_ACCUMULATE;
+        static int map = -2;                 // MNN_GEMM_SPLITK_MAP = 0 | 1 forces a mapping (development); default: by slice count
+        if (map == -2) { const char* e = getenv("MNN_GEMM_SPLITK_MAP"); map = e ? atoi(e) : -1; }
+        if (map == 1 || (map < 0 && split_k % 8 != 0)) flags |= GEMM_SPLITK_CONTIG;       // see splitk_item
     }
     MNN_REQUIRE(!(c_dtype != MNN_F32 && (flags & (MNN_GEMM_ACCUMULATE | MNN_GEMM_ATOMIC))), "mnn_gemm_tn: a 16-bit C cannot accumulate");
     const int c16 = c_dtype == MNN_F32 ? 0 : c_dtype;      // 0: f32 C; else the mnn_dtype code of the 16-bit C

@@ -156,6 +156,24 @@ class LstmStack:
             self._rpws[key] = ops.lstm_rowpar_workspace(T, B, self.packed[l]["u"], dev)
         return self._rpws[key]
 
+    # One weight-gradient GEMM per layer over the concatenated operand [x^T ; h_prev^T] (row-parallel form): dz^T is streamed once for dWx and
+    # dWh, and 2 x 4 column tiles of a K slice share every dz^T panel on an XCD's L2 instead of 2 x 2 (layer 1 at [1024,256,88,5]: 1.33 ->
+    # 1.03 ms for the pair, scratch/gemm_merge_probe.py).  The layer's forward writes h^T -- and the layer below its y^T -- into views of it.
+    merge_wgrads = os.environ.get("MULTINN_MERGE_WGRADS", "1") != "0"
+
+    def _cat_shape(self, l, Np):
+        p = self.packed[l]
+        return (p["ld"] + p["u"], Np)
+
+    def input_T(self, T, B, dev):
+        """Buffer for the caller's transposed copy of the stack's input (x^T [ld0, Np], layer 1's weight-gradient operand): a view of layer
+        1's concatenated operand when the row-parallel form with merged weight-gradient GEMMs will run, else None (caller allocates)."""
+        if not (self.merge_wgrads and self._rowpar(B, T)):
+            return None
+        Np = ops.round_up(T * B, 64)
+        self._cat0 = (torch.zeros if Np != T * B else torch.empty)(self._cat_shape(0, Np), device=dev, dtype=self.dtype)
+        return self._cat0[:self.packed[0]["ld"]]
+
     def _forward_rowpar(self, x_tm, keep_prob, seed, row0, save, step_dev):
         """Layer by layer: gate-minor input projection (one GEMM over all T*B rows), then the layer's whole recurrence in one launch."""
         T, B, _ = x_tm.shape
@@ -163,6 +181,16 @@ class LstmStack:
         Np = ops.round_up(N, 64)
         zalloc = torch.zeros if Np != N else torch.empty
         inp, ctx, final = x_tm, [], []
+        cats = [None] * len(self.packed)
+        if save and self.merge_wgrads:
+            for l, p in enumerate(self.packed):
+                if l > 0 and p["ld"] != self.packed[l - 1]["u"]:
+                    continue                            # a padded input pitch: the layer below's y^T is not this layer's x^T row for row
+                c0 = getattr(self, "_cat0", None) if l == 0 else None
+                if c0 is not None and tuple(c0.shape) == self._cat_shape(0, Np) and c0.device == dev:
+                    cats[l], self._cat0 = c0, None
+                else:
+                    cats[l] = zalloc(self._cat_shape(l, Np), device=dev, dtype=self.dtype)
         for l, p in enumerate(self.packed):
             u = p["u"]
             # the input projection is the step's largest tensor (TGT layer 1: 2.1 GB in f32): written and read once, in bf16 by default
@@ -178,18 +206,19 @@ class LstmStack:
             c = torch.empty((T, B, u), device=dev)
             hT = yT = None
             if save:
-                hT = torch.empty((u, Np), device=dev, dtype=self.dtype)
+                hT = cats[l][p["ld"]:] if cats[l] is not None else torch.empty((u, Np), device=dev, dtype=self.dtype)
                 hT[:, :B].zero_()                      # h_{-1} = 0; columns [B, T*B) are written by the launch
                 if Np != N:
                     hT[:, N:].zero_()
-                yT = zalloc((u, Np), device=dev, dtype=self.dtype)
+                nxt = cats[l + 1] if l + 1 < len(self.packed) else None
+                yT = nxt[:u] if nxt is not None else zalloc((u, Np), device=dev, dtype=self.dtype)
             d = ops.lstm2_fwd_layer(xproj, p["wh_t"], None, None, gates, c, h, hT, y, mask, yT=yT, gates_dtype=self.dtype,
                                     xproj_dtype=self.rowpar_xproj_dtype)
             ops.lstm_rowpar_fwd(T, B, d, keep_prob, self._rp_workspace(l, T, B, dev))
             out = y if y is not None else h
             if save:
                 ctx.append(dict(inp=inp, gates=gates, c=c, h=h, c0=None, h0=None, hT=hT, mask=mask, yT=yT,
-                                inT=ctx[l - 1]["yT"] if l > 0 else None, persist=True, rowpar=True))
+                                inT=ctx[l - 1]["yT"] if l > 0 else None, persist=True, rowpar=True, catT=cats[l]))
             final.append((c[-1], h[-1]))
             inp = out
         return inp, ctx, final
@@ -338,9 +367,12 @@ class LstmStack:
         # about 512 workgroups of the 128 x 128 tile (two per CU): every slice adds its tile with f32 atomics, and those run at one
         # chip-wide rate (~1.3 TB/s) -- 16 slices of dWh1 were 67 MB of adds, half of that GEMM's time (profiles/tools/gemm_sweep.py)
         # (at K >= 64 k the adds are a small share again and more slices win: 1024 workgroups)
+        # a power of two from 8 up: equal K slices and the XCD-local mapping of id % split_k (the Dense gradient [256 x 704], K = 262144: 64
+        # slices 159 us, 85 slices 213 us)
         tiles = -(-rows_out // 128) * -(-cols_out // 128)
         target = 512 if K < 65536 else 1024
-        return int(max(1, min(target // max(tiles, 1), K // 1024)))
+        sk = int(max(1, min(target // max(tiles, 1), K // 1024)))
+        return 1 << (sk.bit_length() - 1) if sk >= 8 else sk
 
     def _weight_grads(self, l, cx, dzT, db_p, T, B):
         """dWx^T[4u,ld] = dz^T . inp ; dWh^T[4u,u] = dz^T . h_prev  (reduction over the N rows); dzT [4u,Np] and
@@ -351,6 +383,25 @@ class LstmStack:
         Np = dzT.shape[1]
         dev = dzT.device
         inT = cx.get("inT")                 # the producer's own transposed copy (persistent forward: y^T of the layer below)
+        cat = cx.get("catT")
+        if cat is not None:                 # [x^T ; h_prev^T] in one buffer (h^T is a view of it): one GEMM for both gradients
+            if inT is None:
+                ops.transpose(cx["inp"].view(N, ld), cat[:ld])
+            elif inT.data_ptr() != cat.data_ptr():
+                cat[:ld].copy_(inT)
+            if not hasattr(self, "_acc_cat"):
+                self._acc_cat = {}
+            if l not in self._acc_cat:
+                self._acc_cat[l] = torch.zeros((4 * u, ld + u), device=dev)
+            dw_cat = self._acc_cat[l]
+            # one resident round of 256 x 256 tiles (one per CU), the slice count a multiple of 4: measured at [1024 x 768], K = 262144:
+            # split 20 400 us, 16 461, 21 669, 24 613, 32 494 (scratch/gemm_merge_probe2.py)
+            tiles = -(-4 * u // 256) * -(-(ld + u) // 256)
+            sk = max(1, min(256 // tiles // 4 * 4 if 256 // tiles >= 4 else 256 // tiles, Np // 1024))
+            ops.gemm_tn(dzT, cat, dw_cat, accumulate=True, split_k=sk)
+            ops.lstm_unpack_grads_cat(dw_cat, db_p, n_in, u, ld, self.store.gviews[f"{self.rnn.prefix}/cell_{l}/kernel"],
+                                      self.store.gviews[f"{self.rnn.prefix}/cell_{l}/bias"])
+            return (cat, dw_cat)
         if inT is None:
             inT = (torch.zeros if Np != N else torch.empty)((ld, Np), device=dev, dtype=self.dtype)
             ops.transpose(cx["inp"].view(N, ld), inT)
@@ -843,8 +894,11 @@ class RnnNade(RnnEstimator):
             n_valid = B * T * world()[1]
         x_tmT = None
         if mode == "train" and self.dtype in ops.H16:              # the same pass also writes x^T, layer 1's weight-gradient operand
-            Np = ops.round_up(T * B, 64)
-            x_tmT = (torch.zeros if Np != T * B else torch.empty)((self._stack.ld0, Np), device=dev, dtype=self.dtype)
+            self._ensure_packed()
+            x_tmT = self._stack.input_T(T, B, dev)                  # (a view of the layer's concatenated operand where that form runs)
+            if x_tmT is None:
+                Np = ops.round_up(T * B, 64)
+                x_tmT = (torch.zeros if Np != T * B else torch.empty)((self._stack.ld0, Np), device=dev, dtype=self.dtype)
         ops.pianoroll_shift_timemajor(x_u8.view(B, T, D), lengths, x_tm, v, rw, n_valid, inputs_t=x_tmT)
         self._forward_tm(x_tm, v.view(1, T, B, D), rw, lengths, B, T, train=(mode == "train"), x_tmT=x_tmT)
         self._is_built = True

@@ -150,6 +150,15 @@ def lstm_unpack_grads(dwx_t, dwh_t, db_p, n_in, units, dW, db, consume=False):
          _ptr(dW), _ptr(db))
 
 
+def lstm_unpack_grads_cat(dw_cat, db_p, n_in, units, ld_in, dW, db):
+    """dw_cat f32 [4u, ld_in + u] = [dWx^T | dWh^T] (one GEMM over the concatenated operand) -> dW [(in+u), 4u], db [4u], accumulating; the
+    packed sources are zeroed as they are read."""
+    _req(dw_cat.dtype == torch.float32 and dw_cat.shape == (4 * units, ld_in + units) and dw_cat.is_contiguous(), "unpack_cat: dw_cat f32 [4u, ld+u]")
+    _req(dW.dtype == torch.float32 and dW.shape == (n_in + units, 4 * units) and dW.is_contiguous(), "unpack_cat: dW f32 [(in+u),4u]")
+    _req(db.numel() == 4 * units and db_p.numel() == 4 * units and db_p.dtype == torch.float32, "unpack_cat: bias sizes")
+    call("mnn_lstm_unpack_grads_cat", _stream(), _ptr(dw_cat), _ptr(db_p), n_in, units, ld_in, _ptr(dW), _ptr(db))
+
+
 def lstm_fused_outputs(dtype, units):
     return bool(_lib.load().mnn_lstm_fused_outputs(dtype_code(dtype), int(units)))
 
