@@ -283,7 +283,14 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
                 float* __restrict__ d_bias, float* __restrict__ d_w_enc, float* __restrict__ d_w_dec, float* __restrict__ slab) {
     constexpr int W = HQ * 64;
     __shared__ __attribute__((aligned(16))) float wl[2][2][8 * W];
-    __shared__ __attribute__((aligned(16))) float red[8][4][2][W];     // [wave][visible-in-half-chunk][d w_dec | d w_enc][hidden]: one exchange per 4 visibles
+    // [buffer][wave][visible-in-half-chunk][d w_dec | d w_enc][hidden]: one exchange per 4 visibles.  Two buffers where they fit beside a second
+    // workgroup of the CU (HQ <= 2: 2 x 32 KB + 16 KB of weights = 80 KB): an exchange then needs ONE barrier (stores -> barrier -> sums; the next
+    // exchange stores into the other buffer, and a wave gets there only through the barrier every wave reaches after its previous sums), and
+    // the barrier at the end of a chunk goes too -- 2 barriers per 8 visibles instead of 5: 3.60 -> 3.38 ms at [1024,256,88,5].
+    // (Measured and dropped: the 64 v_readlane per chunk that broadcast d nll / d logit replaced by scalar loads of the same values --
+    // s_load_dwordx2 per row and visible pair; the 16 + 16 extra scalar registers spill, 4.27 ms.)
+    constexpr int NRED = HQ <= 2 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float red_[NRED][8][4][2][W];
     // blockIdx.y = track * nslice + hidden slice: the backward scan is separable over hidden units (only the forward logit sums over them), so a
     // wide layer may run as nslice narrower workgroups (fewer registers and less LDS each: more of them resident per CU)
     const int m = blockIdx.y / nslice, hb = (blockIdx.y - m * nslice) * W;
@@ -402,7 +409,8 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
             // behind this chunk's f32 atomics.  The other buffer of wl was last read in the previous chunk (barrier at its end).
             if (half == 1) bwd_lstore<HQ>(st, wl[(cc + 1) & 1][0], wl[(cc + 1) & 1][1]);
             // one cross-wave exchange per 4 visibles (the per-visible barrier was 60 % of the wave time)
-            __syncthreads();                             // the previous exchange has been read
+            float (*red)[4][2][W] = red_[(2 * cc + 1 - half) & (NRED - 1)];
+            if (NRED == 1) __syncthreads();              // the previous exchange has been read
             if constexpr (HQ >= 2) {
                 // exchange slots are LANE-major (the four hidden units lane, lane+64, lane+128, lane+192 of a lane side by side): one
                 // 16-byte LDS store per (visible, matrix) instead of four 4-byte ones, and the summing thread -- one per (visible,
@@ -472,7 +480,7 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
         }
 #pragma unroll
         for (int g = 0; g < RG; ++g) { vcur[g] = vnext[g]; dcur[g] = dnext[g]; }
-        __syncthreads();
+        if (NRED == 1) __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < BWD_R; ++r)
