@@ -214,12 +214,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // value -- written here it made every request wait for its own HBM round trip (1.5 us per step in the stage trace).  The keep bytes
     // come as ONE 16-byte load per lane and reach their (row, unit) lanes through the LDS tile at the top of the next item: a wave can
     // have 63 vector-memory operations outstanding (vmcnt is 6 bits), and 40 stores + 16 + 16 loads made every request wait for stores
+    const uint8_t* __restrict__ mask_or_c = drop ? A.mask : reinterpret_cast<const uint8_t*>(A.c);
     auto prefetch = [&](int t) {
         constexpr int XS = XB ? 2 : 4;              // bytes per stored value
         const char* xb = reinterpret_cast<const char*>(A.xproj) + ((size_t)t * 4 * us + (size_t)m0 * 4 * U) * XS + og / (4 / XS);
 #pragma unroll
         for (int k = 0; k < 16; ++k) xv[k] = *reinterpret_cast<const typename RpX<XB, F>::T*>(xb + (size_t)rp_krow(k) * 4 * XS * U);
-        if (drop) mq = *reinterpret_cast<const uint4*>(A.mask + (size_t)t * us + (size_t)(m0 + prow) * U + nt * 32 + (lane & 1) * 16);
+        mq = *reinterpret_cast<const uint4*>(mask_or_c + (size_t)t * us + (size_t)(m0 + prow) * U + nt * 32 + (lane & 1) * 16);     // unconditional: see the pair kernels
     };
     prefetch(0);
     const bool trc = nt == 0 && rt == 0;
@@ -415,6 +416,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);
     float cp[16];
     const int srow = lane >> 3, spc = lane & 7, prow = lane >> 1;
+    const uint8_t* __restrict__ mask_or_c = drop ? A.mask : reinterpret_cast<const uint8_t*>(A.c);
     auto prefetch = [&](int t) {
         const float* pb = A.c + (size_t)(t > 0 ? t - 1 : 0) * us + (size_t)(m0 + srow) * U + nt * 32 + spc * 4;
         const float* db = A.dh_ext + (size_t)t * us + (size_t)(m0 + srow) * U + nt * 32 + spc * 4;
@@ -423,7 +425,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             cq[j] = *reinterpret_cast<const float4*>(pb + (size_t)(8 * j) * U);
             dq[j] = *reinterpret_cast<const float4*>(db + (size_t)(8 * j) * U);
         }
-        if (drop) mq = *reinterpret_cast<const uint4*>(A.mask + (size_t)t * us + (size_t)(m0 + prow) * U + nt * 32 + (lane & 1) * 16);
+        mq = *reinterpret_cast<const uint4*>(mask_or_c + (size_t)t * us + (size_t)(m0 + prow) * U + nt * 32 + (lane & 1) * 16);     // unconditional: see the pair kernels
         const char* gb = reinterpret_cast<const char*>(A.gates + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og / 2;
 #pragma unroll
         for (int k = 0; k < 16; ++k) gv[k] = *reinterpret_cast<const uint2*>(gb + (size_t)rp_krow(k) * 8 * U);
@@ -643,12 +645,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int k = 0; k < 8; ++k) { creg[k] = 0.f; mk[k] = 0u; }
+    const uint8_t* __restrict__ mask_or_c = drop ? A.mask : reinterpret_cast<const uint8_t*>(A.c);
     auto prefetch = [&](int t) {
         constexpr int XS = XB ? 2 : 4;              // bytes per stored value
         const char* xb = reinterpret_cast<const char*>(A.xproj) + ((size_t)t * 4 * us + (size_t)m0 * 4 * U) * XS + og / (4 / XS);
 #pragma unroll
         for (int k = 0; k < 8; ++k) xv[k] = *reinterpret_cast<const typename RpX<XB, F>::T*>(xb + (size_t)rp_krow(k) * 4 * XS * U);
-        if (drop && lane < 32) mq = *reinterpret_cast<const uint4*>(A.mask + (size_t)t * us + (size_t)(m0 + 16 * half + (lane >> 1)) * U + nt * 32 + (lane & 1) * 16);
+        // (every lane loads -- the upper half repeats the lower half's 16 bytes: under a lane predicate the compiler moved the loaded registers
+        // and put an s_waitcnt vmcnt(0) in front of the moves, a full drain of the hand-off stores and prefetches just issued, once per timestep)
+        // Unconditional as well (without a mask the same offsets are read from c, which is four times as large, and the result is ignored): a
+        // conditionally assigned mq became a phi whose operands sat in different registers -- same moves, same drain.
+        mq = *reinterpret_cast<const uint4*>(mask_or_c + (size_t)t * us + (size_t)(m0 + 16 * half + ((lane & 31) >> 1)) * U + nt * 32 + (lane & 1) * 16);
     };
     prefetch(0);
     const bool trc = nt == 0 && rt == 0 && half == 0;
@@ -880,6 +887,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     uint4 mq = make_uint4(0u, 0u, 0u, 0u);
     float cp[8];
     const int srow = lane >> 3, spc = lane & 7;
+    const uint8_t* __restrict__ mask_or_c = drop ? A.mask : reinterpret_cast<const uint8_t*>(A.c);
     auto prefetch = [&](int t) {
         const float* pb = A.c + (size_t)(t > 0 ? t - 1 : 0) * us + (size_t)(m0 + 16 * half + srow) * U + nt * 32 + spc * 4;
         const float* db = A.dh_ext + (size_t)t * us + (size_t)(m0 + 16 * half + srow) * U + nt * 32 + spc * 4;
@@ -888,7 +896,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             cq[j] = *reinterpret_cast<const float4*>(pb + (size_t)(8 * j) * U);
             dq[j] = *reinterpret_cast<const float4*>(db + (size_t)(8 * j) * U);
         }
-        if (drop && lane < 32) mq = *reinterpret_cast<const uint4*>(A.mask + (size_t)t * us + (size_t)(m0 + 16 * half + (lane >> 1)) * U + nt * 32 + (lane & 1) * 16);
+        // (every lane loads -- the upper half repeats the lower half's 16 bytes: under a lane predicate the compiler moved the loaded registers
+        // and put an s_waitcnt vmcnt(0) in front of the moves, a full drain of the hand-off stores and prefetches just issued, once per timestep)
+        // Unconditional as well (without a mask the same offsets are read from c, which is four times as large, and the result is ignored): a
+        // conditionally assigned mq became a phi whose operands sat in different registers -- same moves, same drain.
+        mq = *reinterpret_cast<const uint4*>(mask_or_c + (size_t)t * us + (size_t)(m0 + 16 * half + ((lane & 31) >> 1)) * U + nt * 32 + (lane & 1) * 16);
         const char* gb = reinterpret_cast<const char*>(A.gates + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og / 2;
 #pragma unroll
         for (int k = 0; k < 8; ++k) gv[k] = *reinterpret_cast<const uint2*>(gb + (size_t)rp_krow(k) * 8 * U);
