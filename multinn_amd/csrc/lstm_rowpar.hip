@@ -661,6 +661,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const bool trc = nt == 0 && rt == 0 && half == 0;
     for (int t = 0; t < T; ++t) {
         RP_TR(0, trc, t, 0);
+        // The keep bytes reach their lanes HERE, in front of the flag wait (the time a wave spends waiting anyway): behind the h loads the
+        // compiler put s_waitcnt vmcnt(0) in front of this LDS store (the keep bytes were requested a step ago, but the wait it chose also
+        // covered the h loads just issued), and the MFMA chain started only when the last of them had landed.
+        if (drop) {                                 // keep bytes of this wave's 16 rows through its (idle) h tile
+            uint8_t* mt = reinterpret_cast<uint8_t*>(&sH[0][0]);
+            RP_LDS_FENCE();
+            if (lane < 32) *reinterpret_cast<uint4*>(mt + (lane >> 1) * 32 + (lane & 1) * 16) = mq;
+            RP_LDS_FENCE();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mk[k] = mt[(rp_krow(k) + 4 * hh) * 32 + r];
+            RP_LDS_FENCE();
+        }
         if (t > 0 && !rp_wait(flags, status, 2 * nb, (unsigned)t)) return;
         RP_TR(0, trc, t, 1);
         typename F::x8 a[KS];
@@ -681,15 +693,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 16; ++k) { acc[0][k] = 0.f; acc[1][k] = 0.f; }
-        if (drop) {                                 // keep bytes of this wave's 16 rows through its (idle) h tile
-            uint8_t* mt = reinterpret_cast<uint8_t*>(&sH[0][0]);
-            RP_LDS_FENCE();
-            if (lane < 32) *reinterpret_cast<uint4*>(mt + (lane >> 1) * 32 + (lane & 1) * 16) = mq;
-            RP_LDS_FENCE();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) mk[k] = mt[(rp_krow(k) + 4 * hh) * 32 + r];
-            RP_LDS_FENCE();
-        }
         typename F::x8 bq[2][2];
 #pragma unroll
         for (int g = 0; g < 2; ++g) bq[0][g] = __builtin_bit_cast(typename F::x8, wl[((g0 + g) * KS + 0) * 64 + lane]);
