@@ -237,7 +237,7 @@ def step_roofline(N, D, precision, t_step_s, sig_peak, phase_ms, nnz_row, nade_f
       dense     SURVEY 8(d): D Hn + D sigmoids forward, D Hn recomputed backward, against the sigmoid rate MEASURED here -- what a kernel that
                 evaluated every hidden state of the reference formulation would need.  The kernels do NOT: `a` only moves where v = 1.
       executed  per row with nnz active visibles: sigmoids 2 (1 + nnz) Hn + 2 D; vector FMAs: decoder dots D Hn forward (0 when they run on
-                the matrix cores) + 2 D Hn backward + 2 nnz Hn encoder adds; MFMA flops 2 x 2 D Hn when the forward is the matrix-core form.
+                the matrix cores) + 2 D Hn backward + 2 nnz Hn encoder adds; MFMA flops 2 x 2 D Hn when the forward is the matrix-core form (x 3 for the fp16 mode's hi + lo operand pairs).
                 T_min = FMAs / f32 vector peak + sigmoids / measured sigmoid rate + MFMA flops / MFMA peak (they share the SIMDs: additive).
     roofline.step.frac = sum of the EXECUTED T_min over the measured step time; "invalid" when any executed phase fraction exceeds 1."""
     R1, R2 = UNITS
@@ -255,8 +255,10 @@ def step_roofline(N, D, precision, t_step_s, sig_peak, phase_ms, nnz_row, nade_f
     t2_dense = max(sig_dense / sig_peak, bytes_nade / (PEAK_HBM_GBS * 1e9))
     # executed accounting of the scan
     sig_exec = N * (2.0 * (1.0 + nnz_row) * HN + 2.0 * D)
-    fma_exec = N * ((0.0 if nade_fwd_form == "mfma" else 1.0) * D * HN + 2.0 * D * HN + 2.0 * nnz_row * HN)
-    mfma_exec = N * 4.0 * D * HN if nade_fwd_form == "mfma" else 0.0
+    on_mfma = nade_fwd_form.startswith("mfma")
+    fma_exec = N * ((0.0 if on_mfma else 1.0) * D * HN + 2.0 * D * HN + 2.0 * nnz_row * HN)
+    # the fp16 mode's split-operand form issues THREE 16-bit products per logit (hi.hi + hi.lo + lo.hi)
+    mfma_exec = N * 4.0 * D * HN * (3.0 if nade_fwd_form == "mfma-split3" else 1.0) if on_mfma else 0.0
     t2_exec = max(fma_exec / (PEAK_VALU_F32_TFLOPS * 1e12 / 2) + sig_exec / sig_peak + mfma_exec / (PEAK_MFMA_16_TFLOPS * 1e12),
                   bytes_nade / (PEAK_HBM_GBS * 1e9))
     phases = {
@@ -578,7 +580,8 @@ def main(argv=None):
     sig = sigmoid_peak(dev)
     phase_ms = {"nade_scan": sum(v[0] for k, v in per_call.items() if k.startswith(NADE_ENTRIES)),
                 "lstm_dense": sum(v[0] for k, v in per_call.items() if not k.startswith(NADE_ENTRIES))}
-    roof["step"] = step_roofline(N, D, a.precision, sec, sig["sigmoids_per_s"], phase_ms, nnz_row, "mfma" if nade_mfma_form else "valu")
+    roof["step"] = step_roofline(N, D, a.precision, sec, sig["sigmoids_per_s"], phase_ms, nnz_row,
+                                ("mfma-split3" if a.precision == "fp16" else "mfma") if nade_mfma_form else "valu")
     roof["step"]["sigmoid_peak"] = sig
     roof["step"]["rho"] = a.rho
 
