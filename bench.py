@@ -224,7 +224,7 @@ def sigmoid_peak(dev):
                 source="mnn_probe_sigmoid timed with HIP events in this run (8 chains/thread, 8 waves/SIMD)")
 
 
-NADE_ENTRIES = ("mnn_nade_logprob", "mnn_density_gate", "mnn_nade_split_pack")
+NADE_ENTRIES = ("mnn_nade_logprob", "mnn_density_gate", "mnn_nade_f32_pack")
 
 
 def step_roofline(N, D, precision, t_step_s, sig_peak, phase_ms, nnz_row, nade_fwd_form):
