@@ -59,6 +59,9 @@ const char* mnn_last_error(void);
  * ------------------------------------------------------------------------------------------ */
 #define MNN_GEMM_ACCUMULATE 1
 #define MNN_GEMM_ATOMIC 2
+#define MNN_GEMM_A_KMAJOR 4   /* A is given K-major: [K][M] row-major, lda = elements per k row (>= M).  16-bit operands, M % 256 == 0,
+                               * K % 64 == 0.  Lets a producer that writes dz [rows, 4u] row-major feed the weight-gradient GEMM dz^T . X
+                               * without a transposed copy (rnn.py:60-62 kernel gradient).  B and C as usual. */
 int mnn_gemm_tn(mnn_stream_t s, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                 void* C, int ldc, int c_dtype, const float* bias, int flags, int split_k);
 

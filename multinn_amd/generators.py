@@ -235,20 +235,23 @@ class LstmStack:
         for l in range(len(self.packed) - 1, -1, -1):
             p, cx = self.packed[l], ctx[l]
             u = p["u"]
-            dzT = zalloc((4 * u, Np), device=dev, dtype=self.dtype)
-            dzc = torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype) if l > 0 else None
+            # K-major weight gradient: the GEMM reads dz row-major (transposed LDS reads), the launch writes no dz^T -- 64 lanes x 16 bytes to 64
+            # rows 512 KB apart per store instruction, 0.9 us per timestep on the backward chain
+            km = self.kmajor_wgrads and cx.get("catT") is not None and Np == N and ops.gemm_a_kmajor_ok(self.dtype, 4 * u, N)
+            dzT = None if km else zalloc((4 * u, Np), device=dev, dtype=self.dtype)
+            dzc = torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype) if (l > 0 or km) else None
             db_p = self._accum(l, dev)[2]
             e = ops.lstm2_bwd_layer(dh.view(T, B, u), p["wh_p"], cx["gates"], cx["c"], None, dzc, ops.lstm_seq_bwd_workspace(B, u, dev), dzT, db_p,
                                     cx["mask"] if keep_prob < 1.0 else None, gates_dtype=self.dtype)
             ops.lstm_rowpar_bwd(T, B, e, keep_prob, self._rp_workspace(l, T, B, dev))
-            st[l] = dict(dzT=dzT, db_p=db_p)
+            st[l] = dict(dzT=dzT, dzc=dzc, db_p=db_p)
             if l > 0:
                 dh = torch.empty((N, p["n_in"]), device=dev)
                 ops.gemm_tn(dzc.view(N, 4 * u), p["wx_p"], dh)
         if getattr(self, "keep_debug", False):
-            self._dbg_dzT = [s_["dzT"] for s_ in st]
-        keep = [self._weight_grads(l, ctx[l], st[l]["dzT"], st[l]["db_p"], T, B) for l in range(len(self.packed) - 1, -1, -1)]
-        return self._input_grad(st[0]["dzT"], T, B) if need_dx else None
+            self._dbg_dzT = [s_["dzT"] if s_["dzT"] is not None else s_["dzc"] for s_ in st]
+        keep = [self._weight_grads(l, ctx[l], st[l]["dzT"], st[l]["db_p"], T, B, dz=st[l]["dzc"]) for l in range(len(self.packed) - 1, -1, -1)]
+        return self._input_grad(st[0]["dzT"], T, B, dz=st[0]["dzc"]) if need_dx else None
 
     def _workspace(self, T, B, dev):
         """Flags + exchange area of the persistent launches, one per (T, B) (kept alive: captured graphs point at it)."""
@@ -374,14 +377,19 @@ class LstmStack:
         sk = int(max(1, min(target // max(tiles, 1), K // 1024)))
         return 1 << (sk.bit_length() - 1) if sk >= 8 else sk
 
-    def _weight_grads(self, l, cx, dzT, db_p, T, B):
+    # MULTINN_KMAJOR_WGRADS=1: the weight-gradient GEMM reads dz row-major (MNN_GEMM_A_KMAJOR) and the backward recurrence writes no dz^T.
+    # Measured at [1024,256,88,5] (profiles/round3_e_kmajor.md): recurrence backward 3.18 -> 2.82 ms, the two GEMMs +0.46 ms (the transposed
+    # LDS reads run the 256 x 256 tile ~20-40 % slower): no net gain, so the default stays the transposed copy.
+    kmajor_wgrads = os.environ.get("MULTINN_KMAJOR_WGRADS", "0") == "1"
+
+    def _weight_grads(self, l, cx, dzT, db_p, T, B, dz=None):
         """dWx^T[4u,ld] = dz^T . inp ; dWh^T[4u,u] = dz^T . h_prev  (reduction over the N rows); dzT [4u,Np] and
         h_prev^T come straight from the step kernels, db_p from their epilogue."""
         p = self.packed[l]
         u, ld, n_in = p["u"], p["ld"], p["n_in"]
         N = T * B
-        Np = dzT.shape[1]
-        dev = dzT.device
+        Np = dzT.shape[1] if dzT is not None else N
+        dev = db_p.device
         inT = cx.get("inT")                 # the producer's own transposed copy (persistent forward: y^T of the layer below)
         cat = cx.get("catT")
         if cat is not None:                 # [x^T ; h_prev^T] in one buffer (h^T is a view of it): one GEMM for both gradients
@@ -398,7 +406,10 @@ class LstmStack:
             # split 20 400 us, 16 461, 21 669, 24 613, 32 494 (scratch/gemm_merge_probe2.py)
             tiles = -(-4 * u // 256) * -(-(ld + u) // 256)
             sk = max(1, min(256 // tiles // 4 * 4 if 256 // tiles >= 4 else 256 // tiles, Np // 1024))
-            ops.gemm_tn(dzT, cat, dw_cat, accumulate=True, split_k=sk)
+            if dzT is None:                 # dz [N, 4u] row-major as the K-major A operand
+                ops.gemm_tn(dz.view(N, 4 * u), cat, dw_cat, accumulate=True, split_k=sk, a_kmajor=True)
+            else:
+                ops.gemm_tn(dzT, cat, dw_cat, accumulate=True, split_k=sk)
             ops.lstm_unpack_grads_cat(dw_cat, db_p, n_in, u, ld, self.store.gviews[f"{self.rnn.prefix}/cell_{l}/kernel"],
                                       self.store.gviews[f"{self.rnn.prefix}/cell_{l}/bias"])
             return (cat, dw_cat)
@@ -503,7 +514,7 @@ class LstmStack:
             main.wait_stream(s)
         return self._input_grad(st[0]["dzT"], T, B) if need_dx else None
 
-    def _input_grad(self, dzT0, T, B):
+    def _input_grad(self, dzT0, T, B, dz=None):
         """Gradient wrt the stack's inputs, f32 [T,B,n_in] = dz_0 . Wx_0^T (only the feedback modes consume it: the feedback vector is part of
         every per-track generator's input, multinn_feedback.py:85-91).  Every form of the recurrence leaves layer 0's dz as dz^T [4u, N]
         (the weight-gradient operand): one transpose pass makes the K-contiguous A operand."""
@@ -512,9 +523,12 @@ class LstmStack:
         if p.get("wx_p0") is None:          # [ld0, 4u]: the packed (gate-interleaved) input weights with K = 4u contiguous, once per pack
             p["wx_p0"] = torch.empty((p["ld"], 4 * p["u"]), device=dzT0.device, dtype=self.dtype)
             ops.transpose(p["wx_t"], p["wx_p0"])
-        dz = torch.empty((N, 4 * p["u"]), device=dzT0.device, dtype=self.dtype)
-        ops.transpose(dzT0[:, :N], dz)
-        dx = torch.empty((N, p["n_in"]), device=dzT0.device)
+        if dzT0 is None:
+            dz = dz.view(N, 4 * p["u"])
+        else:
+            dz = torch.empty((N, 4 * p["u"]), device=dzT0.device, dtype=self.dtype)
+            ops.transpose(dzT0[:, :N], dz)
+        dx = torch.empty((N, p["n_in"]), device=dz.device)
         ops.gemm_tn(dz, p["wx_p0"][:p["n_in"]], dx)
         return dx.view(T, B, p["n_in"])
 

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, U8, F16, GEMM_ACCUMULATE
+from ._lib import F32, BF16, U8, F16, GEMM_ACCUMULATE, GEMM_A_KMAJOR
 
 
 def call(name, *args):
@@ -51,19 +51,28 @@ def round_up(x, m):
 
 
 # ------------------------------------------------------------------------------------------------
-def gemm_tn(A, B, C_out, bias=None, accumulate=False, split_k=1):
-    """C[M,N] (+)= A[M,K] . B[N,K]^T (+bias).  A,B same dtype (f32/bf16), K-contiguous views."""
+def gemm_tn(A, B, C_out, bias=None, accumulate=False, split_k=1, a_kmajor=False):
+    """C[M,N] (+)= A[M,K] . B[N,K]^T (+bias).  A,B same dtype (f32/bf16/f16), K-contiguous views.  a_kmajor: A is given as [K, M] (row-major
+    over K: e.g. dz [rows, 4u] for the weight gradient dz^T . X), 16-bit, M % 256 == 0, K % 64 == 0 (`gemm_a_kmajor_ok`)."""
     _rowmajor(A, "gemm A"); _rowmajor(B, "gemm B"); _rowmajor(C_out, "gemm C")
     _req(A.dtype == B.dtype and A.dtype in (torch.float32,) + H16, "gemm: A/B must both be f32, bf16 or f16")
-    M, K = A.shape
+    if a_kmajor:
+        K, M = A.shape
+        _req(gemm_a_kmajor_ok(A.dtype, M, K), "gemm: a K-major A needs 16-bit operands, M % 256 == 0 and K % 64 == 0")
+    else:
+        M, K = A.shape
     N, K2 = B.shape
     _req(K == K2 and C_out.shape == (M, N), f"gemm: shape mismatch A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(C_out.shape)}")
     _req(C_out.dtype in (torch.float32,) + H16, "gemm: C must be f32/bf16/f16")
     if bias is not None:
         _req(bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous(), "gemm: bias must be f32[N]")
     call("mnn_gemm_tn", _stream(), dtype_code(A), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C_out), C_out.stride(0),
-         dtype_code(C_out), _ptr(bias), GEMM_ACCUMULATE if accumulate else 0, split_k)
+         dtype_code(C_out), _ptr(bias), (GEMM_ACCUMULATE if accumulate else 0) | (GEMM_A_KMAJOR if a_kmajor else 0), split_k)
     return C_out
+
+
+def gemm_a_kmajor_ok(dtype, M, K):
+    return dtype in H16 and M % 256 == 0 and K % 64 == 0
 
 
 def transpose(src, out):
@@ -275,7 +284,7 @@ def lstm2_bwd_layer(dh_ext, wh_p, gates, c, c0, dz_T, ws, dzT_t, db_p, mask=None
     _req(dz_T is None or (dz_T.shape == (T, B, N4) and dz_T.dtype == dt and dz_T.is_contiguous()), "lstm2 bwd: dz_T [T,B,4u] in the layer's 16-bit type")
     _req(dzT_t is None or (dzT_t.dim() == 2 and dzT_t.shape[0] == N4 and dzT_t.stride(1) == 1 and dzT_t.shape[1] >= T * B
                            and dzT_t.dtype == dt), "lstm2 bwd: dzT_t")
-    _req(db_p is None or (db_p.dtype == torch.float32 and db_p.numel() == N4 and dzT_t is not None), "lstm2 bwd: db_p")
+    _req(db_p is None or (db_p.dtype == torch.float32 and db_p.numel() == N4 and (dzT_t is not None or dz_T is not None)), "lstm2 bwd: db_p")
     _req(ws.numel() >= B * u * 4, "lstm2 bwd: workspace too small")
     _req(mask is None or (mask.dtype == torch.uint8 and mask.shape == (T, B, u) and mask.is_contiguous()), "lstm2 bwd: mask u8 [T,B,u]")
     _req(wx_p is None or (wx_p.dim() == 2 and wx_p.shape[1] == N4 and wx_p.is_contiguous() and wx_p.dtype == dt), "lstm2 bwd: wx_p [n_in,4u]")
