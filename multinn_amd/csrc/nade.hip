@@ -250,14 +250,16 @@ template <int HQ>
 __device__ __forceinline__ void bwd_gload(WStage<HQ>& st, const float* __restrict__ wd, const float* __restrict__ we, int i0, int D, int Hn, int ld) {
     if constexpr (HQ >= 2) {
         const int i = i0 + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;     // the visible is wave-uniform
-        const bool rowok = i >= 0 && i < D;                                                                  // scalar
-        const float* __restrict__ pd = wd + (size_t)(rowok ? i : 0) * ld + l;                                // uniform row base + lane
-        const float* __restrict__ pe = we + (size_t)(rowok ? i : 0) * ld + l;
+        // UNCONDITIONAL loads from clamped addresses (rows outside [0, D) and hidden units past the slice are never used: their visibles are
+        // skipped, their lanes never stored): a predicated load is a branch around the load, and the loads of a chunk then drain one by one
+        const int ic = min(max(i, 0), D - 1);                                                                // scalar
+        const float* __restrict__ pd = wd + (size_t)ic * ld;
+        const float* __restrict__ pe = we + (size_t)ic * ld;
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
-            const bool ok = rowok && l + 64 * q < Hn;
-            st.rd[q] = ok ? pd[64 * q] : 0.f;                // immediate offsets 0, 256, 512, 768 bytes
-            st.re[q] = ok ? pe[64 * q] : 0.f;
+            const int col = min(l + 64 * q, Hn - 1);
+            st.rd[q] = pd[col];
+            st.re[q] = pe[col];
         }
     } else {
         st.gload(wd, we, i0, D, Hn, ld);
@@ -344,13 +346,17 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
         const int i0 = (nch - 1 - cc) * 8;
         const int inext = i0 - 8 + fi;
         bwd_gload<HQ>(st, wd, we, i0 - 8, D, Hn, HnT);                             // next (lower) chunk, zeros below 0
-        bool vnext[RG];
-        float dnext[RG];
+        // the next chunk's v byte and d nll / d logit: RAW, unconditional loads (clamped index); they are looked at -- compared, masked -- only
+        // at the END of this chunk.  Evaluated here (`!= 0`, `valid ? x : 0`), each load was followed by s_waitcnt vmcnt(0): one full memory
+        // round trip per chunk, the weight prefetch just issued included
+        uint8_t vraw[RG];
+        float draw[RG];
         unsigned long long mask[RG], many = 0ull;
+        const int inc = max(inext, 0);
 #pragma unroll
         for (int g = 0; g < RG; ++g) {
-            vnext[g] = fvalid[g] && inext >= 0 && vm[(size_t)frr[g] * D + inext] != 0;
-            dnext[g] = (fvalid[g] && inext >= 0) ? d_bias[(size_t)frr[g] * ld_bias + dl_off + inext] : 0.f;
+            vraw[g] = vm[(size_t)frr[g] * D + inc];
+            draw[g] = d_bias[(size_t)frr[g] * ld_bias + dl_off + inc];
             mask[g] = __ballot(vcur[g]);
             many |= mask[g];
         }
@@ -479,7 +485,11 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
             }
         }
 #pragma unroll
-        for (int g = 0; g < RG; ++g) { vcur[g] = vnext[g]; dcur[g] = dnext[g]; }
+        for (int g = 0; g < RG; ++g) {
+            const bool ok = fvalid[g] && inext >= 0;
+            vcur[g] = ok && vraw[g] != 0;
+            dcur[g] = ok ? draw[g] : 0.f;
+        }
         if (NRED == 1) __syncthreads();
     }
 #pragma unroll

@@ -159,13 +159,19 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
     // flip (indirect register addressing); that frees 32 KiB of LDS (two workgroups per CU with the doubled state tiles) and takes the
     // LDS round trip out of every flip's read-modify-write
     float areg[SPLIT ? 32 : 1];
+    {
+        // all 32 encoder-bias loads in flight before the first is used (unconditional, from clamped rows): with `row < N ? load : 0` every
+        // load sat behind its own branch and s_waitcnt vmcnt(0) -- 32 memory round trips in a row at the start of every workgroup
+        float av[32];
 #pragma unroll
-    for (int n = 0; n < 32; ++n) {
-        const int row = rb + n;
-        const float av = row < N ? bias[(size_t)row * ld_bias + m * Hn + tid] : 0.f;
-        if constexpr (SPLIT) areg[n] = av;
-        else S.sA[n][tid] = av;
-        S.sH[n][tid] = nm_state<SPLIT>(fast_sigmoid(av));
+        for (int n = 0; n < 32; ++n) av[n] = bias[(size_t)min(rb + n, N - 1) * ld_bias + m * Hn + tid];
+#pragma unroll
+        for (int n = 0; n < 32; ++n) {
+            const float x = rb + n < N ? av[n] : 0.f;
+            if constexpr (SPLIT) areg[n] = x;
+            else S.sA[n][tid] = x;
+            S.sH[n][tid] = nm_state<SPLIT>(fast_sigmoid(x));
+        }
     }
     // v bytes of rows 8w .. 8w+7 of a tile: lane -> (row 8w + 2i + (lane >> 5), column lane & 31)
     auto load_v = [&](int c, unsigned char (&vb)[4]) {
@@ -261,6 +267,9 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
         float bdec[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) bdec[k] = bias[(size_t)err * ld_bias + bd_off + min(32 * c + ed0 + k, D - 1)];
+        // (Requesting these and the v bytes in the middle of the tile before instead -- so that the flip pass, whose generated waits drain the
+        // memory queue by its last flip, never waits at HBM latency -- was measured: 2.18 -> 2.25 ms, not kept.)
+        __builtin_amdgcn_sched_barrier(0);
         nm_logit_tile<SPLIT>(S.sH, w, lane, bfr, S.sLb);
         if (c + 1 < ntile) {
             ballots(c + 1, vb, S.sMask[nbuf]);               // v bytes requested one tile ago
@@ -376,6 +385,11 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
         } else if (F > 32 && c + 1 < ntile) {
             load_we(c + 1, nbuf, 0, wev);                    // the extra chunks overwrote the prefetched values
         }
+        // b_dec of this tile (requested at its top) is waited for HERE, in front of the w_dec request: the wait the compiler puts in front of
+        // the pointwise must hold on every path that reaches it (also the last tile's, which requests nothing), so it is `vmcnt(3)` -- placed
+        // behind the 16 w_dec loads it made the pointwise wait for all of them (2.47 -> 2.18 ms with the batched bias loads above)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm volatile("" :: "v"(bdec[k]));
         if (c + 1 < ntile) load_b(c + 1, bfr);               // the tile's MFMAs are issued: fetch the next tile's w_dec fragments under the pointwise
         NM_T(7);
         // ---- S3: pointwise of this thread's 4 pairs, once per tile ----
