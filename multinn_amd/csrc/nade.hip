@@ -310,12 +310,19 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
     // and recomputed only there, and sum_i dl_i * w_dec[i] is accumulated per constant-h segment (c) and
     // folded into G with ONE h(1-h) factor when the segment ends.  a_D comes from the forward kernel.
     float a[BWD_R][HQ], h[BWD_R][HQ], c[BWD_R][HQ], G[BWD_R][HQ];
+    // all a_D loads in flight together (unconditional, clamped row / hidden unit), masked afterwards: behind `valid ? load : 0` each load
+    // waited for its own round trip (s_waitcnt vmcnt(0) per element at the start of every workgroup)
+#pragma unroll
+    for (int r = 0; r < BWD_R; ++r)
+#pragma unroll
+        for (int q = 0; q < HQ; ++q)
+            a[r][q] = a_final[((size_t)m * N + min(rbase + r, N - 1)) * HnT + hb + min(lane + 64 * q, Hn - 1)];
 #pragma unroll
     for (int r = 0; r < BWD_R; ++r)
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
             const int j = lane + 64 * q, row = rbase + r;
-            a[r][q] = (row < N && j < Hn) ? a_final[((size_t)m * N + row) * HnT + hb + j] : 0.f;
+            if (!(row < N && j < Hn)) a[r][q] = 0.f;
             h[r][q] = fast_sigmoid(a[r][q]);
             G[r][q] = 0.f;
             c[r][q] = 0.f;
