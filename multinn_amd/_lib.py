@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MULTINN_HIP_LIB", os.path.join(HERE, "libmultinn_hip.so"))   # override: A/B builds of the same ABI
 
 F32, BF16, U8, F16 = 0, 1, 2, 3
-GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_A_KMAJOR = 1, 2, 4
+GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_A_KMAJOR, GEMM_A_KBLOCK32 = 1, 2, 4, 8
 
 _p, _i, _l, _f, _u64, _u32, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_uint32, C.c_size_t
 

@@ -339,26 +339,36 @@ __device__ __forceinline__ int swz(int row) { return CPR == 8 ? ((row >> 1) & 7)
 // This thread's LDS-DMA slots of one operand tile (ROWS rows x CPR 16-byte chunks, NW waves): the global address of every slot at
 // k = 0 is computed ONCE per workgroup (row clamp, swizzle, 64-bit row * ld); staging a K tile is then one 64-bit add per slot.
 // Recomputing them per K tile cost ~0.5 us of address arithmetic per tile in front of the 8 DMA instructions (profiles/tools/gemm_trace.hip).
-template <int ROWS, int NW, int CPR>
+// KB = the operand is stored K-BLOCKED: element (row, k) at ((k >> 5) * ld + row) * 32 + (k & 31), ld = its total row count -- 32 consecutive k of
+// one row are 64 contiguous bytes, and the 32 k of all rows of a block are one contiguous slab.  A producer that owns a (32-k block, row
+// range) -- the backward recurrence: 32 batch rows of one timestep x its 128 gate columns -- writes its piece of dz^T as whole contiguous
+// kilobytes instead of one 32-byte run per row (rows 512 KB apart).  The LDS image and everything behind it are the same as for the plain
+// K-contiguous operand (BK = 64 = two blocks: chunks 0..3 from block 2 kt, chunks 4..7 from block 2 kt + 1).
+template <int ROWS, int NW, int CPR, bool KB = false>
 struct GldsSlots {
     static constexpr int NS = ROWS * CPR / (64 * NW);
     const bf16_t* base;                                    // wave-uniform
     unsigned off[NS];                                       // element offset of the slot at k = 0 (operands stay below 2^31 elements)
+    unsigned kmul;                                          // KB: elements per unit of k0 (= ld); plain: 1
     __device__ __forceinline__ void init(const bf16_t* __restrict__ G, int ld, int rows_total, int r0, int wave, int lane) {
+        static_assert(!KB || CPR == 8, "the K-blocked layout is defined for 64-deep K tiles");
         base = G;
+        kmul = KB ? (unsigned)ld : 1u;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int p = (s * NW + wave) * 64 + lane;      // linear 16-byte slot of the tile image
             const int row = p / CPR, pc = p % CPR;
             const int c = pc ^ swz<CPR>(row);               // logical K chunk held by this slot
             const int gr = min(r0 + row, rows_total - 1);   // rows past the edge replicate the last row (never stored)
-            off[s] = (unsigned)gr * (unsigned)ld + (unsigned)(c * 8);
+            if (KB) off[s] = ((unsigned)(c >> 2) * (unsigned)ld + (unsigned)gr) * 32u + (unsigned)((c & 3) * 8);
+            else off[s] = (unsigned)gr * (unsigned)ld + (unsigned)(c * 8);
         }
     }
     __device__ __forceinline__ void stage(int k0, char* tile, int wave) const {
+        const bf16_t* b = base + (size_t)k0 * kmul;         // wave-uniform (K-blocked: 64 k = two blocks = 64 ld elements)
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-            __builtin_amdgcn_global_load_lds((gas_ptr_t)(base + (off[s] + (unsigned)k0)), (lds_ptr_t)(tile + (s * NW + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gas_ptr_t)(b + off[s]), (lds_ptr_t)(tile + (s * NW + wave) * 1024), 16, 0, 0);
     }
 };
 
@@ -492,7 +502,7 @@ __device__ long long gm_trace[16];
 #define GM_T(k) do { } while (0)
 #define GM_T0() do { } while (0)
 #endif
-template <typename F, bool AKM = false>
+template <typename F, bool AKM = false, bool AKB = false>
 __global__ void __launch_bounds__(512)
 gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c_bf16,
                        const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
@@ -518,7 +528,7 @@ gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    typename std::conditional<AKM, GldsSlotsKM<8>, GldsSlots<256, 8, CPR>>::type slotA;
+    typename std::conditional<AKM, GldsSlotsKM<8>, GldsSlots<256, 8, CPR, AKB>>::type slotA;
     GldsSlots<256, 8, CPR> slotB;
     if constexpr (AKM) slotA.init(A, lda, m0, wave, lane);          // A given K-major [K][M] (M % 256 == 0: no row clamp)
     else slotA.init(A, lda, M, m0, wave, lane);
@@ -625,6 +635,22 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
         // A persistent ring form of this tile (4 LDS slots of 32-deep sub-tiles, counted vmcnt, raw barriers) was measured in round 3 and is NOT
         // shipped (profiles/round3_b_gemm_ablation.md): slower on K = 448 .. 1024 and on the K = 262144 weight gradients, because the operand
         // stream arrives at ~34 GB/s per CU whatever is in flight; its one win (K = 256, the Dense forward) needs an N-edge epilogue at N = 704.
+        if (flags & MNN_GEMM_A_KBLOCK32) {                  // A stored K-blocked: the 256 x 256 tile, only the LDS-DMA source addresses differ
+            using F = typename FlavorOf<T>::type;
+            static bool attr_kb[64];
+            int dev = 0;
+            MNN_HIP(hipGetDevice(&dev));
+            MNN_REQUIRE(dev >= 0 && dev < 64, "mnn_gemm_tn: device index %d", dev);
+            if (!attr_kb[dev]) {
+                MNN_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds256_kernel<F, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128));
+                attr_kb[dev] = true;
+            }
+            dim3 grid2(cdiv(ntm2, 8) * 8 * ntn2, split_k);
+            hipLaunchKernelGGL((gemm_tn_glds256_kernel<F, false, true>), grid2, dim3(512), 4 * 256 * 128, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C,
+                               ldc, c_bf16, bias, M, N, K, flags, split_k, ntm2, ntn2);
+            MNN_LAUNCH_CHECK();
+            return MNN_OK;
+        }
         if (flags & MNN_GEMM_A_KMAJOR) {                    // A given as [K][M]: the 256 x 256 tile with transposed LDS reads (checked by the caller)
             using F = typename FlavorOf<T>::type;
             static bool attr_km[64];
@@ -679,7 +705,11 @@ extern "C" int mnn_gemm_tn(mnn_stream_t s, int dtype, int M, int N, int K, const
     const int al = dtype == MNN_F32 ? 4 : 8;
     MNN_REQUIRE(K % al == 0 && lda % al == 0 && ldb % al == 0, "mnn_gemm_tn: K/lda/ldb must be multiples of %d (K=%d lda=%d ldb=%d)",
                 al, K, lda, ldb);
-    if (flags & MNN_GEMM_A_KMAJOR) {
+    if (flags & MNN_GEMM_A_KBLOCK32) {
+        MNN_REQUIRE(dtype != MNN_F32 && !(flags & MNN_GEMM_A_KMAJOR) && K % 64 == 0 && lda >= M && ldb >= K && ldc >= N &&
+                    (size_t)K * (size_t)lda < ((size_t)1 << 32),
+                    "mnn_gemm_tn: a K-blocked A needs 16-bit operands, K %% 64 == 0, lda (its row count) >= M, K * lda < 2^32 (M=%d K=%d lda=%d)", M, K, lda);
+    } else if (flags & MNN_GEMM_A_KMAJOR) {
         MNN_REQUIRE(dtype != MNN_F32 && M % 256 == 0 && K % 64 == 0 && lda >= M && ldb >= K && ldc >= N,
                     "mnn_gemm_tn: a K-major A needs 16-bit operands, M %% 256 == 0, K %% 64 == 0, lda >= M (M=%d K=%d lda=%d)", M, K, lda);
     } else {

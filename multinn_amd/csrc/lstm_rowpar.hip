@@ -556,8 +556,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int p = j * 64 + lane, gu = p >> 2, piece = p & 3;
-                *reinterpret_cast<uint4*>(A.dzT + (size_t)(nt * 128 + gu) * A.ld_t + (size_t)t * B + m0 + piece * 8) =
-                    *reinterpret_cast<const uint4*>(&sT[gu >> 5][gu & 31][piece * 8]);
+                // ld_t == 0: the K-BLOCKED layout [T B / 32][4U][32] (mnn_gemm_tn, MNN_GEMM_A_KBLOCK32): this wave's 128 columns x 32 rows are one
+                // contiguous 8 KB slab of block t B / 32 + rt -- every store instruction writes a whole kilobyte
+                bf16_t* dst = A.ld_t == 0 ? A.dzT + (((size_t)t * (B >> 5) + rt) * (4 * U) + nt * 128 + gu) * 32 + piece * 8
+                                          : A.dzT + (size_t)(nt * 128 + gu) * A.ld_t + (size_t)t * B + m0 + piece * 8;
+                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sT[gu >> 5][gu & 31][piece * 8]);
             }
             behind += 8;
         }
@@ -1064,8 +1067,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int p = j * 64 + lane, gu = p >> 1, piece = p & 1;
-                *reinterpret_cast<uint4*>(A.dzT + (size_t)(nt * 128 + gu) * A.ld_t + (size_t)t * B + m0 + 16 * half + piece * 8) =
-                    *reinterpret_cast<const uint4*>(sT + gu * 8 + piece * 4);
+                // ld_t == 0: the K-BLOCKED layout [T B / 32][4U][32] (see the one-wave kernel): the pair's two halves interleave 32-byte runs
+                // inside one contiguous 8 KB slab
+                bf16_t* dst = A.ld_t == 0 ? A.dzT + (((size_t)t * (B >> 5) + rt) * (4 * U) + nt * 128 + gu) * 32 + 16 * half + piece * 8
+                                          : A.dzT + (size_t)(nt * 128 + gu) * A.ld_t + (size_t)t * B + m0 + 16 * half + piece * 8;
+                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(sT + gu * 8 + piece * 4);
             }
             behind += 4;
         }
@@ -1227,7 +1233,8 @@ extern "C" int mnn_lstm_rowpar_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_
                                                  "device's workgroups (B=%d u=%d)", B, U);
     MNN_REQUIRE(L->dh_ext && L->wh_p && L->gates && L->c, "mnn_lstm_rowpar_bwd: null pointer");
     MNN_REQUIRE(L->c0 == nullptr && L->dz == nullptr, "mnn_lstm_rowpar_bwd: no initial state / f32 dz output in this form");
-    MNN_REQUIRE(L->dzT_t == nullptr || (L->ld_t >= T * B && (L->ld_t & 7) == 0), "mnn_lstm_rowpar_bwd: ld_t too small / not a multiple of 8");
+    MNN_REQUIRE(L->dzT_t == nullptr || L->ld_t == 0 || (L->ld_t >= T * B && (L->ld_t & 7) == 0),
+                "mnn_lstm_rowpar_bwd: ld_t too small / not a multiple of 8 (0 = the K-blocked layout [T*B/32][4u][32])");
     a.dh_ext = L->dh_ext; a.wh_p = (const bf16_t*)L->wh_p; a.gates = (const bf16_t*)L->gates; a.c = L->c; a.mask = L->mask;
     a.dzc = (bf16_t*)L->dz_T; a.dzT = (bf16_t*)L->dzT_t; a.ld_t = L->ld_t; a.db_p = L->db_p;
     a.sync = (unsigned*)workspace; a.dzx0 = (const char*)workspace + rp_sync_bytes(a.nrt); a.dzx = (char*)workspace + rp_xchg_off(a.nrt, U);

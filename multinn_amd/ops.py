@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, U8, F16, GEMM_ACCUMULATE, GEMM_A_KMAJOR
+from ._lib import F32, BF16, U8, F16, GEMM_ACCUMULATE, GEMM_A_KMAJOR, GEMM_A_KBLOCK32
 
 
 def call(name, *args):
@@ -51,23 +51,33 @@ def round_up(x, m):
 
 
 # ------------------------------------------------------------------------------------------------
-def gemm_tn(A, B, C_out, bias=None, accumulate=False, split_k=1, a_kmajor=False):
+def gemm_tn(A, B, C_out, bias=None, accumulate=False, split_k=1, a_kmajor=False, a_kblock=False):
     """C[M,N] (+)= A[M,K] . B[N,K]^T (+bias).  A,B same dtype (f32/bf16/f16), K-contiguous views.  a_kmajor: A is given as [K, M] (row-major
-    over K: e.g. dz [rows, 4u] for the weight gradient dz^T . X), 16-bit, M % 256 == 0, K % 64 == 0 (`gemm_a_kmajor_ok`)."""
-    _rowmajor(A, "gemm A"); _rowmajor(B, "gemm B"); _rowmajor(C_out, "gemm C")
+    over K: e.g. dz [rows, 4u] for the weight gradient dz^T . X), 16-bit, M % 256 == 0, K % 64 == 0 (`gemm_a_kmajor_ok`).  a_kblock: A is
+    given K-blocked, a contiguous [K/32, rows >= M, 32] tensor (element (m, k) at [k // 32, m, k % 32]), 16-bit, K % 64 == 0."""
+    _rowmajor(B, "gemm B"); _rowmajor(C_out, "gemm C")
     _req(A.dtype == B.dtype and A.dtype in (torch.float32,) + H16, "gemm: A/B must both be f32, bf16 or f16")
-    if a_kmajor:
+    if a_kblock:
+        _req(A.dim() == 3 and A.is_contiguous() and A.shape[2] == 32 and A.dtype in H16 and not a_kmajor, "gemm: a K-blocked A is a contiguous 16-bit [K/32, rows, 32]")
+        K, M, lda = A.shape[0] * 32, C_out.shape[0], A.shape[1]
+        _req(M <= lda and K % 64 == 0, "gemm: K-blocked A: rows >= M, K % 64 == 0")
+    elif a_kmajor:
+        _rowmajor(A, "gemm A")
         K, M = A.shape
+        lda = A.stride(0)
         _req(gemm_a_kmajor_ok(A.dtype, M, K), "gemm: a K-major A needs 16-bit operands, M % 256 == 0 and K % 64 == 0")
     else:
+        _rowmajor(A, "gemm A")
         M, K = A.shape
+        lda = A.stride(0)
     N, K2 = B.shape
     _req(K == K2 and C_out.shape == (M, N), f"gemm: shape mismatch A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(C_out.shape)}")
     _req(C_out.dtype in (torch.float32,) + H16, "gemm: C must be f32/bf16/f16")
     if bias is not None:
         _req(bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous(), "gemm: bias must be f32[N]")
-    call("mnn_gemm_tn", _stream(), dtype_code(A), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C_out), C_out.stride(0),
-         dtype_code(C_out), _ptr(bias), (GEMM_ACCUMULATE if accumulate else 0) | (GEMM_A_KMAJOR if a_kmajor else 0), split_k)
+    flags = (GEMM_ACCUMULATE if accumulate else 0) | (GEMM_A_KMAJOR if a_kmajor else 0) | (GEMM_A_KBLOCK32 if a_kblock else 0)
+    call("mnn_gemm_tn", _stream(), dtype_code(A), M, N, K, _ptr(A), lda, _ptr(B), B.stride(0), _ptr(C_out), C_out.stride(0),
+         dtype_code(C_out), _ptr(bias), flags, split_k)
     return C_out
 
 
@@ -282,8 +292,9 @@ def lstm2_bwd_layer(dh_ext, wh_p, gates, c, c0, dz_T, ws, dzT_t, db_p, mask=None
     _req(gates.shape == (T, B, N4) and gates.dtype == gates_dtype and gates.is_contiguous(), "lstm2 bwd: gates")
     _req(c.shape == (T, B, u) and c.dtype == torch.float32 and c.is_contiguous(), "lstm2 bwd: c")
     _req(dz_T is None or (dz_T.shape == (T, B, N4) and dz_T.dtype == dt and dz_T.is_contiguous()), "lstm2 bwd: dz_T [T,B,4u] in the layer's 16-bit type")
-    _req(dzT_t is None or (dzT_t.dim() == 2 and dzT_t.shape[0] == N4 and dzT_t.stride(1) == 1 and dzT_t.shape[1] >= T * B
-                           and dzT_t.dtype == dt), "lstm2 bwd: dzT_t")
+    kblock = dzT_t is not None and dzT_t.dim() == 3         # [T*B/32, 4u, 32]: the K-blocked layout (row-parallel form only; ld_t = 0 in the ABI)
+    _req(dzT_t is None or (kblock and dzT_t.shape == (T * B // 32, N4, 32) and dzT_t.is_contiguous() and dzT_t.dtype == dt and B % 32 == 0)
+         or (dzT_t.dim() == 2 and dzT_t.shape[0] == N4 and dzT_t.stride(1) == 1 and dzT_t.shape[1] >= T * B and dzT_t.dtype == dt), "lstm2 bwd: dzT_t")
     _req(db_p is None or (db_p.dtype == torch.float32 and db_p.numel() == N4 and (dzT_t is not None or dz_T is not None)), "lstm2 bwd: db_p")
     _req(ws.numel() >= B * u * 4, "lstm2 bwd: workspace too small")
     _req(mask is None or (mask.dtype == torch.uint8 and mask.shape == (T, B, u) and mask.is_contiguous()), "lstm2 bwd: mask u8 [T,B,u]")
@@ -291,7 +302,7 @@ def lstm2_bwd_layer(dh_ext, wh_p, gates, c, c0, dz_T, ws, dzT_t, db_p, mask=None
     for t in (wh_p, gates, c, ws):
         _ptr(t)
     return _lib.LstmBwdLayer(u, _p0(dh_ext), _p0(wh_p), _p0(gates), _p0(c), _p0(c0), None, _p0(dz_T), _p0(ws), _p0(dzT_t),
-                             dzT_t.stride(0) if dzT_t is not None else 0, _p0(db_p), _p0(mask), _p0(wx_p), 1 if dt == torch.float16 else 0)
+                             dzT_t.stride(0) if (dzT_t is not None and not kblock) else 0, _p0(db_p), _p0(mask), _p0(wx_p), 1 if dt == torch.float16 else 0)
 
 
 def lstm2_seq_bwd(T, B, L1, L2, keep_prob, k_begin=0, k_end=None):

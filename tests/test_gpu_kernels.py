@@ -118,6 +118,31 @@ def test_gemm_tn_a_kmajor(ops, M, N, K, split_k, dt):
         ops.gemm_tn(Akm[:, :128].contiguous(), Bt, torch.zeros((128, N), device=DEV), a_kmajor=True)
 
 
+@pytest.mark.parametrize("M,N,K,split_k,rows", [(256, 192, 64, 1, 256), (300, 704, 4096, 1, 320), (2048, 960, 16384, 8, 2048), (1024, 768, 16384, 20, 1024)])
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_gemm_tn_a_kblock(ops, M, N, K, split_k, rows, dt):
+    """A stored K-blocked ([K/32, rows, 32]: the layout the backward recurrence writes dz^T in) against the K-contiguous form on the same
+    values: bit-identical operands in LDS, so the results agree to the split-K summation order; also against torch's f32 product."""
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    A = (torch.randn((rows, K), device=DEV, generator=g) * 0.5).to(tdt)
+    A[min(37, M - 1)] = 0
+    A[min(37, M - 1), K // 2 + 3] = 1.0
+    Akb = A.view(rows, K // 32, 32).permute(1, 0, 2).contiguous()
+    Bt = (torch.randn((N, K), device=DEV, generator=g) * 0.5).to(tdt)
+    ref = A[:M].float() @ Bt.float().T
+    scale = float(ref.abs().max())
+    C = torch.zeros((M + 1, N), device=DEV)
+    C[M] = 7.0
+    ops.gemm_tn(Akb, Bt, C[:M], accumulate=True, split_k=split_k, a_kblock=True)
+    assert float((C[:M] - ref).abs().max()) < 2e-5 * scale * max(1, K // 1024)
+    assert bool((C[M] == 7.0).all())
+    if split_k == 1:
+        C2 = torch.zeros((M, N), device=DEV)
+        ops.gemm_tn(A[:M], Bt, C2, accumulate=True)
+        assert torch.equal(C[:M], C2) or float((C[:M] - C2).abs().max()) < 1e-6 * scale
+
+
 def test_gemm_strided_views_and_errors(ops):
     R = np.random.default_rng(0)
     A = dev(R.standard_normal((50, 96)).astype(np.float32))
