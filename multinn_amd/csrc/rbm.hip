@@ -17,28 +17,37 @@ __device__ __forceinline__ uint32_t rbm_rowid(const uint32_t* __restrict__ row_i
 // out-unit phase: for each output unit `o` (strided over threads) and each of the block's rows
 //   z[r] = sum_{k asc} in[r][k] * Wk[k*ldw + o]  + bias[row r][o]
 // in_s: LDS [RBM_R][Kpad] f32 (Kpad multiple of 4, zero padded).  Calls fn(r, o, z).
+// The bias rows bias[(n0 + r) * ld_bias + o] (ld_bias = 0: one shared row) are REQUESTED in front of the K loop and added behind it; the
+// weights come 16 k at a time, unconditionally (k clamped: the inputs are zero past K, so the clamped weight contributes fma(0, w, acc) = acc
+// exactly -- same ascending fma chain, bit for bit).  Round 3: with `k < K ? load : 0` per weight and the bias loaded inside the per-row
+// callback every load was waited for on its own (s_waitcnt vmcnt(0) per element: 4 + 8 memory round trips per 4 k).
 template <typename F>
 __device__ __forceinline__ void rbm_phase(const float* __restrict__ in_s, int Kpad, int K, const float* __restrict__ Wk, int ldw, int n_out,
-                                          F&& fn) {
+                                          const float* __restrict__ bias, int ld_bias, int n0, int N, F&& fn) {
     for (int o = threadIdx.x; o < n_out; o += blockDim.x) {
-        float acc[RBM_R];
+        float acc[RBM_R], bb[RBM_R];
 #pragma unroll
-        for (int r = 0; r < RBM_R; ++r) acc[r] = 0.f;
-        for (int k0 = 0; k0 < K; k0 += 4) {
-            float w[4];
+        for (int r = 0; r < RBM_R; ++r) { acc[r] = 0.f; bb[r] = bias[(size_t)min(n0 + r, N - 1) * ld_bias + o]; }
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            float w[16];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) w[kk] = (k0 + kk < K) ? Wk[(size_t)(k0 + kk) * ldw + o] : 0.f;
+            for (int kk = 0; kk < 16; ++kk) w[kk] = Wk[(size_t)min(k0 + kk, K - 1) * ldw + o];
 #pragma unroll
-            for (int r = 0; r < RBM_R; ++r) {
-                const float4 x = *reinterpret_cast<const float4*>(in_s + r * Kpad + k0);
-                acc[r] = fmaf(x.x, w[0], acc[r]);
-                acc[r] = fmaf(x.y, w[1], acc[r]);
-                acc[r] = fmaf(x.z, w[2], acc[r]);
-                acc[r] = fmaf(x.w, w[3], acc[r]);
+            for (int q = 0; q < 4; ++q) {
+                if (k0 + 4 * q < K) {                       // block-uniform; Kpad covers the quad
+#pragma unroll
+                    for (int r = 0; r < RBM_R; ++r) {
+                        const float4 x = *reinterpret_cast<const float4*>(in_s + r * Kpad + k0 + 4 * q);
+                        acc[r] = fmaf(x.x, w[4 * q + 0], acc[r]);
+                        acc[r] = fmaf(x.y, w[4 * q + 1], acc[r]);
+                        acc[r] = fmaf(x.z, w[4 * q + 2], acc[r]);
+                        acc[r] = fmaf(x.w, w[4 * q + 3], acc[r]);
+                    }
+                }
             }
         }
 #pragma unroll
-        for (int r = 0; r < RBM_R; ++r) fn(r, o, acc[r]);
+        for (int r = 0; r < RBM_R; ++r) fn(r, o, acc[r] + bb[r]);
     }
 }
 
@@ -78,19 +87,19 @@ rbm_gibbs_kernel(int N, int D, int Hn, int k, const uint8_t* __restrict__ v0, co
         return;
     }
     for (int it = 0; it < k; ++it) {
-        rbm_phase(vs, Dp, D, W, Hn, Hn, [&](int r, int j, float acc) {
+        rbm_phase(vs, Dp, D, W, Hn, Hn, bh, ld_bh, n0, N, [&](int r, int j, float z) {
             const int n = n0 + r;
             if (n >= N) return;
-            const float p = det_sigmoid(acc + bh[(size_t)n * ld_bh + j]);
+            const float p = det_sigmoid(z);
             const float u = philox_uniform1(seed, MNN_STREAM_RBM_H, rbm_rowid(row_ids, row0, n), sub0 + (uint32_t)it, (uint32_t)j);
             hs[r * Hp + j] = u < p ? 1.f : 0.f;
         });
         __syncthreads();
         const bool last = it == k - 1;
-        rbm_phase(hs, Hp, Hn, Wt, D, D, [&](int r, int d, float acc) {
+        rbm_phase(hs, Hp, Hn, Wt, D, D, bv, ld_bv, n0, N, [&](int r, int d, float z) {
             const int n = n0 + r;
             if (n >= N) return;
-            const float p = det_sigmoid(acc + bv[(size_t)n * ld_bv + d]);
+            const float p = det_sigmoid(z);
             const float u = philox_uniform1(seed, MNN_STREAM_RBM_V, rbm_rowid(row_ids, row0, n), sub0 + (uint32_t)it, (uint32_t)d);
             const float s = u < p ? 1.f : 0.f;
             vs[r * Dp + d] = s;
@@ -294,10 +303,10 @@ rbm_half_kernel(int N, int K, int n_out, const TV* __restrict__ in, const float*
     const int n0 = blockIdx.x * RBM_R;
     rbm_load_rows<TV>(in, N, n0, K, Kp, smem);
     __syncthreads();
-    rbm_phase(smem, Kp, K, Wk, ldw, n_out, [&](int r, int o, float acc) {
+    rbm_phase(smem, Kp, K, Wk, ldw, n_out, b, ld_b, n0, N, [&](int r, int o, float z) {
         const int n = n0 + r;
         if (n >= N) return;
-        const float p = det_sigmoid(acc + b[(size_t)n * ld_b + o]);
+        const float p = det_sigmoid(z);
         if (p_out) p_out[(size_t)n * n_out + o] = p;
         if (s_out) {
             const float u = philox_uniform1(seed, (uint32_t)stream_id, row0 + (uint32_t)n, sub, (uint32_t)o);
@@ -355,9 +364,9 @@ rbm_free_energy_kernel(int N, int D, int Hn, const uint8_t* __restrict__ v, cons
     float part[RBM_R];
 #pragma unroll
     for (int r = 0; r < RBM_R; ++r) part[r] = 0.f;
-    rbm_phase(smem, Dp, D, W, Hn, Hn, [&](int r, int j, float acc) {
+    rbm_phase(smem, Dp, D, W, Hn, Hn, bh, ld_bh, n0, N, [&](int r, int j, float z) {
         const int n = n0 + r;
-        if (n < N) part[r] -= softplus_f(acc + bh[(size_t)n * ld_bh + j]);
+        if (n < N) part[r] -= softplus_f(z);
     });
     for (int d = threadIdx.x; d < D; d += blockDim.x)
 #pragma unroll
