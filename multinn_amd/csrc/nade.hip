@@ -75,12 +75,14 @@ struct WStage {
     __device__ __forceinline__ void gload(const float* __restrict__ wd, const float* __restrict__ we, int i0, int D, int Hn, int ld = 0) {
         if (ld == 0) ld = Hn;                    // row stride (a hidden slice of a wider matrix passes its width as Hn)
 #pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            const int e = threadIdx.x + k * 512;
+        for (int k = 0; k < NE; ++k) {                      // unconditional loads from clamped (visible, hidden unit), zeroed afterwards: a
+            const int e = threadIdx.x + k * 512;            // predicated load is a branch and a wait per element (see nade_bwd_kernel)
             const int ii = e / W, j = e - ii * W, i = i0 + ii;
             const bool ok = i >= 0 && i < D && j < Hn;
-            rd[k] = ok ? wd[(size_t)i * ld + j] : 0.f;
-            re[k] = ok ? we[(size_t)i * ld + j] : 0.f;
+            const size_t o = (size_t)min(max(i, 0), D - 1) * ld + min(j, Hn - 1);
+            const float xd = wd[o], xe = we[o];
+            rd[k] = ok ? xd : 0.f;
+            re[k] = ok ? xe : 0.f;
         }
     }
     __device__ __forceinline__ void lstore(float* __restrict__ sd, float* __restrict__ se) const {
@@ -114,9 +116,14 @@ nade_fwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
 #pragma unroll
     for (int r = 0; r < FWD_R; ++r)
 #pragma unroll
+        for (int q = 0; q < HQ; ++q)
+            a[r][q] = bias[(size_t)min(rbase + r, N - 1) * ld_bias + m * Hn + min(lane + 64 * q, Hn - 1)];     // all in flight together
+#pragma unroll
+    for (int r = 0; r < FWD_R; ++r)
+#pragma unroll
         for (int q = 0; q < HQ; ++q) {
             const int j = lane + 64 * q, row = rbase + r;
-            a[r][q] = (row < N && j < Hn) ? bias[(size_t)row * ld_bias + m * Hn + j] : 0.f;
+            if (!(row < N && j < Hn)) a[r][q] = 0.f;
             h[r][q] = fast_sigmoid(a[r][q]);
         }
     // lane L owns (row L>>3, visible L&7) of every chunk: it prefetches that v / b_dec and finalises that logit
@@ -137,8 +144,11 @@ nade_fwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
         const int i0 = c * 8;
         const int inext = i0 + 8 + fi;
         st.gload(wd, we, i0 + 8, D, Hn);                                      // chunk c+1 (zeros past D)
-        const bool vnext = fvalid && inext < D && vm[(size_t)frr * D + inext] != 0;
-        const float bnext = inext < D ? bias[(size_t)frr * ld_bias + bd_off + inext] : 0.f;
+        // raw, unconditional requests; looked at only at the end of the chunk (evaluated here they were waited for here: s_waitcnt vmcnt(0)
+        // behind the weight prefetch just issued, once per chunk)
+        const int inc = min(inext, D - 1);
+        const uint8_t vraw = vm[(size_t)frr * D + inc];
+        const float braw = bias[(size_t)frr * ld_bias + bd_off + inc];
         const unsigned long long mask = __ballot(vcur);                          // bit r*8+ii : v[row r][i0+ii]
         const float* __restrict__ sd = wl[c & 1][0];
         const float* __restrict__ se = wl[c & 1][1];
@@ -180,8 +190,8 @@ nade_fwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
             }
         }
         st.lstore(wl[(c + 1) & 1][0], wl[(c + 1) & 1][1]);
-        vcur = vnext;
-        bcur = bnext;
+        vcur = fvalid && inext < D && vraw != 0;
+        bcur = inext < D ? braw : 0.f;
         __syncthreads();
     }
     lp += dpp_xor1(lp);
