@@ -528,7 +528,7 @@ class LstmStack:
         p = self.packed[0]
         N = T * B
         if p.get("wx_p0") is None:          # [ld0, 4u]: the packed (gate-interleaved) input weights with K = 4u contiguous, once per pack
-            p["wx_p0"] = torch.empty((p["ld"], 4 * p["u"]), device=dzT0.device, dtype=self.dtype)
+            p["wx_p0"] = torch.empty((p["ld"], 4 * p["u"]), device=p["wx_t"].device, dtype=self.dtype)
             ops.transpose(p["wx_t"], p["wx_p0"])
         if dzT0 is None or dzT0.dim() == 3:
             dz = dz.view(N, 4 * p["u"])

@@ -265,3 +265,39 @@ def test_persistent_forms_refuse_grids_that_cannot_be_resident():
     ws = torch.zeros(_lib.load().mnn_lstm_rowpar_workspace_bytes(T, B, u), device=DEV, dtype=torch.uint8)
     with pytest.raises(MnnError):
         ops.lstm_rowpar_fwd(T, B, d, 1.0, ws)
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("layout", ["kblock", "plain", "kmajor"])
+def test_rowpar_input_gradient_and_weight_gradient_layouts(precision, layout, monkeypatch):
+    """The row-parallel backward with `need_dx` (feedback modes: d loss / d inputs) and the three ways its dz reaches the weight-gradient GEMM --
+    K-blocked dz^T (default), plain dz^T, row-major dz as a K-major operand -- against the launch-per-step kernels on the same weights:
+    every gradient and the input gradient agree to the summation order of the split-K atomics."""
+    from multinn_amd import RnnNade
+    from multinn_amd.generators import LstmStack
+    monkeypatch.setattr(LstmStack, "rowpar_min_batch", 32)
+    monkeypatch.setattr(LstmStack, "kblock_wgrads", layout == "kblock")
+    monkeypatch.setattr(LstmStack, "kmajor_wgrads", layout == "kmajor")
+    B, T = 64, 8
+    x = dev(synth(B, T, 41, 0.05))
+    a = RnnNade(D, HN, UNITS, keep_prob=0.9, precision=precision, seed=23)
+    a._materialize(D)
+    a.need_dx = True
+    a.build_pianoroll(x, None, True, "train")
+    assert a._stack._rowpar(B, T)
+    a.backward()
+    a._stack.check()
+    ga, dxa = a.store.grad.clone(), a._dx.clone()
+    b = RnnNade(D, HN, UNITS, keep_prob=0.9, precision=precision, seed=23)
+    b._materialize(D)
+    b.store.theta.copy_(a.store.theta)
+    b._stack.rowpar = False
+    b._stack.persistent = False
+    b.need_dx = True
+    b.build_pianoroll(x, None, True, "train")
+    b.backward()
+    tol = 2e-3 if precision == "fp16" else 2e-2
+    assert float((ga - b.store.grad).abs().max()) <= tol * float(b.store.grad.abs().max())
+    assert float((dxa - b._dx).abs().max()) <= tol * float(b._dx.abs().max())
+    assert float(torch.nn.functional.cosine_similarity(dxa.view(-1), b._dx.view(-1), dim=0)) > 0.9999
+
