@@ -229,6 +229,7 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
         }
     };
     // w_enc[column of flip k0+u][this hidden unit] for the 32 flips of a chunk (entries past the tile's count re-read flip 0's row)
+    const __amdgpu_buffer_rsrc_t we_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(we), 0, D * Hn * 4, 0x00020000);
     auto load_we = [&](int c, int buf, int k0, float (&wv)[32]) {
         const int F = (int)S.sSb[buf][32];
         // ONE list read per lane (lane u holds entry k0 + u), the entries then come out of the lanes with v_readlane: a uniform LDS read per
@@ -236,8 +237,10 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
         const int entv = (int)S.sFl[buf][(k0 + (lane & 31) < F) ? k0 + (lane & 31) : 0];
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
+            // buffer load: the row offset rides in the instruction's SCALAR offset operand, the lane offset (4 tid) is one loop-invariant
+            // register -- no vector ALU work per load (a global load took a 64-bit vector add per row: 32 per tile and thread)
             const int e = __builtin_amdgcn_readlane(entv, u);
-            wv[u] = we[(size_t)min(32 * c + (e & 31), D - 1) * Hn + tid];
+            wv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(we_rs, tid * 4, min(32 * c + (e & 31), D - 1) * (Hn * 4), 0));
         }
     };
     unsigned char vb[4];
