@@ -667,7 +667,7 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
             MNN_LAUNCH_CHECK();
             return MNN_OK;
         }
-        if (!no256 && K % 64 == 0 && M >= 256 && N >= 192 && (long)ntm2 * ntn2 * split_k >= 192 && K / 64 / split_k >= 6) {     // measured per shape: profiles/round1_f_gemm_shapes.md
+        if (!no256 && K % 64 == 0 && M >= 256 && N >= 192 && (long)ntm2 * ntn2 * split_k >= 192 && K / 64 / split_k >= 4) {     // measured per shape: profiles/round1_f_gemm_shapes.md; round 3: 4 K tiles suffice (Dense forward K = 256: 362 -> 247 us)
             using F = typename FlavorOf<T>::type;
             static bool attr_set[64];
             int dev = 0;
