@@ -263,8 +263,9 @@ extern "C" int mnn_rbm_gibbs_stepped(mnn_stream_t s, int N, int D, int Hn, int k
     MNN_REQUIRE(rbm_lds_bytes(D, Hn) <= 160 * 1024, "mnn_rbm_gibbs: D+Hn too large for LDS");
     if (N < 2048 && Hn <= 256 && D <= 256 && getenv("MNN_RBM_STREAM_W") == nullptr) {
         // sampling-sized batches: W resident in LDS, two rows per workgroup (one workgroup per CU: at training sizes -- 32 768 rows --
-        // the streaming kernel's eight rows per workgroup and several workgroups per CU win, 1.5 vs 2.5 ms); rows per thread by how
-        // many row groups of n_out threads fit 256
+        // the streaming kernel's eight rows per workgroup and several workgroups per CU win, 1.5 vs 2.5 ms; round 3: also with the workgroup
+        // walking over its row groups so that W is loaded once, 4.9 ms -- two rows per pass are two dependent fma chains per thread at one
+        // wave per SIMD: latency-bound); rows per thread by how many row groups of n_out threads fit 256
         hipStream_t st = (hipStream_t)s;
         const int gh = 256 / Hn, gv = 256 / D;          // row groups available in the hidden / visible phase
         bool done = false;
