@@ -388,15 +388,26 @@ def main(argv=None):
     dp_info = {"ranks": world, "backend": None, "devices": [local]}
     if multi:
         import torch.distributed as dist
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(a.backend)
-        # what the job really is: the world size after an actual all-reduce over the backend, and every rank's device
-        probe = torch.ones(1, device=dev)
-        dist.all_reduce(probe)
-        ids = [torch.zeros(1, device=dev, dtype=torch.int64) for _ in range(dist.get_world_size())]
-        dist.all_gather(ids, torch.tensor([local], device=dev, dtype=torch.int64))
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout carries ONE JSON line: the C-level descriptor
+        # points at stderr until the first collectives have run
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if a.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(a.backend)
+            # what the job really is: the world size after an actual all-reduce over the backend, and every rank's device
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)
+            ids = [torch.zeros(1, device=dev, dtype=torch.int64) for _ in range(dist.get_world_size())]
+            dist.all_gather(ids, torch.tensor([local], device=dev, dtype=torch.int64))
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         dp_info = {"ranks": dist.get_world_size(), "allreduce_sum_of_ones": float(probe), "backend": dist.get_backend(),
                    "devices": [int(t) for t in ids], "rccl_ranks": dist.get_world_size() if a.backend == "nccl" else None}
     from multinn_amd import RnnNade, AdamOptimizer, _lib
