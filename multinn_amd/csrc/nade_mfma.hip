@@ -395,21 +395,40 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
         for (int k = 0; k < 4; ++k) asm volatile("" :: "v"(bdec[k]));
         if (c + 1 < ntile) load_b(c + 1, bfr);               // the tile's MFMAs are issued: fetch the next tile's w_dec fragments under the pointwise
         NM_T(7);
-        // ---- S3: pointwise of this thread's 4 pairs, once per tile ----
+        // ---- S3: pointwise of this thread's 4 pairs, once per tile; the four results of a matrix leave as ONE 16-byte store where the
+        //      four columns exist and the address is aligned (one store instruction instead of four per matrix and tile)
+        float prv[4], dbv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int dpos = ed0 + k, gd = 32 * c + dpos;
+            prv[k] = 0.f; dbv[k] = 0.f;
             if (gd >= D) continue;
             const float l = bdec[k] + lsel[k];
             const bool on = (mk >> dpos) & 1u;
             const float pr = fast_sigmoid(l);
             const float qr = fast_sigmoid(-l);               // 1-p without cancellation
             lp += on ? nm_ln(NADE_EPS + pr) : nm_ln(NADE_EPS + qr);
-            if (evalid) {
-                if (cond_p != nullptr) cond_p[((size_t)m * N + erow) * D + gd] = pr;
-                if (d_bias != nullptr) {
-                    const float dnll_dp = on ? -fast_rcp(NADE_EPS + pr) : fast_rcp(NADE_EPS + qr);
-                    d_bias[(size_t)erow * ld_bias + bd_off + gd] = rw * dnll_dp * pr * qr;
+            prv[k] = pr;
+            const float dnll_dp = on ? -fast_rcp(NADE_EPS + pr) : fast_rcp(NADE_EPS + qr);
+            dbv[k] = rw * dnll_dp * pr * qr;
+        }
+        if (evalid) {
+            const int gd0 = 32 * c + ed0;
+            const bool full = gd0 + 3 < D;
+            if (cond_p != nullptr) {
+                float* dst = cond_p + ((size_t)m * N + erow) * D + gd0;
+                if (full && (((size_t)dst) & 15) == 0) *reinterpret_cast<float4*>(dst) = make_float4(prv[0], prv[1], prv[2], prv[3]);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (gd0 + k < D) dst[k] = prv[k];
+                }
+            }
+            if (d_bias != nullptr) {
+                float* dst = d_bias + (size_t)erow * ld_bias + bd_off + gd0;
+                if (full && (((size_t)dst) & 15) == 0) *reinterpret_cast<float4*>(dst) = make_float4(dbv[0], dbv[1], dbv[2], dbv[3]);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (gd0 + k < D) dst[k] = dbv[k];
                 }
             }
         }
