@@ -45,6 +45,11 @@ typedef enum { MNN_F32 = 0, MNN_BF16 = 1, MNN_U8 = 2, MNN_F16 = 3 } mnn_dtype;  
 enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_STREAM_RBM_V = 3,
        MNN_STREAM_DBN_ENC = 4, MNN_STREAM_DBN_DEC = 5 };
 
+/* ABI version of THIS header: bumped whenever a signature or a descriptor struct changes.  mnn_version() returns the value the library
+ * was built with; a loader must compare the two before its first call (multinn_amd/_lib.py load() does) -- a library built for another
+ * version reads garbage arguments without any diagnosis otherwise.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
+ * mnn_pianoroll_shift_timemajor_t / mnn_grad_rows_fanout and the `f16` descriptor fields of round 3 are part of it. */
+#define MNN_ABI_VERSION 110
 int mnn_version(void);
 const char* mnn_last_error(void);
 
@@ -350,11 +355,14 @@ int mnn_sigmoid_grad_f32(mnn_stream_t s, long n, const float* dy, const float* y
  *   gn = sqrt(*sumsq) read ON DEVICE; TF Adam with epsilon outside the bias correction;
  *   `step` is the 1-based step count; if step_dev (device int32) is given the count is *step_dev + 1,
  *   read ON DEVICE (hipGraph replay) and mnn_step_increment advances it.  sgd != 0 -> plain SGD (train.py:61-62).
+ *   A gradient norm that is not finite (*sumsq is inf / NaN: an overflow of the loss-scaled f16 backward pass) SKIPS the update on the
+ *   device -- theta, m, v unchanged -- and adds 1 to *skipped (device int32, may be NULL); clip_norm <= 0 disables the test.
  * ------------------------------------------------------------------------------------------ */
 int mnn_sumsq(mnn_stream_t s, const float* x, long n, float* out);
 int mnn_weighted_sum(mnn_stream_t s, const float* x, const float* w, long n, float* out);
 int mnn_clip_adam_step(mnn_stream_t s, float* theta, const float* grad, float* m, float* v, long n, const float* sumsq,
-                       float clip_norm, float lr, float beta1, float beta2, float eps, int step, const int32_t* step_dev, int sgd);
+                       float clip_norm, float lr, float beta1, float beta2, float eps, int step, const int32_t* step_dev, int sgd,
+                       int32_t* skipped);
 int mnn_step_increment(mnn_stream_t s, int32_t* step_dev);
 int mnn_bias_grad(mnn_stream_t s, const float* dY, int rows, int cols, int ld, float* db, int accumulate);
 int mnn_fill_f32(mnn_stream_t s, float* x, long n, float value);

@@ -98,6 +98,8 @@ class ParamStore:
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)     # device copy of `step` (read by kernels under hipGraph replay)
+        # optimiser steps the device skipped because the gradient norm was not finite (mnn_clip_adam_step; f16 loss-scale overflow)
+        self.skipped = torch.zeros(1, device=dev, dtype=torch.int32)
         off = 0
         for name, shape, init in self._specs:
             k = math.prod(shape)
@@ -121,6 +123,17 @@ class ParamStore:
 
     def names(self):
         return [n for n, _, _ in self._specs]
+
+    def check(self):
+        """Raise FloatingPointError if an optimiser step has been skipped on the device since the last check (non-finite gradient norm:
+        the f16 backward pass overflowed, or a NaN reached the gradient).  Synchronises; clears the counter."""
+        if self.theta is None:
+            return
+        n = int(self.skipped.item())
+        if n:
+            self.skipped.zero_()
+            raise FloatingPointError(f"{n} optimiser step(s) skipped: the gradient norm was not finite (f16 loss-scale overflow or NaN "
+                                     "gradient); lower LstmStack.loss_scale_rows or use precision='bf16'")
 
     def state_dict(self):
         return dict(theta=self.theta.cpu(), m=self.m.cpu(), v=self.v.cpu(), step=self.step, names=self.names(),

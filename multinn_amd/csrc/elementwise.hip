@@ -15,7 +15,7 @@ void mnn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* mnn_last_error(void) { return g_err; }
-extern "C" int mnn_version(void) { return 100; }
+extern "C" int mnn_version(void) { return MNN_ABI_VERSION; }
 
 template <typename T> __device__ __forceinline__ float ld_as_f32(const T* p, size_t i);
 template <> __device__ __forceinline__ float ld_as_f32<float>(const float* p, size_t i) { return p[i]; }
@@ -600,7 +600,13 @@ extern "C" int mnn_weighted_sum(mnn_stream_t s, const float* x, const float* w, 
 
 __global__ void clip_adam_kernel(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
                                  long n, const float* __restrict__ sumsq, float clip, float lr_t, float lr, float b1, float b2, float eps,
-                                 int sgd, const int32_t* __restrict__ step_dev) {
+                                 int sgd, const int32_t* __restrict__ step_dev, int32_t* __restrict__ skipped) {
+    // a gradient norm that is not finite (an overflow of the loss-scaled f16 backward pass, or a NaN from anywhere): the update is NOT
+    // applied -- theta, m, v keep their values -- and the caller's counter records it (read by ParamStore.check on the host)
+    if (clip > 0.f && sumsq != nullptr && !isfinite(sumsq[0])) {
+        if (skipped != nullptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
+        return;
+    }
     if (step_dev != nullptr) {          // step counter lives on the device (hipGraph replay): t = *step_dev + 1
         __shared__ float s_lr_t;        // two double-precision pow() once per workgroup, not once per thread
         if (threadIdx.x == 0) {
@@ -654,12 +660,13 @@ __global__ void clip_adam_kernel(float* __restrict__ theta, const float* __restr
 }
 
 extern "C" int mnn_clip_adam_step(mnn_stream_t s, float* theta, const float* grad, float* m, float* v, long n, const float* sumsq,
-                                  float clip_norm, float lr, float beta1, float beta2, float eps, int step, const int32_t* step_dev, int sgd) {
+                                  float clip_norm, float lr, float beta1, float beta2, float eps, int step, const int32_t* step_dev, int sgd,
+                                  int32_t* skipped) {
     MNN_REQUIRE(theta && grad && n > 0 && (sgd || (m && v)) && (step >= 1 || step_dev != nullptr), "mnn_clip_adam_step: bad arguments");
     if (step < 1) step = 1;
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
     hipLaunchKernelGGL(clip_adam_kernel, dim3((int)min(2048L, (n + 255) / 256)), dim3(256), 0, (hipStream_t)s, theta, grad, m, v, n, sumsq,
-                       clip_norm, (float)lr_t, lr, beta1, beta2, eps, sgd, step_dev);
+                       clip_norm, (float)lr_t, lr, beta1, beta2, eps, sgd, step_dev, skipped);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

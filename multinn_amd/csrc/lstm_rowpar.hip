@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         // ---- issued BEHIND the hand-off stores, which alone the flag waits for: the next step's operands (first: they are needed soonest),
         // then what the rest of the train step reads ----
         int behind = 0;
-        if (t + 1 < T) { prefetch(t + 1); behind += drop ? 17 : 16; }
+        if (t + 1 < T) { prefetch(t + 1); behind += 17; }    // 16 xproj loads + the keep-byte load, which is issued with or without a mask (see prefetch)
         if (A.gates != nullptr) {                 // saved activations: bf16, gate-minor (8 bytes per (row, unit)) -- only mnn_lstm_rowpar_bwd reads them
             char* gb = reinterpret_cast<char*>(A.gates + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og / 2;
 #pragma unroll
@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         RP_TR(1, trc, kk, 4);
         // ---- issued BEHIND the hand-off stores, which alone the flag waits for: the next item's operands, then what the rest of the step reads ----
         int behind = 0;
-        if (kk + 1 < T) { prefetch(t - 1); behind += drop ? 25 : 24; }
+        if (kk + 1 < T) { prefetch(t - 1); behind += 25; }
         if (A.dzc != nullptr) {                  // row-major dz [t][row][4U] (gate-interleaved columns): the A operand of the input-gradient GEMM
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -776,7 +776,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         RP_HANDOFF_FENCE();
         RP_TR(0, trc, t, 4);
         int behind = 0;
-        if (t + 1 < T) { prefetch(t + 1); behind += drop ? 9 : 8; }
+        if (t + 1 < T) { prefetch(t + 1); behind += 9; }
         if (A.gates != nullptr) {
             char* gb = reinterpret_cast<char*>(A.gates + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og / 2;
 #pragma unroll
@@ -1047,7 +1047,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         RP_HANDOFF_FENCE();
         RP_TR(1, trc, kk, 4);
         int behind = 0;
-        if (kk + 1 < T) { prefetch(t - 1); behind += drop ? 13 : 12; }
+        if (kk + 1 < T) { prefetch(t - 1); behind += 13; }
         if (A.dzc != nullptr) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

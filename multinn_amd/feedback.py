@@ -44,14 +44,15 @@ class FeedbackRnn(Model):
         self._ctx = dict(lstm=ctx, kp=kp) if train else None
         return y.transpose(0, 1).float(), [(c.clone(), h.clone()) for c, h in final]
 
-    def backward(self, d_out):
-        """d_out f32 [B,T,F]: gradient wrt the feedback vectors -> the module's kernel / bias gradients (its inputs are codes: no gradient)."""
+    def backward(self, d_out, n_valid=None):
+        """d_out f32 [B,T,F]: gradient wrt the feedback vectors -> the module's kernel / bias gradients (its inputs are codes: no gradient).
+        n_valid: valid rows the generators' mean-over-rows losses divide by (all ranks; default B*T) -- sizes the f16 loss scale."""
         if self._ctx is None:
             raise RuntimeError("FeedbackRnn.backward: run(..., train=True) first")
         self.store.grad.zero_()
         dy = d_out.transpose(0, 1).contiguous()
         # f16 operands: the pass runs on loss-scaled values (LstmStack.loss_scale); d_out comes from mean-over-rows losses, ~1/(B T) per element
-        ls = self._stack.loss_scale(dy.shape[0] * dy.shape[1])
+        ls = self._stack.loss_scale(n_valid if n_valid else dy.shape[0] * dy.shape[1])
         if ls != 1.0:
             dy = dy * ls
         self._stack.backward(dy, self._ctx["lstm"], self._ctx["kp"], self.seed, self.row0, step_dev=self.store.step_dev)
@@ -161,8 +162,8 @@ class FeedbackDnn(Model):
         """_apply_feedback(single_step=False): x [B,T,Din] -> (outputs [B,T,F] f32, state placeholder)."""
         return self._dnn(x, save=bool(train)), None
 
-    def backward(self, d_out):
-        """d_out f32 [B,T,F]: gradient wrt the feedback vectors -> the Dense layers' gradients."""
+    def backward(self, d_out, n_valid=None):
+        """d_out f32 [B,T,F]: gradient wrt the feedback vectors -> the Dense layers' gradients (f32 arithmetic: n_valid is unused)."""
         self._dnn.backward(d_out)
 
     def single(self, x, state):

@@ -68,13 +68,17 @@ class LstmStack:
     # IEEE half has 5 exponent bits: the backward pass of a mean-over-rows loss (seeds of 1/N ~ 4e-6 at the bench shape) would sit in its
     # subnormals.  The owner of a backward pass (RnnNade / RnnRBM / FeedbackRnn) multiplies its gradient seed by loss_scale(N) -- a power of
     # two, so every f32 result is the unscaled one times 2^k exactly -- and multiplies store.grad (and d loss / d inputs) by 1/scale at its
-    # end: callers always see unscaled gradients.  256 / N keeps |d logits| <= 256 and typical dz around 1..100 (f16: 6e-5 .. 65504).
+    # end: callers always see unscaled gradients.  The seed of a row is 1 / n_valid (VALID rows of all ranks, not B*T: on a ragged window the
+    # two differ by up to max_len), so 256 * n_valid keeps |d logits| <= 256 and typical dz around 1..100 (f16: 6e-5 .. 65504) for ragged
+    # batches too.  An overflow that happens anyway leaves a non-finite gradient norm: mnn_clip_adam_step skips that update on the device
+    # and Generator.check() raises.
     loss_scale_rows = 256.0
 
-    def loss_scale(self, n_rows):
+    def loss_scale(self, n_valid):
+        """n_valid: number of VALID rows the mean-over-rows loss divides by (summed over all ranks)."""
         if self.dtype != torch.float16:
             return 1.0
-        return float(2.0 ** round(math.log2(self.loss_scale_rows * max(int(n_rows), 1))))
+        return float(2.0 ** round(math.log2(self.loss_scale_rows * max(int(n_valid), 1))))
 
     def pack(self):
         dev = self.store.theta.device
@@ -650,16 +654,19 @@ class RnnEstimator(Generator):
         return out
 
     def _row_weight(self, lengths, B, T, device):
-        """1/N_valid on valid rows (N_valid summed over ALL ranks), 0 on padding."""
+        """1/N_valid on valid rows (N_valid summed over ALL ranks), 0 on padding.  Leaves the host copy of N_valid in self._n_valid (the
+        f16 loss scale is derived from it)."""
         if lengths is None:
             # full-length batches: every rank holds B*T valid rows, the total is known on the host -- no copy, no collective (this
             # path runs inside captured steps)
             n_ranks = torch.distributed.get_world_size() if (dp_active() and torch.distributed.is_initialized()) else 1
+            self._n_valid = B * T * n_ranks
             return torch.full((T * B,), 1.0 / float(B * T * n_ranks), device=device)
         mask = (torch.arange(T, device=device)[:, None] < lengths.to(device)[None, :]).float()
         n_tot = mask.sum()
         if dp_active():
             torch.distributed.all_reduce(n_tot)
+        self._n_valid = max(int(n_tot), 1)              # ragged windows run eagerly: a host read is allowed here
         return (mask / n_tot).reshape(-1).contiguous()
 
     def steps(self, inputs, initial_state=None):
@@ -669,6 +676,7 @@ class RnnEstimator(Generator):
         """Raise if a persistent recurrence launch of this generator ever gave up on a bounded spin (LstmStack.check)."""
         if getattr(self, "_stack", None) is not None:
             self._stack.check()
+        self.store.check()                  # an optimiser step the device skipped (non-finite gradient norm) raises here
 
     def _unscale(self, ls):
         """End of a loss-scaled backward pass (LstmStack.loss_scale): gradients and d loss / d inputs back to their true scale."""
@@ -913,6 +921,7 @@ class RnnNade(RnnEstimator):
             n_valid = int(n_tot)
         else:
             n_valid = B * T * world()[1]
+        self._n_valid = max(n_valid, 1)
         x_tmT = None
         if mode == "train" and self.dtype in ops.H16:              # the same pass also writes x^T, layer 1's weight-gradient operand
             self._ensure_packed()
@@ -944,7 +953,7 @@ class RnnNade(RnnEstimator):
                 d_out[:, self.n_out:].zero_()       # fp32: d_out itself is the dgrad operand; bf16: grad_rows_fanout writes the zero padding
         a_fin = torch.empty((M, N, Hn), device=dev) if train else None
         # gradient seed only (the reported loss stays unscaled): the mode's weight of this generator's loss, and the f16 loss scale
-        ls = self._stack.loss_scale(N * world()[1]) if train else 1.0
+        ls = self._stack.loss_scale(self._n_valid) if train else 1.0
         gs = self.grad_scale * ls
         rw_g = rw_m if gs == 1.0 else rw_m * gs
         if self._nade_mfma():
@@ -1260,7 +1269,8 @@ class RnnRBM(RnnEstimator):
             cost = Fv - Fs
             loss = torch.zeros(1, device=dev)
             ops.weighted_sum(cost, rw, loss)
-            self._ctx = dict(y=yy, lstm=ctx, out=out, tgt=tgt, v_s=v_s, rw=rw, kp=kp, seed=seed, B=B, T=T, bh_u=bh_u, bv_u=bv_u)
+            self._ctx = dict(y=yy, lstm=ctx, out=out, tgt=tgt, v_s=v_s, rw=rw, kp=kp, seed=seed, B=B, T=T, bh_u=bh_u, bv_u=bv_u,
+                             n_valid=self._n_valid)
             self._cost_tm, self._F_tm, self._pv_tm, self._vs_tm, self._loss = cost, Fv, p_v, v_s, loss
             self._lengths, self._flat_idx = lengths, None
             self._recon_tm = torch.empty(N, device=dev)
@@ -1300,7 +1310,7 @@ class RnnRBM(RnnEstimator):
         # Dense-output-shaped gradient block and the two scaled hidden blocks of d cost / d W = v_s^T (w ss) - v^T (w sv)
         d_out = torch.empty((N, self.ldo), device=dev)
         pos = torch.empty((N, Hn), device=dev); neg = torch.empty((N, Hn), device=dev)
-        ls = self._stack.loss_scale(N * world()[1])
+        ls = self._stack.loss_scale(cx["n_valid"])
         ops.rbm_cd_rows(cx["tgt"], cx["v_s"], sv, ss, cx["rw"], self.grad_scale * ls, d_out, pos, neg)
         Np = ops.round_up(N, 4)
         def tr(xm, rows):

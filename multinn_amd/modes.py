@@ -247,10 +247,28 @@ class MultINNCore(Model):
         return metrics, metrics_upd, {"metrics": None, "weights": None, "gradients": None}
 
     def load_encoders(self, sess=None, ckpt_dir=None):
-        """multinn_core.py:425-448."""
+        """multinn_core.py:425-448: restore the ENCODER variables only, from the checkpoint `save()` wrote into ckpt_dir (the reference flow:
+        train_encoders.py `model.save(encoders_dir)`, then train.py:126 `model.load_encoders(encoders_dir)`).  The encoder stores are read
+        from the mode's one checkpoint file; a directory that only holds the older per-encoder `{encoder.name}.pt` files is still read (with a
+        warning), and a directory with neither returns False."""
         if self._encoder_type == "Pass":
             return True
-        return all(e.load(None, ckpt_dir) for e in self._encoders)
+        path = self._ckpt_path(ckpt_dir)
+        if os.path.exists(path):
+            blob = torch.load(path)
+            if list(blob.get("tracks", [])) != list(self._tracks) or len(blob.get("encoders", [])) != len(self._encoders):
+                raise ValueError(f"checkpoint {path} does not match this model's tracks / encoders")
+            if any(sd is None for sd in blob["encoders"]):
+                return False                            # written before the encoders had variables: nothing to restore
+            for e, sd in zip(self._encoders, blob["encoders"]):
+                e.store.load_state_dict(sd)
+            return True
+        old = [os.path.join(ckpt_dir, f"{e.name}.pt") for e in self._encoders]
+        if all(os.path.exists(p) for p in old):
+            import warnings
+            warnings.warn(f"{ckpt_dir} holds per-encoder checkpoint files of the older format and no {os.path.basename(path)}: loading those")
+            return all(e.load(None, ckpt_dir) for e in self._encoders)
+        return False
 
     # -- checkpoints (model.py:180-234: ONE tf Saver over uniquely scoped variables) ------------------------------------------------
     # One file per mode, `{name}.pt`: every generator / encoder / feedback store under its own index (the M per-track generators of the
@@ -283,6 +301,10 @@ class MultINNCore(Model):
     def load(self, sess=None, ckpt_dir=None):
         path = self._ckpt_path(ckpt_dir)
         if not os.path.exists(path):
+            if os.path.isdir(ckpt_dir) and any(f.endswith(".pt") for f in os.listdir(ckpt_dir)):
+                import warnings
+                warnings.warn(f"{ckpt_dir} holds .pt files but no {os.path.basename(path)} (per-model files of an older format are not "
+                              "read by load()): starting from the initial weights")
             return False
         blob = torch.load(path)
         if blob.get("mode") != self._mode or list(blob.get("tracks", [])) != list(self._tracks):
@@ -321,9 +343,13 @@ class MultINNCore(Model):
         for g in self._generators:
             if getattr(g, "_stack", None) is not None:
                 g._stack.check()
+            if getattr(g, "store", None) is not None:
+                g.store.check()             # optimiser steps skipped on the device (non-finite gradient norm)
         fl = getattr(self, "_feedback_layer", None)
         if fl is not None and getattr(fl, "_stack", None) is not None:
             fl._stack.check()
+        if fl is not None and getattr(fl, "store", None) is not None:
+            fl.store.check()
 
     # -- train.py:178-189: one `sess.run([update_ops, loss], feed_dict)` -----------------------------
     def generator_loss(self):
@@ -718,7 +744,8 @@ class MultINNFeedback(MultINNJamming):
             ops.convert2d(dx.view(T * B, E + F)[:, E:], tmp)
             flat = acc.view(-1)[:T * B * F]
             ops.axpby(1.0, flat, 1.0, tmp.view(-1), flat)
-        self._feedback_layer.backward(acc.transpose(0, 1).contiguous())       # [B, T+1, F], the row order of the forward call
+        nv = getattr(self.generators[0], "_n_valid", None)
+        self._feedback_layer.backward(acc.transpose(0, 1).contiguous(), n_valid=nv)   # [B, T+1, F], the row order of the forward call
 
     def _generator_io(self, i):
         inputs = torch.cat([self._x_encoded[i].float(), self._x_feedback], dim=-1)               # multinn_feedback.py:85-91

@@ -663,12 +663,12 @@ def weighted_sum(x, w, out):
     call("mnn_weighted_sum", _stream(), _ptr(x), _ptr(w), x.numel(), _ptr(out))
 
 
-def clip_adam_step(theta, grad, m, v, sumsq_buf, clip_norm, lr, beta1, beta2, eps, step, sgd=False, step_dev=None):
+def clip_adam_step(theta, grad, m, v, sumsq_buf, clip_norm, lr, beta1, beta2, eps, step, sgd=False, step_dev=None, skipped=None):
     n = theta.numel()
     for t in (theta, grad) + (() if sgd else (m, v)):
         _req(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n, "adam: flat f32 buffers of equal size")
     call("mnn_clip_adam_step", _stream(), _ptr(theta), _ptr(grad), _ptr(m), _ptr(v), n, _ptr(sumsq_buf), float(clip_norm), float(lr),
-         float(beta1), float(beta2), float(eps), int(step), _ptr(step_dev), int(sgd))
+         float(beta1), float(beta2), float(eps), int(step), _ptr(step_dev), int(sgd), _ptr(skipped))
 
 
 def step_increment(step_dev):

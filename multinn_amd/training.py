@@ -58,7 +58,7 @@ def compute_gradients(optimizer, store, clip_norm=5.0, lr=None, reduce=True):
     store.step += 1
     # the step count is read from store.step_dev ON DEVICE (= store.step - 1 here), so a captured graph stays valid
     ops.clip_adam_step(store.theta, store.grad, store.m, store.v, sumsq, clip_norm, optimizer.lr if lr is None else lr,
-                       optimizer.beta1, optimizer.beta2, optimizer.epsilon, store.step, optimizer.sgd, store.step_dev)
+                       optimizer.beta1, optimizer.beta2, optimizer.epsilon, store.step, optimizer.sgd, store.step_dev, store.skipped)
     ops.step_increment(store.step_dev)
     return sumsq
 
@@ -77,6 +77,6 @@ def compute_gradients_multi(optimizer, stores, clip_norm=5.0, lr=None, reduce=Tr
     for st in stores:
         st.step += 1
         ops.clip_adam_step(st.theta, st.grad, st.m, st.v, sumsq, clip_norm, optimizer.lr if lr is None else lr,
-                           optimizer.beta1, optimizer.beta2, optimizer.epsilon, st.step, optimizer.sgd, st.step_dev)
+                           optimizer.beta1, optimizer.beta2, optimizer.epsilon, st.step, optimizer.sgd, st.step_dev, st.skipped)
         ops.step_increment(st.step_dev)
     return sumsq

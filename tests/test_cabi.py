@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol(lib):
 def test_loader_binds_every_symbol(lib):
     from multinn_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()
-    assert lib.mnn_version() == 100
+    hdr = open(os.path.join(ROOT, "include", "multinn_hip.h")).read()
+    assert lib.mnn_version() == _lib.ABI_VERSION == int(re.search(r"#define MNN_ABI_VERSION (\d+)", hdr).group(1))
     assert lib.mnn_lstm_seq_bwd_workspace_bytes(4, 32) == 4 * 32 * 4
     assert lib.mnn_rbm_workspace_bytes(88, 256) == 88 * 256 * 4
 

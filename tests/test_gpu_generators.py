@@ -92,6 +92,52 @@ def test_rnn_nade_joint_train_step(precision, ragged, units):
             assert np.abs(gen.store[name].cpu().numpy().reshape(ref.shape) - ref).max() < 2e-4, name
 
 
+def test_fp16_ragged_lengths_loss_scale_and_overflow_guard():
+    """precision='fp16' on a RAGGED window -- one long song and many rows of length 1, N / n_valid = 8 -- against the float64 oracle: the loss
+    scale of the backward pass is derived from the number of VALID rows (a scale taken from B*T would multiply every gradient seed by
+    N / n_valid and push dz past f16's 65504), so every gradient stays finite and within the f16 bounds.  Then the guard: a gradient norm
+    that is not finite skips the optimiser step ON THE DEVICE (theta, m, v untouched) and `check()` raises."""
+    from multinn_amd import RnnNade, AdamOptimizer
+    B, T, P, M, Hn, units = 32, 16, 8, 2, 256, [128, 128]
+    D = P * M
+    x = make_batch(B, T, P, M, 5)
+    lengths = np.ones(B, np.int32)
+    lengths[0] = T
+    lengths[1:17] = 3
+    n_valid = int(lengths.sum())
+    assert B * T / n_valid > 6
+    p = G.init_rnn_nade(7, D, D, Hn, units, np.float64)
+    for W, b in p['lstm']:
+        b += 0.05
+    gen = RnnNade(D, Hn, units, keep_prob=0.9, precision="fp16", seed=23)
+    gen._materialize(D)
+    load_nade_params(gen, p)
+    gen._packed_step = -1
+    gen.build_pianoroll(dev(x), dev(lengths), is_train=True, mode="train")
+    assert gen._n_valid == n_valid and gen._ctx["ls"] == 2.0 ** round(np.log2(256.0 * n_valid))
+    inp, tgt = G.joint_inputs(x.astype(np.float64))
+    fw = G.rnn_nade_forward(inp, tgt, lengths, p, 0.9, G.dropout_uniforms(23, B, T, units))
+    g = G.rnn_nade_backward(fw, p)
+    assert abs(float(gen.metrics['batch/loss']) - fw['loss']) < 1e-4 * abs(fw['loss'])
+    gen.backward()
+    assert bool(torch.isfinite(gen.store.grad).all())
+    for name, ref in zip(gen.store.names(), oracle_grad_list(g)):
+        got = gen.store.gviews[name].cpu().numpy().reshape(ref.shape)
+        assert rel(got, ref) < 3e-3, (name, rel(got, ref))
+    opt = AdamOptimizer(0.01)
+    gen.train(opt, None)
+    gen.check()                                         # a finite norm: the step was applied, nothing to report
+    # the guard: poison the gradient, the device skips the update and the host check raises
+    th, m_, v_ = gen.store.theta.clone(), gen.store.m.clone(), gen.store.v.clone()
+    from multinn_amd.training import compute_gradients
+    gen.store.grad[3] = float("inf")
+    compute_gradients(opt, gen.store, gen.clip_norm, None)
+    assert torch.equal(gen.store.theta, th) and torch.equal(gen.store.m, m_) and torch.equal(gen.store.v, v_)
+    with pytest.raises(FloatingPointError):
+        gen.check()
+    gen.check()                                         # the counter was cleared by the raise
+
+
 @pytest.mark.parametrize("tracks", [1, 3])
 def test_rnn_nade_internal_bias(tracks):
     """internal_bias=True (nade.py:69-87, rnn_nade.py:245-251): b_enc / b_dec of the NADE(s) are added to the Dense outputs.  The oracle gets

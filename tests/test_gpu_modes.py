@@ -511,3 +511,27 @@ def test_mode_checkpoint_round_trip(mode, enc, gen, tmp_path):
     with pytest.raises(ValueError):
         other = "joint" if mode != "joint" else "jamming"
         MultINN(config(P, TRACKS5), params(other, gen="NADE", Hn=16, units=[32, 32]), mode=other, precision="fp32").load(None, str(tmp_path))
+
+
+def test_load_encoders_restores_the_encoder_stores_from_the_mode_checkpoint(tmp_path):
+    """The reference flow train_encoders.py `model.save(encoders_dir)` -> train.py:126 `model.load_encoders(encoders_dir)`: a fresh composer
+    model restores its per-track DBN encoder variables -- and ONLY those -- from the one checkpoint file `save()` writes; a directory with
+    nothing in it returns False."""
+    from multinn_amd import MultINN
+    B, T, P, M = 4, 5, 12, 5
+    x = dev(batch(B, T, P, M, 13))
+    kw = dict(enc="DBN", enc_hidden=[10, 8], gen="NADE", Hn=16, units=[32, 32])
+    a = MultINN(config(P, TRACKS5), params("composer", **kw), mode="composer", precision="fp32")
+    for e in a.encoders:                                # stand-in for the pre-training: distinct, non-initial encoder weights
+        e.store.theta.add_(torch.randn_like(e.store.theta) * 0.1)
+    a.save(None, str(tmp_path))
+    b = MultINN(config(P, TRACKS5), params("composer", **kw), mode="composer", precision="fp32")
+    before = [e.store.theta.clone() for e in b.encoders]
+    assert b.load_encoders(None, str(tmp_path / "nowhere")) is False
+    assert all(torch.equal(e.store.theta, t0) for e, t0 in zip(b.encoders, before))
+    assert b.load_encoders(None, str(tmp_path)) is True
+    for ea, eb in zip(a.encoders, b.encoders):
+        assert torch.equal(ea.store.theta, eb.store.theta)
+    assert all(g.store.theta is None for g in b.generators)          # the generators were not touched
+    b.train_step(x, None, __import__("multinn_amd").AdamOptimizer(0.01))
+    b.check()

@@ -240,6 +240,49 @@ def test_rowpar_recurrence_vs_oracle(units, B, T, max_g, precision, monkeypatch)
     gen._stack.check()
 
 
+def test_timed_kernels_long_sequence_vs_oracle(monkeypatch):
+    """The TIMED kernel forms of the bench step -- the wave-pair row-parallel recurrence `lstm_rowpar_fwd2 / bwd2<512 | 256, Fp16F>` with TWO
+    row tiles per workgroup, the split-operand matrix-core NADE forward, the K-blocked dz^T weight-gradient operand -- against the float64
+    oracle over T = 64 timesteps (the other oracle cases stop at T <= 9): flag epochs, the 8-chunk dz ring and the K-blocked layout are
+    exercised for 64 hand-offs per row tile, at the real widths and the bench density rho = 0.03."""
+    from multinn_amd import RnnNade
+    monkeypatch.setenv("MNN_ROWPAR_MAX_G", "1")        # both row tiles of B = 64 on one workgroup per unit tile: both pair slots, as at B = 1024
+    B, T, rho = 64, 64, 0.03
+    x = synth(B, T, 29, rho)
+    p = G.init_rnn_nade(31, D, D, HN, UNITS, np.float64)
+    for W, b in p['lstm']:
+        b += 0.05
+    p['fc_b'][HN:] += np.log(rho / (1 - rho))
+    inp, tgt = G.joint_inputs(x.astype(np.float64))
+    fw = G.rnn_nade_forward(inp, tgt, None, p, 0.9, G.dropout_uniforms(23, B, T, UNITS))
+    g = G.rnn_nade_backward(fw, p)
+    gen = RnnNade(D, HN, UNITS, keep_prob=0.9, precision="fp16", seed=23)
+    gen._materialize(D)
+    load(gen, p)
+    gen._stack.rowpar_min_batch = 32
+    gen.build_pianoroll(dev(x), None, is_train=True, mode="train")
+    assert gen._stack._rowpar(B, T) and gen._ctx["lstm"][0].get("rowpar") and gen._nade_mfma() and gen._nade_exact()
+    assert gen._stack.kblock_wgrads and not gen._stack.kmajor_wgrads
+    loss = float(gen.metrics["batch/loss"])
+    nll = gen.log_probs.cpu().numpy()
+    cp_err = np.abs(gen.cond_probs.cpu().numpy() - fw['cond_p'][0]).max()
+    gen.backward()
+    gen._stack.check()
+    errs = {"loss": abs(loss - fw['loss']) / abs(fw['loss']), "nll": rel(nll, fw['nll'][0])}
+    cosv = {}
+    for name, ref in zip(gen.store.names(), oracle_grads(g)):
+        got = gen.store.gviews[name].cpu().numpy().reshape(ref.shape)
+        errs[name] = rel(got, ref)
+        cosv[name] = cosine(got, ref)
+    print(f"\n[timed kernels fp16 B={B} T={T} rho={rho}] relative error vs float64 oracle:")
+    for k, v in errs.items():
+        print(f"    {k:24s} {v:.3e}" + (f"   cos {cosv[k]:.6f}" if k in cosv else ""))
+    print(f"    {'cond_probs (abs)':24s} {cp_err:.3e}")
+    assert errs["loss"] < 1e-4 and errs["nll"] < 1e-4 and cp_err < 1e-4, (errs, cp_err)
+    assert all(v < 3e-3 for v in errs.values()), errs
+    assert all(c > 0.99999 for c in cosv.values()), cosv
+
+
 def test_persistent_forms_refuse_grids_that_cannot_be_resident():
     """Co-residency is a construction, not an assumption: the host plans size every persistent grid to at most one workgroup per CU of THIS
     device and refuse shapes whose row tiles do not fit (the caller then takes the launch-per-timestep kernels -- still device code); the C
