@@ -396,6 +396,34 @@ int mnn_eval_counts(mnn_stream_t s, const uint8_t* targets, const uint8_t* predi
 int mnn_log_loss_rows(mnn_stream_t s, const uint8_t* targets, const float* probs, int N, int D, int ld_probs, float* out);
 
 /* ------------------------------------------------------------------------------------------
+ * Deterministic f32 single steps of the SAMPLING scan (rnn_estimator.py:293-323 `_generate_recurrence`: sample_single -> single_step;
+ * rnn_nade.py:253-277; multinn_feedback.py:175-218; the LSTM cell of rnn.py:124, the Dense of rnn_nade.py:54-57 / rnn_rbm.py:252-253).
+ * Every output is a fixed sequence of IEEE f32 operations -- z = ascending-k fmaf chain over xh = [x | x2 | h_prev] from 0, then + bias;
+ * i, f, o = det_sigmoid(z), ci = det_tanh(z) = 2 det_sigmoid(2 z) - 1; c = round(ci i) + round(c_prev f); h = det_tanh(c) o; Dense:
+ * ascending-k fmaf chain from 0, then + bias -- which oracle/det_ref.c restates, so a whole generate() scan is checked bit for bit.
+ * Weights are the f32 MASTER weights in their TF layout (LSTM kernel [(n_x + n_x2 + units), 4 units], column blocks i | ci | f | o;
+ * Dense kernel [K, N] with row pitch ld_w).  `jobs` is a HOST array of 1..MNN_DET_MAX_JOBS descriptors (passed to the kernel by
+ * value): the jobs of one call run as ONE launch -- the M per-track generators of a feedback-scan step.  x: u8 cells (0 / 1) or f32.
+ * ------------------------------------------------------------------------------------------ */
+#define MNN_DET_MAX_JOBS 8
+typedef struct {
+    const void* x; int x_dtype; int n_x; int ld_x;          /* first input block [B, ld_x]: MNN_U8 or MNN_F32; n_x may be 0 */
+    const float* x2; int n_x2; int ld_x2;                   /* optional second block (the feedback vector), concatenated behind x */
+    const float* h_prev; const float* c_prev;               /* [B, units]; both NULL = zero state */
+    const float* W; const float* bias;                      /* [(n_x + n_x2 + units), 4 units], [4 units] */
+    float* c_out; float* h_out;                             /* [B, units] (may not alias c_prev / h_prev) */
+    int units;                                              /* multiple of 32 */
+} mnn_det_lstm_job;
+typedef struct {
+    const float* x; int ld_x; int K;                        /* [B, ld_x] */
+    const float* W; int ld_w; int N;                        /* [K, ld_w >= N] */
+    const float* bias;                                      /* [N] or NULL */
+    float* out; int ld_out;                                 /* [B, ld_out >= N] */
+} mnn_det_dense_job;
+int mnn_lstm_step_det(mnn_stream_t s, int B, int njobs, const mnn_det_lstm_job* jobs);
+int mnn_dense_det(mnn_stream_t s, int B, int njobs, const mnn_det_dense_job* jobs);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement support (not on the product path).  mnn_probe_sigmoid: `blocks` x 256 threads x 8 independent chains x `iters`
  * sigmoids (the NADE kernels' v_exp_f32 + v_rcp_f32 form), out f32 [blocks*256]: bench.py times it with HIP events to get the
  * device's measured transcendental peak, the bound of the NADE phases in the step roofline.

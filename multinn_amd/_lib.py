@@ -51,7 +51,20 @@ SIGNATURES = {
     "mnn_bias_grad": (_i, [_p, _p, _i, _i, _i, _p, _i]),
     "mnn_grad_rows_fanout": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i]),
     "mnn_fill_f32": (_i, [_p, _p, _l, _f]),
+    "mnn_lstm_step_det": (_i, [_p, _i, _i, _p]),
+    "mnn_dense_det": (_i, [_p, _i, _i, _p]),
 }
+
+class DetLstmJob(C.Structure):
+    """mnn_det_lstm_job (include/multinn_hip.h)."""
+    _fields_ = [("x", _p), ("x_dtype", _i), ("n_x", _i), ("ld_x", _i), ("x2", _p), ("n_x2", _i), ("ld_x2", _i), ("h_prev", _p), ("c_prev", _p),
+                ("W", _p), ("bias", _p), ("c_out", _p), ("h_out", _p), ("units", _i)]
+
+
+class DetDenseJob(C.Structure):
+    """mnn_det_dense_job (include/multinn_hip.h)."""
+    _fields_ = [("x", _p), ("ld_x", _i), ("K", _i), ("W", _p), ("ld_w", _i), ("N", _i), ("bias", _p), ("out", _p), ("ld_out", _i)]
+
 
 class LstmFwdLayer(C.Structure):
     _fields_ = [("units", _i), ("xproj", _p), ("wh_t", _p), ("h0", _p), ("c0", _p), ("gates", _p), ("c", _p), ("h", _p), ("hT", _p), ("ld_hT", _i), ("y", _p), ("mask", _p),

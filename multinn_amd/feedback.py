@@ -5,7 +5,7 @@ import torch
 
 from . import ops
 from .common import Model, RNN, ParamStore
-from .generators import LstmStack, _compute_dtype
+from .generators import LstmStack, RnnEstimator, _compute_dtype, det_steps
 
 
 class FeedbackRnn(Model):
@@ -24,6 +24,8 @@ class FeedbackRnn(Model):
         self.seed, self.row0, self._ctx = seed, 0, None
         self._is_built = True
 
+    det_sampling = RnnEstimator.det_sampling            # the sampling scans' deterministic f32 arithmetic (see RnnEstimator)
+
     def build_metrics(self, targets, predictions, cond_probs=None, log_probs=None):
         return [], [], None
 
@@ -36,6 +38,15 @@ class FeedbackRnn(Model):
     def run(self, x, initial_state=None, train=False):
         """_apply_feedback(single_step=False): x [B,T,Din] -> (outputs [B,T,F] f32, final_state).  train=True keeps what backward() needs
         and applies the module's output dropout (multinn_feedback_rnn.py:56-57: built with is_train)."""
+        if not train and self.det_sampling:
+            # sampling: deterministic f32 steps on the master weights (generators.RnnEstimator.det_sampling), one per time step
+            xs = x if x.dtype in (torch.uint8, torch.float32) else x.float()
+            st = initial_state
+            outs = []
+            for t in range(xs.shape[1]):
+                h, st = self._stack.det_step(xs[:, t], st)
+                outs.append(h)
+            return torch.stack(outs, 1), st
         self._stack.pack()
         self._rnn.build_cell(bool(train))
         kp = self._rnn.effective_keep_prob() if train else 1.0
@@ -61,6 +72,8 @@ class FeedbackRnn(Model):
 
     def single(self, x, state):
         """_apply_feedback(single_step=True): x [B,Din] -> (output [B,F] f32, new_state)."""
+        if self.det_sampling:
+            return self._stack.det_step(x if x.dtype in (torch.uint8, torch.float32) else x.float(), state)
         xin = torch.zeros((x.shape[0], self._stack.ld0), device=x.device, dtype=self.dtype)
         ops.convert2d(x.contiguous(), xin[:, :x.shape[1]])
         h, new = self._stack.single_step(xin, state)
@@ -202,6 +215,12 @@ class FeedbackRnnSampler:
 
         return self._scan_graphs.run(key, x_u8, scan, lambda sx: self._generate_scan(sx, min(int(num_steps), 2)), stale)
 
+    def _group_dense(self, hs, rnn_states):
+        """The M generators' Dense layers on their top outputs in one launch -> their RnnEstimatorStateTuples."""
+        jobs, outs = zip(*[g._det_dense_job(h) for g, h in zip(self.generators, hs)])
+        ops.dense_det(list(jobs))
+        return [g._state_from_dense(o, tuple(st)) for g, o, st in zip(self.generators, outs, rnn_states)]
+
     def _generate_scan(self, x_u8, num_steps):
         B, Ti, P, M = x_u8.shape
         assert M == self.num_tracks
@@ -218,12 +237,26 @@ class FeedbackRnnSampler:
         x_u8 = enc_tracks[0]
         stack = torch.stack(enc_tracks, 3).reshape(B, -1, P * M)                                    # feature p*M+m (stack axis 3 + reshape)
         x_fb, fb_state = self.feedback.run(stack)
+        det = all(getattr(g, "det_sampling", False) for g in self.generators)
+        # deterministic arithmetic: the M generators' LSTM steps of a time step run as ONE launch per layer, their Dense layers as one more
+        # (ops.lstm_step_det / dense_det take up to 8 jobs) -- the tracks are independent inside a step
+        group = det and all(hasattr(g, "_det_dense_job") for g in self.generators) and \
+            len({len(g._rnn.num_units) for g in self.generators}) == 1 and M <= 8
         states = []
         for i, g in enumerate(self.generators):
             g._materialize(P + x_fb.shape[-1])
             g._rnn.build_cell(False)
-            g._ensure_packed()
-            states.append(g.steps(torch.cat([enc_tracks[i].float(), x_fb], -1)))                    # multinn_feedback.py:143-149
+            if not det:
+                g._ensure_packed()
+        if group:
+            sts = [None] * M
+            for t in range(stack.shape[1]):
+                res = det_steps([g._stack for g in self.generators], [e[:, t] for e in enc_tracks], sts, [x_fb[:, t]] * M)
+                sts = [r[1] for r in res]
+            states = self._group_dense([r[0] for r in res], sts)
+        else:
+            for i, g in enumerate(self.generators):
+                states.append(g.steps(torch.cat([enc_tracks[i].float(), x_fb], -1)))                # multinn_feedback.py:143-149
         out = torch.empty((B, num_steps, P, M), device=dev, dtype=torch.uint8)
         # Inside a step the tracks are independent: generator i's {sample | LSTM step, Dense} run on stream i, joined on
         # the main stream around the feedback step.  Their single steps take the launch-per-step LSTM kernels: persistent launches
@@ -255,11 +288,16 @@ class FeedbackRnnSampler:
                 st = torch.stack(samples, -1)                                                       # [B,P,M]
                 out[:, s] = st
                 fb, fb_state = self.feedback.single(st.reshape(B, P * M), fb_state)
+                if group:                               # on the main stream: two grouped LSTM launches + one grouped Dense for all M tracks
+                    res = det_steps([g._stack for g in self.generators], samples, [list(s_.rnn_state) for s_ in states], [fb] * M)
+                    states = self._group_dense([r[0] for r in res], [r[1] for r in res])
+                    continue
                 for i, g in enumerate(self.generators):
                     if par:
                         lanes[i].wait_stream(main)
                     with on(i):
-                        states[i] = g.single_step(torch.cat([samples[i].float(), fb], 1), states[i])
+                        states[i] = g.single_step(samples[i], states[i], x2=fb) if det else \
+                            g.single_step(torch.cat([samples[i].float(), fb], 1), states[i])
             if par:
                 for ln in lanes:
                     main.wait_stream(ln)

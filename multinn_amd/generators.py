@@ -548,6 +548,52 @@ class LstmStack:
         y, _, final = self.forward(x.view(1, *x.shape), 1.0, save=False, state0=state)
         return y[0], [(c, h) for c, h in final]
 
+    # -- deterministic f32 single steps (csrc/det_step.hip): the arithmetic of every sampling scan -----------------------------------
+    def det_job(self, l, x, n_x, x2, st):
+        """Descriptor of layer l's deterministic step (ops.lstm_step_det) with fresh f32 outputs.  The master weights are read in place."""
+        u = self.rnn.num_units[l]
+        ref = x if x is not None else x2
+        c = torch.empty((ref.shape[0], u), device=ref.device)
+        h = torch.empty_like(c)
+        pre = self.rnn.prefix
+        return dict(x=x, n_x=n_x, x2=x2, h_prev=None if st is None else st[1], c_prev=None if st is None else st[0],
+                    W=self.store[f"{pre}/cell_{l}/kernel"], bias=self.store[f"{pre}/cell_{l}/bias"], c_out=c, h_out=h)
+
+    def det_step(self, x, state, x2=None):
+        """One deterministic f32 step of the stack: x u8 | f32 [B, n_x] (unit inner stride), optional x2 f32 [B, n_x2] concatenated behind
+        it; state [(c, h)...] f32 or None (zero state) -> (h_top f32 [B, u_last], new_state)."""
+        return det_steps([self], [x], [state], [x2])[0]
+
+
+def _det_f32(t):
+    return t if t is None or t.dtype == torch.float32 else t.float()
+
+
+def det_steps(stacks, xs, states, x2s=None):
+    """One deterministic step of several LSTM stacks of equal depth (the M per-track generators of a feedback-scan step): layer by layer,
+    the stacks' jobs of a layer run as ONE launch.  Returns [(h_top, new_state)] per stack."""
+    n = len(stacks)
+    x2s = x2s if x2s is not None else [None] * n
+    L = len(stacks[0].rnn.num_units)
+    assert all(len(s.rnn.num_units) == L for s in stacks)
+    inp, inp2 = list(xs), list(x2s)
+    new = [[] for _ in range(n)]
+    for l in range(L):
+        jobs = []
+        for i, s in enumerate(stacks):
+            x = inp[i]
+            if x is not None and x.dtype not in (torch.uint8, torch.float32):
+                x = x.float()
+            st = None if states[i] is None else (_det_f32(states[i][l][0]).contiguous(), _det_f32(states[i][l][1]).contiguous())
+            n_x = s.rnn.layer_inputs()[l] - (inp2[i].shape[1] if inp2[i] is not None else 0)
+            jobs.append(s.det_job(l, x, n_x, inp2[i], st))
+        ops.lstm_step_det(jobs)
+        for i, j in enumerate(jobs):
+            new[i].append((j["c_out"], j["h_out"]))
+            inp[i], inp2[i] = j["h_out"], None
+    return [(inp[i], new[i]) for i in range(n)]
+
+
 
 # ------------------------------------------------------------------------------------------------
 class Generator(Model):
@@ -669,8 +715,32 @@ class RnnEstimator(Generator):
         self._n_valid = max(int(n_tot), 1)              # ragged windows run eagerly: a host read is allowed here
         return (mask / n_tot).reshape(-1).contiguous()
 
+    # The sampling scans -- generate(), and the feedback modes' scans through steps() / single_step() -- run in DETERMINISTIC f32 arithmetic
+    # on the master weights whatever the training precision is (csrc/det_step.hip; the reference samples in f32 too): every LSTM step, Dense
+    # and conditional is a fixed sequence of IEEE operations that the tests' C checker restates, so a whole scan is checked bit for bit
+    # (BASELINE.json: "bit-exact for Bernoulli sampling indices under a fixed RNG").  MULTINN_DET_SAMPLING=0 restores the throughput
+    # kernels (hardware exp2 / rcp activations, packed 16-bit weights), whose scans can only be checked to a tolerance.
+    det_sampling = os.environ.get("MULTINN_DET_SAMPLING", "1") != "0"
+
     def steps(self, inputs, initial_state=None):
+        """rnn_estimator.py:237-252: run the RNN over `inputs` [B,T,Din] and return the state after the last step."""
+        if self.det_sampling:
+            self._materialize(inputs.shape[-1])
+            if inputs.dim() == 2:
+                inputs = inputs[:, None, :]
+            x = inputs if inputs.dtype in (torch.uint8, torch.float32) else inputs.float()
+            st = None if initial_state is None else [(c, h) for c, h in initial_state.rnn_state]
+            h = None
+            for t in range(x.shape[1]):
+                h, st = self._stack.det_step(x[:, t], st)
+            return self._det_state(h, st)
         return self._get_state(inputs, initial_state=initial_state, last_outputs=True)
+
+    def _det_single_step(self, inputs, initial_state, x2=None):
+        """single_step in the deterministic arithmetic: inputs u8 | f32 [B, n_x]; x2 (optional, f32 [B, F]) is concatenated behind it -- the
+        feedback vector of multinn_feedback.py:85-91, read in place instead of through a torch.cat."""
+        h, new = self._stack.det_step(inputs, [(c, hh) for c, hh in initial_state.rnn_state], x2=x2)
+        return self._det_state(h, new)
 
     def check(self):
         """Raise if a persistent recurrence launch of this generator ever gave up on a bounded spin (LstmStack.check)."""
@@ -766,8 +836,11 @@ class RnnEstimator(Generator):
     def _generate_scan(self, x, num_steps):
         self._materialize(x.shape[-1])
         self._rnn.build_cell(False)
-        self._ensure_packed()
-        state = self._get_state(x, lengths=None, last_outputs=True)
+        if self.det_sampling:
+            state = self.steps(x)
+        else:
+            self._ensure_packed()
+            state = self._get_state(x, lengths=None, last_outputs=True)
         intro = x[:, -1, :]
         out = []
         for s in range(num_steps):
@@ -1150,8 +1223,29 @@ class RnnNade(RnnEstimator):
             out = self._dense(y.view(T * B, -1))[flat_index(lengths, B, T, inputs.device)]
         return self._state_from_dense(out, tuple((c.clone(), h.clone()) for c, h in final))
 
-    def single_step(self, inputs, initial_state):
+    def _det_fc_bias(self):
+        if not self.internal_bias:
+            return self.store["dense/bias"]
+        b = torch.empty(self.n_out, device=self.store.theta.device)          # dense/bias + [b_enc | b_dec] (see _init_estimator)
+        ops.axpby(1.0, self.store["dense/bias"], 1.0, self._internal_flat(self.store.theta), b)
+        return b
+
+    def _det_dense_job(self, h):
+        """(job, out): the Dense layer on h f32 [B, R] in the deterministic arithmetic (ops.dense_det), master weights in place."""
+        out = torch.empty((h.shape[0], self.ldo), device=h.device)            # columns [n_out, ldo) are alignment only: no kernel reads them
+        return dict(x=h, W=self.store["dense/kernel"], bias=self._det_fc_bias(), out=out[:, :self.n_out]), out
+
+    def _det_state(self, h, rnn_state):
+        job, out = self._det_dense_job(h)
+        ops.dense_det([job])
+        return self._state_from_dense(out, tuple(rnn_state))
+
+    def single_step(self, inputs, initial_state, x2=None):
         """rnn_nade.py:253-277."""
+        if self.det_sampling:
+            return self._det_single_step(inputs, initial_state, x2)
+        if x2 is not None:
+            inputs = torch.cat([inputs.float(), x2], 1)
         x = self._step_input(inputs.shape[0], inputs.device)
         ops.convert2d(inputs.contiguous() if inputs.dtype in (torch.uint8, torch.float32, torch.bfloat16, torch.float16) else inputs.float(),
                       x[:, :inputs.shape[1]])
@@ -1369,8 +1463,21 @@ class RnnRBM(RnnEstimator):
         Hn, D = self.num_hidden[-1], self.num_dims
         return RnnEstimatorStateTuple(out[:, :Hn], out[:, Hn:Hn + D], tuple((c.clone(), h.clone()) for c, h in final))
 
-    def single_step(self, inputs, initial_state):
+    def _det_state(self, h, rnn_state):
+        """rnn_rbm.py:240-259 in the deterministic arithmetic: bh_t = rbm.bh + h . Wuh, bv_t = rbm.bv + h . Wuv (two jobs, one launch)."""
+        Hn, D = self.num_hidden[-1], self.num_dims
+        out = torch.empty((h.shape[0], self.ldo), device=h.device)
+        ib = self.internal_bias
+        ops.dense_det([dict(x=h, W=self.store["Wuh"], bias=self._rbm.bh.view(-1) if ib else None, out=out[:, :Hn]),
+                       dict(x=h, W=self.store["Wuv"], bias=self._rbm.bv.view(-1) if ib else None, out=out[:, Hn:Hn + D])])
+        return RnnEstimatorStateTuple(out[:, :Hn], out[:, Hn:Hn + D], tuple(rnn_state))
+
+    def single_step(self, inputs, initial_state, x2=None):
         """rnn_rbm.py:261-281."""
+        if self.det_sampling:
+            return self._det_single_step(inputs, initial_state, x2)
+        if x2 is not None:
+            inputs = torch.cat([inputs.float(), x2], 1)
         x = self._step_input(inputs.shape[0], inputs.device)
         ops.convert2d(inputs.contiguous(), x[:, :inputs.shape[1]])
         h, new = self._stack.single_step(x, [(c, hh) for c, hh in initial_state.rnn_state])

@@ -736,3 +736,51 @@ def log_loss_rows(targets, probs, out):
     _req(probs.dtype == torch.float32 and probs.shape == (N, D) and probs.stride(1) == 1, "log_loss_rows: probs f32 [N,D]")
     _req(out.dtype == torch.float32 and out.numel() == N and out.is_contiguous(), "log_loss_rows: out f32 [N]")
     call("mnn_log_loss_rows", _stream(), _ptr(targets), _ptr(probs), N, D, probs.stride(0), _ptr(out))
+
+
+# ------------------------------------------------------------------------------------------------
+# deterministic f32 single steps of the sampling scan (csrc/det_step.hip)
+def lstm_step_det(jobs):
+    """One LSTMBlockCell step per job, ALL jobs in one launch.  job = dict(x=[B, >= n_x] u8 | f32 (or None), n_x, x2=f32 [B, n_x2] or None,
+    h_prev / c_prev f32 [B, u] or None (zero state), W f32 [(n_x + n_x2 + u), 4u] (TF layout), bias f32 [4u], c_out / h_out f32 [B, u])."""
+    _req(1 <= len(jobs) <= 8, "lstm_step_det: 1..8 jobs")
+    arr = (_lib.DetLstmJob * len(jobs))()
+    B = jobs[0]["c_out"].shape[0]
+    for a, j in zip(arr, jobs):
+        u = j["c_out"].shape[1]
+        x, x2 = j.get("x"), j.get("x2")
+        n_x = int(j.get("n_x", x.shape[1] if x is not None else 0))
+        n_x2 = x2.shape[1] if x2 is not None else 0
+        W, b = j["W"], j["bias"]
+        _req(W.dtype == torch.float32 and W.is_contiguous() and tuple(W.shape) == (n_x + n_x2 + u, 4 * u), f"lstm_step_det: W {tuple(W.shape)} != ({n_x + n_x2 + u}, {4 * u})")
+        _req(b.dtype == torch.float32 and b.is_contiguous() and b.numel() == 4 * u, "lstm_step_det: bias f32 [4u]")
+        for k in ("c_out", "h_out", "h_prev", "c_prev"):
+            t = j.get(k)
+            _req(t is None or (t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (B, u)), f"lstm_step_det: {k} must be contiguous f32 [B, u]")
+        if x is not None:
+            _rowmajor(x, "lstm_step_det x")
+            _req(x.shape[0] == B and x.shape[1] >= n_x and x.dtype in (torch.uint8, torch.float32), "lstm_step_det: x is u8 / f32 [B, >= n_x]")
+        if x2 is not None:
+            _rowmajor(x2, "lstm_step_det x2")
+            _req(x2.shape[0] == B and x2.dtype == torch.float32, "lstm_step_det: x2 is f32 [B, n_x2]")
+        a.x, a.x_dtype, a.n_x, a.ld_x = (_ptr(x) if x is not None else None), (dtype_code(x) if x is not None else F32), n_x, (x.stride(0) if x is not None else 0)
+        a.x2, a.n_x2, a.ld_x2 = (_ptr(x2) if x2 is not None else None), n_x2, (x2.stride(0) if x2 is not None else 0)
+        a.h_prev, a.c_prev = _ptr(j.get("h_prev")), _ptr(j.get("c_prev"))
+        a.W, a.bias, a.c_out, a.h_out, a.units = _ptr(W), _ptr(b), _ptr(j["c_out"]), _ptr(j["h_out"]), u
+    call("mnn_lstm_step_det", _stream(), B, len(jobs), arr)
+
+
+def dense_det(jobs):
+    """out = x . W + bias per job (ascending-k fmaf chain), all jobs in one launch.  job = dict(x f32 [B, K], W f32 [K, N] (row pitch >= N),
+    bias f32 [N] or None, out f32 [B, >= N] view)."""
+    _req(1 <= len(jobs) <= 8, "dense_det: 1..8 jobs")
+    arr = (_lib.DetDenseJob * len(jobs))()
+    B = jobs[0]["x"].shape[0]
+    for a, j in zip(arr, jobs):
+        x, W, b, out = j["x"], j["W"], j.get("bias"), j["out"]
+        _rowmajor(x, "dense_det x"); _rowmajor(W, "dense_det W"); _rowmajor(out, "dense_det out")
+        K, N = W.shape
+        _req(x.dtype == W.dtype == out.dtype == torch.float32 and x.shape == (B, K) and out.shape[0] == B and out.shape[1] == N, "dense_det: f32 x [B,K], W [K,N], out [B,N]")
+        _req(b is None or (b.dtype == torch.float32 and b.is_contiguous() and b.numel() == N), "dense_det: bias f32 [N]")
+        a.x, a.ld_x, a.K, a.W, a.ld_w, a.N, a.bias, a.out, a.ld_out = _ptr(x), x.stride(0), K, _ptr(W), W.stride(0), N, _ptr(b), _ptr(out), out.stride(0)
+    call("mnn_dense_det", _stream(), B, len(jobs), arr)

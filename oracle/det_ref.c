@@ -114,3 +114,53 @@ void rbm_gibbs_det(int N, int D, int Hn, int k, const uint8_t* v0, const float* 
     }
     for (long e = 0; e < (long)N * D; ++e) v_out[e] = (uint8_t)vbuf[e];
 }
+
+/* ---- deterministic single steps of the sampling scan (DESIGN.md "Deterministic sampling"; the device side is csrc/det_step.hip) ----
+ * det_tanh(x) = 2 det_sigmoid(2 x) - 1 (both multiplications by 2 are exact; one rounding in the subtraction). */
+static float det_tanh(float x) { return 2.0f * det_sigmoid(2.0f * x) - 1.0f; }
+
+/* rnn.py:124 (CudnnCompatibleLSTMCell = LSTMBlockCell, forget_bias 0): xh = [x | h_prev]; z = xh . W + b with W [(n_in + u), 4u], column
+ * blocks i | ci | f | o; every z is ONE ascending-k fmaf chain from 0 followed by the bias add.  h_prev / c_prev NULL = zero state. */
+void lstm_step_det(int B, int n_in, int u, const float* x, int ld_x, const float* h_prev, const float* c_prev, const float* W,
+                   const float* bias, float* c_out, float* h_out) {
+    float z[4 * 1024];                               /* u <= 1024 */
+    for (int n = 0; n < B; ++n) {
+        /* the chains of the 4u columns advance together, k ascending (each z[col] is still ONE chain: the loop order only lets the
+         * compiler use vector fma instructions across columns) */
+        for (int col = 0; col < 4 * u; ++col) z[col] = 0.0f;
+        for (int k = 0; k < n_in; ++k) {
+            const float xv = x[(long)n * ld_x + k];
+            const float* w = W + (long)k * 4 * u;
+            for (int col = 0; col < 4 * u; ++col) z[col] = fmaf(xv, w[col], z[col]);
+        }
+        for (int k = 0; k < u; ++k) {
+            const float hv = h_prev ? h_prev[(long)n * u + k] : 0.0f;
+            const float* w = W + (long)(n_in + k) * 4 * u;
+            for (int col = 0; col < 4 * u; ++col) z[col] = fmaf(hv, w[col], z[col]);
+        }
+        for (int col = 0; col < 4 * u; ++col) z[col] = z[col] + bias[col];
+        for (int j = 0; j < u; ++j) {
+            const float gi = det_sigmoid(z[j]), gc = det_tanh(z[u + j]), gf = det_sigmoid(z[2 * u + j]), go = det_sigmoid(z[3 * u + j]);
+            const float cp = c_prev ? c_prev[(long)n * u + j] : 0.0f;
+            const float t1 = gc * gi, t2 = cp * gf;
+            const float c = t1 + t2;
+            c_out[(long)n * u + j] = c;
+            h_out[(long)n * u + j] = det_tanh(c) * go;
+        }
+    }
+}
+
+/* tf.layers.Dense (rnn_nade.py:54-57, rnn_rbm.py:252-253): out = x . W + b, W [K, N]; ascending-k fmaf chain from 0, then + b. */
+void dense_det(int B, int K, int N, const float* x, int ld_x, const float* W, const float* bias, float* out, int ld_out) {
+    for (int n = 0; n < B; ++n) {
+        float* o = out + (long)n * ld_out;
+        for (int j = 0; j < N; ++j) o[j] = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const float xv = x[(long)n * ld_x + k];
+            const float* w = W + (long)k * N;
+            for (int j = 0; j < N; ++j) o[j] = fmaf(xv, w[j], o[j]);
+        }
+        if (bias)
+            for (int j = 0; j < N; ++j) o[j] = o[j] + bias[j];
+    }
+}
