@@ -275,7 +275,7 @@ class FeedbackRnnSampler:
             for s in range(num_steps):                                                              # _feedback_recurrence (175-218)
                 samples = []
                 for i, g in enumerate(self.generators):
-                    if par and s == 0:
+                    if par and (s == 0 or group):           # grouped steps run on the main stream: every lane waits for their Dense outputs
                         lanes[i].wait_stream(main)
                     with on(i):
                         g._gen_step = s

@@ -279,11 +279,35 @@ def test_generate_scan(tracks):
     load_nade_params(gen, p)
     out = gen.generate(dev(intro), steps)
     assert out.shape == (B, steps, Din) and out.dtype == torch.uint8
-    _check_autoregressive_samples(out.cpu().numpy(), intro, p, 31, tracks, E)
+    # EVERY cell of the scan equals the deterministic float32 checker's (oracle/det_ref.c: LSTM steps, Dense, NADE conditionals)
+    assert np.array_equal(out.cpu().numpy(), det.rnn_nade_generate(intro, steps, p, 31, tracks=tracks))
+    _check_autoregressive_samples(out.cpu().numpy(), intro, p, 31, tracks, E)          # and the float64 oracle agrees wherever |u - p| > 2e-5
     assert torch.equal(out, gen.generate(dev(intro), steps))          # fixed RNG -> reproducible
     gen.row0 = 2                                                        # row-keyed RNG: a batch slice reproduces its rows
     sub = gen.generate(dev(intro[2:]), steps)
     assert torch.equal(sub, out[2:])
+
+
+@pytest.mark.parametrize("precision", ["fp16", "fp32"])
+def test_generate_scan_bit_exact_at_bench_size(precision):
+    """BASELINE.json: "bit-exact for Bernoulli sampling indices under a fixed RNG" -- the WHOLE scan of the bench's sampling leg (72 intros of
+    32 steps -> 128 generated steps, D = 440, NADE 256, LSTM [512, 256]; rnn_estimator.py:271-323) against the deterministic float32
+    checker: 72 x 128 x 440 cells, every one equal.  The scan runs in f32 on the master weights whatever the training precision is."""
+    from multinn_amd import RnnNade
+    B, Ti, D, Hn, units, steps = 72, 32, 440, 256, [512, 256], 128
+    R = np.random.default_rng(61)
+    intro = (R.random((B, Ti, D)) < 0.03).astype(np.uint8)
+    p = G.init_rnn_nade(62, D, D, Hn, units, np.float32)
+    p['fc_b'][Hn:] += np.float32(np.log(0.05 / 0.95))                  # piano-roll-like conditionals instead of coin flips
+    gen = RnnNade(D, Hn, units, precision=precision, seed=23)
+    gen._materialize(D)
+    load_nade_params(gen, p)
+    assert gen.det_sampling
+    got = gen.generate(dev(intro), steps).cpu().numpy()
+    ref = det.rnn_nade_generate(intro, steps, p, 23)
+    assert got.shape == ref.shape == (B, steps, D)
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} of {got.size} cells differ; first at {np.argwhere(got != ref)[:3].tolist()}"
+    assert 0.005 < got.mean() < 0.5 and got[:, 96:].any()
 
 
 @pytest.mark.parametrize("kind", ["nade", "multinade", "rbm"])
@@ -438,9 +462,33 @@ def test_feedback_rnn_sampling_scan():
     probs, us = G.feedback_rnn_teacher_forced(x, got, gparams, fb_layers, seeds)
     bad = (us < probs) != (got > 0)
     assert not (bad & (np.abs(us - probs) > 2e-5)).any()
-    ref, _ = G.feedback_rnn_generate(x, steps, gparams, fb_layers, seeds)
-    assert (ref == got).mean() > 0.99
+    # every cell equals the deterministic float32 checker's scan (oracle/det.py: feedback LSTM, M generators, Dense, NADE draws)
+    assert np.array_equal(got, det.feedback_rnn_generate(x, steps, gparams, fb_layers, seeds))
     assert torch.equal(out, FeedbackRnnSampler(gens, fb).generate(dev(x), steps))
+
+
+def test_feedback_scan_bit_exact_at_real_widths():
+    """C5 at its real widths (default_feedback_rnn.yaml:11-13: generators [256, 256], NADE 256, feedback LSTM [256, 128], P = 88, 5 tracks):
+    8 intros of 8 steps -> 64 generated steps, every cell of the 8 x 64 x 88 x 5 piano-roll equal to the deterministic checker's."""
+    from multinn_amd import RnnNade
+    from multinn_amd.feedback import FeedbackRnn, FeedbackRnnSampler
+    B, Ti, P, M, Hn, F, steps = 8, 8, 88, 5, 256, 128, 64
+    R = np.random.default_rng(71)
+    x = (R.random((B, Ti, P, M)) < .05).astype(np.uint8)
+    fb = FeedbackRnn(P * M, [256, F], precision="fp16", seed=40)
+    gens, gparams, seeds = [], [], []
+    for i in range(M):
+        g = RnnNade(P, Hn, [256, 256], precision="fp16", seed=50 + i)
+        g._materialize(P + F)
+        p = G.init_rnn_nade(80 + i, P + F, P, Hn, [256, 256], np.float32)
+        p['fc_b'][Hn:] += np.float32(np.log(0.1 / 0.9))
+        load_nade_params(g, p)
+        gens.append(g); gparams.append(p); seeds.append(50 + i)
+    fb_layers = [(fb.store[f"feedback/rnn/cell_{l}/kernel"].cpu().numpy(), fb.store[f"feedback/rnn/cell_{l}/bias"].cpu().numpy()) for l in range(2)]
+    got = FeedbackRnnSampler(gens, fb).generate(dev(x), steps).cpu().numpy()
+    ref = det.feedback_rnn_generate(x, steps, gparams, fb_layers, seeds)
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} of {got.size} cells differ; first at {np.argwhere(got != ref)[:3].tolist()}"
+    assert 0.005 < got.mean() < 0.6
 
 
 def test_dense_feedback_module_and_sampling_scan():

@@ -766,3 +766,42 @@ def test_eval_counts_and_log_loss_rows(ops):
     assert abs(m["accuracy"] - (tb == pb).mean()) < 1e-12
     assert abs(m["precision"] - (tb & pb).sum() / max(1, pb.sum())) < 1e-12 and abs(m["recall"] - (tb & pb).sum() / max(1, tb.sum())) < 1e-12
     assert abs(float(m["batch/loss"]) - float(loss.mean())) < 1e-6 and abs(m["f1_score"] - m["precision"]) < 1e-12        # R5: f1 uses precision twice
+
+
+def test_det_lstm_step_and_dense_bit_exact():
+    """mnn_lstm_step_det / mnn_dense_det (csrc/det_step.hip; rnn.py:124, rnn_nade.py:54-57) against oracle/det_ref.c: every bit of c, h and of
+    the Dense outputs -- u8 and f32 inputs, a second (feedback) input block, a zero state, row counts that are not a multiple of the
+    rows per workgroup, unit counts of 32 .. 512, and several jobs in one launch."""
+    from multinn_amd import ops
+    rng = np.random.default_rng(77)
+    jobs, refs = [], []
+    B = 13
+    for (n_x, n_x2, u, u8, zero) in [(20, 0, 32, True, True), (440, 0, 512, True, False), (88, 128, 256, True, False), (96, 0, 96, False, False)]:
+        W = (rng.standard_normal((n_x + n_x2 + u, 4 * u)) * 0.2).astype(np.float32)
+        b = (rng.standard_normal(4 * u) * 0.1).astype(np.float32)
+        x = (rng.random((B, n_x)) < 0.3).astype(np.uint8) if u8 else rng.standard_normal((B, n_x)).astype(np.float32)
+        x2 = rng.standard_normal((B, n_x2)).astype(np.float32) if n_x2 else None
+        c0 = None if zero else rng.standard_normal((B, u)).astype(np.float32)
+        h0 = None if zero else np.tanh(rng.standard_normal((B, u))).astype(np.float32)
+        xin = x.astype(np.float32) if x2 is None else np.concatenate([x.astype(np.float32), x2], 1)
+        _, st = det.lstm_step(xin, None if zero else [(c0, h0)], [(W, b)])
+        refs.append(st[0])
+        xd = torch.zeros((B, n_x + 3), dtype=torch.uint8 if u8 else torch.float32, device=DEV)        # a padded row pitch
+        xd[:, :n_x] = dev(x)
+        jobs.append(dict(x=xd, n_x=n_x, x2=None if x2 is None else dev(x2), h_prev=None if zero else dev(h0), c_prev=None if zero else dev(c0),
+                         W=dev(W), bias=dev(b), c_out=torch.empty((B, u), device=DEV), h_out=torch.empty((B, u), device=DEV)))
+    ops.lstm_step_det(jobs)                                            # four jobs of different widths: ONE launch
+    for j, (c_ref, h_ref) in zip(jobs, refs):
+        assert np.array_equal(j["c_out"].cpu().numpy(), c_ref) and np.array_equal(j["h_out"].cpu().numpy(), h_ref)
+    djobs, drefs = [], []
+    for (K, N, with_bias) in [(256, 696, True), (32, 5, False), (512, 344, True)]:
+        x = rng.standard_normal((B, K)).astype(np.float32)
+        W = (rng.standard_normal((K, N)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32) if with_bias else None
+        out = torch.full((B, N + 8), -7.0, device=DEV)
+        djobs.append(dict(x=dev(x), W=dev(W), bias=None if b is None else dev(b), out=out[:, :N]))
+        drefs.append((det.dense(x, W, b), out))
+    ops.dense_det(djobs)
+    for j, (ref, full) in zip(djobs, drefs):
+        assert np.array_equal(j["out"].cpu().numpy(), ref)
+        assert bool((full[:, ref.shape[1]:] == -7.0).all())            # nothing written past N

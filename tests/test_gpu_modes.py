@@ -315,8 +315,7 @@ def test_c5_feedback_rnn_mode_sampling_scan():
     probs, us = G.feedback_rnn_teacher_forced(x, got, gparams, fb_layers, seeds)
     bad = (us < probs) != (got > 0)
     assert not (bad & (np.abs(us - probs) > 2e-5)).any()
-    ref, _ = G.feedback_rnn_generate(x, steps, gparams, fb_layers, seeds)
-    assert (ref == got).mean() > 0.99
+    assert np.array_equal(got, det.feedback_rnn_generate(x, steps, gparams, fb_layers, seeds))      # every cell == the deterministic checker's scan
     assert torch.equal(out, m.generate(steps))
     # eval build of the same mode: generator inputs = concat(track code, feedback vector)[:, :-1] (multinn_feedback.py:85-94)
     m.build(dev(x), lengths=None, is_train=False, mode="eval")
@@ -341,6 +340,8 @@ def test_c5_feedback_rnn_512_generated_steps():
     probs, us = G.feedback_rnn_teacher_forced(x, got, gparams, fb_layers, seeds)
     bad = (us < probs) != (got > 0)
     assert not (bad & (np.abs(us - probs) > 5e-5)).any(), int((bad & (np.abs(us - probs) > 5e-5)).sum())
+    ref = det.feedback_rnn_generate(x, steps, gparams, fb_layers, seeds)         # and bit for bit: all 512 x 4 x 88 x 5 cells
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} cells differ; first at {np.argwhere(got != ref)[:3].tolist()}"
     dens = got.mean()
     assert 0.01 < dens < 0.6, dens
     late = got[:, 384:]
