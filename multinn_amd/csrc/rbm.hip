@@ -248,6 +248,161 @@ static bool launch_gibbs_lds(hipStream_t st, int N, int D, int Hn, int k, const 
     return true;
 }
 
+// ----------------------------------------------------------------------------------------------
+// The chain on the MATRIX CORES, bit for bit the same draws (training batches, N >= 2048 rows).  v_mfma_f32_32x32x2_f32 computes
+// D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) with one IEEE rounding per product-add (cdna_hip_programming.md, "FP32-input MFMA"): a run of
+// such instructions over ascending k IS the ascending-index fmaf chain of the vector kernels above, so the logits -- and with them every
+// Bernoulli draw -- are identical, at the matrix pipe's rate instead of one fma per lane and term (the vector form reaches 22 TFLOP/s of the
+// 157 f32 peak: its inner loop is LDS reads and address arithmetic).  Layout: a workgroup (8 waves) owns 64 rows for the whole chain; W sits
+// in LDS once (f32 [D][Hn + 1]); the binary v / h states sit in LDS as BYTES (row pitch = an odd number of words: the B-operand reads of the
+// 32 rows of a tile hit 32 banks).  The product is formed TRANSPOSED, C[out unit][row] = sum_k W(k, unit) state[row][k] (A = the weights,
+// B = the states): a lane then holds four CONSECUTIVE output units of one row per accumulator quad = exactly the four uniforms of one
+// Philox block (element >> 2 is the block counter), so every Philox evaluation is used in full -- the vector kernels draw one element per
+// evaluation.  Hidden phase: 2 row tiles x (Hn / 32) unit tiles, two unit tiles per wave share the state operand; visible phase:
+// 2 x ceil(D / 32) jobs on the first waves (one K = Hn chain per output: it cannot be split without changing the summation order).
+// ----------------------------------------------------------------------------------------------
+typedef float gm_f32x16 __attribute__((ext_vector_type(16)));
+#define GM_ROWS 64
+
+struct GibbsMfmaArgs {
+    int N, D, Hn, k;
+    const uint8_t* v0; const float* W; const float* bh; int ld_bh; const float* bv; int ld_bv;
+    uint64_t seed; uint32_t row0; const uint32_t* row_ids; uint32_t sub0; float* p_v; uint8_t* v_out; const int* seed_step;
+};
+
+// pitch (bytes) of a byte-state row of `n` cells: covers n rounded up to even (the k pairs of the MFMA), a whole number of words, and an ODD
+// number of words (rows land in distinct banks)
+static __host__ __device__ __forceinline__ int gm_pitch(int n) { int w = (n + 1 + 3) / 4; return 4 * (w | 1); }
+
+// one output tile (32 units x 32 rows) of a phase: K ascending in pairs; A = W (unit, k) from LDS, B = the rows' byte states
+template <bool VIS>
+__device__ __forceinline__ void gm_chain(const float* __restrict__ Ws, int ldw, const uint8_t* __restrict__ st, int pitch, int K, int unit,
+                                         int lane, gm_f32x16& acc) {
+    const int r = lane & 31, hh = lane >> 5;
+    const uint8_t* sp = st + r * pitch + hh;
+    // hidden phase: A[i = hidden j][k = d] = W[d][j] (walks down a column); visible phase: A[i = visible d][k = j] = W[d][j] (walks a row)
+    const float* ap = VIS ? Ws + (size_t)unit * ldw + hh : Ws + (size_t)hh * ldw + unit;
+    const int astep = VIS ? 2 : 2 * ldw;
+#pragma unroll 4
+    for (int s = 0; s < K / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(size_t)s * astep], (float)sp[2 * s], acc, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(512) rbm_gibbs_mfma_kernel(GibbsMfmaArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint64_t seed = A.seed;
+    if (A.seed_step != nullptr) seed += (uint64_t)(int64_t)*A.seed_step;
+    const int N = A.N, D = A.D, Hn = A.Hn, ldw = Hn + 1;
+    const int De = (D + 1) & ~1, He = (Hn + 1) & ~1;          // K of the two phases (even; the states are zero past D / Hn)
+    const int pv = gm_pitch(D), ph = gm_pitch(Hn);
+    float* Ws = smem;                                         // [De][ldw] (row D, if any, repeats row D - 1: its inputs are zero)
+    uint8_t* vs = reinterpret_cast<uint8_t*>(Ws + (size_t)De * ldw);      // [64][pv]
+    uint8_t* hs = vs + GM_ROWS * pv;                                        // [64][ph]
+    const int n0 = blockIdx.x * GM_ROWS;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int d = w; d < De; d += 8)                          // one wave per row of W: coalesced
+        for (int j = lane; j < ldw; j += 64) Ws[d * ldw + j] = j < Hn ? A.W[(size_t)min(d, D - 1) * Hn + j] : 0.f;
+    for (int e = threadIdx.x; e < GM_ROWS * pv; e += 512) {
+        const int r = e / pv, kx = e - r * pv, n = n0 + r;
+        vs[e] = (n < N && kx < D) ? A.v0[(size_t)n * D + kx] : (uint8_t)0;
+    }
+    for (int e = threadIdx.x; e < GM_ROWS * ph; e += 512) hs[e] = 0;
+    const int r = lane & 31, hh = lane >> 5;
+    // jobs: hidden -- row tile w >> 2, unit tiles 2 (w & 3) + 8 q ... (two per pass, all Hn / 32 covered in ceil(Hn / 256) passes);
+    //       visible -- job id w (+ 8 per pass) = row tile * ndt + unit tile
+    const int nht = (Hn + 31) / 32, ndt = (D + 31) / 32;
+    const int rt_h = w >> 2;
+    const int row_h = n0 + 32 * rt_h + r;                     // the batch row of this lane's accumulator column (hidden jobs)
+    const uint32_t id_h = rbm_rowid(A.row_ids, A.row0, min(row_h, N - 1));
+    __syncthreads();
+    if (A.k == 0) {
+        for (int e = threadIdx.x; e < GM_ROWS * D; e += 512) {
+            const int rr = e / D, d = e - rr * D, n = n0 + rr;
+            if (n < N) {
+                if (A.p_v) A.p_v[(size_t)n * D + d] = (float)vs[rr * pv + d];
+                if (A.v_out) A.v_out[(size_t)n * D + d] = vs[rr * pv + d];
+            }
+        }
+        return;
+    }
+    for (int it = 0; it < A.k; ++it) {
+        // ---- hidden phase ----
+        for (int jt0 = 2 * (w & 3); jt0 < nht; jt0 += 8) {
+            gm_f32x16 acc[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+            const uint8_t* sp = vs + (32 * rt_h + r) * pv + hh;
+            const int u0 = min(32 * jt0 + r, Hn - 1), u1 = min(32 * (jt0 + 1) + r, Hn - 1);
+            const float* a0 = Ws + (size_t)hh * ldw + u0;
+            const float* a1 = Ws + (size_t)hh * ldw + u1;
+            const bool two = jt0 + 1 < nht;
+#pragma unroll 4
+            for (int s = 0; s < De / 2; ++s) {                // the two unit tiles share the state operand
+                const float b = (float)sp[2 * s];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[(size_t)s * 2 * ldw], b, acc[0], 0, 0, 0);
+                if (two) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[(size_t)s * 2 * ldw], b, acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (q == 1 && !two) break;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int j0 = 32 * (jt0 + q) + 8 * g4 + 4 * hh;          // four consecutive hidden units: one Philox block
+                    if (j0 >= Hn) continue;
+                    float u[4];
+                    philox_uniform4(seed, MNN_STREAM_RBM_H, id_h, A.sub0 + (uint32_t)it, (uint32_t)(j0 >> 2), u);
+                    uint32_t pk = 0u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int j = min(j0 + e, Hn - 1);
+                        const float bb = A.bh[(size_t)min(row_h, N - 1) * A.ld_bh + j];
+                        const float p = det_sigmoid(acc[q][4 * g4 + e] + bb);
+                        pk |= (u[e] < p && j0 + e < Hn ? 1u : 0u) << (8 * e);
+                    }
+                    *reinterpret_cast<uint32_t*>(hs + (32 * rt_h + r) * ph + j0) = pk;     // j0 % 4 == 0, ph % 4 == 0
+                }
+            }
+        }
+        __syncthreads();
+        // ---- visible phase ----
+        const bool last = it == A.k - 1;
+        for (int job = w; job < 2 * ndt; job += 8) {
+            const int rt = job / ndt, dt = job - rt * ndt;
+            gm_f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            gm_chain<true>(Ws, ldw, hs + 32 * rt * ph, ph, He, min(32 * dt + r, D - 1), lane, acc);
+            const int row = n0 + 32 * rt + r;
+            const uint32_t idv = rbm_rowid(A.row_ids, A.row0, min(row, N - 1));
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = 32 * dt + 8 * g4 + 4 * hh;
+                if (d0 >= D) continue;
+                float u[4];
+                philox_uniform4(seed, MNN_STREAM_RBM_V, idv, A.sub0 + (uint32_t)it, (uint32_t)(d0 >> 2), u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int d = d0 + e;
+                    if (d >= D) continue;
+                    const float p = det_sigmoid(acc[4 * g4 + e] + A.bv[(size_t)min(row, N - 1) * A.ld_bv + d]);
+                    const uint8_t sv = u[e] < p ? 1 : 0;
+                    vs[(32 * rt + r) * pv + d] = sv;
+                    if (last && row < N) {
+                        if (A.p_v) A.p_v[(size_t)row * D + d] = p;
+                        if (A.v_out) A.v_out[(size_t)row * D + d] = sv;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static size_t gibbs_mfma_lds_bytes(int D, int Hn) {
+    return (size_t)((D + 1) & ~1) * (Hn + 1) * sizeof(float) + (size_t)GM_ROWS * (gm_pitch(D) + gm_pitch(Hn));
+}
+
 extern "C" size_t mnn_rbm_workspace_bytes(int D, int Hn) { return (size_t)D * Hn * sizeof(float); }
 
 extern "C" int mnn_transpose(mnn_stream_t s, const void* in, int in_dtype, int R, int C, int ld_in, void* out, int out_dtype, int ld_out);
@@ -277,6 +432,18 @@ extern "C" int mnn_rbm_gibbs_stepped(mnn_stream_t s, int N, int D, int Hn, int k
             MNN_LAUNCH_CHECK();
             return MNN_OK;
         }
+    }
+    if (gibbs_mfma_lds_bytes(D, Hn) <= 158 * 1024 && getenv("MNN_RBM_NO_MFMA") == nullptr) {
+        // training batches: the chain on the f32 matrix cores (same draws: see rbm_gibbs_mfma_kernel)
+        static bool raised = false;
+        if (!raised) {
+            MNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rbm_gibbs_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+        GibbsMfmaArgs a{N, D, Hn, k, v0, W, bh, ld_bh, bv, ld_bv, seed, row0, row_ids, sub0, p_v, v_out, seed_step};
+        hipLaunchKernelGGL(rbm_gibbs_mfma_kernel, dim3(cdiv(N, GM_ROWS)), dim3(512), gibbs_mfma_lds_bytes(D, Hn), (hipStream_t)s, a);
+        MNN_LAUNCH_CHECK();
+        return MNN_OK;
     }
     int rc = mnn_transpose(s, W, MNN_F32, D, Hn, Hn, workspace, MNN_F32, D);
     if (rc != MNN_OK) return rc;

@@ -232,6 +232,7 @@ class FeedbackRnnSampler:
         [B, Ti+1, E] (zero first step included) -> sampled codes u8 [B, num_steps, E, M]; the caller decodes them through
         its encoders (identity for PassEncoder)."""
         M = self.num_tracks
+        enc_tracks = [e.contiguous() for e in enc_tracks]            # (views of a [B, T, P, M] roll have inner stride M)
         B, _, P = enc_tracks[0].shape
         dev = enc_tracks[0].device
         x_u8 = enc_tracks[0]

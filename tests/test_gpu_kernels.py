@@ -647,10 +647,13 @@ def test_nade_sample_near_ties_take_the_exact_comparison(ops):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,D,Hn,k,bcast", [(20, 88, 256, 10, False), (9, 30, 20, 3, True), (17, 440, 64, 2, False), (5, 12, 7, 0, False),
                                             (2101, 88, 256, 2, False), (2050, 40, 100, 2, True), (33, 200, 130, 2, False), (2049, 130, 200, 1, False),
-                                            (40, 200, 100, 2, False), (2060, 200, 100, 1, True)])
+                                            (40, 200, 100, 2, False), (2060, 200, 100, 1, True), (2053, 13, 21, 3, False), (2048, 12, 7, 0, False),
+                                            (4096, 88, 256, 10, False), (2050, 300, 280, 1, False)])
 def test_rbm_gibbs_bit_exact(ops, N, D, Hn, k, bcast):
     """Below 2048 rows with D, Hn <= 256: W resident in LDS, two rows per workgroup (rows split over spare threads when a phase has
-    at most 128 outputs); otherwise the streaming kernel.  Every form must reproduce the oracle's draws and probabilities."""
+    at most 128 outputs); from 2048 rows on the chain runs on the f32 matrix cores (v_mfma_f32_32x32x2_f32 = the same ascending fmaf chain:
+    odd widths, widths that are no multiple of the 32-unit tile, a shared bias row, k = 0) while W and the byte states fit LDS, else the
+    streaming kernel (the last shape).  Every form must reproduce the oracle's draws and probabilities."""
     R = np.random.default_rng(D)
     W = (R.standard_normal((D, Hn)) * .3).astype(np.float32)
     bh = (R.standard_normal((1 if bcast else N, Hn)) * .3).astype(np.float32)
