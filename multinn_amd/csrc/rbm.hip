@@ -483,8 +483,81 @@ rbm_half_kernel(int N, int K, int n_out, const TV* __restrict__ in, const float*
     });
 }
 
+// The half-step on the f32 matrix cores (same ascending fmaf chain per output: see rbm_gibbs_mfma_kernel): 64 rows per workgroup, the rows'
+// inputs in LDS as f32 [64][odd pitch], Wk [K][n_out] in LDS, C[out unit][row] tiles of 32 x 32 spread over the 8 waves; a lane's accumulator
+// quad = four consecutive outputs of one row = one Philox block.  From 2048 rows on (DBN encode / decode of a training batch, dbn.py:136-180,
+// and the free-energy gradient's hidden passes).
+template <typename TV>
+__global__ void __launch_bounds__(512)
+rbm_half_mfma_kernel(int N, int K, int n_out, const TV* __restrict__ in, const float* __restrict__ Wk, int ldw, const float* __restrict__ b, int ld_b,
+                     int stream_id, uint64_t seed, uint32_t row0, uint32_t sub, float* __restrict__ p_out, uint8_t* __restrict__ s_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Ke = (K + 1) & ~1, lw = n_out | 1, pin = Ke | 1;
+    float* Ws = smem;                       // [Ke][lw]
+    float* xs = smem + (size_t)Ke * lw;     // [64][pin]
+    const int n0 = blockIdx.x * GM_ROWS;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int k = w; k < Ke; k += 8)
+        for (int o = lane; o < lw; o += 64) Ws[k * lw + o] = o < n_out ? Wk[(size_t)min(k, K - 1) * ldw + o] : 0.f;
+    for (int e = threadIdx.x; e < GM_ROWS * pin; e += 512) {
+        const int r = e / pin, k = e - r * pin, n = n0 + r;
+        xs[e] = (n < N && k < K) ? (float)in[(size_t)n * K + k] : 0.f;
+    }
+    __syncthreads();
+    const int r = lane & 31, hh = lane >> 5;
+    const int not_ = (n_out + 31) / 32;
+    for (int job = w; job < 2 * not_; job += 8) {
+        const int rt = job / not_, ot = job - rt * not_;
+        gm_f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const float* ap = Ws + (size_t)hh * lw + min(32 * ot + r, n_out - 1);
+        const float* bp = xs + (32 * rt + r) * pin + hh;
+#pragma unroll 4
+        for (int s2 = 0; s2 < Ke / 2; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(size_t)s2 * 2 * lw], bp[2 * s2], acc, 0, 0, 0);
+        const int row = n0 + 32 * rt + r;
+        if (row >= N) continue;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int o0 = 32 * ot + 8 * g4 + 4 * hh;
+            if (o0 >= n_out) continue;
+            float u[4] = {0.f, 0.f, 0.f, 0.f};
+            if (s_out) philox_uniform4(seed, (uint32_t)stream_id, row0 + (uint32_t)row, sub, (uint32_t)(o0 >> 2), u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int o = o0 + e;
+                if (o >= n_out) continue;
+                const float p = det_sigmoid(acc[4 * g4 + e] + b[(size_t)row * ld_b + o]);
+                if (p_out) p_out[(size_t)row * n_out + o] = p;
+                if (s_out) s_out[(size_t)row * n_out + o] = u[e] < p ? 1 : 0;
+            }
+        }
+    }
+}
+static size_t half_mfma_lds_bytes(int K, int n_out) {
+    const int Ke = (K + 1) & ~1;
+    return ((size_t)Ke * (n_out | 1) + (size_t)GM_ROWS * (Ke | 1)) * sizeof(float);
+}
+
 static int launch_half(hipStream_t st, int N, int K, int n_out, const void* in, int in_dtype, const float* Wk, int ldw, const float* b,
                        int ld_b, int stream_id, uint64_t seed, uint32_t row0, uint32_t sub, float* p_out, uint8_t* s_out) {
+    if (N >= 2048 && half_mfma_lds_bytes(K, n_out) <= 158 * 1024 && getenv("MNN_RBM_NO_MFMA") == nullptr) {
+        static bool raised = false;
+        if (!raised) {
+            MNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rbm_half_mfma_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            MNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rbm_half_mfma_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+        const size_t l2 = half_mfma_lds_bytes(K, n_out);
+        if (in_dtype == MNN_U8)
+            hipLaunchKernelGGL(rbm_half_mfma_kernel<uint8_t>, dim3(cdiv(N, GM_ROWS)), dim3(512), l2, st, N, K, n_out, (const uint8_t*)in, Wk, ldw, b, ld_b,
+                               stream_id, seed, row0, sub, p_out, s_out);
+        else
+            hipLaunchKernelGGL(rbm_half_mfma_kernel<float>, dim3(cdiv(N, GM_ROWS)), dim3(512), l2, st, N, K, n_out, (const float*)in, Wk, ldw, b, ld_b,
+                               stream_id, seed, row0, sub, p_out, s_out);
+        MNN_LAUNCH_CHECK();
+        return MNN_OK;
+    }
     const size_t lds = (size_t)RBM_R * ((K + 3) & ~3) * sizeof(float);
     if (in_dtype == MNN_U8)
         hipLaunchKernelGGL(rbm_half_kernel<uint8_t>, dim3(cdiv(N, RBM_R)), dim3(256), lds, st, N, K, n_out, (const uint8_t*)in, Wk, ldw, b, ld_b,

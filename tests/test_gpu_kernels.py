@@ -708,6 +708,32 @@ def test_rbm_half_steps_and_free_energy(ops):
     assert rel(F.cpu().numpy(), -Hn * np.log(2) - (v * bv).sum(1)) < 1e-6
 
 
+@pytest.mark.parametrize("N,D,Hn", [(2100, 88, 168), (2049, 168, 84), (2051, 13, 21)])
+def test_rbm_half_steps_on_the_matrix_cores_bit_exact(ops, N, D, Hn):
+    """From 2048 rows on the half-steps run on v_mfma_f32_32x32x2_f32 (rbm_half_mfma_kernel): probabilities and draws bit-identical to the
+    deterministic checker -- byte and float inputs, per-row and shared bias rows, widths that are odd / no multiple of the 32-unit tile."""
+    R = np.random.default_rng(N)
+    W = (R.standard_normal((D, Hn)) * .3).astype(np.float32)
+    bh = (R.standard_normal((N, Hn)) * .3).astype(np.float32)
+    bv = (R.standard_normal((1, D)) * .3).astype(np.float32)
+    v = (R.random((N, D)) < .2).astype(np.uint8)
+    p_h = torch.zeros((N, Hn), device=DEV); h = torch.zeros((N, Hn), device=DEV, dtype=torch.uint8)
+    ops.rbm_hidden(dev(v), dev(W), dev(bh), philox.STREAM_DBN_ENC, 5, 40, 2, p_h, h)
+    ph_ref = det.rbm_hidden(v, W, bh)
+    assert np.array_equal(p_h.cpu().numpy(), ph_ref)
+    u = philox.uniform_block(5, philox.STREAM_DBN_ENC, np.arange(40, 40 + N), 2, Hn)
+    assert np.array_equal(h.cpu().numpy(), (u < ph_ref).astype(np.uint8))
+    p_v = torch.zeros((N, D), device=DEV); vs = torch.zeros((N, D), device=DEV, dtype=torch.uint8)
+    ops.rbm_visible(h, dev(W), dev(bv), philox.STREAM_DBN_DEC, 5, 40, 2, p_v, vs)
+    pv_ref = det.rbm_visible(h.cpu().numpy(), W, bv)
+    assert np.array_equal(p_v.cpu().numpy(), pv_ref)
+    u = philox.uniform_block(5, philox.STREAM_DBN_DEC, np.arange(40, 40 + N), 2, D)
+    assert np.array_equal(vs.cpu().numpy(), (u < pv_ref).astype(np.uint8))
+    p_h2 = torch.zeros((N, Hn), device=DEV)                                # float inputs (probabilities)
+    ops.rbm_hidden(p_v, dev(W), dev(bh), 0, 0, 0, 0, p_h2, None)
+    assert np.array_equal(p_h2.cpu().numpy(), det.rbm_hidden(pv_ref, W, bh))
+
+
 # ------------------------------------------------------------------------------------------------
 def test_reductions_and_adam(ops):
     R = np.random.default_rng(10)
