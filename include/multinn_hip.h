@@ -302,6 +302,18 @@ int mnn_nade_logprob_bwd_ws(mnn_stream_t s, int tracks, int N, int D, int Hn, co
 int mnn_nade_sample(mnn_stream_t s, int tracks, int N, int D, int Hn, const float* bias, int ld_bias, const float* w_enc,
                     const float* w_dec, float temperature, uint64_t seed, uint32_t row0, uint32_t sub, uint8_t* samples,
                     long s_track_stride, int s_row_stride, int s_elem_stride, float* nll);
+/* mnn_nade_sample for SEVERAL single-NADE generators in ONE launch (multinn_feedback.py:196: every per-track generator's sample_single in a
+ * step of the feedback scan).  `jobs`: HOST array of 1..8 descriptors (passed to the kernel by value): the generator's Dense output matrix
+ * bias [N, ld_bias] (b_enc at column 0, b_dec at column Hn), its weights [D, Hn], its Philox seed and where its samples go
+ * (samples[row * s_row_stride + i * s_elem_stride]: e.g. straight into track m of a [B, steps, P, M] piano-roll). */
+typedef struct {
+    const float* bias; int ld_bias;
+    const float* w_enc; const float* w_dec;
+    uint64_t seed;
+    uint8_t* samples; float* nll;            /* nll [N] or NULL */
+} mnn_nade_sample_job;
+int mnn_nade_sample_multi(mnn_stream_t s, int njobs, const mnn_nade_sample_job* jobs, int N, int D, int Hn, float temperature,
+                          uint32_t row0, uint32_t sub, long s_row_stride, int s_elem_stride);
 
 /* ------------------------------------------------------------------------------------------
  * RBM (models/common/rbm.py).  W f32 [D,Hn]; bh f32 [N or 1, Hn] (ld_bh = 0 broadcasts one row);
@@ -407,7 +419,8 @@ int mnn_log_loss_rows(mnn_stream_t s, const uint8_t* targets, const float* probs
  * ------------------------------------------------------------------------------------------ */
 #define MNN_DET_MAX_JOBS 8
 typedef struct {
-    const void* x; int x_dtype; int n_x; int ld_x;          /* first input block [B, ld_x]: MNN_U8 or MNN_F32; n_x may be 0 */
+    const void* x; int x_dtype; int n_x; int ld_x; int es_x; /* first input block: element (row, k) at x[row * ld_x + k * es_x] (es_x >= 1: e.g. one
+                                                              * track of a [B, P, M] step); MNN_U8 or MNN_F32; n_x may be 0 */
     const float* x2; int n_x2; int ld_x2;                   /* optional second block (the feedback vector), concatenated behind x */
     const float* h_prev; const float* c_prev;               /* [B, units]; both NULL = zero state */
     const float* W; const float* bias;                      /* [(n_x + n_x2 + units), 4 units], [4 units] */

@@ -53,12 +53,18 @@ SIGNATURES = {
     "mnn_fill_f32": (_i, [_p, _p, _l, _f]),
     "mnn_lstm_step_det": (_i, [_p, _i, _i, _p]),
     "mnn_dense_det": (_i, [_p, _i, _i, _p]),
+    "mnn_nade_sample_multi": (_i, [_p, _i, _p, _i, _i, _i, _f, _u32, _u32, _l, _i]),
 }
 
 class DetLstmJob(C.Structure):
     """mnn_det_lstm_job (include/multinn_hip.h)."""
-    _fields_ = [("x", _p), ("x_dtype", _i), ("n_x", _i), ("ld_x", _i), ("x2", _p), ("n_x2", _i), ("ld_x2", _i), ("h_prev", _p), ("c_prev", _p),
+    _fields_ = [("x", _p), ("x_dtype", _i), ("n_x", _i), ("ld_x", _i), ("es_x", _i), ("x2", _p), ("n_x2", _i), ("ld_x2", _i), ("h_prev", _p), ("c_prev", _p),
                 ("W", _p), ("bias", _p), ("c_out", _p), ("h_out", _p), ("units", _i)]
+
+
+class NadeSampleJob(C.Structure):
+    """mnn_nade_sample_job (include/multinn_hip.h)."""
+    _fields_ = [("bias", _p), ("ld_bias", _i), ("w_enc", _p), ("w_dec", _p), ("seed", _u64), ("samples", _p), ("nll", _p)]
 
 
 class DetDenseJob(C.Structure):

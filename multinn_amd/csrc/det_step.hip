@@ -13,88 +13,94 @@
 // Master weights are read in their TF layout and in f32 (no packed / 16-bit copies): sampling runs in the reference's own arithmetic
 // whatever the training precision is.
 //
-// Mapping (sampling batches are small -- 72 rows by default, default_config.yaml:43-51): a workgroup = 64 units x 4 gates (thread = one
-// pre-activation column, so a wave reads 256 contiguous bytes of a W row) x R rows; the R rows of xh sit in LDS and are broadcast;
-// each thread carries R independent chains (the chain of ONE output is sequential by definition, 4 cycles per link and wave).  The four
-// gates of a unit meet through LDS for the pointwise part.  Several (generator, layer) jobs -- the M per-track generators of the feedback
-// scan -- run as ONE launch (blockIdx.z = job).
+// Mapping (sampling batches are small -- 72 rows by default, default_config.yaml:43-51): the chains run on the f32 MATRIX cores.
+// v_mfma_f32_32x32x2_f32 computes D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)), one IEEE rounding per product-add (cdna_hip_programming.md,
+// "FP32-input MFMA"), so a run of them over ascending k IS the specified fmaf chain -- 1024 chains per wave and instruction instead of one
+// per lane.  (Round 4's first form, a vector fma chain per thread with the rows' inputs broadcast from LDS, took ~170 us per step of the
+// [512, 256] stack at 72 rows: every group of eight weight loads was waited for at L2 latency.)  The product is formed transposed,
+// C[column][row] = sum_k W[k][column] xh[row][k] (A = weights straight from global memory, a ring of PF k-pairs ahead of their MFMAs;
+// B = the 32 rows' inputs from LDS, f32 [32][odd pitch]: conflict-free).  LSTM: a wave's 32 A rows are the FOUR gates of 8 units
+// (row g * 8 + uu <-> TF column g * units + unit), so a lane's accumulator quads hold i, ci, f, o of four (row, unit) pairs and the
+// pointwise part needs no exchange.  A workgroup = 4 waves = 32 units x 32 rows; K is walked in chunks of DS_KC through the staging
+// buffer.  Several (generator, layer) jobs -- the M per-track generators of the feedback scan -- run as ONE launch (blockIdx.z = job).
 #include "common.h"
 
-#define DS_R 6                       // rows per workgroup
+#define DS_KC 1024                   // k per staging chunk (f32 [32][DS_KC + 1] = 128 KiB)
+#define DS_PF 16                     // k-pairs of weights in flight per wave
 #define DS_MAXJOBS MNN_DET_MAX_JOBS
+typedef float ds_f32x16 __attribute__((ext_vector_type(16)));
 
 struct DetLstmJobs { mnn_det_lstm_job job[DS_MAXJOBS]; };
 struct DetDenseJobs { mnn_det_dense_job job[DS_MAXJOBS]; };
 
 __device__ __forceinline__ float det_tanh(float x) { return __fsub_rn(__fmul_rn(2.0f, det_sigmoid(__fmul_rn(2.0f, x))), 1.0f); }
 
-// xh[r][k] of the job for rows r0 .. r0 + R - 1 into LDS (rows past B: zeros), k-contiguous, pitch Kp (multiple of 4)
-__device__ __forceinline__ void ds_stage_rows(const mnn_det_lstm_job& jb, int B, int r0, int K, int Kp, float* xs) {
-    const int n1 = jb.n_x, n2 = jb.n_x2, u = jb.units;
-    for (int e = threadIdx.x; e < DS_R * Kp; e += blockDim.x) {
-        const int r = e / Kp, k = e - r * Kp, row = r0 + r;
-        float v = 0.f;
-        if (row < B && k < K) {
-            if (k < n1) v = jb.x_dtype == MNN_U8 ? (float)reinterpret_cast<const uint8_t*>(jb.x)[(size_t)row * jb.ld_x + k]
-                                                  : reinterpret_cast<const float*>(jb.x)[(size_t)row * jb.ld_x + k];
-            else if (k < n1 + n2) v = jb.x2[(size_t)row * jb.ld_x2 + (k - n1)];
-            else if (jb.h_prev != nullptr) v = jb.h_prev[(size_t)row * u + (k - n1 - n2)];
+// One chunk of a wave's chain: acc += sum over k in [k0, k0 + kc) (kc even, zero-padded inputs) of W[k][col] * xs[row][k - k0].
+// w_k(k) returns the lane's weight of row k (clamped to the last row: its input is zero there); loads run DS_PF k-pairs ahead.
+template <typename WF>
+__device__ __forceinline__ void ds_chain_chunk(WF&& w_k, int k0, int kc, int K, const float* __restrict__ xs_row, int hh, ds_f32x16& acc) {
+    const int np = kc / 2;
+    float wa[DS_PF];
+#pragma unroll
+    for (int j = 0; j < DS_PF; ++j) wa[j] = w_k(min(k0 + 2 * j + hh, K - 1));
+    for (int s0 = 0; s0 < np; s0 += DS_PF) {
+#pragma unroll
+        for (int j = 0; j < DS_PF; ++j) {
+            const int s = s0 + j;
+            const float a = wa[j];
+            wa[j] = w_k(min(k0 + 2 * (s + DS_PF) + hh, K - 1));          // unconditional (clamped): a load under a branch is waited for behind it
+            if (s < np) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs_row[2 * s + hh], acc, 0, 0, 0);
         }
-        xs[e] = v;
     }
 }
 
-// R chains of one column: acc[r] = fma(xs[r][k], W[k][col], acc[r]), k ascending.  Eight W rows are requested ahead of their FMAs.
-__device__ __forceinline__ void ds_chains(const float* __restrict__ w, size_t ldw, int K, const float* xs, int Kp, float (&acc)[DS_R]) {
-#pragma unroll
-    for (int r = 0; r < DS_R; ++r) acc[r] = 0.f;
-    int k = 0;
-    for (; k + 8 <= K; k += 8) {
-        float wv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) wv[j] = w[(size_t)(k + j) * ldw];
-#pragma unroll
-        for (int r = 0; r < DS_R; ++r) {
-            const float4 a = *reinterpret_cast<const float4*>(xs + r * Kp + k);
-            const float4 b = *reinterpret_cast<const float4*>(xs + r * Kp + k + 4);
-            float t = acc[r];
-            t = fmaf(a.x, wv[0], t); t = fmaf(a.y, wv[1], t); t = fmaf(a.z, wv[2], t); t = fmaf(a.w, wv[3], t);
-            t = fmaf(b.x, wv[4], t); t = fmaf(b.y, wv[5], t); t = fmaf(b.z, wv[6], t); t = fmaf(b.w, wv[7], t);
-            acc[r] = t;
-        }
-    }
-    for (; k < K; ++k) {
-        const float wv = w[(size_t)k * ldw];
-#pragma unroll
-        for (int r = 0; r < DS_R; ++r) acc[r] = fmaf(xs[r * Kp + k], wv, acc[r]);
-    }
+// the 32 rows' inputs of chunk [k0, k0 + kc) into LDS: f32 [32][pitch], zeros past K and for rows past B
+template <typename XF>
+__device__ __forceinline__ void ds_stage(XF&& x_of, int B, int r0, int k0, int kc, int K, int pitch, float* xs) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;           // a wave per row (coalesced, no index division), rows w, w + 4, ...
+    for (int r = w; r < 32; r += 4)
+        for (int k = lane; k < kc; k += 64) xs[r * pitch + k] = (r0 + r < B && k0 + k < K) ? x_of(r0 + r, k0 + k) : 0.f;
 }
 
 __global__ void __launch_bounds__(256) lstm_step_det_kernel(DetLstmJobs J, int B) {
     extern __shared__ __attribute__((aligned(16))) float ds_smem[];
     const mnn_det_lstm_job& jb = J.job[blockIdx.z];
-    const int u = jb.units, ub = blockIdx.x * 64;
+    const int u = jb.units, ub = blockIdx.x * 32;
     if (ub >= u) return;                             // the grid covers the widest job
-    const int r0 = blockIdx.y * DS_R;
-    const int K = jb.n_x + jb.n_x2 + u, Kp = (K + 3) & ~3;
-    float* xs = ds_smem;                             // [R][Kp]
-    float* zs = ds_smem + DS_R * Kp;                 // [4][R][64]
-    ds_stage_rows(jb, B, r0, K, Kp, xs);
-    __syncthreads();
-    const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int unit = min(ub + l, u - 1);             // units are a multiple of 32: the upper half of the last workgroup may repeat a column
-    const int col = g * u + unit;
-    float acc[DS_R];
-    ds_chains(jb.W + col, (size_t)4 * u, K, xs, Kp, acc);
-    const float bv = jb.bias[col];
+    const int r0 = blockIdx.y * 32;
+    const int n1 = jb.n_x, n2 = jb.n_x2;
+    const int K = n1 + n2 + u;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    // this lane's A row: gate g = r >> 3 of unit ub + 8 w + (r & 7)  ->  TF column g * u + unit
+    const int col = (r >> 3) * u + ub + 8 * w + (r & 7);
+    const float* __restrict__ wp = jb.W + col;
+    const size_t ldw = (size_t)4 * u;
+    auto w_k = [&](int k) { return wp[(size_t)k * ldw]; };
+    auto x_of = [&](int row, int k) -> float {
+        if (k < n1) return jb.x_dtype == MNN_U8 ? (float)reinterpret_cast<const uint8_t*>(jb.x)[(size_t)row * jb.ld_x + (size_t)k * jb.es_x]
+                                                : reinterpret_cast<const float*>(jb.x)[(size_t)row * jb.ld_x + (size_t)k * jb.es_x];
+        if (k < n1 + n2) return jb.x2[(size_t)row * jb.ld_x2 + (k - n1)];
+        return jb.h_prev != nullptr ? jb.h_prev[(size_t)row * u + (k - n1 - n2)] : 0.f;
+    };
+    ds_f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < DS_R; ++r) zs[(g * DS_R + r) * 64 + l] = __fadd_rn(acc[r], bv);
-    __syncthreads();
-    for (int e = threadIdx.x; e < DS_R * 64; e += 256) {
-        const int r = e >> 6, ll = e & 63, row = r0 + r, un = ub + ll;
-        if (row >= B || un >= u) continue;
-        const float gi = det_sigmoid(zs[(0 * DS_R + r) * 64 + ll]), gc = det_tanh(zs[(1 * DS_R + r) * 64 + ll]);
-        const float gf = det_sigmoid(zs[(2 * DS_R + r) * 64 + ll]), go = det_sigmoid(zs[(3 * DS_R + r) * 64 + ll]);
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += DS_KC) {
+        const int kc = (min(DS_KC, K - k0) + 1) & ~1, pitch = kc | 1;
+        if (k0 > 0) __syncthreads();
+        ds_stage(x_of, B, r0, k0, kc, K, pitch, ds_smem);
+        __syncthreads();
+        ds_chain_chunk(w_k, k0, kc, K, ds_smem + r * pitch, hh, acc);
+    }
+    // accumulator register e: A row (e & 3) + 8 (e >> 2) + 4 hh = gate (e >> 2), unit offset (e & 3) + 4 hh; C column = batch row r
+    const int row = r0 + r;
+    if (row >= B) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int un = ub + 8 * w + 4 * hh + q;
+        const float zi = __fadd_rn(acc[q], jb.bias[un]), zc = __fadd_rn(acc[4 + q], jb.bias[u + un]);
+        const float zf = __fadd_rn(acc[8 + q], jb.bias[2 * u + un]), zo = __fadd_rn(acc[12 + q], jb.bias[3 * u + un]);
+        const float gi = det_sigmoid(zi), gc = det_tanh(zc), gf = det_sigmoid(zf), go = det_sigmoid(zo);
         const float cp = jb.c_prev != nullptr ? jb.c_prev[(size_t)row * u + un] : 0.f;
         const float c = __fadd_rn(__fmul_rn(gc, gi), __fmul_rn(cp, gf));
         jb.c_out[(size_t)row * u + un] = c;
@@ -105,25 +111,43 @@ __global__ void __launch_bounds__(256) lstm_step_det_kernel(DetLstmJobs J, int B
 __global__ void __launch_bounds__(256) dense_det_kernel(DetDenseJobs J, int B) {
     extern __shared__ __attribute__((aligned(16))) float ds_smem[];
     const mnn_det_dense_job& jb = J.job[blockIdx.z];
-    const int nb = blockIdx.x * 256;
+    const int nb = blockIdx.x * 128;
     if (nb >= jb.N) return;
-    const int r0 = blockIdx.y * DS_R;
-    const int K = jb.K, Kp = (K + 3) & ~3;
-    float* xs = ds_smem;
-    for (int e = threadIdx.x; e < DS_R * Kp; e += 256) {
-        const int r = e / Kp, k = e - r * Kp, row = r0 + r;
-        xs[e] = (row < B && k < K) ? jb.x[(size_t)row * jb.ld_x + k] : 0.f;
-    }
-    __syncthreads();
-    const int n = min(nb + (int)threadIdx.x, jb.N - 1);
-    float acc[DS_R];
-    ds_chains(jb.W + n, (size_t)jb.ld_w, K, xs, Kp, acc);
-    const float bv = jb.bias != nullptr ? jb.bias[n] : 0.f;
-    if (nb + (int)threadIdx.x < jb.N) {
+    const int r0 = blockIdx.y * 32;
+    const int K = jb.K;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const int n = min(nb + 32 * w + r, jb.N - 1);    // this lane's A row = output column n
+    const float* __restrict__ wp = jb.W + n;
+    const size_t ldw = (size_t)jb.ld_w;
+    auto w_k = [&](int k) { return wp[(size_t)k * ldw]; };
+    auto x_of = [&](int row, int k) -> float { return jb.x[(size_t)row * jb.ld_x + k]; };
+    ds_f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < DS_R; ++r)
-            if (r0 + r < B) jb.out[(size_t)(r0 + r) * jb.ld_out + n] = __fadd_rn(acc[r], bv);
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += DS_KC) {
+        const int kc = (min(DS_KC, K - k0) + 1) & ~1, pitch = kc | 1;
+        if (k0 > 0) __syncthreads();
+        ds_stage(x_of, B, r0, k0, kc, K, pitch, ds_smem);
+        __syncthreads();
+        ds_chain_chunk(w_k, k0, kc, K, ds_smem + r * pitch, hh, acc);
     }
+    const int row = r0 + r;
+    if (row >= B) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int nn = nb + 32 * w + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (nn < jb.N) jb.out[(size_t)row * jb.ld_out + nn] = jb.bias != nullptr ? __fadd_rn(acc[e], jb.bias[nn]) : acc[e];
+    }
+}
+
+static size_t ds_lds_bytes(int K) { const int kc = (min(DS_KC, K) + 1) & ~1; return (size_t)32 * (kc | 1) * sizeof(float); }
+static hipError_t ds_raise_lds() {
+    static bool raised = false;
+    if (raised) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_step_det_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_det_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raised = e == hipSuccess;
+    return e;
 }
 
 extern "C" int mnn_lstm_step_det(mnn_stream_t s, int B, int njobs, const mnn_det_lstm_job* jobs) {
@@ -134,17 +158,16 @@ extern "C" int mnn_lstm_step_det(mnn_stream_t s, int B, int njobs, const mnn_det
     for (int j = 0; j < njobs; ++j) {
         const mnn_det_lstm_job& jb = jobs[j];
         MNN_REQUIRE(jb.units > 0 && jb.units % 32 == 0 && jb.W && jb.bias && jb.c_out && jb.h_out, "mnn_lstm_step_det: job %d: units %% 32, W, bias, c_out, h_out", j);
-        MNN_REQUIRE(jb.n_x >= 0 && jb.n_x2 >= 0 && (jb.n_x == 0 || (jb.x && jb.ld_x >= jb.n_x && (jb.x_dtype == MNN_U8 || jb.x_dtype == MNN_F32))) &&
+        MNN_REQUIRE(jb.n_x >= 0 && jb.n_x2 >= 0 && (jb.n_x == 0 || (jb.x && jb.es_x >= 1 && (jb.x_dtype == MNN_U8 || jb.x_dtype == MNN_F32))) &&
                     (jb.n_x2 == 0 || (jb.x2 && jb.ld_x2 >= jb.n_x2)), "mnn_lstm_step_det: job %d: input blocks", j);
         MNN_REQUIRE((jb.h_prev == nullptr) == (jb.c_prev == nullptr), "mnn_lstm_step_det: job %d: h_prev and c_prev come together", j);
         J.job[j] = jb;
         umax = max(umax, jb.units);
         kmax = max(kmax, jb.n_x + jb.n_x2 + jb.units);
     }
-    const size_t lds = ((size_t)DS_R * ((kmax + 3) & ~3) + 4 * DS_R * 64) * sizeof(float);
-    MNN_REQUIRE(lds <= 64 * 1024, "mnn_lstm_step_det: %d inputs + units do not fit the staging buffer", kmax);
-    dim3 grid(cdiv(umax, 64), cdiv(B, DS_R), njobs);
-    hipLaunchKernelGGL(lstm_step_det_kernel, grid, dim3(256), lds, (hipStream_t)s, J, B);
+    MNN_HIP(ds_raise_lds());
+    dim3 grid(umax / 32, cdiv(B, 32), njobs);
+    hipLaunchKernelGGL(lstm_step_det_kernel, grid, dim3(256), ds_lds_bytes(kmax), (hipStream_t)s, J, B);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
@@ -162,10 +185,9 @@ extern "C" int mnn_dense_det(mnn_stream_t s, int B, int njobs, const mnn_det_den
         nmax = max(nmax, jb.N);
         kmax = max(kmax, jb.K);
     }
-    const size_t lds = (size_t)DS_R * ((kmax + 3) & ~3) * sizeof(float);
-    MNN_REQUIRE(lds <= 64 * 1024, "mnn_dense_det: K = %d does not fit the staging buffer", kmax);
-    dim3 grid(cdiv(nmax, 256), cdiv(B, DS_R), njobs);
-    hipLaunchKernelGGL(dense_det_kernel, grid, dim3(256), lds, (hipStream_t)s, J, B);
+    MNN_HIP(ds_raise_lds());
+    dim3 grid(cdiv(nmax, 128), cdiv(B, 32), njobs);
+    hipLaunchKernelGGL(dense_det_kernel, grid, dim3(256), ds_lds_bytes(kmax), (hipStream_t)s, J, B);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

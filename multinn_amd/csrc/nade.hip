@@ -650,14 +650,28 @@ __device__ __forceinline__ bool prob_at_least_half(float x) {           // det_s
     return __builtin_amdgcn_ballot_w64(det_sigmoid(x) >= 0.5f) != 0ull;
 }
 
+// one (generator, track) of a launch: where its biases, weights, uniforms and outputs are
+struct SampleJob {
+    const float* bias; int ld_bias; int enc_off, dec_off;    // b_enc at bias[row, enc_off ..], b_dec at bias[row, dec_off ..]
+    const float* w_enc; const float* w_dec;                  // [D, Hn] of this track
+    uint64_t seed; uint32_t elem0;                           // Philox key; element index of visible 0 (m D inside a MultiNADE, 0 otherwise)
+    uint8_t* samples; float* nll;                            // samples[row * s_row_stride + i * s_elem_stride]; nll [N] or NULL
+};
+#define SAMPLE_MAX_JOBS 8
+struct SampleJobs { SampleJob job[SAMPLE_MAX_JOBS]; };
+
 // TMODE: 0 = threshold draws (temperature None / <= 0), 1 = temperature 1, 2 = any other temperature.  FULL: Hn == 256, no lane is idle.
 template <int TMODE, bool FULL, bool SPEC>
 __global__ void __launch_bounds__(256)
-nade_sample_kernel(int tracks, int N, int D, int Hn, const float* __restrict__ bias, int ld_bias, const float* __restrict__ w_enc,
-                   const float* __restrict__ w_dec, float temperature, uint64_t seed, uint32_t row0, uint32_t sub,
-                   uint8_t* __restrict__ samples, long s_track_stride, int s_row_stride, int s_elem_stride, float* __restrict__ nll) {
+nade_sample_kernel(SampleJobs J, int N, int D, int Hn, float temperature, uint32_t row0, uint32_t sub, long s_row_stride, int s_elem_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char nade_sample_smem[];       // per wave: logit / log term [Dp] f32, b_dec [Dp] f32, draws [Dp] u8, 256 uniforms
-    const int m = blockIdx.y;
+    // blockIdx.y = job: a track of one MultiNADE (mnn_nade_sample) or one of several generators sampled together (mnn_nade_sample_multi)
+    const SampleJob& jb = J.job[blockIdx.y];
+    const float* __restrict__ bias = jb.bias;
+    const int ld_bias = jb.ld_bias;
+    const uint64_t seed = jb.seed;
+    uint8_t* __restrict__ samples = jb.samples;
+    float* __restrict__ nll = jb.nll;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wv;
     if (row >= N) return;                                   // wave-uniform; the kernel has no workgroup barrier
@@ -666,9 +680,9 @@ nade_sample_kernel(int tracks, int N, int D, int Hn, const float* __restrict__ b
     float* sbd = reinterpret_cast<float*>(nade_sample_smem) + (size_t)(4 + wv) * Dp;
     unsigned char* son = nade_sample_smem + (size_t)32 * Dp + (size_t)wv * Dp;
     float* su = reinterpret_cast<float*>(nade_sample_smem + (size_t)36 * Dp) + wv * 256;    // uniforms of Philox blocks b0 .. b0 + 63
-    const float* __restrict__ we = w_enc + (size_t)m * D * Hn;
-    const float* __restrict__ wd = w_dec + (size_t)m * D * Hn;
-    const float* __restrict__ bd = bias + (size_t)row * ld_bias + tracks * Hn + m * D;
+    const float* __restrict__ we = jb.w_enc;
+    const float* __restrict__ wd = jb.w_dec;
+    const float* __restrict__ bd = bias + (size_t)row * ld_bias + jb.dec_off;
     float a[4], h[4];
     bool in[4];
     int off[4];                                             // hidden index of (lane, q), 0 where there is none: loads are never predicated
@@ -676,7 +690,7 @@ nade_sample_kernel(int tracks, int N, int D, int Hn, const float* __restrict__ b
     for (int q = 0; q < 4; ++q) {
         in[q] = FULL || lane + 64 * q < Hn;
         off[q] = in[q] ? lane + 64 * q : 0;
-        const float av = bias[(size_t)row * ld_bias + m * Hn + off[q]];
+        const float av = bias[(size_t)row * ld_bias + jb.enc_off + off[q]];
         a[q] = in[q] ? av : 0.f;
         h[q] = det_sigmoid(a[q]);
     }
@@ -696,7 +710,7 @@ nade_sample_kernel(int tracks, int N, int D, int Hn, const float* __restrict__ b
         fetch(k, k);
         __builtin_amdgcn_sched_barrier(0);                  // issue order = ring order, in the prologue as in the loop (the waits count loads)
     }
-    const uint32_t e0 = (uint32_t)(m * D);                  // element index of visible 0 (RNG contract: elem = m D + i)
+    const uint32_t e0 = jb.elem0;                           // element index of visible 0 (RNG contract: elem = m D + i)
     uint32_t b0 = e0 >> 2;                                  // lane l holds the uniforms of Philox block b0 + l
     auto refill = [&]() {                                   // lane l: the four uniforms of Philox block b0 + l, parked in LDS (one broadcast read per visible)
         float u4[4];
@@ -760,14 +774,28 @@ nade_sample_kernel(int tracks, int N, int D, int Hn, const float* __restrict__ b
     for (int i = lane; i < D; i += 64) {
         const float p = det_sigmoid(sp[i]);
         const bool on = son[i] != 0;
-        samples[(size_t)m * s_track_stride + (size_t)row * s_row_stride + (size_t)i * s_elem_stride] = on ? 1 : 0;
+        samples[(size_t)row * s_row_stride + (size_t)i * s_elem_stride] = on ? 1 : 0;
         sp[i] = on ? logf(NADE_EPS + p) : logf(NADE_EPS + (1.0f - p));
     }
     if (nll != nullptr) {
         float logp = 0.f;
         for (int i = 0; i < D; ++i) logp += sp[i];
-        if (lane == 0) nll[(size_t)m * N + row] = -logp;
+        if (lane == 0) nll[row] = -logp;
     }
+}
+
+static int launch_sample(hipStream_t st, const SampleJobs& J, int njobs, int N, int D, int Hn, float temperature, uint32_t row0, uint32_t sub,
+                         long s_row_stride, int s_elem_stride) {
+    dim3 grid(cdiv(N, 4), njobs);
+    const size_t lds = (size_t)36 * ((D + 3) & ~3) + 4096;   // 4 waves x ((2 f32 + u8) per visible + 256 uniforms)
+    const int tmode = temperature > 0.f ? (temperature == 1.0f ? 1 : 2) : 0;
+#define SMP(TM, FU, SP) hipLaunchKernelGGL((nade_sample_kernel<TM, FU, SP>), grid, dim3(256), lds, st, J, N, D, Hn, temperature, row0, sub, s_row_stride, s_elem_stride)
+    if (Hn == 256 && tmode == 1) { if (getenv("MNN_SAMPLE_NO_SPEC")) SMP(1, true, false); else SMP(1, true, true); }
+    else if (Hn == 256) { if (tmode == 0) SMP(0, true, false); else SMP(2, true, false); }
+    else { if (tmode == 0) SMP(0, false, false); else if (tmode == 1) SMP(1, false, false); else SMP(2, false, false); }
+#undef SMP
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
 }
 
 extern "C" int mnn_nade_sample(mnn_stream_t s, int tracks, int N, int D, int Hn, const float* bias, int ld_bias, const float* w_enc,
@@ -777,15 +805,34 @@ extern "C" int mnn_nade_sample(mnn_stream_t s, int tracks, int N, int D, int Hn,
     MNN_REQUIRE(bias && w_enc && w_dec && samples, "mnn_nade_sample: null pointer");
     MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_sample: ld_bias too small");
     MNN_REQUIRE(D <= 1536, "mnn_nade_sample: D <= 1536 (logits, b_dec and draws of a row are parked in LDS, 36 B per visible and wave; D=%d)", D);
-    dim3 grid(cdiv(N, 4), tracks);
-    const size_t lds = (size_t)36 * ((D + 3) & ~3) + 4096;   // 4 waves x ((2 f32 + u8) per visible + 256 uniforms)
-    const int tmode = temperature > 0.f ? (temperature == 1.0f ? 1 : 2) : 0;
-#define SMP(TM, FU, SP) hipLaunchKernelGGL((nade_sample_kernel<TM, FU, SP>), grid, dim3(256), lds, (hipStream_t)s, tracks, N, D, Hn, bias, ld_bias, w_enc, \
-                                           w_dec, temperature, seed, row0, sub, samples, s_track_stride, s_row_stride, s_elem_stride, nll)
-    if (Hn == 256 && tmode == 1) { if (getenv("MNN_SAMPLE_NO_SPEC")) SMP(1, true, false); else SMP(1, true, true); }
-    else if (Hn == 256) { if (tmode == 0) SMP(0, true, false); else SMP(2, true, false); }
-    else { if (tmode == 0) SMP(0, false, false); else if (tmode == 1) SMP(1, false, false); else SMP(2, false, false); }
-#undef SMP
-    MNN_LAUNCH_CHECK();
+    for (int m0 = 0; m0 < tracks; m0 += SAMPLE_MAX_JOBS) {            // the tracks of a MultiNADE: up to eight per launch
+        SampleJobs J;
+        memset(&J, 0, sizeof(J));
+        const int nj = min(SAMPLE_MAX_JOBS, tracks - m0);
+        for (int j = 0; j < nj; ++j) {
+            const int m = m0 + j;
+            J.job[j] = SampleJob{bias, ld_bias, m * Hn, tracks * Hn + m * D, w_enc + (size_t)m * D * Hn, w_dec + (size_t)m * D * Hn, seed,
+                                 (uint32_t)(m * D), samples + (size_t)m * s_track_stride, nll ? nll + (size_t)m * N : nullptr};
+        }
+        const int rc = launch_sample((hipStream_t)s, J, nj, N, D, Hn, temperature, row0, sub, s_row_stride, s_elem_stride);
+        if (rc != MNN_OK) return rc;
+    }
     return MNN_OK;
+}
+
+// The same scan for SEVERAL single-NADE generators in one launch (the M per-track generators of a feedback-scan step,
+// multinn_feedback.py:196: `generators[i].sample_single` for every track): job j has its own Dense output matrix, weights, seed and output
+// pointer; rows, widths, temperature, the RNG row / sub counters and the output strides are shared.
+extern "C" int mnn_nade_sample_multi(mnn_stream_t s, int njobs, const mnn_nade_sample_job* jobs, int N, int D, int Hn, float temperature,
+                                     uint32_t row0, uint32_t sub, long s_row_stride, int s_elem_stride) {
+    MNN_REQUIRE(njobs > 0 && njobs <= SAMPLE_MAX_JOBS && jobs && N > 0 && D > 0 && Hn > 0 && Hn <= 256 && D <= 1536,
+                "mnn_nade_sample_multi: 1..%d jobs, N, D > 0, 0 < Hn <= 256, D <= 1536", SAMPLE_MAX_JOBS);
+    SampleJobs J;
+    memset(&J, 0, sizeof(J));
+    for (int j = 0; j < njobs; ++j) {
+        const mnn_nade_sample_job& q = jobs[j];
+        MNN_REQUIRE(q.bias && q.w_enc && q.w_dec && q.samples && q.ld_bias >= Hn + D, "mnn_nade_sample_multi: job %d: null pointer or ld_bias < Hn + D", j);
+        J.job[j] = SampleJob{q.bias, q.ld_bias, 0, Hn, q.w_enc, q.w_dec, q.seed, 0u, q.samples, q.nll};
+    }
+    return launch_sample((hipStream_t)s, J, njobs, N, D, Hn, temperature, row0, sub, s_row_stride, s_elem_stride);
 }

@@ -262,6 +262,23 @@ class FeedbackRnnSampler:
         # Inside a step the tracks are independent: generator i's {sample | LSTM step, Dense} run on stream i, joined on
         # the main stream around the feedback step.  Their single steps take the launch-per-step LSTM kernels: persistent launches
         # spin on their own workgroups and must not share the device with one another (LstmStack.persist_single_step).
+        # all-NADE generators of one shape: their M sampling scans of a step are ONE launch too (ops.nade_sample_multi), writing straight into
+        # track m of out[:, s] -- a generated step is then 6 launches on one stream: samples | feedback LSTM x layers | generators' LSTM x
+        # layers | generators' Dense (35 graph nodes per step in round 3)
+        gs = self.generators
+        if group and all(type(g).__name__ == "RnnNade" and g.num_tracks == 1 and g.num_dims == P and g.num_hidden[-1] == gs[0].num_hidden[-1]
+                         and g.row0 == gs[0].row0 for g in gs):
+            Hn = gs[0].num_hidden[-1]
+            fb_strided = getattr(self.feedback, "det_sampling", False) and hasattr(self.feedback, "_stack")
+            for s in range(num_steps):                                                              # _feedback_recurrence (175-218)
+                views = [out[:, s, :, i] for i in range(M)]                                          # u8 [B, P] views of track i (element stride M)
+                ops.nade_sample_multi([dict(bias=states[i].dense, w_enc=g.store["nade/w_enc"][0], w_dec=g.store["nade/w_dec"][0], seed=g.seed,
+                                            samples=views[i]) for i, g in enumerate(gs)], P, Hn, 1.0, gs[0].row0, s)
+                st = out[:, s].reshape(B, P * M)                                                     # [B, P*M] view, feature p*M+m
+                fb, fb_state = self.feedback.single(st if fb_strided else st.contiguous(), fb_state)
+                res = det_steps([g._stack for g in gs], views, [list(s_.rnn_state) for s_ in states], [fb] * M)
+                states = self._group_dense([r[0] for r in res], [r[1] for r in res])
+            return out
         par = self.concurrent and x_u8.is_cuda and M > 1
         main = torch.cuda.current_stream() if x_u8.is_cuda else None
         if par:

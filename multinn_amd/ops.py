@@ -532,6 +532,25 @@ def nade_sample(bias, w_enc, w_dec, tracks, D, Hn, temperature, seed, row0, sub,
          float(-1.0 if temperature is None else temperature), int(seed), int(row0), int(sub), _ptr(samples), ts, tracks * D, es, _ptr(nll))
 
 
+def nade_sample_multi(jobs, D, Hn, temperature, row0, sub):
+    """mnn_nade_sample for up to 8 single-NADE generators in ONE launch.  job = dict(bias f32 [N, >= Hn + D] (the generator's Dense output),
+    w_enc / w_dec f32 [D, Hn], seed, samples = a u8 [N, D] VIEW (any strides, the same for every job: e.g. out[:, s, :, m] of a
+    [B, steps, P, M] piano-roll), nll f32 [N] or None)."""
+    _req(1 <= len(jobs) <= 8, "nade_sample_multi: 1..8 jobs")
+    arr = (_lib.NadeSampleJob * len(jobs))()
+    N = jobs[0]["bias"].shape[0]
+    rs, es = jobs[0]["samples"].stride()
+    for a, j in zip(arr, jobs):
+        b, smp, nll = j["bias"], j["samples"], j.get("nll")
+        _req(b.dtype == torch.float32 and b.dim() == 2 and b.stride(1) == 1 and b.shape == (N, b.shape[1]) and b.shape[1] >= Hn + D, "sample_multi: bias")
+        _req(smp.dtype == torch.uint8 and tuple(smp.shape) == (N, D) and smp.stride() == (rs, es) and es >= 1, "sample_multi: samples u8 [N, D] views of equal strides")
+        for w in (j["w_enc"], j["w_dec"]):
+            _req(w.dtype == torch.float32 and w.is_contiguous() and w.numel() == D * Hn, "sample_multi: weights f32 [D, Hn]")
+        _req(nll is None or (nll.dtype == torch.float32 and nll.is_contiguous() and nll.numel() == N), "sample_multi: nll f32 [N]")
+        a.bias, a.ld_bias, a.w_enc, a.w_dec, a.seed, a.samples, a.nll = _ptr(b), b.stride(0), _ptr(j["w_enc"]), _ptr(j["w_dec"]), int(j["seed"]), _ptr(smp), _ptr(nll)
+    call("mnn_nade_sample_multi", _stream(), len(jobs), arr, N, D, Hn, float(-1.0 if temperature is None else temperature), int(row0), int(sub), rs, es)
+
+
 # ------------------------------------------------------------------------------------------------
 def _ldb(b, n):
     _req(b.dtype == torch.float32 and b.dim() == 2 and b.stride(1) == 1 and b.shape[1] >= n, "rbm: bias must be f32 [N or 1, n]")
@@ -757,13 +776,14 @@ def lstm_step_det(jobs):
         for k in ("c_out", "h_out", "h_prev", "c_prev"):
             t = j.get(k)
             _req(t is None or (t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (B, u)), f"lstm_step_det: {k} must be contiguous f32 [B, u]")
-        if x is not None:
-            _rowmajor(x, "lstm_step_det x")
-            _req(x.shape[0] == B and x.shape[1] >= n_x and x.dtype in (torch.uint8, torch.float32), "lstm_step_det: x is u8 / f32 [B, >= n_x]")
+        if x is not None:         # any 2-D view: element (row, k) at row * stride(0) + k * stride(1) (one track of a [B, P, M] step has stride(1) = M)
+            _req(x.dim() == 2 and x.stride(1) >= 1 and x.shape[0] == B and x.shape[1] >= n_x and x.dtype in (torch.uint8, torch.float32),
+                 "lstm_step_det: x is a u8 / f32 [B, >= n_x] view")
         if x2 is not None:
             _rowmajor(x2, "lstm_step_det x2")
             _req(x2.shape[0] == B and x2.dtype == torch.float32, "lstm_step_det: x2 is f32 [B, n_x2]")
         a.x, a.x_dtype, a.n_x, a.ld_x = (_ptr(x) if x is not None else None), (dtype_code(x) if x is not None else F32), n_x, (x.stride(0) if x is not None else 0)
+        a.es_x = x.stride(1) if x is not None else 1
         a.x2, a.n_x2, a.ld_x2 = (_ptr(x2) if x2 is not None else None), n_x2, (x2.stride(0) if x2 is not None else 0)
         a.h_prev, a.c_prev = _ptr(j.get("h_prev")), _ptr(j.get("c_prev"))
         a.W, a.bias, a.c_out, a.h_out, a.units = _ptr(W), _ptr(b), _ptr(j["c_out"]), _ptr(j["h_out"]), u

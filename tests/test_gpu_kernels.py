@@ -815,8 +815,13 @@ def test_det_lstm_step_and_dense_bit_exact():
         xin = x.astype(np.float32) if x2 is None else np.concatenate([x.astype(np.float32), x2], 1)
         _, st = det.lstm_step(xin, None if zero else [(c0, h0)], [(W, b)])
         refs.append(st[0])
-        xd = torch.zeros((B, n_x + 3), dtype=torch.uint8 if u8 else torch.float32, device=DEV)        # a padded row pitch
-        xd[:, :n_x] = dev(x)
+        if u == 256:                                       # one track of a [B, n_x, 3] step: element stride 3 (the feedback scan's sample views)
+            x3 = torch.zeros((B, n_x, 3), dtype=torch.uint8 if u8 else torch.float32, device=DEV)
+            x3[:, :, 1] = dev(x)
+            xd = x3[:, :, 1]
+        else:
+            xd = torch.zeros((B, n_x + 3), dtype=torch.uint8 if u8 else torch.float32, device=DEV)    # a padded row pitch
+            xd[:, :n_x] = dev(x)
         jobs.append(dict(x=xd, n_x=n_x, x2=None if x2 is None else dev(x2), h_prev=None if zero else dev(h0), c_prev=None if zero else dev(c0),
                          W=dev(W), bias=dev(b), c_out=torch.empty((B, u), device=DEV), h_out=torch.empty((B, u), device=DEV)))
     ops.lstm_step_det(jobs)                                            # four jobs of different widths: ONE launch
@@ -834,3 +839,26 @@ def test_det_lstm_step_and_dense_bit_exact():
     for j, (ref, full) in zip(djobs, drefs):
         assert np.array_equal(j["out"].cpu().numpy(), ref)
         assert bool((full[:, ref.shape[1]:] == -7.0).all())            # nothing written past N
+
+
+def test_nade_sample_multi_equals_per_generator_launches():
+    """mnn_nade_sample_multi: M single-NADE generators sampled in ONE launch, straight into the tracks of a [B, P, M] step, == M separate
+    mnn_nade_sample launches (and therefore the deterministic checker, test_nade_sample_bit_exact)."""
+    from multinn_amd import ops
+    rng = np.random.default_rng(91)
+    N, D, Hn, M = 9, 88, 256, 5
+    step = torch.zeros((N, 3, D, M), dtype=torch.uint8, device=DEV)          # [B, steps, P, M]; sample into step 1
+    jobs, refs = [], []
+    for m in range(M):
+        bias = dev((rng.standard_normal((N, Hn + D + 8)) * 0.5).astype(np.float32))
+        we = dev((rng.standard_normal((D, Hn)) * 0.1).astype(np.float32)); wd = dev((rng.standard_normal((D, Hn)) * 0.1).astype(np.float32))
+        nll = torch.zeros(N, device=DEV)
+        jobs.append(dict(bias=bias, w_enc=we, w_dec=wd, seed=70 + m, samples=step[:, 1, :, m], nll=nll))
+        ref = torch.zeros((N, D), dtype=torch.uint8, device=DEV); rn = torch.zeros((1, N), device=DEV)
+        ops.nade_sample(bias, we, wd, 1, D, Hn, 1.0, 70 + m, 4, 6, ref, nll=rn)
+        refs.append((ref, rn[0]))
+    ops.nade_sample_multi(jobs, D, Hn, 1.0, 4, 6)
+    for m, (ref, rn) in enumerate(refs):
+        assert torch.equal(step[:, 1, :, m], ref) and torch.equal(jobs[m]["nll"], rn)
+        assert 0 < float(ref.float().mean()) < 1
+    assert not bool(step[:, 0].any()) and not bool(step[:, 2].any())
