@@ -67,9 +67,7 @@ const char* mnn_last_error(void);
 #define MNN_GEMM_A_KBLOCK32 8 /* A is stored K-blocked: element (m, k) at ((k >> 5) * lda + m) * 32 + (k & 31), lda = its row count (>= M).
                                * 16-bit operands, K % 64 == 0.  The layout a producer of dz^T writes in contiguous kilobytes (it owns 32 rows
                                * of a timestep = one block of 32 k): mnn_lstm_rowpar_bwd with L->ld_t == 0 emits it. */
-#define MNN_GEMM_A_KMAJOR 4   /* A is given K-major: [K][M] row-major, lda = elements per k row (>= M).  16-bit operands, M % 256 == 0,
-                               * K % 64 == 0.  Lets a producer that writes dz [rows, 4u] row-major feed the weight-gradient GEMM dz^T . X
-                               * without a transposed copy (rnn.py:60-62 kernel gradient).  B and C as usual. */
+/* (flag value 4, a K-major A read through transposing LDS loads, was measured net-neutral in round 3 and removed in round 4.) */
 int mnn_gemm_tn(mnn_stream_t s, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                 void* C, int ldc, int c_dtype, const float* bias, int flags, int split_k);
 

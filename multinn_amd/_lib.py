@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("MULTINN_HIP_LIB", os.path.join(HERE, "libmultinn_hip.
 
 ABI_VERSION = 110          # == MNN_ABI_VERSION of include/multinn_hip.h; load() refuses a library built for another one
 F32, BF16, U8, F16 = 0, 1, 2, 3
-GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_A_KMAJOR, GEMM_A_KBLOCK32 = 1, 2, 4, 8
+GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_A_KBLOCK32 = 1, 2, 8
 
 _p, _i, _l, _f, _u64, _u32, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_uint32, C.c_size_t
 

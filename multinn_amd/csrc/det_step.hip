@@ -54,12 +54,51 @@ __device__ __forceinline__ void ds_chain_chunk(WF&& w_k, int k0, int kc, int K, 
     }
 }
 
-// the 32 rows' inputs of chunk [k0, k0 + kc) into LDS: f32 [32][pitch], zeros past K and for rows past B
-template <typename XF>
-__device__ __forceinline__ void ds_stage(XF&& x_of, int B, int r0, int k0, int kc, int K, int pitch, float* xs) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;           // a wave per row (coalesced, no index division), rows w, w + 4, ...
-    for (int r = w; r < 32; r += 4)
-        for (int k = lane; k < kc; k += 64) xs[r * pitch + k] = (r0 + r < B && k0 + k < K) ? x_of(r0 + r, k0 + k) : 0.f;
+// Staging: one SEGMENT (a run of columns of one source array) of the 32 rows into LDS, f32 [32][pitch] at column offset `c0`; rows past B
+// and columns outside the chunk are skipped / zero.  Eight loads per thread are in flight before the first is used (the first version staged
+// element by element behind a three-way source test: every element waited for its own memory round trip, ~100 us per step).
+// Thread t: row t >> 3, lanes t & 7 walk the columns; loads are unconditional from clamped addresses.
+template <typename T>
+__device__ __forceinline__ void ds_stage_seg(const T* __restrict__ src, size_t ld, size_t es, int n, int seg0, int B, int r0, int k0, int kc,
+                                             int pitch, float* xs) {
+    // columns of this segment that fall into the chunk [k0, k0 + kc): global k = seg0 + j, j in [j_lo, j_hi)
+    const int j_lo = max(0, k0 - seg0), j_hi = min(n, k0 + kc - seg0);
+    if (j_lo >= j_hi) return;
+    const int r = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const bool rv = r0 + r < B;
+    const T* __restrict__ p = src + (size_t)min(r0 + r, B - 1) * ld;
+    float* d = xs + r * pitch + (seg0 - k0);
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    if (es == 1 && ((uintptr_t)src % (4 * sizeof(T))) == 0 && ld % 4 == 0 && j_lo % 4 == 0 && (j_hi - j_lo) % 4 == 0) {
+        // contiguous, aligned: four elements per load, up to sixteen loads in flight per thread (512 f32 per row = one batch)
+        const int nv = (j_hi - j_lo) / 4;
+        const T4* __restrict__ p4 = reinterpret_cast<const T4*>(p + j_lo);
+        for (int v0 = sub; v0 < nv; v0 += 128) {
+            T4 v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = p4[min(v0 + 8 * q, nv - 1)];
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (v0 + 8 * q < nv) {
+                    float* dd = d + j_lo + 4 * (v0 + 8 * q);
+                    dd[0] = rv ? (float)v[q].x : 0.f; dd[1] = rv ? (float)v[q].y : 0.f; dd[2] = rv ? (float)v[q].z : 0.f; dd[3] = rv ? (float)v[q].w : 0.f;
+                }
+        }
+        return;
+    }
+    for (int j0 = j_lo + sub; j0 < j_hi; j0 += 128) {
+        T v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = p[(size_t)min(j0 + 8 * q, j_hi - 1) * es];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (j0 + 8 * q < j_hi) d[j0 + 8 * q] = rv ? (float)v[q] : 0.f;
+    }
+}
+// zero the columns [c_lo, c_hi) of the staged chunk (the even-K pad; a zero initial state)
+__device__ __forceinline__ void ds_stage_zero(int c_lo, int c_hi, int pitch, float* xs) {
+    const int r = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    for (int c = c_lo + sub; c < c_hi; c += 8) xs[r * pitch + c] = 0.f;
 }
 
 __global__ void __launch_bounds__(256) lstm_step_det_kernel(DetLstmJobs J, int B) {
@@ -76,19 +115,20 @@ __global__ void __launch_bounds__(256) lstm_step_det_kernel(DetLstmJobs J, int B
     const float* __restrict__ wp = jb.W + col;
     const size_t ldw = (size_t)4 * u;
     auto w_k = [&](int k) { return wp[(size_t)k * ldw]; };
-    auto x_of = [&](int row, int k) -> float {
-        if (k < n1) return jb.x_dtype == MNN_U8 ? (float)reinterpret_cast<const uint8_t*>(jb.x)[(size_t)row * jb.ld_x + (size_t)k * jb.es_x]
-                                                : reinterpret_cast<const float*>(jb.x)[(size_t)row * jb.ld_x + (size_t)k * jb.es_x];
-        if (k < n1 + n2) return jb.x2[(size_t)row * jb.ld_x2 + (k - n1)];
-        return jb.h_prev != nullptr ? jb.h_prev[(size_t)row * u + (k - n1 - n2)] : 0.f;
-    };
     ds_f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     for (int k0 = 0; k0 < K; k0 += DS_KC) {
         const int kc = (min(DS_KC, K - k0) + 1) & ~1, pitch = kc | 1;
         if (k0 > 0) __syncthreads();
-        ds_stage(x_of, B, r0, k0, kc, K, pitch, ds_smem);
+        if (n1 > 0) {
+            if (jb.x_dtype == MNN_U8) ds_stage_seg(reinterpret_cast<const uint8_t*>(jb.x), (size_t)jb.ld_x, (size_t)jb.es_x, n1, 0, B, r0, k0, kc, pitch, ds_smem);
+            else ds_stage_seg(reinterpret_cast<const float*>(jb.x), (size_t)jb.ld_x, (size_t)jb.es_x, n1, 0, B, r0, k0, kc, pitch, ds_smem);
+        }
+        if (n2 > 0) ds_stage_seg(jb.x2, (size_t)jb.ld_x2, (size_t)1, n2, n1, B, r0, k0, kc, pitch, ds_smem);
+        if (jb.h_prev != nullptr) ds_stage_seg(jb.h_prev, (size_t)u, (size_t)1, u, n1 + n2, B, r0, k0, kc, pitch, ds_smem);
+        else ds_stage_zero(max(0, n1 + n2 - k0), min(kc, K - k0), pitch, ds_smem);
+        if (K - k0 < kc) ds_stage_zero(K - k0, kc, pitch, ds_smem);          // the pad column of an odd K
         __syncthreads();
         ds_chain_chunk(w_k, k0, kc, K, ds_smem + r * pitch, hh, acc);
     }
@@ -120,14 +160,14 @@ __global__ void __launch_bounds__(256) dense_det_kernel(DetDenseJobs J, int B) {
     const float* __restrict__ wp = jb.W + n;
     const size_t ldw = (size_t)jb.ld_w;
     auto w_k = [&](int k) { return wp[(size_t)k * ldw]; };
-    auto x_of = [&](int row, int k) -> float { return jb.x[(size_t)row * jb.ld_x + k]; };
     ds_f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     for (int k0 = 0; k0 < K; k0 += DS_KC) {
         const int kc = (min(DS_KC, K - k0) + 1) & ~1, pitch = kc | 1;
         if (k0 > 0) __syncthreads();
-        ds_stage(x_of, B, r0, k0, kc, K, pitch, ds_smem);
+        ds_stage_seg(jb.x, (size_t)jb.ld_x, (size_t)1, K, 0, B, r0, k0, kc, pitch, ds_smem);
+        if (K - k0 < kc) ds_stage_zero(K - k0, kc, pitch, ds_smem);
         __syncthreads();
         ds_chain_chunk(w_k, k0, kc, K, ds_smem + r * pitch, hh, acc);
     }

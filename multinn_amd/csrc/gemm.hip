@@ -372,39 +372,6 @@ struct GldsSlots {
     }
 };
 
-// K-MAJOR operand (round 3): the matrix is given as [K][rows] (row-major over K, `ld` elements per k), e.g. dz [T*B, 4u] as the A operand of
-// the weight gradient dW^T = dz^T . [x | h] -- no transposed copy dz^T has to be written by the recurrence (64 lanes x 16 B to 64 rows 512 KB
-// apart per store instruction: 0.9 us per timestep on the backward chain).  LDS image of a K tile: [64 k][256 rows] 16-bit, 512-byte k rows,
-// 16-byte chunk c of k row at chunk c ^ ((k & 3) << 2); the MFMA fragments come out of it with ds_read_b64_tr_b16 (cdna_hip_programming.md
-// T10): a 16-lane group reads a 4 k x 16 row block and each lane receives 4 consecutive k of one row -- two reads per 32x32x16 A operand.
-// A 32-lane half covers 4 k rows x 64 bytes: with the swizzle their 16 chunks fall on 16 different 16-byte bank groups (conflict-free).
-template <int NW>
-struct GldsSlotsKM {
-    static constexpr int NS = 64 * 32 / (64 * NW);          // 2048 16-byte slots per tile
-    const bf16_t* base;
-    unsigned off[NS];
-    unsigned kstride;                                       // elements per k row
-    __device__ __forceinline__ void init(const bf16_t* __restrict__ G, int ld, int r0, int wave, int lane) {
-        base = G;
-        kstride = (unsigned)ld;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int p = (s * NW + wave) * 64 + lane;      // linear 16-byte slot of the tile image
-            const int k = p >> 5, pc = p & 31;
-            const int c = pc ^ ((k & 3) << 2);              // logical chunk (8 rows of the operand) held by this slot
-            off[s] = (unsigned)k * (unsigned)ld + (unsigned)(r0 + c * 8);
-        }
-    }
-    __device__ __forceinline__ void stage(int k0, char* tile, int wave) const {
-        const bf16_t* b = base + (size_t)k0 * kstride;      // wave-uniform
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-            __builtin_amdgcn_global_load_lds((gas_ptr_t)(b + off[s]), (lds_ptr_t)(tile + (s * NW + wave) * 1024), 16, 0, 0);
-    }
-};
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-typedef short s16x8_t __attribute__((ext_vector_type(8)));
-
 // Split-K work mapping.  The hardware deals consecutive workgroup ids round-robin over the 8 XCDs (xcd = id % 8).  All tiles that read the same
 // K slice should run on ONE XCD, so that the slice's A and B panels are fetched into that L2 once and the other tiles hit.  `z = id % split_k`
 // achieves that when split_k is a multiple of 8 (or the real tiles sit at multiples of 8 in the slot order: a single row group).  For other
@@ -502,7 +469,7 @@ __device__ long long gm_trace[16];
 #define GM_T(k) do { } while (0)
 #define GM_T0() do { } while (0)
 #endif
-template <typename F, bool AKM = false, bool AKB = false>
+template <typename F, bool AKB = false>
 __global__ void __launch_bounds__(512)
 gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c_bf16,
                        const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
@@ -528,15 +495,10 @@ gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    typename std::conditional<AKM, GldsSlotsKM<8>, GldsSlots<256, 8, CPR, AKB>>::type slotA;
+    GldsSlots<256, 8, CPR, AKB> slotA;
     GldsSlots<256, 8, CPR> slotB;
-    if constexpr (AKM) slotA.init(A, lda, m0, wave, lane);          // A given K-major [K][M] (M % 256 == 0: no row clamp)
-    else slotA.init(A, lda, M, m0, wave, lane);
+    slotA.init(A, lda, M, m0, wave, lane);
     slotB.init(B, ldb, N, n0, wave, lane);
-    // K-major A: this lane's byte offset inside a k-step's 16 k rows (group g = lane >> 4: rows 16 (g & 1) .. + 15, k 8 (g >> 1) .. + 7;
-    // lane 4 q + p of the group addresses k row q, rows 4 p .. 4 p + 3 of the block)
-    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
-    const int tr_row = 8 * (tg >> 1) + tq;                          // k row of the first read inside the k-step; the second is + 4
     auto stage = [&](int buf, int kt) {
         slotA.stage(kt * BK, smem256 + (buf * 2 + 0) * TILE, wave);
         slotB.stage(kt * BK, smem256 + (buf * 2 + 1) * TILE, wave);
@@ -555,33 +517,6 @@ gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
         GM_T(2);
         const char* sA = smem256 + (cur * 2 + 0) * TILE;
         const char* sB = smem256 + (cur * 2 + 1) * TILE;
-        if constexpr (AKM) {
-            // (An explicit two-set prefetch of the next k-step's fragments was tried: 52 spilled registers -- 128 accumulator registers leave no
-            // room at two waves per SIMD.  As compiled, each A fragment's two transposed reads sit right in front of the MFMA pair that uses
-            // them: the K-major form runs ~20 % behind the K-contiguous one, 902 -> 1096 us on the [2048 x 960] x 262144 weight gradient.)
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                typename F::x8 a[4], b[2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = wm * 16 + i * 4 + 2 * (tg & 1) + (tp >> 1);          // logical chunk of the lane's 4 rows
-                    const char* p0 = sA + (ks * 16 + tr_row) * 512 + ((c ^ (tq << 2)) << 4) + 8 * (tp & 1);
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0));
-                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 4 * 512));
-                    const s16x8_t v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    a[i] = __builtin_bit_cast(typename F::x8, v);
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int row = wn * 64 + j * 32 + r;
-                    b[j] = *reinterpret_cast<const typename F::x8*>(sB + row * ROWB + (((ks * 2 + h) ^ swz<CPR>(row)) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = F::mfma32(a[i], b[j], acc[i][j]);
-            }
-        } else {
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             typename F::x8 a[4], b[2];
@@ -605,7 +540,6 @@ gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
                     asm volatile("" :: "v"(a[i]), "v"(b[j]));
 #endif
                 }
-        }
         }
         GM_T(3);
         __syncthreads();
@@ -642,28 +576,12 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
             MNN_HIP(hipGetDevice(&dev));
             MNN_REQUIRE(dev >= 0 && dev < 64, "mnn_gemm_tn: device index %d", dev);
             if (!attr_kb[dev]) {
-                MNN_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds256_kernel<F, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128));
+                MNN_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds256_kernel<F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128));
                 attr_kb[dev] = true;
             }
             dim3 grid2(cdiv(ntm2, 8) * 8 * ntn2, split_k);
-            hipLaunchKernelGGL((gemm_tn_glds256_kernel<F, false, true>), grid2, dim3(512), 4 * 256 * 128, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C,
+            hipLaunchKernelGGL((gemm_tn_glds256_kernel<F, true>), grid2, dim3(512), 4 * 256 * 128, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C,
                                ldc, c_bf16, bias, M, N, K, flags, split_k, ntm2, ntn2);
-            MNN_LAUNCH_CHECK();
-            return MNN_OK;
-        }
-        if (flags & MNN_GEMM_A_KMAJOR) {                    // A given as [K][M]: the 256 x 256 tile with transposed LDS reads (checked by the caller)
-            using F = typename FlavorOf<T>::type;
-            static bool attr_km[64];
-            int dev = 0;
-            MNN_HIP(hipGetDevice(&dev));
-            MNN_REQUIRE(dev >= 0 && dev < 64, "mnn_gemm_tn: device index %d", dev);
-            if (!attr_km[dev]) {
-                MNN_HIP(hipFuncSetAttribute((const void*)gemm_tn_glds256_kernel<F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128));
-                attr_km[dev] = true;
-            }
-            dim3 grid2(cdiv(ntm2, 8) * 8 * ntn2, split_k);
-            hipLaunchKernelGGL((gemm_tn_glds256_kernel<F, true>), grid2, dim3(512), 4 * 256 * 128, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc,
-                               c_bf16, bias, M, N, K, flags, split_k, ntm2, ntn2);
             MNN_LAUNCH_CHECK();
             return MNN_OK;
         }
@@ -706,12 +624,9 @@ extern "C" int mnn_gemm_tn(mnn_stream_t s, int dtype, int M, int N, int K, const
     MNN_REQUIRE(K % al == 0 && lda % al == 0 && ldb % al == 0, "mnn_gemm_tn: K/lda/ldb must be multiples of %d (K=%d lda=%d ldb=%d)",
                 al, K, lda, ldb);
     if (flags & MNN_GEMM_A_KBLOCK32) {
-        MNN_REQUIRE(dtype != MNN_F32 && !(flags & MNN_GEMM_A_KMAJOR) && K % 64 == 0 && lda >= M && ldb >= K && ldc >= N &&
+        MNN_REQUIRE(dtype != MNN_F32 && K % 64 == 0 && lda >= M && ldb >= K && ldc >= N &&
                     (size_t)K * (size_t)lda < ((size_t)1 << 32),
                     "mnn_gemm_tn: a K-blocked A needs 16-bit operands, K %% 64 == 0, lda (its row count) >= M, K * lda < 2^32 (M=%d K=%d lda=%d)", M, K, lda);
-    } else if (flags & MNN_GEMM_A_KMAJOR) {
-        MNN_REQUIRE(dtype != MNN_F32 && M % 256 == 0 && K % 64 == 0 && lda >= M && ldb >= K && ldc >= N,
-                    "mnn_gemm_tn: a K-major A needs 16-bit operands, M %% 256 == 0, K %% 64 == 0, lda >= M (M=%d K=%d lda=%d)", M, K, lda);
     } else {
         MNN_REQUIRE(lda >= K, "mnn_gemm_tn: leading dimension too small");
     }

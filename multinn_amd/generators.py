@@ -239,15 +239,12 @@ class LstmStack:
         for l in range(len(self.packed) - 1, -1, -1):
             p, cx = self.packed[l], ctx[l]
             u = p["u"]
-            # K-major weight gradient: the GEMM reads dz row-major (transposed LDS reads), the launch writes no dz^T -- 64 lanes x 16 bytes to 64
-            # rows 512 KB apart per store instruction, 0.9 us per timestep on the backward chain
-            km = self.kmajor_wgrads and cx.get("catT") is not None and Np == N and ops.gemm_a_kmajor_ok(self.dtype, 4 * u, N)
-            # default: dz^T in the K-BLOCKED layout [N/32, 4u, 32] (MNN_GEMM_A_KBLOCK32): a wave's 128 gate columns x 32 rows are one contiguous
+            # dz^T in the K-BLOCKED layout [N/32, 4u, 32] (MNN_GEMM_A_KBLOCK32): a wave's 128 gate columns x 32 rows are one contiguous
             # 8 KB slab (one kilobyte per store instruction) instead of 128 runs of 64 bytes 512 KB apart -- 0.7 us less per timestep on the
             # backward chain, and the GEMM only changes its LDS-DMA source addresses
-            kb = (not km) and self.kblock_wgrads and cx.get("catT") is not None and Np == N and N % 64 == 0
-            dzT = None if km else (torch.empty((N // 32, 4 * u, 32), device=dev, dtype=self.dtype) if kb else zalloc((4 * u, Np), device=dev, dtype=self.dtype))
-            dzc = torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype) if (l > 0 or km or (kb and need_dx)) else None
+            kb = self.kblock_wgrads and cx.get("catT") is not None and Np == N and N % 64 == 0
+            dzT = torch.empty((N // 32, 4 * u, 32), device=dev, dtype=self.dtype) if kb else zalloc((4 * u, Np), device=dev, dtype=self.dtype)
+            dzc = torch.empty((T, B, 4 * u), device=dev, dtype=self.dtype) if (l > 0 or (kb and need_dx)) else None
             db_p = self._accum(l, dev)[2]
             e = ops.lstm2_bwd_layer(dh.view(T, B, u), p["wh_p"], cx["gates"], cx["c"], None, dzc, ops.lstm_seq_bwd_workspace(B, u, dev), dzT, db_p,
                                     cx["mask"] if keep_prob < 1.0 else None, gates_dtype=self.dtype)
@@ -257,7 +254,7 @@ class LstmStack:
                 dh = torch.empty((N, p["n_in"]), device=dev)
                 ops.gemm_tn(dzc.view(N, 4 * u), p["wx_p"], dh)
         if getattr(self, "keep_debug", False):
-            self._dbg_dzT = [s_["dzT"] if s_["dzT"] is not None else s_["dzc"] for s_ in st]
+            self._dbg_dzT = [s_["dzT"] for s_ in st]
         keep = [self._weight_grads(l, ctx[l], st[l]["dzT"], st[l]["db_p"], T, B, dz=st[l]["dzc"]) for l in range(len(self.packed) - 1, -1, -1)]
         return self._input_grad(st[0]["dzT"], T, B, dz=st[0]["dzc"]) if need_dx else None
 
@@ -385,10 +382,8 @@ class LstmStack:
         sk = int(max(1, min(target // max(tiles, 1), K // 1024)))
         return 1 << (sk.bit_length() - 1) if sk >= 8 else sk
 
-    # MULTINN_KMAJOR_WGRADS=1: the weight-gradient GEMM reads dz row-major (MNN_GEMM_A_KMAJOR) and the backward recurrence writes no dz^T.
-    # Measured at [1024,256,88,5] (profiles/round3_e_kmajor.md): recurrence backward 3.18 -> 2.82 ms, the two GEMMs +0.46 ms (the transposed
-    # LDS reads run the 256 x 256 tile ~20-40 % slower): no net gain, so the default stays the transposed copy.
-    kmajor_wgrads = os.environ.get("MULTINN_KMAJOR_WGRADS", "0") == "1"
+    # MULTINN_KBLOCK_WGRADS=0: dz^T as a plain [4u, N] matrix instead of the K-blocked layout.  (A third form -- no dz^T at all, the GEMM reading
+    # dz row-major through transposing LDS loads -- was measured net-neutral in round 3, profiles/round3_e_kmajor.md, and removed in round 4.)
     kblock_wgrads = os.environ.get("MULTINN_KBLOCK_WGRADS", "1") != "0"
 
     def _weight_grads(self, l, cx, dzT, db_p, T, B, dz=None):
@@ -397,7 +392,7 @@ class LstmStack:
         p = self.packed[l]
         u, ld, n_in = p["u"], p["ld"], p["n_in"]
         N = T * B
-        Np = N if (dzT is None or dzT.dim() == 3) else dzT.shape[1]
+        Np = N if dzT.dim() == 3 else dzT.shape[1]
         dev = db_p.device
         inT = cx.get("inT")                 # the producer's own transposed copy (persistent forward: y^T of the layer below)
         cat = cx.get("catT")
@@ -415,9 +410,7 @@ class LstmStack:
             # split 20 400 us, 16 461, 21 669, 24 613, 32 494 (scratch/gemm_merge_probe2.py)
             tiles = -(-4 * u // 256) * -(-(ld + u) // 256)
             sk = max(1, min(256 // tiles // 4 * 4 if 256 // tiles >= 4 else 256 // tiles, Np // 1024))
-            if dzT is None:                 # dz [N, 4u] row-major as the K-major A operand
-                ops.gemm_tn(dz.view(N, 4 * u), cat, dw_cat, accumulate=True, split_k=sk, a_kmajor=True)
-            elif dzT.dim() == 3:            # K-blocked dz^T
+            if dzT.dim() == 3:              # K-blocked dz^T
                 ops.gemm_tn(dzT, cat, dw_cat, accumulate=True, split_k=sk, a_kblock=True)
             else:
                 ops.gemm_tn(dzT, cat, dw_cat, accumulate=True, split_k=sk)
@@ -534,7 +527,7 @@ class LstmStack:
         if p.get("wx_p0") is None:          # [ld0, 4u]: the packed (gate-interleaved) input weights with K = 4u contiguous, once per pack
             p["wx_p0"] = torch.empty((p["ld"], 4 * p["u"]), device=p["wx_t"].device, dtype=self.dtype)
             ops.transpose(p["wx_t"], p["wx_p0"])
-        if dzT0 is None or dzT0.dim() == 3:
+        if dzT0.dim() == 3:
             dz = dz.view(N, 4 * p["u"])
         else:
             dz = torch.empty((N, 4 * p["u"]), device=dzT0.device, dtype=self.dtype)

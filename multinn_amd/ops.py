@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, U8, F16, GEMM_ACCUMULATE, GEMM_A_KMAJOR, GEMM_A_KBLOCK32
+from ._lib import F32, BF16, U8, F16, GEMM_ACCUMULATE, GEMM_A_KBLOCK32
 
 
 def call(name, *args):
@@ -51,21 +51,15 @@ def round_up(x, m):
 
 
 # ------------------------------------------------------------------------------------------------
-def gemm_tn(A, B, C_out, bias=None, accumulate=False, split_k=1, a_kmajor=False, a_kblock=False):
-    """C[M,N] (+)= A[M,K] . B[N,K]^T (+bias).  A,B same dtype (f32/bf16/f16), K-contiguous views.  a_kmajor: A is given as [K, M] (row-major
-    over K: e.g. dz [rows, 4u] for the weight gradient dz^T . X), 16-bit, M % 256 == 0, K % 64 == 0 (`gemm_a_kmajor_ok`).  a_kblock: A is
+def gemm_tn(A, B, C_out, bias=None, accumulate=False, split_k=1, a_kblock=False):
+    """C[M,N] (+)= A[M,K] . B[N,K]^T (+bias).  A,B same dtype (f32/bf16/f16), K-contiguous views.  a_kblock: A is
     given K-blocked, a contiguous [K/32, rows >= M, 32] tensor (element (m, k) at [k // 32, m, k % 32]), 16-bit, K % 64 == 0."""
     _rowmajor(B, "gemm B"); _rowmajor(C_out, "gemm C")
     _req(A.dtype == B.dtype and A.dtype in (torch.float32,) + H16, "gemm: A/B must both be f32, bf16 or f16")
     if a_kblock:
-        _req(A.dim() == 3 and A.is_contiguous() and A.shape[2] == 32 and A.dtype in H16 and not a_kmajor, "gemm: a K-blocked A is a contiguous 16-bit [K/32, rows, 32]")
+        _req(A.dim() == 3 and A.is_contiguous() and A.shape[2] == 32 and A.dtype in H16, "gemm: a K-blocked A is a contiguous 16-bit [K/32, rows, 32]")
         K, M, lda = A.shape[0] * 32, C_out.shape[0], A.shape[1]
         _req(M <= lda and K % 64 == 0, "gemm: K-blocked A: rows >= M, K % 64 == 0")
-    elif a_kmajor:
-        _rowmajor(A, "gemm A")
-        K, M = A.shape
-        lda = A.stride(0)
-        _req(gemm_a_kmajor_ok(A.dtype, M, K), "gemm: a K-major A needs 16-bit operands, M % 256 == 0 and K % 64 == 0")
     else:
         _rowmajor(A, "gemm A")
         M, K = A.shape
@@ -75,14 +69,10 @@ def gemm_tn(A, B, C_out, bias=None, accumulate=False, split_k=1, a_kmajor=False,
     _req(C_out.dtype in (torch.float32,) + H16, "gemm: C must be f32/bf16/f16")
     if bias is not None:
         _req(bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous(), "gemm: bias must be f32[N]")
-    flags = (GEMM_ACCUMULATE if accumulate else 0) | (GEMM_A_KMAJOR if a_kmajor else 0) | (GEMM_A_KBLOCK32 if a_kblock else 0)
+    flags = (GEMM_ACCUMULATE if accumulate else 0) | (GEMM_A_KBLOCK32 if a_kblock else 0)
     call("mnn_gemm_tn", _stream(), dtype_code(A), M, N, K, _ptr(A), lda, _ptr(B), B.stride(0), _ptr(C_out), C_out.stride(0),
          dtype_code(C_out), _ptr(bias), flags, split_k)
     return C_out
-
-
-def gemm_a_kmajor_ok(dtype, M, K):
-    return dtype in H16 and M % 256 == 0 and K % 64 == 0
 
 
 def transpose(src, out):

@@ -92,32 +92,6 @@ def test_gemm_tn_step_shapes(ops, M, N, K, split_k, dt):
         assert bool((Cb[M] == 7.0).all())
 
 
-@pytest.mark.parametrize("M,N,K,split_k", [(256, 192, 64, 1), (512, 704, 4096, 1), (2048, 960, 16384, 8), (1024, 768, 16384, 20), (256, 704, 8192, 4)])
-@pytest.mark.parametrize("dt", ["f16", "bf16"])
-def test_gemm_tn_a_kmajor(ops, M, N, K, split_k, dt):
-    """A given K-major ([K, M] row-major: dz as it leaves the backward recurrence) -- the 256 x 256 tile with ds_read_b64_tr_b16 operand
-    reads -- against torch's f32 product and against the K-contiguous form on the transposed copy: every element, with a marker column that
-    catches a wrong (k, row) mapping."""
-    tdt = torch.float16 if dt == "f16" else torch.bfloat16
-    g = torch.Generator(device=DEV).manual_seed(M + N + K)
-    Akm = (torch.randn((K, M), device=DEV, generator=g) * 0.5).to(tdt)
-    Akm[:, min(37, M - 1)] = 0
-    Akm[K // 2 + 3, min(37, M - 1)] = 1.0
-    Bt = (torch.randn((N, K), device=DEV, generator=g) * 0.5).to(tdt)
-    ref = Akm.float().T @ Bt.float().T
-    scale = float(ref.abs().max())
-    C = torch.zeros((M + 1, N), device=DEV)
-    C[M] = 7.0
-    ops.gemm_tn(Akm, Bt, C[:M], accumulate=True, split_k=split_k, a_kmajor=True)
-    assert float((C[:M] - ref).abs().max()) < 2e-5 * scale * max(1, K // 1024)
-    assert bool((C[M] == 7.0).all())
-    C2 = torch.zeros((M, N), device=DEV)
-    ops.gemm_tn(Akm.T.contiguous(), Bt, C2, accumulate=True, split_k=split_k)
-    assert float((C[:M] - C2).abs().max()) < 2e-5 * scale * max(1, K // 1024)
-    with pytest.raises(Exception):
-        ops.gemm_tn(Akm[:, :128].contiguous(), Bt, torch.zeros((128, N), device=DEV), a_kmajor=True)
-
-
 @pytest.mark.parametrize("M,N,K,split_k,rows", [(256, 192, 64, 1, 256), (300, 704, 4096, 1, 320), (2048, 960, 16384, 8, 2048), (1024, 768, 16384, 20, 1024)])
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 def test_gemm_tn_a_kblock(ops, M, N, K, split_k, rows, dt):

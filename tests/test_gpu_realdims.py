@@ -262,7 +262,7 @@ def test_timed_kernels_long_sequence_vs_oracle(monkeypatch):
     gen._stack.rowpar_min_batch = 32
     gen.build_pianoroll(dev(x), None, is_train=True, mode="train")
     assert gen._stack._rowpar(B, T) and gen._ctx["lstm"][0].get("rowpar") and gen._nade_mfma() and gen._nade_exact()
-    assert gen._stack.kblock_wgrads and not gen._stack.kmajor_wgrads
+    assert gen._stack.kblock_wgrads
     loss = float(gen.metrics["batch/loss"])
     nll = gen.log_probs.cpu().numpy()
     cp_err = np.abs(gen.cond_probs.cpu().numpy() - fw['cond_p'][0]).max()
@@ -311,16 +311,15 @@ def test_persistent_forms_refuse_grids_that_cannot_be_resident():
 
 
 @pytest.mark.parametrize("precision", ["fp16", "bf16"])
-@pytest.mark.parametrize("layout", ["kblock", "plain", "kmajor"])
+@pytest.mark.parametrize("layout", ["kblock", "plain"])
 def test_rowpar_input_gradient_and_weight_gradient_layouts(precision, layout, monkeypatch):
-    """The row-parallel backward with `need_dx` (feedback modes: d loss / d inputs) and the three ways its dz reaches the weight-gradient GEMM --
-    K-blocked dz^T (default), plain dz^T, row-major dz as a K-major operand -- against the launch-per-step kernels on the same weights:
+    """The row-parallel backward with `need_dx` (feedback modes: d loss / d inputs) and the two ways its dz reaches the weight-gradient GEMM --
+    K-blocked dz^T (default), plain dz^T -- against the launch-per-step kernels on the same weights:
     every gradient and the input gradient agree to the summation order of the split-K atomics."""
     from multinn_amd import RnnNade
     from multinn_amd.generators import LstmStack
     monkeypatch.setattr(LstmStack, "rowpar_min_batch", 32)
     monkeypatch.setattr(LstmStack, "kblock_wgrads", layout == "kblock")
-    monkeypatch.setattr(LstmStack, "kmajor_wgrads", layout == "kmajor")
     B, T = 64, 8
     x = dev(synth(B, T, 41, 0.05))
     a = RnnNade(D, HN, UNITS, keep_prob=0.9, precision=precision, seed=23)
