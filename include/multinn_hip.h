@@ -290,13 +290,6 @@ int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const
 int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                          const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* a_final,
                          float* d_bias, float* d_w_enc, float* d_w_dec);
-/* The same backward with the weight-gradient sums over rows taken WITHOUT cross-workgroup atomics: every 64-row workgroup stores its
- * partial d w_dec / d w_enc into its own slab of `workspace` (mnn_nade_logprob_bwd_workspace_bytes: cdiv(N,64) * tracks * 2 * D * Hn floats,
- * 16-byte aligned; needs D * Hn % 4 == 0) and one pass sums the slabs into d_w_dec / d_w_enc (accumulating, as the atomic form does). */
-size_t mnn_nade_logprob_bwd_workspace_bytes(int tracks, int N, int D, int Hn);
-int mnn_nade_logprob_bwd_ws(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
-                            const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* a_final,
-                            float* d_bias, float* d_w_enc, float* d_w_dec, void* workspace, size_t workspace_bytes);
 int mnn_nade_sample(mnn_stream_t s, int tracks, int N, int D, int Hn, const float* bias, int ld_bias, const float* w_enc,
                     const float* w_dec, float temperature, uint64_t seed, uint32_t row0, uint32_t sub, uint8_t* samples,
                     long s_track_stride, int s_row_stride, int s_elem_stride, float* nll);

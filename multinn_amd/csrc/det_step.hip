@@ -26,7 +26,7 @@
 #include "common.h"
 
 #define DS_KC 1024                   // k per staging chunk (f32 [32][DS_KC + 1] = 128 KiB)
-#define DS_PF 16                     // k-pairs of weights in flight per wave
+#define DS_PF 28                     // k-pairs per weight register set; two sets alternate, so every load has 28 .. 56 MFMAs (0.75 .. 1.5 us) to land
 #define DS_MAXJOBS MNN_DET_MAX_JOBS
 typedef float ds_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -39,17 +39,27 @@ __device__ __forceinline__ float det_tanh(float x) { return __fsub_rn(__fmul_rn(
 // w_k(k) returns the lane's weight of row k (clamped to the last row: its input is zero there); loads run DS_PF k-pairs ahead.
 template <typename WF>
 __device__ __forceinline__ void ds_chain_chunk(WF&& w_k, int k0, int kc, int K, const float* __restrict__ xs_row, int hh, ds_f32x16& acc) {
+    // Two register sets of DS_PF weights alternate: while the MFMAs of one set run, the loads of the set after next are in flight, and the wait
+    // in front of a set only covers loads issued a whole set earlier.  (A single ring refilled slot by slot compiles to `s_waitcnt vmcnt(0)` at
+    // the loop header -- the last refills are then waited for at full Infinity-Cache latency once per round: ~38 us per launch at K = 952
+    // with 16 slots, where the chain itself is 13.)  Loads are unconditional from clamped rows (the inputs are zero there).
     const int np = kc / 2;
-    float wa[DS_PF];
+    float wa[2][DS_PF];
 #pragma unroll
-    for (int j = 0; j < DS_PF; ++j) wa[j] = w_k(min(k0 + 2 * j + hh, K - 1));
-    for (int s0 = 0; s0 < np; s0 += DS_PF) {
+    for (int j = 0; j < DS_PF; ++j) wa[0][j] = w_k(min(k0 + 2 * j + hh, K - 1));
+    for (int s0 = 0; s0 < np; s0 += 2 * DS_PF) {
 #pragma unroll
-        for (int j = 0; j < DS_PF; ++j) {
-            const int s = s0 + j;
-            const float a = wa[j];
-            wa[j] = w_k(min(k0 + 2 * (s + DS_PF) + hh, K - 1));          // unconditional (clamped): a load under a branch is waited for behind it
-            if (s < np) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs_row[2 * s + hh], acc, 0, 0, 0);
+        for (int half = 0; half < 2; ++half) {
+            const int sb = s0 + half * DS_PF;                 // first k-pair of the set about to be consumed
+#pragma unroll
+            for (int j = 0; j < DS_PF; ++j) wa[half ^ 1][j] = w_k(min(k0 + 2 * (sb + DS_PF + j) + hh, K - 1));
+            __builtin_amdgcn_sched_barrier(0);                // the refill loads first, then this set's MFMAs
+            if (sb < np) {
+#pragma unroll
+                for (int j = 0; j < DS_PF; ++j)
+                    if (sb + j < np) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[half][j], xs_row[2 * (sb + j) + hh], acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }

@@ -292,7 +292,7 @@ template <int HQ, int RG>
 __global__ void __launch_bounds__(512)
 nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias,
                 int ld_bias, const float* __restrict__ w_enc, const float* __restrict__ w_dec, const float* __restrict__ a_final,
-                float* __restrict__ d_bias, float* __restrict__ d_w_enc, float* __restrict__ d_w_dec, float* __restrict__ slab) {
+                float* __restrict__ d_bias, float* __restrict__ d_w_enc, float* __restrict__ d_w_dec) {
     constexpr int W = HQ * 64;
     __shared__ __attribute__((aligned(16))) float wl[2][2][8 * W];
     // [buffer][wave][visible-in-half-chunk][d w_dec | d w_enc][hidden]: one exchange per 4 visibles.  Two buffers where they fit beside a second
@@ -458,25 +458,17 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
                         for (int q = 0; q < HQ; ++q) sum[q] += pq[q];
                     }
                     if (i < D) {
-                        if (slab != nullptr) {
-                            // this workgroup's own partial-sum slab [workgroup][track][d w_dec | d w_enc][D][Hn]: plain stores (every (i < D, hidden)
-                            // word is written exactly once per workgroup), summed over the workgroups by nade_bwd_reduce_kernel.  The f32 atomics
-                            // of the other branch all land in the same 2 x D x Hn words from every 64-row workgroup: 3.7 GB of adds at TGT, at the
-                            // chip-wide ~1.3 TB/s atomic rate (MI355X_MICROARCH.md, Global float atomics)
-                            float* dst = slab + ((((size_t)blockIdx.x * tracks + m) * 2 + which) * D + i) * HnT + hb + lane;
-#pragma unroll
-                            for (int q = 0; q < HQ; ++q)
-                                if (lane + 64 * q < Hn) dst[64 * q] = sum[q];
-                        } else {
-                            float* dst = (which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * HnT + hb + lane;
+                        // one f32 atomic per (visible, hidden unit) and 64-row workgroup, 256 contiguous bytes per wave.  (Per-workgroup slabs
+                        // + a reduction pass instead -- bit-reproducible sums -- were measured slower, 5.1 vs 4.0 ms at [1024,256,88,5], and
+                        // removed in round 4: the atomics ride under the scan's VALU work, the slab stores and their 3.7 GB read-back do not.)
+                        float* dst = (which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * HnT + hb + lane;
 #ifdef NADE_BWD_NO_ATOMIC       // development only (timing the scan without its f32 atomics: results are wrong)
-                            if (sum[0] == 1.2345e30f) dst[0] = sum[0];
+                        if (sum[0] == 1.2345e30f) dst[0] = sum[0];
 #else
 #pragma unroll
-                            for (int q = 0; q < HQ; ++q)
-                                if (lane + 64 * q < Hn) atomicAdd(dst + 64 * q, sum[q]);
+                        for (int q = 0; q < HQ; ++q)
+                            if (lane + 64 * q < Hn) atomicAdd(dst + 64 * q, sum[q]);
 #endif
-                        }
                     }
                 }
             } else {
@@ -495,8 +487,7 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
                         float sum = 0.f;
 #pragma unroll
                         for (int ww = 0; ww < 8; ++ww) sum += red[ww][k][which][j];
-                        if (slab != nullptr) slab[((((size_t)blockIdx.x * tracks + m) * 2 + which) * D + i) * HnT + hb + j] = sum;
-                        else atomicAdd((which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * HnT + hb + j, sum);
+                        atomicAdd((which == 0 ? d_w_dec : d_w_enc) + ((size_t)m * D + i) * HnT + hb + j, sum);
                     }
                 }
             }
@@ -522,82 +513,22 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
         }
 }
 
-// out[y][e] += sum over this z-slice's workgroup slabs of slab[b][y][e]   (y = track * 2 + {d w_dec, d w_enc}; e over D * Hn words, 16 bytes per
-// thread; the slices of z add with one f32 atomic per word -- 4 per word in all instead of one per 64 rows)
-__global__ void __launch_bounds__(256) nade_bwd_reduce_kernel(const float* __restrict__ slab, int nblk, int tracks, long dh, float* __restrict__ d_w_dec,
-                                                              float* __restrict__ d_w_enc) {
-    const long e4 = (long)blockIdx.x * 256 + threadIdx.x;                 // float4 index inside one [D, Hn] matrix
-    if (e4 * 4 >= dh) return;
-    const int y = blockIdx.y, m = y >> 1, which = y & 1;
-    const int per = (nblk + gridDim.z - 1) / gridDim.z, b0 = blockIdx.z * per, b1 = min(nblk, b0 + per);
-    const size_t stride = (size_t)tracks * 2 * dh;
-    const float* p = slab + (size_t)y * dh + e4 * 4;
-    float4 acc[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-    int b = b0;
-    for (; b + 4 <= b1; b += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float4 q = *reinterpret_cast<const float4*>(p + (size_t)(b + u) * stride);
-            acc[u].x += q.x; acc[u].y += q.y; acc[u].z += q.z; acc[u].w += q.w;
-        }
-    }
-    for (; b < b1; ++b) {
-        const float4 q = *reinterpret_cast<const float4*>(p + (size_t)b * stride);
-        acc[0].x += q.x; acc[0].y += q.y; acc[0].z += q.z; acc[0].w += q.w;
-    }
-    float* out = (which == 0 ? d_w_dec : d_w_enc) + (size_t)m * dh + e4 * 4;
-    atomicAdd(out + 0, (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x));
-    atomicAdd(out + 1, (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y));
-    atomicAdd(out + 2, (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z));
-    atomicAdd(out + 3, (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w));
-}
-
-extern "C" size_t mnn_nade_logprob_bwd_workspace_bytes(int tracks, int N, int D, int Hn) {
-    if (tracks <= 0 || N <= 0 || D <= 0 || Hn <= 0 || ((long)D * Hn) % 4 != 0) return 0;
-    return (size_t)cdiv(N, 64) * tracks * 2 * D * Hn * sizeof(float);
-}
-
 extern "C" int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                     const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* a_final,
                                     float* d_bias, float* d_w_enc, float* d_w_dec) {
-    return mnn_nade_logprob_bwd_ws(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec, a_final, d_bias, d_w_enc, d_w_dec, nullptr, 0);
-}
-
-extern "C" int mnn_nade_logprob_bwd_ws(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
-                                       const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* a_final,
-                                       float* d_bias, float* d_w_enc, float* d_w_dec, void* workspace, size_t workspace_bytes) {
     MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn > 0 && Hn <= 256, "mnn_nade_logprob_bwd: need tracks,N,D>0 and 0<Hn<=256 (Hn=%d)", Hn);
     MNN_REQUIRE(v && bias && w_enc && w_dec && a_final && d_bias && d_w_enc && d_w_dec, "mnn_nade_logprob_bwd: null pointer");
     MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_logprob_bwd: ld_bias too small");
-    const size_t need = mnn_nade_logprob_bwd_workspace_bytes(tracks, N, D, Hn);
-    MNN_REQUIRE(workspace == nullptr || (need > 0 && workspace_bytes >= need && ((size_t)workspace & 15) == 0),
-                "mnn_nade_logprob_bwd_ws: workspace must be 16-byte aligned and hold mnn_nade_logprob_bwd_workspace_bytes() bytes (D*Hn %% 4 == 0)");
-    float* slab = (float*)workspace;
     hipStream_t st = (hipStream_t)s;
-    // hidden slices: Hn <= 256 in one workgroup of lane-major quads (HQ = 4), or as two 128-wide slices at twice the residency (HQ = 2)
-    static int split = -1;
-    if (split < 0) { const char* e = getenv("MULTINN_NADE_BWD_SLICES"); split = e ? atoi(e) : 2; }
-    // rows per workgroup: 64, or with MULTINN_NADE_BWD_ROWS=128 two groups of 8 rows per wave (half the f32 atomics per row, a quarter fewer LDS
-    // reads per FMA).  Measured SLOWER at the bench shape (4.98 vs 3.94 ms, rho = 0.5: 8.6 vs 6.5): 187 registers leave two waves per SIMD
-    // instead of four -- the scan is bound by issue / latency at that occupancy, its atomics ride along
-    static int rows2 = -1;
-    if (rows2 < 0) { const char* e = getenv("MULTINN_NADE_BWD_ROWS"); rows2 = (e && atoi(e) == 128) ? 2 : 0; }
-#define BWD(HQ, RG, NS) hipLaunchKernelGGL((nade_bwd_kernel<HQ, RG>), dim3(cdiv(N, 64 * (RG)), tracks * (NS)), dim3(512), 0, st, tracks, N, D, Hn, NS, v, \
-                                           v_track_stride, bias, ld_bias, w_enc, w_dec, a_final, d_bias, d_w_enc, d_w_dec, slab)
-    const bool r2 = slab == nullptr && rows2 == 2;
-    if (Hn <= 64) BWD(1, 1, 1);
-    else if (Hn <= 128) { if (split == 4) BWD(1, 1, cdiv(Hn, 64)); else if (r2) BWD(2, 2, 1); else BWD(2, 1, 1); }
-    else if (split == 4) BWD(1, 1, cdiv(Hn, 64));
-    else if (split == 2) { if (r2) BWD(2, 2, cdiv(Hn, 128)); else BWD(2, 1, cdiv(Hn, 128)); }
-    else BWD(4, 1, 1);
+    // The backward scan is separable over hidden units, so a wide layer runs as 128-wide slices (HQ = 2: 116 VGPRs, 80 KB of LDS -> two
+    // workgroups per CU).  Measured and removed in round 4 (never the default): one 256-wide workgroup (HQ = 4), 64-wide slices, and 128 rows
+    // per workgroup (two row groups per wave: 4.98 vs 3.94 ms at [1024,256,88,5] -- 187 registers leave two waves per SIMD instead of four).
+#define BWD(HQ, NS) hipLaunchKernelGGL((nade_bwd_kernel<HQ, 1>), dim3(cdiv(N, 64), tracks * (NS)), dim3(512), 0, st, tracks, N, D, Hn, NS, v, \
+                                       v_track_stride, bias, ld_bias, w_enc, w_dec, a_final, d_bias, d_w_enc, d_w_dec)
+    if (Hn <= 64) BWD(1, 1);
+    else BWD(2, cdiv(Hn, 128));
 #undef BWD
     MNN_LAUNCH_CHECK();
-    if (slab != nullptr) {
-        const long dh = (long)D * Hn;
-        const int nblk = cdiv(N, 64), split = nblk >= 64 ? 4 : 1;
-        hipLaunchKernelGGL(nade_bwd_reduce_kernel, dim3(cdiv(dh / 4, 256), tracks * 2, split), dim3(256), 0, st, slab, nblk, tracks, dh, d_w_dec, d_w_enc);
-        MNN_LAUNCH_CHECK();
-    }
     return MNN_OK;
 }
 

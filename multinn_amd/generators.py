@@ -917,10 +917,6 @@ class RnnNade(RnnEstimator):
 
     nade_mfma = os.environ.get("MULTINN_NADE_MFMA", "1") != "0"
 
-    # per-workgroup slabs + a reduction pass instead of f32 atomics for d w_enc / d w_dec: measured SLOWER on MI355X (TGT: 5.09 vs 3.99 ms --
-    # the atomics ride under the scan's VALU work, the slab stores + the 3.7 GB read-back do not), so it is opt-in (bit-reproducible sums)
-    nade_bwd_slabs = os.environ.get("MULTINN_NADE_BWD_SLABS", "0") != "0"
-
     nade_dense_above = float(os.environ.get("MULTINN_NADE_DENSE_ABOVE", "0.07"))   # density above which the f32 scan replaces the matrix-core form
 
     def _nade_fwd(self, v, out, rw, nll, cond_p, d_out, a_fin):
@@ -1086,14 +1082,8 @@ class RnnNade(RnnEstimator):
         g = self.store.gviews
         self.store.grad.zero_()
         d_out = cx["d_out"]
-        # weight-gradient sums over rows through per-workgroup slabs + one reduction pass (no cross-workgroup f32 atomics) once there are
-        # enough 64-row workgroups for the atomics to be the bound (measured: from N = 4096 rows on)
-        ws = None
-        nb = ops.nade_bwd_workspace_bytes(M, N, D, Hn)
-        if self.nade_bwd_slabs and N >= 4096 and nb > 0:
-            ws = torch.empty(nb, device=dev, dtype=torch.uint8)
         ops.nade_logprob_bwd(cx["v"].view(M, N, D), cx["out"], self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn, cx["a_fin"],
-                             d_out, g["nade/w_enc"], g["nade/w_dec"], workspace=ws)
+                             d_out, g["nade/w_enc"], g["nade/w_dec"])
         # dense: dK[R,n_out] = y^T d_out ; db = sum d_out ; dy = d_out K^T
         Np = ops.round_up(N, 64)
         zalloc = torch.zeros if Np != N else torch.empty

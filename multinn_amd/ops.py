@@ -487,23 +487,13 @@ def nade_logprob_fwd_auto(v, bias, w_enc, w_dec, w_dec_bf, tracks, D, Hn, gate, 
     call("mnn_nade_logprob_fwd_gated", _stream(), *common, _ptr(w_dec), *tail, 1)
 
 
-def nade_bwd_workspace_bytes(tracks, N, D, Hn):
-    return int(_lib.load().mnn_nade_logprob_bwd_workspace_bytes(int(tracks), int(N), int(D), int(Hn)))
-
-
-def nade_logprob_bwd(v, bias, w_enc, w_dec, tracks, D, Hn, a_final, d_bias, d_w_enc, d_w_dec, workspace=None):
+def nade_logprob_bwd(v, bias, w_enc, w_dec, tracks, D, Hn, a_final, d_bias, d_w_enc, d_w_dec):
     N = bias.shape[0]
     _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)
     _req(d_bias.shape == bias.shape and d_bias.stride() == bias.stride() and d_bias.dtype == torch.float32, "nade bwd: d_bias")
     for w in (d_w_enc, d_w_dec):
         _req(w.dtype == torch.float32 and w.is_contiguous() and w.numel() == tracks * D * Hn, "nade bwd: grad weights f32 [tracks,D,Hn]")
     _req(a_final.dtype == torch.float32 and a_final.numel() == tracks * N * Hn and a_final.is_contiguous(), "nade bwd: a_final f32 [tracks,N,Hn]")
-    if workspace is not None:
-        _req(workspace.dtype == torch.uint8 and workspace.is_contiguous() and workspace.numel() >= nade_bwd_workspace_bytes(tracks, N, D, Hn) > 0,
-             "nade bwd: workspace must be the tensor of nade_bwd_workspace(tracks, N, D, Hn)")
-        call("mnn_nade_logprob_bwd_ws", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
-             _ptr(a_final), _ptr(d_bias), _ptr(d_w_enc), _ptr(d_w_dec), _ptr(workspace), workspace.numel())
-        return
     call("mnn_nade_logprob_bwd", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
          _ptr(a_final), _ptr(d_bias), _ptr(d_w_enc), _ptr(d_w_dec))
 

@@ -499,35 +499,6 @@ def test_nade_mfma_exact_forward_vs_oracle(ops, N, D, tracks, rho):
     assert torch.equal(nll, nll2) and torch.equal(cp, cp2)              # deterministic
 
 
-@pytest.mark.parametrize("N,D,Hn,tracks", [(4100, 24, 256, 1), (300, 52, 100, 2), (64, 440, 256, 1), (130, 20, 8, 3)])
-def test_nade_bwd_slab_reduction_matches_atomic_form(ops, N, D, Hn, tracks):
-    """mnn_nade_logprob_bwd_ws: per-workgroup partial-sum slabs + one reduction pass give the same weight gradients as the form that
-    adds every workgroup's partials with f32 atomics (and both match the oracle, test_nade_logprob_fwd_bwd); accumulates into its outputs."""
-    g = torch.Generator(device="cuda").manual_seed(N + D + Hn)
-    ld = tracks * (Hn + D)
-    v = (torch.rand((tracks, N, D), device="cuda", generator=g) < 0.2).to(torch.uint8)
-    bias = torch.randn((N, ld), device="cuda", generator=g) * 0.5
-    we = torch.randn((tracks, D, Hn), device="cuda", generator=g) * 0.2
-    wd = torch.randn((tracks, D, Hn), device="cuda", generator=g) * 0.2
-    rw = torch.rand(N, device="cuda", generator=g) / N
-    z = lambda *s_: torch.zeros(s_, device="cuda")
-    d0, a_fin = torch.zeros_like(bias), z(tracks, N, Hn)
-    ops.nade_logprob_fwd(v, bias, we, wd, tracks, D, Hn, rw, z(tracks, N), None, d0, a_fin)
-    d1 = d0.clone()
-    dwe0, dwd0 = z(tracks, D, Hn), z(tracks, D, Hn)
-    ops.nade_logprob_bwd(v, bias, we, wd, tracks, D, Hn, a_fin, d0, dwe0, dwd0)
-    nb = ops.nade_bwd_workspace_bytes(tracks, N, D, Hn)
-    assert nb == -(-N // 64) * tracks * 2 * D * Hn * 4
-    ws = torch.full((nb,), 0xFF, device="cuda", dtype=torch.uint8)          # poisoned: every word that is summed must have been written
-    dwe1, dwd1 = torch.ones(tracks, D, Hn, device="cuda"), torch.ones(tracks, D, Hn, device="cuda")
-    ops.nade_logprob_bwd(v, bias, we, wd, tracks, D, Hn, a_fin, d1, dwe1, dwd1, workspace=ws)
-    assert torch.equal(d0, d1)
-    for a_, b_ in ((dwe0, dwe1 - 1.0), (dwd0, dwd1 - 1.0)):
-        assert float((a_ - b_).abs().max()) <= 2e-5 * float(a_.abs().max()) + 1e-6
-    with pytest.raises(ValueError):
-        ops.nade_logprob_bwd(v, bias, we, wd, tracks, D, Hn, a_fin, d1, dwe1, dwd1, workspace=ws[: nb // 2])
-
-
 @pytest.mark.parametrize("rho,expect", [(0.03, 0), (0.3, 1)])
 def test_nade_forward_density_gate(ops, rho, expect):
     """mnn_density_gate + the two gated launches: a sparse batch runs the matrix-core form (bit-identical to calling it directly), a dense
