@@ -280,35 +280,79 @@ def step_roofline(N, D, precision, t_step_s, sig_peak, phase_ms, nnz_row, nade_f
                 phases=phases, accounting="executed (device-counted density); dense beside it")
 
 
+def _recorded(workload, precision, kind):
+    """The newest committed counter recording of this workload / precision (profiles/roundN_<workload>_<precision>_<kind>.json) and whether it
+    was taken on THIS build (its sources_sha16 == profiles/tools/source_hash.py of the tree bench.py runs from)."""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
+    try:
+        from source_hash import source_hash
+        here = source_hash()
+    except Exception:
+        here = None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"round*_{workload}_{precision}_{kind}.json")),
+                   key=lambda f: int(os.path.basename(f)[5:].split("_")[0]))
+    for f in reversed(files):
+        try:
+            data = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        return data, os.path.basename(f), bool(here and data.get("sources_sha16") == here), here
+    return None, None, False, here
+
+
 def attach_counters(rf, workload, precision):
-    """mfma_busy / parked / HBM-side bytes of the kernel behind an entry point, from the rocprofv3 passes committed under profiles/ for this
-    workload and precision (counters cannot be collected from inside this process): profiles/round3_<workload>_<precision>_{sq_counters,pmc_traffic}.json."""
+    """rocprofv3 counters cannot be collected from inside this process: the line carries the counters RECORDED by profiles/tools/record_round4.sh
+    (separate --pmc passes over this command in eager mode) under roofline.recorded_counters, with the file, the source hash of the recorded
+    build and `same_build`.  Only when the recording was taken on this very build are its HBM bytes also reported as roofline.traffic (the
+    contract's field); otherwise traffic stays null -- stale counters never stand beside live timings unmarked."""
     kern = rf.get("kernel")
+    rf.setdefault("traffic", None)
     if not kern:
         return
+    rec = {}
     for kind in ("sq_counters", "pmc_traffic"):
-        fn = f"round3_{workload}_{precision}_{kind}.json"
-        try:
-            data = json.load(open(os.path.join(ROOT, "profiles", fn)))
-        except (OSError, ValueError):
+        data, fn, same, here = _recorded(workload, precision, kind)
+        if data is None:
             continue
         hit = [v for k, v in data.get("kernels", {}).items() if k.startswith(kern)]
         if not hit:
             continue
         calls = sum(h["calls"] for h in hit)
+        r = rec.setdefault(kind, {"file": "profiles/" + fn, "recorded_sources_sha16": data.get("sources_sha16"), "this_build_sha16": here,
+                                  "same_build": same})
         if kind == "sq_counters":
             for key in ("mfma_busy_frac", "parked_frac", "active_frac"):
                 vals = [(h[key], h["calls"]) for h in hit if key in h]
                 if vals:
-                    rf[key.replace("_frac", "")] = sum(v * c for v, c in vals) / sum(c for _, c in vals)
-            rf["counters_source"] = f"profiles/{fn} (one rocprofv3 --pmc pass of SQ / GRBM counters over the same command)"
+                    r[key.replace("_frac", "")] = sum(v * c for v, c in vals) / sum(c for _, c in vals)
+            r["method"] = "one rocprofv3 --pmc pass of SQ / GRBM counters over this command in eager mode"
         else:
-            rf["traffic"] = sum(h["hbm_side_bytes_per_launch"] * h["calls"] for h in hit) / calls
-            rf["traffic_unit"] = "bytes/launch"
-            rf["traffic_write"] = sum(h["write_bytes"] * h["calls"] for h in hit) / calls
-            if rf.get("avg_launch_us"):
-                rf["hbm_gbs"] = rf["traffic"] / (rf["avg_launch_us"] * 1e-6) / 1e9
-            rf["traffic_source"] = f"profiles/{fn} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
+            r["traffic"] = sum(h["hbm_side_bytes_per_launch"] * h["calls"] for h in hit) / calls
+            r["traffic_unit"] = "bytes/launch"
+            r["traffic_write"] = sum(h["write_bytes"] * h["calls"] for h in hit) / calls
+            r["method"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 (MI355X_MICROARCH.md)"
+            if same:
+                rf["traffic"] = r["traffic"]
+                rf["traffic_unit"] = "bytes/launch"
+                if rf.get("avg_launch_us"):
+                    rf["hbm_gbs"] = r["traffic"] / (rf["avg_launch_us"] * 1e-6) / 1e9
+    if rec:
+        rf["recorded_counters"] = rec
+
+
+def step_traffic(workload, precision, algorithmic_bytes):
+    """HBM-side bytes of the whole step (sum over every kernel of the recorded FETCH / WRITE passes) next to the algorithmic bytes of SURVEY 8(d)."""
+    out = {"algorithmic_gb_per_step": algorithmic_bytes / 1e9, "hbm_side_gb_per_step": None}
+    data, fn, same, here = _recorded(workload, precision, "pmc_traffic")
+    if data is not None:
+        per_step = data.get("hbm_side_bytes_per_step")
+        if per_step is None:         # recordings of earlier rounds: the steps they contain = their clip_adam_kernel launches
+            steps = next((k["calls"] for n, k in data["kernels"].items() if n.startswith("clip_adam_kernel")), 4)
+            per_step = sum(k["hbm_side_bytes_per_launch"] * k["calls"] for k in data["kernels"].values()) / float(steps)
+        out.update(hbm_side_gb_per_step=per_step / 1e9, ratio=per_step / algorithmic_bytes, file="profiles/" + fn, same_build=same,
+                   recorded_sources_sha16=data.get("sources_sha16"), this_build_sha16=here)
+    return out
 
 
 def collective_only(a):
@@ -595,6 +639,8 @@ def main(argv=None):
                                 ("mfma-split3" if a.precision == "fp16" else "mfma") if nade_mfma_form else "valu")
     roof["step"]["sigmoid_peak"] = sig
     roof["step"]["rho"] = a.rho
+    ph = roof["step"]["phases"]
+    traffic_step = step_traffic(a.workload, a.precision, ph["lstm_dense"]["bytes"] + ph["nade_scan"]["bytes"])
 
     out = {
         "metric": "piano-roll timesteps/sec (train step), 5-track LSTM-NADE", "value": world * B * T / sec,
@@ -611,6 +657,7 @@ def main(argv=None):
                            ("bf16 operands (8 significant bits): loss 6e-6, per-row NLL 1.2e-4, conditionals 3e-4 abs, gradients 2e-3..4.5e-3 vs the "
                             "float64 oracle (tests/test_gpu_realdims.py, printed bounds)")},
         "roofline": roof,
+        "hbm_traffic": traffic_step,
         "breakdown_ms": {k: round(v[0], 3) for k, v in top},
     }
     out.update(extras)

@@ -13,15 +13,13 @@
  * Each entry cites the reference interface it replaces as file:line under
  * /root/reference/multinn (ilya16/MultINN).
  *
- * Two entries of SURVEY.md 8(b)'s proposed symbol list are deliberately NOT exported:
+ * One entry of SURVEY.md 8(b)'s proposed symbol list is deliberately NOT exported:
  *   - mnn_generate_scan (rnn_estimator.py:271-323, multinn_feedback.py:120-218): the sampling scan is the sequence
  *     {mnn_nade_sample | mnn_rbm_gibbs, mnn_lstm2_seq_fwd / mnn_lstm_seq_fwd, mnn_gemm_tn} per generated step, captured ONCE
  *     into a hipGraph by the host (multinn_amd/common.py ScanGraphs) and replayed -- every step's RNG counter is a kernel
  *     argument baked into its node, so one replay is one whole scan; a dedicated symbol would only repeat that loop in C.
- *   - mnn_comm_init / mnn_allreduce_flat / mnn_comm_destroy: the single data-parallel exchange of a step is ONE
- *     all-reduce of the flat f32 gradient buffer (or of the flat CD delta) issued by the host through torch.distributed,
- *     backend "nccl" = RCCL over xGMI (multinn_amd/training.py allreduce_flat); the library never owns a communicator, so
- *     it keeps "no global mutable state" and the buffer it hands over is a plain caller-owned device pointer.
+ * (mnn_comm_init / mnn_allreduce_flat / mnn_comm_destroy ARE exported since round 4 -- see "Data-parallel exchange" below; the Python mirror
+ *  still issues its all-reduce through torch.distributed by default, backend "nccl" = the same RCCL.)
  */
 #ifndef MULTINN_HIP_H
 #define MULTINN_HIP_H
@@ -426,6 +424,23 @@ typedef struct {
 } mnn_det_dense_job;
 int mnn_lstm_step_det(mnn_stream_t s, int B, int njobs, const mnn_det_lstm_job* jobs);
 int mnn_dense_det(mnn_stream_t s, int B, int njobs, const mnn_det_dense_job* jobs);
+
+/* ------------------------------------------------------------------------------------------
+ * Data-parallel exchange (the gradients of utils/training.py:151-177 as ONE flat f32 buffer): RCCL over xGMI, one
+ * communicator per process = per GPU, created, passed and destroyed by the CALLER (the library keeps no communicator).
+ *   mnn_comm_unique_id: rank 0 fills 128 bytes (MNN_COMM_ID_BYTES) and ships them to the other ranks through any host channel;
+ *   mnn_comm_init: collective over all `world` ranks, binds to the calling thread's current HIP device;
+ *   mnn_allreduce_flat: buf[0..n) := sum over ranks, in place, asynchronous on stream s (the step's ONE collective);
+ *   mnn_comm_destroy.
+ * RCCL is bound at run time (dlopen librccl.so.1 -- the copy already in the process if there is one); without it these calls return an
+ * error and every other entry point works.
+ * ------------------------------------------------------------------------------------------ */
+#define MNN_COMM_ID_BYTES 128
+typedef struct mnn_comm_s* mnn_comm_t;
+int mnn_comm_unique_id(void* id_out);
+int mnn_comm_init(mnn_comm_t* comm, int rank, int world, const void* id);
+int mnn_allreduce_flat(mnn_comm_t comm, mnn_stream_t s, float* buf, long n);
+int mnn_comm_destroy(mnn_comm_t comm);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement support (not on the product path).  mnn_probe_sigmoid: `blocks` x 256 threads x 8 independent chains x `iters`

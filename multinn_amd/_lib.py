@@ -54,6 +54,10 @@ SIGNATURES = {
     "mnn_lstm_step_det": (_i, [_p, _i, _i, _p]),
     "mnn_dense_det": (_i, [_p, _i, _i, _p]),
     "mnn_nade_sample_multi": (_i, [_p, _i, _p, _i, _i, _i, _f, _u32, _u32, _l, _i]),
+    "mnn_comm_unique_id": (_i, [_p]),
+    "mnn_comm_init": (_i, [C.POINTER(_p), _i, _i, _p]),
+    "mnn_allreduce_flat": (_i, [_p, _p, _p, _l]),
+    "mnn_comm_destroy": (_i, [_p]),
 }
 
 class DetLstmJob(C.Structure):

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmultinn_hip.so")
-SOURCES = ["gemm.hip", "lstm_persist.hip", "lstm_rowpar.hip", "elementwise.hip", "nade.hip", "nade_mfma.hip", "rbm.hip", "musical.hip", "det_step.hip"]
+SOURCES = ["gemm.hip", "lstm_persist.hip", "lstm_rowpar.hip", "elementwise.hip", "nade.hip", "nade_mfma.hip", "rbm.hip", "musical.hip", "det_step.hip", "comm.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 
 
@@ -35,7 +35,7 @@ def build(force=False, verbose=True):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -40,10 +40,56 @@ def dp_active():
     return dist.get_world_size() > 1 or os.environ.get("MULTINN_DP_REHEARSAL") == "1"
 
 
+class CabiComm:
+    """The step's collective through the C ABI (mnn_comm_init / mnn_allreduce_flat: RCCL over xGMI), for hosts without torch.distributed's
+    collectives -- and the path MULTINN_COMM=capi takes here.  The 128-byte unique id is created by rank 0 and handed to the other ranks by
+    `exchange` (default: a torch.distributed object broadcast, which only uses the store / any backend; a host may pass its own function
+    rank-0-bytes -> everybody's-bytes)."""
+
+    def __init__(self, rank, world, exchange=None):
+        import ctypes as C
+        from . import _lib
+        self._lib, self.rank, self.world = _lib, rank, world
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.call("mnn_comm_unique_id", buf)
+        uid = bytes(buf.raw)
+        if world > 1:
+            if exchange is None:
+                box = [uid]
+                dist.broadcast_object_list(box, src=0)
+                uid = box[0]
+            else:
+                uid = exchange(uid)
+        self._h = C.c_void_p()
+        _lib.call("mnn_comm_init", C.byref(self._h), int(rank), int(world), C.create_string_buffer(uid, 128))
+
+    def all_reduce(self, grad):
+        import ctypes as C
+        assert grad.is_cuda and grad.dtype == torch.float32 and grad.is_contiguous()
+        self._lib.call("mnn_allreduce_flat", self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(grad.data_ptr()), grad.numel())
+        return grad
+
+    def close(self):
+        if self._h:
+            self._lib.call("mnn_comm_destroy", self._h)
+            self._h = None
+
+
+_CABI_COMM = None
+
+
 def allreduce_flat(grad):
-    """The single data-parallel exchange of the step: sum the flat gradient over ranks."""
+    """The single data-parallel exchange of the step: sum the flat gradient over ranks.  torch.distributed (backend "nccl" = RCCL) by
+    default; MULTINN_COMM=capi issues the same RCCL all-reduce through the library's own entry points (CabiComm)."""
+    global _CABI_COMM
     if dp_active():
-        dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+        if os.environ.get("MULTINN_COMM") == "capi" and grad.is_cuda:
+            if _CABI_COMM is None:
+                _CABI_COMM = CabiComm(dist.get_rank(), dist.get_world_size())
+            _CABI_COMM.all_reduce(grad)
+        else:
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM)
     return grad
 
 

@@ -5,7 +5,7 @@
                    XCDs -- checked on the persistent backward: 14.35 M = 8 x (757 us x 2.37 GHz), and its MFMA cycles are exactly
                    32 x the 3 670 016 MFMAs of a launch)
   parked_frac    = SQ_WAIT_ANY / SQ_WAVE_CYCLES  (waves parked on s_waitcnt / barriers), issue_stall_frac = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
-Usage: python profiles/sq_counters.py <dir of the pass> <out.json>"""
+Usage: python profiles/sq_counters.py <dir of the pass> <out.json> [workload label] [sources sha16 (profiles/tools/source_hash.py)]"""
 import collections, csv, glob, json, os, re, sys
 
 
@@ -17,7 +17,8 @@ def main():
             name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
             acc[name][r["Counter_Name"]] += float(r["Counter_Value"])
             calls[name].add(r["Dispatch_Id"])
-    out = {"workload": sys.argv[3] if len(sys.argv) > 3 else "C2 [256,128,88,5] bf16, eager launches, 3 steps + 1 warm-up", "kernels": {}}
+    out = {"workload": sys.argv[3] if len(sys.argv) > 3 else "C2 [256,128,88,5] bf16, eager launches, 3 steps + 1 warm-up",
+           "sources_sha16": sys.argv[4] if len(sys.argv) > 4 else None, "kernels": {}}
     for name, c in sorted(acc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0.0)):
         n = len(calls[name])
         if n == 0 or name.startswith("at::") or "rocclr" in name:

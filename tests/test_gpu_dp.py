@@ -84,3 +84,25 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["value"] > 0 and out["launch"] == "hipgraph-replay"
     assert out["roofline"]["step"]["frac"] > 0
+
+
+def test_cabi_communicator_all_reduce_single_rank():
+    """mnn_comm_unique_id / mnn_comm_init / mnn_allreduce_flat / mnn_comm_destroy: a one-rank RCCL communicator created
+    through the C ABI alone (no torch.distributed), the flat f32 buffer all-reduced in place on the current stream -- with one rank the sum
+    is the buffer itself -- and argument validation.  (More than one rank needs more than one GPU: the driver's scaling run.)"""
+    import ctypes as C
+    from multinn_amd import _lib
+    from multinn_amd.training import CabiComm
+    comm = CabiComm(0, 1)
+    g = torch.arange(3_143_352, device="cuda:0", dtype=torch.float32) * 1e-3          # the joint model's flat gradient size
+    ref = g.clone()
+    comm.all_reduce(g)
+    comm.all_reduce(g)
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref)
+    with pytest.raises(_lib.MnnError):
+        _lib.call("mnn_allreduce_flat", None, None, C.c_void_p(g.data_ptr()), g.numel())
+    with pytest.raises(_lib.MnnError):
+        _lib.call("mnn_comm_init", C.byref(C.c_void_p()), 3, 2, C.create_string_buffer(128))
+    comm.close()
+    comm.close()
