@@ -495,41 +495,55 @@ rbm_half_mfma_kernel(int N, int K, int n_out, const TV* __restrict__ in, const f
     const int Ke = (K + 1) & ~1, lw = n_out | 1, pin = Ke | 1;
     float* Ws = smem;                       // [Ke][lw]
     float* xs = smem + (size_t)Ke * lw;     // [64][pin]
-    const int n0 = blockIdx.x * GM_ROWS;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int k = w; k < Ke; k += 8)
         for (int o = lane; o < lw; o += 64) Ws[k * lw + o] = o < n_out ? Wk[(size_t)min(k, K - 1) * ldw + o] : 0.f;
-    for (int e = threadIdx.x; e < GM_ROWS * pin; e += 512) {
-        const int r = e / pin, k = e - r * pin, n = n0 + r;
-        xs[e] = (n < N && k < K) ? (float)in[(size_t)n * K + k] : 0.f;
-    }
-    __syncthreads();
     const int r = lane & 31, hh = lane >> 5;
     const int not_ = (n_out + 31) / 32;
-    for (int job = w; job < 2 * not_; job += 8) {
-        const int rt = job / not_, ot = job - rt * not_;
-        gm_f32x16 acc;
+    // persistent over 64-row tiles: the weights are fetched into LDS once per workgroup (one workgroup per CU), not once per 64 rows -- a
+    // half-step has a single K-long chain per output, so a per-tile weight load (59 KB for 5.6 KB of inputs at 88 -> 168) was most of its time
+    for (int tile = blockIdx.x; tile * GM_ROWS < N; tile += gridDim.x) {
+        const int n0 = tile * GM_ROWS;
+        __syncthreads();                                        // the previous tile's chains have read xs (first pass: Ws is complete)
+        {   // the 64 rows' inputs: thread t -> row t >> 3, eight lanes walk its columns; sixteen loads in flight per thread (unconditional, clamped)
+            const int rr = threadIdx.x >> 3, sub = threadIdx.x & 7, n = n0 + rr;
+            const TV* __restrict__ src = in + (size_t)min(n, N - 1) * K;
+            float* d = xs + rr * pin;
+            for (int kb = sub; kb < pin; kb += 128) {
+                TV v[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        const float* ap = Ws + (size_t)hh * lw + min(32 * ot + r, n_out - 1);
-        const float* bp = xs + (32 * rt + r) * pin + hh;
+                for (int q = 0; q < 16; ++q) v[q] = src[min(kb + 8 * q, K - 1)];
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (kb + 8 * q < pin) d[kb + 8 * q] = (n < N && kb + 8 * q < K) ? (float)v[q] : 0.f;
+            }
+        }
+        __syncthreads();
+        for (int job = w; job < 2 * not_; job += 8) {
+            const int rt = job / not_, ot = job - rt * not_;
+            gm_f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            const float* ap = Ws + (size_t)hh * lw + min(32 * ot + r, n_out - 1);
+            const float* bp = xs + (32 * rt + r) * pin + hh;
 #pragma unroll 4
-        for (int s2 = 0; s2 < Ke / 2; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(size_t)s2 * 2 * lw], bp[2 * s2], acc, 0, 0, 0);
-        const int row = n0 + 32 * rt + r;
-        if (row >= N) continue;
+            for (int s2 = 0; s2 < Ke / 2; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(size_t)s2 * 2 * lw], bp[2 * s2], acc, 0, 0, 0);
+            const int row = n0 + 32 * rt + r;
+            if (row >= N) continue;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int o0 = 32 * ot + 8 * g4 + 4 * hh;
-            if (o0 >= n_out) continue;
-            float u[4] = {0.f, 0.f, 0.f, 0.f};
-            if (s_out) philox_uniform4(seed, (uint32_t)stream_id, row0 + (uint32_t)row, sub, (uint32_t)(o0 >> 2), u);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int o0 = 32 * ot + 8 * g4 + 4 * hh;
+                if (o0 >= n_out) continue;
+                float u[4] = {0.f, 0.f, 0.f, 0.f};
+                if (s_out) philox_uniform4(seed, (uint32_t)stream_id, row0 + (uint32_t)row, sub, (uint32_t)(o0 >> 2), u);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int o = o0 + e;
-                if (o >= n_out) continue;
-                const float p = det_sigmoid(acc[4 * g4 + e] + b[(size_t)row * ld_b + o]);
-                if (p_out) p_out[(size_t)row * n_out + o] = p;
-                if (s_out) s_out[(size_t)row * n_out + o] = u[e] < p ? 1 : 0;
+                for (int e = 0; e < 4; ++e) {
+                    const int o = o0 + e;
+                    if (o >= n_out) continue;
+                    const float p = det_sigmoid(acc[4 * g4 + e] + b[(size_t)row * ld_b + o]);
+                    if (p_out) p_out[(size_t)row * n_out + o] = p;
+                    if (s_out) s_out[(size_t)row * n_out + o] = u[e] < p ? 1 : 0;
+                }
             }
         }
     }
@@ -549,11 +563,15 @@ static int launch_half(hipStream_t st, int N, int K, int n_out, const void* in, 
             raised = true;
         }
         const size_t l2 = half_mfma_lds_bytes(K, n_out);
+        int dev = 0, cus = 256;
+        MNN_HIP(hipGetDevice(&dev));
+        MNN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int grid = min(cdiv(N, GM_ROWS), max(cus, 1));        // one workgroup per CU walks the row tiles
         if (in_dtype == MNN_U8)
-            hipLaunchKernelGGL(rbm_half_mfma_kernel<uint8_t>, dim3(cdiv(N, GM_ROWS)), dim3(512), l2, st, N, K, n_out, (const uint8_t*)in, Wk, ldw, b, ld_b,
+            hipLaunchKernelGGL(rbm_half_mfma_kernel<uint8_t>, dim3(grid), dim3(512), l2, st, N, K, n_out, (const uint8_t*)in, Wk, ldw, b, ld_b,
                                stream_id, seed, row0, sub, p_out, s_out);
         else
-            hipLaunchKernelGGL(rbm_half_mfma_kernel<float>, dim3(cdiv(N, GM_ROWS)), dim3(512), l2, st, N, K, n_out, (const float*)in, Wk, ldw, b, ld_b,
+            hipLaunchKernelGGL(rbm_half_mfma_kernel<float>, dim3(grid), dim3(512), l2, st, N, K, n_out, (const float*)in, Wk, ldw, b, ld_b,
                                stream_id, seed, row0, sub, p_out, s_out);
         MNN_LAUNCH_CHECK();
         return MNN_OK;
