@@ -301,9 +301,17 @@ __global__ void __launch_bounds__(512) rbm_gibbs_mfma_kernel(GibbsMfmaArgs A) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int d = w; d < De; d += 8)                          // one wave per row of W: coalesced
         for (int j = lane; j < ldw; j += 64) Ws[d * ldw + j] = j < Hn ? A.W[(size_t)min(d, D - 1) * Hn + j] : 0.f;
-    for (int e = threadIdx.x; e < GM_ROWS * pv; e += 512) {
-        const int r = e / pv, kx = e - r * pv, n = n0 + r;
-        vs[e] = (n < N && kx < D) ? A.v0[(size_t)n * D + kx] : (uint8_t)0;
+    {   // v0 rows: thread t -> row t >> 3, eight lanes walk its bytes, sixteen loads in flight (unconditional, clamped)
+        const int rr = threadIdx.x >> 3, sub = threadIdx.x & 7, n = n0 + rr;
+        const uint8_t* __restrict__ src = A.v0 + (size_t)min(n, N - 1) * D;
+        for (int kb = sub; kb < pv; kb += 128) {
+            uint8_t v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = src[min(kb + 8 * q, D - 1)];
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (kb + 8 * q < pv) vs[rr * pv + kb + 8 * q] = (n < N && kb + 8 * q < D) ? v[q] : (uint8_t)0;
+        }
     }
     for (int e = threadIdx.x; e < GM_ROWS * ph; e += 512) hs[e] = 0;
     const int r = lane & 31, hh = lane >> 5;
@@ -313,6 +321,22 @@ __global__ void __launch_bounds__(512) rbm_gibbs_mfma_kernel(GibbsMfmaArgs A) {
     const int rt_h = w >> 2;
     const int row_h = n0 + 32 * rt_h + r;                     // the batch row of this lane's accumulator column (hidden jobs)
     const uint32_t id_h = rbm_rowid(A.row_ids, A.row0, min(row_h, N - 1));
+    // the biases of this wave's first-pass jobs stay in registers over the chain (they do not change between Gibbs iterations; loaded inside
+    // the epilogue, every accumulator quad waited for its own L2 round trip in every iteration)
+    float bhr[2][16], bvr[16];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j = min(32 * (2 * (w & 3) + q) + (e & 3) + 8 * (e >> 2) + 4 * hh, Hn - 1);
+            bhr[q][e] = A.bh[(size_t)min(row_h, N - 1) * A.ld_bh + j];
+        }
+    {
+        const int job = min(w, 2 * ndt - 1), rt = job / ndt, dt = job - rt * ndt;
+        const int row = min(n0 + 32 * rt + r, N - 1);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bvr[e] = A.bv[(size_t)row * A.ld_bv + min(32 * dt + (e & 3) + 8 * (e >> 2) + 4 * hh, D - 1)];
+    }
     __syncthreads();
     if (A.k == 0) {
         for (int e = threadIdx.x; e < GM_ROWS * D; e += 512) {
@@ -356,7 +380,7 @@ __global__ void __launch_bounds__(512) rbm_gibbs_mfma_kernel(GibbsMfmaArgs A) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int j = min(j0 + e, Hn - 1);
-                        const float bb = A.bh[(size_t)min(row_h, N - 1) * A.ld_bh + j];
+                        const float bb = jt0 < 8 ? bhr[q][4 * g4 + e] : A.bh[(size_t)min(row_h, N - 1) * A.ld_bh + j];
                         const float p = det_sigmoid(acc[q][4 * g4 + e] + bb);
                         pk |= (u[e] < p && j0 + e < Hn ? 1u : 0u) << (8 * e);
                     }
@@ -385,7 +409,7 @@ __global__ void __launch_bounds__(512) rbm_gibbs_mfma_kernel(GibbsMfmaArgs A) {
                 for (int e = 0; e < 4; ++e) {
                     const int d = d0 + e;
                     if (d >= D) continue;
-                    const float p = det_sigmoid(acc[4 * g4 + e] + A.bv[(size_t)min(row, N - 1) * A.ld_bv + d]);
+                    const float p = det_sigmoid(acc[4 * g4 + e] + (job < 8 ? bvr[4 * g4 + e] : A.bv[(size_t)min(row, N - 1) * A.ld_bv + d]));
                     const uint8_t sv = u[e] < p ? 1 : 0;
                     vs[(32 * rt + r) * pv + d] = sv;
                     if (last && row < N) {
