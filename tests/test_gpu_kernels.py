@@ -674,9 +674,12 @@ def test_rbm_half_steps_on_the_matrix_cores_bit_exact(ops, N, D, Hn):
     assert np.array_equal(p_v.cpu().numpy(), pv_ref)
     u = philox.uniform_block(5, philox.STREAM_DBN_DEC, np.arange(40, 40 + N), 2, D)
     assert np.array_equal(vs.cpu().numpy(), (u < pv_ref).astype(np.uint8))
-    p_h2 = torch.zeros((N, Hn), device=DEV)                                # float inputs (probabilities)
-    ops.rbm_hidden(p_v, dev(W), dev(bh), 0, 0, 0, 0, p_h2, None)
+    p_h2 = torch.zeros((N, Hn), device=DEV); h2 = torch.zeros((N, Hn), device=DEV, dtype=torch.uint8)      # float inputs (probabilities)
+    ops.rbm_hidden(p_v, dev(W), dev(bh), philox.STREAM_DBN_ENC, 5, 40, 3, p_h2, h2)
     assert np.array_equal(p_h2.cpu().numpy(), det.rbm_hidden(pv_ref, W, bh))
+    p_h3 = torch.zeros((N, Hn), device=DEV)                                # probabilities only: the vector kernel, same bits
+    ops.rbm_hidden(p_v, dev(W), dev(bh), 0, 0, 0, 0, p_h3, None)
+    assert torch.equal(p_h3, p_h2)
 
 
 # ------------------------------------------------------------------------------------------------
