@@ -53,11 +53,16 @@ __device__ __forceinline__ void ds_chain_chunk(WF&& w_k, int k0, int kc, int K, 
             const int sb = s0 + half * DS_PF;                 // first k-pair of the set about to be consumed
 #pragma unroll
             for (int j = 0; j < DS_PF; ++j) wa[half ^ 1][j] = w_k(min(k0 + 2 * (sb + DS_PF + j) + hh, K - 1));
-            __builtin_amdgcn_sched_barrier(0);                // the refill loads first, then this set's MFMAs
+            // ... and this set's input operands out of LDS, all of them in front of the first MFMA: with a read + s_waitcnt lgkmcnt(0) in front
+            // of every MFMA the 64-cycle instruction waited another ~64 cycles for its operand each time
+            float xb[DS_PF];
+#pragma unroll
+            for (int j = 0; j < DS_PF; ++j) xb[j] = xs_row[2 * min(sb + j, np - 1) + hh];
+            __builtin_amdgcn_sched_barrier(0);                // the refill loads and the LDS reads first, then this set's MFMAs
             if (sb < np) {
 #pragma unroll
                 for (int j = 0; j < DS_PF; ++j)
-                    if (sb + j < np) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[half][j], xs_row[2 * (sb + j) + hh], acc, 0, 0, 0);
+                    if (sb + j < np) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[half][j], xb[j], acc, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
