@@ -399,9 +399,10 @@ int mnn_log_loss_rows(mnn_stream_t s, const uint8_t* targets, const float* probs
 /* ------------------------------------------------------------------------------------------
  * Deterministic f32 single steps of the SAMPLING scan (rnn_estimator.py:293-323 `_generate_recurrence`: sample_single -> single_step;
  * rnn_nade.py:253-277; multinn_feedback.py:175-218; the LSTM cell of rnn.py:124, the Dense of rnn_nade.py:54-57 / rnn_rbm.py:252-253).
- * Every output is a fixed sequence of IEEE f32 operations -- z = ascending-k fmaf chain over xh = [x | x2 | h_prev] from 0, then + bias;
- * i, f, o = det_sigmoid(z), ci = det_tanh(z) = 2 det_sigmoid(2 z) - 1; c = round(ci i) + round(c_prev f); h = det_tanh(c) o; Dense:
- * ascending-k fmaf chain from 0, then + bias -- which oracle/det_ref.c restates, so a whole generate() scan is checked bit for bit.
+ * Every output is a fixed sequence of IEEE f32 operations -- z = ((p_0 + p_1) + (p_2 + p_3)) + bias with p_s the ascending-k fmaf chain
+ * (from 0) over quarter s of xh = [x | x2 | h_prev] (quarters: the k-pairs of every 1024-column chunk cut into four runs of ceil(pairs / 4));
+ * i, f, o = det_sigmoid(z), ci = det_tanh(z) = 2 det_sigmoid(2 z) - 1; c = round(ci i) + round(c_prev f); h = det_tanh(c) o; Dense: the
+ * same four quarter chains, then + bias -- which oracle/det_ref.c restates, so a whole generate() scan is checked bit for bit.
  * Weights are the f32 MASTER weights in their TF layout (LSTM kernel [(n_x + n_x2 + units), 4 units], column blocks i | ci | f | o;
  * Dense kernel [K, N] with row pitch ld_w).  `jobs` is a HOST array of 1..MNN_DET_MAX_JOBS descriptors (passed to the kernel by
  * value): the jobs of one call run as ONE launch -- the M per-track generators of a feedback-scan step.  x: u8 cells (0 / 1) or f32.

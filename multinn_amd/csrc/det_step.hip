@@ -5,11 +5,12 @@
 // approximations, whose results no C program can restate.
 //
 // Specification (DESIGN.md "Deterministic sampling"; oracle/det_ref.c restates it independently):
-//   z[col]  = fmaf-chain over k ascending of xh[k] * W[k][col], starting from 0, xh = [x | x2 | h_prev] (TF's concat order, rnn.py:124
-//             LSTMBlockCell xh = [x, h]);  then + bias[col]            (one rounding per product-add, one for the bias add)
+//   z[col]  = ((p_0 + p_1) + (p_2 + p_3)) + bias[col], p_s = fmaf-chain over the k of quarter s ascending of xh[k] * W[k][col], starting from 0;
+//             xh = [x | x2 | h_prev] (TF's concat order, rnn.py:124 LSTMBlockCell xh = [x, h]); quarter s = k-pairs [s q, (s + 1) q) of
+//             the K (rounded up to even) columns, q = ceil(pairs / 4)  (chunks of DS_KC = 1024 columns are quartered one by one)
 //   i, f, o = det_sigmoid(z)   ci = det_tanh(z) = 2 det_sigmoid(2 z) - 1
 //   c       = round(ci * i) + round(c_prev * f)      h = det_tanh(c) * o        (forget_bias 0, no peephole, no clipping)
-//   Dense:  out[n] = fmaf-chain over k ascending of x[k] * W[k][n] from 0; then + bias[n]
+//   Dense:  out[n] = ((p_0 + p_1) + (p_2 + p_3)) + bias[n], the same four quarter chains over x[k] * W[k][n]
 // Master weights are read in their TF layout and in f32 (no packed / 16-bit copies): sampling runs in the reference's own arithmetic
 // whatever the training precision is.
 //
@@ -21,8 +22,8 @@
 // C[column][row] = sum_k W[k][column] xh[row][k] (A = weights straight from global memory, a ring of PF k-pairs ahead of their MFMAs;
 // B = the 32 rows' inputs from LDS, f32 [32][odd pitch]: conflict-free).  LSTM: a wave's 32 A rows are the FOUR gates of 8 units
 // (row g * 8 + uu <-> TF column g * units + unit), so a lane's accumulator quads hold i, ci, f, o of four (row, unit) pairs and the
-// pointwise part needs no exchange.  A workgroup = 4 waves = 32 units x 32 rows; K is walked in chunks of DS_KC through the staging
-// buffer.  Several (generator, layer) jobs -- the M per-track generators of the feedback scan -- run as ONE launch (blockIdx.z = job).
+// pointwise part needs no exchange of gates.  A workgroup = 4 waves = the 4 K quarters of 8 units x 32 rows (partial sums meet in LDS); K is
+// staged in chunks of DS_KC.  Several (generator, layer) jobs -- the M per-track generators of the feedback scan -- run as ONE launch (blockIdx.z = job).
 #include "common.h"
 
 #define DS_KC 1024                   // k per staging chunk (f32 [32][DS_KC + 1] = 128 KiB)
@@ -116,20 +117,30 @@ __device__ __forceinline__ void ds_stage_zero(int c_lo, int c_hi, int pitch, flo
     for (int c = c_lo + sub; c < c_hi; c += 8) xs[r * pitch + c] = 0.f;
 }
 
+// K split (specification, restated by oracle/det_ref.c): the k-pairs of a staging chunk (all of K when K <= DS_KC) are cut into FOUR contiguous
+// quarters of ceil(pairs / 4) pairs; quarter s has its own ascending fmaf chain p_s from 0 (running on over the chunks, if there are several),
+// and  z = ((p_0 + p_1) + (p_2 + p_3)) + bias.  The four chains of an output run on the four waves of a workgroup at the same time: the
+// sampling scan is latency-bound on a nearly idle chip (clocks drop to ~1 GHz there), and a K = 952 chain is 476 dependent 64-cycle MFMAs.
+#define DS_SPLIT 4
+__device__ __forceinline__ int ds_quarter(int kc) { return ((kc / 2) + DS_SPLIT - 1) / DS_SPLIT; }      // pairs per quarter of a chunk of kc (even) columns
+
 __global__ void __launch_bounds__(256) lstm_step_det_kernel(DetLstmJobs J, int B) {
     extern __shared__ __attribute__((aligned(16))) float ds_smem[];
     const mnn_det_lstm_job& jb = J.job[blockIdx.z];
-    const int u = jb.units, ub = blockIdx.x * 32;
+    const int u = jb.units, ub = blockIdx.x * 8;
     if (ub >= u) return;                             // the grid covers the widest job
     const int r0 = blockIdx.y * 32;
     const int n1 = jb.n_x, n2 = jb.n_x2;
     const int K = n1 + n2 + u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
-    // this lane's A row: gate g = r >> 3 of unit ub + 8 w + (r & 7)  ->  TF column g * u + unit
-    const int col = (r >> 3) * u + ub + 8 * w + (r & 7);
+    // every wave of the workgroup: the same 32 A rows = the four gates of units ub .. ub + 7 (row g * 8 + uu <-> TF column g * u + ub + uu);
+    // wave w walks quarter w of K
+    const int col = (r >> 3) * u + ub + (r & 7);
     const float* __restrict__ wp = jb.W + col;
     const size_t ldw = (size_t)4 * u;
     auto w_k = [&](int k) { return wp[(size_t)k * ldw]; };
+    float* part = ds_smem;                           // [4 waves][16 registers][64 lanes]: the quarters' partial sums
+    float* xs = ds_smem + DS_SPLIT * 16 * 64;
     ds_f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -137,65 +148,81 @@ __global__ void __launch_bounds__(256) lstm_step_det_kernel(DetLstmJobs J, int B
         const int kc = (min(DS_KC, K - k0) + 1) & ~1, pitch = kc | 1;
         if (k0 > 0) __syncthreads();
         if (n1 > 0) {
-            if (jb.x_dtype == MNN_U8) ds_stage_seg(reinterpret_cast<const uint8_t*>(jb.x), (size_t)jb.ld_x, (size_t)jb.es_x, n1, 0, B, r0, k0, kc, pitch, ds_smem);
-            else ds_stage_seg(reinterpret_cast<const float*>(jb.x), (size_t)jb.ld_x, (size_t)jb.es_x, n1, 0, B, r0, k0, kc, pitch, ds_smem);
+            if (jb.x_dtype == MNN_U8) ds_stage_seg(reinterpret_cast<const uint8_t*>(jb.x), (size_t)jb.ld_x, (size_t)jb.es_x, n1, 0, B, r0, k0, kc, pitch, xs);
+            else ds_stage_seg(reinterpret_cast<const float*>(jb.x), (size_t)jb.ld_x, (size_t)jb.es_x, n1, 0, B, r0, k0, kc, pitch, xs);
         }
-        if (n2 > 0) ds_stage_seg(jb.x2, (size_t)jb.ld_x2, (size_t)1, n2, n1, B, r0, k0, kc, pitch, ds_smem);
-        if (jb.h_prev != nullptr) ds_stage_seg(jb.h_prev, (size_t)u, (size_t)1, u, n1 + n2, B, r0, k0, kc, pitch, ds_smem);
-        else ds_stage_zero(max(0, n1 + n2 - k0), min(kc, K - k0), pitch, ds_smem);
-        if (K - k0 < kc) ds_stage_zero(K - k0, kc, pitch, ds_smem);          // the pad column of an odd K
+        if (n2 > 0) ds_stage_seg(jb.x2, (size_t)jb.ld_x2, (size_t)1, n2, n1, B, r0, k0, kc, pitch, xs);
+        if (jb.h_prev != nullptr) ds_stage_seg(jb.h_prev, (size_t)u, (size_t)1, u, n1 + n2, B, r0, k0, kc, pitch, xs);
+        else ds_stage_zero(max(0, n1 + n2 - k0), min(kc, K - k0), pitch, xs);
+        if (K - k0 < kc) ds_stage_zero(K - k0, kc, pitch, xs);               // the pad column of an odd K
         __syncthreads();
-        ds_chain_chunk(w_k, k0, kc, K, ds_smem + r * pitch, hh, acc);
+        const int q = ds_quarter(kc), p0 = min(w * q, kc / 2), p1 = min(p0 + q, kc / 2);
+        if (p1 > p0) ds_chain_chunk(w_k, k0 + 2 * p0, 2 * (p1 - p0), K, xs + r * pitch + 2 * p0, hh, acc);
     }
-    // accumulator register e: A row (e & 3) + 8 (e >> 2) + 4 hh = gate (e >> 2), unit offset (e & 3) + 4 hh; C column = batch row r
-    const int row = r0 + r;
-    if (row >= B) return;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int un = ub + 8 * w + 4 * hh + q;
-        const float zi = __fadd_rn(acc[q], jb.bias[un]), zc = __fadd_rn(acc[4 + q], jb.bias[u + un]);
-        const float zf = __fadd_rn(acc[8 + q], jb.bias[2 * u + un]), zo = __fadd_rn(acc[12 + q], jb.bias[3 * u + un]);
-        const float gi = det_sigmoid(zi), gc = det_tanh(zc), gf = det_sigmoid(zf), go = det_sigmoid(zo);
-        const float cp = jb.c_prev != nullptr ? jb.c_prev[(size_t)row * u + un] : 0.f;
-        const float c = __fadd_rn(__fmul_rn(gc, gi), __fmul_rn(cp, gf));
-        jb.c_out[(size_t)row * u + un] = c;
-        jb.h_out[(size_t)row * u + un] = __fmul_rn(det_tanh(c), go);
+    for (int e = 0; e < 16; ++e) part[(w * 16 + e) * 64 + lane] = acc[e];
+    __syncthreads();
+    // pointwise: thread -> (unit ub + (t & 7), row r0 + (t >> 3)); accumulator register of A row i = g * 8 + uu: e = 4 g + (uu & 3), lane half uu >> 2
+    const int uu = threadIdx.x & 7, rr = threadIdx.x >> 3, row = r0 + rr, un = ub + uu;
+    if (row >= B) return;
+    float z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int at = (4 * g + (uu & 3)) * 64 + rr + 32 * (uu >> 2);
+        const float s01 = __fadd_rn(part[at], part[16 * 64 + at]), s23 = __fadd_rn(part[2 * 16 * 64 + at], part[3 * 16 * 64 + at]);
+        z[g] = __fadd_rn(__fadd_rn(s01, s23), jb.bias[g * u + un]);
     }
+    const float gi = det_sigmoid(z[0]), gc = det_tanh(z[1]), gf = det_sigmoid(z[2]), go = det_sigmoid(z[3]);
+    const float cp = jb.c_prev != nullptr ? jb.c_prev[(size_t)row * u + un] : 0.f;
+    const float c = __fadd_rn(__fmul_rn(gc, gi), __fmul_rn(cp, gf));
+    jb.c_out[(size_t)row * u + un] = c;
+    jb.h_out[(size_t)row * u + un] = __fmul_rn(det_tanh(c), go);
 }
 
 __global__ void __launch_bounds__(256) dense_det_kernel(DetDenseJobs J, int B) {
     extern __shared__ __attribute__((aligned(16))) float ds_smem[];
     const mnn_det_dense_job& jb = J.job[blockIdx.z];
-    const int nb = blockIdx.x * 128;
+    const int nb = blockIdx.x * 32;
     if (nb >= jb.N) return;
     const int r0 = blockIdx.y * 32;
     const int K = jb.K;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
-    const int n = min(nb + 32 * w + r, jb.N - 1);    // this lane's A row = output column n
+    const int n = min(nb + r, jb.N - 1);             // this lane's A row = output column n (the same for the four waves: wave w walks quarter w of K)
     const float* __restrict__ wp = jb.W + n;
     const size_t ldw = (size_t)jb.ld_w;
     auto w_k = [&](int k) { return wp[(size_t)k * ldw]; };
+    float* part = ds_smem;
+    float* xs = ds_smem + DS_SPLIT * 16 * 64;
     ds_f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     for (int k0 = 0; k0 < K; k0 += DS_KC) {
         const int kc = (min(DS_KC, K - k0) + 1) & ~1, pitch = kc | 1;
         if (k0 > 0) __syncthreads();
-        ds_stage_seg(jb.x, (size_t)jb.ld_x, (size_t)1, K, 0, B, r0, k0, kc, pitch, ds_smem);
-        if (K - k0 < kc) ds_stage_zero(K - k0, kc, pitch, ds_smem);
+        ds_stage_seg(jb.x, (size_t)jb.ld_x, (size_t)1, K, 0, B, r0, k0, kc, pitch, xs);
+        if (K - k0 < kc) ds_stage_zero(K - k0, kc, pitch, xs);
         __syncthreads();
-        ds_chain_chunk(w_k, k0, kc, K, ds_smem + r * pitch, hh, acc);
+        const int q = ds_quarter(kc), p0 = min(w * q, kc / 2), p1 = min(p0 + q, kc / 2);
+        if (p1 > p0) ds_chain_chunk(w_k, k0 + 2 * p0, 2 * (p1 - p0), K, xs + r * pitch + 2 * p0, hh, acc);
     }
-    const int row = r0 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[(w * 16 + e) * 64 + lane] = acc[e];
+    __syncthreads();
+    // thread -> (column nb + i, row r0 + (t >> 3)), i = (t & 7) + 8 pass: consecutive threads store consecutive columns
+    const int rr = threadIdx.x >> 3, row = r0 + rr;
     if (row >= B) return;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int nn = nb + 32 * w + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        if (nn < jb.N) jb.out[(size_t)row * jb.ld_out + nn] = jb.bias != nullptr ? __fadd_rn(acc[e], jb.bias[nn]) : acc[e];
+    for (int pass = 0; pass < 4; ++pass) {
+        const int i = (threadIdx.x & 7) + 8 * pass, nn = nb + i;
+        if (nn >= jb.N) continue;
+        const int at = ((i & 3) + 4 * (i >> 3)) * 64 + rr + 32 * ((i >> 2) & 1);      // A row i = (e & 3) + 8 (e >> 2) + 4 hh
+        const float s01 = __fadd_rn(part[at], part[16 * 64 + at]), s23 = __fadd_rn(part[2 * 16 * 64 + at], part[3 * 16 * 64 + at]);
+        const float zz = __fadd_rn(s01, s23);
+        jb.out[(size_t)row * jb.ld_out + nn] = jb.bias != nullptr ? __fadd_rn(zz, jb.bias[nn]) : zz;
     }
 }
 
-static size_t ds_lds_bytes(int K) { const int kc = (min(DS_KC, K) + 1) & ~1; return (size_t)32 * (kc | 1) * sizeof(float); }
+static size_t ds_lds_bytes(int K) { const int kc = (min(DS_KC, K) + 1) & ~1; return ((size_t)32 * (kc | 1) + DS_SPLIT * 16 * 64) * sizeof(float); }
 static hipError_t ds_raise_lds() {
     static bool raised = false;
     if (raised) return hipSuccess;
@@ -221,7 +248,7 @@ extern "C" int mnn_lstm_step_det(mnn_stream_t s, int B, int njobs, const mnn_det
         kmax = max(kmax, jb.n_x + jb.n_x2 + jb.units);
     }
     MNN_HIP(ds_raise_lds());
-    dim3 grid(umax / 32, cdiv(B, 32), njobs);
+    dim3 grid(umax / 8, cdiv(B, 32), njobs);
     hipLaunchKernelGGL(lstm_step_det_kernel, grid, dim3(256), ds_lds_bytes(kmax), (hipStream_t)s, J, B);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
@@ -241,7 +268,7 @@ extern "C" int mnn_dense_det(mnn_stream_t s, int B, int njobs, const mnn_det_den
         kmax = max(kmax, jb.K);
     }
     MNN_HIP(ds_raise_lds());
-    dim3 grid(cdiv(nmax, 128), cdiv(B, 32), njobs);
+    dim3 grid(cdiv(nmax, 32), cdiv(B, 32), njobs);
     hipLaunchKernelGGL(dense_det_kernel, grid, dim3(256), ds_lds_bytes(kmax), (hipStream_t)s, J, B);
     MNN_LAUNCH_CHECK();
     return MNN_OK;

@@ -119,28 +119,43 @@ void rbm_gibbs_det(int N, int D, int Hn, int k, const uint8_t* v0, const float* 
  * det_tanh(x) = 2 det_sigmoid(2 x) - 1 (both multiplications by 2 are exact; one rounding in the subtraction). */
 static float det_tanh(float x) { return 2.0f * det_sigmoid(2.0f * x) - 1.0f; }
 
+/* Summation order of the deterministic Dense / LSTM contractions (the specification csrc/det_step.hip implements on the matrix cores): the K
+ * input columns are taken in chunks of 1024; the k-PAIRS (2p, 2p + 1) of a chunk (its column count rounded up to even; a missing last column
+ * counts as input 0) are cut into FOUR contiguous quarters of q = ceil(pairs / 4) pairs; quarter s has its own ascending fmaf chain p_s from
+ * 0, running on over the chunks; the result is ((p_0 + p_1) + (p_2 + p_3)) + bias. */
+#define DET_KC 1024
+static int det_quarter(int k, int K) {
+    const int k0 = (k / DET_KC) * DET_KC;
+    int kc = K - k0 < DET_KC ? K - k0 : DET_KC;
+    kc = (kc + 1) & ~1;
+    const int pairs = kc / 2, q = (pairs + 3) / 4;
+    return ((k - k0) / 2) / q;
+}
+
 /* rnn.py:124 (CudnnCompatibleLSTMCell = LSTMBlockCell, forget_bias 0): xh = [x | h_prev]; z = xh . W + b with W [(n_in + u), 4u], column
- * blocks i | ci | f | o; every z is ONE ascending-k fmaf chain from 0 followed by the bias add.  h_prev / c_prev NULL = zero state. */
+ * blocks i | ci | f | o, summed in the quartered order above.  h_prev / c_prev NULL = zero state. */
 void lstm_step_det(int B, int n_in, int u, const float* x, int ld_x, const float* h_prev, const float* c_prev, const float* W,
                    const float* bias, float* c_out, float* h_out) {
-    float z[4 * 1024];                               /* u <= 1024 */
+    static float z[4][4 * 1024];                     /* u <= 1024 */
+    const int K = n_in + u;
     for (int n = 0; n < B; ++n) {
-        /* the chains of the 4u columns advance together, k ascending (each z[col] is still ONE chain: the loop order only lets the
-         * compiler use vector fma instructions across columns) */
-        for (int col = 0; col < 4 * u; ++col) z[col] = 0.0f;
-        for (int k = 0; k < n_in; ++k) {
-            const float xv = x[(long)n * ld_x + k];
+        /* the chains of the 4u columns advance together, k ascending (each partial sum is still ONE chain per column: the loop order only
+         * lets the compiler use vector fma instructions across columns) */
+        for (int s = 0; s < 4; ++s)
+            for (int col = 0; col < 4 * u; ++col) z[s][col] = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const float xv = k < n_in ? x[(long)n * ld_x + k] : (h_prev ? h_prev[(long)n * u + (k - n_in)] : 0.0f);
             const float* w = W + (long)k * 4 * u;
-            for (int col = 0; col < 4 * u; ++col) z[col] = fmaf(xv, w[col], z[col]);
+            float* zs = z[det_quarter(k, K)];
+            for (int col = 0; col < 4 * u; ++col) zs[col] = fmaf(xv, w[col], zs[col]);
         }
-        for (int k = 0; k < u; ++k) {
-            const float hv = h_prev ? h_prev[(long)n * u + k] : 0.0f;
-            const float* w = W + (long)(n_in + k) * 4 * u;
-            for (int col = 0; col < 4 * u; ++col) z[col] = fmaf(hv, w[col], z[col]);
+        for (int col = 0; col < 4 * u; ++col) {
+            const float s01 = z[0][col] + z[1][col], s23 = z[2][col] + z[3][col];
+            const float t = s01 + s23;
+            z[0][col] = t + bias[col];
         }
-        for (int col = 0; col < 4 * u; ++col) z[col] = z[col] + bias[col];
         for (int j = 0; j < u; ++j) {
-            const float gi = det_sigmoid(z[j]), gc = det_tanh(z[u + j]), gf = det_sigmoid(z[2 * u + j]), go = det_sigmoid(z[3 * u + j]);
+            const float gi = det_sigmoid(z[0][j]), gc = det_tanh(z[0][u + j]), gf = det_sigmoid(z[0][2 * u + j]), go = det_sigmoid(z[0][3 * u + j]);
             const float cp = c_prev ? c_prev[(long)n * u + j] : 0.0f;
             const float t1 = gc * gi, t2 = cp * gf;
             const float c = t1 + t2;
@@ -150,17 +165,23 @@ void lstm_step_det(int B, int n_in, int u, const float* x, int ld_x, const float
     }
 }
 
-/* tf.layers.Dense (rnn_nade.py:54-57, rnn_rbm.py:252-253): out = x . W + b, W [K, N]; ascending-k fmaf chain from 0, then + b. */
+/* tf.layers.Dense (rnn_nade.py:54-57, rnn_rbm.py:252-253): out = x . W + b, W [K, N], summed in the quartered order above. */
 void dense_det(int B, int K, int N, const float* x, int ld_x, const float* W, const float* bias, float* out, int ld_out) {
+    static float z[4][8192];                         /* N <= 8192 */
     for (int n = 0; n < B; ++n) {
         float* o = out + (long)n * ld_out;
-        for (int j = 0; j < N; ++j) o[j] = 0.0f;
+        for (int s = 0; s < 4; ++s)
+            for (int j = 0; j < N; ++j) z[s][j] = 0.0f;
         for (int k = 0; k < K; ++k) {
             const float xv = x[(long)n * ld_x + k];
             const float* w = W + (long)k * N;
-            for (int j = 0; j < N; ++j) o[j] = fmaf(xv, w[j], o[j]);
+            float* zs = z[det_quarter(k, K)];
+            for (int j = 0; j < N; ++j) zs[j] = fmaf(xv, w[j], zs[j]);
         }
-        if (bias)
-            for (int j = 0; j < N; ++j) o[j] = o[j] + bias[j];
+        for (int j = 0; j < N; ++j) {
+            const float s01 = z[0][j] + z[1][j], s23 = z[2][j] + z[3][j];
+            const float t = s01 + s23;
+            o[j] = bias ? t + bias[j] : t;
+        }
     }
 }
