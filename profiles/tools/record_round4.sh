@@ -25,3 +25,12 @@ python3 profiles/sq_counters.py $out/pmc_sq $out/sq_counters.json "$label" $sha 
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 find $out -name "*.db" -delete; find $out -name "*counter_collection.csv" -delete; find $out -name "*kernel_trace.csv" -size +5M -delete
 ls -la $out
+# side configurations and the f32 leg (round 4): bench lines of C3 / C4, the two sampling scans, kernel stats of the fp32 mode
+python3 bench.py --workload c3 > $out/c3_bench.json 2> $out/c3_bench.log
+python3 bench.py --workload c4 > $out/c4_bench.json 2> $out/c4_bench.log
+python3 profiles/tools/bench_generate.py > $out/generate_scan.json 2>&1
+python3 profiles/tools/bench_feedback.py > $out/feedback_scan.json 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats32 -o fp32 -- python3 bench.py --precision fp32 --no-cpu-baseline --no-sampling --no-extras --no-graph --steps 2 --warmup 1 > $out/stats32.log 2>&1
+cp $(find $out/stats32 -name "*kernel_stats.csv" | head -1) $out/fp32_kernel_stats.csv
+find $out -name "*.db" -delete; find $out -name "*kernel_trace.csv" -size +5M -delete
+ls -la $out
