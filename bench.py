@@ -639,8 +639,10 @@ def main(argv=None):
                                 ("mfma-split3" if a.precision == "fp16" else "mfma") if nade_mfma_form else "valu")
     roof["step"]["sigmoid_peak"] = sig
     roof["step"]["rho"] = a.rho
-    ph = roof["step"]["phases"]
-    traffic_step = step_traffic(a.workload, a.precision, ph["lstm_dense"]["bytes"] + ph["nade_scan"]["bytes"])
+    # algorithmic bytes per step as SURVEY.md 8(d) counts them: x u8 | LSTM saved activations (gates + c + h, 16-bit, written + read) | b_enc, b_dec
+    # f32 written + read | conditionals out | weights, gradients, Adam slots  (~6.9 GB at [1024,256,88,5])
+    survey_bytes = N * D + 2.0 * 2 * N * 6 * (R1 + R2) + 2.0 * 4 * N * (HN + D) + 4.0 * N * D + 7 * 4 * N_PARAMS
+    traffic_step = step_traffic(a.workload, a.precision, survey_bytes)
 
     out = {
         "metric": "piano-roll timesteps/sec (train step), 5-track LSTM-NADE", "value": world * B * T / sec,
