@@ -453,7 +453,9 @@ def main(argv=None):
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
         dp_info = {"ranks": dist.get_world_size(), "allreduce_sum_of_ones": float(probe), "backend": dist.get_backend(),
-                   "devices": [int(t) for t in ids], "rccl_ranks": dist.get_world_size() if a.backend == "nccl" else None}
+                   "devices": [int(t) for t in ids], "rccl_ranks": dist.get_world_size() if a.backend == "nccl" else None,
+                   # which entry point issues the step's ONE all-reduce of the flat gradient (multinn_amd/training.py allreduce_flat)
+                   "collective": "mnn_allreduce_flat (C ABI)" if os.environ.get("MULTINN_COMM") == "capi" else "torch.distributed.all_reduce"}
     from multinn_amd import RnnNade, AdamOptimizer, _lib
 
     w = WORKLOADS[a.workload]

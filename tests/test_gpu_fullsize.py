@@ -196,8 +196,11 @@ def test_two_graph_step_replays_at_full_size(monkeypatch):
     assert g.store.step == 8 and int(g.store.step_dev) == 8
 
 
-def test_bench_data_parallel_rehearsal_over_rccl():
-    """bench.py's N>1 code path on this one GPU: torch.distributed.run with ONE rank, backend nccl (= RCCL), and
+@pytest.mark.parametrize("comm", ["torch", "capi"])
+def test_bench_data_parallel_rehearsal_over_rccl(comm):
+    """(comm = capi: the all-reduce between the two graphs goes through the library's own mnn_allreduce_flat -- MULTINN_COMM=capi, a RCCL
+    communicator created through the C ABI, the unique id broadcast as an object -- instead of torch.distributed.all_reduce.)
+    bench.py's N>1 code path on this one GPU: torch.distributed.run with ONE rank, backend nccl (= RCCL), and
     MULTINN_DP_REHEARSAL=1 so that the step takes the two-graph form with the eager all-reduce of the flat gradient between
     them.  With hipMemsetAsync nodes in the graphs this run failed on the second replay (stale 16-byte fill pattern over the
     hand-off flags -> 'persistent LSTM launch timed out'); the library now fills with its own kernels."""
@@ -207,6 +210,8 @@ def test_bench_data_parallel_rehearsal_over_rccl():
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, MULTINN_DP_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if comm == "capi":
+        env["MULTINN_COMM"] = "capi"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
@@ -214,5 +219,6 @@ def test_bench_data_parallel_rehearsal_over_rccl():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["launch"] == "hipgraph-replay" and out["value"] > 0
+    assert out["dp"].get("collective") == ("mnn_allreduce_flat (C ABI)" if comm == "capi" else "torch.distributed.all_reduce")
     smp = out["sampling"]                      # the sampling scan runs on rank 0 after the timed region, process group still up
     assert smp["unit"] == "generated timesteps/s" and smp["value"] > 0 and smp["launch"] == "hipgraph-replay"
