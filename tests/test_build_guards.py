@@ -44,3 +44,33 @@ def test_rowpar_kernels_use_no_scratch_memory(tmp_path):
             assert j >= 0 and "buffer_store_dwordx4" in lines[j], (body[:60], lines[j] if j >= 0 else None)
             checked += 1
     assert checked >= 36, checked
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_matrix_core_chain_kernels_use_no_scratch_and_read_operands_ahead(tmp_path):
+    """The f32 matrix-core chain kernels of round 4 (deterministic LSTM / Dense steps, Gibbs chain, sampling half-steps): no scratch memory
+    (their weight rings and operand batches are register arrays with compile-time indices only), and the MFMAs of the det steps come in
+    runs -- a rolled loop with one LDS read + wait in front of every MFMA (what the compiler makes of the naive form) would show up as
+    single MFMAs separated by `s_waitcnt lgkmcnt(0)`."""
+    from multinn_amd import build
+    for fn, names, min_run in (("det_step.hip", ("lstm_step_det_kernel", "dense_det_kernel"), 8), ("rbm.hip", ("rbm_gibbs_mfma_kernel", "rbm_half_mfma_kernel"), 4)):
+        out = str(tmp_path / (fn + ".s"))
+        subprocess.check_call([HIPCC] + build.FLAGS + ["-S", "--cuda-device-only", os.path.join(build.CSRC, fn), "-o", out], stderr=subprocess.DEVNULL)
+        text = open(out).read()
+        sizes = {m.group(1): int(m.group(2))
+                 for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text)}
+        for nm in names:
+            hit = {k: v for k, v in sizes.items() if nm in k}
+            assert hit and all(v == 0 for v in hit.values()), (nm, hit)
+        for body in re.split(r"\n(?=_Z\w+:)", text):
+            if not any(re.match(r"_Z\w*" + nm, body) for nm in names):
+                continue
+            runs, cur = [], 0
+            for ln in body.split("\n"):
+                if "v_mfma_f32_32x32x2_f32" in ln:
+                    cur += 1
+                elif "s_waitcnt" in ln and "lgkmcnt(0)" in ln and cur:
+                    runs.append(cur)
+                    cur = 0
+            runs.append(cur)
+            assert max(runs) >= min_run, (body[:70], runs[:20])
