@@ -1389,12 +1389,16 @@ class RnnRBM(RnnEstimator):
         pos = torch.empty((N, Hn), device=dev); neg = torch.empty((N, Hn), device=dev)
         ls = self._stack.loss_scale(cx["n_valid"])
         ops.rbm_cd_rows(cx["tgt"], cx["v_s"], sv, ss, cx["rw"], self.grad_scale * ls, d_out, pos, neg)
-        Np = ops.round_up(N, 4)
+        # d cost / d W = v_s^T pos + v^T neg, [D, N] . [N, Hn] with K = N rows.  16-bit modes: the operands in the compute type (v, v_s are 0 / 1:
+        # exact; pos / neg are loss-scaled products of a weight and a sigmoid) on the LDS-DMA GEMM -- as f32 products on v_mfma_f32_32x32x2_f32
+        # (1/16 of the 16-bit rate) the two GEMMs were 0.53 ms per track of the 3.6 ms jamming step (round 4 profile); fp32 mode keeps f32.
+        h16 = self._stack.h16
+        Np = ops.round_up(N, 64 if h16 else 4)
         def tr(xm, rows):
-            o = torch.zeros((rows, Np), device=dev)
+            o = torch.zeros((rows, Np), device=dev, dtype=self.dtype if h16 else torch.float32)
             return ops.transpose(xm, o)
-        # [D, N] . [N, Hn] in f32: two output tiles and K = N rows -- without split-K two workgroups walk the whole batch (6.7 ms of
-        # a 19.6 ms step at N = 32 768); slices of >= 256 rows, up to one workgroup per CU
+        # two output tiles and K = N rows -- without split-K two workgroups walk the whole batch (6.7 ms of a 19.6 ms step at N = 32 768);
+        # slices of >= 256 rows, up to one workgroup per CU
         sk = int(max(1, min(256 // (-(-D // 128) * -(-Hn // 128)), Np // 256)))
         gW = g[f"{self._rbm.prefix}/W"]
         ops.gemm_tn(tr(cx["v_s"], D), tr(pos, Hn), gW, accumulate=True, split_k=sk)

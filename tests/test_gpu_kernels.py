@@ -753,7 +753,9 @@ def test_det_lstm_step_and_dense_bit_exact():
     rng = np.random.default_rng(77)
     jobs, refs = [], []
     B = 13
-    for (n_x, n_x2, u, u8, zero) in [(20, 0, 32, True, True), (440, 0, 512, True, False), (88, 128, 256, True, False), (96, 0, 96, False, False)]:
+    # (the last two: K = 1112 and 1059 > 1024 -- two staging chunks, each quartered on its own; an odd K: a zero pad column)
+    for (n_x, n_x2, u, u8, zero) in [(20, 0, 32, True, True), (440, 0, 512, True, False), (88, 128, 256, True, False), (96, 0, 96, False, False),
+                                     (600, 0, 512, False, False), (900, 31, 128, True, False)]:
         W = (rng.standard_normal((n_x + n_x2 + u, 4 * u)) * 0.2).astype(np.float32)
         b = (rng.standard_normal(4 * u) * 0.1).astype(np.float32)
         x = (rng.random((B, n_x)) < 0.3).astype(np.uint8) if u8 else rng.standard_normal((B, n_x)).astype(np.float32)
@@ -772,11 +774,11 @@ def test_det_lstm_step_and_dense_bit_exact():
             xd[:, :n_x] = dev(x)
         jobs.append(dict(x=xd, n_x=n_x, x2=None if x2 is None else dev(x2), h_prev=None if zero else dev(h0), c_prev=None if zero else dev(c0),
                          W=dev(W), bias=dev(b), c_out=torch.empty((B, u), device=DEV), h_out=torch.empty((B, u), device=DEV)))
-    ops.lstm_step_det(jobs)                                            # four jobs of different widths: ONE launch
+    ops.lstm_step_det(jobs)                                            # six jobs of different widths: ONE launch
     for j, (c_ref, h_ref) in zip(jobs, refs):
         assert np.array_equal(j["c_out"].cpu().numpy(), c_ref) and np.array_equal(j["h_out"].cpu().numpy(), h_ref)
     djobs, drefs = [], []
-    for (K, N, with_bias) in [(256, 696, True), (32, 5, False), (512, 344, True)]:
+    for (K, N, with_bias) in [(256, 696, True), (32, 5, False), (512, 344, True), (1101, 40, True), (7, 33, False)]:
         x = rng.standard_normal((B, K)).astype(np.float32)
         W = (rng.standard_normal((K, N)) * 0.1).astype(np.float32)
         b = rng.standard_normal(N).astype(np.float32) if with_bias else None
