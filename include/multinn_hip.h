@@ -45,9 +45,9 @@ enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_ST
 
 /* ABI version of THIS header: bumped whenever a signature or a descriptor struct changes.  mnn_version() returns the value the library
  * was built with; a loader must compare the two before its first call (multinn_amd/_lib.py load() does) -- a library built for another
- * version reads garbage arguments without any diagnosis otherwise.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
+ * version reads garbage arguments without any diagnosis otherwise.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
  * mnn_pianoroll_shift_timemajor_t / mnn_grad_rows_fanout and the `f16` descriptor fields of round 3 are part of it. */
-#define MNN_ABI_VERSION 110
+#define MNN_ABI_VERSION 111
 int mnn_version(void);
 const char* mnn_last_error(void);
 
@@ -330,7 +330,7 @@ int mnn_rbm_visible(mnn_stream_t s, int N, int D, int Hn, const void* h, int h_d
                     int ld_bv, int stream_id, uint64_t seed, uint32_t row0, uint32_t sub, float* p_v, uint8_t* v,
                     void* workspace);
 int mnn_rbm_free_energy(mnn_stream_t s, int N, int D, int Hn, const uint8_t* v, const float* W, const float* bh, int ld_bh,
-                        const float* bv, int ld_bv, float* F);
+                        const float* bv, int ld_bv, float* F, float* p_h /* optional f32 [N, Hn]: sigmoid(v W + bh), = -dF/dz, for the backward pass */);
 /* CD-k bias deltas (rbm.py:318-327): dbv[d] += scale * sum_n (v - p_v)[n,d], dbh[j] += scale * sum_n (h - p_h)[n,j] (f32 atomics: zero
  * the outputs first).  The weight delta is two mnn_gemm_tn products combined by mnn_axpby_f32, which is also the `assign_add` of
  * rbm.py:329-333: out[i] = a*x[i] + b*y[i] (out may alias x or y; y may be NULL when b == 0).  Under data parallelism the flat

@@ -275,8 +275,8 @@ struct GibbsMfmaArgs {
 static __host__ __device__ __forceinline__ int gm_pitch(int n) { int w = (n + 1 + 3) / 4; return 4 * (w | 1); }
 
 // one output tile (32 units x 32 rows) of a phase: K ascending in pairs; A = W (unit, k) from LDS, B = the rows' byte states
-// EIGHT k-pairs of operands are read from LDS before their eight MFMAs: left to the compiler the loop stays rolled, one LDS read + s_waitcnt
-// lgkmcnt(0) in front of every MFMA -- the 64-cycle MFMA then waits ~64 more cycles for its operand each time (measured on the first version).
+// (Reading the operands of eight k-pairs ahead of their MFMAs -- what the single-wave det-step kernels need -- was measured SLOWER here, 2.78 ->
+// 3.19 ms per jamming step: with two waves per SIMD the other wave's MFMA fills the LDS wait, and the batches cost 60 more registers.)
 template <bool VIS>
 __device__ __forceinline__ void gm_chain(const float* __restrict__ Ws, int ldw, const uint8_t* __restrict__ st, int pitch, int K, int unit,
                                          int lane, gm_f32x16& acc) {
@@ -285,20 +285,7 @@ __device__ __forceinline__ void gm_chain(const float* __restrict__ Ws, int ldw, 
     // hidden phase: A[i = hidden j][k = d] = W[d][j] (walks down a column); visible phase: A[i = visible d][k = j] = W[d][j] (walks a row)
     const float* ap = VIS ? Ws + (size_t)unit * ldw + hh : Ws + (size_t)hh * ldw + unit;
     const int astep = VIS ? 2 : 2 * ldw;
-    const int np = K / 2;
-    for (int s0 = 0; s0 < np; s0 += 8) {
-        float av[8], bv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int sx = min(s0 + j, np - 1);
-            av[j] = ap[(size_t)sx * astep];
-            bv[j] = (float)sp[2 * sx];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (s0 + j < np) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
-    }
+    for (int s = 0; s < K / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(size_t)s * astep], (float)sp[2 * s], acc, 0, 0, 0);
 }
 
 __global__ void __launch_bounds__(512) rbm_gibbs_mfma_kernel(GibbsMfmaArgs A) {
@@ -375,23 +362,10 @@ __global__ void __launch_bounds__(512) rbm_gibbs_mfma_kernel(GibbsMfmaArgs A) {
             const float* a0 = Ws + (size_t)hh * ldw + u0;
             const float* a1 = Ws + (size_t)hh * ldw + u1;
             const bool two = jt0 + 1 < nht;
-            const int np = De / 2;
-            for (int s0 = 0; s0 < np; s0 += 8) {              // the two unit tiles share the state operand; operands of 8 k-pairs first (see gm_chain)
-                float av0[8], av1[8], bv[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int sx = min(s0 + j, np - 1);
-                    av0[j] = a0[(size_t)sx * 2 * ldw];
-                    av1[j] = a1[(size_t)sx * 2 * ldw];
-                    bv[j] = (float)sp[2 * sx];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (s0 + j < np) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv[j], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv[j], acc[1], 0, 0, 0);      // (a lone last tile repeats column Hn - 1: discarded)
-                    }
+            for (int s = 0; s < De / 2; ++s) {                // the two unit tiles share the state operand
+                const float b = (float)sp[2 * s];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[(size_t)s * 2 * ldw], b, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[(size_t)s * 2 * ldw], b, acc[1], 0, 0, 0);      // (a lone last tile repeats column Hn - 1: discarded)
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -576,19 +550,7 @@ rbm_half_mfma_kernel(int N, int K, int n_out, const TV* __restrict__ in, const f
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
             const float* ap = Ws + (size_t)hh * lw + min(32 * ot + r, n_out - 1);
             const float* bp = xs + (32 * rt + r) * pin + hh;
-            for (int s0 = 0; s0 < Ke / 2; s0 += 8) {          // operands of 8 k-pairs first, then their MFMAs (see gm_chain)
-                float av[8], bv[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int sx = min(s0 + j, Ke / 2 - 1);
-                    av[j] = ap[(size_t)sx * 2 * lw];
-                    bv[j] = bp[2 * sx];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (s0 + j < Ke / 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
-            }
+            for (int s2 = 0; s2 < Ke / 2; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(size_t)s2 * 2 * lw], bp[2 * s2], acc, 0, 0, 0);
             const int row = n0 + 32 * rt + r;
             if (row >= N) continue;
 #pragma unroll
@@ -676,7 +638,7 @@ __device__ __forceinline__ float softplus_f(float z) { return fmaxf(z, 0.f) + lo
 
 __global__ void __launch_bounds__(256)
 rbm_free_energy_kernel(int N, int D, int Hn, const uint8_t* __restrict__ v, const float* __restrict__ W, const float* __restrict__ bh, int ld_bh,
-                       const float* __restrict__ bv, int ld_bv, float* __restrict__ F) {
+                       const float* __restrict__ bv, int ld_bv, float* __restrict__ F, float* __restrict__ p_h) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float fsum[RBM_R];
     const int Dp = (D + 3) & ~3;
@@ -689,7 +651,12 @@ rbm_free_energy_kernel(int N, int D, int Hn, const uint8_t* __restrict__ v, cons
     for (int r = 0; r < RBM_R; ++r) part[r] = 0.f;
     rbm_phase(smem, Dp, D, W, Hn, Hn, bh, ld_bh, n0, N, [&](int r, int j, float z) {
         const int n = n0 + r;
-        if (n < N) part[r] -= softplus_f(z);
+        if (n < N) {
+            part[r] -= softplus_f(z);
+            // d F / d z = -sigmoid(z): the backward pass's hidden activations, from the pre-activation this pass has anyway (the same
+            // det_sigmoid as mnn_rbm_hidden, so the gradient keeps its bits; saves that pass re-reading v and W and re-forming z)
+            if (p_h != nullptr) p_h[(size_t)n * Hn + j] = det_sigmoid(z);
+        }
     });
     for (int d = threadIdx.x; d < D; d += blockDim.x)
 #pragma unroll
@@ -709,11 +676,11 @@ rbm_free_energy_kernel(int N, int D, int Hn, const uint8_t* __restrict__ v, cons
 }
 
 extern "C" int mnn_rbm_free_energy(mnn_stream_t s, int N, int D, int Hn, const uint8_t* v, const float* W, const float* bh, int ld_bh,
-                                   const float* bv, int ld_bv, float* F) {
+                                   const float* bv, int ld_bv, float* F, float* p_h) {
     MNN_REQUIRE(N > 0 && D > 0 && Hn > 0 && v && W && bh && bv && F, "mnn_rbm_free_energy: bad arguments");
     MNN_REQUIRE((ld_bh == 0 || ld_bh >= Hn) && (ld_bv == 0 || ld_bv >= D), "mnn_rbm_free_energy: bad bias leading dimension");
     const size_t lds = (size_t)RBM_R * ((D + 3) & ~3) * sizeof(float);
-    hipLaunchKernelGGL(rbm_free_energy_kernel, dim3(cdiv(N, RBM_R)), dim3(256), lds, (hipStream_t)s, N, D, Hn, v, W, bh, ld_bh, bv, ld_bv, F);
+    hipLaunchKernelGGL(rbm_free_energy_kernel, dim3(cdiv(N, RBM_R)), dim3(256), lds, (hipStream_t)s, N, D, Hn, v, W, bh, ld_bh, bv, ld_bv, F, p_h);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

@@ -1341,13 +1341,16 @@ class RnnRBM(RnnEstimator):
             else:
                 bh_u, bv_u = self._rbm.bh, self._rbm.bv
             Fv = torch.empty(N, device=dev); Fs = torch.empty(N, device=dev)
-            ops.rbm_free_energy(tgt, self._rbm.W, bh_u, bv_u, Fv)
-            ops.rbm_free_energy(v_s, self._rbm.W, bh_u, bv_u, Fs)
+            # train mode: the same pass leaves sigmoid(z) of both chains' ends, the hidden activations of the free-energy gradient (backward)
+            sv = torch.empty((N, Hn), device=dev) if mode == "train" else None
+            ss = torch.empty((N, Hn), device=dev) if mode == "train" else None
+            ops.rbm_free_energy(tgt, self._rbm.W, bh_u, bv_u, Fv, p_h=sv)
+            ops.rbm_free_energy(v_s, self._rbm.W, bh_u, bv_u, Fs, p_h=ss)
             cost = Fv - Fs
             loss = torch.zeros(1, device=dev)
             ops.weighted_sum(cost, rw, loss)
             self._ctx = dict(y=yy, lstm=ctx, out=out, tgt=tgt, v_s=v_s, rw=rw, kp=kp, seed=seed, B=B, T=T, bh_u=bh_u, bv_u=bv_u,
-                             n_valid=self._n_valid)
+                             n_valid=self._n_valid, sv=sv, ss=ss)
             self._cost_tm, self._F_tm, self._pv_tm, self._vs_tm, self._loss = cost, Fv, p_v, v_s, loss
             self._lengths, self._flat_idx = lengths, None
             self._recon_tm = torch.empty(N, device=dev)
@@ -1380,9 +1383,9 @@ class RnnRBM(RnnEstimator):
         N, dev = B * T, cx["out"].device
         g = self.store.gviews
         self.store.grad.zero_()
-        sv = torch.empty((N, Hn), device=dev); ss = torch.empty((N, Hn), device=dev)
-        ops.rbm_hidden(cx["tgt"], self._rbm.W, cx["bh_u"], 0, 0, 0, 0, sv, None)
-        ops.rbm_hidden(cx["v_s"], self._rbm.W, cx["bh_u"], 0, 0, 0, 0, ss, None)
+        sv, ss = cx.get("sv"), cx.get("ss")           # sigmoid(z(v)), sigmoid(z(v_s)): left by the forward's free-energy passes
+        if sv is None:
+            raise RuntimeError("build(..., mode='train') must run before train()")
         # dF/dbh = -sigmoid(z), dF/dbv = -v, dF/dW = -v^T sigmoid(z); cost = F(v) - F(v_s), v_s constant (rbm.py:229).  One pass writes the
         # Dense-output-shaped gradient block and the two scaled hidden blocks of d cost / d W = v_s^T (w ss) - v^T (w sv)
         d_out = torch.empty((N, self.ldo), device=dev)

@@ -589,13 +589,15 @@ def rbm_visible(h, W, bv, stream_id, seed, row0, sub, p_v=None, v=None):
          int(sub), _ptr(p_v), _ptr(v), _ptr(ws))
 
 
-def rbm_free_energy(v, W, bh, bv, F):
+def rbm_free_energy(v, W, bh, bv, F, p_h=None):
+    """p_h (optional, f32 [N, Hn]): also receives sigmoid(v W + bh) -- the hidden activations the free-energy gradient needs."""
     N, D = v.shape
     Hn = W.shape[1]
+    _req(p_h is None or (p_h.dtype == torch.float32 and p_h.is_contiguous() and tuple(p_h.shape) == (N, Hn)), "free_energy: p_h f32 [N, Hn]")
     _req(v.dtype == torch.uint8 and v.is_contiguous() and W.shape == (D, Hn) and W.is_contiguous(), "free_energy: shapes")
     _req(F.dtype == torch.float32 and F.numel() == N, "free_energy: F f32 [N]")
     _req(bh.shape[0] in (1, N) and bv.shape[0] in (1, N), "free_energy: bias rows")
-    call("mnn_rbm_free_energy", _stream(), N, D, Hn, _ptr(v), _ptr(W), _ptr(bh), _ldb(bh, Hn), _ptr(bv), _ldb(bv, D), _ptr(F))
+    call("mnn_rbm_free_energy", _stream(), N, D, Hn, _ptr(v), _ptr(W), _ptr(bh), _ldb(bh, Hn), _ptr(bv), _ldb(bv, D), _ptr(F), _ptr(p_h))
     return F
 
 

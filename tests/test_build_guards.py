@@ -49,11 +49,11 @@ def test_rowpar_kernels_use_no_scratch_memory(tmp_path):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_matrix_core_chain_kernels_use_no_scratch_and_read_operands_ahead(tmp_path):
     """The f32 matrix-core chain kernels of round 4 (deterministic LSTM / Dense steps, Gibbs chain, sampling half-steps): no scratch memory
-    (their weight rings and operand batches are register arrays with compile-time indices only), and the MFMAs of the det steps come in
-    runs -- a rolled loop with one LDS read + wait in front of every MFMA (what the compiler makes of the naive form) would show up as
-    single MFMAs separated by `s_waitcnt lgkmcnt(0)`."""
+    (their weight rings and operand batches are register arrays with compile-time indices only), and the MFMAs of the det steps (one wave
+    per SIMD: nothing else hides an LDS wait) come in runs -- a rolled loop with one LDS read + wait in front of every MFMA would show up as
+    single MFMAs separated by `s_waitcnt lgkmcnt(0)`.  (The Gibbs / half-step kernels run two waves per SIMD and keep the rolled loop: measured.)"""
     from multinn_amd import build
-    for fn, names, min_run in (("det_step.hip", ("lstm_step_det_kernel", "dense_det_kernel"), 8), ("rbm.hip", ("rbm_gibbs_mfma_kernel", "rbm_half_mfma_kernel"), 4)):
+    for fn, names, min_run in (("det_step.hip", ("lstm_step_det_kernel", "dense_det_kernel"), 8), ("rbm.hip", ("rbm_gibbs_mfma_kernel", "rbm_half_mfma_kernel"), 1)):
         out = str(tmp_path / (fn + ".s"))
         subprocess.check_call([HIPCC] + build.FLAGS + ["-S", "--cuda-device-only", os.path.join(build.CSRC, fn), "-o", out], stderr=subprocess.DEVNULL)
         text = open(out).read()
