@@ -519,6 +519,8 @@ rbm_half_mfma_kernel(int N, int K, int n_out, const TV* __restrict__ in, const f
     const int Ke = (K + 1) & ~1, lw = n_out | 1, pin = Ke | 1;
     float* Ws = smem;                       // [Ke][lw]
     float* xs = smem + (size_t)Ke * lw;     // [64][pin]
+    float* tile_p = xs + (size_t)GM_ROWS * pin;                                   // [8 waves][32][33] f32: a job's probabilities, [row][unit]
+    uint8_t* tile_s = reinterpret_cast<uint8_t*>(tile_p + 8 * 32 * 33);           // [8 waves][32][36] u8: its draws
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int k = w; k < Ke; k += 8)
         for (int o = lane; o < lw; o += 64) Ws[k * lw + o] = o < n_out ? Wk[(size_t)min(k, K - 1) * ldw + o] : 0.f;
@@ -551,21 +553,32 @@ rbm_half_mfma_kernel(int N, int K, int n_out, const TV* __restrict__ in, const f
             const float* ap = Ws + (size_t)hh * lw + min(32 * ot + r, n_out - 1);
             const float* bp = xs + (32 * rt + r) * pin + hh;
             for (int s2 = 0; s2 < Ke / 2; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(size_t)s2 * 2 * lw], bp[2 * s2], acc, 0, 0, 0);
-            const int row = n0 + 32 * rt + r;
-            if (row >= N) continue;
+            const int row = min(n0 + 32 * rt + r, N - 1);       // (rows past N repeat the last row; masked at the stores)
+            // results through a wave-private LDS tile [row][unit], then out row-major: a lane holds four units of ONE row, so direct stores
+            // would be 64 scattered 4-byte (and 1-byte) writes per instruction; from the tile every instruction writes two rows' 128-byte runs
+            float* tp = tile_p + w * (32 * 33);
+            uint8_t* ts = tile_s + w * (32 * 36);
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int o0 = 32 * ot + 8 * g4 + 4 * hh;
-                if (o0 >= n_out) continue;
                 float u[4] = {0.f, 0.f, 0.f, 0.f};
                 if (s_out) philox_uniform4(seed, (uint32_t)stream_id, row0 + (uint32_t)row, sub, (uint32_t)(o0 >> 2), u);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int o = o0 + e;
-                    if (o >= n_out) continue;
+                    const int o = min(o0 + e, n_out - 1);
                     const float p = det_sigmoid(acc[4 * g4 + e] + b[(size_t)row * ld_b + o]);
-                    if (p_out) p_out[(size_t)row * n_out + o] = p;
-                    if (s_out) s_out[(size_t)row * n_out + o] = u[e] < p ? 1 : 0;
+                    tp[r * 33 + 8 * g4 + 4 * hh + e] = p;
+                    ts[r * 36 + 8 * g4 + 4 * hh + e] = u[e] < p ? 1 : 0;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's own LDS writes, then its reads (LDS serves a wave in order)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int idx = i * 64 + lane, rr = idx >> 5, cc = idx & 31;
+                const int row2 = n0 + 32 * rt + rr, o = 32 * ot + cc;
+                if (row2 < N && o < n_out) {
+                    if (p_out) p_out[(size_t)row2 * n_out + o] = tp[rr * 33 + cc];
+                    if (s_out) s_out[(size_t)row2 * n_out + o] = ts[rr * 36 + cc];
                 }
             }
         }
@@ -573,7 +586,7 @@ rbm_half_mfma_kernel(int N, int K, int n_out, const TV* __restrict__ in, const f
 }
 static size_t half_mfma_lds_bytes(int K, int n_out) {
     const int Ke = (K + 1) & ~1;
-    return ((size_t)Ke * (n_out | 1) + (size_t)GM_ROWS * (Ke | 1)) * sizeof(float);
+    return ((size_t)Ke * (n_out | 1) + (size_t)GM_ROWS * (Ke | 1) + 8 * 32 * 33) * sizeof(float) + 8 * 32 * 36;
 }
 
 static int launch_half(hipStream_t st, int N, int K, int n_out, const void* in, int in_dtype, const float* Wk, int ldw, const float* b,
