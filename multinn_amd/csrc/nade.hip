@@ -575,25 +575,6 @@ __device__ __forceinline__ bool draw_below(float u, float x) {          // u < d
     if (__builtin_amdgcn_ballot_w64(fabsf(d) > 1e-4f * r + 1e-30f) != 0ull) return __builtin_amdgcn_ballot_w64(d < 0.f) != 0ull;
     return __builtin_amdgcn_ballot_w64(u < det_sigmoid(x)) != 0ull;
 }
-// Round 4: the same decision with NO transcendental on the serial chain.  u < det_sigmoid(x) is certain when x lies outside the logit
-// interval of u widened by a probability margin: with u_hi = u (1 + 1e-4) + 3e-7 and u_lo = u (1 - 1e-4) - 3e-7 (det_sigmoid is within 2e-7 of the
-// true sigmoid),  x > logit(u_hi)  =>  sigmoid(x) > u_hi  =>  det_sigmoid(x) > u  (draw 1),  x < logit(u_lo)  =>  draw 0; anything between takes the
-// exact comparison.  The two bounds depend on the uniform only, so they are evaluated where the uniforms are (64 Philox blocks at a time, off
-// the chain) with the hardware log2, and widened by its error (1e-4 + 1e-5 |bound| covers it: u sits on the 2^-23 grid, |log2| <= 24); the chain
-// keeps one add and two compares per visible instead of mul, exp2, add, rcp, sub, compare (~250 -> ~190 cycles per conditional at D = 440).
-__device__ __forceinline__ float logit_approx(float x) { return 0.6931471805599453f * (__builtin_amdgcn_logf(x) - __builtin_amdgcn_logf(1.0f - x)); }
-__device__ __forceinline__ void draw_bounds(float u, float& lo, float& hi) {
-    const float uh = fmaf(u, 1e-4f, u) + 3e-7f, ul = fmaf(u, -1e-4f, u) - 3e-7f;
-    hi = uh < 1.0f ? logit_approx(uh) : __builtin_inff();
-    lo = ul > 0.0f ? logit_approx(ul) : -__builtin_inff();
-    hi += 1e-4f + 1e-5f * fabsf(hi);                                   // (inf stays inf)
-    lo -= 1e-4f + 1e-5f * fabsf(lo);
-}
-__device__ __forceinline__ bool draw_below_bounds(float u, float lo, float hi, float x) {       // u < det_sigmoid(x); wave-uniform operands
-    if (__builtin_amdgcn_ballot_w64(x > hi) != 0ull) return true;
-    if (__builtin_amdgcn_ballot_w64(x < lo) != 0ull) return false;
-    return __builtin_amdgcn_ballot_w64(u < det_sigmoid(x)) != 0ull;
-}
 __device__ __forceinline__ bool prob_at_least_half(float x) {           // det_sigmoid(x) >= 0.5f
     const float d = sig_approx(x) - 0.5f;
     if (__builtin_amdgcn_ballot_w64(fabsf(d) > 1e-4f) != 0ull) return __builtin_amdgcn_ballot_w64(d > 0.f) != 0ull;
@@ -629,7 +610,7 @@ nade_sample_kernel(SampleJobs J, int N, int D, int Hn, float temperature, uint32
     float* sp = reinterpret_cast<float*>(nade_sample_smem) + (size_t)wv * Dp;
     float* sbd = reinterpret_cast<float*>(nade_sample_smem) + (size_t)(4 + wv) * Dp;
     unsigned char* son = nade_sample_smem + (size_t)32 * Dp + (size_t)wv * Dp;
-    float* su = reinterpret_cast<float*>(nade_sample_smem + (size_t)36 * Dp) + wv * 768;    // uniforms of Philox blocks b0 .. b0 + 63 | their lower | upper logit bounds
+    float* su = reinterpret_cast<float*>(nade_sample_smem + (size_t)36 * Dp) + wv * 256;    // uniforms of Philox blocks b0 .. b0 + 63
     const float* __restrict__ we = jb.w_enc;
     const float* __restrict__ wd = jb.w_dec;
     const float* __restrict__ bd = bias + (size_t)row * ld_bias + jb.dec_off;
@@ -666,11 +647,6 @@ nade_sample_kernel(SampleJobs J, int N, int D, int Hn, float temperature, uint32
         float u4[4];
         philox_uniform4(seed, MNN_STREAM_NADE, row0 + (uint32_t)row, sub, b0 + (uint32_t)lane, u4);
         *reinterpret_cast<float4*>(su + 4 * lane) = make_float4(u4[0], u4[1], u4[2], u4[3]);
-        float lo4[4], hi4[4];                               // the uniforms' decision bounds in logit space (draw_bounds): off the serial chain
-#pragma unroll
-        for (int e = 0; e < 4; ++e) draw_bounds(u4[e], lo4[e], hi4[e]);
-        *reinterpret_cast<float4*>(su + 256 + 4 * lane) = make_float4(lo4[0], lo4[1], lo4[2], lo4[3]);
-        *reinterpret_cast<float4*>(su + 512 + 4 * lane) = make_float4(hi4[0], hi4[1], hi4[2], hi4[3]);
     };
     if (TMODE != 0) refill();
     auto dot = [&](int k) {                                 // sum_j h_j w_dec[visible of ring slot k][j], the contract's order
@@ -679,7 +655,6 @@ nade_sample_kernel(SampleJobs J, int N, int D, int Hn, float temperature, uint32
         for (int q = 0; q < 4; ++q) acc = fmaf(h[q], in[q] ? wdr[k][q] : 0.f, acc);
         return wave_xor_sum(acc);
     };
-    float lo_cur = 0.f, hi_cur = 0.f;                       // decision bounds of the current uniform (set by uniform_of)
     // the uniform of visible i, fetched one visible ahead (with the rare Philox refill) so that the block below -- speculative dot
     // product next to the draw -- stays one straight line the scheduler can interleave
     auto uniform_of = [&](int i) {
@@ -688,10 +663,7 @@ nade_sample_kernel(SampleJobs J, int N, int D, int Hn, float temperature, uint32
             b0 += 64u;
             refill();
         }
-        const uint32_t at = e - 4u * b0;
-        lo_cur = su[256 + at];
-        hi_cur = su[512 + at];
-        return su[at];
+        return su[e - 4u * b0];
     };
     float u_cur = TMODE != 0 ? uniform_of(0) : 0.f;
     float acc = dot(0);
@@ -706,7 +678,7 @@ nade_sample_kernel(SampleJobs J, int N, int D, int Hn, float temperature, uint32
                 const float l = sbd[i] + acc;
                 bool on;
                 if (TMODE != 0) {
-                    on = draw_below_bounds(u_cur, lo_cur, hi_cur, TMODE == 1 ? l : l / temperature);
+                    on = draw_below(u_cur, TMODE == 1 ? l : l / temperature);
                 } else {
                     on = prob_at_least_half(l);              // nade.py:278-279
                 }
@@ -746,7 +718,7 @@ nade_sample_kernel(SampleJobs J, int N, int D, int Hn, float temperature, uint32
 static int launch_sample(hipStream_t st, const SampleJobs& J, int njobs, int N, int D, int Hn, float temperature, uint32_t row0, uint32_t sub,
                          long s_row_stride, int s_elem_stride) {
     dim3 grid(cdiv(N, 4), njobs);
-    const size_t lds = (size_t)36 * ((D + 3) & ~3) + 3 * 4096;   // 4 waves x ((2 f32 + u8) per visible + 256 uniforms and their two bounds)
+    const size_t lds = (size_t)36 * ((D + 3) & ~3) + 4096;   // 4 waves x ((2 f32 + u8) per visible + 256 uniforms)
     const int tmode = temperature > 0.f ? (temperature == 1.0f ? 1 : 2) : 0;
 #define SMP(TM, FU, SP) hipLaunchKernelGGL((nade_sample_kernel<TM, FU, SP>), grid, dim3(256), lds, st, J, N, D, Hn, temperature, row0, sub, s_row_stride, s_elem_stride)
     if (Hn == 256 && tmode == 1) { if (getenv("MNN_SAMPLE_NO_SPEC")) SMP(1, true, false); else SMP(1, true, true); }
