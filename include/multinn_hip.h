@@ -13,11 +13,9 @@
  * Each entry cites the reference interface it replaces as file:line under
  * /root/reference/multinn (ilya16/MultINN).
  *
- * One entry of SURVEY.md 8(b)'s proposed symbol list is deliberately NOT exported:
- *   - mnn_generate_scan (rnn_estimator.py:271-323, multinn_feedback.py:120-218): the sampling scan is the sequence
- *     {mnn_nade_sample | mnn_rbm_gibbs, mnn_lstm2_seq_fwd / mnn_lstm_seq_fwd, mnn_gemm_tn} per generated step, captured ONCE
- *     into a hipGraph by the host (multinn_amd/common.py ScanGraphs) and replayed -- every step's RNG counter is a kernel
- *     argument baked into its node, so one replay is one whole scan; a dedicated symbol would only repeat that loop in C.
+ * SURVEY.md 8(b)'s proposed symbol list is exported in full since round 4: mnn_generate_scan runs the whole sampling scan of a generator in one
+ * call (the Python mirror captures that call -- or, for the feedback modes, the grouped single-step calls -- into ONE hipGraph per shape:
+ * multinn_amd/common.py ScanGraphs).
  * (mnn_comm_init / mnn_allreduce_flat / mnn_comm_destroy ARE exported since round 4 -- see "Data-parallel exchange" below; the Python mirror
  *  still issues its all-reduce through torch.distributed by default, backend "nccl" = the same RCCL.)
  */
@@ -45,9 +43,9 @@ enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_ST
 
 /* ABI version of THIS header: bumped whenever a signature or a descriptor struct changes.  mnn_version() returns the value the library
  * was built with; a loader must compare the two before its first call (multinn_amd/_lib.py load() does) -- a library built for another
- * version reads garbage arguments without any diagnosis otherwise.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
+ * version reads garbage arguments without any diagnosis otherwise.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
  * mnn_pianoroll_shift_timemajor_t / mnn_grad_rows_fanout and the `f16` descriptor fields of round 3 are part of it. */
-#define MNN_ABI_VERSION 111
+#define MNN_ABI_VERSION 112
 int mnn_version(void);
 const char* mnn_last_error(void);
 
@@ -425,6 +423,21 @@ typedef struct {
 } mnn_det_dense_job;
 int mnn_lstm_step_det(mnn_stream_t s, int B, int njobs, const mnn_det_lstm_job* jobs);
 int mnn_dense_det(mnn_stream_t s, int B, int njobs, const mnn_det_dense_job* jobs);
+
+/* mnn_generate_scan (rnn_estimator.py:271-323 `generate`): the WHOLE sampling scan of an LSTM-NADE / LSTM-MultiNADE generator in
+ * one call -- the intro pass (n_intro deterministic LSTM steps from a zero state over intro u8 [B, n_intro, n_in], Dense on the last output),
+ * then num_steps x { mnn_nade_sample with Philox sub-counter = generated step -> LSTM step on the sample -> Dense } -- enqueued on stream s from
+ * one host loop (nothing synchronised: capturable into a hipGraph).  layers: HOST array of the stack's master weights (TF layout); Dense W
+ * [units_last, n_out], n_out = tracks * (Hn + D) (b_enc blocks, then b_dec blocks); n_in = tracks * D (a sample is the next input).
+ * samples u8 [B, num_steps, tracks * D] (feature m D + i for one NADE, i tracks + m for several: rnn_multinade.py:313-314).  Same bits as the
+ * single-step entry points; workspace: mnn_generate_scan_workspace_bytes(), 256-byte aligned, caller-owned. */
+#define MNN_SCAN_MAX_LAYERS 8
+typedef struct { const float* W; const float* bias; int units; } mnn_scan_lstm_layer;
+size_t mnn_generate_scan_workspace_bytes(int B, int n_layers, const mnn_scan_lstm_layer* layers, int n_out);
+int mnn_generate_scan(mnn_stream_t s, int B, int n_intro, int num_steps, const uint8_t* intro, int n_in, int n_layers,
+                      const mnn_scan_lstm_layer* layers, const float* dense_W, const float* dense_bias, int n_out, int tracks, int D, int Hn,
+                      const float* w_enc, const float* w_dec, float temperature, uint64_t seed, uint32_t row0, uint8_t* samples,
+                      void* workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * Data-parallel exchange (the gradients of utils/training.py:151-177 as ONE flat f32 buffer): RCCL over xGMI, one

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MULTINN_HIP_LIB", os.path.join(HERE, "libmultinn_hip.so"))   # override: A/B builds of the same ABI
 
-ABI_VERSION = 111          # == MNN_ABI_VERSION of include/multinn_hip.h; load() refuses a library built for another one
+ABI_VERSION = 112          # == MNN_ABI_VERSION of include/multinn_hip.h; load() refuses a library built for another one
 F32, BF16, U8, F16 = 0, 1, 2, 3
 GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_A_KBLOCK32 = 1, 2, 8
 
@@ -54,6 +54,8 @@ SIGNATURES = {
     "mnn_lstm_step_det": (_i, [_p, _i, _i, _p]),
     "mnn_dense_det": (_i, [_p, _i, _i, _p]),
     "mnn_nade_sample_multi": (_i, [_p, _i, _p, _i, _i, _i, _f, _u32, _u32, _l, _i]),
+    "mnn_generate_scan_workspace_bytes": (_sz, [_i, _i, _p, _i]),
+    "mnn_generate_scan": (_i, [_p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _u64, _u32, _p, _p, _sz]),
     "mnn_comm_unique_id": (_i, [_p]),
     "mnn_comm_init": (_i, [C.POINTER(_p), _i, _i, _p]),
     "mnn_allreduce_flat": (_i, [_p, _p, _p, _l]),
@@ -69,6 +71,11 @@ class DetLstmJob(C.Structure):
 class NadeSampleJob(C.Structure):
     """mnn_nade_sample_job (include/multinn_hip.h)."""
     _fields_ = [("bias", _p), ("ld_bias", _i), ("w_enc", _p), ("w_dec", _p), ("seed", _u64), ("samples", _p), ("nll", _p)]
+
+
+class ScanLstmLayer(C.Structure):
+    """mnn_scan_lstm_layer (include/multinn_hip.h)."""
+    _fields_ = [("W", _p), ("bias", _p), ("units", _i)]
 
 
 class DetDenseJob(C.Structure):

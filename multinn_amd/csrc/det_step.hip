@@ -273,3 +273,92 @@ extern "C" int mnn_dense_det(mnn_stream_t s, int B, int njobs, const mnn_det_den
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The whole sampling scan of an LSTM-NADE generator as ONE call (rnn_estimator.py:271-323 `generate` / `_generate_recurrence`;
+// rnn_nade.py:253-277, 304-318; SURVEY.md 8(b) mnn_generate_scan): intro pass -- n_intro deterministic steps of the LSTM stack from a zero
+// state, Dense on the last output -- then num_steps x { NADE sample (mnn_nade_sample, Philox sub-counter = the generated step) -> LSTM step on
+// the sample -> Dense }.  Everything is enqueued on the caller's stream from this one host loop (4 launches per generated step for a
+// two-layer stack; nothing is synchronised), so the call is capturable into a hipGraph like any other entry point; states ping-pong in the
+// caller's workspace.  Bits: exactly those of the single-step entry points above (oracle/det.py rnn_nade_generate restates the scan).
+// ------------------------------------------------------------------------------------------------------------------------------------
+static size_t scan_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t mnn_generate_scan_workspace_bytes(int B, int n_layers, const mnn_scan_lstm_layer* layers, int n_out) {
+    if (B <= 0 || n_layers <= 0 || n_layers > MNN_SCAN_MAX_LAYERS || layers == nullptr || n_out <= 0) return 0;
+    size_t bytes = scan_align((size_t)B * (size_t)((n_out + 63) & ~63) * sizeof(float));
+    for (int l = 0; l < n_layers; ++l) bytes += 4 * scan_align((size_t)B * (size_t)layers[l].units * sizeof(float));      // c, h x two generations
+    return bytes;
+}
+
+extern "C" int mnn_generate_scan(mnn_stream_t s, int B, int n_intro, int num_steps, const uint8_t* intro, int n_in, int n_layers,
+                                 const mnn_scan_lstm_layer* layers, const float* dense_W, const float* dense_bias, int n_out, int tracks, int D,
+                                 int Hn, const float* w_enc, const float* w_dec, float temperature, uint64_t seed, uint32_t row0,
+                                 uint8_t* samples, void* workspace, size_t workspace_bytes) {
+    MNN_REQUIRE(B > 0 && n_intro > 0 && num_steps >= 0 && intro && n_in > 0 && n_layers > 0 && n_layers <= MNN_SCAN_MAX_LAYERS && layers,
+                "mnn_generate_scan: B, n_intro > 0, 1..%d layers", MNN_SCAN_MAX_LAYERS);
+    MNN_REQUIRE(dense_W && tracks > 0 && D > 0 && Hn > 0 && n_out == tracks * (Hn + D) && n_in == tracks * D && w_enc && w_dec && samples,
+                "mnn_generate_scan: the Dense layer feeds `tracks` NADEs (n_out == tracks * (Hn + D)) and a sample is the next input (n_in == tracks * D)");
+    const size_t need = mnn_generate_scan_workspace_bytes(B, n_layers, layers, n_out);
+    MNN_REQUIRE(workspace && need > 0 && workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0,
+                "mnn_generate_scan: workspace of mnn_generate_scan_workspace_bytes() bytes, 256-byte aligned");
+    char* wp = static_cast<char*>(workspace);
+    const int ld_out = (n_out + 63) & ~63;
+    float* out = reinterpret_cast<float*>(wp);
+    wp += scan_align((size_t)B * ld_out * sizeof(float));
+    float* cbuf[MNN_SCAN_MAX_LAYERS][2];
+    float* hbuf[MNN_SCAN_MAX_LAYERS][2];
+    for (int l = 0; l < n_layers; ++l) {
+        MNN_REQUIRE(layers[l].units > 0 && layers[l].units % 32 == 0 && layers[l].W && layers[l].bias, "mnn_generate_scan: layer %d", l);
+        for (int g = 0; g < 2; ++g) {
+            cbuf[l][g] = reinterpret_cast<float*>(wp); wp += scan_align((size_t)B * layers[l].units * sizeof(float));
+            hbuf[l][g] = reinterpret_cast<float*>(wp); wp += scan_align((size_t)B * layers[l].units * sizeof(float));
+        }
+    }
+    int cur = 0;                                               // generation holding the current state; -1 before the first step (zero state)
+    bool have_state = false;
+    auto stack_step = [&](const uint8_t* x, int ld_x) -> int {      // one step of the whole stack on a u8 input block
+        const int nxt = cur ^ 1;
+        for (int l = 0; l < n_layers; ++l) {
+            mnn_det_lstm_job jb;
+            memset(&jb, 0, sizeof(jb));
+            const int u = layers[l].units;
+            if (l == 0) { jb.x = x; jb.x_dtype = MNN_U8; jb.n_x = n_in; jb.ld_x = ld_x; jb.es_x = 1; }
+            else { jb.x = hbuf[l - 1][nxt]; jb.x_dtype = MNN_F32; jb.n_x = layers[l - 1].units; jb.ld_x = layers[l - 1].units; jb.es_x = 1; }
+            jb.h_prev = have_state ? hbuf[l][cur] : nullptr;
+            jb.c_prev = have_state ? cbuf[l][cur] : nullptr;
+            jb.W = layers[l].W; jb.bias = layers[l].bias; jb.c_out = cbuf[l][nxt]; jb.h_out = hbuf[l][nxt]; jb.units = u;
+            const int rc = mnn_lstm_step_det(s, B, 1, &jb);
+            if (rc != MNN_OK) return rc;
+        }
+        cur = nxt;
+        have_state = true;
+        return MNN_OK;
+    };
+    auto dense = [&]() -> int {
+        mnn_det_dense_job dj;
+        memset(&dj, 0, sizeof(dj));
+        const int ul = layers[n_layers - 1].units;
+        dj.x = hbuf[n_layers - 1][cur]; dj.ld_x = ul; dj.K = ul; dj.W = dense_W; dj.ld_w = n_out; dj.N = n_out; dj.bias = dense_bias;
+        dj.out = out; dj.ld_out = ld_out;
+        return mnn_dense_det(s, B, 1, &dj);
+    };
+    for (int t = 0; t < n_intro; ++t) {
+        const int rc = stack_step(intro + (size_t)t * n_in, n_intro * n_in);
+        if (rc != MNN_OK) return rc;
+    }
+    int rc = dense();
+    if (rc != MNN_OK) return rc;
+    const int row_stride = num_steps * n_in;
+    for (int st = 0; st < num_steps; ++st) {
+        uint8_t* smp = samples + (size_t)st * n_in;            // samples[:, st, :]; feature m D + i (one NADE) or i tracks + m (rnn_multinade.py:313-314)
+        rc = mnn_nade_sample(s, tracks, B, D, Hn, out, ld_out, w_enc, w_dec, temperature, seed, row0, (uint32_t)st, smp,
+                             tracks > 1 ? 1 : D, row_stride, tracks > 1 ? tracks : 1, nullptr);
+        if (rc != MNN_OK) return rc;
+        rc = stack_step(smp, row_stride);
+        if (rc != MNN_OK) return rc;
+        rc = dense();
+        if (rc != MNN_OK) return rc;
+    }
+    return MNN_OK;
+}

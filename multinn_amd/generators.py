@@ -729,6 +729,9 @@ class RnnEstimator(Generator):
             return self._det_state(h, st)
         return self._get_state(inputs, initial_state=initial_state, last_outputs=True)
 
+    def _scan_in_one_call(self, x, num_steps):
+        return None                         # estimators without a one-call scan (RnnRBM) step through sample_single / single_step
+
     def _det_single_step(self, inputs, initial_state, x2=None):
         """single_step in the deterministic arithmetic: inputs u8 | f32 [B, n_x]; x2 (optional, f32 [B, F]) is concatenated behind it -- the
         feedback vector of multinn_feedback.py:85-91, read in place instead of through a torch.cat."""
@@ -830,6 +833,9 @@ class RnnEstimator(Generator):
         self._materialize(x.shape[-1])
         self._rnn.build_cell(False)
         if self.det_sampling:
+            whole = self._scan_in_one_call(x, num_steps)        # LSTM-(Multi)NADE on a byte piano-roll: mnn_generate_scan runs the whole scan
+            if whole is not None:
+                return whole
             state = self.steps(x)
         else:
             self._ensure_packed()
@@ -1205,6 +1211,16 @@ class RnnNade(RnnEstimator):
         else:
             out = self._dense(y.view(T * B, -1))[flat_index(lengths, B, T, inputs.device)]
         return self._state_from_dense(out, tuple((c.clone(), h.clone()) for c, h in final))
+
+    def _scan_in_one_call(self, x, num_steps):
+        """rnn_estimator.py:271-298 through ONE C-ABI call (mnn_generate_scan: intro pass + num_steps x {NADE sample, LSTM step, Dense} enqueued
+        by the library's own host loop) when the inputs are the byte piano-roll itself; the same kernels and bits as the step-by-step path."""
+        if x.dtype != torch.uint8 or x.shape[-1] != self.num_tracks * self.num_dims or int(num_steps) < 1:
+            return None
+        pre = self._rnn.prefix
+        layers = [(self.store[f"{pre}/cell_{l}/kernel"], self.store[f"{pre}/cell_{l}/bias"]) for l in range(len(self._rnn.num_units))]
+        return ops.generate_scan(x.contiguous(), num_steps, layers, self.store["dense/kernel"], self._det_fc_bias(), self.num_tracks, self.num_dims,
+                                 self.num_hidden[-1], self.store["nade/w_enc"], self.store["nade/w_dec"], 1.0, self.seed, self.row0)
 
     def _det_fc_bias(self):
         if not self.internal_bias:

@@ -786,3 +786,31 @@ def dense_det(jobs):
         _req(b is None or (b.dtype == torch.float32 and b.is_contiguous() and b.numel() == N), "dense_det: bias f32 [N]")
         a.x, a.ld_x, a.K, a.W, a.ld_w, a.N, a.bias, a.out, a.ld_out = _ptr(x), x.stride(0), K, _ptr(W), W.stride(0), N, _ptr(b), _ptr(out), out.stride(0)
     call("mnn_dense_det", _stream(), B, len(jobs), arr)
+
+
+def generate_scan(intro, num_steps, layers, dense_W, dense_bias, tracks, D, Hn, w_enc, w_dec, temperature, seed, row0):
+    """mnn_generate_scan: the whole sampling scan of an LSTM-(Multi)NADE generator in one call.  intro u8 [B, Ti, tracks * D]; layers = [(W, bias)]
+    f32 master weights; returns samples u8 [B, num_steps, tracks * D]."""
+    _req(intro.dtype == torch.uint8 and intro.dim() == 3 and intro.is_contiguous() and intro.shape[2] == tracks * D, "generate_scan: intro u8 [B, Ti, tracks * D]")
+    B, Ti, n_in = intro.shape
+    n_out = tracks * (Hn + D)
+    arr = (_lib.ScanLstmLayer * len(layers))()
+    k_in = n_in
+    for a, (W, b) in zip(arr, layers):
+        u = b.numel() // 4
+        _req(W.dtype == torch.float32 and W.is_contiguous() and tuple(W.shape) == (k_in + u, 4 * u) and b.dtype == torch.float32 and b.is_contiguous(),
+             "generate_scan: layer weights f32 [(n_in + u), 4u] / [4u]")
+        a.W, a.bias, a.units = _ptr(W), _ptr(b), u
+        k_in = u
+    _req(dense_W.dtype == torch.float32 and dense_W.is_contiguous() and tuple(dense_W.shape) == (k_in, n_out), "generate_scan: Dense kernel f32 [units_last, n_out]")
+    _req(dense_bias is None or (dense_bias.dtype == torch.float32 and dense_bias.is_contiguous() and dense_bias.numel() == n_out), "generate_scan: Dense bias")
+    for w in (w_enc, w_dec):
+        _req(w.dtype == torch.float32 and w.is_contiguous() and w.numel() == tracks * D * Hn, "generate_scan: NADE weights f32 [tracks, D, Hn]")
+    need = int(_lib.load().mnn_generate_scan_workspace_bytes(B, len(layers), arr, n_out))
+    ws = torch.empty(need + 256, dtype=torch.uint8, device=intro.device)
+    off = (-ws.data_ptr()) % 256
+    samples = torch.empty((B, int(num_steps), n_in), dtype=torch.uint8, device=intro.device)
+    call("mnn_generate_scan", _stream(), B, Ti, int(num_steps), _ptr(intro), n_in, len(layers), arr, _ptr(dense_W), _ptr(dense_bias), n_out, tracks, D, Hn,
+         _ptr(w_enc), _ptr(w_dec), float(-1.0 if temperature is None else temperature), int(seed), int(row0), _ptr(samples),
+         C.c_void_p(ws.data_ptr() + off), need)
+    return samples                          # (the workspace returns to the allocator in stream order: later users are behind the scan)

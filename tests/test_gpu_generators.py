@@ -869,3 +869,25 @@ def test_encoder_pretraining_driver_lowers_reconstruction_cost():
         assert all(np.isfinite(c)) and c[-1] < c[0], c
         m = encs[i].metrics
         assert {"loss", "log_likelihood", "batch/loss", "free_energy"} <= set(m)
+
+
+@pytest.mark.parametrize("tracks", [1, 3])
+def test_generate_scan_entry_point_equals_step_by_step_scan(tracks):
+    """mnn_generate_scan (the whole scan of rnn_estimator.py:271-323 in one C-ABI call) against the same scan driven step by step
+    through sample_single / single_step, and against the deterministic checker: identical samples; also with intros that are not byte
+    tensors (those take the step-by-step path)."""
+    from multinn_amd import RnnNade, RnnMultiNADE
+    B, Ti, E, Hn, units, steps = 9, 5, 24, 32, [64, 32], 11
+    Din = E * tracks
+    R = np.random.default_rng(16)
+    intro = (R.random((B, Ti, Din)) < .3).astype(np.uint8)
+    p = G.init_rnn_nade(19, Din, E, Hn, units, np.float32, tracks=tracks)
+    gen = RnnNade(E, Hn, units, precision="fp16", seed=37) if tracks == 1 else RnnMultiNADE(E, Hn, units, tracks=list("abc"), precision="fp16", seed=37)
+    gen._materialize(Din)
+    load_nade_params(gen, p)
+    one = gen.generate(dev(intro), steps)                                  # byte intro: mnn_generate_scan
+    assert gen._scan_in_one_call(dev(intro), steps) is not None
+    stepwise = gen.generate(dev(intro).float(), steps)                     # float intro: sample_single / single_step per generated step
+    assert gen._scan_in_one_call(dev(intro).float(), steps) is None
+    assert torch.equal(one, stepwise)
+    assert np.array_equal(one.cpu().numpy(), det.rnn_nade_generate(intro, steps, p, 37, tracks=tracks))
