@@ -160,3 +160,28 @@ def feedback_rnn_generate(x, num_steps, gen_params, fb_layers, seeds, row0=0):
             hs[i], states[i] = lstm_step(np.concatenate([cur[i].astype(np.float32), fb], 1), states[i], p['lstm'])
             outs[i] = dense(hs[i], p['fc_k'], p['fc_b'])
     return samples
+
+
+def rnn_rbm_generate(intro, num_steps, p, k, seed, row0=0, internal_bias=True):
+    """RnnRBM.generate (rnn_estimator.py:271-298 with rnn_rbm.py:240-297; R1: k = rbm.k) in the deterministic float32 arithmetic: intro pass,
+    then per generated step a k-step Gibbs chain from the previous step's visibles (uniforms: streams 2 / 3, row = global batch index, sub =
+    step * k + iteration) -> LSTM step on the sample -> bh_t = bh + h . Wuh, bv_t = bv + h . Wuv.  intro u8 [B, Ti, D] -> samples u8 [B, num_steps, D]."""
+    from . import generators as G
+    B, Ti, D = intro.shape
+    Hn = p['W'].shape[1]
+    state, h = None, None
+    for t in range(Ti):
+        h, state = lstm_step(intro[:, t], state, p['lstm'])
+    bh0 = f32(p['bh']).reshape(-1) if internal_bias else None
+    bv0 = f32(p['bv']).reshape(-1) if internal_bias else None
+    rows = np.arange(row0, row0 + B, dtype=np.uint32)
+    prev = np.ascontiguousarray(intro[:, -1], np.uint8)
+    out = np.empty((B, num_steps, D), np.uint8)
+    for s in range(num_steps):
+        bh_t, bv_t = dense(h, p['Wuh'], bh0), dense(h, p['Wuv'], bv0)
+        u_h, u_v = G.gibbs_uniforms(seed, rows, k, Hn, D, sub0=s * max(k, 1))
+        _, v = rbm_gibbs(prev, p['W'], bh_t, bv_t, k, u_h, u_v)
+        out[:, s] = v
+        h, state = lstm_step(v, state, p['lstm'])
+        prev = v
+    return out

@@ -891,3 +891,27 @@ def test_generate_scan_entry_point_equals_step_by_step_scan(tracks):
     assert gen._scan_in_one_call(dev(intro).float(), steps) is None
     assert torch.equal(one, stepwise)
     assert np.array_equal(one.cpu().numpy(), det.rnn_nade_generate(intro, steps, p, 37, tracks=tracks))
+
+
+def test_rnn_rbm_generate_scan_bit_exact():
+    """RnnRBM.generate (A11 with the LSTM-RBM estimator: Gibbs chain per generated step, rnn_rbm.py:283-297 with k = rbm.k) against the
+    deterministic checker: every cell of the scan."""
+    from multinn_amd import RnnRBM
+    B, Ti, D, Hn, units, k, steps = 10, 4, 24, 40, [64, 32], 4, 9
+    R = np.random.default_rng(26)
+    intro = (R.random((B, Ti, D)) < .3).astype(np.uint8)
+    p = G.init_rnn_rbm(27, D, D, Hn, units, np.float32)
+    p['bh'] += np.float32(0.1); p['bv'] -= np.float32(0.3)
+    gen = RnnRBM(D, Hn, units, k=k, precision="fp16", seed=41)
+    gen._materialize(D)
+    s = gen.store
+    for l, (W, b) in enumerate(p['lstm']):
+        s[f"rnn/cell_{l}/kernel"].copy_(dev(W)); s[f"rnn/cell_{l}/bias"].copy_(dev(b))
+    for kk in ("W", "bh", "bv"):
+        s[f"rbm/{kk}"].copy_(dev(p[kk]))
+    s["Wuh"].copy_(dev(p['Wuh'])); s["Wuv"].copy_(dev(p['Wuv']))
+    got = gen.generate(dev(intro), steps).cpu().numpy()
+    ref = det.rnn_rbm_generate(intro, steps, p, k, 41)
+    assert got.shape == ref.shape == (B, steps, D)
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} of {got.size} cells differ; first at {np.argwhere(got != ref)[:3].tolist()}"
+    assert 0.02 < got.mean() < 0.98
