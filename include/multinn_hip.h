@@ -43,9 +43,9 @@ enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_ST
 
 /* ABI version of THIS header: bumped whenever a signature or a descriptor struct changes.  mnn_version() returns the value the library
  * was built with; a loader must compare the two before its first call (multinn_amd/_lib.py load() does) -- a library built for another
- * version reads garbage arguments without any diagnosis otherwise.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
+ * version reads garbage arguments without any diagnosis otherwise.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
  * mnn_pianoroll_shift_timemajor_t / mnn_grad_rows_fanout and the `f16` descriptor fields of round 3 are part of it. */
-#define MNN_ABI_VERSION 112
+#define MNN_ABI_VERSION 113
 int mnn_version(void);
 const char* mnn_last_error(void);
 
@@ -91,7 +91,8 @@ int mnn_pianoroll_shift_timemajor(mnn_stream_t s, const uint8_t* x, int B, int T
  * column t*B+b), the K-major operand of layer 1's weight-gradient GEMM (saves a transpose pass over `inputs`). */
 int mnn_pianoroll_shift_timemajor_t(mnn_stream_t s, const uint8_t* x, int B, int T, int D, const int32_t* lengths, void* inputs,
                                     int ld_in, void* inputs_t, int ld_t, uint8_t* targets, float* row_weight, long n_valid_total,
-                                    int dtype /* MNN_BF16 or MNN_F16: the flavour of inputs / inputs_t */);
+                                    int dtype /* MNN_BF16 or MNN_F16: the flavour of inputs / inputs_t */,
+                                    unsigned* count /* optional: += number of set target cells (feeds mnn_density_gate with v = NULL) */);
 
 /* per-track variant: targets_tracks u8 [M,T,B,P] from x u8 [B,T,P,M]  (multi_encoder_nn.py:66-76) */
 int mnn_pianoroll_split_tracks(mnn_stream_t s, const uint8_t* x, int B, int T, int P, int M, uint8_t* targets_tracks);

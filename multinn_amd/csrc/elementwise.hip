@@ -155,8 +155,9 @@ template <typename F>
 __global__ void __launch_bounds__(256)
 pianoroll_shift_tiled_kernel(const uint8_t* __restrict__ x, int B, int Tn, int D, const int32_t* __restrict__ lengths,
                              bf16_t* __restrict__ inputs, int ld_in, bf16_t* __restrict__ inputs_t, int ld_t,
-                             uint8_t* __restrict__ targets, float* __restrict__ row_weight, float inv_n) {
+                             uint8_t* __restrict__ targets, float* __restrict__ row_weight, float inv_n, unsigned* __restrict__ count) {
     __shared__ bf16_t tile[64][66];
+    unsigned nset = 0;                                   // set cells among the target bytes this thread writes (the NADE forward's density gate)
     const int N = B * Tn;
     const int n0 = blockIdx.y * 64, f0 = blockIdx.x * 64;
     const int fq = threadIdx.x & 7, f = f0 + 8 * fq;
@@ -195,6 +196,8 @@ pianoroll_shift_tiled_kernel(const uint8_t* __restrict__ x, int B, int Tn, int D
                     if (f + e < ld_in) inputs[(size_t)n * ld_in + f + e] = o[e];
             }
             if (targets != nullptr && f < D) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) nset += cv[e] != 0;
                 if (vec) *reinterpret_cast<uint2*>(targets + (size_t)n * D + f) = *reinterpret_cast<uint2*>(cv);
                 else {
 #pragma unroll
@@ -207,6 +210,11 @@ pianoroll_shift_tiled_kernel(const uint8_t* __restrict__ x, int B, int Tn, int D
                 row_weight[n] = (lengths == nullptr || t < lengths[b]) ? inv_n : 0.f;
             }
         }
+    }
+    if (count != nullptr) {                              // one atomic per wave: the count mnn_density_gate would take in a second pass over the targets
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nset += __shfl_xor(nset, o);
+        if ((threadIdx.x & 63) == 0 && nset != 0u) atomicAdd(count, nset);
     }
     __syncthreads();
     const int tc = threadIdx.x >> 2, rq = threadIdx.x & 3;
@@ -227,7 +235,8 @@ pianoroll_shift_tiled_kernel(const uint8_t* __restrict__ x, int B, int Tn, int D
 }
 
 extern "C" int mnn_pianoroll_shift_timemajor_t(mnn_stream_t s, const uint8_t* x, int B, int T, int D, const int32_t* lengths, void* inputs,
-                                               int ld_in, void* inputs_t, int ld_t, uint8_t* targets, float* row_weight, long n_valid_total, int dtype) {
+                                               int ld_in, void* inputs_t, int ld_t, uint8_t* targets, float* row_weight, long n_valid_total, int dtype,
+                                               unsigned* count) {
     MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F16, "mnn_pianoroll_shift_timemajor_t: dtype must be bf16 or f16");
     MNN_REQUIRE(x && inputs && inputs_t && B > 0 && T > 0 && D > 0 && ld_in >= D, "mnn_pianoroll_shift_timemajor_t: bad arguments");
     MNN_REQUIRE(ld_in % 8 == 0 && ld_t % 8 == 0 && ld_t >= B * T, "mnn_pianoroll_shift_timemajor_t: ld_in, ld_t must be multiples of 8, ld_t >= B*T");
@@ -238,10 +247,10 @@ extern "C" int mnn_pianoroll_shift_timemajor_t(mnn_stream_t s, const uint8_t* x,
     dim3 grid(cdiv(ld_in, 64), cdiv((long)B * T, 64));
     if (dtype == MNN_F16)
         hipLaunchKernelGGL(pianoroll_shift_tiled_kernel<Fp16F>, grid, dim3(256), 0, (hipStream_t)s, x, B, T, D, lengths, (bf16_t*)inputs, ld_in,
-                           (bf16_t*)inputs_t, ld_t, targets, row_weight, inv_n);
+                           (bf16_t*)inputs_t, ld_t, targets, row_weight, inv_n, count);
     else
         hipLaunchKernelGGL(pianoroll_shift_tiled_kernel<Bf16F>, grid, dim3(256), 0, (hipStream_t)s, x, B, T, D, lengths, (bf16_t*)inputs, ld_in,
-                           (bf16_t*)inputs_t, ld_t, targets, row_weight, inv_n);
+                           (bf16_t*)inputs_t, ld_t, targets, row_weight, inv_n, count);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
@@ -870,8 +879,9 @@ __global__ void density_decide_kernel(unsigned* __restrict__ count, unsigned lon
     count[0] = 0u;
 }
 extern "C" int mnn_density_gate(mnn_stream_t s, const uint8_t* v, long n, long threshold, int* gate, unsigned* count) {
-    MNN_REQUIRE(v && gate && count && n > 0 && threshold >= 0 && n < (1L << 32), "mnn_density_gate: bad arguments");
-    hipLaunchKernelGGL(density_count_kernel, dim3((int)min(1024L, (n + 4095) / 4096)), dim3(256), 0, (hipStream_t)s, v, n, count);
+    MNN_REQUIRE(gate && count && n > 0 && threshold >= 0 && n < (1L << 32), "mnn_density_gate: bad arguments");
+    // v == NULL: *count already holds the number of set cells (mnn_pianoroll_shift_timemajor_t counted them while writing the targets)
+    if (v != nullptr) hipLaunchKernelGGL(density_count_kernel, dim3((int)min(1024L, (n + 4095) / 4096)), dim3(256), 0, (hipStream_t)s, v, n, count);
     hipLaunchKernelGGL(density_decide_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, count, (unsigned long long)threshold, gate);
     MNN_LAUNCH_CHECK();
     return MNN_OK;

@@ -933,8 +933,9 @@ class RnnNade(RnnEstimator):
                                              1.0, rw, nll, cond_p, d_out, a_fin, exact=exact)
         if getattr(self, "_gate", None) is None or self._gate.device != out.device:
             self._gate = torch.zeros(2, device=out.device, dtype=torch.int32)            # [gate, count]
+        counted = bool(getattr(self, "_v_counted", False)) and rw is not None      # (the on-demand conditionals pass of a train build runs later: not counted)
         return ops.nade_logprob_fwd_auto(v, out, self.store["nade/w_enc"], self.store["nade/w_dec"], self._wdec_bf, M, D, Hn, self._gate[:1],
-                                         self._gate[1:], self.nade_dense_above, rw, nll, cond_p, d_out, a_fin, exact=exact)
+                                         self._gate[1:], self.nade_dense_above, rw, nll, cond_p, d_out, a_fin, exact=exact, counted=counted)
 
     # fp16 mode: the split-operand matrix-core scan (nade_mfma.hip, SPLIT: f16 hi + lo pairs, three 16-bit MFMA products) or the f32 vector scan
     nade_exact = os.environ.get("MULTINN_NADE_EXACT_MFMA", "1") != "0"
@@ -997,8 +998,15 @@ class RnnNade(RnnEstimator):
             if x_tmT is None:
                 Np = ops.round_up(T * B, 64)
                 x_tmT = (torch.zeros if Np != T * B else torch.empty)((self._stack.ld0, Np), device=dev, dtype=self.dtype)
-        ops.pianoroll_shift_timemajor(x_u8.view(B, T, D), lengths, x_tm, v, rw, n_valid, inputs_t=x_tmT)
+        # the NADE forward's density gate needs the number of set target cells: counted by this pass while it writes them (no second pass over v)
+        cnt = None
+        if x_tmT is not None and self._nade_mfma() and self.nade_dense_above < 1.0:
+            if getattr(self, "_gate", None) is None or self._gate.device != dev:
+                self._gate = torch.zeros(2, device=dev, dtype=torch.int32)            # [gate, count]
+            cnt = self._gate[1:]
+        self._v_counted = ops.pianoroll_shift_timemajor(x_u8.view(B, T, D), lengths, x_tm, v, rw, n_valid, inputs_t=x_tmT, count=cnt)
         self._forward_tm(x_tm, v.view(1, T, B, D), rw, lengths, B, T, train=(mode == "train"), x_tmT=x_tmT)
+        self._v_counted = False
         self._is_built = True
 
     def _forward_tm(self, x_tm, v, rw, lengths, B, T, train, x_tmT=None):

@@ -91,7 +91,7 @@ def convert2d(src, dst):
     return dst
 
 
-def pianoroll_shift_timemajor(x, lengths, inputs, targets, row_weight, n_valid_total=0, inputs_t=None):
+def pianoroll_shift_timemajor(x, lengths, inputs, targets, row_weight, n_valid_total=0, inputs_t=None, count=None):
     """x u8 [B,T,D] -> inputs [T,B,ld] (shifted, zero first step), targets u8 [T,B,D], row_weight f32 [T*B];
     inputs_t (bf16 [ld, >= T*B], optional): the transposed copy of inputs, written by the same pass."""
     _req(x.dtype == torch.uint8 and x.dim() == 3 and x.is_contiguous(), "pianoroll: x must be contiguous u8 [B,T,D]")
@@ -109,10 +109,11 @@ def pianoroll_shift_timemajor(x, lengths, inputs, targets, row_weight, n_valid_t
         _req(inputs.dtype in H16 and inputs_t.dtype == inputs.dtype and inputs_t.dim() == 2 and inputs_t.stride(1) == 1
              and inputs_t.shape[0] == inputs.shape[2] and inputs_t.shape[1] >= T * B, "pianoroll: inputs_t must be 16-bit [ld, >=T*B] like inputs")
         call("mnn_pianoroll_shift_timemajor_t", _stream(), _ptr(x), B, T, D, _ptr(lengths), _ptr(inputs), inputs.shape[2], _ptr(inputs_t),
-             inputs_t.stride(0), _ptr(targets), _ptr(row_weight), int(n_valid_total), dtype_code(inputs))
-        return
+             inputs_t.stride(0), _ptr(targets), _ptr(row_weight), int(n_valid_total), dtype_code(inputs), _ptr(count))
+        return count is not None                    # True: `count` now holds the number of set target cells
     call("mnn_pianoroll_shift_timemajor", _stream(), _ptr(x), B, T, D, _ptr(lengths), _ptr(inputs), dtype_code(inputs), inputs.shape[2],
          _ptr(targets), _ptr(row_weight), int(n_valid_total))
+    return False
 
 
 def pianoroll_split_tracks(x, out):
@@ -460,7 +461,7 @@ def nade_f32_pack(w_dec, out):
 
 
 def nade_logprob_fwd_auto(v, bias, w_enc, w_dec, w_dec_bf, tracks, D, Hn, gate, count, dense_above=0.07, row_weight=None, nll=None,
-                          cond_p=None, d_bias=None, a_final=None, exact=False):
+                          cond_p=None, d_bias=None, a_final=None, exact=False, counted=False):
     """16-bit compute modes (exact=True: the split-operand hi + lo form of fp16 mode): the matrix-core form of the scan when at most `dense_above` of the cells of v are active, the f32 vector
     form otherwise; decided on the device (mnn_density_gate), both launches issued (one returns at once).  gate int32[1], count: a zeroed
     int32[1] scratch word (left zero)."""
@@ -482,7 +483,8 @@ def nade_logprob_fwd_auto(v, bias, w_enc, w_dec, w_dec_bf, tracks, D, Hn, gate, 
     if gate is None:                                # gate off: always the matrix-core form
         call(mfma, _stream(), *common, _ptr(w_dec_bf), *tail, 0)
         return
-    call("mnn_density_gate", _stream(), _ptr(v), v.numel(), int(dense_above * v.numel()), _ptr(gate), _ptr(count))
+    # counted: `count` already holds the set cells of v (the piano-roll pass counted them while writing v): only the decision kernel runs
+    call("mnn_density_gate", _stream(), None if counted else _ptr(v), v.numel(), int(dense_above * v.numel()), _ptr(gate), _ptr(count))
     call(mfma, _stream(), *common, _ptr(w_dec_bf), *tail, 0)
     call("mnn_nade_logprob_fwd_gated", _stream(), *common, _ptr(w_dec), *tail, 1)
 
