@@ -92,7 +92,7 @@ int mnn_pianoroll_shift_timemajor(mnn_stream_t s, const uint8_t* x, int B, int T
 int mnn_pianoroll_shift_timemajor_t(mnn_stream_t s, const uint8_t* x, int B, int T, int D, const int32_t* lengths, void* inputs,
                                     int ld_in, void* inputs_t, int ld_t, uint8_t* targets, float* row_weight, long n_valid_total,
                                     int dtype /* MNN_BF16 or MNN_F16: the flavour of inputs / inputs_t */,
-                                    unsigned* count /* optional: += number of set target cells (feeds mnn_density_gate with v = NULL) */);
+                                    unsigned* count /* optional u32 [MNN_DENSITY_SLOTS]: += set target cells (mnn_density_gate, v = NULL) */);
 
 /* per-track variant: targets_tracks u8 [M,T,B,P] from x u8 [B,T,P,M]  (multi_encoder_nn.py:66-76) */
 int mnn_pianoroll_split_tracks(mnn_stream_t s, const uint8_t* x, int B, int T, int P, int M, uint8_t* targets_tracks);
@@ -245,9 +245,12 @@ int mnn_nade_logprob_fwd_mfma(mnn_stream_t s, int tracks, int N, int D, int Hn, 
                               float* d_bias, float* a_final);
 /* Density-gated pair (bf16 compute mode, nade.py:155-229 unchanged): the matrix-core form's cost grows with the number of ACTIVE visibles
  * (one hidden state per active visible and row), the f32 vector form's hardly does (MI355X, [1024,256,88,5]: 2.4 vs 3.6 ms at density 0.03,
- * 19.7 vs 6.6 ms at 0.5).  mnn_density_gate counts the non-zero bytes of v ON THE DEVICE and writes gate[0] = (count > threshold) (count: a
- * zeroed u32 scratch word, left zero); the two *_gated entries are then both launched and each returns at once unless gate[0] == run_if
+ * 19.7 vs 6.6 ms at 0.5).  mnn_density_gate counts the non-zero bytes of v ON THE DEVICE and writes gate[0] = (count > threshold); `count` is
+ * a zeroed scratch array of MNN_DENSITY_SLOTS u32 partial counts (spread so that the adds do not serialise on one address), left zero.
+ * v == NULL: the partial counts are already there (mnn_pianoroll_shift_timemajor_t counted while it wrote v) and only the decision runs.
+ * The two *_gated entries are then both launched and each returns at once unless gate[0] == run_if
  * (gate NULL: always runs).  A captured step so takes the cheaper form at every replay, whatever batch it is fed. */
+#define MNN_DENSITY_SLOTS 256
 int mnn_density_gate(mnn_stream_t s, const uint8_t* v, long n, long threshold, int* gate, unsigned* count);
 int mnn_nade_logprob_fwd_gated(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* row_weight,

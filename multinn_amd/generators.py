@@ -932,7 +932,7 @@ class RnnNade(RnnEstimator):
             return ops.nade_logprob_fwd_auto(v, out, self.store["nade/w_enc"], self.store["nade/w_dec"], self._wdec_bf, M, D, Hn, None, None,
                                              1.0, rw, nll, cond_p, d_out, a_fin, exact=exact)
         if getattr(self, "_gate", None) is None or self._gate.device != out.device:
-            self._gate = torch.zeros(2, device=out.device, dtype=torch.int32)            # [gate, count]
+            self._gate = torch.zeros(1 + ops.DENSITY_SLOTS, device=out.device, dtype=torch.int32)            # [gate | partial counts]
         counted = bool(getattr(self, "_v_counted", False)) and rw is not None      # (the on-demand conditionals pass of a train build runs later: not counted)
         return ops.nade_logprob_fwd_auto(v, out, self.store["nade/w_enc"], self.store["nade/w_dec"], self._wdec_bf, M, D, Hn, self._gate[:1],
                                          self._gate[1:], self.nade_dense_above, rw, nll, cond_p, d_out, a_fin, exact=exact, counted=counted)
@@ -1002,7 +1002,7 @@ class RnnNade(RnnEstimator):
         cnt = None
         if x_tmT is not None and self._nade_mfma() and self.nade_dense_above < 1.0:
             if getattr(self, "_gate", None) is None or self._gate.device != dev:
-                self._gate = torch.zeros(2, device=dev, dtype=torch.int32)            # [gate, count]
+                self._gate = torch.zeros(1 + ops.DENSITY_SLOTS, device=dev, dtype=torch.int32)            # [gate | partial counts]
             cnt = self._gate[1:]
         self._v_counted = ops.pianoroll_shift_timemajor(x_u8.view(B, T, D), lengths, x_tm, v, rw, n_valid, inputs_t=x_tmT, count=cnt)
         self._forward_tm(x_tm, v.view(1, T, B, D), rw, lengths, B, T, train=(mode == "train"), x_tmT=x_tmT)

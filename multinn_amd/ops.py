@@ -17,6 +17,7 @@ def call(name, *args):
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.uint8: U8, torch.float16: F16}
 H16 = (torch.bfloat16, torch.float16)          # the two 16-bit operand flavours (precision "bf16" / "fp16")
+DENSITY_SLOTS = 256                             # MNN_DENSITY_SLOTS: u32 partial counts of mnn_density_gate / the piano-roll pass
 
 
 def dtype_code(t):
@@ -469,7 +470,8 @@ def nade_logprob_fwd_auto(v, bias, w_enc, w_dec, w_dec_bf, tracks, D, Hn, gate, 
     _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)
     _req(w_dec_bf.dtype == (torch.float32 if exact else torch.bfloat16) and w_dec_bf.is_contiguous() and w_dec_bf.numel() == tracks * D * Hn,
          "nade auto: w_dec_bf bf16 [tracks,D,Hn] (exact form: the f32-sized [tracks,D,Hn] output of nade_f32_pack)")
-    _req(gate is None or (gate.dtype == torch.int32 and gate.numel() == 1 and count.dtype == torch.int32 and count.numel() == 1), "nade auto: gate / count int32[1]")
+    _req(gate is None or (gate.dtype == torch.int32 and gate.numel() == 1 and count.dtype == torch.int32 and count.numel() == DENSITY_SLOTS and count.is_contiguous()),
+         "nade auto: gate int32[1], count int32[DENSITY_SLOTS]")
     for t, n in ((nll, tracks * N), (cond_p, tracks * N * D), (a_final, tracks * N * Hn)):
         _req(t is None or (t.dtype == torch.float32 and t.numel() == n and t.is_contiguous()), "nade auto: f32 outputs")
     if d_bias is not None:

@@ -512,11 +512,11 @@ def test_nade_forward_density_gate(ops, rho, expect):
     wdb = wd.to(torch.bfloat16)
     rw = torch.rand(N, device="cuda", generator=g)
     z = lambda *s_: torch.zeros(s_, device="cuda")
-    gate = torch.full((2,), 7, device="cuda", dtype=torch.int32)
-    gate[1] = 0
+    gate = torch.full((1 + ops.DENSITY_SLOTS,), 7, device="cuda", dtype=torch.int32)          # [gate | partial counts (zeroed scratch, left zero)]
+    gate[1:] = 0
     nll, cp, db, af = z(tracks, N), z(tracks, N, D), torch.zeros_like(bias), z(tracks, N, Hn)
     ops.nade_logprob_fwd_auto(v, bias, we, wd, wdb, tracks, D, Hn, gate[:1], gate[1:], 0.07, rw, nll, cp, db, af)
-    assert gate.tolist() == [expect, 0]
+    assert int(gate[0]) == expect and not bool(gate[1:].any())
     nll2, cp2, db2, af2 = z(tracks, N), z(tracks, N, D), torch.zeros_like(bias), z(tracks, N, Hn)
     if expect:
         ops.nade_logprob_fwd(v, bias, we, wd, tracks, D, Hn, rw, nll2, cp2, db2, af2)
@@ -526,7 +526,11 @@ def test_nade_forward_density_gate(ops, rho, expect):
     # the same buffers, the other kind of batch: the decision follows the data
     v2 = (torch.rand((tracks, N, D), device="cuda", generator=g) < (0.3 if not expect else 0.02)).to(torch.uint8)
     ops.nade_logprob_fwd_auto(v2, bias, we, wd, wdb, tracks, D, Hn, gate[:1], gate[1:], 0.07, rw, nll, cp, db, af)
-    assert gate.tolist() == [1 - expect, 0]
+    assert int(gate[0]) == 1 - expect and not bool(gate[1:].any())
+    # counts taken elsewhere (the piano-roll pass): only the decision runs, from the partial counts
+    gate[1:4] = torch.tensor([int(0.05 * v.numel()), int(0.05 * v.numel()), 3], device="cuda", dtype=torch.int32)
+    ops.nade_logprob_fwd_auto(v2, bias, we, wd, wdb, tracks, D, Hn, gate[:1], gate[1:], 0.07, rw, nll, cp, db, af, counted=True)
+    assert int(gate[0]) == 1 and not bool(gate[1:].any())
 
 
 def test_nade_edge_cases(ops):
