@@ -342,3 +342,35 @@ def test_generate_scan_shapes_and_determinism():
     s3 = G.rnn_nade_generate(intro[1:], 4, p, seed=5, row0=1)
     assert s1.shape == (2, 4, 8) and np.array_equal(s1, s2)
     assert np.array_equal(s1[1:], s3)          # row-keyed RNG: independent of batch split
+
+
+def test_det_checker_lstm_step_and_dense_against_float64():
+    """The deterministic float32 checker of the sampling path (oracle/det_ref.c: quartered fmaf chains, det_sigmoid / det_tanh) against the
+    float64 restatement of the same cell (tf_semantics.lstm_block_cell) and Dense: within float32 rounding, for widths that exercise the
+    quarter boundaries (K not a multiple of 8, K > 1024: two chunks) -- and the closed forms W = 0 (K12) and a single non-zero input."""
+    from oracle import det, tf_semantics as S
+    rng = np.random.default_rng(12)
+    for n_in, u in [(5, 32), (13, 64), (440, 512), (601, 512)]:
+        B = 3
+        W = (rng.standard_normal((n_in + u, 4 * u)) * 0.1).astype(np.float32)
+        b = (rng.standard_normal(4 * u) * 0.1).astype(np.float32)
+        x = rng.standard_normal((B, n_in)).astype(np.float32)
+        c0 = rng.standard_normal((B, u)).astype(np.float32)
+        h0 = np.tanh(rng.standard_normal((B, u))).astype(np.float32)
+        _, st = det.lstm_step(x, [(c0, h0)], [(W, b)])
+        h64, c64, _ = S.lstm_block_cell(x.astype(np.float64), c0.astype(np.float64), h0.astype(np.float64), W.astype(np.float64), b.astype(np.float64))
+        assert np.abs(st[0][0] - c64).max() < 5e-6 and np.abs(st[0][1] - h64).max() < 5e-6, (n_in, u)
+        out = det.dense(st[0][1], W[:u, :40].copy(), b[:40].copy())
+        assert np.abs(out - (st[0][1].astype(np.float64) @ W[:u, :40].astype(np.float64) + b[:40])).max() < 5e-6
+    # K12: W = 0, b = 0 -> gates 1/2, ci = 0: c = c_prev / 2, h = tanh(c) / 2; zero state stays zero
+    u, n_in = 32, 7
+    z = det.lstm_step(np.ones((2, n_in), np.float32), None, [(np.zeros((n_in + u, 4 * u), np.float32), np.zeros(4 * u, np.float32))])[1][0]
+    assert not z[0].any() and not z[1].any()
+    c0 = np.full((2, u), 0.8, np.float32)
+    _, st = det.lstm_step(np.ones((2, n_in), np.float32), [(c0, np.zeros((2, u), np.float32))], [(np.zeros((n_in + u, 4 * u), np.float32), np.zeros(4 * u, np.float32))])
+    assert np.allclose(st[0][0], 0.4, atol=1e-7) and np.allclose(st[0][1], np.tanh(0.4) / 2, atol=1e-6)
+    # one non-zero input column: the sum is that single product whatever quarter the column falls into
+    W = rng.standard_normal((1100, 8)).astype(np.float32)
+    for k in (0, 137, 275, 549, 1023, 1024, 1099):
+        x = np.zeros((1, 1100), np.float32); x[0, k] = 1.5
+        assert np.array_equal(det.dense(x, W), (np.float32(1.5) * W[k])[None, :])
