@@ -45,7 +45,7 @@ enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_ST
  * was built with; a loader must compare the two before its first call (multinn_amd/_lib.py load() does) -- a library built for another
  * version reads garbage arguments without any diagnosis otherwise.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
  * mnn_pianoroll_shift_timemajor_t / mnn_grad_rows_fanout and the `f16` descriptor fields of round 3 are part of it. */
-#define MNN_ABI_VERSION 113
+#define MNN_ABI_VERSION 114
 int mnn_version(void);
 const char* mnn_last_error(void);
 
@@ -222,6 +222,13 @@ size_t mnn_lstm_rowpar_workspace_bytes(int T, int B, int units);
 int mnn_lstm_rowpar_status(const void* workspace, int* status);
 int mnn_lstm_rowpar_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L, float keep_prob, void* workspace);
 int mnn_lstm_rowpar_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L, float keep_prob, void* workspace);
+/* CU-resident recurrence of ONE 256-unit layer (multinn_amd/csrc/lstm_resident.hip; rnn.py:104-145 as above): a workgroup owns four batch
+ * rows for the whole sequence and keeps the layer's ENTIRE recurrent matrix on its CU (three quarters in the registers of its four waves,
+ * one quarter in LDS), so a timestep hands nothing between workgroups -- no flags, no exchange area, no workspace, no co-residency
+ * requirement (any grid size runs).  Same layer descriptors, inputs, outputs and layouts as mnn_lstm_rowpar_fwd (16-bit gate-minor xproj
+ * REQUIRED: L->xproj_bf16 != 0); units must be 256 and B a multiple of 4 (mnn_lstm_resident_ok). */
+int mnn_lstm_resident_ok(int B, int units);
+int mnn_lstm_resident_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L, float keep_prob);
 int mnn_dropout_mask(mnn_stream_t s, uint8_t* mask, int T, int B, int units, float keep_prob, uint64_t seed, const int32_t* step_dev,
                      uint32_t row0, int layer);
 

@@ -6,8 +6,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmultinn_hip.so")
-SOURCES = ["gemm.hip", "lstm_persist.hip", "lstm_rowpar.hip", "elementwise.hip", "nade.hip", "nade_mfma.hip", "rbm.hip", "musical.hip", "det_step.hip", "comm.hip"]
+SOURCES = ["gemm.hip", "lstm_persist.hip", "lstm_rowpar.hip", "lstm_resident.hip", "elementwise.hip", "nade.hip", "nade_mfma.hip", "rbm.hip", "musical.hip", "det_step.hip", "comm.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+# per-source additions.  lstm_resident.hip: MFMA results in VGPRs (the pointwise reads them there: no v_accvgpr_read per accumulator register),
+# which leaves the AGPRs to the recurrent weights the matrix cores read in place
+EXTRA_FLAGS = {"lstm_resident.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
+def flags_for(src):
+    return FLAGS + EXTRA_FLAGS.get(os.path.basename(src), [])
 
 
 def _stale():
@@ -27,7 +34,7 @@ def build(force=False, verbose=True):
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + flags_for(src) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

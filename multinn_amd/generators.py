@@ -143,6 +143,13 @@ class LstmStack:
     # step's largest tensor), f32 with MULTINN_ROWPAR_XPROJ=f32
     rowpar_xproj_f32 = os.environ.get("MULTINN_ROWPAR_XPROJ", "16") == "f32"
 
+    # CU-resident form of a 256-unit layer inside the row-parallel path (lstm_resident.hip): the layer's whole recurrent matrix sits on every CU
+    # and a workgroup owns four batch rows, so a timestep has no hand-off between workgroups (MULTINN_RESIDENT=0: row-parallel kernels only)
+    resident = os.environ.get("MULTINN_RESIDENT", "1") != "0"
+
+    def _resident(self, l, B):
+        return self.resident and not self.rowpar_xproj_f32 and ops.lstm_resident_ok(B, self.packed[l]["u"])
+
     @property
     def rowpar_xproj_dtype(self):
         return torch.float32 if self.rowpar_xproj_f32 else self.dtype
@@ -218,7 +225,10 @@ class LstmStack:
                 yT = nxt[:u] if nxt is not None else zalloc((u, Np), device=dev, dtype=self.dtype)
             d = ops.lstm2_fwd_layer(xproj, p["wh_t"], None, None, gates, c, h, hT, y, mask, yT=yT, gates_dtype=self.dtype,
                                     xproj_dtype=self.rowpar_xproj_dtype)
-            ops.lstm_rowpar_fwd(T, B, d, keep_prob, self._rp_workspace(l, T, B, dev))
+            if self._resident(l, B):
+                ops.lstm_resident_fwd(T, B, d, keep_prob)
+            else:
+                ops.lstm_rowpar_fwd(T, B, d, keep_prob, self._rp_workspace(l, T, B, dev))
             out = y if y is not None else h
             if save:
                 ctx.append(dict(inp=inp, gates=gates, c=c, h=h, c0=None, h0=None, hT=hT, mask=mask, yT=yT,

@@ -366,6 +366,16 @@ def lstm_rowpar_bwd(T, B, L, keep_prob, ws):
     call("mnn_lstm_rowpar_bwd", _stream(), T, B, C.byref(L), float(keep_prob), _ptr(ws))
 
 
+def lstm_resident_ok(B, units):
+    """True when the CU-resident recurrence (a 256-unit layer's whole recurrent matrix on every CU, four batch rows per workgroup) covers this shape."""
+    return bool(_lib.load().mnn_lstm_resident_ok(int(B), int(units)))
+
+
+def lstm_resident_fwd(T, B, L, keep_prob):
+    """L: descriptor of lstm2_fwd_layer, as for lstm_rowpar_fwd with a 16-bit xproj; no workspace."""
+    call("mnn_lstm_resident_fwd", _stream(), T, B, C.byref(L), float(keep_prob))
+
+
 def lstm_rowpar_check(ws):
     st = C.c_int(0)
     call("mnn_lstm_rowpar_status", _ptr(ws), C.byref(st))
