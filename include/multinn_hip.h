@@ -226,9 +226,13 @@ int mnn_lstm_rowpar_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* 
  * rows for the whole sequence and keeps the layer's ENTIRE recurrent matrix on its CU (three quarters in the registers of its four waves,
  * one quarter in LDS), so a timestep hands nothing between workgroups -- no flags, no exchange area, no workspace, no co-residency
  * requirement (any grid size runs).  Same layer descriptors, inputs, outputs and layouts as mnn_lstm_rowpar_fwd (16-bit gate-minor xproj
- * REQUIRED: L->xproj_bf16 != 0); units must be 256 and B a multiple of 4 (mnn_lstm_resident_ok). */
+ * REQUIRED: L->xproj_bf16 != 0; the saved gates, hT and yT come together or not at all); units must be 256 and B a multiple of 4
+ * (mnn_lstm_resident_ok); every tensor of the call below 2 GB (buffer descriptors). */
 int mnn_lstm_resident_ok(int B, int units);
 int mnn_lstm_resident_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L, float keep_prob);
+/* ... and its backward: descriptor, outputs and layouts of mnn_lstm_rowpar_bwd (dh_ext required; dz_T, dzT_t / ld_t (0 = K-blocked), db_p optional;
+ * workspace / wx_p / dz unused).  The saved gates must be the 16-bit gate-minor copy written by mnn_lstm_resident_fwd / mnn_lstm_rowpar_fwd. */
+int mnn_lstm_resident_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L, float keep_prob);
 int mnn_dropout_mask(mnn_stream_t s, uint8_t* mask, int T, int B, int units, float keep_prob, uint64_t seed, const int32_t* step_dev,
                      uint32_t row0, int layer);
 

@@ -17,6 +17,8 @@
 // pointwise of B x u pairs over all 1024 SIMDs.
 #include "common.h"
 
+__device__ __forceinline__ float dpp_xor2(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_xor1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false)); }
 #define RES_LDS_FENCE() asm volatile("" ::: "memory")
 #define RES_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -68,10 +70,12 @@ __device__ __forceinline__ int res_row_group(int b, int nblk) { return (nblk & 7
 typedef __attribute__((address_space(1))) const void* res_gptr_t;
 typedef __attribute__((address_space(3))) void* res_lptr_t;
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #define RES_VMC(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
 __device__ __forceinline__ void res_wait_all_but(int n) {       // loads, stores and LDS-DMA of a wave complete in issue order (MI355X_MICROARCH.md)
     switch (n) {
         RES_VMC(0) RES_VMC(1) RES_VMC(2) RES_VMC(3) RES_VMC(4) RES_VMC(5) RES_VMC(6) RES_VMC(7) RES_VMC(8) RES_VMC(9) RES_VMC(10) RES_VMC(11) RES_VMC(12)
+        RES_VMC(13) RES_VMC(14) RES_VMC(15) RES_VMC(16)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
@@ -138,27 +142,56 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RES_BARRIER();
 
-    // ---- what leaves a step through LDS: h / y row-major (16-byte pieces) and h^T / y^T (a unit's four rows = 8 bytes) ----
-    auto emit = [&](int t) {                       // outputs of step t: h[t] sits in state buffer (t + 1) & 1, y[t] in y buffer t & 1
+    // ---- what leaves a step through LDS: h / y row-major (16-byte pieces) and h^T / y^T (a unit's four rows = 8 bytes).  Branch-free: buffer
+    // stores whose offset is pushed out of range are dropped by the hardware, so the step's code stays one scheduling region ----
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)A.h, 0, (int)min((size_t)T * us * 2, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(DROP ? (void*)A.y : (void*)A.h, 0, (int)min((size_t)T * us * 2, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_hT = __builtin_amdgcn_make_buffer_rsrc(SAVE ? (void*)A.hT : (void*)A.h, 0, SAVE ? (int)min((size_t)U * A.ld_hT * 2, (size_t)0x7fffffff) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_yT = __builtin_amdgcn_make_buffer_rsrc(SAVE ? (void*)A.yT : (void*)A.h, 0, SAVE ? (int)min((size_t)U * A.ld_yT * 2, (size_t)0x7fffffff) : 0, 0x00020000);
+    const int er = (tid >> 5) & 3, epc = tid & 31;
+    const unsigned vo_row = (unsigned)(er * U + epc * 8) * 2u;                  // row-major piece of this thread inside the step's 4 x u block
+    const unsigned vo_lo = tid < 128 ? vo_row : OOB, vo_hi = tid >= 128 ? vo_row : OOB;
+    const unsigned vo_hT = (unsigned)tid * (unsigned)A.ld_hT * 2u, vo_yT = (unsigned)tid * (unsigned)A.ld_yT * 2u;
+    // (the SCALAR offset of a buffer access is not range-checked: only the lane offset can push a store out of range)
+    // Two halves: the LDS reads are issued early in the first group's MFMA stream and consumed (packed, stored) a few k-steps later, so that
+    // their latency is under the MFMAs (read and used in one place they stalled the stream for ~1000 cycles per step).
+    u32x4_t e_hrow, e_yrow;
+    unsigned e_col[2][4];
+    auto emit_read = [&](int t) {                  // outputs of step t: h[t] sits in state buffer (t + 1) & 1, y[t] in y buffer t & 1
         const char* hb = smem + G::OFF_H + ((t + 1) & 1) * 4 * G::PH;
         const char* yb = smem + G::OFF_Y + (t & 1) * 4 * G::PH;
-        const int r = (tid >> 5) & 3, pc = tid & 31;
-        if (DROP) {
-            if (tid >= 128) *reinterpret_cast<uint4*>(A.y + (size_t)t * us + (size_t)(row0 + r) * U + pc * 8) = *reinterpret_cast<const uint4*>(yb + r * G::PH + pc * 16);
-            else if (t + 1 == T) *reinterpret_cast<uint4*>(A.h + (size_t)t * us + (size_t)(row0 + r) * U + pc * 8) = *reinterpret_cast<const uint4*>(hb + r * G::PH + pc * 16);
-        } else if (tid < 128) {
-            *reinterpret_cast<uint4*>(A.h + (size_t)t * us + (size_t)(row0 + r) * U + pc * 8) = *reinterpret_cast<const uint4*>(hb + r * G::PH + pc * 16);
+        e_hrow = *reinterpret_cast<const u32x4_t*>(hb + er * G::PH + epc * 16);
+        if (DROP) e_yrow = *reinterpret_cast<const u32x4_t*>(yb + er * G::PH + epc * 16);
+        if (SAVE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e_col[0][r] = reinterpret_cast<const h16_t*>(hb)[tid + r * (G::PH / 2)];
+                if (DROP) e_col[1][r] = reinterpret_cast<const h16_t*>(yb)[tid + r * (G::PH / 2)];
+            }
         }
-        auto column = [&](const char* tile) {
-            uint2 v;
-            const h16_t* p = reinterpret_cast<const h16_t*>(tile) + tid;
-            v.x = (unsigned)p[0] | ((unsigned)p[G::PH / 2] << 16);
-            v.y = (unsigned)p[G::PH] | ((unsigned)p[3 * (G::PH / 2)] << 16);
-            return v;
-        };
-        if (A.hT != nullptr && t + 1 < T) *reinterpret_cast<uint2*>(A.hT + (size_t)tid * A.ld_hT + (size_t)(t + 1) * B + row0) = column(hb);
-        if (A.yT != nullptr) *reinterpret_cast<uint2*>(A.yT + (size_t)tid * A.ld_yT + (size_t)t * B + row0) = column(DROP ? yb : hb);
     };
+    auto emit_store = [&](int t) {                 // t = -1: nothing leaves
+        const int tc = t < 0 ? 0 : t;
+        const unsigned none = t < 0 ? OOB : 0u;                                  // wave-uniform kill bits, OR-ed into the lane offsets
+        const unsigned so_row = (unsigned)(((size_t)tc * us + (size_t)row0 * U) * 2);
+        if (DROP) {
+            __builtin_amdgcn_raw_buffer_store_b128(e_yrow, rs_y, vo_hi | none, so_row, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(e_hrow, rs_h, vo_lo | (t + 1 == T ? 0u : OOB), so_row, 0);   // only the final state reads h
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(e_hrow, rs_h, vo_lo | none, so_row, 0);
+        }
+        if (SAVE) {
+            u32x2_t hc, yc;
+            hc[0] = e_col[0][0] | (e_col[0][1] << 16); hc[1] = e_col[0][2] | (e_col[0][3] << 16);
+            if (DROP) { yc[0] = e_col[1][0] | (e_col[1][1] << 16); yc[1] = e_col[1][2] | (e_col[1][3] << 16); }
+            else yc = hc;
+            const int tn = t + 1 < T ? t + 1 : 0;
+            __builtin_amdgcn_raw_buffer_store_b64(hc, rs_hT, vo_hT | ((t < 0 || t + 1 >= T) ? OOB : 0u), (unsigned)(((size_t)tn * B + row0) * 2), 0);
+            __builtin_amdgcn_raw_buffer_store_b64(yc, rs_yT, vo_yT | none, (unsigned)(((size_t)tc * B + row0) * 2), 0);
+        }
+    };
+    constexpr int EMIT_STORES = (DROP ? 2 : 1) + (SAVE ? 2 : 0);
 
     float creg[G::NG];
 #pragma unroll
@@ -175,9 +208,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #ifdef RES_TRACE
         tr_[9] = clock64();
 #endif
-        if (t > 0) emit(t - 1);                                 // the previous step's outputs leave in the shadow of this step's MFMAs
-        asm volatile("" ::: "memory");
-        stage(t + 1 < T ? t + 1 : t, (t + 1) & 1);              // unconditional (clamped)
+        stage(t + 1 < T ? t + 1 : t, (t + 1) & 1);              // unconditional (clamped); everything below is younger than these requests
         asm volatile("" ::: "memory");
         const char* hin = smem + G::OFF_H + (t & 1) * 4 * G::PH + row * G::PH + g4 * 16;
         char* hout = smem + G::OFF_H + ((t + 1) & 1) * 4 * G::PH + row * G::PH;
@@ -215,6 +246,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     ac[j] = F::mfma16(in_lds(s) ? lw[j] : wr[4 * q + j][s < G::KR ? s : 0], b[i], c0);
                 }
                 if (in_lds(s)) request();
+                if (q == 0 && i == 0) emit_read(t - 1);         // the previous step's outputs leave in the shadow of this step's first MFMAs
+                if (q == 0 && i == 4) emit_store(t - 1);
                 // the state fragments stay PFB k-steps ahead (left alone, the scheduler requests all eight at the top of the group: 16 registers
                 // more than there are); vector / scalar / transcendental work, stores and LDS writes of the previous group's pointwise may cross
                 __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400 | 0x40 | 0x200);
@@ -263,13 +296,236 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             pointwise(q, acc[q & 1]);
             RES_TR(3 + q);
         }
-        res_wait_all_but(G::NG * (SAVE ? 2 : 1));               // the staged rows of step t + 1 are in LDS (the pointwise stores behind them may not be out)
+        res_wait_all_but(EMIT_STORES + G::NG * (SAVE ? 2 : 1));               // the staged rows of step t + 1 are in LDS (the pointwise stores behind them may not be out)
         RES_TR(7);
         RES_BARRIER();
         RES_TR(8);
         RES_TR_FLUSH(0, t);
     }
-    emit(T - 1);
+    emit_read(T - 1);
+    emit_store(T - 1);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward:  dh = dh_ext[t] (/ kp * keep when a mask is given) + dz[t+1] . Wh ;  gate backward -> dz[t], dc   (rnn.py:124 LSTMBlockCell autodiff)
+// Same ownership (four rows per workgroup, the whole [u, 4u] matrix on the CU).  A = Wh rows (16 output units x 32 gate columns per MFMA),
+// B = dz[t+1] (4 rows, replicated over the banks), K = 4u = 32 k-steps: a wave's four accumulators run over all of them, bank b keeps tile b,
+// and a lane then owns FOUR CONSECUTIVE units of one row: u0 = 64 w + 16 bank + 4 (l >> 4), row l & 3.  Its operands (saved gates 32 bytes,
+// c[t-1] 16, dh_ext 16, keep bytes 4) are five contiguous loads issued a step ahead.  The step is serial by nature -- all of dz[t+1] is needed
+// before the first MFMA and all MFMAs before the pointwise -- so the outputs of the previous step (dz row-major and dz^T) leave from the
+// LDS tile in the shadow of the MFMA phase.
+// ------------------------------------------------------------------------------------------------------------------
+struct ResBwdArgs {
+    const float* dh_ext; const h16_t* wh_p; const h16_t* gates; const float* c; const uint8_t* mask;
+    h16_t* dzc; h16_t* dzT; int ld_t; float* db_p;
+    int T, B; float kp;
+};
+
+template <int U> struct ResBwdGeom {
+    static_assert(U == 256, "the CU-resident recurrence is sized for 256-unit layers");
+    static constexpr int KS = 4 * U / 32;       // k-steps of 32 over the gate columns
+    static constexpr int KL = KS / 4;           // every fourth k-step's fragments live in LDS
+    static constexpr int PZ = 4 * U * 2 + 64;   // pitch of a dz row in LDS (rows 16 banks apart)
+    static constexpr int OFF_W = 0;
+    static constexpr int OFF_Z = OFF_W + 4 * 4 * KL * 1024;
+    static constexpr int LDS = OFF_Z + 2 * 4 * PZ;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+template <int U, typename F, bool DROP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_res_bwd_kernel(ResBwdArgs A) {
+    typedef ResBwdGeom<U> G;
+    typedef typename F::x8 frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = lane & 3, bank = (lane & 15) >> 2, g4 = lane >> 4;
+    const int T = A.T, B = A.B;
+    const int row0 = 4 * res_row_group(blockIdx.x, gridDim.x);
+    const size_t us = (size_t)B * U;
+    const float ikp = 1.0f / A.kp;
+    const int u0 = 64 * w + 16 * bank + 4 * g4;                              // this lane's four units (after the bank selection)
+
+    // ---- Wh [u, 4u]: A fragments of this wave's four 16-unit tiles; k-steps s % 4 != 3 in registers (0..15 of them pinned to AGPRs), s % 4 == 3 in LDS ----
+    frag_t wr[4][G::KS - G::KL];
+    {
+        uint4* wl = reinterpret_cast<uint4*>(smem + G::OFF_W);
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            const h16_t* src = A.wh_p + (size_t)(64 * w + 16 * tl + (lane & 15)) * (4 * U) + 8 * g4;
+#pragma unroll
+            for (int s = 0; s < G::KS; ++s) {
+                const uint4 v = *reinterpret_cast<const uint4*>(src + 32 * s);
+                if ((s & 3) == 3) wl[((w * 4 + tl) * G::KL + (s >> 2)) * 64 + lane] = v;
+                else {
+                    const int si = s - (s >> 2);
+                    wr[tl][si] = __builtin_bit_cast(frag_t, v);
+                    if (si < 16) asm volatile("" : "+a"(wr[tl][si]));
+                }
+            }
+        }
+    }
+    for (int i = tid; i < 4 * G::PZ / 4; i += 256) reinterpret_cast<unsigned*>(smem + G::OFF_Z)[i] = 0u;     // dz[T] = 0
+
+    // ---- the step's operands: buffer loads with a scalar per-step base and one lane offset (units u0 .. u0+3 of row `row`) ----
+    const int lim = (int)min((size_t)T * us * 8, (size_t)0x7fffffff);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)A.gates, 0, lim, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)A.c, 0, (int)min((size_t)T * us * 4, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)A.dh_ext, 0, (int)min((size_t)T * us * 4, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(DROP ? (void*)A.mask : (void*)A.c, 0, (int)min((size_t)T * us, (size_t)0x7fffffff), 0x00020000);
+    const unsigned vo_e = (unsigned)(row * U + u0);                          // element offset inside a step's 4 x u block
+    u32x4_t gq0, gq1, cq, dq;
+    unsigned mq = 0u;
+    auto request = [&](int t) {                                              // operands of step t (t >= 0)
+        const unsigned so = (unsigned)(((size_t)t * us + (size_t)row0 * U));
+        gq0 = __builtin_amdgcn_raw_buffer_load_b128(rs_g, vo_e * 8, so * 8, 0);
+        gq1 = __builtin_amdgcn_raw_buffer_load_b128(rs_g, vo_e * 8 + 16, so * 8, 0);
+        const unsigned sp = (unsigned)(((size_t)(t > 0 ? t - 1 : 0) * us + (size_t)row0 * U));
+        cq = __builtin_amdgcn_raw_buffer_load_b128(rs_c, vo_e * 4, sp * 4, 0);       // c[t-1] (t = 0: read and ignored)
+        dq = __builtin_amdgcn_raw_buffer_load_b128(rs_d, vo_e * 4, so * 4, 0);
+        if (DROP) mq = __builtin_amdgcn_raw_buffer_load_b32(rs_m, vo_e, so, 0);
+    };
+    float cnext[4], dcreg[4], dbv[4][4];
+    {
+        const u32x4_t c_last = __builtin_amdgcn_raw_buffer_load_b128(rs_c, vo_e * 4, (unsigned)(((size_t)(T - 1) * us + (size_t)row0 * U)) * 4, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cnext[r] = __uint_as_float(c_last[r]);
+            dcreg[r] = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dbv[g][r] = 0.f;
+        }
+    }
+    request(T - 1);
+
+    // ---- what leaves through the LDS tile: dz row-major [t][row][4u] (16-byte pieces) and dz^T (a column's four rows = 8 bytes) ----
+    constexpr unsigned OOB = 0x80000000u;
+    const size_t N = (size_t)T * B;
+    const bool kb = A.ld_t == 0;
+    const __amdgpu_buffer_rsrc_t rs_zc = __builtin_amdgcn_make_buffer_rsrc(A.dzc ? (void*)A.dzc : (void*)A.c, 0, A.dzc ? (int)min(N * 4 * U * 2, (size_t)0x7fffffff) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_zt = __builtin_amdgcn_make_buffer_rsrc(A.dzT ? (void*)A.dzT : (void*)A.c, 0,
+                                                                           A.dzT ? (int)min(kb ? N * 4 * U * 2 : (size_t)4 * U * A.ld_t * 2, (size_t)0x7fffffff) : 0, 0x00020000);
+    const unsigned vo_zc = (unsigned)((tid >> 6) * 4 * U + (tid & 63) * 8) * 2u;
+    const unsigned vo_zt = kb ? (unsigned)(tid * 32 + (row0 & 31)) * 2u : (unsigned)tid * (unsigned)A.ld_t * 2u;
+    const unsigned st_zt = kb ? 256u * 64u : 256u * (unsigned)A.ld_t * 2u;                      // between this thread's four columns
+    // (the SCALAR offset of a buffer access is not range-checked: only the lane offset can push a store out of range)
+    // Two halves (as in the forward): LDS reads early in the MFMA stream, packing and stores a few k-steps later.
+    // The four columns go in two rounds (8 + 8 registers instead of 24 at once: the wave has none to spare).
+    u32x4_t e_row;
+    unsigned e_col[2][4];
+    auto emit_read = [&](int buf, int half) {
+        const char* zb = smem + G::OFF_Z + buf * 4 * G::PZ;
+        e_row = *reinterpret_cast<const u32x4_t*>(zb + (tid >> 6) * G::PZ + ((tid & 63) + 64 * half) * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e_col[i][r] = reinterpret_cast<const h16_t*>(zb)[tid + 256 * (2 * half + i) + r * (G::PZ / 2)];
+    };
+    auto emit_store = [&](int tt, int half) {       // dz[tt] (tt >= T: nothing)
+        const unsigned none = tt >= T ? OOB : 0u;
+        const int tc = tt >= T ? 0 : tt;
+        const unsigned so_c = (unsigned)(((size_t)tc * B + row0) * 4 * U * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(e_row, rs_zc, (vo_zc + 64 * 16 * half) | none, so_c, 0);
+        const unsigned so_t = kb ? (unsigned)((((size_t)tc * (B >> 5) + (row0 >> 5)) * 4 * U) * 64) : (unsigned)(((size_t)tc * B + row0) * 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x2_t v;
+            v[0] = e_col[i][0] | (e_col[i][1] << 16);
+            v[1] = e_col[i][2] | (e_col[i][3] << 16);
+            __builtin_amdgcn_raw_buffer_store_b64(v, rs_zt, vo_zt | none, so_t + st_zt * (2 * half + i), 0);
+        }
+    };
+
+    const uint4* wl = reinterpret_cast<const uint4*>(smem + G::OFF_W) + (size_t)w * 4 * G::KL * 64 + lane;
+    constexpr int PFB = 3;
+    RES_BARRIER();
+    RES_TR_DECL;
+    for (int kk = 0; kk < T; ++kk) {
+        const int t = T - 1 - kk;
+        RES_TR(0);
+        const char* zin = smem + G::OFF_Z + (kk & 1) * 4 * G::PZ + row * G::PZ + g4 * 16;
+        char* zout = smem + G::OFF_Z + ((kk + 1) & 1) * 4 * G::PZ + row * G::PZ;
+        mnn_f32x4 acc[4];
+        {
+            frag_t b[G::KS], lw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lw[j] = __builtin_bit_cast(frag_t, wl[(j * G::KL + 0) * 64]);
+#pragma unroll
+            for (int i = 0; i < PFB; ++i) b[i] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(zin + 64 * i));
+#pragma unroll
+            for (int s = 0; s < G::KS; ++s) {
+                if (s + PFB < G::KS) b[s + PFB] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(zin + 64 * (s + PFB)));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const mnn_f32x4 c0 = s == 0 ? mnn_f32x4{0.f, 0.f, 0.f, 0.f} : acc[j];
+                    acc[j] = F::mfma16((s & 3) == 3 ? lw[j] : wr[j][s - (s >> 2)], b[s], c0);
+                }
+                if ((s & 3) == 3 && s + 4 < G::KS) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) lw[j] = __builtin_bit_cast(frag_t, wl[(j * G::KL + (s >> 2) + 1) * 64]);
+                }
+                if (s == 0) emit_read(kk & 1, 0);               // the previous step's outputs, in the shadow of the MFMA stream
+                if (s == 5) emit_store(t + 1, 0);
+                if (s == 6) emit_read(kk & 1, 1);
+                if (s == 11) emit_store(t + 1, 1);
+                __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400 | 0x40 | 0x200);
+            }
+        }
+        RES_TR(1);
+        // ---- pointwise: bank b keeps tile b; register r = unit u0 + r ----
+        float dhr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float lo = bank & 1 ? acc[1][r] : acc[0][r], hi = bank & 1 ? acc[3][r] : acc[2][r];
+            dhr[r] = bank & 2 ? hi : lo;
+        }
+        h16_t b4[4][4];                                 // [gate][unit]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned g01 = r < 2 ? gq0[2 * r] : gq1[2 * r - 4], g23 = r < 2 ? gq0[2 * r + 1] : gq1[2 * r - 3];
+            const float gi = F::lo(g01), gg = F::hi(g01), gf = F::lo(g23), go = F::hi(g23);
+            const float dv = __uint_as_float(dq[r]);
+            const float dh = (DROP ? dv * ikp * (float)((mq >> (8 * r)) & 0xffu) : dv) + dhr[r];
+            const float tc = fast_tanh(cnext[r]);
+            const float d_o = dh * tc;
+            const float d_c = dh * go * (1.f - tc * tc) + dcreg[r];
+            const float cprev = t > 0 ? __uint_as_float(cq[r]) : 0.f;
+            const float dzv[4] = {d_c * gg * gi * (1.f - gi), d_c * gi * (1.f - gg * gg), d_c * cprev * gf * (1.f - gf), d_o * go * (1.f - go)};
+            dcreg[r] = d_c * gf;
+            cnext[r] = cprev;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                b4[g][r] = F::cvt(dzv[g]);
+                dbv[g][r] += F::f32(b4[g][r]);          // the (16-bit) values the weight-gradient GEMMs see
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2_t v;
+            v[0] = (unsigned)b4[g][0] | ((unsigned)b4[g][1] << 16);
+            v[1] = (unsigned)b4[g][2] | ((unsigned)b4[g][3] << 16);
+            *reinterpret_cast<u32x2_t*>(zout + gate_perm_col(g, u0) * 2) = v;
+        }
+        RES_TR(2);
+        if (kk + 1 < T) request(t - 1);
+        RES_BARRIER();
+        RES_TR(3);
+        RES_TR_FLUSH(1, kk);
+    }
+    emit_read(T & 1, 0);
+    emit_store(0, 0);
+    emit_read(T & 1, 1);
+    emit_store(0, 1);
+    if (A.db_p != nullptr) {                            // bias gradient: sums over this workgroup's four rows and all steps
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = dbv[g][r];
+                v += dpp_xor1(v);
+                v += dpp_xor2(v);
+                if (row == 0) atomicAdd(A.db_p + gate_perm_col(g, u0 + r), v);
+            }
+    }
 }
 
 extern "C" int mnn_lstm_resident_ok(int B, int units) {
@@ -282,6 +538,11 @@ template <typename F> static res_fwd_fn res_fwd_pick(bool drop, bool save) {
     return save ? lstm_res_fwd_kernel<256, F, false, true> : lstm_res_fwd_kernel<256, F, false, false>;
 }
 static res_fwd_fn res_fwd_kernel(bool f16, bool drop, bool save) { return f16 ? res_fwd_pick<Fp16F>(drop, save) : res_fwd_pick<Bf16F>(drop, save); }
+typedef void (*res_bwd_fn)(ResBwdArgs);
+static res_bwd_fn res_bwd_kernel(bool f16, bool drop) {
+    if (f16) return drop ? lstm_res_bwd_kernel<256, Fp16F, true> : lstm_res_bwd_kernel<256, Fp16F, false>;
+    return drop ? lstm_res_bwd_kernel<256, Bf16F, true> : lstm_res_bwd_kernel<256, Bf16F, false>;
+}
 static hipError_t res_prepare() {
     static bool done[64];
     int dev = 0;
@@ -291,6 +552,10 @@ static hipError_t res_prepare() {
     if (done[dev]) return hipSuccess;
     for (int i = 0; i < 8; ++i) {
         e = hipFuncSetAttribute((const void*)res_fwd_kernel(i & 1, i & 2, i & 4), hipFuncAttributeMaxDynamicSharedMemorySize, ResGeom<256>::LDS);
+        if (e != hipSuccess) return e;
+    }
+    for (int i = 0; i < 4; ++i) {
+        e = hipFuncSetAttribute((const void*)res_bwd_kernel(i & 1, i & 2), hipFuncAttributeMaxDynamicSharedMemorySize, ResBwdGeom<256>::LDS);
         if (e != hipSuccess) return e;
     }
     done[dev] = true;
@@ -308,12 +573,36 @@ extern "C" int mnn_lstm_resident_fwd(mnn_stream_t s, int T, int B, const mnn_lst
     MNN_REQUIRE(L->yT == nullptr || (L->ld_yT >= T * B && (L->ld_yT & 3) == 0), "mnn_lstm_resident_fwd: ld_yT too small / not a multiple of 4");
     MNN_REQUIRE((L->mask == nullptr) == (keep_prob >= 1.0f) && (L->mask == nullptr || L->y != nullptr),
                 "mnn_lstm_resident_fwd: a keep mask and a y buffer are needed exactly when keep_prob < 1");
+    MNN_REQUIRE((L->gates != nullptr) == (L->hT != nullptr) && (L->gates != nullptr) == (L->yT != nullptr),
+                "mnn_lstm_resident_fwd: the saved gates, hT and yT come together (training) or not at all");
+    MNN_REQUIRE((size_t)T * B * 256 * 8 < ((size_t)1 << 31) && (size_t)256 * (size_t)(L->ld_hT > L->ld_yT ? L->ld_hT : L->ld_yT) * 2 < ((size_t)1 << 31),
+                "mnn_lstm_resident_fwd: a tensor of this call exceeds the 2 GB a buffer descriptor addresses");
     ResFwdArgs a{};
     a.xproj = (const h16_t*)L->xproj; a.wh_t = (const h16_t*)L->wh_t; a.gates = (h16_t*)L->gates; a.c = L->c; a.h = (h16_t*)L->h; a.y = (h16_t*)L->y;
     a.mask = L->mask; a.hT = (h16_t*)L->hT; a.ld_hT = L->ld_hT; a.yT = (h16_t*)L->yT; a.ld_yT = L->ld_yT;
     a.T = T; a.B = B; a.kp = keep_prob;
     MNN_HIP(res_prepare());
     hipLaunchKernelGGL(res_fwd_kernel(L->f16 != 0, L->mask != nullptr, L->gates != nullptr), dim3(B / 4), dim3(256), ResGeom<256>::LDS, st, a);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+extern "C" int mnn_lstm_resident_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L, float keep_prob) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(L && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm_resident_bwd: bad arguments");
+    MNN_REQUIRE(mnn_lstm_resident_ok(B, L->units), "mnn_lstm_resident_bwd: units must be 256 and B a multiple of 4 (B=%d u=%d)", B, L->units);
+    MNN_REQUIRE(L->dh_ext && L->wh_p && L->gates && L->c, "mnn_lstm_resident_bwd: null pointer");
+    MNN_REQUIRE(L->c0 == nullptr && L->dz == nullptr, "mnn_lstm_resident_bwd: no initial state / f32 dz output in this form");
+    MNN_REQUIRE(L->dzT_t == nullptr || (L->ld_t == 0 ? (B & 31) == 0 : (L->ld_t >= T * B && (L->ld_t & 3) == 0)),
+                "mnn_lstm_resident_bwd: ld_t too small / not a multiple of 4 (0 = the K-blocked layout [T*B/32][4u][32], B a multiple of 32)");
+    MNN_REQUIRE((size_t)T * B * 256 * 8 < ((size_t)1 << 31) && (size_t)1024 * (size_t)L->ld_t * 2 < ((size_t)1 << 31),
+                "mnn_lstm_resident_bwd: a tensor of this call exceeds the 2 GB a buffer descriptor addresses");
+    ResBwdArgs a{};
+    a.dh_ext = L->dh_ext; a.wh_p = (const h16_t*)L->wh_p; a.gates = (const h16_t*)L->gates; a.c = L->c; a.mask = keep_prob < 1.0f ? L->mask : nullptr;
+    a.dzc = (h16_t*)L->dz_T; a.dzT = (h16_t*)L->dzT_t; a.ld_t = L->ld_t; a.db_p = L->db_p;
+    a.T = T; a.B = B; a.kp = keep_prob;
+    MNN_HIP(res_prepare());
+    hipLaunchKernelGGL(res_bwd_kernel(L->f16 != 0, a.mask != nullptr), dim3(B / 4), dim3(256), ResBwdGeom<256>::LDS, st, a);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

@@ -258,7 +258,10 @@ class LstmStack:
             db_p = self._accum(l, dev)[2]
             e = ops.lstm2_bwd_layer(dh.view(T, B, u), p["wh_p"], cx["gates"], cx["c"], None, dzc, ops.lstm_seq_bwd_workspace(B, u, dev), dzT, db_p,
                                     cx["mask"] if keep_prob < 1.0 else None, gates_dtype=self.dtype)
-            ops.lstm_rowpar_bwd(T, B, e, keep_prob, self._rp_workspace(l, T, B, dev))
+            if self._resident(l, B):
+                ops.lstm_resident_bwd(T, B, e, keep_prob)
+            else:
+                ops.lstm_rowpar_bwd(T, B, e, keep_prob, self._rp_workspace(l, T, B, dev))
             st[l] = dict(dzT=dzT, dzc=dzc, db_p=db_p)
             if l > 0:
                 dh = torch.empty((N, p["n_in"]), device=dev)

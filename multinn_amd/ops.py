@@ -376,6 +376,11 @@ def lstm_resident_fwd(T, B, L, keep_prob):
     call("mnn_lstm_resident_fwd", _stream(), T, B, C.byref(L), float(keep_prob))
 
 
+def lstm_resident_bwd(T, B, L, keep_prob):
+    """L: descriptor of lstm2_bwd_layer, as for lstm_rowpar_bwd; no workspace."""
+    call("mnn_lstm_resident_bwd", _stream(), T, B, C.byref(L), float(keep_prob))
+
+
 def lstm_rowpar_check(ws):
     st = C.c_int(0)
     call("mnn_lstm_rowpar_status", _ptr(ws), C.byref(st))

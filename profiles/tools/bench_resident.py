@@ -66,6 +66,34 @@ def main():
     out["resident_ms"] = timed(lambda: ops.lstm_resident_fwd(T, B, db, keep))
     out["resident_us_per_step"] = out["resident_ms"] * 1e3 / T
     out["finite"] = bool(torch.isfinite(b["c"]).all())
+    # ---- backward on the forward's saved tensors ----
+    dh = (torch.randn((T, B, u), generator=g) * 0.01).to(dev)
+    whp = wh.t().contiguous()
+    kbl = N % 64 == 0 and B % 32 == 0 and "--plain" not in sys.argv
+
+    def bbuf():
+        return dict(dzc=torch.zeros((T, B, 4 * u), device=dev, dtype=dt),
+                    dzT=torch.zeros((N // 32, 4 * u, 32), device=dev, dtype=dt) if kbl else torch.zeros((4 * u, N), device=dev, dtype=dt),
+                    db=torch.zeros(4 * u, device=dev))
+    ba, bb = bbuf(), bbuf()
+    wsb = ops.lstm_seq_bwd_workspace(B, u, dev)
+    src = a if rp else b
+    ea = ops.lstm2_bwd_layer(dh, whp, src["gates"], src["c"], None, ba["dzc"], wsb, ba["dzT"], ba["db"], mask, gates_dtype=dt)
+    eb = ops.lstm2_bwd_layer(dh, whp, src["gates"], src["c"], None, bb["dzc"], wsb, bb["dzT"], bb["db"], mask, gates_dtype=dt)
+    if rp:
+        ops.lstm_rowpar_bwd(T, B, ea, keep, ws)
+    ops.lstm_resident_bwd(T, B, eb, keep)
+    torch.cuda.synchronize()
+    if rp:
+        ops.lstm_rowpar_check(ws)
+        for k in ba:
+            x, y = ba[k].float(), bb[k].float()
+            out["bwd_maxdiff_" + k] = float((x - y).abs().max())
+            out["bwd_maxabs_" + k] = float(x.abs().max())
+        out["rowpar_bwd_ms"] = timed(lambda: ops.lstm_rowpar_bwd(T, B, ea, keep, ws))
+    out["resident_bwd_ms"] = timed(lambda: ops.lstm_resident_bwd(T, B, eb, keep))
+    out["resident_bwd_us_per_step"] = out["resident_bwd_ms"] * 1e3 / T
+    out["bwd_finite"] = bool(torch.isfinite(bb["dzc"].float()).all())
     print(json.dumps(out))
 
 

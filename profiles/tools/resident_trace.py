@@ -37,5 +37,19 @@ step = np.diff(st[:, 0]) * 0.01
 print(f"forward: median step {np.median(step):.3f} us")
 for k in range(8):
     print(f"    {names[k]:22s} median {np.median(seg[:, k]):6.3f}  mean {np.mean(seg[:, k]):6.3f} us")
+dh = (torch.randn((T, B, u), generator=g) * 0.01).to(dev)
+dzc = torch.zeros((T, B, 4 * u), device=dev, dtype=dt)
+dzT = torch.zeros((N // 32, 4 * u, 32), device=dev, dtype=dt)
+db = torch.zeros(4 * u, device=dev)
+e = ops.lstm2_bwd_layer(dh, wh.t().contiguous(), bufs["gates"], bufs["c"], None, dzc, ops.lstm_seq_bwd_workspace(B, u, dev), dzT, db, mask, gates_dtype=dt)
+for _ in range(3):
+    ops.lstm_resident_bwd(T, B, e, 0.9)
+torch.cuda.synchronize()
+assert lib.mnn_lstm_resident_trace(buf.ctypes.data_as(C.c_void_p)) == 0
+st = buf[1, 8:min(T, 512) - 8, :4].astype(np.float64)
+seg = np.diff(st, axis=1) * 0.01
+print(f"backward: median step {np.median(np.diff(st[:, 0]) * 0.01):.3f} us")
+for k, nm in enumerate(["MFMA phase (+ emit)", "pointwise", "requests + barrier"]):
+    print(f"    {nm:22s} median {np.median(seg[:, k]):6.3f}  mean {np.mean(seg[:, k]):6.3f} us")
 clk = np.diff(buf[0, 8:min(T, 512) - 8, 9].astype(np.float64))
 print(f"shader clock: {np.median(clk / (step * 1e-6)) / 1e9:.3f} GHz (s_memtime ticks per wall-clock second over a step)")
