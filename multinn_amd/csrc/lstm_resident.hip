@@ -199,9 +199,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const uint4* wl = reinterpret_cast<const uint4*>(smem + G::OFF_W) + (size_t)w * G::WPW * 64 + lane;
     // order of the k-steps inside a group: the two LDS-resident ones sit two register k-steps apart, so that the four fragment registers
     // of the first can be re-requested for the second while 8 MFMAs run
-    constexpr int ORD[8] = {0, 1, 6, 2, 3, 7, 4, 5};
+    constexpr int ORD[8] = {0, 1, 6, 2, 3, 4, 7, 5};
     constexpr int PFB = 3;                          // state fragments requested ahead of their MFMAs (LDS latency ~ 2 k-steps of 4 MFMAs)
 
+    static_assert(G::KL == 2 && G::XL == 0, "the fragment ring below assumes two LDS-resident k-steps per tile");
+    frag_t lw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lw[j] = __builtin_bit_cast(frag_t, wl[(j * G::KL + 0) * 64]);
     RES_TR_DECL;
     for (int t = 0; t < T; ++t) {
         RES_TR(0);
@@ -221,19 +225,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         mnn_f32x4 acc[2][4];
         // the MFMA stream of one group of four tiles; `filler(i)` is called between k-steps (the pointwise of the previous group)
         auto group = [&](int q, mnn_f32x4 (&ac)[4]) {
-            auto in_lds = [&](int s_) { return s_ >= G::KR || (s_ == G::KR - 1 && 4 * q < G::XL); };
-            auto lds_frag = [&](int s_, int j) { return s_ >= G::KR ? ((4 * q + j) * G::KL + (s_ - G::KR)) * 64 : (G::NT * G::KL + 4 * q + j) * 64; };
-            frag_t b[G::KS], lw[4];
-            int nxt = 0;                                     // position (in ORD) of the next LDS-resident k-step to request
-            auto request = [&]() {
-                while (nxt < G::KS && !in_lds(ORD[nxt])) ++nxt;
-                if (nxt < G::KS) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) lw[j] = __builtin_bit_cast(frag_t, wl[lds_frag(ORD[nxt], j)]);
-                    ++nxt;
-                }
-            };
-            request();
+            // the group's two LDS-resident k-steps sit at positions 2 and 6 of ORD.  `lw` arrives holding the first (requested while the previous
+            // group ran its last k-steps -- across the timestep boundary too: weights do not change), is re-requested for the second right behind
+            // the first's MFMAs (four k-steps ahead) and for the NEXT group's first right behind the second's.
+            frag_t b[G::KS];
 #pragma unroll
             for (int i = 0; i < PFB; ++i) b[i] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(hin + 64 * ORD[i]));
 #pragma unroll
@@ -243,9 +238,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const mnn_f32x4 c0 = i == 0 ? mnn_f32x4{0.f, 0.f, 0.f, 0.f} : ac[j];
-                    ac[j] = F::mfma16(in_lds(s) ? lw[j] : wr[4 * q + j][s < G::KR ? s : 0], b[i], c0);
+                    ac[j] = F::mfma16(s >= G::KR ? lw[j] : wr[4 * q + j][s < G::KR ? s : 0], b[i], c0);
                 }
-                if (in_lds(s)) request();
+                if (s >= G::KR) {
+                    const int qn = s + 1 < G::KS ? q : (q + 1) % G::NG, sn = s + 1 < G::KS ? s + 1 : G::KR;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) lw[j] = __builtin_bit_cast(frag_t, wl[((4 * qn + j) * G::KL + (sn - G::KR)) * 64]);
+                }
                 if (q == 0 && i == 0) emit_read(t - 1);         // the previous step's outputs leave in the shadow of this step's first MFMAs
                 if (q == 0 && i == 4) emit_store(t - 1);
                 // the state fragments stay PFB k-steps ahead (left alone, the scheduler requests all eight at the top of the group: 16 registers

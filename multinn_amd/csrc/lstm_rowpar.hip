@@ -775,56 +775,58 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
         RP_HANDOFF_FENCE();
         RP_TR(0, trc, t, 4);
+        // Behind the hand-off store: the next step's operands, then everything the row-major outputs need EXCEPT their stores (packing, the
+        // LDS transposes) -- that work runs while the hand-off store is on its way; the flag goes up as soon as that ONE store is out, and
+        // only then are the row-major stores issued (in front of the flag their issue alone was 0.6 us of every timestep's chain).
         int behind = 0;
         if (t + 1 < T) { prefetch(t + 1); behind += 9; }
+        uint2 gpk[8];
         if (A.gates != nullptr) {
-            char* gb = reinterpret_cast<char*>(A.gates + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og / 2;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                uint2 pk;
-                pk.x = (unsigned)F::cvt(gact[0][k]) | ((unsigned)F::cvt(gact[1][k]) << 16);
-                pk.y = (unsigned)F::cvt(gact[2][k]) | ((unsigned)F::cvt(gact[3][k]) << 16);
-                *reinterpret_cast<uint2*>(gb + (size_t)rp_krow(k) * 8 * U) = pk;
+                gpk[k].x = (unsigned)F::cvt(gact[0][k]) | ((unsigned)F::cvt(gact[1][k]) << 16);
+                gpk[k].y = (unsigned)F::cvt(gact[2][k]) | ((unsigned)F::cvt(gact[3][k]) << 16);
             }
-            behind += 8;
         }
-        if (!drop || t + 1 == T) {   // h rows (16 rows x 4 pieces of 16 bytes): with dropout the layer's output is y, and only the final state reads h
-            bf16_t* dst = A.h + (size_t)t * us + (size_t)(m0 + 16 * half + (lane >> 2)) * U + nt * 32 + (lane & 3) * 8;
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sH[lane >> 2][(lane & 3) * 8]);
-            behind += 1;
-        }
-        if (A.hT != nullptr && t + 1 < T) {          // hT[unit][(t+1) B + row]: 16 rows = 32 bytes per unit, through the transposed tile
+        const bool want_h = !drop || t + 1 == T;      // with dropout the layer's output is y, and only the final state reads h
+        const bool want_hT = A.hT != nullptr && t + 1 < T;
+        uint4 p_h = make_uint4(0u, 0u, 0u, 0u), p_hT = p_h, p_y = p_h, p_yT = p_h;
+        if (want_h) p_h = *reinterpret_cast<const uint4*>(&sH[lane >> 2][(lane & 3) * 8]);       // h rows: 16 rows x 4 pieces of 16 bytes
+        if (want_hT) {                                // hT[unit][(t+1) B + row]: 16 rows = 32 bytes per unit, through the transposed tile
             RP_LDS_FENCE();
 #pragma unroll
             for (int j = 0; j < 4; ++j) sT[r * 8 + ((rp_krow(2 * j) + 4 * hh) >> 1)] = hbv[2 * j] | (hbv[2 * j + 1] << 16);
             RP_LDS_FENCE();
-            bf16_t* dst = A.hT + (size_t)(nt * 32 + (lane >> 1)) * A.ld_hT + (size_t)(t + 1) * B + m0 + 16 * half + (lane & 1) * 8;
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(sT + (lane >> 1) * 8 + (lane & 1) * 4);
-            behind += 1;
+            p_hT = *reinterpret_cast<const uint4*>(sT + (lane >> 1) * 8 + (lane & 1) * 4);
         }
         if (drop) {
             RP_LDS_FENCE();
 #pragma unroll
             for (int k = 0; k < 8; ++k) sH[rp_krow(k) + 4 * hh][r] = (bf16_t)yb[k];
             RP_LDS_FENCE();
-            bf16_t* dst = A.y + (size_t)t * us + (size_t)(m0 + 16 * half + (lane >> 2)) * U + nt * 32 + (lane & 3) * 8;
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&sH[lane >> 2][(lane & 3) * 8]);
-            behind += 1;
+            p_y = *reinterpret_cast<const uint4*>(&sH[lane >> 2][(lane & 3) * 8]);
         }
         if (A.yT != nullptr) {
             RP_LDS_FENCE();
 #pragma unroll
             for (int j = 0; j < 4; ++j) sT[r * 8 + ((rp_krow(2 * j) + 4 * hh) >> 1)] = yb[2 * j] | (yb[2 * j + 1] << 16);
             RP_LDS_FENCE();
-            bf16_t* dst = A.yT + (size_t)(nt * 32 + (lane >> 1)) * A.ld_yT + (size_t)t * B + m0 + 16 * half + (lane & 1) * 8;
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(sT + (lane >> 1) * 8 + (lane & 1) * 4);
-            behind += 1;
+            p_yT = *reinterpret_cast<const uint4*>(sT + (lane >> 1) * 8 + (lane & 1) * 4);
         }
         RP_LDS_FENCE();
         RP_TR(0, trc, t, 5);
         rp_wait_all_but(behind);
         if (lane == 0) rp_raise(flags + 2 * nt + half, (unsigned)(t + 1), local);
         RP_TR(0, trc, t, 6);
+        if (A.gates != nullptr) {
+            char* gb = reinterpret_cast<char*>(A.gates + (size_t)t * 4 * us + (size_t)m0 * 4 * U) + og / 2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) *reinterpret_cast<uint2*>(gb + (size_t)rp_krow(k) * 8 * U) = gpk[k];
+        }
+        if (want_h) *reinterpret_cast<uint4*>(A.h + (size_t)t * us + (size_t)(m0 + 16 * half + (lane >> 2)) * U + nt * 32 + (lane & 3) * 8) = p_h;
+        if (want_hT) *reinterpret_cast<uint4*>(A.hT + (size_t)(nt * 32 + (lane >> 1)) * A.ld_hT + (size_t)(t + 1) * B + m0 + 16 * half + (lane & 1) * 8) = p_hT;
+        if (drop) *reinterpret_cast<uint4*>(A.y + (size_t)t * us + (size_t)(m0 + 16 * half + (lane >> 2)) * U + nt * 32 + (lane & 3) * 8) = p_y;
+        if (A.yT != nullptr) *reinterpret_cast<uint4*>(A.yT + (size_t)(nt * 32 + (lane >> 1)) * A.ld_yT + (size_t)t * B + m0 + 16 * half + (lane & 1) * 8) = p_yT;
         {
             char* cb = reinterpret_cast<char*>(A.c + (size_t)t * us + (size_t)m0 * U) + oc;
 #pragma unroll
@@ -1046,17 +1048,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
         RP_HANDOFF_FENCE();
         RP_TR(1, trc, kk, 4);
+        // As in the forward: the next item's operands and the LDS work of the row-major outputs run while the hand-off stores are on their way,
+        // the flag goes up as soon as those four stores are out, the eight row-major stores are issued behind it.
         int behind = 0;
         if (kk + 1 < T) { prefetch(t - 1); behind += 13; }
-        if (A.dzc != nullptr) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int p = j * 64 + lane, row = p >> 4, pc = p & 15;
-                *reinterpret_cast<uint4*>(A.dzc + ((size_t)t * B + m0 + 16 * half + row) * 4 * U + nt * 128 + pc * 8) = *reinterpret_cast<const uint4*>(&sZ[row][pc * 8]);
-            }
-            behind += 4;
+        // (the pieces are read whether or not their output is wanted: registers defined under one condition and stored under another end up in scratch memory)
+        u32x4_t p_c0, p_c1, p_c2, p_c3, p_t0, p_t1, p_t2, p_t3;
+        {
+            const int p = lane;
+            p_c0 = *reinterpret_cast<const u32x4_t*>(&sZ[(p + 0) >> 4][(p & 15) * 8]);
+            p_c1 = *reinterpret_cast<const u32x4_t*>(&sZ[(p + 64) >> 4][(p & 15) * 8]);
+            p_c2 = *reinterpret_cast<const u32x4_t*>(&sZ[(p + 128) >> 4][(p & 15) * 8]);
+            p_c3 = *reinterpret_cast<const u32x4_t*>(&sZ[(p + 192) >> 4][(p & 15) * 8]);
         }
-        if (A.dzT != nullptr) {                  // dzT[nt*128 + 32 g + unit][t B + row]: 16 rows = 32 bytes per (gate, unit), through the transposed tile
+        {                                        // dzT[nt*128 + 32 g + unit][t B + row]: 16 rows = 32 bytes per (gate, unit), through the transposed tile
             unsigned* sT = reinterpret_cast<unsigned*>(tile);        // [gate*32 + unit][8 row pairs], over the dz tile (read above)
             RP_LDS_FENCE();
 #pragma unroll
@@ -1064,21 +1069,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
                 for (int j = 0; j < 4; ++j) sT[(g * 32 + r) * 8 + ((rp_krow(2 * j) + 4 * hh) >> 1)] = bz[g][2 * j] | (bz[g][2 * j + 1] << 16);
             RP_LDS_FENCE();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int p = j * 64 + lane, gu = p >> 1, piece = p & 1;
-                // ld_t == 0: the K-BLOCKED layout [T B / 32][4U][32] (see the one-wave kernel): the pair's two halves interleave 32-byte runs
-                // inside one contiguous 8 KB slab
-                bf16_t* dst = A.ld_t == 0 ? A.dzT + (((size_t)t * (B >> 5) + rt) * (4 * U) + nt * 128 + gu) * 32 + 16 * half + piece * 8
-                                          : A.dzT + (size_t)(nt * 128 + gu) * A.ld_t + (size_t)t * B + m0 + 16 * half + piece * 8;
-                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(sT + gu * 8 + piece * 4);
-            }
-            behind += 4;
+            const int p = lane;
+            p_t0 = *reinterpret_cast<const u32x4_t*>(sT + ((p + 0) >> 1) * 8 + (p & 1) * 4);
+            p_t1 = *reinterpret_cast<const u32x4_t*>(sT + ((p + 64) >> 1) * 8 + (p & 1) * 4);
+            p_t2 = *reinterpret_cast<const u32x4_t*>(sT + ((p + 128) >> 1) * 8 + (p & 1) * 4);
+            p_t3 = *reinterpret_cast<const u32x4_t*>(sT + ((p + 192) >> 1) * 8 + (p & 1) * 4);
         }
         RP_LDS_FENCE();
         RP_TR(1, trc, kk, 5);
         rp_wait_all_but(behind);
         if (lane == 0) rp_raise(flags + 2 * nt + half, (unsigned)(kk + 1), local);
+        if (A.dzc != nullptr) {
+            auto put = [&](int j, const u32x4_t& v) {
+                const int p = j * 64 + lane, row = p >> 4, pc = p & 15;
+                *reinterpret_cast<u32x4_t*>(A.dzc + ((size_t)t * B + m0 + 16 * half + row) * 4 * U + nt * 128 + pc * 8) = v;
+            };
+            put(0, p_c0); put(1, p_c1); put(2, p_c2); put(3, p_c3);
+        }
+        if (A.dzT != nullptr) {
+            auto put = [&](int j, const u32x4_t& v) {
+                const int p = j * 64 + lane, gu = p >> 1, piece = p & 1;
+                // ld_t == 0: the K-BLOCKED layout [T B / 32][4U][32] (see the one-wave kernel): the pair's two halves interleave 32-byte runs
+                // inside one contiguous 8 KB slab
+                bf16_t* dst = A.ld_t == 0 ? A.dzT + (((size_t)t * (B >> 5) + rt) * (4 * U) + nt * 128 + gu) * 32 + 16 * half + piece * 8
+                                          : A.dzT + (size_t)(nt * 128 + gu) * A.ld_t + (size_t)t * B + m0 + 16 * half + piece * 8;
+                *reinterpret_cast<u32x4_t*>(dst) = v;
+            };
+            put(0, p_t0); put(1, p_t1); put(2, p_t2); put(3, p_t3);
+        }
         RP_TR(1, trc, kk, 6);
         RP_TR(1, trc, kk, 7);
     }

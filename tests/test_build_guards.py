@@ -55,7 +55,7 @@ def test_matrix_core_chain_kernels_use_no_scratch_and_read_operands_ahead(tmp_pa
     from multinn_amd import build
     for fn, names, min_run in (("det_step.hip", ("lstm_step_det_kernel", "dense_det_kernel"), 8), ("rbm.hip", ("rbm_gibbs_mfma_kernel", "rbm_half_mfma_kernel"), 1)):
         out = str(tmp_path / (fn + ".s"))
-        subprocess.check_call([HIPCC] + build.FLAGS + ["-S", "--cuda-device-only", os.path.join(build.CSRC, fn), "-o", out], stderr=subprocess.DEVNULL)
+        subprocess.check_call([HIPCC] + build.flags_for(fn) + ["-S", "--cuda-device-only", os.path.join(build.CSRC, fn), "-o", out], stderr=subprocess.DEVNULL)
         text = open(out).read()
         sizes = {m.group(1): int(m.group(2))
                  for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text)}
@@ -74,3 +74,30 @@ def test_matrix_core_chain_kernels_use_no_scratch_and_read_operands_ahead(tmp_pa
                     cur = 0
             runs.append(cur)
             assert max(runs) >= min_run, (body[:70], runs[:20])
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_resident_recurrence_keeps_its_weights_in_registers(tmp_path):
+    """The CU-resident recurrence (lstm_resident.hip) holds 384 of a lane's 512 registers of recurrent weights for the whole sequence: every
+    instantiation must compile without scratch memory (a spilled fragment is reloaded with `s_waitcnt vmcnt(0)` behind the step's LDS-DMA:
+    the whole memory latency on the chain of every timestep), the matrix cores must read the AGPR-pinned fragments in place (no
+    v_accvgpr_read in front of an MFMA: the MFMA results live in VGPRs, -amdgpu-mfma-vgpr-form), and the step must stay one scheduling region
+    (all 128 MFMAs of a wave's timestep in one basic block of the loop)."""
+    from multinn_amd import build
+    out = str(tmp_path / "res.s")
+    subprocess.check_call([HIPCC] + build.flags_for("lstm_resident.hip") + ["-S", "--cuda-device-only", os.path.join(build.CSRC, "lstm_resident.hip"), "-o", out],
+                          stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    sizes = {m.group(1): int(m.group(2))
+             for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text)}
+    kernels = {k: v for k, v in sizes.items() if "lstm_res_" in k}
+    assert len(kernels) == 12, sizes            # forward: 2 flavours x (mask | none) x (saving | not); backward: 2 flavours x (mask | none)
+    assert all(v == 0 for v in kernels.values()), kernels
+    for body in re.split(r"\n(?=_Z\w+:)", text):
+        if not re.match(r"_Z\w*lstm_res_(fwd|bwd)_kernel", body):
+            continue
+        blocks = re.split(r"\n\.LBB\w+:", body)
+        per_block = [len(re.findall(r"v_mfma_f32_16x16x32", b)) for b in blocks]
+        assert max(per_block) == 128, (body[:60], per_block)
+        assert len(re.findall(r"v_mfma_f32_16x16x32_\w+ \S+ a\[", body)) >= 64, body[:60]      # srcA straight from AGPRs
+        assert "v_accvgpr_read" not in "".join(b for b, n in zip(blocks, per_block) if n == 128), body[:60]

@@ -816,3 +816,112 @@ def test_nade_sample_multi_equals_per_generator_launches():
         assert torch.equal(step[:, 1, :, m], ref) and torch.equal(jobs[m]["nll"], rn)
         assert 0 < float(ref.float().mean()) < 1
     assert not bool(step[:, 0].any()) and not bool(step[:, 2].any())
+
+
+# ------------------------------------------------------------------------------------------------
+def _gate_perm(u):
+    """natural TF column g * u + unit -> (unit / 32) * 128 + g * 32 + unit % 32 (DESIGN.md "LSTM layout")"""
+    unit = np.arange(u)
+    return np.stack([(unit >> 5) * 128 + g * 32 + (unit & 31) for g in range(4)])        # [gate][unit]
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,T,keep,layout,save", [(8, 6, 0.9, "plain", True), (64, 5, 0.9, "kblock", True), (36, 4, 1.0, "plain", True), (12, 7, 0.9, None, False)])
+def test_lstm_resident_recurrence_vs_float64(ops, B, T, keep, layout, save, dt):
+    """The CU-resident recurrence of a 256-unit layer (lstm_resident.hip: four rows per workgroup, the whole recurrent matrix on the CU) against
+    a float64 restatement of rnn.py:104-145 on the SAME 16-bit operands (gate order i, g, f, o; the state it feeds back is the rounded h; the saved
+    gates are the rounded activations): forward h / y / c / gates and both transposed copies, backward dz in all three layouts and the bias
+    gradient.  B = 36 runs nine workgroups off the XCD-contiguous row mapping, save = False is the inference variant (nothing saved)."""
+    u = 256
+    tdt = torch.float16 if dt == "fp16" else torch.bfloat16
+    eps = 2.0 ** -10 if dt == "fp16" else 2.0 ** -7
+    rng = np.random.default_rng(11)
+    r16 = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(tdt)            # noqa: E731
+    wh_t = r16(rng.normal(0, 0.06, (4 * u, u)))                                     # [gate-interleaved row][k]
+    xproj = r16(rng.normal(0, 1.2, (T, B, u, 4)))                                    # gate-minor
+    mask = (rng.random((T, B, u)) < keep).astype(np.uint8) if keep < 1.0 else None
+    N = T * B
+    Np = N
+    d = lambda t_: t_.to(DEV)                                                        # noqa: E731
+    gates = torch.zeros((T, B, 4 * u), device=DEV, dtype=tdt) if save else None
+    c = torch.zeros((T, B, u), device=DEV)
+    h = torch.zeros((T, B, u), device=DEV, dtype=tdt)
+    y = torch.zeros((T, B, u), device=DEV, dtype=tdt) if mask is not None else None
+    hT = torch.zeros((u, Np), device=DEV, dtype=tdt) if save else None
+    yT = torch.zeros((u, Np), device=DEV, dtype=tdt) if save else None
+    md = dev(mask) if mask is not None else None
+    assert ops.lstm_resident_ok(B, u) and not ops.lstm_resident_ok(B + 1, u) and not ops.lstm_resident_ok(B, 512)
+    L = ops.lstm2_fwd_layer(d(xproj).view(T, B, 4 * u), d(wh_t), None, None, gates, c, h, hT, y, md, yT=yT, gates_dtype=tdt, xproj_dtype=tdt)
+    ops.lstm_resident_fwd(T, B, L, keep)
+    torch.cuda.synchronize()
+    # ---- float64 forward on the same operands ----
+    perm = _gate_perm(u)
+    W = wh_t.double().numpy()                                                        # z[n] += sum_k h[k] W[n][k]
+    X = xproj.double().numpy()
+    sig = lambda a: 1.0 / (1.0 + np.exp(-a))                                        # noqa: E731
+    hp, cp = np.zeros((B, u)), np.zeros((B, u))
+    ref = dict(g=np.zeros((T, B, u, 4)), c=np.zeros((T, B, u)), h=np.zeros((T, B, u)))
+    for t in range(T):
+        z = np.stack([X[t, :, :, g] + hp @ W[perm[g]].T for g in range(4)], -1)     # [B, u, 4]
+        gi, gg, gf, go = sig(z[..., 0]), np.tanh(z[..., 1]), sig(z[..., 2]), sig(z[..., 3])
+        cp = gg * gi + cp * gf
+        hv = np.tanh(cp) * go
+        ref["g"][t] = np.stack([gi, gg, gf, go], -1)
+        ref["c"][t] = cp
+        ref["h"][t] = hv
+        hp = h[t].double().cpu().numpy() if (mask is None or t + 1 == T) else r16(hv).double().numpy()     # the 16-bit state the kernel feeds back
+    got_c = c.cpu().numpy()
+    assert np.abs(got_c - ref["c"]).max() < 4 * eps, np.abs(got_c - ref["c"]).max()
+    if mask is None:
+        assert np.abs(h.double().cpu().numpy() - ref["h"]).max() < 2 * eps
+        out16 = h
+    else:
+        assert np.abs(h[-1].double().cpu().numpy() - ref["h"][-1]).max() < 2 * eps          # only the final state leaves through h
+        yref = r16(ref["h"]).double().numpy() / keep * mask
+        assert np.abs(y.double().cpu().numpy() - yref).max() < 3 * eps
+        out16 = y
+    if save:
+        assert np.abs(gates.double().cpu().numpy().reshape(T, B, u, 4) - ref["g"]).max() < 2 * eps
+        # h^T[unit][(t + 1) B + row] = h[t] (column block 0 untouched: h_{-1}), y^T[unit][t B + row] = the layer's output
+        assert torch.equal(yT.view(u, T, B), out16.permute(2, 0, 1))
+        hh = r16(ref["h"]).double().numpy()
+        assert np.abs(hT.view(u, T, B)[:, 1:].double().cpu().numpy() - np.transpose(hh, (2, 0, 1))[:, :-1]).max() < 2 * eps
+        assert float(hT.view(u, T, B)[:, 0].abs().max()) == 0.0
+    if not save:
+        return
+    # ---- backward on the kernel's own saved tensors ----
+    dh = torch.from_numpy(rng.normal(0, 0.02, (T, B, u)).astype(np.float32)).to(DEV)
+    wh_p = wh_t.t().contiguous().to(DEV)                                             # [k][gate-interleaved column]
+    kb = layout == "kblock"
+    dzc = torch.zeros((T, B, 4 * u), device=DEV, dtype=tdt)
+    dzT = torch.zeros((N // 32, 4 * u, 32), device=DEV, dtype=tdt) if kb else torch.zeros((4 * u, Np), device=DEV, dtype=tdt)
+    db = torch.zeros(4 * u, device=DEV)
+    E = ops.lstm2_bwd_layer(dh, wh_p, gates, c, None, dzc, ops.lstm_seq_bwd_workspace(B, u, DEV), dzT, db, md, gates_dtype=tdt)
+    ops.lstm_resident_bwd(T, B, E, keep)
+    torch.cuda.synchronize()
+    Gs = gates.double().cpu().numpy().reshape(T, B, u, 4)
+    Cs = c.double().cpu().numpy()
+    dz_ref = np.zeros((T, B, 4 * u))
+    dcv, dz_next = np.zeros((B, u)), np.zeros((B, 4 * u))
+    for t in range(T - 1, -1, -1):
+        gi, gg, gf, go = (Gs[t, :, :, k] for k in range(4))
+        dhv = dh[t].double().cpu().numpy() * (mask[t] / keep if mask is not None else 1.0) + dz_next @ W      # sum_n dz[n] W[n][k]
+        tc = np.tanh(Cs[t])
+        d_o = dhv * tc
+        d_c = dhv * go * (1 - tc * tc) + dcv
+        cprev = Cs[t - 1] if t > 0 else np.zeros((B, u))
+        dzs = [d_c * gg * gi * (1 - gi), d_c * gi * (1 - gg * gg), d_c * cprev * gf * (1 - gf), d_o * go * (1 - go)]
+        dcv = d_c * gf
+        for g in range(4):
+            dz_ref[t][:, perm[g]] = dzs[g]
+        dz_next = dzc[t].double().cpu().numpy()                                      # the 16-bit values the kernel feeds back
+    scale = np.abs(dz_ref).max()
+    got = dzc.double().cpu().numpy()
+    assert np.abs(got - dz_ref).max() < 3 * eps * scale, (np.abs(got - dz_ref).max(), scale)
+    flat = dzc.view(N, 4 * u)
+    if kb:
+        assert torch.equal(dzT.permute(0, 2, 1).reshape(N, 4 * u), flat)
+    else:
+        assert torch.equal(dzT[:, :N].t(), flat)
+    db_ref = flat.double().sum(0).cpu().numpy()
+    assert np.abs(db.cpu().numpy() - db_ref).max() < 1e-5 * max(1.0, np.abs(db_ref).max()) + 1e-6
