@@ -147,8 +147,10 @@ class LstmStack:
     # and a workgroup owns four batch rows, so a timestep has no hand-off between workgroups (MULTINN_RESIDENT=0: row-parallel kernels only)
     resident = os.environ.get("MULTINN_RESIDENT", "1") != "0"
 
-    def _resident(self, l, B):
-        return self.resident and not self.rowpar_xproj_f32 and ops.lstm_resident_ok(B, self.packed[l]["u"])
+    def _resident(self, l, B, T):
+        # (the kernels address their tensors through 2 GB buffer descriptors: the saved gates [T, B, 4u] in 16 bits are the largest)
+        return (self.resident and not self.rowpar_xproj_f32 and ops.lstm_resident_ok(B, self.packed[l]["u"])
+                and T * B * self.packed[l]["u"] * 8 < 2 ** 31)
 
     @property
     def rowpar_xproj_dtype(self):
@@ -225,7 +227,7 @@ class LstmStack:
                 yT = nxt[:u] if nxt is not None else zalloc((u, Np), device=dev, dtype=self.dtype)
             d = ops.lstm2_fwd_layer(xproj, p["wh_t"], None, None, gates, c, h, hT, y, mask, yT=yT, gates_dtype=self.dtype,
                                     xproj_dtype=self.rowpar_xproj_dtype)
-            if self._resident(l, B):
+            if self._resident(l, B, T):
                 ops.lstm_resident_fwd(T, B, d, keep_prob)
             else:
                 ops.lstm_rowpar_fwd(T, B, d, keep_prob, self._rp_workspace(l, T, B, dev))
@@ -258,7 +260,7 @@ class LstmStack:
             db_p = self._accum(l, dev)[2]
             e = ops.lstm2_bwd_layer(dh.view(T, B, u), p["wh_p"], cx["gates"], cx["c"], None, dzc, ops.lstm_seq_bwd_workspace(B, u, dev), dzT, db_p,
                                     cx["mask"] if keep_prob < 1.0 else None, gates_dtype=self.dtype)
-            if self._resident(l, B):
+            if self._resident(l, B, T):
                 ops.lstm_resident_bwd(T, B, e, keep_prob)
             else:
                 ops.lstm_rowpar_bwd(T, B, e, keep_prob, self._rp_workspace(l, T, B, dev))

@@ -826,12 +826,14 @@ def _gate_perm(u):
 
 
 @pytest.mark.parametrize("dt", ["fp16", "bf16"])
-@pytest.mark.parametrize("B,T,keep,layout,save", [(8, 6, 0.9, "plain", True), (64, 5, 0.9, "kblock", True), (36, 4, 1.0, "plain", True), (12, 7, 0.9, None, False)])
+@pytest.mark.parametrize("B,T,keep,layout,save", [(8, 6, 0.9, "plain", True), (64, 5, 0.9, "kblock", True), (36, 4, 1.0, "plain", True), (12, 7, 0.9, None, False),
+                                                   (2048, 2, 0.9, "kblock", True)])
 def test_lstm_resident_recurrence_vs_float64(ops, B, T, keep, layout, save, dt):
     """The CU-resident recurrence of a 256-unit layer (lstm_resident.hip: four rows per workgroup, the whole recurrent matrix on the CU) against
     a float64 restatement of rnn.py:104-145 on the SAME 16-bit operands (gate order i, g, f, o; the state it feeds back is the rounded h; the saved
     gates are the rounded activations): forward h / y / c / gates and both transposed copies, backward dz in all three layouts and the bias
-    gradient.  B = 36 runs nine workgroups off the XCD-contiguous row mapping, save = False is the inference variant (nothing saved)."""
+    gradient.  B = 36 runs nine workgroups off the XCD-contiguous row mapping, B = 2048 twice as many workgroups as the device has CUs (no
+    co-residency requirement: they run in rounds), save = False is the inference variant (nothing saved)."""
     u = 256
     tdt = torch.float16 if dt == "fp16" else torch.bfloat16
     eps = 2.0 ** -10 if dt == "fp16" else 2.0 ** -7

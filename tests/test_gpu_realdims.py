@@ -241,8 +241,8 @@ def test_rowpar_recurrence_vs_oracle(units, B, T, max_g, precision, monkeypatch)
 
 
 def test_timed_kernels_long_sequence_vs_oracle(monkeypatch):
-    """The TIMED kernel forms of the bench step -- the wave-pair row-parallel recurrence `lstm_rowpar_fwd2 / bwd2<512 | 256, Fp16F>` with TWO
-    row tiles per workgroup, the split-operand matrix-core NADE forward, the K-blocked dz^T weight-gradient operand -- against the float64
+    """The TIMED kernel forms of the bench step -- the wave-pair row-parallel recurrence `lstm_rowpar_fwd2 / bwd2<512, Fp16F>` with TWO
+    row tiles per workgroup for layer 1, the CU-resident recurrence `lstm_res_fwd / bwd_kernel<256, Fp16F>` for layer 2, the split-operand matrix-core NADE forward, the K-blocked dz^T weight-gradient operand -- against the float64
     oracle over T = 64 timesteps (the other oracle cases stop at T <= 9): flag epochs, the 8-chunk dz ring and the K-blocked layout are
     exercised for 64 hand-offs per row tile, at the real widths and the bench density rho = 0.03."""
     from multinn_amd import RnnNade
@@ -263,6 +263,7 @@ def test_timed_kernels_long_sequence_vs_oracle(monkeypatch):
     gen.build_pianoroll(dev(x), None, is_train=True, mode="train")
     assert gen._stack._rowpar(B, T) and gen._ctx["lstm"][0].get("rowpar") and gen._nade_mfma() and gen._nade_exact()
     assert gen._stack.kblock_wgrads
+    assert gen._stack._resident(1, B, T) and not gen._stack._resident(0, B, T)      # layer 2 (256 units) on the CU-resident kernels, layer 1 row-parallel
     loss = float(gen.metrics["batch/loss"])
     nll = gen.log_probs.cpu().numpy()
     cp_err = np.abs(gen.cond_probs.cpu().numpy() - fw['cond_p'][0]).max()
