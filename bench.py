@@ -605,12 +605,25 @@ def main(argv=None):
                              "the number to watch is avg_timestep_us")
         elif dom in ("mnn_lstm_rowpar_fwd", "mnn_lstm_rowpar_bwd"):
             # one launch per LAYER: every wave carries one 32-row tile through all T steps against a 32-unit weight tile resident in LDS
-            roof = dict(bound="mfma", achieved=rec_flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
+            # (256-unit layers run on the CU-resident kernels instead: their products are counted there)
+            res_layers = [u for u in UNITS if u == 256] if any(k.startswith("mnn_lstm_resident") for k in per_call) else []
+            rp_flops = rec_flops - 2.0 * N * sum(u * 4 * u for u in res_layers)
+            roof = dict(bound="mfma", achieved=rp_flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
                         kernel="lstm_rowpar_%s" % ("bwd" if dom.endswith("bwd") else "fwd"), entry_point=dom, launches_per_step=dom_calls,
                         avg_launch_us=dom_ms * 1e3 / dom_calls, avg_timestep_us=dom_ms * 1e3 / dom_calls / T,
-                        algorithmic_flop_per_launch=rec_flops / dom_calls,
+                        algorithmic_flop_per_launch=rp_flops / dom_calls,
                         note="latency-bound chain: per timestep every row tile exchanges its 32-row h (backward: dz) slice with the other unit "
                              "tiles through L2 (flag per wave); the number to watch is avg_timestep_us")
+        elif dom in ("mnn_lstm_resident_fwd", "mnn_lstm_resident_bwd"):
+            # one launch per 256-unit LAYER: four batch rows per workgroup, the layer's whole recurrent matrix in the registers + LDS of its CU
+            rs_flops = 2.0 * N * sum(u * 4 * u for u in UNITS if u == 256)
+            roof = dict(bound="mfma", achieved=rs_flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
+                        kernel="lstm_res_%s_kernel" % ("bwd" if dom.endswith("bwd") else "fwd"), entry_point=dom, launches_per_step=dom_calls,
+                        avg_launch_us=dom_ms * 1e3 / dom_calls, avg_timestep_us=dom_ms * 1e3 / dom_calls / T,
+                        algorithmic_flop_per_launch=rs_flops / dom_calls,
+                        note="no hand-offs: a timestep is 128 MFMAs per wave (12 of their 16 columns repeat the workgroup's four rows: the matrix "
+                             "streams through the matrix cores once per step whatever the row count) + the gate pointwise; issue-bound, the "
+                             "number to watch is avg_timestep_us")
         elif dom in ("mnn_lstm_seq_fwd", "mnn_lstm_seq_bwd", "mnn_lstm2_seq_fwd", "mnn_lstm2_seq_bwd"):
             fused = dom.startswith("mnn_lstm2")
             launches = (T + 2) if fused else 2 * T            # fused: one three-stage launch per timestep for both layers (lag 2)

@@ -43,7 +43,7 @@ enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_ST
 
 /* ABI version of THIS header: bumped whenever a signature or a descriptor struct changes.  mnn_version() returns the value the library
  * was built with; a loader must compare the two before its first call (multinn_amd/_lib.py load() does) -- a library built for another
- * version reads garbage arguments without any diagnosis otherwise.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
+ * version reads garbage arguments without any diagnosis otherwise.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
  * mnn_pianoroll_shift_timemajor_t / mnn_grad_rows_fanout and the `f16` descriptor fields of round 3 are part of it. */
 #define MNN_ABI_VERSION 114
 int mnn_version(void);

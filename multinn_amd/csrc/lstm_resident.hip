@@ -527,9 +527,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 }
 
+static hipError_t res_prepare();
+// (also raises the kernels' dynamic-LDS limit on this device: the host asks before every use, so never for the first time under stream capture)
 extern "C" int mnn_lstm_resident_ok(int B, int units) {
-    return (units == 256 && B > 0 && (B & 3) == 0) ? 1 : 0;
+    if (!(units == 256 && B > 0 && (B & 3) == 0)) return 0;
+    return res_prepare() == hipSuccess ? 1 : 0;
 }
+static bool res_shape_ok(int B, int units) { return units == 256 && B > 0 && (B & 3) == 0; }
 
 typedef void (*res_fwd_fn)(ResFwdArgs);
 template <typename F> static res_fwd_fn res_fwd_pick(bool drop, bool save) {
@@ -564,7 +568,7 @@ static hipError_t res_prepare() {
 extern "C" int mnn_lstm_resident_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L, float keep_prob) {
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(L && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm_resident_fwd: bad arguments");
-    MNN_REQUIRE(mnn_lstm_resident_ok(B, L->units), "mnn_lstm_resident_fwd: units must be 256 and B a multiple of 4 (B=%d u=%d)", B, L->units);
+    MNN_REQUIRE(res_shape_ok(B, L->units), "mnn_lstm_resident_fwd: units must be 256 and B a multiple of 4 (B=%d u=%d)", B, L->units);
     MNN_REQUIRE(L->xproj && L->wh_t && L->c && L->h, "mnn_lstm_resident_fwd: null pointer");
     MNN_REQUIRE(L->xproj_bf16 != 0, "mnn_lstm_resident_fwd: the input projection must be in the layer's 16-bit type (gate-minor, bias included)");
     MNN_REQUIRE(L->h0 == nullptr && L->c0 == nullptr, "mnn_lstm_resident_fwd: an initial state is not supported by this form (zero state per window)");
@@ -589,7 +593,7 @@ extern "C" int mnn_lstm_resident_fwd(mnn_stream_t s, int T, int B, const mnn_lst
 extern "C" int mnn_lstm_resident_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L, float keep_prob) {
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(L && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm_resident_bwd: bad arguments");
-    MNN_REQUIRE(mnn_lstm_resident_ok(B, L->units), "mnn_lstm_resident_bwd: units must be 256 and B a multiple of 4 (B=%d u=%d)", B, L->units);
+    MNN_REQUIRE(res_shape_ok(B, L->units), "mnn_lstm_resident_bwd: units must be 256 and B a multiple of 4 (B=%d u=%d)", B, L->units);
     MNN_REQUIRE(L->dh_ext && L->wh_p && L->gates && L->c, "mnn_lstm_resident_bwd: null pointer");
     MNN_REQUIRE(L->c0 == nullptr && L->dz == nullptr, "mnn_lstm_resident_bwd: no initial state / f32 dz output in this form");
     MNN_REQUIRE(L->dzT_t == nullptr || (L->ld_t == 0 ? (B & 31) == 0 : (L->ld_t >= T * B && (L->ld_t & 3) == 0)),
