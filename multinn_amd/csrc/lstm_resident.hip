@@ -19,7 +19,6 @@
 
 __device__ __forceinline__ float dpp_xor2(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false)); }
 __device__ __forceinline__ float dpp_xor1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false)); }
-#define RES_LDS_FENCE() asm volatile("" ::: "memory")
 #define RES_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 #ifdef RES_TRACE     // development only (profiles/tools/resident_trace.py): wall-clock stamps (100 MHz) of wave 0 of workgroup 0, [direction][step][stage]
@@ -53,8 +52,7 @@ template <int U> struct ResGeom {
     static constexpr int PH = U * 2 + 64;       // pitch of a state row in LDS: rows 16 banks apart (the 4 rows x 4 k-groups of a B read cover all 64)
     static constexpr int PX = U * 8 + 128;      // pitch of an xproj row in LDS (rows 32 banks apart)
     static constexpr int OFF_W = 0;
-    static constexpr int XL = 0;                // + the fragments of tiles 0..3 at k-step KR - 1 (what is left of the 160 KB): 16 registers less
-    static constexpr int WPW = NT * KL + XL;    // LDS fragments (1 KB each) per wave
+    static constexpr int WPW = NT * KL;         // LDS fragments (1 KB each) per wave
     static constexpr int OFF_H = OFF_W + 4 * WPW * 1024;
     static constexpr int OFF_Y = OFF_H + 2 * 4 * PH;
     static constexpr int OFF_X = OFF_Y + 2 * 4 * PH;
@@ -104,10 +102,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
             for (int s = 0; s < G::KS; ++s) {
                 const uint4 v = *reinterpret_cast<const uint4*>(src + 32 * s);
-                if (s == G::KR - 1 && tl < G::XL) {
-                    wl[(w * G::WPW + G::NT * G::KL + tl) * 64 + lane] = v;
-                    wr[tl][s] = __builtin_bit_cast(frag_t, make_uint4(0u, 0u, 0u, 0u));          // never read
-                } else if (s < G::KR) {
+                if (s < G::KR) {
                     wr[tl][s] = __builtin_bit_cast(frag_t, v);
                     // k-steps 0..3 are pinned to AGPRs, which the matrix cores read directly (left to itself the register allocator treats
                     // AGPRs as spill space and copies every fragment back with four v_accvgpr_read per MFMA); 4..5 stay in VGPRs
@@ -202,7 +197,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     constexpr int ORD[8] = {0, 1, 6, 2, 3, 4, 7, 5};
     constexpr int PFB = 3;                          // state fragments requested ahead of their MFMAs (LDS latency ~ 2 k-steps of 4 MFMAs)
 
-    static_assert(G::KL == 2 && G::XL == 0, "the fragment ring below assumes two LDS-resident k-steps per tile");
+    static_assert(G::KL == 2, "the fragment ring below assumes two LDS-resident k-steps per tile");
     frag_t lw[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) lw[j] = __builtin_bit_cast(frag_t, wl[(j * G::KL + 0) * 64]);
