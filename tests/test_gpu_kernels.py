@@ -927,3 +927,33 @@ def test_lstm_resident_recurrence_vs_float64(ops, B, T, keep, layout, save, dt):
         assert torch.equal(dzT[:, :N].t(), flat)
     db_ref = flat.double().sum(0).cpu().numpy()
     assert np.abs(db.cpu().numpy() - db_ref).max() < 1e-5 * max(1.0, np.abs(db_ref).max()) + 1e-6
+
+
+def test_lstm_resident_entry_points_refuse_what_they_do_not_cover(ops):
+    """Error behaviour of the CU-resident entries through the C ABI (no launch): other widths, a batch off the 4-row workgroups, an f32
+    input projection, saved gates without the transposed copies (they leave together), a mask without keep_prob < 1."""
+    from multinn_amd._lib import MnnError
+    T, B, u = 3, 8, 256
+    dt = torch.float16
+    mk = lambda *s, d=dt: torch.zeros(s, device=DEV, dtype=d)      # noqa: E731
+    wh, c, h = mk(4 * u, u), mk(T, B, u, d=torch.float32), mk(T, B, u)
+    ok = ops.lstm2_fwd_layer(mk(T, B, 4 * u), wh, None, None, None, c, h, None, gates_dtype=dt, xproj_dtype=dt)
+    ops.lstm_resident_fwd(T, B, ok, 1.0)                               # the inference form is fine
+    f32x = ops.lstm2_fwd_layer(mk(T, B, 4 * u, d=torch.float32), wh, None, None, None, c, h, None, gates_dtype=dt)
+    with pytest.raises(MnnError):
+        ops.lstm_resident_fwd(T, B, f32x, 1.0)
+    gates_only = ops.lstm2_fwd_layer(mk(T, B, 4 * u), wh, None, None, mk(T, B, 4 * u), c, h, None, gates_dtype=dt, xproj_dtype=dt)
+    with pytest.raises(MnnError):
+        ops.lstm_resident_fwd(T, B, gates_only, 1.0)
+    masked = ops.lstm2_fwd_layer(mk(T, B, 4 * u), wh, None, None, None, c, h, None, mk(T, B, u), mk(T, B, u, d=torch.uint8), gates_dtype=dt, xproj_dtype=dt)
+    with pytest.raises(MnnError):
+        ops.lstm_resident_fwd(T, B, masked, 1.0)
+    u5 = 512
+    wide = ops.lstm2_fwd_layer(mk(T, B, 4 * u5), mk(4 * u5, u5), None, None, None, mk(T, B, u5, d=torch.float32), mk(T, B, u5), None, gates_dtype=dt,
+                               xproj_dtype=dt)
+    with pytest.raises(MnnError):
+        ops.lstm_resident_fwd(T, B, wide, 1.0)
+    odd = ops.lstm2_fwd_layer(mk(T, 6, 4 * u), wh, None, None, None, mk(T, 6, u, d=torch.float32), mk(T, 6, u), None, gates_dtype=dt, xproj_dtype=dt)
+    with pytest.raises(MnnError):
+        ops.lstm_resident_fwd(T, 6, odd, 1.0)
+    torch.cuda.synchronize()
