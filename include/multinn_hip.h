@@ -45,7 +45,7 @@ enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_ST
  * was built with; a loader must compare the two before its first call (multinn_amd/_lib.py load() does) -- a library built for another
  * version reads garbage arguments without any diagnosis otherwise.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
  * mnn_pianoroll_shift_timemajor_t / mnn_grad_rows_fanout and the `f16` descriptor fields of round 3 are part of it. */
-#define MNN_ABI_VERSION 115
+#define MNN_ABI_VERSION 114
 int mnn_version(void);
 const char* mnn_last_error(void);
 
@@ -301,19 +301,6 @@ int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const
 int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                          const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* a_final,
                          float* d_bias, float* d_w_enc, float* d_w_dec);
-/* The backward scan on the matrix cores (multinn_amd/csrc/nade_bwd_mfma.hip; same mathematics, nade.py:199-229 under autodiff): a wave owns
- * 32 rows x 32 hidden units, the sums over rows of d w_dec = DL^T . H and d w_enc are MFMA products with the rows as K, a workgroup adds
- * ONE f32 atomic per (visible, hidden unit) and 256 rows.  Operands in IEEE half (d nll / d logit as the forward left it in d_bias -- in
- * the fp16 mode it carries the loss scale --, the hidden states, G; sums and state in f32).  For piano-roll-like inputs (a few v = 1 per 32
- * visibles); dense inputs stay on mnn_nade_logprob_bwd.  mnn_nade_bwd_mfma_ok: D % 4 == 0, Hn a multiple of 32 up to 256.
- * mnn_nade_bwd_pack: w_dec f32 [tracks,D,Hn] -> its MFMA fragments (mnn_nade_bwd_pack_bytes bytes, 16-byte aligned), once per weight update.
- * v bytes must be 0 / 1.  run_if (optional): the launch exits unless *run_if == run_val (mnn_density_gate). */
-int mnn_nade_bwd_mfma_ok(int D, int Hn);
-size_t mnn_nade_bwd_pack_bytes(int tracks, int D, int Hn);
-int mnn_nade_bwd_pack(mnn_stream_t s, int tracks, int D, int Hn, const float* w_dec, void* wdp);
-int mnn_nade_logprob_bwd_mfma(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride, int ld_bias,
-                              const float* w_enc, const void* wdp, const float* a_final, float* d_bias, float* d_w_enc, float* d_w_dec,
-                              const int* run_if, int run_val);
 int mnn_nade_sample(mnn_stream_t s, int tracks, int N, int D, int Hn, const float* bias, int ld_bias, const float* w_enc,
                     const float* w_dec, float temperature, uint64_t seed, uint32_t row0, uint32_t sub, uint8_t* samples,
                     long s_track_stride, int s_row_stride, int s_elem_stride, float* nll);

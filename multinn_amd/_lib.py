@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MULTINN_HIP_LIB", os.path.join(HERE, "libmultinn_hip.so"))   # override: A/B builds of the same ABI
 
-ABI_VERSION = 115          # == MNN_ABI_VERSION of include/multinn_hip.h; load() refuses a library built for another one
+ABI_VERSION = 114          # == MNN_ABI_VERSION of include/multinn_hip.h; load() refuses a library built for another one
 F32, BF16, U8, F16 = 0, 1, 2, 3
 GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_A_KBLOCK32 = 1, 2, 8
 
@@ -116,10 +116,6 @@ SIGNATURES["mnn_nade_logprob_fwd_gated"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p,
 SIGNATURES["mnn_nade_logprob_fwd_mfma_gated"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i])
 SIGNATURES["mnn_nade_logprob_fwd_mfma_f32"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i])
 SIGNATURES["mnn_nade_f32_pack"] = (_i, [_p, _p, _l, _i, _p])
-SIGNATURES["mnn_nade_bwd_mfma_ok"] = (_i, [_i, _i])
-SIGNATURES["mnn_nade_bwd_pack_bytes"] = (_sz, [_i, _i, _i])
-SIGNATURES["mnn_nade_bwd_pack"] = (_i, [_p, _i, _i, _i, _p, _p])
-SIGNATURES["mnn_nade_logprob_bwd_mfma"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _i])
 SIGNATURES["mnn_musical_bar_stats"] = (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p])
 SIGNATURES["mnn_musical_note_stats"] = (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p])
 SIGNATURES["mnn_eval_counts"] = (_i, [_p, _p, _p, _l, _p])

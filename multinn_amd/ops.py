@@ -517,35 +517,6 @@ def nade_logprob_bwd(v, bias, w_enc, w_dec, tracks, D, Hn, a_final, d_bias, d_w_
          _ptr(a_final), _ptr(d_bias), _ptr(d_w_enc), _ptr(d_w_dec))
 
 
-def nade_bwd_mfma_ok(D, Hn):
-    return bool(_lib.load().mnn_nade_bwd_mfma_ok(int(D), int(Hn)))
-
-
-def nade_bwd_pack(w_dec, tracks, D, Hn, out=None):
-    """w_dec f32 [tracks,D,Hn] -> the matrix-core backward's fragment image (a flat f16 buffer)."""
-    n = _lib.load().mnn_nade_bwd_pack_bytes(tracks, D, Hn) // 2
-    if out is None:
-        out = torch.empty(n, device=w_dec.device, dtype=torch.float16)
-    _req(out.dtype == torch.float16 and out.numel() == n and out.is_contiguous(), "nade_bwd_pack: out")
-    _req(w_dec.dtype == torch.float32 and w_dec.is_contiguous() and w_dec.numel() == tracks * D * Hn, "nade_bwd_pack: w_dec f32 [tracks,D,Hn]")
-    call("mnn_nade_bwd_pack", _stream(), tracks, D, Hn, _ptr(w_dec), _ptr(out))
-    return out
-
-
-def nade_logprob_bwd_mfma(v, w_enc, wdp, tracks, D, Hn, a_final, d_bias, d_w_enc, d_w_dec, gate=None, run_if=0):
-    """The backward scan on the matrix cores (see include/multinn_hip.h): d_bias holds d nll / d logit (columns tracks*Hn..) on entry."""
-    N = d_bias.shape[0]
-    _req(v.dtype == torch.uint8 and v.is_contiguous() and v.numel() == tracks * N * D, "nade bwd mfma: v u8 [tracks,N,D]")
-    _req(d_bias.dtype == torch.float32 and d_bias.dim() == 2 and d_bias.stride(1) == 1 and d_bias.shape[1] >= tracks * (Hn + D), "nade bwd mfma: d_bias")
-    _req(w_enc.dtype == torch.float32 and w_enc.is_contiguous() and w_enc.numel() == tracks * D * Hn, "nade bwd mfma: w_enc f32 [tracks,D,Hn]")
-    for w in (d_w_enc, d_w_dec):
-        _req(w.dtype == torch.float32 and w.is_contiguous() and w.numel() == tracks * D * Hn, "nade bwd mfma: grad weights f32 [tracks,D,Hn]")
-    _req(a_final.dtype == torch.float32 and a_final.numel() == tracks * N * Hn and a_final.is_contiguous(), "nade bwd mfma: a_final f32 [tracks,N,Hn]")
-    _req(wdp.dtype == torch.float16 and wdp.is_contiguous(), "nade bwd mfma: wdp from nade_bwd_pack")
-    call("mnn_nade_logprob_bwd_mfma", _stream(), tracks, N, D, Hn, _ptr(v), N * D, d_bias.stride(0), _ptr(w_enc), _ptr(wdp), _ptr(a_final),
-         _ptr(d_bias), _ptr(d_w_enc), _ptr(d_w_dec), _ptr(gate), int(run_if))
-
-
 def nade_sample(bias, w_enc, w_dec, tracks, D, Hn, temperature, seed, row0, sub, samples, track_minor=False, nll=None):
     """samples u8 [N, tracks*D]; feature index m*D+i (track_minor False) or i*tracks+m (True, rnn_multinade.py:313-314)."""
     N = bias.shape[0]

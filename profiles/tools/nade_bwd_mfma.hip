@@ -24,7 +24,10 @@
 // ~1.3 TB/s atomic rate (MI355X_MICROARCH.md "Global float atomics").
 // Operands are IEEE half (dl carries the loss scale of the fp16 mode: |dl| <= 256), sums f32; the dense-input form (every other visible a
 // flip) stays on nade_bwd_kernel (the density gate decides).
-#include "common.h"
+// PROTOTYPE, not part of the library (it loses to nade_bwd_kernel: profiles/round5_c_nade_bwd_mfma_notes.md).  To run it again: check out the
+// commit "NADE backward on the matrix cores (rows as K): prototype wired ..." (header entries, loader signatures, ops wrappers, build list) and
+// run profiles/tools/nade_bwd_probe.py there.  Ablation macros: NBM_NO_RANKS, NBM_NO_PAIRS, NBM_NO_EXCHANGE.
+#include "../../multinn_amd/csrc/common.h"
 #include <stdlib.h>
 
 typedef float nb_f32x16 __attribute__((ext_vector_type(16)));

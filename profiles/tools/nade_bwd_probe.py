@@ -1,4 +1,5 @@
-"""NADE backward: the matrix-core scan (mnn_nade_logprob_bwd_mfma) against the vector scan (mnn_nade_logprob_bwd) on the same inputs, in one
+"""(Needs the commit in which nade_bwd_mfma.hip was wired into the library: see the header of profiles/tools/nade_bwd_mfma.hip.)
+NADE backward: the matrix-core scan (mnn_nade_logprob_bwd_mfma) against the vector scan (mnn_nade_logprob_bwd) on the same inputs, in one
 process: small / ragged shapes first (results compared), then the bench shape (joint LSTM-NADE: N = 262 144 rows, D = 440, Hn = 256) timed.
     python profiles/tools/nade_bwd_probe.py [scale]        row weights = U[0,1) * scale: |d nll / d logit| <= scale (the fp16 mode's loss scale keeps it <= 256)"""
 import sys
