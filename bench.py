@@ -20,6 +20,7 @@ Rank 0 prints ONE JSON line: the contract fields plus
   ragged        the step on lengths ~ U{T/2..T} (seed 24), eager launches (a ragged batch needs a host-side row count);
   bf16 / fp32   the same step in the other two modes, with their loss against the headline mode's on the same batch;
   strong        (N > 1) the step with the GLOBAL batch fixed at B, B/N sequences per rank;
+  strong_proxy  (N = 1) the step at B/8 sequences: the per-GPU share of the global batch at 8 GPUs (8 x its rate = the strong leg's ceiling);
   sampling      generated timesteps/s of the sampling scan;
   cpu_baseline  the oracle's torch-CPU port of the reference formulation on the host cores (N = 1 only): one step at C2 [256,128,88,5].
 `--workload c3|c4` (BASELINE configs[2] / [3]: jamming 5 x LSTM-RBM CD-10, composer DBNEncoder -> LSTM-MultiNADE) time the mode classes'
@@ -543,6 +544,17 @@ def main(argv=None):
                 torch.cuda.synchronize()
         sec, loss = time_region(step_fn, steps)
         gen._stack.check()              # a persistent launch that gave up on a bounded spin would have produced garbage: fail loudly
+        if keep:
+            # SURVEY 8(d) asks for the MEDIAN step: `steps` more replays, each between two HIP events (the contract's value stays the mean of
+            # the bracketed region above)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            for e0, e1 in evs:
+                e0.record()
+                step_fn()
+                e1.record()
+            torch.cuda.synchronize()
+            ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+            timed_steps.median_ms = ts[len(ts) // 2]
         res = (sec, float(loss), (gen, x, opt) if keep else None, "hipgraph-replay" if graph else "eager")
         if not keep:
             del gen, x, step_fn
@@ -662,6 +674,7 @@ def main(argv=None):
     out = {
         "metric": "piano-roll timesteps/sec (train step), 5-track LSTM-NADE", "value": world * B * T / sec,
         "unit": "timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": sec * 1e3,
+        "ms_per_step_median": getattr(timed_steps, "median_ms", None),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[a.precision],
         "data": "synthetic",
         "config": {"workload": w["name"], "global_batch": world * B, "per_gpu_batch": B, "seq_len": T, "pitches": P, "tracks": M, "rho": a.rho,
@@ -683,6 +696,13 @@ def main(argv=None):
     del gen, x, opt, kept
     torch.cuda.empty_cache()
     if world == 1 and not rehearsal and not a.no_extras:
+        # strong-scaling proxy: the per-GPU share of the GLOBAL batch at 8 GPUs, B / 8 sequences, on this one GPU -- what the step
+        # costs on the kernel forms that shape selects; 8 x that throughput is the ceiling of the strong-scaling leg before any collective
+        if B % 8 == 0 and (B // 8) % 32 == 0:
+            sp, lp, _, lmp = timed_steps(a.precision, a.rho, B // 8, max(3, a.steps // 2), 2)
+            out["strong_proxy"] = {"per_gpu_batch": B // 8, "global_batch": B, "ms_per_step": sp * 1e3, "value_1gpu": (B // 8) * T / sp,
+                                   "value_8gpu_ceiling": 8 * (B // 8) * T / sp, "unit": "timesteps/s", "vs_weak_per_row": (sp / (B // 8)) / (sec / B),
+                                   "launch": lmp, "note": "no collective in it: 8 x the one-GPU rate of the B/8 shape"}
         # dense stress input: the NADE kernels' exact sparsity shortcuts vanish at rho = 0.5
         s5, l5, _, _ = timed_steps(a.precision, 0.5, B, max(3, a.steps // 2), 2)
         out["rho05"] = {"rho": 0.5, "ms_per_step": s5 * 1e3, "value": B * T / s5, "unit": "timesteps/s", "loss": l5,

@@ -45,7 +45,7 @@ enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_ST
  * was built with; a loader must compare the two before its first call (multinn_amd/_lib.py load() does) -- a library built for another
  * version reads garbage arguments without any diagnosis otherwise.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
  * mnn_pianoroll_shift_timemajor_t / mnn_grad_rows_fanout and the `f16` descriptor fields of round 3 are part of it. */
-#define MNN_ABI_VERSION 114
+#define MNN_ABI_VERSION 115
 int mnn_version(void);
 const char* mnn_last_error(void);
 
@@ -371,13 +371,15 @@ int mnn_sigmoid_grad_f32(mnn_stream_t s, long n, const float* dy, const float* y
  *   read ON DEVICE (hipGraph replay) and mnn_step_increment advances it.  sgd != 0 -> plain SGD (train.py:61-62).
  *   A gradient norm that is not finite (*sumsq is inf / NaN: an overflow of the loss-scaled f16 backward pass) SKIPS the update on the
  *   device -- theta, m, v unchanged -- and adds 1 to *skipped (device int32, may be NULL); clip_norm <= 0 disables the test.
+ *   mnn_step_increment takes the same (sumsq, clip_norm) and leaves the counter alone on such a step (sumsq may be NULL: always advance),
+ *   so the bias correction counts APPLIED steps.
  * ------------------------------------------------------------------------------------------ */
 int mnn_sumsq(mnn_stream_t s, const float* x, long n, float* out);
 int mnn_weighted_sum(mnn_stream_t s, const float* x, const float* w, long n, float* out);
 int mnn_clip_adam_step(mnn_stream_t s, float* theta, const float* grad, float* m, float* v, long n, const float* sumsq,
                        float clip_norm, float lr, float beta1, float beta2, float eps, int step, const int32_t* step_dev, int sgd,
                        int32_t* skipped);
-int mnn_step_increment(mnn_stream_t s, int32_t* step_dev);
+int mnn_step_increment(mnn_stream_t s, int32_t* step_dev, const float* sumsq, float clip_norm);
 int mnn_bias_grad(mnn_stream_t s, const float* dY, int rows, int cols, int ld, float* db, int accumulate);
 int mnn_fill_f32(mnn_stream_t s, float* x, long n, float value);
 /* One pass over the f32 gradient block dY[rows, cols_c] of the dense layer (rnn_estimator.py:205-215's tf.gradients through the

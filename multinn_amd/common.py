@@ -132,11 +132,12 @@ class ParamStore:
         n = int(self.skipped.item())
         if n:
             self.skipped.zero_()
+            self.step = int(self.step_dev.item())       # the host mirror counts attempts; the device counter only APPLIED steps
             raise FloatingPointError(f"{n} optimiser step(s) skipped: the gradient norm was not finite (f16 loss-scale overflow or NaN "
                                      "gradient); lower LstmStack.loss_scale_rows or use precision='bf16'")
 
     def state_dict(self):
-        return dict(theta=self.theta.cpu(), m=self.m.cpu(), v=self.v.cpu(), step=self.step, names=self.names(),
+        return dict(theta=self.theta.cpu(), m=self.m.cpu(), v=self.v.cpu(), step=int(self.step_dev.item()), names=self.names(),
                     shapes=[s for _, s, _ in self._specs])
 
     def load_state_dict(self, sd):

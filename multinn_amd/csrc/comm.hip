@@ -55,7 +55,8 @@ struct Comm { rccl_comm_t c; int rank, world; };
 extern "C" int mnn_comm_unique_id(void* id_out) {
     MNN_REQUIRE(id_out != nullptr, "mnn_comm_unique_id: null pointer");
     const Rccl* R = rccl();
-    MNN_REQUIRE(R != nullptr, "mnn_comm_unique_id: librccl.so.1 could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+    const char* dle = R == nullptr ? dlerror() : nullptr;        // ONE call: dlerror() clears the message it returns
+    MNN_REQUIRE(R != nullptr, "mnn_comm_unique_id: librccl.so.1 could not be loaded (%s)", dle ? dle : "symbols missing");
     rccl_unique_id id;
     MNN_RCCL(R->GetUniqueId(&id));
     memcpy(id_out, id.internal, sizeof(id.internal));

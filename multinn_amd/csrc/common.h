@@ -32,6 +32,13 @@ void mnn_set_error(const char* fmt, ...);
 #define MNN_LAUNCH_CHECK() MNN_HIP(hipGetLastError())
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// "done once" flags of things that are set PER DEVICE (hipFuncSetAttribute: a process-wide flag would leave the second device of a process at
+// the default dynamic-LDS limit): the current device's slot of a static array
+static inline bool& mnn_dev_flag(bool (&flags)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    return flags[dev];
+}
 
 // ----------------------------------------------------------------------------------------------
 // Stream-ordered zero fills and device copies as plain kernels.  The library never calls hipMemsetAsync / hipMemcpyAsync

@@ -224,7 +224,8 @@ __global__ void __launch_bounds__(256) dense_det_kernel(DetDenseJobs J, int B) {
 
 static size_t ds_lds_bytes(int K) { const int kc = (min(DS_KC, K) + 1) & ~1; return ((size_t)32 * (kc | 1) + DS_SPLIT * 16 * 64) * sizeof(float); }
 static hipError_t ds_raise_lds() {
-    static bool raised = false;
+    static bool raised_[64];
+    bool& raised = mnn_dev_flag(raised_);
     if (raised) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_step_det_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_det_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

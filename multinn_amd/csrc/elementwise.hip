@@ -802,10 +802,15 @@ extern "C" int mnn_grad_rows_fanout(mnn_stream_t s, const float* dY, int rows, i
     return MNN_OK;
 }
 
-__global__ void step_increment_kernel(int32_t* step_dev) { step_dev[0] += 1; }
-extern "C" int mnn_step_increment(mnn_stream_t s, int32_t* step_dev) {
+// the same test as clip_adam_kernel: a step whose gradient norm is not finite was NOT applied, so it does not count (the Adam bias
+// correction of the next applied step uses the number of APPLIED steps)
+__global__ void step_increment_kernel(int32_t* step_dev, const float* __restrict__ sumsq, float clip) {
+    if (clip > 0.f && sumsq != nullptr && !isfinite(sumsq[0])) return;
+    step_dev[0] += 1;
+}
+extern "C" int mnn_step_increment(mnn_stream_t s, int32_t* step_dev, const float* sumsq, float clip_norm) {
     MNN_REQUIRE(step_dev, "mnn_step_increment: null pointer");
-    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, step_dev);
+    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, step_dev, sumsq, clip_norm);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

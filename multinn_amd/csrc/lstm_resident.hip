@@ -121,10 +121,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // __builtin_amdgcn_global_load_lds -- here the reads of THIS step's staged rows, one buffer over: the whole memory latency on the chain of
     // every step (3.5 us per step measured).  The step waits for its own DMA itself (res_wait_all_but, in-order completion), one barrier later.
     auto dma16 = [&](const void* g, const void* l) {
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"((unsigned)(uintptr_t)(res_lptr_t)const_cast<void*>(l)), "v"(g) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"((unsigned)(uintptr_t)(res_lptr_t)const_cast<void*>(l)), "v"(g) : "memory", "m0");
     };
     auto dma4 = [&](const void* g, const void* l) {
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off" :: "s"((unsigned)(uintptr_t)(res_lptr_t)const_cast<void*>(l)), "v"(g) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off" :: "s"((unsigned)(uintptr_t)(res_lptr_t)const_cast<void*>(l)), "v"(g) : "memory", "m0");
     };
     auto stage = [&](int t, int buf) {
         const char* xb = xsrc + (size_t)t * us * 8;
@@ -595,6 +595,7 @@ extern "C" int mnn_lstm_resident_bwd(mnn_stream_t s, int T, int B, const mnn_lst
                 "mnn_lstm_resident_bwd: ld_t too small / not a multiple of 4 (0 = the K-blocked layout [T*B/32][4u][32], B a multiple of 32)");
     MNN_REQUIRE((size_t)T * B * 256 * 8 < ((size_t)1 << 31) && (size_t)1024 * (size_t)L->ld_t * 2 < ((size_t)1 << 31),
                 "mnn_lstm_resident_bwd: a tensor of this call exceeds the 2 GB a buffer descriptor addresses");
+    MNN_REQUIRE((L->mask == nullptr) == (keep_prob >= 1.0f), "mnn_lstm_resident_bwd: a keep mask goes with keep_prob < 1 and only with it (the forward's rule)");
     ResBwdArgs a{};
     a.dh_ext = L->dh_ext; a.wh_p = (const h16_t*)L->wh_p; a.gates = (const h16_t*)L->gates; a.c = L->c; a.mask = keep_prob < 1.0f ? L->mask : nullptr;
     a.dzc = (h16_t*)L->dz_T; a.dzT = (h16_t*)L->dzT_t; a.ld_t = L->ld_t; a.db_p = L->db_p;

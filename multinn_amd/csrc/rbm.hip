@@ -234,7 +234,8 @@ static bool launch_gibbs_lds(hipStream_t st, int N, int D, int Hn, int k, const 
                              int ld_bv, uint64_t seed, uint32_t row0, const uint32_t* row_ids, uint32_t sub0, float* p_v, uint8_t* v_out,
                              const int* seed_step) {
     const size_t lds = rbm_lds_resident_bytes(R, D, Hn);
-    static bool raised = false;                        // per instantiation: dynamic LDS above 64 KB has to be asked for once
+    static bool raised_[64];                           // per instantiation and device: dynamic LDS above 64 KB has to be asked for once
+    bool& raised = mnn_dev_flag(raised_);
     if (!raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rbm_gibbs_lds_kernel<R, RGH, RGV>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess) {
@@ -459,7 +460,8 @@ extern "C" int mnn_rbm_gibbs_stepped(mnn_stream_t s, int N, int D, int Hn, int k
     }
     if (gibbs_mfma_lds_bytes(D, Hn) <= 158 * 1024 && getenv("MNN_RBM_NO_MFMA") == nullptr) {
         // training batches: the chain on the f32 matrix cores (same draws: see rbm_gibbs_mfma_kernel)
-        static bool raised = false;
+        static bool raised_[64];
+        bool& raised = mnn_dev_flag(raised_);
         if (!raised) {
             MNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rbm_gibbs_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             raised = true;
@@ -595,7 +597,8 @@ static int launch_half(hipStream_t st, int N, int K, int n_out, const void* in, 
     // lane); a probabilities-only pass (the free-energy gradient's hidden activations) stays on the vector kernel, whose stores are
     // coalesced -- measured at [32768, 88 -> 256]: 0.11 ms vector vs 0.19 ms matrix-core per call
     if (N >= 2048 && s_out != nullptr && half_mfma_lds_bytes(K, n_out) <= 158 * 1024 && getenv("MNN_RBM_NO_MFMA") == nullptr) {
-        static bool raised = false;
+        static bool raised_[64];
+        bool& raised = mnn_dev_flag(raised_);
         if (!raised) {
             MNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rbm_half_mfma_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             MNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rbm_half_mfma_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -17,38 +17,48 @@ import numpy as np
 
 
 class LossAccumulator:
-    """utils/training.py:98-148: mean loss omitting NaN / +-inf values (which are counted)."""
+    """Running mean of the per-batch losses of an epoch that keeps non-finite values OUT of the mean and tallies them by kind (the
+    behaviour train.py:150-195 relies on from utils/training.py:98-148: a NaN batch is reported, not averaged)."""
+
+    KINDS = ("nan", "+inf", "-inf")
 
     def __init__(self):
         self.clear()
 
     def clear(self):
-        self._sum_loss, self._num_loss, self._num_nan, self._num_posinf, self._num_neginf, self._num_total = 0.0, 0, 0, 0, 0, 0
+        self.finite_sum, self.finite_n = 0.0, 0
+        self.bad = dict.fromkeys(self.KINDS, 0)
+
+    @staticmethod
+    def _kind(x):
+        if math.isnan(x):
+            return "nan"
+        if math.isinf(x):
+            return "+inf" if x > 0 else "-inf"
+        return None
 
     def update(self, loss):
-        self._num_total += 1
-        if np.isnan(loss):
-            self._num_nan += 1
-        elif np.isposinf(loss):
-            self._num_posinf += 1
-        elif np.isneginf(loss):
-            self._num_neginf += 1
+        loss = float(loss)
+        kind = self._kind(loss)
+        if kind is None:
+            self.finite_sum += loss
+            self.finite_n += 1
         else:
-            self._num_loss += 1
-            self._sum_loss += loss
+            self.bad[kind] += 1
 
     def loss(self):
-        return self._sum_loss / self._num_loss if self._num_loss > 0 else float("nan")
+        return self.finite_sum / self.finite_n if self.finite_n else float("nan")
 
     def num_bad(self):
-        return self._num_nan + self._num_posinf + self._num_neginf
+        return sum(self.bad.values())
 
     def ratio_bad(self):
-        return self.num_bad() / self._num_total
+        seen = self.finite_n + self.num_bad()
+        return self.num_bad() / seen if seen else 0.0
 
     def __str__(self):
-        return (f" - loss: {self.loss():7.3f} (nan: {self._num_nan}, +inf: {self._num_posinf}, -inf: {self._num_neginf}, "
-                f"bad: {100. * self.ratio_bad():.2f}%)")
+        tally = ", ".join(f"{k}: {n}" for k, n in self.bad.items())
+        return f" - loss: {self.loss():7.3f} ({tally}, bad: {100.0 * self.ratio_bad():.2f}%)"
 
 
 class TrainingStats:

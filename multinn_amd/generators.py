@@ -1151,7 +1151,8 @@ class RnnNade(RnnEstimator):
         parallelism the ONE gradient all-reduce stays an eager torch.distributed call between two graphs
         (forward+backward | clip+Adam), so nothing of RCCL is captured.  Full-length batches only (ragged lengths
         need a host-side row count)."""
-        from .training import allreduce_flat
+        from .training import allreduce_flat, setup_cabi_comm
+        setup_cabi_comm()               # MULTINN_COMM=capi: the communicator exists before anything is captured
         static_x = x_u8.clone()
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()

@@ -254,6 +254,24 @@ class MultINNCore(Model):
         if self._encoder_type == "Pass":
             return True
         path = self._ckpt_path(ckpt_dir)
+        if not os.path.exists(path):
+            # the reference restores whatever checkpoint sits in the directory, by variable name: encoders pre-trained through ANOTHER mode
+            # class (other default name, e.g. MultINN-jamming) are found by content -- any mode checkpoint with these tracks and encoders
+            import glob
+            import warnings
+            hits = []
+            for cand in sorted(glob.glob(os.path.join(ckpt_dir, "*.pt"))):
+                try:
+                    b = torch.load(cand)
+                except Exception:
+                    continue
+                if isinstance(b, dict) and list(b.get("tracks", [])) == list(self._tracks) and len(b.get("encoders", [])) == len(self._encoders) \
+                        and all(sd is not None for sd in b["encoders"]):
+                    hits.append(cand)
+            if hits:
+                if len(hits) > 1:
+                    warnings.warn(f"{ckpt_dir}: several mode checkpoints hold encoders for these tracks ({[os.path.basename(h) for h in hits]}); loading {os.path.basename(hits[0])}")
+                path = hits[0]
         if os.path.exists(path):
             blob = torch.load(path)
             if list(blob.get("tracks", [])) != list(self._tracks) or len(blob.get("encoders", [])) != len(self._encoders):
@@ -261,7 +279,13 @@ class MultINNCore(Model):
             if any(sd is None for sd in blob["encoders"]):
                 return False                            # written before the encoders had variables: nothing to restore
             for e, sd in zip(self._encoders, blob["encoders"]):
-                e.store.load_state_dict(sd)
+                if e.store.theta is None:
+                    e.store.materialize()               # load-before-first-build, as load() does
+                # the reference's Saver(trainable_encoder_variables) restores the WEIGHTS only (multinn_core.py:431-436): the Adam slots and
+                # the step count of the pre-training run are not carried into the generator training
+                if list(sd["names"]) != e.store.names():
+                    raise ValueError(f"checkpoint {path}: encoder variables {sd['names']} do not match {e.store.names()}")
+                e.store.theta.copy_(sd["theta"])
             return True
         old = [os.path.join(ckpt_dir, f"{e.name}.pt") for e in self._encoders]
         if all(os.path.exists(p) for p in old):
@@ -350,6 +374,9 @@ class MultINNCore(Model):
             fl._stack.check()
         if fl is not None and getattr(fl, "store", None) is not None:
             fl.store.check()
+        for e in getattr(self, "_encoders", None) or []:      # the encoders' stores take optimiser steps too (pretrain_encoders, compute_gradients)
+            if getattr(e, "store", None) is not None:
+                e.store.check()
 
     # -- train.py:178-189: one `sess.run([update_ops, loss], feed_dict)` -----------------------------
     def generator_loss(self):

@@ -691,9 +691,10 @@ def clip_adam_step(theta, grad, m, v, sumsq_buf, clip_norm, lr, beta1, beta2, ep
          float(beta1), float(beta2), float(eps), int(step), _ptr(step_dev), int(sgd), _ptr(skipped))
 
 
-def step_increment(step_dev):
+def step_increment(step_dev, sumsq_buf=None, clip_norm=0.0):
+    """Advance the device step counter -- unless (sumsq_buf, clip_norm) say that clip_adam_step skipped this step (non-finite norm)."""
     _step_ok(step_dev)
-    call("mnn_step_increment", _stream(), _ptr(step_dev))
+    call("mnn_step_increment", _stream(), _ptr(step_dev), _ptr(sumsq_buf), float(clip_norm))
 
 
 def bias_grad(dY, db, accumulate=False):

@@ -79,6 +79,18 @@ class CabiComm:
 _CABI_COMM = None
 
 
+def setup_cabi_comm():
+    """Create the C-ABI communicator NOW (MULTINN_COMM=capi with an initialised process group): ncclCommInitRank and the id broadcast must
+    not run inside a hipGraph capture, which is where the first all-reduce of a graphed step would otherwise create it.  Idempotent; the
+    communicator is destroyed at interpreter exit."""
+    global _CABI_COMM
+    if _CABI_COMM is None and dp_active() and os.environ.get("MULTINN_COMM") == "capi" and torch.cuda.is_available():
+        import atexit
+        _CABI_COMM = CabiComm(dist.get_rank(), dist.get_world_size())
+        atexit.register(lambda: _CABI_COMM is not None and _CABI_COMM.close())
+    return _CABI_COMM
+
+
 def allreduce_flat(grad):
     """The single data-parallel exchange of the step: sum the flat gradient over ranks.  torch.distributed (backend "nccl" = RCCL) by
     default; MULTINN_COMM=capi issues the same RCCL all-reduce through the library's own entry points (CabiComm)."""
@@ -86,7 +98,9 @@ def allreduce_flat(grad):
     if dp_active():
         if os.environ.get("MULTINN_COMM") == "capi" and grad.is_cuda:
             if _CABI_COMM is None:
-                _CABI_COMM = CabiComm(dist.get_rank(), dist.get_world_size())
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("MULTINN_COMM=capi: call training.setup_cabi_comm() before capturing a step (the communicator cannot be created inside a capture)")
+                setup_cabi_comm()
             _CABI_COMM.all_reduce(grad)
         else:
             dist.all_reduce(grad, op=dist.ReduceOp.SUM)
@@ -105,7 +119,7 @@ def compute_gradients(optimizer, store, clip_norm=5.0, lr=None, reduce=True):
     # the step count is read from store.step_dev ON DEVICE (= store.step - 1 here), so a captured graph stays valid
     ops.clip_adam_step(store.theta, store.grad, store.m, store.v, sumsq, clip_norm, optimizer.lr if lr is None else lr,
                        optimizer.beta1, optimizer.beta2, optimizer.epsilon, store.step, optimizer.sgd, store.step_dev, store.skipped)
-    ops.step_increment(store.step_dev)
+    ops.step_increment(store.step_dev, sumsq, clip_norm)       # a skipped (non-finite) step does not count
     return sumsq
 
 
@@ -124,5 +138,5 @@ def compute_gradients_multi(optimizer, stores, clip_norm=5.0, lr=None, reduce=Tr
         st.step += 1
         ops.clip_adam_step(st.theta, st.grad, st.m, st.v, sumsq, clip_norm, optimizer.lr if lr is None else lr,
                            optimizer.beta1, optimizer.beta2, optimizer.epsilon, st.step, optimizer.sgd, st.step_dev, st.skipped)
-        ops.step_increment(st.step_dev)
+        ops.step_increment(st.step_dev, sumsq, clip_norm)
     return sumsq

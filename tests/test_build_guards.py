@@ -101,3 +101,20 @@ def test_resident_recurrence_keeps_its_weights_in_registers(tmp_path):
         assert max(per_block) == 128, (body[:60], per_block)
         assert len(re.findall(r"v_mfma_f32_16x16x32_\w+ \S+ a\[", body)) >= 64, body[:60]      # srcA straight from AGPRs
         assert "v_accvgpr_read" not in "".join(b for b, n in zip(blocks, per_block) if n == 128), body[:60]
+        if re.match(r"_Z\w*lstm_res_fwd_kernel", body):
+            # The step waits for the NEXT step's LDS-DMA with `s_waitcnt vmcnt(N)`, N = the buffer stores WRITTEN behind the DMA in the source
+            # (res_wait_all_but(EMIT_STORES + NG * (SAVE ? 2 : 1))).  The wait covers the DMA only if exactly N vector-memory operations, all of
+            # them stores, stand between the last global_load_lds and that wait in the ISA: a merged, elided or extra memory operation would make
+            # step t + 1 read rows that have not landed.
+            big = [b for b, n in zip(blocks, per_block) if n == 128][0].split("\n")
+            dma = [i for i, ln in enumerate(big) if "global_load_lds" in ln]
+            assert dma, body[:60]
+            behind, wait = [], None
+            for ln in big[dma[-1] + 1:]:
+                if re.search(r"\b(global_load|global_store|global_atomic|buffer_load|buffer_store|flat_|scratch_)", ln):
+                    behind.append(ln.split()[0])
+                mm = re.search(r"s_waitcnt vmcnt\((\d+)\)", ln)
+                if mm:
+                    wait = int(mm.group(1))
+                    break
+            assert wait is not None and wait == len(behind) and all(x.startswith("buffer_store") for x in behind), (body[:60], wait, behind)

@@ -957,3 +957,54 @@ def test_lstm_resident_entry_points_refuse_what_they_do_not_cover(ops):
     with pytest.raises(MnnError):
         ops.lstm_resident_fwd(T, 6, odd, 1.0)
     torch.cuda.synchronize()
+
+
+def test_clip_adam_skips_a_non_finite_step_and_the_step_counter_with_it(ops):
+    """a gradient whose norm is not finite leaves theta, m, v AND the device step counter untouched (the Adam bias correction
+    counts applied steps), and the skip is counted."""
+    n = 4099
+    R = np.random.default_rng(3)
+    th, g = dev(R.standard_normal(n).astype(np.float32)), dev(R.standard_normal(n).astype(np.float32))
+    m, v = dev(R.random(n).astype(np.float32)), dev(R.random(n).astype(np.float32))
+    th0, m0, v0 = th.clone(), m.clone(), v.clone()
+    sd = torch.full((1,), 7, device=DEV, dtype=torch.int32)
+    skipped = torch.zeros(1, device=DEV, dtype=torch.int32)
+    gbad = g.clone()
+    gbad[17] = float("inf")
+    for bad in (gbad, torch.full_like(g, float("nan"))):
+        ss = torch.zeros(1, device=DEV)
+        ops.sumsq(bad, ss)
+        ops.clip_adam_step(th, bad, m, v, ss, 5.0, 0.01, 0.9, 0.999, 1e-4, 0, step_dev=sd, skipped=skipped)
+        ops.step_increment(sd, ss, 5.0)
+    assert torch.equal(th, th0) and torch.equal(m, m0) and torch.equal(v, v0) and int(sd) == 7 and int(skipped) == 2
+    ss = torch.zeros(1, device=DEV)
+    ops.sumsq(g, ss)
+    ops.clip_adam_step(th, g, m, v, ss, 5.0, 0.01, 0.9, 0.999, 1e-4, 0, step_dev=sd, skipped=skipped)
+    ops.step_increment(sd, ss, 5.0)
+    assert int(sd) == 8 and int(skipped) == 2 and not torch.equal(th, th0)
+    ops.step_increment(sd)                      # without the norm: always advances
+    assert int(sd) == 9
+
+
+@pytest.mark.parametrize("M,N,K,cdt,hb", [(1000, 696, 256, torch.float32, True), (512, 200, 64, torch.float16, True), (768, 2048, 448, torch.float16, True),
+                                           (300, 128, 96, torch.bfloat16, False), (2048, 256, 704, torch.float32, True), (4096, 512, 1024, torch.float32, False)])
+def test_gemm_pair_kernel_matches_the_product(ops, M, N, K, cdt, hb, monkeypatch):
+    """The short-K form (two 4-wave workgroups of 256 x 128 per CU, profiles/round5_a_gemm_pair_notes.md), forced on with MNN_GEMM_PAIR: both
+    epilogues (whole lines through LDS = 1, straight from the registers = 2) against an f32 product of the same 16-bit operands -- M not a
+    multiple of 256, an N edge inside a wave tile, K = 64, padding columns of C untouched."""
+    g = torch.Generator(device=DEV).manual_seed(1)
+    for dt in (torch.float16, torch.bfloat16):
+        if cdt != torch.float32 and cdt != dt:
+            continue
+        A = (torch.randn(M, K, device=DEV, generator=g) * 0.5).to(dt)
+        Bm = (torch.randn(N, K, device=DEV, generator=g) * 0.5).to(dt)
+        bias = torch.randn(N, device=DEV, generator=g) if hb else None
+        ref = A.float() @ Bm.float().t() + (bias if hb else 0.0)
+        ldc = (N + 63) // 64 * 64
+        for mode in ("1", "2", "0"):
+            monkeypatch.setenv("MNN_GEMM_PAIR", mode)
+            Cfull = torch.full((M, ldc), 7.0, device=DEV, dtype=cdt)
+            ops.gemm_tn(A, Bm, Cfull[:, :N], bias=bias)
+            tol = 2e-3 if cdt == torch.float32 else (0.25 if cdt == torch.bfloat16 else 0.03)
+            assert float((Cfull[:, :N].float() - ref).abs().max()) < tol, (mode, dt)
+            assert bool((Cfull[:, N:] == 7.0).all()), (mode, dt)

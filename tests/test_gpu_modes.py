@@ -536,3 +536,43 @@ def test_load_encoders_restores_the_encoder_stores_from_the_mode_checkpoint(tmp_
     assert all(g.store.theta is None for g in b.generators)          # the generators were not touched
     b.train_step(x, None, __import__("multinn_amd").AdamOptimizer(0.01))
     b.check()
+
+
+def test_check_raises_for_skipped_steps_of_generator_encoder_and_feedback_stores(tmp_path):
+    """an optimiser step the device skipped (non-finite gradient norm) must surface through MultINNCore.check() whichever
+    store it happened in -- the per-track generators', the feedback module's and the ENCODERS' (which also receive store.skipped)."""
+    from multinn_amd import MultINN, AdamOptimizer
+    B, T, P, M = 4, 5, 12, 5
+    x = dev(batch(B, T, P, M, 21))
+    a = MultINN(config(P, TRACKS5), params("composer", enc="DBN", enc_hidden=[10, 8], gen="NADE", Hn=16, units=[32, 32]), mode="composer", precision="fp32")
+    a.train_step(x, None, AdamOptimizer(0.01))
+    a.check()
+    for store in [a.generators[0].store, a.encoders[0].store]:
+        store.skipped.fill_(1)
+        with pytest.raises(FloatingPointError):
+            a.check()
+        a.check()                                        # the counter is cleared by the raise
+    f = MultINN(config(P, TRACKS5), params("feedback-rnn", gen="NADE", Hn=16, units=[32, 32], feedback=[64, 32]), mode="feedback-rnn", precision="fp32")
+    f.train_step(x, None, AdamOptimizer(0.01))
+    f.check()
+    f._feedback_layer.store.skipped.fill_(1)
+    with pytest.raises(FloatingPointError):
+        f.check()
+
+
+def test_load_encoders_finds_another_mode_class_checkpoint_and_restores_weights_only(tmp_path):
+    """multinn_core.py:425-448 restores the encoder variables from whatever checkpoint the directory holds: encoders pre-trained under one
+    mode name are found by a model constructed under another; only the weights are copied (the Adam slots of the pre-training stay behind)."""
+    from multinn_amd import MultINN
+    P = 12
+    kw = dict(enc="DBN", enc_hidden=[10, 8], gen="NADE", Hn=16, units=[32, 32])
+    a = MultINN(config(P, TRACKS5), params("composer", **kw), mode="composer", name="pretrain-run", precision="fp32")
+    for e in a.encoders:
+        e.store.theta.add_(torch.randn_like(e.store.theta) * 0.1)
+        e.store.m.fill_(3.0)
+        e.store.step_dev.fill_(5)
+    a.save(None, str(tmp_path))
+    b = MultINN(config(P, TRACKS5), params("composer", **kw), mode="composer", precision="fp32")
+    assert b.name != a.name and b.load_encoders(None, str(tmp_path)) is True
+    for ea, eb in zip(a.encoders, b.encoders):
+        assert torch.equal(ea.store.theta, eb.store.theta) and float(eb.store.m.abs().max()) == 0.0 and int(eb.store.step_dev) == 0
