@@ -834,6 +834,9 @@ gemm_tn_pair_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restr
 #endif
 }
 
+extern "C" int mnn_gemm_bres_ok(int M, int N, int K);           // gemm_bres.hip
+int mnn_gemm_bres_launch(hipStream_t st, int f16, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias);
+
 template <typename T>
 static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                        int c_bf16, const float* bias, int flags, int split_k) {
@@ -863,6 +866,14 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
                                ldc, c_bf16, bias, M, N, K, flags, split_k, ntm2, ntn2);
             MNN_LAUNCH_CHECK();
             return MNN_OK;
+        }
+        // the input projections (K = 448 / 512, 16-bit C, M a multiple of 128): the weight-resident persistent form (gemm_bres.hip)
+        {
+            const char* be = getenv("MNN_GEMM_BRES");             // development: 0 = never (re-read per call: A/B in one process)
+            if ((be == nullptr || atoi(be) != 0) && split_k == 1 && !(flags & (MNN_GEMM_ACCUMULATE | MNN_GEMM_ATOMIC | MNN_GEMM_A_KBLOCK32)) && c_bf16 != 0 &&
+                c_bf16 == (std::is_same<T, f16_t>::value ? MNN_F16 : MNN_BF16) && mnn_gemm_bres_ok(M, N, K) && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
+                ((uintptr_t)C & 15) == 0 && (size_t)128 * 64 * (size_t)lda < ((size_t)1 << 31))
+                return mnn_gemm_bres_launch(st, std::is_same<T, f16_t>::value ? 1 : 0, M, N, K, A, lda, B, ldb, C, ldc, bias);
         }
         // short-K activation GEMMs (no split-K, plain store): two 4-wave workgroups of 256 x 128 per CU (gemm_tn_pair_kernel)
         {

@@ -118,3 +118,25 @@ def test_resident_recurrence_keeps_its_weights_in_registers(tmp_path):
                     wait = int(mm.group(1))
                     break
             assert wait is not None and wait == len(behind) and all(x.startswith("buffer_store") for x in behind), (body[:60], wait, behind)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_weight_resident_gemm_uses_no_scratch_and_reads_its_weights_in_place(tmp_path):
+    """gemm_bres.hip counts its vector-memory operations by hand (the wait for an LDS-DMA stage allows exactly the younger DMA pieces and C
+    stores): a register spilled to scratch memory would add loads / stores of its own to that count and let a stage be read before it has
+    landed.  Every instantiation must compile without scratch, and the matrix cores must read the pinned weight fragments from AGPRs."""
+    from multinn_amd import build
+    out = str(tmp_path / "bres.s")
+    subprocess.check_call([HIPCC] + build.flags_for("gemm_bres.hip") + ["-S", "--cuda-device-only", os.path.join(build.CSRC, "gemm_bres.hip"), "-o", out],
+                          stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    sizes = {m.group(1): int(m.group(2))
+             for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text)}
+    kernels = {k: v for k, v in sizes.items() if "gemm_bres_kernel" in k}
+    assert len(kernels) >= 4 and all(v == 0 for v in kernels.values()), kernels
+    for body in re.split(r"\n(?=_Z\w+:)", text):
+        if not re.match(r"_Z\w*gemm_bres_kernel", body):
+            continue
+        assert "scratch_" not in body, body[:60]
+        n_mfma = len(re.findall(r"v_mfma_f32_32x32x16", body))
+        assert len(re.findall(r"v_mfma_f32_32x32x16_\w+ \S+ a\[", body)) >= 0.75 * n_mfma, body[:60]
