@@ -834,7 +834,7 @@ gemm_tn_pair_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restr
 #endif
 }
 
-extern "C" int mnn_gemm_bres_ok(int M, int N, int K);           // gemm_bres.hip
+int mnn_gemm_bres_ok(int M, int N, int K);                      // gemm_bres.hip (internal: not part of the C ABI)
 int mnn_gemm_bres_launch(hipStream_t st, int f16, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias);
 
 template <typename T>

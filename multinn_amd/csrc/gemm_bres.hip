@@ -252,7 +252,7 @@ gemm_bres_kernel(const h16_t* __restrict__ A, int lda, const h16_t* __restrict__
 
 // K = 448 or 512, 16-bit operands and C, M a multiple of 128, N a multiple of 256 (whole column panels: every store of the epilogue
 // issues, which its vmcnt bookkeeping relies on), plain store: the shapes this form is built and measured for
-extern "C" int mnn_gemm_bres_ok(int M, int N, int K) { return ((K == 448 || K == 512) && M >= 128 * 64 && M % 128 == 0 && N >= 256 && N % 256 == 0) ? 1 : 0; }
+int mnn_gemm_bres_ok(int M, int N, int K) { return ((K == 448 || K == 512) && M >= 128 * 64 && M % 128 == 0 && N >= 256 && N % 256 == 0) ? 1 : 0; }
 
 int mnn_gemm_bres_launch(hipStream_t st, int f16, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias) {
     MNN_REQUIRE(mnn_gemm_bres_ok(M, N, K), "gemm_bres: shape not covered (M=%d N=%d K=%d)", M, N, K);
