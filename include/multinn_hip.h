@@ -43,9 +43,9 @@ enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_ST
 
 /* ABI version of THIS header: bumped whenever a signature or a descriptor struct changes.  mnn_version() returns the value the library
  * was built with; a loader must compare the two before its first call (multinn_amd/_lib.py load() does) -- a library built for another
- * version reads garbage arguments without any diagnosis otherwise.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
+ * version reads garbage arguments without any diagnosis otherwise.  116: + mnn_lstm_cluster_ok / _fwd / _bwd.  115: mnn_step_increment gained `sumsq`, `clip_norm`.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
  * mnn_pianoroll_shift_timemajor_t / mnn_grad_rows_fanout and the `f16` descriptor fields of round 3 are part of it. */
-#define MNN_ABI_VERSION 115
+#define MNN_ABI_VERSION 116
 int mnn_version(void);
 const char* mnn_last_error(void);
 
@@ -233,6 +233,14 @@ int mnn_lstm_resident_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer
 /* ... and its backward: descriptor, outputs and layouts of mnn_lstm_rowpar_bwd (dh_ext required; dz_T, dzT_t / ld_t (0 = K-blocked), db_p optional;
  * workspace / wx_p / dz unused).  The saved gates must be the 16-bit gate-minor copy written by mnn_lstm_resident_fwd / mnn_lstm_rowpar_fwd. */
 int mnn_lstm_resident_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L, float keep_prob);
+/* Cluster form of the CU-resident recurrence for ONE 512-unit layer (multinn_amd/csrc/lstm_cluster.hip; rnn.py:104-145 as above): eight
+ * workgroups -- one per CU, on one XCD -- share 32 batch rows for the whole sequence; each keeps the recurrent weights of 64 units in its waves'
+ * registers and the members exchange h[t] (backward: dz[t]) through a two-deep area in their XCD's L2 (progress flags, bounded spins, the sticky
+ * status word of mnn_lstm_rowpar_status).  Same layer descriptors, inputs, outputs, layouts AND workspace as mnn_lstm_rowpar_fwd / _bwd with a
+ * 16-bit gate-minor xproj (the caller may use either form on the same buffers).  units == 512, B a multiple of 256 with B / 4 <= the device's
+ * CUs (mnn_lstm_cluster_ok; the whole grid must be resident at once: never next to another persistent launch); every tensor below 2 GB. */
+int mnn_lstm_cluster_ok(int B, int units);
+int mnn_lstm_cluster_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L, float keep_prob, void* workspace);
 int mnn_dropout_mask(mnn_stream_t s, uint8_t* mask, int T, int B, int units, float keep_prob, uint64_t seed, const int32_t* step_dev,
                      uint32_t row0, int layer);
 

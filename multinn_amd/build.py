@@ -6,11 +6,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmultinn_hip.so")
-SOURCES = ["gemm.hip", "gemm_bres.hip", "lstm_persist.hip", "lstm_rowpar.hip", "lstm_resident.hip", "elementwise.hip", "nade.hip", "nade_mfma.hip", "rbm.hip", "musical.hip", "det_step.hip", "comm.hip"]
+SOURCES = ["gemm.hip", "gemm_bres.hip", "lstm_persist.hip", "lstm_rowpar.hip", "lstm_resident.hip", "lstm_cluster.hip", "elementwise.hip", "nade.hip", "nade_mfma.hip", "rbm.hip", "musical.hip", "det_step.hip", "comm.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 # per-source additions.  lstm_resident.hip: MFMA results in VGPRs (the pointwise reads them there: no v_accvgpr_read per accumulator register),
 # which leaves the AGPRs to the recurrent weights the matrix cores read in place
-EXTRA_FLAGS = {"lstm_resident.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "gemm_bres.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA_FLAGS = {"lstm_resident.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "lstm_cluster.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "gemm_bres.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def flags_for(src):

@@ -1170,6 +1170,18 @@ __global__ void rp_reset_kernel(unsigned* sync, int words) {          // progres
         if (i != 1) sync[i] = 0u;
 }
 
+// the workspace layout and the per-launch reset, for the cluster form (lstm_cluster.hip), which takes the same workspace
+void mnn_rp_workspace_layout(int nrt, int U, size_t* sync_bytes, size_t* xchg_off) {
+    *sync_bytes = rp_sync_bytes(nrt);
+    *xchg_off = rp_xchg_off(nrt, U);
+}
+int mnn_rp_reset_launch(hipStream_t st, void* workspace, int nrt, int U) {
+    (void)U;
+    hipLaunchKernelGGL(rp_reset_kernel, dim3(8), dim3(256), 0, st, (unsigned*)workspace, (int)(rp_sync_bytes(nrt) / sizeof(unsigned)));
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
 // Every instantiation with its dynamic-LDS size.  The MaxDynamicSharedMemorySize attribute is per device: it is set for ALL of them the first
 // time a device asks mnn_lstm_rowpar_ok / launches (the host calls _ok before every use, so never for the first time under stream capture).
 static size_t rp_lds_fwd(int U, bool pair) { return pair ? (size_t)(U / 16) * 4096 + 4 * 2304 + 2 * 8192 + 64 : (size_t)(U / 16) * 4096 + 4 * 5120 + 16; }

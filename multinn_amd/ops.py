@@ -381,6 +381,17 @@ def lstm_resident_bwd(T, B, L, keep_prob):
     call("mnn_lstm_resident_bwd", _stream(), T, B, C.byref(L), float(keep_prob))
 
 
+def lstm_cluster_ok(B, units):
+    """True when the cluster form of the CU-resident recurrence (512 units: eight CUs share 32 rows, all weights in registers) covers this shape."""
+    return bool(_lib.load().mnn_lstm_cluster_ok(int(B), int(units)))
+
+
+def lstm_cluster_fwd(T, B, L, keep_prob, ws):
+    """L: descriptor of lstm2_fwd_layer, as for lstm_rowpar_fwd with a 16-bit xproj; ws: the tensor of lstm_rowpar_workspace(T, B, 512)."""
+    _rp_ws_ok(ws, T, B, L.units)
+    call("mnn_lstm_cluster_fwd", _stream(), T, B, C.byref(L), float(keep_prob), _ptr(ws))
+
+
 def lstm_rowpar_check(ws):
     st = C.c_int(0)
     call("mnn_lstm_rowpar_status", _ptr(ws), C.byref(st))
