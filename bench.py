@@ -619,6 +619,8 @@ def main(argv=None):
             # one launch per LAYER: every wave carries one 32-row tile through all T steps against a 32-unit weight tile resident in LDS
             # (256-unit layers run on the CU-resident kernels instead: their products are counted there)
             res_layers = [u for u in UNITS if u == 256] if any(k.startswith("mnn_lstm_resident") for k in per_call) else []
+            direction = "bwd" if dom.endswith("bwd") else "fwd"
+            res_layers += [u for u in UNITS if u == 512] if ("mnn_lstm_cluster_" + direction) in per_call else []
             rp_flops = rec_flops - 2.0 * N * sum(u * 4 * u for u in res_layers)
             roof = dict(bound="mfma", achieved=rp_flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
                         kernel="lstm_rowpar_%s" % ("bwd" if dom.endswith("bwd") else "fwd"), entry_point=dom, launches_per_step=dom_calls,
@@ -626,6 +628,15 @@ def main(argv=None):
                         algorithmic_flop_per_launch=rp_flops / dom_calls,
                         note="latency-bound chain: per timestep every row tile exchanges its 32-row h (backward: dz) slice with the other unit "
                              "tiles through L2 (flag per wave); the number to watch is avg_timestep_us")
+        elif dom in ("mnn_lstm_cluster_fwd", "mnn_lstm_cluster_bwd"):
+            # one launch per 512-unit LAYER: eight CUs share 32 rows, 64 units' recurrent weights in each CU's registers, h / dz through the XCD's L2
+            cl_flops = 2.0 * N * sum(u * 4 * u for u in UNITS if u == 512)
+            roof = dict(bound="mfma", achieved=cl_flops / (dom_ms * 1e-3) / 1e12, peak=peak_mfma, unit="TFLOP/s", traffic=None,
+                        kernel="lstm_cl_%s_kernel" % ("bwd" if dom.endswith("bwd") else "fwd"), entry_point=dom, launches_per_step=dom_calls,
+                        avg_launch_us=dom_ms * 1e3 / dom_calls, avg_timestep_us=dom_ms * 1e3 / dom_calls / T,
+                        algorithmic_flop_per_launch=cl_flops / dom_calls,
+                        note="a timestep is 64 MFMAs per wave (every column a distinct row) + the gate pointwise + one exchange of the 32-row tile "
+                             "between the cluster's eight CUs (store -> flag -> poll -> LDS-DMA pull); the number to watch is avg_timestep_us")
         elif dom in ("mnn_lstm_resident_fwd", "mnn_lstm_resident_bwd"):
             # one launch per 256-unit LAYER: four batch rows per workgroup, the layer's whole recurrent matrix in the registers + LDS of its CU
             rs_flops = 2.0 * N * sum(u * 4 * u for u in UNITS if u == 256)

@@ -241,6 +241,11 @@ int mnn_lstm_resident_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer
  * CUs (mnn_lstm_cluster_ok; the whole grid must be resident at once: never next to another persistent launch); every tensor below 2 GB. */
 int mnn_lstm_cluster_ok(int B, int units);
 int mnn_lstm_cluster_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L, float keep_prob, void* workspace);
+/* ... and its backward: descriptor, outputs and layouts of mnn_lstm_rowpar_bwd (dh_ext required; dz_T, dzT_t / ld_t (0 = K-blocked), db_p optional;
+ * wx_p / dz unused).  The contraction over the 2048 gate columns is split the way the columns are owned: a member multiplies its own 256 columns
+ * of dz[t+1] (in its LDS: nothing is exchanged in front of the MFMAs) into partial sums for all 512 units, and the members reduce-scatter the
+ * partials (16-bit, 32 KB out + 32 KB in per CU and step).  T >= 4.  A cluster whose workgroups do not share an XCD gives up (status word). */
+int mnn_lstm_cluster_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L, float keep_prob, void* workspace);
 int mnn_dropout_mask(mnn_stream_t s, uint8_t* mask, int T, int B, int units, float keep_prob, uint64_t seed, const int32_t* step_dev,
                      uint32_t row0, int layer);
 

@@ -111,6 +111,7 @@ SIGNATURES["mnn_lstm_resident_fwd"] = (_i, [_p, _i, _i, C.POINTER(LstmFwdLayer),
 SIGNATURES["mnn_lstm_resident_bwd"] = (_i, [_p, _i, _i, C.POINTER(LstmBwdLayer), _f])
 SIGNATURES["mnn_lstm_cluster_ok"] = (_i, [_i, _i])
 SIGNATURES["mnn_lstm_cluster_fwd"] = (_i, [_p, _i, _i, C.POINTER(LstmFwdLayer), _f, _p])
+SIGNATURES["mnn_lstm_cluster_bwd"] = (_i, [_p, _i, _i, C.POINTER(LstmBwdLayer), _f, _p])
 SIGNATURES["mnn_nade_mfma_ok"] = (_i, [_i])
 SIGNATURES["mnn_nade_logprob_fwd_mfma"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p])
 SIGNATURES["mnn_density_gate"] = (_i, [_p, _p, _l, _l, _p, _p])

@@ -336,6 +336,268 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// backward:  dh = dh_ext[t] (/ kp * keep when a mask is given) + dz[t+1] . Wh ;  gate backward -> dz[t], dc   (rnn.py:124 LSTMBlockCell autodiff)
+// The contraction runs over the 2048 gate columns.  Exchanging dz[t+1] itself (the forward's scheme) would make every CU pull the whole
+// 32 x 2048 tile, 128 KB per step, on the chain.  Instead the K dimension is split the way the columns are OWNED: member c multiplies ITS OWN
+// 256 columns of dz[t+1] -- which its waves wrote into its LDS one step earlier: no exchange in front of the MFMAs -- into partial sums for
+// ALL 512 units (A = rows of Wh: 32 units per tile, B = the member's dz columns, K = 256: 4 tiles x 16 k-steps per wave), and the members
+// reduce-scatter the partials: a wave stores, for each destination wave, the 8 values per lane that wave's lane needs (16-bit, 1 KB per
+// store instruction, contiguous), raises its flag, polls the cluster's flags, loads the eight sources' 1 KB blocks of its own units and
+// sums them in f32.  32 KB out + 32 KB in per CU and step.  Lane layout on both sides (v_mfma_f32_32x32x16 accumulator): row = l & 31,
+// units 8 a + 4 (l >> 5) + b of a 32-unit tile, so a consumer lane owns two groups of four CONSECUTIVE units of one row: its operands
+// (saved gates 32 bytes, c[t-1] 16, dh_ext 16, keep bytes 4 per group) are contiguous loads issued a step ahead.
+// ------------------------------------------------------------------------------------------------------------------
+struct ClBwdArgs {
+    const float* dh_ext; const h16_t* wh_p; const h16_t* gates; const float* c; const uint8_t* mask;
+    h16_t* dzc; h16_t* dzT; int ld_t; float* db_p;
+    char* xchg; unsigned* sync;
+    int T, B, ncl, allow_local; float kp;
+};
+
+struct ClBwdGeom {
+    static constexpr int U = 512;
+    static constexpr int PZ = 256 * 2 + 16;          // pitch of a row of the member's dz columns in LDS (rows 4 banks apart)
+    static constexpr int ZB = 32 * PZ;
+    static constexpr int OFF_Z = 0;
+    static constexpr int OFF_L = OFF_Z + 2 * ZB;
+    static constexpr int LDS = OFF_L + 16;
+    static constexpr int XBUF = 8 * 4 * 8 * 1024;    // one exchange buffer of a cluster: [destination member][destination wave][source member][lane] x 16 bytes
+};
+
+template <typename F, bool DROP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_cl_bwd_kernel(ClBwdArgs A) {
+    typedef ClBwdGeom G;
+    typedef typename F::x8 frag_t;
+    constexpr int U = G::U;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = lane & 31, hf = lane >> 5;
+    const int T = A.T, B = A.B;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3, mem = seq & 7, cl = xcd * (A.ncl >> 3) + (seq >> 3);
+    const int row0 = 32 * cl;
+    const size_t us = (size_t)B * U;
+    const float ikp = 1.0f / A.kp;
+    unsigned* status = A.sync;
+    unsigned* flags = A.sync + CL_FLAGS_OFF + 32 * cl;
+    int* s_local = reinterpret_cast<int*>(smem + G::OFF_L);
+    cl_probe_xcd(A.sync + CL_FLAGS_OFF + 32 * A.ncl + 32 * cl, status, mem, s_local);
+
+    // ---- producer side: Wh[unit][the member's 256 gate columns] for the units [128 w, 128 w + 128): four tiles x 16 k-steps of A fragments, in AGPRs ----
+    frag_t wr[4][16];
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const h16_t* src = A.wh_p + (size_t)(128 * w + 32 * i + (lane & 31)) * (4 * U) + 256 * mem + 8 * hf;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                wr[i][s] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(src + 16 * s));
+                asm volatile("" : "+a"(wr[i][s]));
+            }
+        }
+    }
+    for (int i = tid; i < G::ZB / 4; i += 256) reinterpret_cast<unsigned*>(smem + G::OFF_Z)[i] = 0u;       // dz[T] = 0
+
+    // ---- consumer side: this lane's two groups of four units, their operands a step ahead (buffer loads: scalar per-step base, one lane offset) ----
+    const int u0 = 64 * mem + 16 * w + 4 * hf;                                  // group a: units u0 + 8 a .. + 3
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)A.gates, 0, (int)min((size_t)T * us * 8, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)A.c, 0, (int)min((size_t)T * us * 4, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)A.dh_ext, 0, (int)min((size_t)T * us * 4, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(DROP ? (void*)A.mask : (void*)A.c, 0, (int)min((size_t)T * us, (size_t)0x7fffffff), 0x00020000);
+    const unsigned vo_e = (unsigned)(row * U + u0);                             // element offset inside a step's 32 x u block (group a: + 8 a)
+    u32x4_t gq0[2], gq1[2], cq[2], dq[2];
+    unsigned mq[2] = {0u, 0u};
+    auto request = [&](int t) {                                                 // operands of step t (t >= 0)
+        const unsigned so = (unsigned)((size_t)t * us + (size_t)row0 * U);
+        const unsigned sp = (unsigned)((size_t)(t > 0 ? t - 1 : 0) * us + (size_t)row0 * U);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            gq0[a] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (vo_e + 8 * a) * 8, so * 8, 0);
+            gq1[a] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (vo_e + 8 * a) * 8 + 16, so * 8, 0);
+            cq[a] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, (vo_e + 8 * a) * 4, sp * 4, 0);          // c[t-1] (t = 0: read and ignored)
+            dq[a] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, (vo_e + 8 * a) * 4, so * 4, 0);
+            if (DROP) mq[a] = __builtin_amdgcn_raw_buffer_load_b32(rs_m, vo_e + 8 * a, so, 0);
+        }
+    };
+    float cnext[2][4], dcreg[2][4], dbv[2][4][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const u32x4_t c_last = __builtin_amdgcn_raw_buffer_load_b128(rs_c, (vo_e + 8 * a) * 4, (unsigned)((size_t)(T - 1) * us + (size_t)row0 * U) * 4, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cnext[a][r] = __uint_as_float(c_last[r]);
+            dcreg[a][r] = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dbv[a][g][r] = 0.f;
+        }
+    }
+    request(T - 1);
+    CL_BARRIER();
+    const bool local = A.allow_local != 0 && *s_local != 0;
+    if (*s_local == 0) {
+        // the two-deep exchange area is re-written every other step: only valid while the cluster shares one L2.  Give up loudly (sticky status word).
+        if (tid == 0) { cl_st(status, 1u); cl_st(status + 1, 1u); }
+        return;
+    }
+
+    // ---- the exchange area of this cluster (two buffers) ----
+    char* xch = A.xchg + (size_t)cl * (size_t)(2 * G::XBUF);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xch, 0, 2 * G::XBUF, 0x00020000);
+    const unsigned vo_xl = (unsigned)(((mem * 4 + w) * 8) * 1024 + lane * 16);   // loads: + 1024 source member
+
+    // ---- outputs of a step (the member's 32 x 256 slice of dz, from the LDS tile): row-major 16-byte pieces and the transposed copy ----
+    constexpr unsigned OOB = 0x80000000u;
+    const size_t N = (size_t)T * B;
+    const bool kb = A.ld_t == 0;
+    const __amdgpu_buffer_rsrc_t rs_zc = __builtin_amdgcn_make_buffer_rsrc(A.dzc ? (void*)A.dzc : (void*)A.c, 0, A.dzc ? (int)min(N * 4 * U * 2, (size_t)0x7fffffff) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_zt = __builtin_amdgcn_make_buffer_rsrc(A.dzT ? (void*)A.dzT : (void*)A.c, 0,
+                                                                           A.dzT ? (int)min(kb ? N * 4 * U * 2 : (size_t)4 * U * A.ld_t * 2, (size_t)0x7fffffff) : 0, 0x00020000);
+    // piece j of this thread: p = tid + 256 j;  row-major: row p >> 5, 16-byte piece p & 31;  transposed: column p >> 2, rows 8 (p & 3) ..+7
+    u32x4_t e_row;
+    unsigned e_col[8];
+    auto emit_read = [&](int buf, int j) {
+        const char* zb = smem + G::OFF_Z + buf * G::ZB;
+        const int p = tid + 256 * j;
+        e_row = *reinterpret_cast<const u32x4_t*>(zb + (p >> 5) * G::PZ + (p & 31) * 16);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e_col[k] = *reinterpret_cast<const h16_t*>(zb + (8 * (p & 3) + k) * G::PZ + (p >> 2) * 2);
+    };
+    auto emit_store = [&](int tt, int j) {          // dz[tt] (tt >= T: nothing)
+        const unsigned none = tt >= T ? OOB : 0u;
+        const int tc = tt >= T ? 0 : tt;
+        const int p = tid + 256 * j;
+        const unsigned so_c = (unsigned)(((size_t)tc * B + row0) * 4 * U * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(e_row, rs_zc, (unsigned)(((p >> 5) * 4 * U + 256 * mem) * 2 + (p & 31) * 16) | none, so_c, 0);
+        u32x4_t v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = e_col[2 * k] | (e_col[2 * k + 1] << 16);
+        const int col = 256 * mem + (p >> 2);
+        const unsigned vo_t = kb ? (unsigned)(col * 64 + (p & 3) * 16) : (unsigned)(((size_t)col * A.ld_t + 8 * (p & 3)) * 2);
+        const unsigned so_t = kb ? (unsigned)(((size_t)tc * (B >> 5) + cl) * (4 * U) * 64) : (unsigned)(((size_t)tc * B + row0) * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs_zt, vo_t | none, so_t, 0);
+    };
+
+    CL_TR_DECL;
+    for (int kk = 0; kk < T; ++kk) {
+        const int t = T - 1 - kk;
+        CL_TR(0);
+        const char* zin = smem + G::OFF_Z + (kk & 1) * G::ZB + row * G::PZ + hf * 16;
+        char* zout = smem + G::OFF_Z + ((kk + 1) & 1) * G::ZB + row * G::PZ;
+        const unsigned xb = (unsigned)((kk & 1) * G::XBUF);
+        // ---- partial products, tile by tile: tile 0 requests the 16 fragments of the member's dz columns and keeps them; a tile's partials
+        // leave (two 1 KB stores, one per destination wave) while the next tile runs ----
+        frag_t bq[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mnn_f32x16 ac;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ac[r] = 0.f;
+            if (i == 0) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bq[s] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(zin + 32 * s));
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if (i == 0 && s + 4 < 16) bq[s + 4] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(zin + 32 * (s + 4)));
+                ac = F::mfma32(wr[i][s], bq[s], ac);
+                // the previous step's outputs (dz[t+1], still in the tile the MFMAs read) leave in the shadow of the MFMA stream
+                if (s == 1) emit_read(kk & 1, i);
+                if (s == 9) emit_store(t + 1, i);
+                __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400 | 0x40 | 0x200);
+            }
+            // destination of half h of this tile: member 2 w + (i >> 1), wave 2 (i & 1) + h; its lane l reads what this lane l stores
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4_t v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = pack2<F>(ac[8 * h + 2 * k], ac[8 * h + 2 * k + 1]);
+                const unsigned vo = (unsigned)(((((2 * w + (i >> 1)) * 4 + 2 * (i & 1) + h) * 8 + mem) * 1024) + lane * 16);
+                if (local) __builtin_amdgcn_raw_buffer_store_b128(v, rs_x, vo, xb, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(v, rs_x, vo, xb, CL_SC1);
+            }
+        }
+        CL_TR(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this wave's partials are out
+        if (lane == 0) cl_raise(flags + 4 * mem + w, (unsigned)(kk + 1), local);
+        CL_TR(2);
+        if (!cl_wait(flags, status, 32, (unsigned)(kk + 1))) return;             // every wave of the cluster has stored its partials of this step
+        CL_TR(3);
+        float dhr[2][4];
+        {
+            u32x4_t pq[8];
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) pq[s8] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo_xl + 1024 * s8, xb, CL_SC1);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; ++s8) {
+                        const unsigned wv = pq[s8][2 * a + (r >> 1)];
+                        sum += (r & 1) ? F::hi(wv) : F::lo(wv);
+                    }
+                    dhr[a][r] = sum;
+                }
+        }
+        CL_TR(4);
+        // ---- pointwise: register r of group a = unit u0 + 8 a + r ----
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            h16_t b4[4][4];                                 // [gate][unit]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned g01 = r < 2 ? gq0[a][2 * r] : gq1[a][2 * r - 4], g23 = r < 2 ? gq0[a][2 * r + 1] : gq1[a][2 * r - 3];
+                const float gi = F::lo(g01), gg = F::hi(g01), gf = F::lo(g23), go = F::hi(g23);
+                const float dv = __uint_as_float(dq[a][r]);
+                const float dh = (DROP ? dv * ikp * (float)((mq[a] >> (8 * r)) & 0xffu) : dv) + dhr[a][r];
+                const float tc = fast_tanh(cnext[a][r]);
+                const float d_o = dh * tc;
+                const float d_c = dh * go * (1.f - tc * tc) + dcreg[a][r];
+                const float cprev = t > 0 ? __uint_as_float(cq[a][r]) : 0.f;
+                const float dzv[4] = {d_c * gg * gi * (1.f - gi), d_c * gi * (1.f - gg * gg), d_c * cprev * gf * (1.f - gf), d_o * go * (1.f - go)};
+                dcreg[a][r] = d_c * gf;
+                cnext[a][r] = cprev;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    b4[g][r] = F::cvt(dzv[g]);
+                    dbv[a][g][r] += F::f32(b4[g][r]);       // the (16-bit) values the weight-gradient GEMMs see
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2_t v;
+                v[0] = (unsigned)b4[g][0] | ((unsigned)b4[g][1] << 16);
+                v[1] = (unsigned)b4[g][2] | ((unsigned)b4[g][3] << 16);
+                *reinterpret_cast<u32x2_t*>(zout + (gate_perm_col(g, u0 + 8 * a) - 256 * mem) * 2) = v;
+            }
+        }
+        CL_TR(5);
+        if (kk + 1 < T) request(t - 1);
+        CL_BARRIER();
+        CL_TR(6);
+        CL_TR_FLUSH(1, kk);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        emit_read(T & 1, j);
+        emit_store(0, j);
+    }
+    if (A.db_p != nullptr) {                            // bias gradient: sums over the cluster's 32 rows and all steps
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = dbv[a][g][r];
+#pragma unroll
+                    for (int d = 1; d < 32; d <<= 1) v += __shfl_xor(v, d);
+                    if (row == 0) atomicAdd(A.db_p + gate_perm_col(g, u0 + 8 * a + r), v);
+                }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 void mnn_rp_workspace_layout(int nrt, int U, size_t* sync_bytes, size_t* xchg_off);           // lstm_rowpar.hip: the workspace both forms share
 int mnn_rp_reset_launch(hipStream_t st, void* workspace, int nrt, int U);
@@ -360,6 +622,11 @@ template <typename F> static cl_fwd_fn cl_fwd_pick(bool drop, bool save) {
     return save ? lstm_cl_fwd_kernel<F, false, true> : lstm_cl_fwd_kernel<F, false, false>;
 }
 static cl_fwd_fn cl_fwd_kernel(bool f16, bool drop, bool save) { return f16 ? cl_fwd_pick<Fp16F>(drop, save) : cl_fwd_pick<Bf16F>(drop, save); }
+typedef void (*cl_bwd_fn)(ClBwdArgs);
+static cl_bwd_fn cl_bwd_kernel(bool f16, bool drop) {
+    if (f16) return drop ? lstm_cl_bwd_kernel<Fp16F, true> : lstm_cl_bwd_kernel<Fp16F, false>;
+    return drop ? lstm_cl_bwd_kernel<Bf16F, true> : lstm_cl_bwd_kernel<Bf16F, false>;
+}
 static hipError_t cl_prepare() {
     static bool done[64];
     int dev = 0;
@@ -369,6 +636,10 @@ static hipError_t cl_prepare() {
     if (done[dev]) return hipSuccess;
     for (int i = 0; i < 8; ++i) {
         e = hipFuncSetAttribute((const void*)cl_fwd_kernel(i & 1, i & 2, i & 4), hipFuncAttributeMaxDynamicSharedMemorySize, ClGeom::LDS);
+        if (e != hipSuccess) return e;
+    }
+    for (int i = 0; i < 4; ++i) {
+        e = hipFuncSetAttribute((const void*)cl_bwd_kernel(i & 1, i & 2), hipFuncAttributeMaxDynamicSharedMemorySize, ClBwdGeom::LDS);
         if (e != hipSuccess) return e;
     }
     done[dev] = true;
@@ -406,6 +677,33 @@ extern "C" int mnn_lstm_cluster_fwd(mnn_stream_t s, int T, int B, const mnn_lstm
     MNN_HIP(cl_prepare());
     if (int rc = mnn_rp_reset_launch(st, workspace, B / 32, 512)) return rc;
     hipLaunchKernelGGL(cl_fwd_kernel(L->f16 != 0, L->mask != nullptr, L->gates != nullptr), dim3(8 * a.ncl), dim3(256), ClGeom::LDS, st, a);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+extern "C" int mnn_lstm_cluster_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L, float keep_prob, void* workspace) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(L && workspace && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm_cluster_bwd: bad arguments");
+    MNN_REQUIRE(((size_t)workspace & 255) == 0, "mnn_lstm_cluster_bwd: workspace must be 256-byte aligned");
+    MNN_REQUIRE(cl_shape_ok(B, L->units), "mnn_lstm_cluster_bwd: units must be 512, B a multiple of 256 and B / 4 at most the device's CUs (B=%d u=%d)", B, L->units);
+    MNN_REQUIRE(L->dh_ext && L->wh_p && L->gates && L->c, "mnn_lstm_cluster_bwd: null pointer");
+    MNN_REQUIRE(L->c0 == nullptr && L->dz == nullptr, "mnn_lstm_cluster_bwd: no initial state / f32 dz output in this form");
+    MNN_REQUIRE(L->dzT_t == nullptr || L->ld_t == 0 || (L->ld_t >= T * B && (L->ld_t & 7) == 0),
+                "mnn_lstm_cluster_bwd: ld_t too small / not a multiple of 8 (0 = the K-blocked layout [T*B/32][4u][32])");
+    MNN_REQUIRE((size_t)T * B * 512 * 8 < ((size_t)1 << 31) && (size_t)2048 * (size_t)L->ld_t * 2 < ((size_t)1 << 31),
+                "mnn_lstm_cluster_bwd: a tensor of this call exceeds the 2 GB a buffer descriptor addresses");
+    MNN_REQUIRE((L->mask == nullptr) == (keep_prob >= 1.0f), "mnn_lstm_cluster_bwd: a keep mask goes with keep_prob < 1 and only with it (the forward's rule)");
+    MNN_REQUIRE(T >= 4, "mnn_lstm_cluster_bwd: T >= 4 (the two exchange buffers of a cluster take the room of four timesteps of the row-parallel workspace)");
+    ClBwdArgs a{};
+    a.dh_ext = L->dh_ext; a.wh_p = (const h16_t*)L->wh_p; a.gates = (const h16_t*)L->gates; a.c = L->c; a.mask = keep_prob < 1.0f ? L->mask : nullptr;
+    a.dzc = (h16_t*)L->dz_T; a.dzT = (h16_t*)L->dzT_t; a.ld_t = L->ld_t; a.db_p = L->db_p;
+    size_t sync_bytes = 0, xoff = 0;
+    mnn_rp_workspace_layout(B / 32, 512, &sync_bytes, &xoff);
+    a.sync = (unsigned*)workspace; a.xchg = (char*)workspace + xoff;
+    a.T = T; a.B = B; a.ncl = B / 32; a.kp = keep_prob; a.allow_local = getenv("MNN_PERSIST_NO_LOCAL") == nullptr;
+    MNN_HIP(cl_prepare());
+    if (int rc = mnn_rp_reset_launch(st, workspace, B / 32, 512)) return rc;
+    hipLaunchKernelGGL(cl_bwd_kernel(L->f16 != 0, a.mask != nullptr), dim3(8 * a.ncl), dim3(256), ClBwdGeom::LDS, st, a);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

@@ -152,6 +152,14 @@ class LstmStack:
         return (self.resident and not self.rowpar_xproj_f32 and ops.lstm_resident_ok(B, self.packed[l]["u"])
                 and T * B * self.packed[l]["u"] * 8 < 2 ** 31)
 
+    # Cluster form of the same idea for a 512-unit layer (lstm_cluster.hip): eight CUs share 32 rows, each keeps 64 units' recurrent weights in
+    # its registers, h[t] / dz[t] are exchanged through the XCD's L2 (MULTINN_CLUSTER=0: row-parallel kernels for that layer)
+    cluster = os.environ.get("MULTINN_CLUSTER", "1") != "0"
+
+    def _cluster(self, l, B, T):
+        return (self.cluster and not self.rowpar_xproj_f32 and ops.lstm_cluster_ok(B, self.packed[l]["u"])
+                and T * B * self.packed[l]["u"] * 8 < 2 ** 31)
+
     @property
     def rowpar_xproj_dtype(self):
         return torch.float32 if self.rowpar_xproj_f32 else self.dtype
@@ -229,6 +237,8 @@ class LstmStack:
                                     xproj_dtype=self.rowpar_xproj_dtype)
             if self._resident(l, B, T):
                 ops.lstm_resident_fwd(T, B, d, keep_prob)
+            elif self._cluster(l, B, T):
+                ops.lstm_cluster_fwd(T, B, d, keep_prob, self._rp_workspace(l, T, B, dev))
             else:
                 ops.lstm_rowpar_fwd(T, B, d, keep_prob, self._rp_workspace(l, T, B, dev))
             out = y if y is not None else h
@@ -262,6 +272,8 @@ class LstmStack:
                                     cx["mask"] if keep_prob < 1.0 else None, gates_dtype=self.dtype)
             if self._resident(l, B, T):
                 ops.lstm_resident_bwd(T, B, e, keep_prob)
+            elif self._cluster(l, B, T) and T >= 4:
+                ops.lstm_cluster_bwd(T, B, e, keep_prob, self._rp_workspace(l, T, B, dev))
             else:
                 ops.lstm_rowpar_bwd(T, B, e, keep_prob, self._rp_workspace(l, T, B, dev))
             st[l] = dict(dzT=dzT, dzc=dzc, db_p=db_p)

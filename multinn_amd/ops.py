@@ -392,6 +392,12 @@ def lstm_cluster_fwd(T, B, L, keep_prob, ws):
     call("mnn_lstm_cluster_fwd", _stream(), T, B, C.byref(L), float(keep_prob), _ptr(ws))
 
 
+def lstm_cluster_bwd(T, B, L, keep_prob, ws):
+    """L: descriptor of lstm2_bwd_layer, as for lstm_rowpar_bwd; ws: the tensor of lstm_rowpar_workspace(T, B, 512); T >= 4."""
+    _rp_ws_ok(ws, T, B, L.units)
+    call("mnn_lstm_cluster_bwd", _stream(), T, B, C.byref(L), float(keep_prob), _ptr(ws))
+
+
 def lstm_rowpar_check(ws):
     st = C.c_int(0)
     call("mnn_lstm_rowpar_status", _ptr(ws), C.byref(st))

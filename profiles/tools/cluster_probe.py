@@ -42,6 +42,27 @@ def fwd(kind, T, B, keep, tdt, wh_t, xproj, mask, ws, save=True):
     return e0.elapsed_time(e1), dict(gates=gates, c=c, h=h, y=y, hT=hT, yT=yT)
 
 
+def bwd(kind, T, B, keep, tdt, wh_t, mask, saved, dh, ws, layout):
+    N = T * B
+    wh_p = wh_t.t().contiguous()
+    kb = layout == "kblock"
+    dzc = torch.zeros((T, B, 4 * u), device=DEV, dtype=tdt)
+    dzT = torch.zeros((N // 32, 4 * u, 32), device=DEV, dtype=tdt) if kb else torch.zeros((4 * u, N), device=DEV, dtype=tdt)
+    db = torch.zeros(4 * u, device=DEV)
+    E = ops.lstm2_bwd_layer(dh, wh_p, saved["gates"], saved["c"], None, dzc, ops.lstm_seq_bwd_workspace(B, u, DEV), dzT, db, mask, gates_dtype=tdt)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    if kind == "cluster":
+        ops.lstm_cluster_bwd(T, B, E, keep, ws)
+    else:
+        ops.lstm_rowpar_bwd(T, B, E, keep, ws)
+    e1.record()
+    torch.cuda.synchronize()
+    ops.lstm_rowpar_check(ws)
+    return e0.elapsed_time(e1), dict(dzc=dzc, dzT=dzT, db=db)
+
+
 def diff(a, b):
     if a is None:
         return "-"
@@ -57,6 +78,20 @@ for dt in (torch.float16, torch.bfloat16):
         _, k = fwd("cluster", T, B, keep, dt, *ins, ws, save)
         print(f"fwd {str(dt)[6:]} T={T} B={B} keep={keep} save={save}: max abs diff  " + "  ".join(f"{n} {diff(k[n], r[n])}" for n in ("h", "y", "c", "gates", "hT", "yT")), flush=True)
 
+if what == "both":
+    for dt in (torch.float16, torch.bfloat16):
+        for (T, B, keep, layout) in [(5, 256, 0.9, "kblock"), (4, 512, 1.0, "plain"), (6, 1024, 0.9, "kblock")]:
+            ins = make(T, B, keep, dt)
+            ws = ops.lstm_rowpar_workspace(T, B, u, DEV)
+            _, saved = fwd("rowpar", T, B, keep, dt, *ins, ws, True)
+            dh = torch.randn((T, B, u), device=DEV) * 0.02
+            _, r = bwd("rowpar", T, B, keep, dt, ins[0], ins[2], saved, dh, ws, layout)
+            _, k = bwd("cluster", T, B, keep, dt, ins[0], ins[2], saved, dh, ws, layout)
+            sc = float(r["dzc"].double().abs().max())
+            print(f"bwd {str(dt)[6:]} T={T} B={B} keep={keep} {layout}: max |dz| {sc:.3e}  max abs diff dz {diff(k['dzc'], r['dzc'])}  dzT {diff(k['dzT'], r['dzT'])}  "
+                  f"db {diff(k['db'], r['db'])} (max |db| {float(r['db'].abs().max()):.3e})  dzT == dz^T: "
+                  f"{bool(torch.equal(k['dzT'].permute(0, 2, 1).reshape(T * B, 4 * u) if layout == 'kblock' else k['dzT'][:, :T * B].t(), k['dzc'].view(T * B, 4 * u)))}", flush=True)
+
 T, B, keep, dt = 256, 1024, 0.9, torch.float16
 ins = make(T, B, keep, dt)
 ws = ops.lstm_rowpar_workspace(T, B, u, DEV)
@@ -68,3 +103,13 @@ for rd in range(5):
 _, r = fwd("rowpar", T, B, keep, dt, *ins, ws)
 print(f"fwd B=1024 T=256 fp16 keep=0.9: row-parallel {sorted(tr[1:])[1]:.3f} ms ({sorted(tr[1:])[1] / T * 1e3:.2f} us/step) | cluster {sorted(tc[1:])[1]:.3f} ms "
       f"({sorted(tc[1:])[1] / T * 1e3:.2f} us/step) | max abs diff h {diff(k['h'][-1], r['h'][-1])} y {diff(k['y'], r['y'])} c {diff(k['c'], r['c'])}", flush=True)
+if what == "both":
+    dh = torch.randn((T, B, u), device=DEV) * 0.02
+    tr, tc = [], []
+    for rd in range(5):
+        tr.append(bwd("rowpar", T, B, keep, dt, ins[0], ins[2], r, dh, ws, "kblock")[0])
+        t, kq = bwd("cluster", T, B, keep, dt, ins[0], ins[2], r, dh, ws, "kblock")
+        tc.append(t)
+    _, rq = bwd("rowpar", T, B, keep, dt, ins[0], ins[2], r, dh, ws, "kblock")
+    print(f"bwd B=1024 T=256 fp16 keep=0.9: row-parallel {sorted(tr[1:])[1]:.3f} ms ({sorted(tr[1:])[1] / T * 1e3:.2f} us/step) | cluster {sorted(tc[1:])[1]:.3f} ms "
+          f"({sorted(tc[1:])[1] / T * 1e3:.2f} us/step) | max |dz| {float(rq['dzc'].double().abs().max()):.3e} max abs diff dz {diff(kq['dzc'], rq['dzc'])} db {diff(kq['db'], rq['db'])}", flush=True)

@@ -140,3 +140,44 @@ def test_weight_resident_gemm_uses_no_scratch_and_reads_its_weights_in_place(tmp
         assert "scratch_" not in body, body[:60]
         n_mfma = len(re.findall(r"v_mfma_f32_32x32x16", body))
         assert len(re.findall(r"v_mfma_f32_32x32x16_\w+ \S+ a\[", body)) >= 0.75 * n_mfma, body[:60]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_cluster_recurrence_keeps_its_weights_in_agprs_and_counts_its_staging(tmp_path):
+    """lstm_cluster.hip: a wave's 64 weight fragments (256 registers) are AGPR-pinned and read in place by every MFMA (64 per timestep and
+    wave, both directions); no scratch memory (the forward waits for its LDS-DMA pull with a counted `s_waitcnt vmcnt(N)`, N = the staging
+    requests issued behind it: a spill would add vector-memory operations of its own to that count)."""
+    from multinn_amd import build
+    out = str(tmp_path / "cl.s")
+    subprocess.check_call([HIPCC] + build.flags_for("lstm_cluster.hip") + ["-S", "--cuda-device-only", os.path.join(build.CSRC, "lstm_cluster.hip"), "-o", out],
+                          stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    sizes = {m.group(1): int(m.group(2))
+             for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text)}
+    kernels = {k: v for k, v in sizes.items() if "lstm_cl_" in k}
+    assert len(kernels) == 12 and all(v == 0 for v in kernels.values()), kernels         # forward (drop x save) + backward (drop), two flavours
+    seen = 0
+    for body in re.split(r"\n(?=_Z\w+:)", text):
+        m = re.match(r"_Z\w*lstm_cl_(fwd|bwd)_kernel\w*:", body)
+        if not m:
+            continue
+        seen += 1
+        assert "scratch_" not in body, body[:60]
+        mf = re.findall(r"v_mfma_f32_32x32x16_\w+ \S+ (\S)\[", body)
+        assert len(mf) == 64 and all(x == "a" for x in mf), (body[:60], len(mf))
+        if m.group(1) == "fwd":
+            # the wait in front of the step's barrier: exactly the staging requests (4 xproj row pairs + 2 keep-byte pieces with dropout) may be in flight
+            lines = [ln.strip() for ln in body.split("\n")]
+            drop = "Lb1ELb" in body[:80]
+            waits = [i for i, ln in enumerate(lines) if re.match(r"s_waitcnt vmcnt\((4|6)\)", ln)]
+            assert waits, body[:60]
+            i = waits[-1]
+            assert lines[i] == "s_waitcnt vmcnt(%d)" % (6 if drop else 4), (body[:60], lines[i])
+            behind = []
+            j = i - 1
+            while j >= 0 and len(behind) < (6 if drop else 4):
+                if re.match(r"(global_|buffer_|flat_)", lines[j]):
+                    behind.append(lines[j].split()[0])
+                j -= 1
+            assert all(x.startswith("global_load_lds_dword") for x in behind), (body[:60], behind)
+    assert seen == 12, seen

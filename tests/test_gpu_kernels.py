@@ -929,6 +929,152 @@ def test_lstm_resident_recurrence_vs_float64(ops, B, T, keep, layout, save, dt):
     assert np.abs(db.cpu().numpy() - db_ref).max() < 1e-5 * max(1.0, np.abs(db_ref).max()) + 1e-6
 
 
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,T,keep,layout,save,nolocal", [(256, 5, 0.9, "kblock", True, False), (512, 4, 1.0, "plain", True, False), (256, 6, 0.9, None, False, False),
+                                                           (256, 4, 0.9, "kblock", True, True)])
+def test_lstm_cluster_recurrence_vs_float64(ops, monkeypatch, B, T, keep, layout, save, nolocal, dt):
+    """The cluster form of the CU-resident recurrence (lstm_cluster.hip: eight CUs share 32 rows of a 512-unit layer, all weights in registers,
+    h exchanged through the XCD's L2; backward: K split by column ownership + a reduce-scatter of 16-bit partial sums) against a float64
+    restatement of rnn.py:104-145 on the SAME 16-bit operands: forward h / y / c / gates and both transposed copies, backward dz in all three
+    layouts and the bias gradient.  nolocal = the write-through hand-off policy (one exchange slot per timestep in the forward)."""
+    u = 512
+    if nolocal:
+        monkeypatch.setenv("MNN_PERSIST_NO_LOCAL", "1")
+    tdt = torch.float16 if dt == "fp16" else torch.bfloat16
+    eps = 2.0 ** -10 if dt == "fp16" else 2.0 ** -7
+    rng = np.random.default_rng(13)
+    r16 = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(tdt)            # noqa: E731
+    wh_t = r16(rng.normal(0, 0.04, (4 * u, u)))                                     # [gate-interleaved row][k]
+    xproj = r16(rng.normal(0, 1.2, (T, B, u, 4)))                                    # gate-minor
+    mask = (rng.random((T, B, u)) < keep).astype(np.uint8) if keep < 1.0 else None
+    N = T * B
+    d = lambda t_: t_.to(DEV)                                                        # noqa: E731
+    gates = torch.zeros((T, B, 4 * u), device=DEV, dtype=tdt) if save else None
+    c = torch.zeros((T, B, u), device=DEV)
+    h = torch.zeros((T, B, u), device=DEV, dtype=tdt)
+    y = torch.zeros((T, B, u), device=DEV, dtype=tdt) if mask is not None else None
+    hT = torch.zeros((u, N), device=DEV, dtype=tdt) if save else None
+    yT = torch.zeros((u, N), device=DEV, dtype=tdt) if save else None
+    md = dev(mask) if mask is not None else None
+    assert ops.lstm_cluster_ok(B, u) and not ops.lstm_cluster_ok(B + 32, u) and not ops.lstm_cluster_ok(B, 256)
+    ws = ops.lstm_rowpar_workspace(T, B, u, DEV)
+    L = ops.lstm2_fwd_layer(d(xproj).view(T, B, 4 * u), d(wh_t), None, None, gates, c, h, hT, y, md, yT=yT, gates_dtype=tdt, xproj_dtype=tdt)
+    ops.lstm_cluster_fwd(T, B, L, keep, ws)
+    torch.cuda.synchronize()
+    ops.lstm_rowpar_check(ws)
+    # ---- float64 forward on the same operands ----
+    perm = _gate_perm(u)
+    W = wh_t.double().numpy()                                                        # z[n] += sum_k h[k] W[n][k]
+    X = xproj.double().numpy()
+    sig = lambda a: 1.0 / (1.0 + np.exp(-a))                                        # noqa: E731
+    hp, cp = np.zeros((B, u)), np.zeros((B, u))
+    ref = dict(g=np.zeros((T, B, u, 4)), c=np.zeros((T, B, u)), h=np.zeros((T, B, u)))
+    for t in range(T):
+        z = np.stack([X[t, :, :, g] + hp @ W[perm[g]].T for g in range(4)], -1)     # [B, u, 4]
+        gi, gg, gf, go = sig(z[..., 0]), np.tanh(z[..., 1]), sig(z[..., 2]), sig(z[..., 3])
+        cp = gg * gi + cp * gf
+        hv = np.tanh(cp) * go
+        ref["g"][t] = np.stack([gi, gg, gf, go], -1)
+        ref["c"][t] = cp
+        ref["h"][t] = hv
+        hp = h[t].double().cpu().numpy() if (mask is None or t + 1 == T) else r16(hv).double().numpy()     # the 16-bit state the kernel feeds back
+    got_c = c.cpu().numpy()
+    assert np.abs(got_c - ref["c"]).max() < 4 * eps, np.abs(got_c - ref["c"]).max()
+    if mask is None:
+        assert np.abs(h.double().cpu().numpy() - ref["h"]).max() < 2 * eps
+        out16 = h
+    else:
+        assert np.abs(h[-1].double().cpu().numpy() - ref["h"][-1]).max() < 2 * eps          # only the final state leaves through h
+        yref = r16(ref["h"]).double().numpy() / keep * mask
+        assert np.abs(y.double().cpu().numpy() - yref).max() < 3 * eps
+        out16 = y
+    if not save:
+        return
+    assert np.abs(gates.double().cpu().numpy().reshape(T, B, u, 4) - ref["g"]).max() < 2 * eps
+    # h^T[unit][(t + 1) B + row] = h[t] (column block 0 untouched: h_{-1}), y^T[unit][t B + row] = the layer's output
+    assert torch.equal(yT.view(u, T, B), out16.permute(2, 0, 1))
+    hh = r16(ref["h"]).double().numpy()
+    assert np.abs(hT.view(u, T, B)[:, 1:].double().cpu().numpy() - np.transpose(hh, (2, 0, 1))[:, :-1]).max() < 2 * eps
+    assert float(hT.view(u, T, B)[:, 0].abs().max()) == 0.0
+    # ---- backward on the kernel's own saved tensors ----
+    dh = torch.from_numpy(rng.normal(0, 0.02, (T, B, u)).astype(np.float32)).to(DEV)
+    wh_p = wh_t.t().contiguous().to(DEV)                                             # [k][gate-interleaved column]
+    kb = layout == "kblock"
+    dzc = torch.zeros((T, B, 4 * u), device=DEV, dtype=tdt)
+    dzT = torch.zeros((N // 32, 4 * u, 32), device=DEV, dtype=tdt) if kb else torch.zeros((4 * u, N), device=DEV, dtype=tdt)
+    db = torch.zeros(4 * u, device=DEV)
+    E = ops.lstm2_bwd_layer(dh, wh_p, gates, c, None, dzc, ops.lstm_seq_bwd_workspace(B, u, DEV), dzT, db, md, gates_dtype=tdt)
+    ops.lstm_cluster_bwd(T, B, E, keep, ws)
+    torch.cuda.synchronize()
+    ops.lstm_rowpar_check(ws)
+    Gs = gates.double().cpu().numpy().reshape(T, B, u, 4)
+    Cs = c.double().cpu().numpy()
+    dz_ref = np.zeros((T, B, 4 * u))
+    dcv, dz_next = np.zeros((B, u)), np.zeros((B, 4 * u))
+    for t in range(T - 1, -1, -1):
+        gi, gg, gf, go = (Gs[t, :, :, k] for k in range(4))
+        dhv = dh[t].double().cpu().numpy() * (mask[t] / keep if mask is not None else 1.0) + dz_next @ W      # sum_n dz[n] W[n][k]
+        tc = np.tanh(Cs[t])
+        d_o = dhv * tc
+        d_c = dhv * go * (1 - tc * tc) + dcv
+        cprev = Cs[t - 1] if t > 0 else np.zeros((B, u))
+        dzs = [d_c * gg * gi * (1 - gi), d_c * gi * (1 - gg * gg), d_c * cprev * gf * (1 - gf), d_o * go * (1 - go)]
+        dcv = d_c * gf
+        for g in range(4):
+            dz_ref[t][:, perm[g]] = dzs[g]
+        dz_next = dzc[t].double().cpu().numpy()                                      # the 16-bit values the kernel feeds back
+    scale = np.abs(dz_ref).max()
+    got = dzc.double().cpu().numpy()
+    assert np.abs(got - dz_ref).max() < 3 * eps * scale, (np.abs(got - dz_ref).max(), scale)
+    flat = dzc.view(N, 4 * u)
+    if kb:
+        assert torch.equal(dzT.permute(0, 2, 1).reshape(N, 4 * u), flat)
+    else:
+        assert torch.equal(dzT[:, :N].t(), flat)
+    db_ref = flat.double().sum(0).cpu().numpy()
+    assert np.abs(db.cpu().numpy() - db_ref).max() < 1e-5 * max(1.0, np.abs(db_ref).max()) + 1e-6
+
+
+def test_lstm_cluster_entry_points_refuse_what_they_do_not_cover(ops):
+    """Error behaviour of the cluster entries through the C ABI (no launch): other widths, a batch off the 256-row grid of eight clusters, an f32
+    input projection, saved gates without the transposed copies, a mask without keep_prob < 1, a backward window shorter than four steps."""
+    from multinn_amd._lib import MnnError
+    T, B, u = 4, 256, 512
+    dt = torch.float16
+    mk = lambda *s, d=dt: torch.zeros(s, device=DEV, dtype=d)      # noqa: E731
+    ws = ops.lstm_rowpar_workspace(T, B, u, DEV)
+    wh, c, h = mk(4 * u, u), mk(T, B, u, d=torch.float32), mk(T, B, u)
+    ok = ops.lstm2_fwd_layer(mk(T, B, 4 * u), wh, None, None, None, c, h, None, gates_dtype=dt, xproj_dtype=dt)
+    ops.lstm_cluster_fwd(T, B, ok, 1.0, ws)                            # the inference form is fine
+    torch.cuda.synchronize()
+    ops.lstm_rowpar_check(ws)
+    f32x = ops.lstm2_fwd_layer(mk(T, B, 4 * u, d=torch.float32), wh, None, None, None, c, h, None, gates_dtype=dt)
+    with pytest.raises(MnnError):
+        ops.lstm_cluster_fwd(T, B, f32x, 1.0, ws)
+    gates_only = ops.lstm2_fwd_layer(mk(T, B, 4 * u), wh, None, None, mk(T, B, 4 * u), c, h, None, gates_dtype=dt, xproj_dtype=dt)
+    with pytest.raises(MnnError):
+        ops.lstm_cluster_fwd(T, B, gates_only, 1.0, ws)
+    masked = ops.lstm2_fwd_layer(mk(T, B, 4 * u), wh, None, None, None, c, h, None, mk(T, B, u), mk(T, B, u, d=torch.uint8), gates_dtype=dt, xproj_dtype=dt)
+    with pytest.raises(MnnError):
+        ops.lstm_cluster_fwd(T, B, masked, 1.0, ws)
+    B2 = 288                                                           # a multiple of 32 (row-parallel: fine) but not of 256
+    assert not ops.lstm_cluster_ok(B2, u) and not ops.lstm_cluster_ok(B, 256) and not ops.lstm_cluster_ok(2048, u)
+    c2, h2 = mk(T, B2, u, d=torch.float32), mk(T, B2, u)
+    off = ops.lstm2_fwd_layer(mk(T, B2, 4 * u), wh, None, None, None, c2, h2, None, gates_dtype=dt, xproj_dtype=dt)
+    with pytest.raises(MnnError):
+        ops.lstm_cluster_fwd(T, B2, off, 1.0, ops.lstm_rowpar_workspace(T, B2, u, DEV))
+    T3 = 3
+    c3 = mk(T3, B, u, d=torch.float32)
+    e3 = ops.lstm2_bwd_layer(mk(T3, B, u, d=torch.float32), mk(u, 4 * u), mk(T3, B, 4 * u), c3, None, mk(T3, B, 4 * u), ops.lstm_seq_bwd_workspace(B, u, DEV),
+                             mk(4 * u, T3 * B), mk(4 * u, d=torch.float32), None, gates_dtype=dt)
+    with pytest.raises(MnnError):
+        ops.lstm_cluster_bwd(T3, B, e3, 1.0, ops.lstm_rowpar_workspace(T3, B, u, DEV))
+    em = ops.lstm2_bwd_layer(mk(T, B, u, d=torch.float32), mk(u, 4 * u), mk(T, B, 4 * u), c, None, mk(T, B, 4 * u), ops.lstm_seq_bwd_workspace(B, u, DEV),
+                             mk(4 * u, T * B), mk(4 * u, d=torch.float32), mk(T, B, u, d=torch.uint8), gates_dtype=dt)
+    with pytest.raises(MnnError):
+        ops.lstm_cluster_bwd(T, B, em, 1.0, ws)                         # a mask with keep_prob = 1
+
+
 def test_lstm_resident_entry_points_refuse_what_they_do_not_cover(ops):
     """Error behaviour of the CU-resident entries through the C ABI (no launch): other widths, a batch off the 4-row workgroups, an f32
     input projection, saved gates without the transposed copies (they leave together), a mask without keep_prob < 1."""
