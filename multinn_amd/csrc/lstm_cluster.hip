@@ -156,11 +156,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             const int unit = ub + 8 * j + (m >> 2);
             const h16_t* src = A.wh_t + (size_t)gate_perm_col(m & 3, unit) * U + 8 * hf;
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                wr[j][s] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(src + 16 * s));
-                asm volatile("" : "+a"(wr[j][s]));
-            }
+            for (int s = 0; s < 32; ++s) wr[j][s] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(src + 16 * s));
         }
+        // pinned only after ALL loads have been issued (a pin right behind its load makes every load wait for the one before: 64 round trips per launch)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 32; ++s) asm volatile("" : "+a"(wr[j][s]));
     }
     for (int i = tid; i < G::HB / 4; i += 256) reinterpret_cast<unsigned*>(smem + G::OFF_H)[i] = 0u;       // h[-1] = 0 (state buffer 0)
 
@@ -390,11 +392,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         for (int i = 0; i < 4; ++i) {
             const h16_t* src = A.wh_p + (size_t)(128 * w + 32 * i + (lane & 31)) * (4 * U) + 256 * mem + 8 * hf;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                wr[i][s] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(src + 16 * s));
-                asm volatile("" : "+a"(wr[i][s]));
-            }
+            for (int s = 0; s < 16; ++s) wr[i][s] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(src + 16 * s));
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) asm volatile("" : "+a"(wr[i][s]));
     }
     for (int i = tid; i < G::ZB / 4; i += 256) reinterpret_cast<unsigned*>(smem + G::OFF_Z)[i] = 0u;       // dz[T] = 0
 
@@ -409,7 +412,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     unsigned mq[2] = {0u, 0u};
     auto request = [&](int t) {                                                 // operands of step t (t >= 0)
         const unsigned so = (unsigned)((size_t)t * us + (size_t)row0 * U);
-        const unsigned sp = (unsigned)((size_t)(t > 0 ? t - 1 : 0) * us + (size_t)row0 * U);
+        const unsigned sp = __builtin_amdgcn_readfirstlane((unsigned)((size_t)(t > 0 ? t - 1 : 0) * us + (size_t)row0 * U));
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             gq0[a] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (vo_e + 8 * a) * 8, so * 8, 0);
@@ -517,9 +520,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             }
         }
         CL_TR(1);
+        // ---- everything of the gate backward that does not need dh is worked out while the partial sums travel: group 0 while this wave's
+        // stores are on their way (the flag behind them then goes up without a wait), group 1 behind the flag (under the poll) ----
+        float pe[2][4], pA[2][4], pK[2][4][4], pf[2][4], pc[2][4];             // dh_ext share, d c / d h, d z_gate / d c (gate o: / d h), f, c[t-1]
+        auto pre = [&](int a) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned g01 = r < 2 ? gq0[a][2 * r] : gq1[a][2 * r - 4], g23 = r < 2 ? gq0[a][2 * r + 1] : gq1[a][2 * r - 3];
+                const float gi = F::lo(g01), gg = F::hi(g01), gf = F::lo(g23), go = F::hi(g23);
+                const float dv = __uint_as_float(dq[a][r]);
+                pe[a][r] = DROP ? dv * ikp * (float)((mq[a] >> (8 * r)) & 0xffu) : dv;
+                const float tc = fast_tanh(cnext[a][r]);
+                const float cprev = t > 0 ? __uint_as_float(cq[a][r]) : 0.f;
+                pA[a][r] = go * (1.f - tc * tc);
+                pK[a][0][r] = gg * gi * (1.f - gi);
+                pK[a][1][r] = gi * (1.f - gg * gg);
+                pK[a][2][r] = cprev * gf * (1.f - gf);
+                pK[a][3][r] = tc * go * (1.f - go);
+                pf[a][r] = gf;
+                pc[a][r] = cprev;
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        pre(0);
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this wave's partials are out
         if (lane == 0) cl_raise(flags + 4 * mem + w, (unsigned)(kk + 1), local);
         CL_TR(2);
+        __builtin_amdgcn_sched_barrier(0);
+        pre(1);
+        __builtin_amdgcn_sched_barrier(0);
         if (!cl_wait(flags, status, 32, (unsigned)(kk + 1))) return;             // every wave of the cluster has stored its partials of this step
         CL_TR(3);
         float dhr[2][4];
@@ -541,23 +571,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 }
         }
         CL_TR(4);
-        // ---- pointwise: register r of group a = unit u0 + 8 a + r ----
+        // ---- what is left once dh is known: register r of group a = unit u0 + 8 a + r ----
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             h16_t b4[4][4];                                 // [gate][unit]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const unsigned g01 = r < 2 ? gq0[a][2 * r] : gq1[a][2 * r - 4], g23 = r < 2 ? gq0[a][2 * r + 1] : gq1[a][2 * r - 3];
-                const float gi = F::lo(g01), gg = F::hi(g01), gf = F::lo(g23), go = F::hi(g23);
-                const float dv = __uint_as_float(dq[a][r]);
-                const float dh = (DROP ? dv * ikp * (float)((mq[a] >> (8 * r)) & 0xffu) : dv) + dhr[a][r];
-                const float tc = fast_tanh(cnext[a][r]);
-                const float d_o = dh * tc;
-                const float d_c = dh * go * (1.f - tc * tc) + dcreg[a][r];
-                const float cprev = t > 0 ? __uint_as_float(cq[a][r]) : 0.f;
-                const float dzv[4] = {d_c * gg * gi * (1.f - gi), d_c * gi * (1.f - gg * gg), d_c * cprev * gf * (1.f - gf), d_o * go * (1.f - go)};
-                dcreg[a][r] = d_c * gf;
-                cnext[a][r] = cprev;
+                const float dh = pe[a][r] + dhr[a][r];
+                const float d_c = dh * pA[a][r] + dcreg[a][r];
+                const float dzv[4] = {d_c * pK[a][0][r], d_c * pK[a][1][r], d_c * pK[a][2][r], dh * pK[a][3][r]};
+                dcreg[a][r] = d_c * pf[a][r];
+                cnext[a][r] = pc[a][r];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     b4[g][r] = F::cvt(dzv[g]);
@@ -573,7 +597,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             }
         }
         CL_TR(5);
-        if (kk + 1 < T) request(t - 1);
+        request(t > 0 ? t - 1 : 0);                     // unconditional (clamped): behind a condition the compiler COPIES the freshly requested registers at the join -- and waits for the loads to do it
         CL_BARRIER();
         CL_TR(6);
         CL_TR_FLUSH(1, kk);

@@ -104,12 +104,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 const uint4 v = *reinterpret_cast<const uint4*>(src + 32 * s);
                 if (s < G::KR) {
                     wr[tl][s] = __builtin_bit_cast(frag_t, v);
-                    // k-steps 0..3 are pinned to AGPRs, which the matrix cores read directly (left to itself the register allocator treats
-                    // AGPRs as spill space and copies every fragment back with four v_accvgpr_read per MFMA); 4..5 stay in VGPRs
-                    if (s < 4) asm volatile("" : "+a"(wr[tl][s]));
                 } else wl[(w * G::WPW + tl * G::KL + (s - G::KR)) * 64 + lane] = v;
             }
         }
+        // k-steps 0..3 are pinned to AGPRs, which the matrix cores read directly (left to itself the register allocator treats AGPRs as spill
+        // space and copies every fragment back with four v_accvgpr_read per MFMA); 4..5 stay in VGPRs.  Pinned only after ALL loads have been
+        // issued: a pin right behind its load makes every load wait for the one before (64 memory round trips at the start of every launch)
+#pragma unroll
+        for (int tl = 0; tl < G::NT; ++tl)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) asm volatile("" : "+a"(wr[tl][s]));
     }
     // zero state: h[-1] = 0 in the first state buffer
     for (int i = tid; i < 4 * G::PH / 4; i += 256) reinterpret_cast<unsigned*>(smem + G::OFF_H)[i] = 0u;
@@ -353,10 +357,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 else {
                     const int si = s - (s >> 2);
                     wr[tl][si] = __builtin_bit_cast(frag_t, v);
-                    if (si < 16) asm volatile("" : "+a"(wr[tl][si]));
                 }
             }
         }
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+            for (int si = 0; si < 16; ++si) asm volatile("" : "+a"(wr[tl][si]));     // (pinned after all loads have been issued: see the forward)
     }
     for (int i = tid; i < 4 * G::PZ / 4; i += 256) reinterpret_cast<unsigned*>(smem + G::OFF_Z)[i] = 0u;     // dz[T] = 0
 
@@ -500,7 +507,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             *reinterpret_cast<u32x2_t*>(zout + gate_perm_col(g, u0) * 2) = v;
         }
         RES_TR(2);
-        if (kk + 1 < T) request(t - 1);
+        request(t > 0 ? t - 1 : 0);                     // unconditional (clamped): behind a condition the compiler copies the freshly requested registers at the join and waits for the loads to do it
         RES_BARRIER();
         RES_TR(3);
         RES_TR_FLUSH(1, kk);
