@@ -314,7 +314,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         if (lane == 0) cl_raise(flags + 4 * mem + w, (unsigned)(t + 1), local);
         CL_FENCE();
         CL_TR(4);
-        // ... and leave behind the flag
+        // ... and leave behind the flag.  (Measured and dropped: holding them in registers and issuing them at the START of the next step, behind its
+        // pull and staging requests, so that no store stands between a flag poll / pulled row and its wait -- 4.3 -> 5.6 us per timestep: the
+        // issue of ten scattered 16-byte stores then sits on the chain in front of the barrier, here it runs under the exchange.)
         const unsigned so_e = (unsigned)((size_t)t * us + (size_t)row0 * U);      // element offset of the step's 32 x u block
         if (SAVE) {
 #pragma unroll
@@ -503,9 +505,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             for (int s = 0; s < 16; ++s) {
                 if (i == 0 && s + 4 < 16) bq[s + 4] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(zin + 32 * (s + 4)));
                 ac = F::mfma32(wr[i][s], bq[s], ac);
-                // the previous step's outputs (dz[t+1], still in the tile the MFMAs read) leave in the shadow of the MFMA stream
-                if (s == 1) emit_read(kk & 1, i);
-                if (s == 9) emit_store(t + 1, i);
                 __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400 | 0x40 | 0x200);
             }
             // destination of half h of this tile: member 2 w + (i >> 1), wave 2 (i & 1) + h; its lane l reads what this lane l stores
@@ -515,8 +514,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = pack2<F>(ac[8 * h + 2 * k], ac[8 * h + 2 * k + 1]);
                 const unsigned vo = (unsigned)(((((2 * w + (i >> 1)) * 4 + 2 * (i & 1) + h) * 8 + mem) * 1024) + lane * 16);
-                if (local) __builtin_amdgcn_raw_buffer_store_b128(v, rs_x, vo, xb, 0);
-                else __builtin_amdgcn_raw_buffer_store_b128(v, rs_x, vo, xb, CL_SC1);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_x, vo, xb, 0);      // plain: stays in the XCD's L2 (any other placement has been refused above)
             }
         }
         CL_TR(1);
@@ -553,23 +551,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         if (!cl_wait(flags, status, 32, (unsigned)(kk + 1))) return;             // every wave of the cluster has stored its partials of this step
         CL_TR(3);
         float dhr[2][4];
-        {
-            u32x4_t pq[8];
+        u32x4_t pq[8];
 #pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) pq[s8] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo_xl + 1024 * s8, xb, CL_SC1);
+        for (int s8 = 0; s8 < 8; ++s8) pq[s8] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo_xl + 1024 * s8, xb, CL_SC1);
+        __builtin_amdgcn_sched_barrier(0);
+        // the previous step's outputs (dz[t+1], still in the tile the MFMAs read) leave HERE, behind the requests for the partial sums and while
+        // those travel: in the MFMA stream, in front of the partial stores, they delayed the flag (a wave's stores are acknowledged in issue
+        // order) -- 5.33 -> 5.01 us per timestep at [1024, 256]
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float sum = 0.f;
-#pragma unroll
-                    for (int s8 = 0; s8 < 8; ++s8) {
-                        const unsigned wv = pq[s8][2 * a + (r >> 1)];
-                        sum += (r & 1) ? F::hi(wv) : F::lo(wv);
-                    }
-                    dhr[a][r] = sum;
-                }
+        for (int j = 0; j < 4; ++j) {
+            emit_read(kk & 1, j);
+            emit_store(t + 1, j);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sum = 0.f;
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    const unsigned wv = pq[s8][2 * a + (r >> 1)];
+                    sum += (r & 1) ? F::hi(wv) : F::lo(wv);
+                }
+                dhr[a][r] = sum;
+            }
         CL_TR(4);
         // ---- what is left once dh is known: register r of group a = unit u0 + 8 a + r ----
 #pragma unroll
