@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {  # the north-star target shape, BASELINE.json configs[1], configs[0]'s batch / length with the benchmark's 5 tracks
     "tgt": dict(B=1024, T=256, P=88, M=5, name="TGT joint LSTM-NADE [1024,256,88,5]"),
+    "tgt8": dict(B=128, T=256, P=88, M=5, name="TGT / 8 joint LSTM-NADE [128,256,88,5] (the per-GPU share of the strong-scaling leg)"),
     "c2": dict(B=256, T=128, P=88, M=5, name="C2 joint LSTM-NADE [256,128,88,5]"),
     "c1x5": dict(B=16, T=64, P=88, M=5, name="C1-sized joint LSTM-NADE [16,64,88,5]"),
     "tiny": dict(B=32, T=16, P=88, M=5, name="tiny [32,16,88,5] (plumbing check)"),
