@@ -1,0 +1,55 @@
+"""NADE backward: <HQ = 1, RG = 2> (one hidden unit per lane, 16 rows per wave, FMAs packed over row pairs; MNN_NADE_BWD_FORM=12) against the default
+<2, 1> (two hidden units per lane, 8 rows per wave) on the same inputs in one process.      python profiles/tools/nade_bwd_form_probe.py"""
+import os
+import sys
+import torch
+sys.path.insert(0, ".")
+from multinn_amd import ops
+
+
+def setup(N, D, Hn, tracks, rho, seed=1):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    v = (torch.rand((tracks, N, D), device="cuda", generator=g) < rho).to(torch.uint8)
+    ld = (tracks * (Hn + D) + 63) // 64 * 64
+    bias = (torch.randn((N, ld), device="cuda", generator=g) * 0.5)[:, :tracks * (Hn + D)]
+    we = torch.randn((tracks, D, Hn), device="cuda", generator=g) * 0.1
+    wd = torch.randn((tracks, D, Hn), device="cuda", generator=g) * 0.1
+    rw = torch.rand(N, device="cuda", generator=g) * 256.0
+    d0 = torch.zeros((N, ld), device="cuda")[:, :tracks * (Hn + D)]
+    af = torch.zeros((tracks, N, Hn), device="cuda")
+    ops.nade_logprob_fwd(v, bias, we, wd, tracks, D, Hn, rw, torch.zeros((tracks, N), device="cuda"), None, d0, af)
+    return v, bias, we, wd, d0, af
+
+
+def run(waves, v, bias, we, wd, d0, af, tracks, D, Hn):
+    os.environ["MNN_NADE_BWD_FORM"] = str(waves)
+    dwe, dwd = torch.zeros_like(we), torch.zeros_like(wd)
+    d1 = torch.zeros_like(d0.as_strided((d0.shape[0], d0.stride(0)), (d0.stride(0), 1)))[:, :d0.shape[1]]
+    d1.copy_(d0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.nade_logprob_bwd(v, bias, we, wd, tracks, D, Hn, af, d1, dwe, dwd)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1), dwe, dwd, d1[:, :tracks * Hn].clone()
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+for (N, D, Hn, tracks, rho) in [(512, 88, 128, 2, 0.03), (300, 440, 256, 1, 0.03), (4096, 440, 256, 1, 0.03), (1000, 88, 100, 5, 0.1), (2048, 443, 200, 1, 0.3),
+                                (65, 7, 65, 3, 0.5)]:
+    ins = setup(N, D, Hn, tracks, rho)
+    _, e0, d0_, b0 = run(0, *ins, tracks, D, Hn)
+    _, e1, d1_, b1 = run(12, *ins, tracks, D, Hn)
+    print(f"check N={N} D={D} Hn={Hn} tracks={tracks} rho={rho}: rel diff d w_enc {rel(e1, e0):.2e}  d w_dec {rel(d1_, d0_):.2e}  d b_enc {rel(b1, b0):.2e}", flush=True)
+
+for (N, D, Hn, tracks) in [(262144, 440, 256, 1), (262144, 88, 128, 5), (32768, 440, 256, 1)]:
+    for rho in (0.03, 0.1):
+        ins = setup(N, D, Hn, tracks, rho)
+        t8, t16 = [], []
+        for rd in range(5):
+            t8.append(run(0, *ins, tracks, D, Hn)[0])
+            t16.append(run(12, *ins, tracks, D, Hn)[0])
+        print(f"N={N} D={D} Hn={Hn} tracks={tracks} rho={rho}: <2,1>: 64 rows x 128 hidden per workgroup {sorted(t8[1:])[1]:.3f} ms | <1,2>: 128 rows x 64 hidden, rows packed {sorted(t16[1:])[1]:.3f} ms", flush=True)
