@@ -304,7 +304,7 @@ def _recorded(workload, precision, kind):
 
 
 def attach_counters(rf, workload, precision):
-    """rocprofv3 counters cannot be collected from inside this process: the line carries the counters RECORDED by profiles/tools/record_round4.sh
+    """rocprofv3 counters cannot be collected from inside this process: the line carries the counters RECORDED by profiles/tools/record_round5.sh (record_round4.sh in round 4)
     (separate --pmc passes over this command in eager mode) under roofline.recorded_counters, with the file, the source hash of the recorded
     build and `same_build`.  Only when the recording was taken on this very build are its HBM bytes also reported as roofline.traffic (the
     contract's field); otherwise traffic stays null -- stale counters never stand beside live timings unmarked."""
