@@ -284,6 +284,50 @@ def test_timed_kernels_long_sequence_vs_oracle(monkeypatch):
     assert all(c > 0.99999 for c in cosv.values()), cosv
 
 
+def test_timed_cluster_kernels_long_sequence_vs_oracle():
+    """The kernel forms the bench step takes since round 5 -- layer 1 (512 units) on the CLUSTER form of the CU-resident recurrence
+    (`lstm_cl_fwd / bwd_kernel<Fp16F>`: eight CUs share 32 rows, h through the XCD's L2, backward as K split + reduce-scatter of 16-bit partial
+    sums), layer 2 on the CU-resident kernels, the weight-resident input-projection GEMM, the split-operand matrix-core NADE forward, the
+    K-blocked dz^T operand -- against the float64 oracle over T = 16 timesteps at the real widths and the bench density (B = 256: eight
+    clusters, one per XCD; 16 exchanges per cluster and direction, both exchange buffers re-used 8 times; T = 32 measured the same bounds)."""
+    from multinn_amd import RnnNade
+    B, T, rho = 256, 16, 0.03
+    x = synth(B, T, 37, rho)
+    p = G.init_rnn_nade(41, D, D, HN, UNITS, np.float64)
+    for W, b in p['lstm']:
+        b += 0.05
+    p['fc_b'][HN:] += np.log(rho / (1 - rho))
+    inp, tgt = G.joint_inputs(x.astype(np.float64))
+    fw = G.rnn_nade_forward(inp, tgt, None, p, 0.9, G.dropout_uniforms(23, B, T, UNITS))
+    g = G.rnn_nade_backward(fw, p)
+    gen = RnnNade(D, HN, UNITS, keep_prob=0.9, precision="fp16", seed=23)
+    gen._materialize(D)
+    load(gen, p)
+    gen._stack.rowpar_min_batch = 32
+    gen.build_pianoroll(dev(x), None, is_train=True, mode="train")
+    assert gen._stack._rowpar(B, T) and gen._ctx["lstm"][0].get("rowpar") and gen._nade_mfma() and gen._nade_exact()
+    assert gen._stack.kblock_wgrads
+    assert gen._stack._cluster(0, B, T) and gen._stack._resident(1, B, T) and not gen._stack._resident(0, B, T)
+    loss = float(gen.metrics["batch/loss"])
+    nll = gen.log_probs.cpu().numpy()
+    cp_err = np.abs(gen.cond_probs.cpu().numpy() - fw['cond_p'][0]).max()
+    gen.backward()
+    gen._stack.check()
+    errs = {"loss": abs(loss - fw['loss']) / abs(fw['loss']), "nll": rel(nll, fw['nll'][0])}
+    cosv = {}
+    for name, ref in zip(gen.store.names(), oracle_grads(g)):
+        got = gen.store.gviews[name].cpu().numpy().reshape(ref.shape)
+        errs[name] = rel(got, ref)
+        cosv[name] = cosine(got, ref)
+    print(f"\n[cluster kernels fp16 B={B} T={T} rho={rho}] relative error vs float64 oracle:")
+    for k, v in errs.items():
+        print(f"    {k:24s} {v:.3e}" + (f"   cos {cosv[k]:.6f}" if k in cosv else ""))
+    print(f"    {'cond_probs (abs)':24s} {cp_err:.3e}")
+    assert errs["loss"] < 1e-4 and errs["nll"] < 1e-4 and cp_err < 1e-4, (errs, cp_err)
+    assert all(v < 3e-3 for v in errs.values()), errs
+    assert all(c > 0.99999 for c in cosv.values()), cosv
+
+
 def test_persistent_forms_refuse_grids_that_cannot_be_resident():
     """Co-residency is a construction, not an assumption: the host plans size every persistent grid to at most one workgroup per CU of THIS
     device and refuse shapes whose row tiles do not fit (the caller then takes the launch-per-timestep kernels -- still device code); the C
