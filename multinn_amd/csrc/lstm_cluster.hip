@@ -2,11 +2,13 @@
 // one CU holds (lstm_resident.hip keeps a 256-unit layer's 512 KB on ONE CU).  Here EIGHT workgroups -- one per CU, all on one XCD -- share a tile
 // of 32 batch rows for the whole sequence: member c keeps the weights of units [64 c, 64 c + 64) (256 gate columns x K = 512: 256 KB = 256
 // registers per lane at one wave per SIMD, ALL of them AGPRs the matrix cores read in place; no weights in LDS), computes those units' gates and
-// state for the 32 rows every step, and the members exchange h[t] (backward: dz[t]) through a two-deep area that stays in their XCD's L2:
+// state for the 32 rows every step, and the members exchange h[t] (backward: partial sums of dh, see there) through a two-deep area that stays in
+// their XCD's L2.  Forward:
 //     wave: pointwise -> its 32 x 16 block of h[t] (1 KB) -> exchange area -> s_waitcnt -> its progress flag;
 //           poll the cluster's 32 flags -> pull the whole 32 x 512 tile into LDS (LDS-DMA, L1-bypassing) -> workgroup barrier -> MFMAs.
 // Against the row-parallel form (lstm_rowpar.hip: a workgroup = a 32-unit tile for every row tile, weights in LDS) a CU pulls 32 KB per step
-// instead of 64 KB (backward: 128 KB instead of 256 KB), reads no weight fragments from LDS, and every MFMA column carries a distinct row.
+// instead of 64 KB (backward: 32 KB out + 32 KB in instead of 256 KB in), reads no weight fragments from LDS, and every MFMA column carries a
+// distinct row.  Measured at [1024, 256]: 4.3 / 4.8 us per timestep against 5.9 / 6.9 (profiles/round5_g_cluster_notes.md).
 //
 // Matrix-core layout (v_mfma_f32_32x32x16_{f16,bf16}; D[m][n] += A[m][k] B[k][n]; lane l holds A[l & 31][8 (l >> 5) ..+7], B[8 (l >> 5) ..+7][l & 31],
 // D[8 (i >> 2) + 4 (l >> 5) + (i & 3)][l & 31], i = 0..15):
