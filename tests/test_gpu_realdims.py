@@ -288,10 +288,11 @@ def test_timed_cluster_kernels_long_sequence_vs_oracle():
     """The kernel forms the bench step takes since round 5 -- layer 1 (512 units) on the CLUSTER form of the CU-resident recurrence
     (`lstm_cl_fwd / bwd_kernel<Fp16F>`: eight CUs share 32 rows, h through the XCD's L2, backward as K split + reduce-scatter of 16-bit partial
     sums), layer 2 on the CU-resident kernels, the weight-resident input-projection GEMM, the split-operand matrix-core NADE forward, the
-    K-blocked dz^T operand -- against the float64 oracle over T = 16 timesteps at the real widths and the bench density (B = 256: eight
-    clusters, one per XCD; 16 exchanges per cluster and direction, both exchange buffers re-used 8 times; T = 32 measured the same bounds)."""
+    K-blocked dz^T operand -- against the float64 oracle over T = 8 timesteps at the real widths and the bench density (B = 256: eight
+    clusters, one per XCD; 8 exchanges per cluster and direction, both exchange buffers re-used 4 times; T = 16 and T = 32 measured the same
+    bounds -- the float64 oracle is what takes the time)."""
     from multinn_amd import RnnNade
-    B, T, rho = 256, 16, 0.03
+    B, T, rho = 256, 8, 0.03
     x = synth(B, T, 37, rho)
     p = G.init_rnn_nade(41, D, D, HN, UNITS, np.float64)
     for W, b in p['lstm']:
