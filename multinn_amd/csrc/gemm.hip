@@ -7,6 +7,7 @@
 // K-chunk (32 bf16 / 16 f32) padded to 80 bytes so that the 16 rows a ds_read_b128 lane group
 // touches fall on 16 distinct 16-byte slots (conflict-free, MI355X_MICROARCH "LDS").
 #include "common.h"
+typedef unsigned gm_u4 __attribute__((ext_vector_type(4)));
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
@@ -303,13 +304,15 @@ __device__ __forceinline__ void epi_store_wide(void* __restrict__ Cv, int ldc, i
                     pk.y = pack2<CF>(v0.z, v0.w);
                     pk.z = pack2<CF>(v1.x, v1.y);
                     pk.w = pack2<CF>(v1.z, v1.w);
-                    *reinterpret_cast<uint4*>(Cb + (size_t)(row0 + i * 32 + row) * ldc + col0 + j * 32 + c8) = pk;
+                    // NON-TEMPORAL (also below): the activation GEMMs' C is written once and read by a later kernel; with the default policy it pushes the
+                    // operand panels the tiles of a row share through the L2 out (Dense forward 240 -> 212 us, xproj1 on this kernel 745 -> 605 us)
+                    __builtin_nontemporal_store(__builtin_bit_cast(gm_u4, pk), reinterpret_cast<gm_u4*>(Cb + (size_t)(row0 + i * 32 + row) * ldc + col0 + j * 32 + c8));
                 }
             } else {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int row = 8 * p + (lane >> 3), c4 = 4 * (lane & 7);
-                    *reinterpret_cast<float4*>(Cf + (size_t)(row0 + i * 32 + row) * ldc + col0 + j * 32 + c4) = *reinterpret_cast<const float4*>(sc + row * 36 + c4);
+                    __builtin_nontemporal_store(*reinterpret_cast<const gm_u4*>(sc + row * 36 + c4), reinterpret_cast<gm_u4*>(Cf + (size_t)(row0 + i * 32 + row) * ldc + col0 + j * 32 + c4));
                 }
             }
             asm volatile("" ::: "memory");

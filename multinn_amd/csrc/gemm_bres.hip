@@ -133,7 +133,10 @@ gemm_bres_kernel(const h16_t* __restrict__ A, int lda, const h16_t* __restrict__
         // the tile loop (32 registers, spilled to scratch at K = 512 -- and scratch traffic would break the vmcnt bookkeeping)
         char* cb = reinterpret_cast<char*>(C) + (size_t)(row_base + (long)t_prev * 128 + i * 32 + pp * 8) * (size_t)ldc * 2;
         if (VAR & 1) asm volatile("" :: "v"(pend[i][pp]));
-        else *reinterpret_cast<br_u4*>(cb + lane_off) = pend[i][pp];    // unconditional (N is a multiple of 256): the vmcnt bookkeeping counts on every store issuing
+        // unconditional (N is a multiple of 256): the vmcnt bookkeeping counts on every store issuing.  NON-TEMPORAL: C is written once and read by a
+        // later kernel; stored with the default policy its gigabyte pushes the activation slabs -- which the eight CUs of a column-panel group
+        // share through their XCD's L2 -- out before all of them have read them (xproj1 536 -> 504 us, xproj2 313 -> 289 us)
+        else __builtin_nontemporal_store(pend[i][pp], reinterpret_cast<br_u4*>(cb + lane_off));
     };
 
     // sync(qm): stage (t, qm) has landed for every wave (this wave's pieces by a counted vmcnt -- everything younger may still fly: 5 stages

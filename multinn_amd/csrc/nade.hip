@@ -509,7 +509,7 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
             const int j = lane + 64 * q, row = rbase + r;
-            if (row < N && j < Hn) d_bias[(size_t)row * ld_bias + m * HnT + hb + j] = G[r][q];
+            if (row < N && j < Hn) __builtin_nontemporal_store(G[r][q], &d_bias[(size_t)row * ld_bias + m * HnT + hb + j]);      // written once, read by a later kernel
         }
 }
 
