@@ -22,7 +22,8 @@ Rank 0 prints ONE JSON line: the contract fields plus
   strong        (N > 1) the step with the GLOBAL batch fixed at B, B/N sequences per rank;
   strong_proxy  (N = 1) the step at B/8 sequences: the per-GPU share of the global batch at 8 GPUs (8 x its rate = the strong leg's ceiling);
   sampling      generated timesteps/s of the sampling scan;
-  cpu_baseline  the oracle's torch-CPU port of the reference formulation on the host cores (N = 1 only): one step at C2 [256,128,88,5].
+  cpu_baseline  the oracle's torch-CPU port of the reference formulation on the host cores (N = 1 only): median of 3 steps at C2 [256,128,88,5],
+                preparation (batch, dropout uniforms, conversions) outside the timed region and reported separately.
 `--workload c3|c4` (BASELINE configs[2] / [3]: jamming 5 x LSTM-RBM CD-10, composer DBNEncoder -> LSTM-MultiNADE) time the mode classes'
 captured train step at the reference's layer widths and print the same contract fields.
 """
@@ -117,11 +118,15 @@ def ragged_lengths(B, T, seed=24):
     return np.random.Generator(np.random.PCG64(seed)).integers(T // 2, T + 1, size=B).astype(np.int32)
 
 
-def cpu_baseline(P, M, rho=0.03):
+def cpu_baseline(P, M, rho=0.03, reps=3):
     """The SAME train step on the host cores: the oracle's torch-CPU float32 port of the reference formulation (per-step LSTMBlockCell,
-    per-visible NADE loop keeping every [rows, Hn] sigmoid for autograd, clip + TF Adam), ONE step at C2 [256,128,88,5] (BASELINE.md names
-    C1 / C2 for the CPU path; TGT needs 118 GB in this formulation).  The NADE part runs in row chunks with its backward inside the chunk
-    (the reference keeps all [N, D, Hn] activations: 14.8 GB at C2), which changes memory, not arithmetic."""
+    per-visible NADE loop keeping every [rows, Hn] sigmoid for autograd, clip + TF Adam) at C2 [256,128,88,5] (BASELINE.md names C1 / C2 for
+    the CPU path; TGT needs 118 GB in this formulation).  The NADE part runs in row chunks with its backward inside the chunk (the reference
+    keeps all [N, D, Hn] activations: 14.8 GB at C2), which changes memory, not arithmetic.
+
+    Only the step is timed: the synthetic batch, its input / target slices, the dropout uniforms (25 M NumPy-Philox draws) and every tensor
+    conversion are PREPARED first (reported as `prepare_seconds`), one full-shape step runs untimed (allocator, thread pool, autograd graph
+    caches), then `reps` steps are timed one by one and the MEDIAN is reported (`seconds`; all of them in `seconds_each`)."""
     import numpy as np
     import torch
     from oracle import generators as G, torch_ref as TR
@@ -132,14 +137,16 @@ def cpu_baseline(P, M, rho=0.03):
     Pm = TR.to_torch(G.init_rnn_nade(23, D, D, HN, UNITS, np.float32))
     opt = TR.TFAdam(TR.flat_params(Pm))
 
-    def step(B, T, chunk=2048):
+    def prepare(B, T):
         x = synth(B, T, P, M, 23, rho).astype(np.float32)
         inp, tgt = G.joint_inputs(x)
         du = [torch.tensor(a) for a in G.dropout_uniforms(23, B, T, UNITS)]
-        xi, ti = torch.tensor(inp), torch.tensor(tgt).reshape(B * T, D)
+        return torch.tensor(inp), torch.tensor(tgt).reshape(B * T, D), du
+
+    def step(xi, ti, du, chunk=2048):
+        N = ti.shape[0]
         y, _ = TR.lstm_seq(xi, Pm['lstm'], 0.9, du)
-        out = y.reshape(B * T, -1) @ Pm['fc_k'] + Pm['fc_b']
-        N = B * T
+        out = y.reshape(N, -1) @ Pm['fc_k'] + Pm['fc_b']
         d_out = torch.zeros_like(out)
         loss = 0.0
         for s in range(0, N, chunk):            # forward + backward of the NADE scan per row chunk (weight gradients accumulate in .grad)
@@ -152,12 +159,21 @@ def cpu_baseline(P, M, rho=0.03):
         out.backward(d_out)
         opt.step()
         return loss
-    step(8, 8)                                  # allocator / thread-pool warm-up on a toy batch
     t0 = time.perf_counter()
-    loss = step(B, T)
-    dt = time.perf_counter() - t0
-    return dict(value=B * T / dt, unit="timesteps/s", cores=cores, kind="port", seconds=dt, loss=loss,
-                sample=f"1 train step of C2 [B={B},T={T},88,5] joint LSTM-NADE (oracle/torch_ref.py, float32, {cores} threads, NADE in 2048-row chunks)")
+    batch = prepare(B, T)
+    t_prep = time.perf_counter() - t0
+    step(*batch)                                # untimed full-shape warm-up step
+    each, loss = [], None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        loss = step(*batch)
+        each.append(time.perf_counter() - t0)
+    dt = sorted(each)[len(each) // 2]
+    return dict(value=B * T / dt, unit="timesteps/s", cores=cores, kind="port", seconds=dt, seconds_each=each, prepare_seconds=t_prep,
+                loss=loss,
+                sample=f"median of {reps} train steps (after 1 untimed full-shape step) of C2 [B={B},T={T},88,5] joint LSTM-NADE "
+                       f"(oracle/torch_ref.py, float32, {cores} threads, NADE in 2048-row chunks); batch synthesis, dropout uniforms and "
+                       f"tensor conversion prepared outside the timed region ({t_prep:.2f} s)")
 
 
 def sampling_scan(gen, P, M, n=72, intro=32, steps=128, reps=3):
