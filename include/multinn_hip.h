@@ -43,9 +43,9 @@ enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_ST
 
 /* ABI version of THIS header: bumped whenever a signature or a descriptor struct changes.  mnn_version() returns the value the library
  * was built with; a loader must compare the two before its first call (multinn_amd/_lib.py load() does) -- a library built for another
- * version reads garbage arguments without any diagnosis otherwise.  116: + mnn_lstm_cluster_ok / _fwd / _bwd.  115: mnn_step_increment gained `sumsq`, `clip_norm`.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
+ * version reads garbage arguments without any diagnosis otherwise.  117 (round 6): + mnn_lstm_cluster_bwd_ok.  116: + mnn_lstm_cluster_ok / _fwd / _bwd.  115: mnn_step_increment gained `sumsq`, `clip_norm`.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
  * mnn_pianoroll_shift_timemajor_t / mnn_grad_rows_fanout and the `f16` descriptor fields of round 3 are part of it. */
-#define MNN_ABI_VERSION 116
+#define MNN_ABI_VERSION 117
 int mnn_version(void);
 const char* mnn_last_error(void);
 
@@ -244,7 +244,11 @@ int mnn_lstm_cluster_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer*
 /* ... and its backward: descriptor, outputs and layouts of mnn_lstm_rowpar_bwd (dh_ext required; dz_T, dzT_t / ld_t (0 = K-blocked), db_p optional;
  * wx_p / dz unused).  The contraction over the 2048 gate columns is split the way the columns are owned: a member multiplies its own 256 columns
  * of dz[t+1] (in its LDS: nothing is exchanged in front of the MFMAs) into partial sums for all 512 units, and the members reduce-scatter the
- * partials (16-bit, 32 KB out + 32 KB in per CU and step).  T >= 4.  A cluster whose workgroups do not share an XCD gives up (status word). */
+ * partials (16-bit, 32 KB out + 32 KB in per CU and step).  T >= 4.  The two-deep exchange area is only valid while a cluster's eight workgroups
+ * share an XCD: mnn_lstm_cluster_bwd_ok answers that ON THE HOST (one probe launch of the kernels' grid per device and batch size, cached; also
+ * 0 under MNN_PERSIST_NO_LOCAL) and the caller takes mnn_lstm_rowpar_bwd -- same descriptor, same saved activations -- when it says 0.  A launch
+ * that nevertheless finds a cluster off one XCD gives up (status word) instead of computing on stale lines. */
+int mnn_lstm_cluster_bwd_ok(int B, int units);
 int mnn_lstm_cluster_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L, float keep_prob, void* workspace);
 int mnn_dropout_mask(mnn_stream_t s, uint8_t* mask, int T, int B, int units, float keep_prob, uint64_t seed, const int32_t* step_dev,
                      uint32_t row0, int layer);

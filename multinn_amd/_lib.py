@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MULTINN_HIP_LIB", os.path.join(HERE, "libmultinn_hip.so"))   # override: A/B builds of the same ABI
 
-ABI_VERSION = 116          # == MNN_ABI_VERSION of include/multinn_hip.h; load() refuses a library built for another one
+ABI_VERSION = 117          # == MNN_ABI_VERSION of include/multinn_hip.h; load() refuses a library built for another one
 F32, BF16, U8, F16 = 0, 1, 2, 3
 GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_A_KBLOCK32 = 1, 2, 8
 
@@ -110,6 +110,7 @@ SIGNATURES["mnn_lstm_resident_ok"] = (_i, [_i, _i])
 SIGNATURES["mnn_lstm_resident_fwd"] = (_i, [_p, _i, _i, C.POINTER(LstmFwdLayer), _f])
 SIGNATURES["mnn_lstm_resident_bwd"] = (_i, [_p, _i, _i, C.POINTER(LstmBwdLayer), _f])
 SIGNATURES["mnn_lstm_cluster_ok"] = (_i, [_i, _i])
+SIGNATURES["mnn_lstm_cluster_bwd_ok"] = (_i, [_i, _i])
 SIGNATURES["mnn_lstm_cluster_fwd"] = (_i, [_p, _i, _i, C.POINTER(LstmFwdLayer), _f, _p])
 SIGNATURES["mnn_lstm_cluster_bwd"] = (_i, [_p, _i, _i, C.POINTER(LstmBwdLayer), _f, _p])
 SIGNATURES["mnn_nade_mfma_ok"] = (_i, [_i])

@@ -266,13 +266,23 @@ int mnn_gemm_bres_launch(hipStream_t st, int f16, int M, int N, int K, const voi
     fn_t fn;
     if (K == 448) fn = f16 ? gemm_bres_kernel<Fp16F, 7> : gemm_bres_kernel<Bf16F, 7>;
     else fn = f16 ? gemm_bres_kernel<Fp16F, 8> : gemm_bres_kernel<Bf16F, 8>;
-    const char* ve = getenv("MNN_GEMM_BRES_VAR");
-    const int var = ve ? atoi(ve) : 0;
-    if (var >= 1 && var <= 3 && f16) {
-        if (K == 448) fn = var == 1 ? gemm_bres_kernel<Fp16F, 7, 1> : (var == 2 ? gemm_bres_kernel<Fp16F, 7, 2> : gemm_bres_kernel<Fp16F, 7, 3>);
-        else fn = var == 1 ? gemm_bres_kernel<Fp16F, 8, 1> : (var == 2 ? gemm_bres_kernel<Fp16F, 8, 2> : gemm_bres_kernel<Fp16F, 8, 3>);
-        MNN_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, BR_LDS));
+#ifdef BR_ABLATION      // development builds only (profiles/tools/gemm_bres_probe.py): ablation variants that do NOT store C, chosen by MNN_GEMM_BRES_VAR
+    {
+        const char* ve = getenv("MNN_GEMM_BRES_VAR");
+        const int var = ve ? atoi(ve) : 0;
+        if (var >= 1 && var <= 3 && f16) {
+            if (K == 448) fn = var == 1 ? gemm_bres_kernel<Fp16F, 7, 1> : (var == 2 ? gemm_bres_kernel<Fp16F, 7, 2> : gemm_bres_kernel<Fp16F, 7, 3>);
+            else fn = var == 1 ? gemm_bres_kernel<Fp16F, 8, 1> : (var == 2 ? gemm_bres_kernel<Fp16F, 8, 2> : gemm_bres_kernel<Fp16F, 8, 3>);
+            MNN_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, BR_LDS));
+            const int ncp_ = cdiv(N, 256), mt_ = M / 128;
+            int ns_ = std::min(std::max(8, (256 / ncp_) / 8 * 8), cdiv(mt_, 8) * 8);
+            hipLaunchKernelGGL(fn, dim3(ns_ * ncp_), dim3(256), BR_LDS, st, (const h16_t*)A, lda, (const h16_t*)B, ldb, (h16_t*)C, ldc, bias, M, N, ncp_, ns_,
+                               cdiv(mt_, ns_));
+            MNN_LAUNCH_CHECK();
+            return MNN_OK;                                         // (never touches raised_: the product slot keeps its own LDS-limit bookkeeping)
+        }
     }
+#endif
     static bool raised_[64][4];
     int dev = 0;
     MNN_HIP(hipGetDevice(&dev));

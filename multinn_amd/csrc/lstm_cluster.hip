@@ -447,6 +447,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const bool local = A.allow_local != 0 && *s_local != 0;
     if (*s_local == 0) {
         // the two-deep exchange area is re-written every other step: only valid while the cluster shares one L2.  Give up loudly (sticky status word).
+        // (mnn_lstm_cluster_bwd_ok asks the placement on the host before this form is chosen: reaching this line means the probe and the launch disagree)
         if (tid == 0) { cl_st(status, 1u); cl_st(status + 1, 1u); }
         return;
     }
@@ -685,6 +686,63 @@ static hipError_t cl_prepare() {
 extern "C" int mnn_lstm_cluster_ok(int B, int units) {
     if (!cl_shape_ok(B, units)) return 0;
     return cl_prepare() == hipSuccess ? 1 : 0;
+}
+
+// Placement probe: is every cluster of a (8 ncl)-workgroup launch of these kernels dealt onto ONE XCD?  The backward's two-deep exchange area is only
+// valid then (the forward has a write-through fall-back, the backward does not), and the answer is a property of the device's partitioning and the
+// dispatcher's dealing order -- deterministic, so it is asked ONCE per device and grid on the host (a launch of the kernels' own grid and LDS size whose
+// workgroups post their XCC id), not found out by a training step that has already consumed unwritten gradients.
+__global__ void __launch_bounds__(256) cl_place_probe_kernel(unsigned* __restrict__ out) {
+    extern __shared__ char cl_probe_smem_[];
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) {
+        cl_probe_smem_[0] = (char)xcc;                       // (the dynamic LDS is what keeps one workgroup per CU, as in the real launch)
+        out[blockIdx.x] = 0x100u | (xcc & 0xfu);
+    }
+}
+static int cl_placement_ok(int ncl) {
+    static signed char known[64][9];                         // [device][ncl / 8]: 0 unknown, 1 every cluster on one XCD, -1 not
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || ncl < 8 || ncl > 64 || (ncl & 7)) return 0;
+    signed char& k = known[dev][ncl / 8];
+    if (k != 0) return k > 0;
+    // may be reached for the first time while ANOTHER stream of this thread is capturing: the probe runs on its own stream, relaxed mode for its calls
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) return 0;
+    int ok = 0;
+    hipStream_t st = nullptr;
+    unsigned* d = nullptr;
+    unsigned host[512];
+    do {
+        if (hipFuncSetAttribute((const void*)cl_place_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ClBwdGeom::LDS) != hipSuccess) break;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+        if (hipMalloc((void**)&d, 8 * ncl * sizeof(unsigned)) != hipSuccess) break;
+        if (hipMemsetAsync(d, 0, 8 * ncl * sizeof(unsigned), st) != hipSuccess) break;
+        hipLaunchKernelGGL(cl_place_probe_kernel, dim3(8 * ncl), dim3(256), ClBwdGeom::LDS, st, d);
+        if (hipGetLastError() != hipSuccess) break;
+        if (hipMemcpyAsync(host, d, 8 * ncl * sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess) break;
+        if (hipStreamSynchronize(st) != hipSuccess) break;
+        ok = 1;
+        for (int b = 0; b < 8 * ncl && ok > 0; ++b) {        // the kernels' own mapping: cluster = (blockIdx & 7) * (ncl / 8) + (blockIdx >> 6)
+            const int xcd = b & 7, seq = b >> 3, cl = xcd * (ncl >> 3) + (seq >> 3);
+            const int b0 = xcd + 8 * (8 * (cl - xcd * (ncl >> 3)));     // member 0 of the same cluster
+            if ((host[b] & 0x100u) == 0u || host[b] != host[b0]) ok = -1;
+        }
+    } while (false);
+    if (d) (void)hipFree(d);
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    if (ok == 0) return 0;                                   // the probe itself failed: unknown stays unknown, answer "no"
+    k = (signed char)ok;
+    return ok > 0;
+}
+// The backward may run: shape covered AND every cluster sits on one XCD (MNN_PERSIST_NO_LOCAL, the tests' hook, answers "no" like a repartitioned device).
+// The caller falls back to mnn_lstm_rowpar_bwd, which reads the same saved activations.
+extern "C" int mnn_lstm_cluster_bwd_ok(int B, int units) {
+    if (!mnn_lstm_cluster_ok(B, units)) return 0;
+    if (getenv("MNN_PERSIST_NO_LOCAL") != nullptr) return 0;
+    return cl_placement_ok(B / 32);
 }
 
 extern "C" int mnn_lstm_cluster_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L, float keep_prob, void* workspace) {

@@ -160,6 +160,21 @@ class LstmStack:
         return (self.cluster and not self.rowpar_xproj_f32 and ops.lstm_cluster_ok(B, self.packed[l]["u"])
                 and T * B * self.packed[l]["u"] * 8 < 2 ** 31)
 
+    def _cluster_bwd(self, l, B, T):
+        """The cluster BACKWARD needs every cluster's eight workgroups on one XCD (its two-deep exchange area lives in that XCD's L2; the forward has
+        a write-through fall-back).  The library asks the placement once per device and batch size on the host; when it says no -- a repartitioned
+        device, MNN_PERSIST_NO_LOCAL -- this layer's backward takes the row-parallel kernels (same descriptors, same saved activations), said once."""
+        if not (self._cluster(l, B, T) and T >= 4):
+            return False
+        if ops.lstm_cluster_bwd_ok(B, self.packed[l]["u"]):
+            return True
+        if not getattr(LstmStack, "_cluster_bwd_warned", False):
+            LstmStack._cluster_bwd_warned = True
+            import warnings
+            warnings.warn("multinn_amd: the clusters of the 512-unit recurrence are not dealt onto single XCDs on this device; its backward runs on "
+                          "the row-parallel kernels (lstm_rowpar_bwd) instead of lstm_cluster_bwd")
+        return False
+
     @property
     def rowpar_xproj_dtype(self):
         return torch.float32 if self.rowpar_xproj_f32 else self.dtype
@@ -272,7 +287,7 @@ class LstmStack:
                                     cx["mask"] if keep_prob < 1.0 else None, gates_dtype=self.dtype)
             if self._resident(l, B, T):
                 ops.lstm_resident_bwd(T, B, e, keep_prob)
-            elif self._cluster(l, B, T) and T >= 4:
+            elif self._cluster_bwd(l, B, T):
                 ops.lstm_cluster_bwd(T, B, e, keep_prob, self._rp_workspace(l, T, B, dev))
             else:
                 ops.lstm_rowpar_bwd(T, B, e, keep_prob, self._rp_workspace(l, T, B, dev))

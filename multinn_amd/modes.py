@@ -259,21 +259,33 @@ class MultINNCore(Model):
             # class (other default name, e.g. MultINN-jamming) are found by content -- any mode checkpoint with these tracks and encoders
             import glob
             import warnings
+            # newest first (the reference restores the MOST RECENT checkpoint: tf.train.get_checkpoint_state, multinn_core.py:440-444); a
+            # candidate must carry these tracks, this many encoders AND the same variable names per encoder -- a file that does not is skipped,
+            # not an error; map_location='cpu': a directory of large generator checkpoints is scanned without touching device memory
             hits = []
-            for cand in sorted(glob.glob(os.path.join(ckpt_dir, "*.pt"))):
+            cands = sorted(glob.glob(os.path.join(ckpt_dir, "*.pt")), key=lambda f: os.path.getmtime(f), reverse=True)
+            for cand in cands:
                 try:
-                    b = torch.load(cand)
+                    b = torch.load(cand, map_location="cpu")
                 except Exception:
                     continue
-                if isinstance(b, dict) and list(b.get("tracks", [])) == list(self._tracks) and len(b.get("encoders", [])) == len(self._encoders) \
-                        and all(sd is not None for sd in b["encoders"]):
+                if not (isinstance(b, dict) and list(b.get("tracks", [])) == list(self._tracks) and len(b.get("encoders", [])) == len(self._encoders)
+                        and all(sd is not None for sd in b["encoders"])):
+                    continue
+                names_ok = True
+                for e, sd in zip(self._encoders, b["encoders"]):
+                    if e.store.theta is None:
+                        e.store.materialize()
+                    names_ok = names_ok and isinstance(sd, dict) and list(sd.get("names", [])) == e.store.names()
+                if names_ok:
                     hits.append(cand)
             if hits:
                 if len(hits) > 1:
-                    warnings.warn(f"{ckpt_dir}: several mode checkpoints hold encoders for these tracks ({[os.path.basename(h) for h in hits]}); loading {os.path.basename(hits[0])}")
+                    warnings.warn(f"{ckpt_dir}: several mode checkpoints hold encoders for these tracks ({[os.path.basename(h) for h in hits]}); "
+                                  f"loading the most recent, {os.path.basename(hits[0])}")
                 path = hits[0]
         if os.path.exists(path):
-            blob = torch.load(path)
+            blob = torch.load(path, map_location="cpu")
             if list(blob.get("tracks", [])) != list(self._tracks) or len(blob.get("encoders", [])) != len(self._encoders):
                 raise ValueError(f"checkpoint {path} does not match this model's tracks / encoders")
             if any(sd is None for sd in blob["encoders"]):

@@ -386,6 +386,12 @@ def lstm_cluster_ok(B, units):
     return bool(_lib.load().mnn_lstm_cluster_ok(int(B), int(units)))
 
 
+def lstm_cluster_bwd_ok(B, units):
+    """True when the cluster BACKWARD may run: the shape is covered and every cluster of the launch is dealt onto one XCD (asked on the host by one
+    probe launch per device and batch size, cached in the library; False under MNN_PERSIST_NO_LOCAL).  False: take lstm_rowpar_bwd."""
+    return bool(_lib.load().mnn_lstm_cluster_bwd_ok(int(B), int(units)))
+
+
 def lstm_cluster_fwd(T, B, L, keep_prob, ws):
     """L: descriptor of lstm2_fwd_layer, as for lstm_rowpar_fwd with a 16-bit xproj; ws: the tensor of lstm_rowpar_workspace(T, B, 512)."""
     _rp_ws_ok(ws, T, B, L.units)

@@ -1,4 +1,5 @@
-"""A/B of the short-K activation GEMMs of the bench-shape train step (TGT [1024,256,88,5]: 262 144 rows) in ONE process:
+"""[Historical: the pair kernel left libmultinn_hip.so in round 6 (gemm_pair_kernel.hip.frag); this probe needs the round-5 library.]
+A/B of the short-K activation GEMMs of the bench-shape train step (TGT [1024,256,88,5]: 262 144 rows) in ONE process:
 MNN_GEMM_PAIR=0 (the 256 x 256 kernel), =1 (pair kernel, C in whole lines through LDS), =2 (pair kernel, C straight from the accumulators).
 Every form is first checked against an f32 torch product of the same 16-bit operands.  Run from the repository root on the GPU box:
     python profiles/tools/gemm_pair_probe.py [rounds]"""

@@ -1134,10 +1134,10 @@ def test_clip_adam_skips_a_non_finite_step_and_the_step_counter_with_it(ops):
 
 @pytest.mark.parametrize("M,N,K,cdt,hb", [(1000, 696, 256, torch.float32, True), (512, 200, 64, torch.float16, True), (768, 2048, 448, torch.float16, True),
                                            (300, 128, 96, torch.bfloat16, False), (2048, 256, 704, torch.float32, True), (4096, 512, 1024, torch.float32, False)])
-def test_gemm_pair_kernel_matches_the_product(ops, M, N, K, cdt, hb, monkeypatch):
-    """The short-K form (two 4-wave workgroups of 256 x 128 per CU, profiles/round5_a_gemm_pair_notes.md), forced on with MNN_GEMM_PAIR: both
-    epilogues (whole lines through LDS = 1, straight from the registers = 2) against an f32 product of the same 16-bit operands -- M not a
-    multiple of 256, an N edge inside a wave tile, K = 64, padding columns of C untouched."""
+def test_gemm_tn_short_k_activation_shapes_vs_f32_product(ops, M, N, K, cdt, hb):
+    """The step's short-K activation GEMM shapes (M not a multiple of the row tile, an N edge inside a wave tile, K = 64 .. 1024, f32 and 16-bit
+    C, with and without bias) through mnn_gemm_tn's own dispatch against an f32 product of the same 16-bit operands; padding columns of C stay
+    untouched.  (Round 5's "pair" kernel, which this test used to force on, left the library in round 6: profiles/tools/gemm_pair_kernel.hip.frag.)"""
     g = torch.Generator(device=DEV).manual_seed(1)
     for dt in (torch.float16, torch.bfloat16):
         if cdt != torch.float32 and cdt != dt:
@@ -1147,13 +1147,11 @@ def test_gemm_pair_kernel_matches_the_product(ops, M, N, K, cdt, hb, monkeypatch
         bias = torch.randn(N, device=DEV, generator=g) if hb else None
         ref = A.float() @ Bm.float().t() + (bias if hb else 0.0)
         ldc = (N + 63) // 64 * 64
-        for mode in ("1", "2", "0"):
-            monkeypatch.setenv("MNN_GEMM_PAIR", mode)
-            Cfull = torch.full((M, ldc), 7.0, device=DEV, dtype=cdt)
-            ops.gemm_tn(A, Bm, Cfull[:, :N], bias=bias)
-            tol = 2e-3 if cdt == torch.float32 else (0.25 if cdt == torch.bfloat16 else 0.03)
-            assert float((Cfull[:, :N].float() - ref).abs().max()) < tol, (mode, dt)
-            assert bool((Cfull[:, N:] == 7.0).all()), (mode, dt)
+        Cfull = torch.full((M, ldc), 7.0, device=DEV, dtype=cdt)
+        ops.gemm_tn(A, Bm, Cfull[:, :N], bias=bias)
+        tol = 2e-3 if cdt == torch.float32 else (0.25 if cdt == torch.bfloat16 else 0.03)
+        assert float((Cfull[:, :N].float() - ref).abs().max()) < tol, dt
+        assert bool((Cfull[:, N:] == 7.0).all()), dt
 
 
 @pytest.mark.parametrize("M,N,K,dt,hb", [(8192, 2048, 448, torch.float16, True), (16384, 1024, 512, torch.bfloat16, True), (8192 + 128 * 5, 256, 448, torch.float16, False),

@@ -329,6 +329,54 @@ def test_timed_cluster_kernels_long_sequence_vs_oracle():
     assert all(c > 0.99999 for c in cosv.values()), cosv
 
 
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_cluster_backward_falls_back_to_rowpar_and_agrees_over_a_long_sequence(precision, monkeypatch):
+    """Two things at once, over T = 64 timesteps at the real widths (B = 256: eight clusters, 64 exchanges per cluster and direction, the production
+    loss scale in fp16):
+      * the cluster backward exchanges its eight partial dh sums rounded to 16 bits where the row-parallel backward accumulates the whole
+        K = 2048 contraction in f32 -- the rounding compounds along the chain, so the two are compared over a LONG sequence (every gradient of the
+        step, relative to its largest element: the bound recorded in DESIGN.md);
+      * when the library says a cluster is not dealt onto one XCD (`mnn_lstm_cluster_bwd_ok` = 0; forced here through MNN_PERSIST_NO_LOCAL, which
+        also switches the forward to its write-through hand-offs) the layer's backward runs on `lstm_rowpar_bwd` -- no error, no unwritten
+        gradients, one warning."""
+    import warnings
+    from multinn_amd import RnnNade, ops
+    from multinn_amd.generators import LstmStack
+    B, T, rho = 256, 64, 0.03
+    x = dev(synth(B, T, 43, rho))
+
+    def run():
+        gen = RnnNade(D, HN, UNITS, keep_prob=0.9, precision=precision, seed=23)
+        gen._materialize(D)
+        gen._stack.rowpar_min_batch = 32
+        gen.build_pianoroll(x, None, is_train=True, mode="train")
+        assert gen._stack._rowpar(B, T) and gen._stack._cluster(0, B, T)
+        took = gen._stack._cluster_bwd(0, B, T)
+        gen.backward()
+        gen.check()
+        return took, float(gen.metrics["batch/loss"]), gen.store.grad.clone(), {n: gen.store.gviews[n].clone() for n in gen.store.names()}
+
+    assert ops.lstm_cluster_bwd_ok(B, 512)
+    took_a, loss_a, flat_a, ga = run()
+    monkeypatch.setenv("MNN_PERSIST_NO_LOCAL", "1")
+    monkeypatch.setattr(LstmStack, "_cluster_bwd_warned", False, raising=False)
+    assert not ops.lstm_cluster_bwd_ok(B, 512)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        took_b, loss_b, flat_b, gb = run()
+    assert took_a and not took_b
+    assert any("lstm_rowpar_bwd" in str(m.message) for m in w)
+    assert loss_a == loss_b                                   # the forward's hand-off policy never changes a bit
+    assert bool(torch.isfinite(flat_a).all()) and bool(torch.isfinite(flat_b).all())
+    tol = 2e-3 if precision == "fp16" else 2e-2
+    print(f"\n[cluster vs row-parallel backward, {precision}, T={T}] relative difference per variable:")
+    for n in ga:
+        d = float((ga[n] - gb[n]).abs().max()) / max(float(gb[n].abs().max()), 1e-30)
+        print(f"    {n:24s} {d:.3e}")
+        assert d < tol, (n, d)
+    assert float(torch.nn.functional.cosine_similarity(flat_a, flat_b, dim=0)) > 0.99999
+
+
 def test_persistent_forms_refuse_grids_that_cannot_be_resident():
     """Co-residency is a construction, not an assumption: the host plans size every persistent grid to at most one workgroup per CU of THIS
     device and refuse shapes whose row tiles do not fit (the caller then takes the launch-per-timestep kernels -- still device code); the C

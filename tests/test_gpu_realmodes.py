@@ -59,6 +59,10 @@ def test_c3_jamming_real_widths(precision):
             gerr = max(gerr, TM.rel(g.store.gviews[name].cpu().numpy().reshape(ref.shape), ref / M))
     print(f"\n[C3 {precision}] free energy {worst['free_energy']:.2e}  loss {worst['loss']:.2e}  rows whose Gibbs chain end equals the float64 chain's "
           f"{worst['agree']:.3f}  gradients {gerr:.2e}")
+    # the chain ends themselves: the device's CD-10 chains (f32 products, deterministic sigmoid) against the float64 chains driven by the same
+    # Philox uniforms -- a draw differs only where a probability sits within f32 rounding of its uniform (measured: every row equal in all
+    # three modes; the floor leaves room for one such tie in a thousand rows)
+    assert worst["agree"] >= 0.99, worst
     assert worst["free_energy"] < FWD_TOL[precision] and worst["loss"] < FWD_TOL[precision]
     assert abs(float(metrics["batch/loss"]) - np.mean(losses)) < FWD_TOL[precision] * max(1.0, abs(np.mean(losses)))
     assert gerr < GRAD_TOL[precision]
