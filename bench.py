@@ -17,7 +17,7 @@ Rank 0 prints ONE JSON line: the contract fields plus
                 and `executed` = the FMAs / sigmoids / MFMA flops the kernels really issue at this batch's density (counted on the device).
                 roofline.step.frac uses `executed`; a phase fraction above 1 sets "invalid": true (an accounting the kernels do not execute);
   rho05         the same step on rho = 0.5 input (the NADE kernels skip work where v = 0: this run keeps the number honest);
-  ragged        the step on lengths ~ U{T/2..T} (seed 24), eager launches (a ragged batch needs a host-side row count);
+  ragged        the step on lengths ~ U{T/2..T} (seed 24): Dense + NADE on the valid rows only (device-side compaction), captured like the full step;
   bf16 / fp32   the same step in the other two modes, with their loss against the headline mode's on the same batch;
   strong        (N > 1) the step with the GLOBAL batch fixed at B, B/N sequences per rank;
   strong_proxy  (N = 1) the step at B/8 sequences: the per-GPU share of the global batch at 8 GPUs (8 x its rate = the strong leg's ceiling);
@@ -551,10 +551,12 @@ def main(argv=None):
         for _ in range(warmup):
             gen.train_step(x, lengths, opt)
         step_fn = lambda: gen.train_step(x, lengths, opt)
-        graph = not a.no_graph and lengths is None   # hipGraph replay of the step (N>1: forward+backward | eager all-reduce | clip+Adam)
+        # hipGraph replay of the step (N>1: forward+backward | eager all-reduce | clip+Adam); a ragged step is captured too in the 16-bit modes:
+        # its row counts live on the device (RnnNade.graphed_train_step(lengths=...))
+        graph = not a.no_graph and (lengths is None or (precision != "fp32" and gen.ragged_compact))
         if graph:
             try:
-                step_fn = gen.graphed_train_step(x, opt, warmup=1)
+                step_fn = gen.graphed_train_step(x, opt, warmup=1, lengths=lengths)
             except Exception as e:      # keep the run alive: fall back to eager launches and say so in the JSON line
                 print(f"# hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 graph = False
@@ -739,7 +741,9 @@ def main(argv=None):
         ln = ragged_lengths(B, T)
         sr, lr_, _, lm = timed_steps(a.precision, a.rho, B, max(3, a.steps // 2), 2, lengths=torch.from_numpy(ln).to(dev))
         out["ragged"] = {"lengths": "U{T/2..T}, numpy PCG64 seed 24", "valid_timesteps": int(ln.sum()), "ms_per_step": sr * 1e3,
-                         "value": float(ln.sum()) / sr, "unit": "valid timesteps/s", "loss": lr_, "launch": lm}
+                         "value": float(ln.sum()) / sr, "unit": "valid timesteps/s", "loss": lr_, "launch": lm, "vs_headline_ms": sr / sec,
+                         "rows": "Dense + NADE on the valid rows only (ops.ragged_index: compaction, row count and loss scale on the device); "
+                                 "the LSTM steps every row (impute_finished=False)"}
         for other in [p for p in ("bf16", "fp32") if p != a.precision]:
             so, lo, _, lm = timed_steps(other, a.rho, B, 3 if other == "fp32" else max(3, a.steps // 2), 1)
             out[other] = {"ms_per_step": so * 1e3, "value": B * T / so, "unit": "timesteps/s", "loss": lo, "launch": lm,

@@ -43,7 +43,7 @@ enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_ST
 
 /* ABI version of THIS header: bumped whenever a signature or a descriptor struct changes.  mnn_version() returns the value the library
  * was built with; a loader must compare the two before its first call (multinn_amd/_lib.py load() does) -- a library built for another
- * version reads garbage arguments without any diagnosis otherwise.  117 (round 6): + mnn_lstm_cluster_bwd_ok.  116: + mnn_lstm_cluster_ok / _fwd / _bwd.  115: mnn_step_increment gained `sumsq`, `clip_norm`.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
+ * version reads garbage arguments without any diagnosis otherwise.  117 (round 6): + mnn_lstm_cluster_bwd_ok, + mnn_ragged_index / mnn_rows_gather16 / mnn_rows_scatter_f32, `n_rows_dev` on the gated NADE forwards and mnn_nade_logprob_bwd, `inv` / `hdr` on mnn_pianoroll_shift_timemajor_t, + mnn_lstm_resident_{fwd,bwd}_multi / mnn_lstm_cluster_{fwd,bwd}_multi / _bwd_multi_ok.  116: + mnn_lstm_cluster_ok / _fwd / _bwd.  115: mnn_step_increment gained `sumsq`, `clip_norm`.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
  * mnn_pianoroll_shift_timemajor_t / mnn_grad_rows_fanout and the `f16` descriptor fields of round 3 are part of it. */
 #define MNN_ABI_VERSION 117
 int mnn_version(void);
@@ -92,7 +92,27 @@ int mnn_pianoroll_shift_timemajor(mnn_stream_t s, const uint8_t* x, int B, int T
 int mnn_pianoroll_shift_timemajor_t(mnn_stream_t s, const uint8_t* x, int B, int T, int D, const int32_t* lengths, void* inputs,
                                     int ld_in, void* inputs_t, int ld_t, uint8_t* targets, float* row_weight, long n_valid_total,
                                     int dtype /* MNN_BF16 or MNN_F16: the flavour of inputs / inputs_t */,
-                                    unsigned* count /* optional u32 [MNN_DENSITY_SLOTS]: += set target cells (mnn_density_gate, v = NULL) */);
+                                    unsigned* count /* optional u32 [MNN_DENSITY_SLOTS]: += set target cells (mnn_density_gate, v = NULL) */,
+                                    const int32_t* inv /* optional [B*T]: targets and row_weight are written in COMPACT row order (mnn_ragged_index) */,
+                                    const int32_t* hdr /* with inv: row_weight = hdr's 1/n_valid_total on compact rows < hdr[0], 0 behind them */);
+
+/* Ragged windows without their padding (utils/sequences.py:6-37, rnn_nade.py:91-92,225: the reference drops padded rows before the NADE).
+ * mnn_ragged_index builds, ON THE DEVICE from lengths[B], the permutation of the T*B time-major rows that puts the valid ones (t < lengths[b],
+ * time-major order kept) first and the padding behind them:  idx[k] = row at compact position k,  inv[row] = its compact position, and a header
+ *   hdr[0] = n_valid (int32, this rank's valid rows)      hdr[1] = 1 / n_total (f32 bits; n_total = *n_total_dev, or n_valid when NULL: the
+ *   hdr[2] = loss scale 2^round(log2(scale_rows n_total))           valid rows of ALL ranks the mean-over-rows loss divides by)
+ *   hdr[3] = 1 / hdr[2]                                    (scale_rows <= 0: 1)
+ * so that a captured step serves any lengths: nothing of it is read on the host.  The LSTM still steps every row (dynamic_decode with
+ * impute_finished=False, rnn_nade.py:204-218); Dense + NADE run on the compact rows: mnn_rows_gather16 copies the LSTM outputs into compact order
+ * (rows >= n_valid zeroed; optionally also transposed, the K-major operand of the Dense weight gradient), the scans take n_rows_dev = hdr and
+ * skip workgroups of padding (mnn_nade_logprob_*), and mnn_rows_scatter_f32 puts the Dense input gradient back into time-major order (padding
+ * rows zeroed) for the LSTM backward. */
+int mnn_ragged_index(mnn_stream_t s, const int32_t* lengths, int B, int T, const float* n_total_dev, float scale_rows, int32_t* idx, int32_t* inv,
+                     int32_t* hdr /* 4 words */);
+int mnn_rows_gather16(mnn_stream_t s, const void* src /* 16-bit [N, C], pitch ld_src */, int ld_src, const int32_t* idx, const int32_t* n_rows_dev,
+                      int N, int C, void* dst /* [N, C], pitch ld_dst */, int ld_dst, void* dst_t /* optional [C, ld_t >= N] */, int ld_t);
+int mnn_rows_scatter_f32(mnn_stream_t s, const float* src /* compact [N, C] */, const int32_t* inv, const int32_t* n_rows_dev, int N, int C,
+                         float* dst /* time-major [N, C] */);
 
 /* per-track variant: targets_tracks u8 [M,T,B,P] from x u8 [B,T,P,M]  (multi_encoder_nn.py:66-76) */
 int mnn_pianoroll_split_tracks(mnn_stream_t s, const uint8_t* x, int B, int T, int P, int M, uint8_t* targets_tracks);
@@ -250,6 +270,17 @@ int mnn_lstm_cluster_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer*
  * that nevertheless finds a cluster off one XCD gives up (status word) instead of computing on stale lines. */
 int mnn_lstm_cluster_bwd_ok(int B, int units);
 int mnn_lstm_cluster_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L, float keep_prob, void* workspace);
+/* Several INDEPENDENT layers of one shape in one launch: the M per-track generators of the jamming mode (multinn_jamming.py:40-68,213-221 trains
+ * them on one loss; each has its own LSTM).  L: array of njobs (1..8) descriptors sharing T, B, units, keep_prob, precision, dropout and save
+ * mode; every job keeps its own tensors and -- cluster form -- its own workspace.  The CU-resident and cluster recurrences own row groups for
+ * the whole sequence and hand nothing to another group, so the jobs' groups share one grid (njobs * B / 4 workgroups, resp. 8 * njobs * B / 32 in
+ * rounds when that exceeds the device: a cluster's members are neighbours in dispatch order).  mnn_lstm_cluster_bwd_multi_ok: the placement
+ * answer of mnn_lstm_cluster_bwd_ok for that larger grid. */
+int mnn_lstm_resident_fwd_multi(mnn_stream_t s, int T, int B, int njobs, const mnn_lstm_fwd_layer* L, float keep_prob);
+int mnn_lstm_resident_bwd_multi(mnn_stream_t s, int T, int B, int njobs, const mnn_lstm_bwd_layer* L, float keep_prob);
+int mnn_lstm_cluster_fwd_multi(mnn_stream_t s, int T, int B, int njobs, const mnn_lstm_fwd_layer* L, float keep_prob, void* const* workspaces);
+int mnn_lstm_cluster_bwd_multi(mnn_stream_t s, int T, int B, int njobs, const mnn_lstm_bwd_layer* L, float keep_prob, void* const* workspaces);
+int mnn_lstm_cluster_bwd_multi_ok(int B, int units, int njobs);
 int mnn_dropout_mask(mnn_stream_t s, uint8_t* mask, int T, int B, int units, float keep_prob, uint64_t seed, const int32_t* step_dev,
                      uint32_t row0, int layer);
 
@@ -282,10 +313,11 @@ int mnn_nade_logprob_fwd_mfma(mnn_stream_t s, int tracks, int N, int D, int Hn, 
 int mnn_density_gate(mnn_stream_t s, const uint8_t* v, long n, long threshold, int* gate, unsigned* count);
 int mnn_nade_logprob_fwd_gated(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* row_weight,
-                               float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if);
+                               float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if,
+                               const int* n_rows_dev /* optional: see mnn_ragged_index */);
 int mnn_nade_logprob_fwd_mfma_gated(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride, const float* bias,
                                     int ld_bias, const float* w_enc, const void* w_dec_bf16, const float* row_weight, float* nll, float* cond_p,
-                                    float* d_bias, float* a_final, const int* gate, int run_if);
+                                    float* d_bias, float* a_final, const int* gate, int run_if, const int* n_rows_dev);
 /* Split-operand form of the matrix-core scan (precision "fp16": nade.py:199-221 within 1e-4 on every conditional, which 8- or 11-bit operands
  * of the decoder dot products miss by 2-10x): every hidden state and decoder weight is carried as an IEEE-half pair hi + lo (22 significant
  * bits) and a logit is the f32 sum of the three 16-bit MFMA products hi.hi + hi.lo + lo.hi (~1e-6 of the f32 vector scan).  w_dec_packed:
@@ -294,7 +326,7 @@ int mnn_nade_logprob_fwd_mfma_gated(mnn_stream_t s, int tracks, int N, int D, in
 int mnn_nade_f32_pack(mnn_stream_t s, const float* w_dec, long rows, int Hn, float* w_dec_packed);
 int mnn_nade_logprob_fwd_mfma_f32(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride, const float* bias,
                                   int ld_bias, const float* w_enc, const void* w_dec_packed, const float* row_weight, float* nll, float* cond_p,
-                                  float* d_bias, float* a_final, const int* gate, int run_if);
+                                  float* d_bias, float* a_final, const int* gate, int run_if, const int* n_rows_dev);
 
 /* ------------------------------------------------------------------------------------------
  * NADE (models/common/nade.py).  Weights w_enc,w_dec f32 [tracks,D,Hn].  Rows: v u8
@@ -317,7 +349,7 @@ int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const
                          float* nll, float* cond_p, float* d_bias, float* a_final);
 int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                          const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* a_final,
-                         float* d_bias, float* d_w_enc, float* d_w_dec);
+                         float* d_bias, float* d_w_enc, float* d_w_dec, const int* n_rows_dev /* optional: see mnn_ragged_index */);
 int mnn_nade_sample(mnn_stream_t s, int tracks, int N, int D, int Hn, const float* bias, int ld_bias, const float* w_enc,
                     const float* w_dec, float temperature, uint64_t seed, uint32_t row0, uint32_t sub, uint8_t* samples,
                     long s_track_stride, int s_row_stride, int s_elem_stride, float* nll);

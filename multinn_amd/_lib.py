@@ -23,7 +23,10 @@ SIGNATURES = {
     "mnn_transpose": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _i]),
     "mnn_convert2d": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i]),
     "mnn_pianoroll_shift_timemajor": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _l]),
-    "mnn_pianoroll_shift_timemajor_t": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p, _l, _i, _p]),
+    "mnn_pianoroll_shift_timemajor_t": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p, _l, _i, _p, _p, _p]),
+    "mnn_ragged_index": (_i, [_p, _p, _i, _i, _p, _f, _p, _p, _p]),
+    "mnn_rows_gather16": (_i, [_p, _p, _i, _p, _p, _i, _i, _p, _i, _p, _i]),
+    "mnn_rows_scatter_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "mnn_pianoroll_split_tracks": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mnn_lstm_pack_weights": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "mnn_lstm_unpack_grads": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
@@ -36,7 +39,7 @@ SIGNATURES = {
     "mnn_dropout_fwd": (_i, [_p, _i, _p, _p, _i, _i, _i, _f, _u64, _p, _u32, _i, _i]),
     "mnn_dropout_bwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _u64, _p, _u32, _i, _i, _i]),
     "mnn_nade_logprob_fwd": (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
-    "mnn_nade_logprob_bwd": (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "mnn_nade_logprob_bwd": (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
     "mnn_nade_sample": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _f, _u64, _u32, _u32, _p, _l, _i, _i, _p]),
     "mnn_rbm_workspace_bytes": (_sz, [_i, _i]),
     "mnn_rbm_gibbs": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _u64, _u32, _p, _u32, _p, _p, _p]),
@@ -111,14 +114,19 @@ SIGNATURES["mnn_lstm_resident_fwd"] = (_i, [_p, _i, _i, C.POINTER(LstmFwdLayer),
 SIGNATURES["mnn_lstm_resident_bwd"] = (_i, [_p, _i, _i, C.POINTER(LstmBwdLayer), _f])
 SIGNATURES["mnn_lstm_cluster_ok"] = (_i, [_i, _i])
 SIGNATURES["mnn_lstm_cluster_bwd_ok"] = (_i, [_i, _i])
+SIGNATURES["mnn_lstm_cluster_bwd_multi_ok"] = (_i, [_i, _i, _i])
+SIGNATURES["mnn_lstm_resident_fwd_multi"] = (_i, [_p, _i, _i, _i, C.POINTER(LstmFwdLayer), _f])
+SIGNATURES["mnn_lstm_resident_bwd_multi"] = (_i, [_p, _i, _i, _i, C.POINTER(LstmBwdLayer), _f])
+SIGNATURES["mnn_lstm_cluster_fwd_multi"] = (_i, [_p, _i, _i, _i, C.POINTER(LstmFwdLayer), _f, C.POINTER(C.c_void_p)])
+SIGNATURES["mnn_lstm_cluster_bwd_multi"] = (_i, [_p, _i, _i, _i, C.POINTER(LstmBwdLayer), _f, C.POINTER(C.c_void_p)])
 SIGNATURES["mnn_lstm_cluster_fwd"] = (_i, [_p, _i, _i, C.POINTER(LstmFwdLayer), _f, _p])
 SIGNATURES["mnn_lstm_cluster_bwd"] = (_i, [_p, _i, _i, C.POINTER(LstmBwdLayer), _f, _p])
 SIGNATURES["mnn_nade_mfma_ok"] = (_i, [_i])
 SIGNATURES["mnn_nade_logprob_fwd_mfma"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p])
 SIGNATURES["mnn_density_gate"] = (_i, [_p, _p, _l, _l, _p, _p])
-SIGNATURES["mnn_nade_logprob_fwd_gated"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i])
-SIGNATURES["mnn_nade_logprob_fwd_mfma_gated"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i])
-SIGNATURES["mnn_nade_logprob_fwd_mfma_f32"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i])
+SIGNATURES["mnn_nade_logprob_fwd_gated"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p])
+SIGNATURES["mnn_nade_logprob_fwd_mfma_gated"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p])
+SIGNATURES["mnn_nade_logprob_fwd_mfma_f32"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p])
 SIGNATURES["mnn_nade_f32_pack"] = (_i, [_p, _p, _l, _i, _p])
 SIGNATURES["mnn_musical_bar_stats"] = (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p])
 SIGNATURES["mnn_musical_note_stats"] = (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p])

@@ -155,7 +155,8 @@ template <typename F>
 __global__ void __launch_bounds__(256)
 pianoroll_shift_tiled_kernel(const uint8_t* __restrict__ x, int B, int Tn, int D, const int32_t* __restrict__ lengths,
                              bf16_t* __restrict__ inputs, int ld_in, bf16_t* __restrict__ inputs_t, int ld_t,
-                             uint8_t* __restrict__ targets, float* __restrict__ row_weight, float inv_n, unsigned* __restrict__ count) {
+                             uint8_t* __restrict__ targets, float* __restrict__ row_weight, float inv_n, unsigned* __restrict__ count,
+                             const int32_t* __restrict__ inv, const int32_t* __restrict__ hdr) {
     __shared__ bf16_t tile[64][66];
     unsigned nset = 0;                                   // set cells among the target bytes this thread writes (the NADE forward's density gate)
     const int N = B * Tn;
@@ -195,19 +196,23 @@ pianoroll_shift_tiled_kernel(const uint8_t* __restrict__ x, int B, int Tn, int D
                 for (int e = 0; e < 8; ++e)
                     if (f + e < ld_in) inputs[(size_t)n * ld_in + f + e] = o[e];
             }
+            const int nc = inv != nullptr ? inv[n] : n;                     // compact row order (mnn_ragged_index): targets and weights only
             if (targets != nullptr && f < D) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) nset += cv[e] != 0;
-                if (vec) *reinterpret_cast<uint2*>(targets + (size_t)n * D + f) = *reinterpret_cast<uint2*>(cv);
+                if (vec) *reinterpret_cast<uint2*>(targets + (size_t)nc * D + f) = *reinterpret_cast<uint2*>(cv);
                 else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        if (f + e < D) targets[(size_t)n * D + f + e] = cv[e];
+                        if (f + e < D) targets[(size_t)nc * D + f + e] = cv[e];
                 }
             }
             if (row_weight != nullptr && blockIdx.x == 0 && fq == 0) {
-                const int t = n / B, b = n - t * B;
-                row_weight[n] = (lengths == nullptr || t < lengths[b]) ? inv_n : 0.f;
+                if (inv != nullptr) row_weight[nc] = nc < hdr[0] ? __int_as_float(hdr[1]) : 0.f;
+                else {
+                    const int t = n / B, b = n - t * B;
+                    row_weight[n] = (lengths == nullptr || t < lengths[b]) ? inv_n : 0.f;
+                }
             }
         }
     }
@@ -237,21 +242,152 @@ pianoroll_shift_tiled_kernel(const uint8_t* __restrict__ x, int B, int Tn, int D
 
 extern "C" int mnn_pianoroll_shift_timemajor_t(mnn_stream_t s, const uint8_t* x, int B, int T, int D, const int32_t* lengths, void* inputs,
                                                int ld_in, void* inputs_t, int ld_t, uint8_t* targets, float* row_weight, long n_valid_total, int dtype,
-                                               unsigned* count) {
+                                               unsigned* count, const int32_t* inv, const int32_t* hdr) {
+    MNN_REQUIRE((inv == nullptr) == (hdr == nullptr), "mnn_pianoroll_shift_timemajor_t: inv and hdr (mnn_ragged_index) come together");
     MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F16, "mnn_pianoroll_shift_timemajor_t: dtype must be bf16 or f16");
     MNN_REQUIRE(x && inputs && inputs_t && B > 0 && T > 0 && D > 0 && ld_in >= D, "mnn_pianoroll_shift_timemajor_t: bad arguments");
     MNN_REQUIRE(ld_in % 8 == 0 && ld_t % 8 == 0 && ld_t >= B * T, "mnn_pianoroll_shift_timemajor_t: ld_in, ld_t must be multiples of 8, ld_t >= B*T");
     MNN_REQUIRE(((uintptr_t)inputs & 15) == 0 && ((uintptr_t)inputs_t & 15) == 0 && ((uintptr_t)x & 7) == 0 && (targets == nullptr || ((uintptr_t)targets & 7) == 0),
                 "mnn_pianoroll_shift_timemajor_t: misaligned buffer");
-    MNN_REQUIRE(lengths == nullptr || n_valid_total > 0, "mnn_pianoroll_shift_timemajor_t: n_valid_total required with lengths");
+    MNN_REQUIRE(lengths == nullptr || n_valid_total > 0 || inv != nullptr, "mnn_pianoroll_shift_timemajor_t: n_valid_total required with lengths");
     const float inv_n = 1.0f / (float)(n_valid_total > 0 ? n_valid_total : (long)B * T);
     dim3 grid(cdiv(ld_in, 64), cdiv((long)B * T, 64));
     if (dtype == MNN_F16)
         hipLaunchKernelGGL(pianoroll_shift_tiled_kernel<Fp16F>, grid, dim3(256), 0, (hipStream_t)s, x, B, T, D, lengths, (bf16_t*)inputs, ld_in,
-                           (bf16_t*)inputs_t, ld_t, targets, row_weight, inv_n, count);
+                           (bf16_t*)inputs_t, ld_t, targets, row_weight, inv_n, count, inv, hdr);
     else
         hipLaunchKernelGGL(pianoroll_shift_tiled_kernel<Bf16F>, grid, dim3(256), 0, (hipStream_t)s, x, B, T, D, lengths, (bf16_t*)inputs, ld_in,
-                           (bf16_t*)inputs_t, ld_t, targets, row_weight, inv_n, count);
+                           (bf16_t*)inputs_t, ld_t, targets, row_weight, inv_n, count, inv, hdr);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Ragged windows: compaction of the valid rows (utils/sequences.py:6-37; see include/multinn_hip.h "Ragged windows")
+// ----------------------------------------------------------------------------------------------
+// One workgroup per timestep t.  Valid rows before slab t: sum_b min(len_b, t); inside the slab: a ballot prefix over b.
+__global__ void __launch_bounds__(256) ragged_index_kernel(const int32_t* __restrict__ lengths, int B, int T, const float* __restrict__ n_total_dev,
+                                                           float scale_rows, int32_t* __restrict__ idx, int32_t* __restrict__ inv, int32_t* __restrict__ hdr) {
+    __shared__ int s_red[2][4];
+    __shared__ int s_wave[4];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int before = 0, total = 0;
+    for (int b = tid; b < B; b += 256) {
+        const int len = min(max(lengths[b], 0), T);
+        before += min(len, t);
+        total += len;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); total += __shfl_xor(total, o); }
+    if (lane == 0) { s_red[0][w] = before; s_red[1][w] = total; }
+    __syncthreads();
+    before = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    total = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    if (t == 0 && tid == 0) {
+        const float ntot = n_total_dev != nullptr ? fmaxf(*n_total_dev, 1.f) : (float)max(total, 1);
+        const float ls = scale_rows > 0.f ? exp2f(rintf(log2f(scale_rows * ntot))) : 1.f;
+        hdr[0] = total;
+        hdr[1] = __float_as_int(1.0f / ntot);
+        hdr[2] = __float_as_int(ls);
+        hdr[3] = __float_as_int(1.0f / ls);
+    }
+    int run = 0;                                             // valid rows of this slab in front of the current chunk of 256
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        const int b = b0 + tid;
+        const bool ok = b < B && t < lengths[min(b, B - 1)];
+        const unsigned long long bal = __ballot(ok);
+        __syncthreads();                                     // s_wave of the previous chunk has been read
+        if (lane == 0) s_wave[w] = __popcll(bal);
+        __syncthreads();
+        int pre = 0;
+        for (int ww = 0; ww < w; ++ww) pre += s_wave[ww];
+        const int rank = run + pre + __popcll(bal & ((1ull << lane) - 1ull));
+        if (b < B) {
+            const int row = t * B + b;
+            const int k = ok ? before + rank : total + (row - (before + rank));
+            idx[k] = row;
+            inv[row] = k;
+        }
+        run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    }
+}
+extern "C" int mnn_ragged_index(mnn_stream_t s, const int32_t* lengths, int B, int T, const float* n_total_dev, float scale_rows, int32_t* idx, int32_t* inv,
+                                int32_t* hdr) {
+    MNN_REQUIRE(lengths && idx && inv && hdr && B > 0 && T > 0 && (long)B * T < (1L << 31), "mnn_ragged_index: bad arguments");
+    hipLaunchKernelGGL(ragged_index_kernel, dim3(T), dim3(256), 0, (hipStream_t)s, lengths, B, T, n_total_dev, scale_rows, idx, inv, hdr);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+// dst[k] = k < n_rows ? src[idx[k]] : 0 for 16-bit rows of C elements (C % 8 == 0), 64 x 64 tiles; optionally also the transposed copy
+// dst_t[c][k] (through an LDS tile: 32-byte runs per column).
+__global__ void __launch_bounds__(256) rows_gather16_kernel(const uint16_t* __restrict__ src, int ld_src, const int32_t* __restrict__ idx,
+                                                            const int32_t* __restrict__ n_rows_dev, int N, int C, uint16_t* __restrict__ dst, int ld_dst,
+                                                            uint16_t* __restrict__ dst_t, int ld_t) {
+    __shared__ uint16_t tile[64][66];
+    const int n0 = blockIdx.y * 64, f0 = blockIdx.x * 64;
+    const int nv = n_rows_dev != nullptr ? min(*n_rows_dev, N) : N;
+    const int fq = threadIdx.x & 7, f = f0 + 8 * fq;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int rr = (threadIdx.x >> 3) + 32 * k, n = n0 + rr;
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (n < nv && f < C) q = *reinterpret_cast<const uint4*>(src + (size_t)idx[n] * ld_src + f);
+        if (n < N && f < C) *reinterpret_cast<uint4*>(dst + (size_t)n * ld_dst + f) = q;
+        const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            tile[rr][8 * fq + 2 * e] = (uint16_t)(wq[e] & 0xffffu);
+            tile[rr][8 * fq + 2 * e + 1] = (uint16_t)(wq[e] >> 16);
+        }
+    }
+    if (dst_t == nullptr) return;
+    __syncthreads();
+    const int tc = threadIdx.x >> 2, rq = threadIdx.x & 3;
+    if (f0 + tc < C) {
+        uint16_t* o = dst_t + (size_t)(f0 + tc) * ld_t + n0 + 16 * rq;
+        if (n0 + 16 * rq + 15 < N) {
+            uint32_t wv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wv[e] = (uint32_t)tile[16 * rq + 2 * e][tc] | ((uint32_t)tile[16 * rq + 2 * e + 1][tc] << 16);
+            reinterpret_cast<uint4*>(o)[0] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+            reinterpret_cast<uint4*>(o)[1] = make_uint4(wv[4], wv[5], wv[6], wv[7]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (n0 + 16 * rq + e < N) o[e] = tile[16 * rq + e][tc];
+        }
+    }
+}
+extern "C" int mnn_rows_gather16(mnn_stream_t s, const void* src, int ld_src, const int32_t* idx, const int32_t* n_rows_dev, int N, int C, void* dst,
+                                 int ld_dst, void* dst_t, int ld_t) {
+    MNN_REQUIRE(src && idx && dst && N > 0 && C > 0 && C % 8 == 0 && ld_src >= C && ld_dst >= C && ld_src % 8 == 0 && ld_dst % 8 == 0,
+                "mnn_rows_gather16: C and the pitches must be multiples of 8");
+    MNN_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0 && (dst_t == nullptr || (((uintptr_t)dst_t & 15) == 0 && ld_t >= N && ld_t % 8 == 0)),
+                "mnn_rows_gather16: misaligned buffer / ld_t");
+    hipLaunchKernelGGL(rows_gather16_kernel, dim3(cdiv(C, 64), cdiv(N, 64)), dim3(256), 0, (hipStream_t)s, (const uint16_t*)src, ld_src, idx, n_rows_dev, N, C,
+                       (uint16_t*)dst, ld_dst, (uint16_t*)dst_t, ld_t);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+
+// dst[row] = inv[row] < n_rows ? src[inv[row]] : 0 (f32 rows of C elements, C % 4 == 0): the Dense input gradient back in time-major order
+__global__ void __launch_bounds__(256) rows_scatter_f32_kernel(const float4* __restrict__ src, const int32_t* __restrict__ inv, const int32_t* __restrict__ n_rows_dev,
+                                                               int N, int C4, float4* __restrict__ dst) {
+    const int nv = n_rows_dev != nullptr ? min(*n_rows_dev, N) : N;
+    const long total = (long)N * C4;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int row = (int)(e / C4), c = (int)(e - (long)row * C4);
+        const int k = inv[row];
+        dst[e] = k < nv ? src[(size_t)k * C4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+extern "C" int mnn_rows_scatter_f32(mnn_stream_t s, const float* src, const int32_t* inv, const int32_t* n_rows_dev, int N, int C, float* dst) {
+    MNN_REQUIRE(src && inv && dst && N > 0 && C > 0 && C % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0,
+                "mnn_rows_scatter_f32: C must be a multiple of 4, buffers 16-byte aligned");
+    const long total = (long)N * (C / 4);
+    hipLaunchKernelGGL(rows_scatter_f32_kernel, dim3((int)std::min(16384L, (total + 255) / 256)), dim3(256), 0, (hipStream_t)s, (const float4*)src, inv, n_rows_dev,
+                       N, C / 4, (float4*)dst);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

@@ -112,6 +112,13 @@ struct ClFwdArgs {
     char* xchg; unsigned* sync;
     int T, B, ncl, allow_local; float kp;
 };
+// Several independent layers of the same shape in ONE launch (mnn_lstm_cluster_fwd_multi / _bwd_multi: the per-track generators of the jamming
+// mode, multinn_jamming.py:40-68).  A cluster -- eight workgroups, 32 rows of ONE job -- exchanges nothing with another cluster, so the jobs'
+// clusters share the grid: gridDim.x = 8 * njobs * ncl; the grid's cluster c belongs to job c / ncl (its flags, exchange area and status word
+// are that job's own workspace).  More clusters than the device has room for run in rounds: workgroups are dispatched in blockIdx order and a
+// cluster's eight members are neighbours in that order, so a later round's cluster becomes resident as a whole when an earlier round drains.
+#define CL_MAX_JOBS 8
+struct ClFwdJobs { ClFwdArgs job[CL_MAX_JOBS]; int njobs; };
 
 struct ClGeom {
     static constexpr int U = 512;
@@ -133,17 +140,20 @@ struct ClGeom {
 };
 
 template <typename F, bool DROP, bool SAVE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_cl_fwd_kernel(ClFwdArgs A) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_cl_fwd_kernel(ClFwdJobs J) {
     typedef ClGeom G;
     typedef typename F::x8 frag_t;
     constexpr int U = G::U;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = lane & 31, hf = lane >> 5;
+    // workgroups are dealt round-robin over the 8 XCDs: XCD x = blockIdx & 7 takes the clusters (row tiles) [x ncl/8, (x+1) ncl/8) of the GRID, eight
+    // consecutive workgroups of ITS sequence form a cluster; the grid's cluster then maps to (job, cluster of the job)
+    const int nclg = J.job[0].ncl * J.njobs;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3, mem = seq & 7, clg = xcd * (nclg >> 3) + (seq >> 3);
+    const int jid = clg / J.job[0].ncl, cl = clg - jid * J.job[0].ncl;
+    const ClFwdArgs A = J.job[jid];
     const int T = A.T, B = A.B;
-    // workgroups are dealt round-robin over the 8 XCDs: XCD x = blockIdx & 7 takes the clusters (row tiles) [x ncl/8, (x+1) ncl/8), eight consecutive
-    // workgroups of ITS sequence form a cluster
-    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3, mem = seq & 7, cl = xcd * (A.ncl >> 3) + (seq >> 3);
     const int row0 = 32 * cl;
     const int ub = 64 * mem + 16 * w;                                           // first unit of this wave
     const size_t us = (size_t)B * U;
@@ -364,6 +374,7 @@ struct ClBwdArgs {
     char* xchg; unsigned* sync;
     int T, B, ncl, allow_local; float kp;
 };
+struct ClBwdJobs { ClBwdArgs job[CL_MAX_JOBS]; int njobs; };
 
 struct ClBwdGeom {
     static constexpr int U = 512;
@@ -376,15 +387,18 @@ struct ClBwdGeom {
 };
 
 template <typename F, bool DROP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_cl_bwd_kernel(ClBwdArgs A) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_cl_bwd_kernel(ClBwdJobs J) {
     typedef ClBwdGeom G;
     typedef typename F::x8 frag_t;
     constexpr int U = G::U;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = lane & 31, hf = lane >> 5;
+    const int nclg = J.job[0].ncl * J.njobs;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3, mem = seq & 7, clg = xcd * (nclg >> 3) + (seq >> 3);
+    const int jid = clg / J.job[0].ncl, cl = clg - jid * J.job[0].ncl;
+    const ClBwdArgs A = J.job[jid];
     const int T = A.T, B = A.B;
-    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3, mem = seq & 7, cl = xcd * (A.ncl >> 3) + (seq >> 3);
     const int row0 = 32 * cl;
     const size_t us = (size_t)B * U;
     const float ikp = 1.0f / A.kp;
@@ -653,13 +667,13 @@ static int cl_cu_count() {
 // 32 rows per cluster of eight workgroups, every workgroup on its own CU, the clusters dealt evenly over the 8 XCDs
 static bool cl_shape_ok(int B, int units) { return units == 512 && B > 0 && (B % 256) == 0 && (B / 32) * 8 <= cl_cu_count(); }
 
-typedef void (*cl_fwd_fn)(ClFwdArgs);
+typedef void (*cl_fwd_fn)(ClFwdJobs);
 template <typename F> static cl_fwd_fn cl_fwd_pick(bool drop, bool save) {
     if (drop) return save ? lstm_cl_fwd_kernel<F, true, true> : lstm_cl_fwd_kernel<F, true, false>;
     return save ? lstm_cl_fwd_kernel<F, false, true> : lstm_cl_fwd_kernel<F, false, false>;
 }
 static cl_fwd_fn cl_fwd_kernel(bool f16, bool drop, bool save) { return f16 ? cl_fwd_pick<Fp16F>(drop, save) : cl_fwd_pick<Bf16F>(drop, save); }
-typedef void (*cl_bwd_fn)(ClBwdArgs);
+typedef void (*cl_bwd_fn)(ClBwdJobs);
 static cl_bwd_fn cl_bwd_kernel(bool f16, bool drop) {
     if (f16) return drop ? lstm_cl_bwd_kernel<Fp16F, true> : lstm_cl_bwd_kernel<Fp16F, false>;
     return drop ? lstm_cl_bwd_kernel<Bf16F, true> : lstm_cl_bwd_kernel<Bf16F, false>;
@@ -744,9 +758,14 @@ extern "C" int mnn_lstm_cluster_bwd_ok(int B, int units) {
     if (getenv("MNN_PERSIST_NO_LOCAL") != nullptr) return 0;
     return cl_placement_ok(B / 32);
 }
+// ... for a launch of njobs layers (mnn_lstm_cluster_bwd_multi: the grid's clusters, later rounds included, are probed as one grid)
+extern "C" int mnn_lstm_cluster_bwd_multi_ok(int B, int units, int njobs) {
+    if (!mnn_lstm_cluster_ok(B, units) || njobs < 1 || njobs > CL_MAX_JOBS || ((njobs * (B / 32)) & 7) != 0) return 0;
+    if (getenv("MNN_PERSIST_NO_LOCAL") != nullptr) return 0;
+    return cl_placement_ok(njobs * (B / 32));
+}
 
-extern "C" int mnn_lstm_cluster_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L, float keep_prob, void* workspace) {
-    hipStream_t st = (hipStream_t)s;
+static int cl_fwd_fill(const mnn_lstm_fwd_layer* L, int T, int B, float keep_prob, void* workspace, ClFwdArgs& a) {
     MNN_REQUIRE(L && workspace && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm_cluster_fwd: bad arguments");
     MNN_REQUIRE(((size_t)workspace & 255) == 0, "mnn_lstm_cluster_fwd: workspace must be 256-byte aligned");
     MNN_REQUIRE(cl_shape_ok(B, L->units), "mnn_lstm_cluster_fwd: units must be 512, B a multiple of 256 and B / 4 at most the device's CUs (B=%d u=%d)", B, L->units);
@@ -761,22 +780,39 @@ extern "C" int mnn_lstm_cluster_fwd(mnn_stream_t s, int T, int B, const mnn_lstm
                 "mnn_lstm_cluster_fwd: the saved gates, hT and yT come together (training) or not at all");
     MNN_REQUIRE((size_t)T * B * 512 * 8 < ((size_t)1 << 31) && (size_t)512 * (size_t)(L->ld_hT > L->ld_yT ? L->ld_hT : L->ld_yT) * 2 < ((size_t)1 << 31),
                 "mnn_lstm_cluster_fwd: a tensor of this call exceeds the 2 GB a buffer descriptor addresses");
-    ClFwdArgs a{};
     a.xproj = (const h16_t*)L->xproj; a.wh_t = (const h16_t*)L->wh_t; a.gates = (h16_t*)L->gates; a.c = L->c; a.h = (h16_t*)L->h; a.y = (h16_t*)L->y;
     a.mask = L->mask; a.hT = (h16_t*)L->hT; a.ld_hT = L->ld_hT; a.yT = (h16_t*)L->yT; a.ld_yT = L->ld_yT;
     size_t sync_bytes = 0, xoff = 0;
     mnn_rp_workspace_layout(B / 32, 512, &sync_bytes, &xoff);
     a.sync = (unsigned*)workspace; a.xchg = (char*)workspace + xoff;
     a.T = T; a.B = B; a.ncl = B / 32; a.kp = keep_prob; a.allow_local = getenv("MNN_PERSIST_NO_LOCAL") == nullptr;
+    return MNN_OK;
+}
+// njobs layers of ONE shape and flavour in one launch (see ClFwdJobs); workspaces: one lstm_rowpar workspace per job
+extern "C" int mnn_lstm_cluster_fwd_multi(mnn_stream_t s, int T, int B, int njobs, const mnn_lstm_fwd_layer* L, float keep_prob, void* const* workspaces) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(L && workspaces && njobs >= 1 && njobs <= CL_MAX_JOBS, "mnn_lstm_cluster_fwd_multi: 1..%d jobs", CL_MAX_JOBS);
+    ClFwdJobs j{};
+    j.njobs = njobs;
+    for (int i = 0; i < njobs; ++i) {
+        if (int rc = cl_fwd_fill(L + i, T, B, keep_prob, workspaces[i], j.job[i])) return rc;
+        MNN_REQUIRE((L[i].f16 != 0) == (L[0].f16 != 0) && (L[i].mask != nullptr) == (L[0].mask != nullptr) && (L[i].gates != nullptr) == (L[0].gates != nullptr),
+                    "mnn_lstm_cluster_fwd_multi: the jobs must share precision, dropout and save mode");
+        for (int k = 0; k < i; ++k) MNN_REQUIRE(workspaces[k] != workspaces[i], "mnn_lstm_cluster_fwd_multi: every job needs its own workspace");
+    }
+    MNN_REQUIRE(((njobs * (B / 32)) & 7) == 0, "mnn_lstm_cluster_fwd_multi: the grid's clusters must be a multiple of 8");
     MNN_HIP(cl_prepare());
-    if (int rc = mnn_rp_reset_launch(st, workspace, B / 32, 512)) return rc;
-    hipLaunchKernelGGL(cl_fwd_kernel(L->f16 != 0, L->mask != nullptr, L->gates != nullptr), dim3(8 * a.ncl), dim3(256), ClGeom::LDS, st, a);
+    for (int i = 0; i < njobs; ++i)
+        if (int rc = mnn_rp_reset_launch(st, workspaces[i], B / 32, 512)) return rc;
+    hipLaunchKernelGGL(cl_fwd_kernel(L->f16 != 0, L->mask != nullptr, L->gates != nullptr), dim3(8 * njobs * (B / 32)), dim3(256), ClGeom::LDS, st, j);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
+extern "C" int mnn_lstm_cluster_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L, float keep_prob, void* workspace) {
+    return mnn_lstm_cluster_fwd_multi(s, T, B, 1, L, keep_prob, &workspace);
+}
 
-extern "C" int mnn_lstm_cluster_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L, float keep_prob, void* workspace) {
-    hipStream_t st = (hipStream_t)s;
+static int cl_bwd_fill(const mnn_lstm_bwd_layer* L, int T, int B, float keep_prob, void* workspace, ClBwdArgs& a) {
     MNN_REQUIRE(L && workspace && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm_cluster_bwd: bad arguments");
     MNN_REQUIRE(((size_t)workspace & 255) == 0, "mnn_lstm_cluster_bwd: workspace must be 256-byte aligned");
     MNN_REQUIRE(cl_shape_ok(B, L->units), "mnn_lstm_cluster_bwd: units must be 512, B a multiple of 256 and B / 4 at most the device's CUs (B=%d u=%d)", B, L->units);
@@ -788,16 +824,33 @@ extern "C" int mnn_lstm_cluster_bwd(mnn_stream_t s, int T, int B, const mnn_lstm
                 "mnn_lstm_cluster_bwd: a tensor of this call exceeds the 2 GB a buffer descriptor addresses");
     MNN_REQUIRE((L->mask == nullptr) == (keep_prob >= 1.0f), "mnn_lstm_cluster_bwd: a keep mask goes with keep_prob < 1 and only with it (the forward's rule)");
     MNN_REQUIRE(T >= 4, "mnn_lstm_cluster_bwd: T >= 4 (the two exchange buffers of a cluster take the room of four timesteps of the row-parallel workspace)");
-    ClBwdArgs a{};
     a.dh_ext = L->dh_ext; a.wh_p = (const h16_t*)L->wh_p; a.gates = (const h16_t*)L->gates; a.c = L->c; a.mask = keep_prob < 1.0f ? L->mask : nullptr;
     a.dzc = (h16_t*)L->dz_T; a.dzT = (h16_t*)L->dzT_t; a.ld_t = L->ld_t; a.db_p = L->db_p;
     size_t sync_bytes = 0, xoff = 0;
     mnn_rp_workspace_layout(B / 32, 512, &sync_bytes, &xoff);
     a.sync = (unsigned*)workspace; a.xchg = (char*)workspace + xoff;
     a.T = T; a.B = B; a.ncl = B / 32; a.kp = keep_prob; a.allow_local = getenv("MNN_PERSIST_NO_LOCAL") == nullptr;
+    return MNN_OK;
+}
+extern "C" int mnn_lstm_cluster_bwd_multi(mnn_stream_t s, int T, int B, int njobs, const mnn_lstm_bwd_layer* L, float keep_prob, void* const* workspaces) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(L && workspaces && njobs >= 1 && njobs <= CL_MAX_JOBS, "mnn_lstm_cluster_bwd_multi: 1..%d jobs", CL_MAX_JOBS);
+    ClBwdJobs j{};
+    j.njobs = njobs;
+    for (int i = 0; i < njobs; ++i) {
+        if (int rc = cl_bwd_fill(L + i, T, B, keep_prob, workspaces[i], j.job[i])) return rc;
+        MNN_REQUIRE((L[i].f16 != 0) == (L[0].f16 != 0) && (j.job[i].mask != nullptr) == (j.job[0].mask != nullptr),
+                    "mnn_lstm_cluster_bwd_multi: the jobs must share precision and dropout mode");
+        for (int k = 0; k < i; ++k) MNN_REQUIRE(workspaces[k] != workspaces[i], "mnn_lstm_cluster_bwd_multi: every job needs its own workspace");
+    }
+    MNN_REQUIRE(((njobs * (B / 32)) & 7) == 0, "mnn_lstm_cluster_bwd_multi: the grid's clusters must be a multiple of 8");
     MNN_HIP(cl_prepare());
-    if (int rc = mnn_rp_reset_launch(st, workspace, B / 32, 512)) return rc;
-    hipLaunchKernelGGL(cl_bwd_kernel(L->f16 != 0, a.mask != nullptr), dim3(8 * a.ncl), dim3(256), ClBwdGeom::LDS, st, a);
+    for (int i = 0; i < njobs; ++i)
+        if (int rc = mnn_rp_reset_launch(st, workspaces[i], B / 32, 512)) return rc;
+    hipLaunchKernelGGL(cl_bwd_kernel(L->f16 != 0, j.job[0].mask != nullptr), dim3(8 * njobs * (B / 32)), dim3(256), ClBwdGeom::LDS, st, j);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
+}
+extern "C" int mnn_lstm_cluster_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L, float keep_prob, void* workspace) {
+    return mnn_lstm_cluster_bwd_multi(s, T, B, 1, L, keep_prob, &workspace);
 }

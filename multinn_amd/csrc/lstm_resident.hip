@@ -40,6 +40,11 @@ struct ResFwdArgs {
     h16_t* hT; int ld_hT; h16_t* yT; int ld_yT;
     int T, B; float kp;
 };
+// Several independent layers of the same shape in ONE launch (mnn_lstm_resident_fwd_multi: the per-track generators of the jamming mode,
+// multinn_jamming.py:40-68): a workgroup owns four rows of ONE job for the whole sequence and hands nothing to another workgroup, so the jobs'
+// row groups simply share the grid (any number of rounds).  gridDim.x = njobs * B / 4; job = blockIdx.x / (B / 4).
+#define RES_MAX_JOBS 8
+struct ResFwdJobs { ResFwdArgs job[RES_MAX_JOBS]; int njobs; };
 
 template <int U> struct ResGeom {
     static_assert(U == 256, "the CU-resident recurrence is sized for 256-unit layers (512 KB of 16-bit recurrent weights)");
@@ -79,14 +84,16 @@ __device__ __forceinline__ void res_wait_all_but(int n) {       // loads, stores
 }
 
 template <int U, typename F, bool DROP, bool SAVE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_res_fwd_kernel(ResFwdArgs A) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_res_fwd_kernel(ResFwdJobs J) {
     typedef ResGeom<U> G;
     typedef typename F::x8 frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = lane & 3, bank = (lane & 15) >> 2, g4 = lane >> 4;
+    const int nblk = (int)gridDim.x / J.njobs, jid = (int)blockIdx.x / nblk;   // this workgroup's job (uniform) and its row group inside it
+    const ResFwdArgs A = J.job[jid];
     const int T = A.T, B = A.B;
-    const int row0 = 4 * res_row_group(blockIdx.x, gridDim.x);
+    const int row0 = 4 * res_row_group((int)blockIdx.x - jid * nblk, nblk);
     const size_t us = (size_t)B * U;
     const float ikp = 1.0f / A.kp;
 
@@ -318,6 +325,7 @@ struct ResBwdArgs {
     h16_t* dzc; h16_t* dzT; int ld_t; float* db_p;
     int T, B; float kp;
 };
+struct ResBwdJobs { ResBwdArgs job[RES_MAX_JOBS]; int njobs; };
 
 template <int U> struct ResBwdGeom {
     static_assert(U == 256, "the CU-resident recurrence is sized for 256-unit layers");
@@ -331,14 +339,16 @@ template <int U> struct ResBwdGeom {
 };
 
 template <int U, typename F, bool DROP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_res_bwd_kernel(ResBwdArgs A) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_res_bwd_kernel(ResBwdJobs J) {
     typedef ResBwdGeom<U> G;
     typedef typename F::x8 frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = lane & 3, bank = (lane & 15) >> 2, g4 = lane >> 4;
+    const int nblk = (int)gridDim.x / J.njobs, jid = (int)blockIdx.x / nblk;   // this workgroup's job (uniform) and its row group inside it
+    const ResBwdArgs A = J.job[jid];
     const int T = A.T, B = A.B;
-    const int row0 = 4 * res_row_group(blockIdx.x, gridDim.x);
+    const int row0 = 4 * res_row_group((int)blockIdx.x - jid * nblk, nblk);
     const size_t us = (size_t)B * U;
     const float ikp = 1.0f / A.kp;
     const int u0 = 64 * w + 16 * bank + 4 * g4;                              // this lane's four units (after the bank selection)
@@ -537,13 +547,13 @@ extern "C" int mnn_lstm_resident_ok(int B, int units) {
 }
 static bool res_shape_ok(int B, int units) { return units == 256 && B > 0 && (B & 3) == 0; }
 
-typedef void (*res_fwd_fn)(ResFwdArgs);
+typedef void (*res_fwd_fn)(ResFwdJobs);
 template <typename F> static res_fwd_fn res_fwd_pick(bool drop, bool save) {
     if (drop) return save ? lstm_res_fwd_kernel<256, F, true, true> : lstm_res_fwd_kernel<256, F, true, false>;
     return save ? lstm_res_fwd_kernel<256, F, false, true> : lstm_res_fwd_kernel<256, F, false, false>;
 }
 static res_fwd_fn res_fwd_kernel(bool f16, bool drop, bool save) { return f16 ? res_fwd_pick<Fp16F>(drop, save) : res_fwd_pick<Bf16F>(drop, save); }
-typedef void (*res_bwd_fn)(ResBwdArgs);
+typedef void (*res_bwd_fn)(ResBwdJobs);
 static res_bwd_fn res_bwd_kernel(bool f16, bool drop) {
     if (f16) return drop ? lstm_res_bwd_kernel<256, Fp16F, true> : lstm_res_bwd_kernel<256, Fp16F, false>;
     return drop ? lstm_res_bwd_kernel<256, Bf16F, true> : lstm_res_bwd_kernel<256, Bf16F, false>;
@@ -567,8 +577,7 @@ static hipError_t res_prepare() {
     return hipSuccess;
 }
 
-extern "C" int mnn_lstm_resident_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L, float keep_prob) {
-    hipStream_t st = (hipStream_t)s;
+static int res_fwd_fill(const mnn_lstm_fwd_layer* L, int T, int B, float keep_prob, ResFwdArgs& a) {
     MNN_REQUIRE(L && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm_resident_fwd: bad arguments");
     MNN_REQUIRE(res_shape_ok(B, L->units), "mnn_lstm_resident_fwd: units must be 256 and B a multiple of 4 (B=%d u=%d)", B, L->units);
     MNN_REQUIRE(L->xproj && L->wh_t && L->c && L->h, "mnn_lstm_resident_fwd: null pointer");
@@ -582,18 +591,32 @@ extern "C" int mnn_lstm_resident_fwd(mnn_stream_t s, int T, int B, const mnn_lst
                 "mnn_lstm_resident_fwd: the saved gates, hT and yT come together (training) or not at all");
     MNN_REQUIRE((size_t)T * B * 256 * 8 < ((size_t)1 << 31) && (size_t)256 * (size_t)(L->ld_hT > L->ld_yT ? L->ld_hT : L->ld_yT) * 2 < ((size_t)1 << 31),
                 "mnn_lstm_resident_fwd: a tensor of this call exceeds the 2 GB a buffer descriptor addresses");
-    ResFwdArgs a{};
     a.xproj = (const h16_t*)L->xproj; a.wh_t = (const h16_t*)L->wh_t; a.gates = (h16_t*)L->gates; a.c = L->c; a.h = (h16_t*)L->h; a.y = (h16_t*)L->y;
     a.mask = L->mask; a.hT = (h16_t*)L->hT; a.ld_hT = L->ld_hT; a.yT = (h16_t*)L->yT; a.ld_yT = L->ld_yT;
     a.T = T; a.B = B; a.kp = keep_prob;
+    return MNN_OK;
+}
+// njobs layers of ONE shape and flavour (units 256, the same T, B, keep_prob, precision, mask / save choice) in one launch
+extern "C" int mnn_lstm_resident_fwd_multi(mnn_stream_t s, int T, int B, int njobs, const mnn_lstm_fwd_layer* L, float keep_prob) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(L && njobs >= 1 && njobs <= RES_MAX_JOBS, "mnn_lstm_resident_fwd_multi: 1..%d jobs", RES_MAX_JOBS);
+    ResFwdJobs j{};
+    j.njobs = njobs;
+    for (int i = 0; i < njobs; ++i) {
+        if (int rc = res_fwd_fill(L + i, T, B, keep_prob, j.job[i])) return rc;
+        MNN_REQUIRE((L[i].f16 != 0) == (L[0].f16 != 0) && (L[i].mask != nullptr) == (L[0].mask != nullptr) && (L[i].gates != nullptr) == (L[0].gates != nullptr),
+                    "mnn_lstm_resident_fwd_multi: the jobs must share precision, dropout and save mode");
+    }
     MNN_HIP(res_prepare());
-    hipLaunchKernelGGL(res_fwd_kernel(L->f16 != 0, L->mask != nullptr, L->gates != nullptr), dim3(B / 4), dim3(256), ResGeom<256>::LDS, st, a);
+    hipLaunchKernelGGL(res_fwd_kernel(L->f16 != 0, L->mask != nullptr, L->gates != nullptr), dim3(njobs * (B / 4)), dim3(256), ResGeom<256>::LDS, st, j);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
+extern "C" int mnn_lstm_resident_fwd(mnn_stream_t s, int T, int B, const mnn_lstm_fwd_layer* L, float keep_prob) {
+    return mnn_lstm_resident_fwd_multi(s, T, B, 1, L, keep_prob);
+}
 
-extern "C" int mnn_lstm_resident_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L, float keep_prob) {
-    hipStream_t st = (hipStream_t)s;
+static int res_bwd_fill(const mnn_lstm_bwd_layer* L, int T, int B, float keep_prob, ResBwdArgs& a) {
     MNN_REQUIRE(L && T > 0 && B > 0 && keep_prob > 0.f, "mnn_lstm_resident_bwd: bad arguments");
     MNN_REQUIRE(res_shape_ok(B, L->units), "mnn_lstm_resident_bwd: units must be 256 and B a multiple of 4 (B=%d u=%d)", B, L->units);
     MNN_REQUIRE(L->dh_ext && L->wh_p && L->gates && L->c, "mnn_lstm_resident_bwd: null pointer");
@@ -603,12 +626,26 @@ extern "C" int mnn_lstm_resident_bwd(mnn_stream_t s, int T, int B, const mnn_lst
     MNN_REQUIRE((size_t)T * B * 256 * 8 < ((size_t)1 << 31) && (size_t)1024 * (size_t)L->ld_t * 2 < ((size_t)1 << 31),
                 "mnn_lstm_resident_bwd: a tensor of this call exceeds the 2 GB a buffer descriptor addresses");
     MNN_REQUIRE((L->mask == nullptr) == (keep_prob >= 1.0f), "mnn_lstm_resident_bwd: a keep mask goes with keep_prob < 1 and only with it (the forward's rule)");
-    ResBwdArgs a{};
     a.dh_ext = L->dh_ext; a.wh_p = (const h16_t*)L->wh_p; a.gates = (const h16_t*)L->gates; a.c = L->c; a.mask = keep_prob < 1.0f ? L->mask : nullptr;
     a.dzc = (h16_t*)L->dz_T; a.dzT = (h16_t*)L->dzT_t; a.ld_t = L->ld_t; a.db_p = L->db_p;
     a.T = T; a.B = B; a.kp = keep_prob;
+    return MNN_OK;
+}
+extern "C" int mnn_lstm_resident_bwd_multi(mnn_stream_t s, int T, int B, int njobs, const mnn_lstm_bwd_layer* L, float keep_prob) {
+    hipStream_t st = (hipStream_t)s;
+    MNN_REQUIRE(L && njobs >= 1 && njobs <= RES_MAX_JOBS, "mnn_lstm_resident_bwd_multi: 1..%d jobs", RES_MAX_JOBS);
+    ResBwdJobs j{};
+    j.njobs = njobs;
+    for (int i = 0; i < njobs; ++i) {
+        if (int rc = res_bwd_fill(L + i, T, B, keep_prob, j.job[i])) return rc;
+        MNN_REQUIRE((L[i].f16 != 0) == (L[0].f16 != 0) && (j.job[i].mask != nullptr) == (j.job[0].mask != nullptr),
+                    "mnn_lstm_resident_bwd_multi: the jobs must share precision and dropout mode");
+    }
     MNN_HIP(res_prepare());
-    hipLaunchKernelGGL(res_bwd_kernel(L->f16 != 0, a.mask != nullptr), dim3(B / 4), dim3(256), ResBwdGeom<256>::LDS, st, a);
+    hipLaunchKernelGGL(res_bwd_kernel(L->f16 != 0, j.job[0].mask != nullptr), dim3(njobs * (B / 4)), dim3(256), ResBwdGeom<256>::LDS, st, j);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
+}
+extern "C" int mnn_lstm_resident_bwd(mnn_stream_t s, int T, int B, const mnn_lstm_bwd_layer* L, float keep_prob) {
+    return mnn_lstm_resident_bwd_multi(s, T, B, 1, L, keep_prob);
 }

@@ -16,6 +16,21 @@
 
 __device__ __forceinline__ float fast_ln(float x) { return __builtin_amdgcn_logf(x) * LN2; }
 
+// Compacted ragged batches (mnn_ragged_index: the valid rows of a window first, its padding behind them): the scans take the number of valid
+// rows from the DEVICE (n_rows_dev, may be NULL = all N rows) so that a captured step serves any lengths.  A workgroup whose first row lies
+// beyond it has nothing to scan; it writes zeros where a later kernel reads this workgroup's rows (the Dense weight-gradient and input-gradient
+// GEMMs run over all N rows) and leaves.  Rows of a partly valid workgroup are scanned like any other: their row weight is 0.
+__device__ __forceinline__ bool nade_rows_beyond(const int* __restrict__ n_rows_dev, int first_row) {
+    return n_rows_dev != nullptr && first_row >= *n_rows_dev;
+}
+__device__ __forceinline__ void nade_zero_rows(float* __restrict__ d_bias, int ld_bias, int col0, int ncol, int row0, int nrow, int N, int nthreads) {
+    if (d_bias == nullptr) return;
+    for (int e = threadIdx.x; e < nrow * ncol; e += nthreads) {
+        const int n = e / ncol, i = e - n * ncol;
+        if (row0 + n < N) d_bias[(size_t)(row0 + n) * ld_bias + col0 + i] = 0.f;
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // forward (lane = hidden unit, 8 waves x 8 rows per block; no barrier, no cross-wave traffic)
 //
@@ -99,11 +114,16 @@ __global__ void __launch_bounds__(512)
 nade_fwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias,
                 int ld_bias, const float* __restrict__ w_enc, const float* __restrict__ w_dec, const float* __restrict__ row_weight,
                 float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias, float* __restrict__ a_final,
-                const int* __restrict__ gate, int run_if) {
+                const int* __restrict__ gate, int run_if, const int* __restrict__ n_rows_dev) {
     constexpr int W = HQ * 64;
     __shared__ float wl[2][2][8 * W];            // [buffer][w_dec | w_enc][visible-in-chunk][hidden]
     if (gate != nullptr && *gate != run_if) return;     // density-gated pair of launches (mnn_nade_logprob_fwd_gated): uniform exit
     const int m = blockIdx.y;
+    if (nade_rows_beyond(n_rows_dev, blockIdx.x * 64)) {                  // compacted ragged batch: all 64 rows are padding
+        nade_zero_rows(d_bias, ld_bias, tracks * Hn + m * D, D, blockIdx.x * 64, 64, N, 512);
+        if (nll != nullptr && threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < N) nll[(size_t)m * N + blockIdx.x * 64 + threadIdx.x] = 0.f;
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rbase = blockIdx.x * 64 + w * FWD_R;
@@ -214,12 +234,12 @@ extern "C" int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, in
                                     const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* row_weight,
                                     float* nll, float* cond_p, float* d_bias, float* a_final) {
     return mnn_nade_logprob_fwd_gated(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec, row_weight, nll, cond_p, d_bias, a_final,
-                                      nullptr, 0);
+                                      nullptr, 0, nullptr);
 }
 
 extern "C" int mnn_nade_logprob_fwd_gated(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                           const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* row_weight,
-                                          float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if) {
+                                          float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if, const int* n_rows_dev) {
     MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn > 0 && Hn <= 256, "mnn_nade_logprob_fwd: need tracks,N,D>0 and 0<Hn<=256 (Hn=%d)", Hn);
     MNN_REQUIRE(v && bias && w_enc && w_dec, "mnn_nade_logprob_fwd: null pointer");
     MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_logprob_fwd: ld_bias %d < tracks*(Hn+D)", ld_bias);
@@ -227,7 +247,7 @@ extern "C" int mnn_nade_logprob_fwd_gated(mnn_stream_t s, int tracks, int N, int
     dim3 grid(cdiv(N, 64), tracks);
     hipStream_t st = (hipStream_t)s;
 #define FWD(HQ) hipLaunchKernelGGL(nade_fwd_kernel<HQ>, grid, dim3(512), 0, st, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, \
-                                   w_dec, row_weight, nll, cond_p, d_bias, a_final, gate, run_if)
+                                   w_dec, row_weight, nll, cond_p, d_bias, a_final, gate, run_if, n_rows_dev)
     if (Hn <= 64) FWD(1);
     else if (Hn <= 128) FWD(2);
     else FWD(4);
@@ -292,7 +312,7 @@ template <int HQ, int RG>
 __global__ void __launch_bounds__(512)
 nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias,
                 int ld_bias, const float* __restrict__ w_enc, const float* __restrict__ w_dec, const float* __restrict__ a_final,
-                float* __restrict__ d_bias, float* __restrict__ d_w_enc, float* __restrict__ d_w_dec) {
+                float* __restrict__ d_bias, float* __restrict__ d_w_enc, float* __restrict__ d_w_dec, const int* __restrict__ n_rows_dev) {
     constexpr int W = HQ * 64;
     __shared__ __attribute__((aligned(16))) float wl[2][2][8 * W];
     // [buffer][wave][visible-in-half-chunk][d w_dec | d w_enc][hidden]: one exchange per 4 visibles.  Two buffers where they fit beside a second
@@ -307,6 +327,11 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
     // wide layer may run as nslice narrower workgroups (fewer registers and less LDS each: more of them resident per CU)
     const int m = blockIdx.y / nslice, hb = (blockIdx.y - m * nslice) * W;
     const int Hn = min(W, HnT - hb);                                           // hidden units of this slice
+    if (nade_rows_beyond(n_rows_dev, blockIdx.x * (64 * RG))) {                // compacted ragged batch: padding rows only -- d b_enc = 0
+        nade_zero_rows(d_bias, ld_bias, m * HnT + hb, Hn, blockIdx.x * (64 * RG), 64 * RG, N, 512);
+        return;
+    }
+    const int Nv = n_rows_dev != nullptr ? min(*n_rows_dev, N) : N;           // rows with a forward result
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int BWD_R = 8 * RG;                                              // rows per wave
@@ -332,7 +357,7 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
             const int j = lane + 64 * q, row = rbase + r;
-            if (!(row < N && j < Hn)) a[r][q] = 0.f;
+            if (!(row < Nv && j < Hn)) a[r][q] = 0.f;           // (rows behind a compacted batch's valid ones: a_final was never written for them)
             h[r][q] = fast_sigmoid(a[r][q]);
             G[r][q] = 0.f;
             c[r][q] = 0.f;
@@ -515,7 +540,7 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
 
 extern "C" int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                     const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* a_final,
-                                    float* d_bias, float* d_w_enc, float* d_w_dec) {
+                                    float* d_bias, float* d_w_enc, float* d_w_dec, const int* n_rows_dev) {
     MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn > 0 && Hn <= 256, "mnn_nade_logprob_bwd: need tracks,N,D>0 and 0<Hn<=256 (Hn=%d)", Hn);
     MNN_REQUIRE(v && bias && w_enc && w_dec && a_final && d_bias && d_w_enc && d_w_dec, "mnn_nade_logprob_bwd: null pointer");
     MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_logprob_bwd: ld_bias too small");
@@ -524,7 +549,7 @@ extern "C" int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, in
     // workgroups per CU).  Measured and removed in round 4 (never the default): one 256-wide workgroup (HQ = 4), 64-wide slices, and 128 rows
     // per workgroup (two row groups per wave: 4.98 vs 3.94 ms at [1024,256,88,5] -- 187 registers leave two waves per SIMD instead of four).
 #define BWD(HQ, NS) hipLaunchKernelGGL((nade_bwd_kernel<HQ, 1>), dim3(cdiv(N, 64), tracks * (NS)), dim3(512), 0, st, tracks, N, D, Hn, NS, v, \
-                                       v_track_stride, bias, ld_bias, w_enc, w_dec, a_final, d_bias, d_w_enc, d_w_dec)
+                                       v_track_stride, bias, ld_bias, w_enc, w_dec, a_final, d_bias, d_w_enc, d_w_dec, n_rows_dev)
     if (Hn <= 64) BWD(1, 1);
     else BWD(2, cdiv(Hn, 128));
 #undef BWD

@@ -141,7 +141,7 @@ __device__ __forceinline__ void
 nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias, int ld_bias,
                      const float* __restrict__ w_enc, const bf16_t* __restrict__ w_dec_bf, const float* __restrict__ row_weight,
                      float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias, float* __restrict__ a_final,
-                     const int* __restrict__ gate, int run_if) {
+                     const int* __restrict__ gate, int run_if, const int* __restrict__ n_rows_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     typedef NadeFwdSmemT<SPLIT> NadeFwdSmem;
     typedef typename NmState<SPLIT>::T state_t;
@@ -159,6 +159,16 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
     const bf16_t* __restrict__ wd = w_dec_bf + (size_t)m * D * Hn * (SPLIT ? 2 : 1);        // (split form: f16 [d][hi | lo][Hn] behind the 16-bit pointer type)
     const int bd_off = tracks * Hn + m * D;
     const int ntile = (D + 31) / 32;
+    // compacted ragged batch (mnn_ragged_index; see nade.hip): a workgroup whose 32 rows are all padding writes the zeros later kernels read and leaves
+    if (n_rows_dev != nullptr && rb >= *n_rows_dev) {
+        if (d_bias != nullptr)
+            for (int e = tid; e < 32 * D; e += 256) {
+                const int n = e / D, i = e - n * D;
+                if (rb + n < N) d_bias[(size_t)(rb + n) * ld_bias + bd_off + i] = 0.f;
+            }
+        if (nll != nullptr && tid < 32 && rb + tid < N) nll[(size_t)m * N + rb + tid] = 0.f;
+        return;
+    }
 
     // split form: the pre-activations of this thread's hidden unit for the 32 rows live in REGISTERS, indexed by the wave-uniform row of each
     // flip (indirect register addressing); that frees 32 KiB of LDS (two workgroups per CU with the doubled state tiles) and takes the
@@ -460,22 +470,22 @@ nade_fwd_mfma_body(int tracks, int N, int D, const uint8_t* __restrict__ v, long
 
 // two entry points over the one body: the split form is held to 256 registers (two workgroups per CU), the bf16 form keeps its own allocation
 template <bool SPLIT> __global__ void nade_fwd_mfma_kernel(int, int, int, const uint8_t*, long, const float*, int, const float*, const bf16_t*, const float*,
-                                                           float*, float*, float*, float*, const int*, int);
+                                                           float*, float*, float*, float*, const int*, int, const int*);
 template <>
 __global__ void __launch_bounds__(256)
 nade_fwd_mfma_kernel<false>(int tracks, int N, int D, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias, int ld_bias,
                             const float* __restrict__ w_enc, const bf16_t* __restrict__ w_dec_bf, const float* __restrict__ row_weight,
                             float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias, float* __restrict__ a_final,
-                            const int* __restrict__ gate, int run_if) {
-    nade_fwd_mfma_body<false>(tracks, N, D, v, v_track_stride, bias, ld_bias, w_enc, w_dec_bf, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
+                            const int* __restrict__ gate, int run_if, const int* __restrict__ n_rows_dev) {
+    nade_fwd_mfma_body<false>(tracks, N, D, v, v_track_stride, bias, ld_bias, w_enc, w_dec_bf, row_weight, nll, cond_p, d_bias, a_final, gate, run_if, n_rows_dev);
 }
 template <>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 nade_fwd_mfma_kernel<true>(int tracks, int N, int D, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias, int ld_bias,
                            const float* __restrict__ w_enc, const bf16_t* __restrict__ w_dec_bf, const float* __restrict__ row_weight,
                            float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias, float* __restrict__ a_final,
-                           const int* __restrict__ gate, int run_if) {
-    nade_fwd_mfma_body<true>(tracks, N, D, v, v_track_stride, bias, ld_bias, w_enc, w_dec_bf, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
+                           const int* __restrict__ gate, int run_if, const int* __restrict__ n_rows_dev) {
+    nade_fwd_mfma_body<true>(tracks, N, D, v, v_track_stride, bias, ld_bias, w_enc, w_dec_bf, row_weight, nll, cond_p, d_bias, a_final, gate, run_if, n_rows_dev);
 }
 
 extern "C" int mnn_nade_mfma_ok(int Hn) { return Hn == NM_H ? 1 : 0; }
@@ -484,13 +494,13 @@ extern "C" int mnn_nade_logprob_fwd_mfma(mnn_stream_t s, int tracks, int N, int 
                                          const float* bias, int ld_bias, const float* w_enc, const void* w_dec_bf16, const float* row_weight,
                                          float* nll, float* cond_p, float* d_bias, float* a_final) {
     return mnn_nade_logprob_fwd_mfma_gated(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec_bf16, row_weight, nll, cond_p, d_bias,
-                                           a_final, nullptr, 0);
+                                           a_final, nullptr, 0, nullptr);
 }
 
 template <bool SPLIT>
 static int nm_launch(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride, const float* bias, int ld_bias,
                      const float* w_enc, const void* w_dec16, const float* row_weight, float* nll, float* cond_p, float* d_bias, float* a_final,
-                     const int* gate, int run_if) {
+                     const int* gate, int run_if, const int* n_rows_dev) {
     MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn == NM_H, "mnn_nade_logprob_fwd_mfma: need tracks,N,D>0 and Hn == 256 (Hn=%d)", Hn);
     MNN_REQUIRE(v && bias && w_enc && w_dec16, "mnn_nade_logprob_fwd_mfma: null pointer");
     MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_logprob_fwd_mfma: ld_bias %d < tracks*(Hn+D)", ld_bias);
@@ -506,21 +516,21 @@ static int nm_launch(mnn_stream_t s, int tracks, int N, int D, int Hn, const uin
     }
     dim3 grid(cdiv(N, 32), tracks);
     hipLaunchKernelGGL(nade_fwd_mfma_kernel<SPLIT>, grid, dim3(256), sizeof(NadeFwdSmemT<SPLIT>), (hipStream_t)s, tracks, N, D, v, v_track_stride, bias,
-                       ld_bias, w_enc, (const bf16_t*)w_dec16, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
+                       ld_bias, w_enc, (const bf16_t*)w_dec16, row_weight, nll, cond_p, d_bias, a_final, gate, run_if, n_rows_dev);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
 
 extern "C" int mnn_nade_logprob_fwd_mfma_gated(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                                const float* bias, int ld_bias, const float* w_enc, const void* w_dec_bf16, const float* row_weight,
-                                               float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if) {
-    return nm_launch<false>(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec_bf16, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
+                                               float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if, const int* n_rows_dev) {
+    return nm_launch<false>(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec_bf16, row_weight, nll, cond_p, d_bias, a_final, gate, run_if, n_rows_dev);
 }
 
 extern "C" int mnn_nade_logprob_fwd_mfma_f32(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                              const float* bias, int ld_bias, const float* w_enc, const void* w_dec_packed, const float* row_weight,
-                                             float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if) {
-    return nm_launch<true>(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec_packed, row_weight, nll, cond_p, d_bias, a_final, gate, run_if);
+                                             float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if, const int* n_rows_dev) {
+    return nm_launch<true>(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec_packed, row_weight, nll, cond_p, d_bias, a_final, gate, run_if, n_rows_dev);
 }
 
 // w_dec f32 [rows, Hn] -> f16 [rows][hi | lo][Hn]: the B operand of the split-operand form (4 bytes per weight, as the f32 original)

@@ -55,6 +55,67 @@ def flat_index(lengths, B, T, device):
 
 
 # ------------------------------------------------------------------------------------------------
+# Lockstep execution of several generators (the M per-track generators of the jamming mode, multinn_jamming.py:40-68,213-221).  The parts of a
+# generator that launch an LSTM recurrence are written as Python generator functions (`*_co`) that YIELD the launch instead of issuing it:
+#     ("resident_fwd" | "resident_bwd" | "cluster_fwd" | "cluster_bwd" | "rowpar_fwd" | "rowpar_bwd", T, B, descriptor, keep_prob, workspace)
+# `drive` runs one of them alone (every request becomes its own launch: the ordinary path).  `drive_group` advances M of them side by side and
+# turns the M requests of a rendezvous into ONE launch where the library has a multi-job form (ops.lstm_recurrence_multi: the CU-resident and
+# cluster recurrences own their rows for the whole sequence, so independent layers simply share a grid); everything between two rendezvous
+# (GEMMs, Gibbs chains, ...) is issued per generator, in generator order, on the same stream.
+_SINGLE = {"resident_fwd": lambda T, B, d, kp, ws: ops.lstm_resident_fwd(T, B, d, kp),
+           "resident_bwd": lambda T, B, d, kp, ws: ops.lstm_resident_bwd(T, B, d, kp),
+           "cluster_fwd": lambda T, B, d, kp, ws: ops.lstm_cluster_fwd(T, B, d, kp, ws),
+           "cluster_bwd": lambda T, B, d, kp, ws: ops.lstm_cluster_bwd(T, B, d, kp, ws),
+           "rowpar_fwd": lambda T, B, d, kp, ws: ops.lstm_rowpar_fwd(T, B, d, kp, ws),
+           "rowpar_bwd": lambda T, B, d, kp, ws: ops.lstm_rowpar_bwd(T, B, d, kp, ws)}
+
+
+def drive(co):
+    """Run one `*_co` generator function to its end, issuing every recurrence it asks for as a launch of its own; returns its return value."""
+    try:
+        req = next(co)
+        while True:
+            _SINGLE[req[0]](*req[1:])
+            req = co.send(None)
+    except StopIteration as e:
+        return e.value
+
+
+def drive_group(cos):
+    """Run M `*_co` generator functions in lockstep (see above); returns the list of their return values.  They must ask for the same
+    sequence of recurrences (same kinds and shapes: the caller checks that the generators are alike before grouping them)."""
+    n = len(cos)
+    results, reqs, alive = [None] * n, [None] * n, [True] * n
+
+    def advance(i, first):
+        try:
+            reqs[i] = next(cos[i]) if first else cos[i].send(None)
+        except StopIteration as e:
+            results[i], reqs[i], alive[i] = e.value, None, False
+
+    for i in range(n):
+        advance(i, True)
+    while any(alive):
+        if not all(alive):
+            raise RuntimeError("drive_group: the grouped generators did not ask for the same sequence of recurrences")
+        kind, T, B, _, kp, _ = reqs[0]
+        same = all(r[0] == kind and r[1] == T and r[2] == B and r[4] == kp and r[3].units == reqs[0][3].units for r in reqs)
+        multi = same and n > 1 and kind.split("_")[0] in ("resident", "cluster")
+        if multi and kind == "cluster_bwd" and not ops.lstm_cluster_bwd_multi_ok(B, reqs[0][3].units, n):
+            multi = False
+        if multi and kind.startswith("cluster") and (n * (B // 32)) % 8 != 0:
+            multi = False
+        if multi:
+            ops.lstm_recurrence_multi(kind, T, B, [r[3] for r in reqs], kp, [r[5] for r in reqs] if kind.startswith("cluster") else None)
+        else:
+            for r in reqs:
+                _SINGLE[r[0]](*r[1:])
+        for i in range(n):
+            advance(i, False)
+    return results
+
+
+# ------------------------------------------------------------------------------------------------
 class LstmStack:
     """Executes an RNN (multi-layer LSTM) on packed, gate-interleaved weights."""
 
@@ -179,8 +240,12 @@ class LstmStack:
     def rowpar_xproj_dtype(self):
         return torch.float32 if self.rowpar_xproj_f32 else self.dtype
 
+    # set by a mode that runs several stacks in lockstep (drive_group): the row-parallel path -- whose CU-resident / cluster recurrences have a
+    # multi-job launch -- also below rowpar_min_batch, where one stack alone is faster on the two-layer persistent form
+    group_rowpar = False
+
     def _rowpar(self, B, T=2, state0=None):
-        if not (self.rowpar and self.h16 and state0 is None and T > 1 and B >= self.rowpar_min_batch and B % 32 == 0):
+        if not (self.rowpar and self.h16 and state0 is None and T > 1 and (B >= self.rowpar_min_batch or self.group_rowpar) and B % 32 == 0):
             return False
         return all("wx_gm" in p and ops.lstm_rowpar_ok(B, p["u"]) for p in self.packed)
 
@@ -211,7 +276,11 @@ class LstmStack:
         return self._cat0[:self.packed[0]["ld"]]
 
     def _forward_rowpar(self, x_tm, keep_prob, seed, row0, save, step_dev):
-        """Layer by layer: gate-minor input projection (one GEMM over all T*B rows), then the layer's whole recurrence in one launch."""
+        return drive(self._forward_rowpar_co(x_tm, keep_prob, seed, row0, save, step_dev))
+
+    def _forward_rowpar_co(self, x_tm, keep_prob, seed, row0, save, step_dev):
+        """Layer by layer: gate-minor input projection (one GEMM over all T*B rows), then the layer's whole recurrence in one launch -- YIELDED
+        to the driver (drive / drive_group above), which issues it alone or together with the same layer of other stacks."""
         T, B, _ = x_tm.shape
         dev, N = x_tm.device, T * B
         Np = ops.round_up(N, 64)
@@ -251,11 +320,11 @@ class LstmStack:
             d = ops.lstm2_fwd_layer(xproj, p["wh_t"], None, None, gates, c, h, hT, y, mask, yT=yT, gates_dtype=self.dtype,
                                     xproj_dtype=self.rowpar_xproj_dtype)
             if self._resident(l, B, T):
-                ops.lstm_resident_fwd(T, B, d, keep_prob)
+                yield ("resident_fwd", T, B, d, keep_prob, None)
             elif self._cluster(l, B, T):
-                ops.lstm_cluster_fwd(T, B, d, keep_prob, self._rp_workspace(l, T, B, dev))
+                yield ("cluster_fwd", T, B, d, keep_prob, self._rp_workspace(l, T, B, dev))
             else:
-                ops.lstm_rowpar_fwd(T, B, d, keep_prob, self._rp_workspace(l, T, B, dev))
+                yield ("rowpar_fwd", T, B, d, keep_prob, self._rp_workspace(l, T, B, dev))
             out = y if y is not None else h
             if save:
                 ctx.append(dict(inp=inp, gates=gates, c=c, h=h, c0=None, h0=None, hT=hT, mask=mask, yT=yT,
@@ -265,8 +334,11 @@ class LstmStack:
         return inp, ctx, final
 
     def _backward_rowpar(self, dy, ctx, keep_prob, need_dx=False):
-        """Top layer first: the layer's whole backward recurrence in one launch (dropout backward of its output folded in), then the
-        gradient wrt its input as one GEMM (dz row-major x Wx), which is the next layer's dh_ext."""
+        return drive(self._backward_rowpar_co(dy, ctx, keep_prob, need_dx))
+
+    def _backward_rowpar_co(self, dy, ctx, keep_prob, need_dx=False):
+        """Top layer first: the layer's whole backward recurrence in one launch (dropout backward of its output folded in; yielded to the
+        driver like the forward's), then the gradient wrt its input as one GEMM (dz row-major x Wx), which is the next layer's dh_ext."""
         T, B, _ = dy.shape
         dev, N = dy.device, T * B
         Np = ops.round_up(N, 64)
@@ -286,11 +358,11 @@ class LstmStack:
             e = ops.lstm2_bwd_layer(dh.view(T, B, u), p["wh_p"], cx["gates"], cx["c"], None, dzc, ops.lstm_seq_bwd_workspace(B, u, dev), dzT, db_p,
                                     cx["mask"] if keep_prob < 1.0 else None, gates_dtype=self.dtype)
             if self._resident(l, B, T):
-                ops.lstm_resident_bwd(T, B, e, keep_prob)
+                yield ("resident_bwd", T, B, e, keep_prob, None)
             elif self._cluster_bwd(l, B, T):
-                ops.lstm_cluster_bwd(T, B, e, keep_prob, self._rp_workspace(l, T, B, dev))
+                yield ("cluster_bwd", T, B, e, keep_prob, self._rp_workspace(l, T, B, dev))
             else:
-                ops.lstm_rowpar_bwd(T, B, e, keep_prob, self._rp_workspace(l, T, B, dev))
+                yield ("rowpar_bwd", T, B, e, keep_prob, self._rp_workspace(l, T, B, dev))
             st[l] = dict(dzT=dzT, dzc=dzc, db_p=db_p)
             if l > 0:
                 dh = torch.empty((N, p["n_in"]), device=dev)
@@ -318,6 +390,19 @@ class LstmStack:
     @staticmethod
     def _chunks(T, step):
         return [(t0, min(T, t0 + step)) for t0 in range(0, T, step)]
+
+    def forward_co(self, x_tm, keep_prob=1.0, seed=0, row0=0, save=True, state0=None, step_dev=None):
+        """`forward` as a generator function for drive / drive_group: the row-parallel path yields its recurrence launches, every other path
+        runs at once."""
+        T, B, _ = x_tm.shape
+        if self._rowpar(B, T, state0):
+            return (yield from self._forward_rowpar_co(x_tm, keep_prob, seed, row0, save, step_dev))
+        return self.forward(x_tm, keep_prob, seed, row0, save, state0, step_dev)
+
+    def backward_co(self, dy, ctx, keep_prob=1.0, seed=0, row0=0, need_dx=False, step_dev=None):
+        if ctx and ctx[0].get("rowpar"):
+            return (yield from self._backward_rowpar_co(dy, ctx, keep_prob, need_dx))
+        return self.backward(dy, ctx, keep_prob, seed, row0, need_dx, step_dev)
 
     def forward(self, x_tm, keep_prob=1.0, seed=0, row0=0, save=True, state0=None, step_dev=None):
         """x_tm [T,B,ld0] compute dtype.  Returns (y [T,B,u_last], ctx, final_state[(c,h)...]).
@@ -788,7 +873,11 @@ class RnnEstimator(Generator):
 
     def _unscale(self, ls):
         """End of a loss-scaled backward pass (LstmStack.loss_scale): gradients and d loss / d inputs back to their true scale."""
-        if ls != 1.0:
+        if torch.is_tensor(ls):                         # compacted ragged window: ls is the device word 1 / scale (ops.ragged_index)
+            self.store.grad.mul_(ls)
+            if self._dx is not None:
+                self._dx.mul_(ls)
+        elif ls != 1.0:
             ops.axpby(1.0 / ls, self.store.grad, 0.0, None, self.store.grad)
             if self._dx is not None:
                 flat = self._dx.view(-1)
@@ -967,17 +1056,18 @@ class RnnNade(RnnEstimator):
 
     nade_dense_above = float(os.environ.get("MULTINN_NADE_DENSE_ABOVE", "0.07"))   # density above which the f32 scan replaces the matrix-core form
 
-    def _nade_fwd(self, v, out, rw, nll, cond_p, d_out, a_fin):
+    def _nade_fwd(self, v, out, rw, nll, cond_p, d_out, a_fin, n_rows_dev=None):
         M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
         exact = self._nade_exact()
         if self.nade_dense_above >= 1.0:                 # gate off: always the matrix-core form
             return ops.nade_logprob_fwd_auto(v, out, self.store["nade/w_enc"], self.store["nade/w_dec"], self._wdec_bf, M, D, Hn, None, None,
-                                             1.0, rw, nll, cond_p, d_out, a_fin, exact=exact)
+                                             1.0, rw, nll, cond_p, d_out, a_fin, exact=exact, n_rows_dev=n_rows_dev)
         if getattr(self, "_gate", None) is None or self._gate.device != out.device:
             self._gate = torch.zeros(1 + ops.DENSITY_SLOTS, device=out.device, dtype=torch.int32)            # [gate | partial counts]
         counted = bool(getattr(self, "_v_counted", False)) and rw is not None      # (the on-demand conditionals pass of a train build runs later: not counted)
         return ops.nade_logprob_fwd_auto(v, out, self.store["nade/w_enc"], self.store["nade/w_dec"], self._wdec_bf, M, D, Hn, self._gate[:1],
-                                         self._gate[1:], self.nade_dense_above, rw, nll, cond_p, d_out, a_fin, exact=exact, counted=counted)
+                                         self._gate[1:], self.nade_dense_above, rw, nll, cond_p, d_out, a_fin, exact=exact, counted=counted,
+                                         n_rows_dev=n_rows_dev)
 
     # fp16 mode: the split-operand matrix-core scan (nade_mfma.hip, SPLIT: f16 hi + lo pairs, three 16-bit MFMA products) or the f32 vector scan
     nade_exact = os.environ.get("MULTINN_NADE_EXACT_MFMA", "1") != "0"
@@ -997,6 +1087,10 @@ class RnnNade(RnnEstimator):
     # -- forward --------------------------------------------------------------------------------
     def build(self, x=None, y=None, lengths=None, is_train=None, mode="eval"):
         """rnn_nade.py:64-124.  x inputs [B,T,Din], y targets [B,T,tracks*D] (u8 or float)."""
+        return drive(self._build_co(x, y, lengths, is_train, mode))
+
+    def _build_co(self, x=None, y=None, lengths=None, is_train=None, mode="eval"):
+        """`build` as a generator function (drive / drive_group: the LSTM recurrences are yielded to the driver)."""
         Generator.build(self, x, y, lengths, is_train, mode)
         self._materialize(x.shape[-1] if x is not None else self._num_inputs)
         self._rnn.build_cell(is_train)
@@ -1008,12 +1102,17 @@ class RnnNade(RnnEstimator):
             v = y.to(torch.uint8).transpose(0, 1).reshape(T, B, D, M).permute(3, 0, 1, 2).contiguous() if M > 1 \
                 else y.to(torch.uint8).transpose(0, 1).contiguous().view(1, T, B, D)
             rw = self._row_weight(lengths, B, T, x.device)
-            self._forward_tm(x_tm, v, rw, lengths, B, T, train=(mode == "train"))
+            yield from self._forward_tm_co(x_tm, v, rw, lengths, B, T, train=(mode == "train"))
         self._is_built = True
 
-    def build_pianoroll(self, x_u8, lengths=None, is_train=True, mode="train"):
+    # MULTINN_RAGGED_COMPACT=0: ragged windows keep their padding rows in the Dense + NADE part (weight 0), as before round 6
+    ragged_compact = os.environ.get("MULTINN_RAGGED_COMPACT", "1") != "0"
+
+    def build_pianoroll(self, x_u8, lengths=None, is_train=True, mode="train", n_total_dev=None):
         """Fast joint path: x_u8 [B,T,P,M] piano-roll batch; fuses multinn_joint.py:83-89,132-139
-        (zero first step, inputs = enc[:, :-1], targets = enc[:, 1:]) into one kernel."""
+        (zero first step, inputs = enc[:, :-1], targets = enc[:, 1:]) into one kernel.
+        n_total_dev (f32 [1], optional): valid rows of ALL ranks of a ragged window, for callers that must not run a collective here
+        (a captured step under data parallelism)."""
         if self.num_tracks != 1:
             raise ValueError("build_pianoroll is the joint (single NADE) path")
         B, T, P, Mtr = x_u8.shape
@@ -1025,14 +1124,30 @@ class RnnNade(RnnEstimator):
         x_tm = torch.empty((T, B, self._stack.ld0), device=dev, dtype=self.dtype)
         v = torch.empty((T, B, D), device=dev, dtype=torch.uint8)
         rw = torch.empty(T * B, device=dev)
-        if lengths is not None:
+        # Ragged window, 16-bit train step: Dense + NADE run on the VALID rows only (the reference drops padded rows before the NADE:
+        # utils/sequences.py:6-37, rnn_nade.py:91-92,225; the LSTM still steps them: impute_finished=False).  The compaction index, the row
+        # count, 1 / n_valid and the f16 loss scale all live on the device (ops.ragged_index): nothing of the step depends on a host-side
+        # count, so graphed_train_step captures it once for any lengths.
+        compact = None
+        if lengths is not None and mode == "train" and self.dtype in ops.H16 and self.ragged_compact:
+            len_dev = lengths.to(device=dev, dtype=torch.int32).contiguous()
+            if n_total_dev is None and dp_active():
+                n_total_dev = len_dev.clamp(0, T).sum().float().reshape(1)
+                torch.distributed.all_reduce(n_total_dev)
+            idx, inv, hdr = ops.ragged_index(len_dev, B, T, n_total_dev, self._stack.loss_scale_rows if self.dtype == torch.float16 else 0.0)
+            compact = dict(idx=idx, inv=inv, hdr=hdr, hdr_f=hdr.view(torch.float32))
+            lengths = len_dev
+            n_valid = 0
+            self._n_valid = None                    # device-side only (compact["hdr"])
+        elif lengths is not None:
             n_tot = lengths.sum().to(dev).float()
             if dp_active():
                 torch.distributed.all_reduce(n_tot)
             n_valid = int(n_tot)
+            self._n_valid = max(n_valid, 1)
         else:
             n_valid = B * T * world()[1]
-        self._n_valid = max(n_valid, 1)
+            self._n_valid = max(n_valid, 1)
         x_tmT = None
         if mode == "train" and self.dtype in ops.H16:              # the same pass also writes x^T, layer 1's weight-gradient operand
             self._ensure_packed()
@@ -1046,21 +1161,38 @@ class RnnNade(RnnEstimator):
             if getattr(self, "_gate", None) is None or self._gate.device != dev:
                 self._gate = torch.zeros(1 + ops.DENSITY_SLOTS, device=dev, dtype=torch.int32)            # [gate | partial counts]
             cnt = self._gate[1:]
-        self._v_counted = ops.pianoroll_shift_timemajor(x_u8.view(B, T, D), lengths, x_tm, v, rw, n_valid, inputs_t=x_tmT, count=cnt)
-        self._forward_tm(x_tm, v.view(1, T, B, D), rw, lengths, B, T, train=(mode == "train"), x_tmT=x_tmT)
+        self._v_counted = ops.pianoroll_shift_timemajor(x_u8.view(B, T, D), lengths, x_tm, v, rw, n_valid, inputs_t=x_tmT, count=cnt,
+                                                        compact=(compact["inv"], compact["hdr"]) if compact else None)
+        self._forward_tm(x_tm, v.view(1, T, B, D), rw, lengths, B, T, train=(mode == "train"), x_tmT=x_tmT, compact=compact)
         self._v_counted = False
         self._is_built = True
 
-    def _forward_tm(self, x_tm, v, rw, lengths, B, T, train, x_tmT=None):
+    def _forward_tm(self, x_tm, v, rw, lengths, B, T, train, x_tmT=None, compact=None):
+        return drive(self._forward_tm_co(x_tm, v, rw, lengths, B, T, train, x_tmT, compact))
+
+    def _forward_tm_co(self, x_tm, v, rw, lengths, B, T, train, x_tmT=None, compact=None):
+        """compact (build_pianoroll, ragged windows): v and rw arrive in COMPACT row order; the LSTM output is gathered into it (rows behind the
+        valid ones zeroed) and everything from the Dense layer on -- out, nll, d_out, a_fin -- lives in compact order too."""
         M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
         N, dev = T * B, x_tm.device
         self._ensure_packed()
         kp = self._rnn.effective_keep_prob()
-        y, ctx, _ = self._stack.forward(x_tm, kp, self.seed, self.row0, save=train, step_dev=self.store.step_dev)
+        y, ctx, _ = yield from self._stack.forward_co(x_tm, kp, self.seed, self.row0, save=train, step_dev=self.store.step_dev)
         if ctx and x_tmT is not None:
             ctx[0]["inT"] = x_tmT
+        nrows = None
+        if compact is not None:
+            R = y.shape[-1]
+            Np = ops.round_up(N, 64)
+            y_c = torch.empty((N, R), device=dev, dtype=self.dtype)
+            y_cT = (torch.zeros if Np != N else torch.empty)((R, Np), device=dev, dtype=self.dtype) if train else None
+            ops.rows_gather16(y.view(N, R), compact["idx"], compact["hdr"], y_c, y_cT)
+            compact["y_cT"] = y_cT
+            y_dense, nrows = y_c, compact["hdr"]
+        else:
+            y_dense = y.view(N, -1)
         out = torch.empty((N, self.ldo), device=dev)      # columns >= n_out are padding of the row pitch: never read
-        ops.gemm_tn(y.view(N, -1), self._fc_t, out[:, :self.n_out], bias=self._fc_bias)
+        ops.gemm_tn(y_dense, self._fc_t, out[:, :self.n_out], bias=self._fc_bias)
         nll = torch.empty((M, N), device=dev)
         cond_p = None if train else torch.empty((M, N, D), device=dev)     # the train step needs the loss only: 4 N D bytes less to write per
         rw_m = rw / M if M > 1 else rw                                       # step; `cond_probs` fills it on demand (see the property)
@@ -1071,19 +1203,27 @@ class RnnNade(RnnEstimator):
                 d_out[:, self.n_out:].zero_()       # fp32: d_out itself is the dgrad operand; bf16: grad_rows_fanout writes the zero padding
         a_fin = torch.empty((M, N, Hn), device=dev) if train else None
         # gradient seed only (the reported loss stays unscaled): the mode's weight of this generator's loss, and the f16 loss scale
-        ls = self._stack.loss_scale(self._n_valid) if train else 1.0
-        gs = self.grad_scale * ls
-        rw_g = rw_m if gs == 1.0 else rw_m * gs
+        if compact is not None:                         # the scale is a device word (hdr[2]); its inverse is applied by _unscale
+            ls = compact["hdr_f"][2:3] if (train and self.dtype == torch.float16) else 1.0
+            rw_g = rw_m if (self.grad_scale == 1.0 and not torch.is_tensor(ls)) else rw_m * ls * self.grad_scale
+            if torch.is_tensor(ls):
+                ls = compact["hdr_f"][3:4]               # what _unscale multiplies by
+        else:
+            ls = self._stack.loss_scale(self._n_valid) if train else 1.0
+            gs = self.grad_scale * ls
+            rw_g = rw_m if gs == 1.0 else rw_m * gs
         if self._nade_mfma():
             # bf16 compute mode: the decoder dot products run as a block-sparse bf16 GEMM over each row's hidden states while the batch is
             # piano-roll-sparse; a dense batch takes the f32 vector form (decided on the device, per launch: ops.nade_logprob_fwd_auto)
-            self._nade_fwd(v.view(M, N, D), out, rw_g if train else None, nll, cond_p, d_out, a_fin)
+            self._nade_fwd(v.view(M, N, D), out, rw_g if train else None, nll, cond_p, d_out, a_fin, n_rows_dev=nrows)
         else:
+            assert compact is None or Hn <= 256, "compacted rows: the f32 scan covers Hn <= 256"
             ops.nade_logprob_fwd(v.view(M, N, D), out, self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn,
-                                 rw_g if train else None, nll, cond_p, d_out, a_fin)
+                                 rw_g if train else None, nll, cond_p, d_out, a_fin, n_rows_dev=nrows)
         loss = torch.zeros(1, device=dev)
         ops.weighted_sum(nll.view(-1), rw_m.repeat(M) if M > 1 else rw_m, loss)      # statistical.py:34 / rnn_multinade.py:202-203
-        self._ctx = dict(x_tm=x_tm, v=v, rw=rw_m, y=y, lstm=ctx, out=out, d_out=d_out, a_fin=a_fin, kp=kp, seed=self.seed, B=B, T=T, ls=ls)
+        self._ctx = dict(x_tm=x_tm, v=v, rw=rw_m, y=y, lstm=ctx, out=out, d_out=d_out, a_fin=a_fin, kp=kp, seed=self.seed, B=B, T=T, ls=ls,
+                         compact=compact)
         self._nll_tm, self._cond_tm, self._loss = nll, cond_p, loss
         self._flat_idx = None
         self._lengths = lengths
@@ -1092,8 +1232,12 @@ class RnnNade(RnnEstimator):
 
     # -- API-order views of the flat outputs (b-major then t, sequences.py:30-31) ---------------
     def _idx(self):
+        """Positions of the API-order rows (b-major, then t: sequences.py:30-31) in the arrays the kernels wrote: time-major rows, or -- for a
+        compacted ragged window -- compact rows (through the window's inverse permutation)."""
         if self._flat_idx is None:
-            self._flat_idx = flat_index(self._lengths, self._ctx["B"], self._ctx["T"], self._loss.device)
+            fi = flat_index(self._lengths, self._ctx["B"], self._ctx["T"], self._loss.device)
+            cp = self._ctx.get("compact")
+            self._flat_idx = cp["inv"].long()[fi] if cp is not None else fi
         return self._flat_idx
 
     @property
@@ -1109,7 +1253,8 @@ class RnnNade(RnnEstimator):
             N = cx["B"] * cx["T"]
             cp = torch.empty((M, N, D), device=cx["out"].device)
             if self._nade_mfma():
-                self._nade_fwd(cx["v"].view(M, N, D), cx["out"], None, None, cp, None, None)
+                self._nade_fwd(cx["v"].view(M, N, D), cx["out"], None, None, cp, None, None,
+                               n_rows_dev=cx["compact"]["hdr"] if cx.get("compact") else None)
             else:
                 ops.nade_logprob_fwd(cx["v"].view(M, N, D), cx["out"], self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn, None, None, cp, None,
                                      None)
@@ -1129,6 +1274,9 @@ class RnnNade(RnnEstimator):
     # -- backward -------------------------------------------------------------------------------
     def backward(self):
         """Gradient of metrics['batch/loss'] wrt rnn + nade + dense variables into store.grad."""
+        return drive(self._backward_co())
+
+    def _backward_co(self):
         cx = self._ctx
         if cx["d_out"] is None:
             raise RuntimeError("build(..., mode='train') must run before train()")
@@ -1138,12 +1286,15 @@ class RnnNade(RnnEstimator):
         g = self.store.gviews
         self.store.grad.zero_()
         d_out = cx["d_out"]
+        compact = cx.get("compact")
         ops.nade_logprob_bwd(cx["v"].view(M, N, D), cx["out"], self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn, cx["a_fin"],
-                             d_out, g["nade/w_enc"], g["nade/w_dec"])
+                             d_out, g["nade/w_enc"], g["nade/w_dec"], n_rows_dev=compact["hdr"] if compact else None)
         # dense: dK[R,n_out] = y^T d_out ; db = sum d_out ; dy = d_out K^T
         Np = ops.round_up(N, 64)
         zalloc = torch.zeros if Np != N else torch.empty
         yT = cx["lstm"][-1].get("yT") if cx["lstm"] else None      # emitted by the persistent recurrence
+        if compact is not None:
+            yT = compact["y_cT"]                                    # compact row order, like d_out (rows behind the valid ones are zero in both)
         if yT is None:
             yT = zalloc((R, Np), device=dev, dtype=self.dtype)
             ops.transpose(cx["y"].view(N, R), yT)
@@ -1162,7 +1313,11 @@ class RnnNade(RnnEstimator):
         del yT, doT
         dy = torch.empty((N, R), device=dev)
         ops.gemm_tn(do_c, self._fc_p, dy)
-        self._dx = self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], cx["seed"], self.row0, need_dx=self.need_dx, step_dev=self.store.step_dev)
+        if compact is not None:                                     # back into time-major order for the LSTM backward (padding rows: 0)
+            dy_c, dy = dy, torch.empty((N, R), device=dev)
+            ops.rows_scatter_f32(dy_c, compact["inv"], compact["hdr"], dy)
+        self._dx = yield from self._stack.backward_co(dy.view(T, B, R), cx["lstm"], cx["kp"], cx["seed"], self.row0, need_dx=self.need_dx,
+                                                      step_dev=self.store.step_dev)
         self._unscale(cx.get("ls", 1.0))
 
     def train_step(self, x_u8, lengths, optimizer, lr=None):
@@ -1171,33 +1326,54 @@ class RnnNade(RnnEstimator):
         self.train(optimizer, lr)
         return self._loss
 
-    def graphed_train_step(self, x_u8, optimizer, lr=None, warmup=2):
+    def graphed_train_step(self, x_u8, optimizer, lr=None, warmup=2, lengths=None):
         """Capture one whole optimiser step (plumbing, packing, forward, backward, clip, Adam: ~300 launches) into
-        hipGraphs and return ``run(x=None) -> loss``: the T-step recurrences are launch-bound on the host otherwise.
+        hipGraphs and return ``run(x=None, lengths=None) -> loss``: the T-step recurrences are launch-bound on the host otherwise.
         Step-dependent values (dropout seed, Adam step) are read from store.step_dev on the device.  Under data
         parallelism the ONE gradient all-reduce stays an eager torch.distributed call between two graphs
-        (forward+backward | clip+Adam), so nothing of RCCL is captured.  Full-length batches only (ragged lengths
-        need a host-side row count)."""
+        (forward+backward | clip+Adam), so nothing of RCCL is captured.
+
+        lengths (int32 [B], optional): capture the RAGGED step.  The captured graph holds a static copy of the lengths; the compaction index,
+        the valid-row count, 1 / n_valid and the f16 loss scale are computed from it ON THE DEVICE inside the graph (ops.ragged_index), so one
+        capture serves every later ``run(x, lengths)``.  16-bit modes only (the compacted path); under data parallelism the total row count of
+        all ranks is all-reduced eagerly in front of the replay."""
         from .training import allreduce_flat, setup_cabi_comm
         setup_cabi_comm()               # MULTINN_COMM=capi: the communicator exists before anything is captured
         static_x = x_u8.clone()
+        ragged = lengths is not None
+        if ragged and not (self.dtype in ops.H16 and self.ragged_compact):
+            raise ValueError("graphed_train_step(lengths=...) needs the compacted ragged path (16-bit precision, MULTINN_RAGGED_COMPACT unset)")
+        dev = x_u8.device
+        T = x_u8.shape[1]
+        static_len = lengths.to(device=dev, dtype=torch.int32).clone() if ragged else None
+        multi = dp_active()
+        static_ntot = torch.zeros(1, device=dev) if (ragged and multi) else None
+
+        def set_total():
+            if static_ntot is not None:
+                static_ntot.copy_(static_len.clamp(0, T).sum().float().reshape(1))
+                torch.distributed.all_reduce(static_ntot)
+
+        set_total()
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self.train_step(static_x, None, optimizer, lr)
+                self.build_pianoroll(static_x, static_len, is_train=True, mode="train", n_total_dev=static_ntot)
+                self.train(optimizer, lr)
         cur.wait_stream(side)
-        multi = dp_active()
         self._packed_step = -1          # the captured step packs the weights itself, whatever ran before (warmup = 0: a caller's own steps)
         g_fb, g_opt = torch.cuda.CUDAGraph(), None
         if not multi:
             with torch.cuda.graph(g_fb):
-                loss = self.train_step(static_x, None, optimizer, lr)
+                self.build_pianoroll(static_x, static_len, is_train=True, mode="train")
+                self.train(optimizer, lr)
+                loss = self._loss
         else:
             # thread_local: the process group's watchdog thread may touch the runtime while this thread captures
             with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
-                self.build_pianoroll(static_x, None, is_train=True, mode="train")
+                self.build_pianoroll(static_x, static_len, is_train=True, mode="train", n_total_dev=static_ntot)
                 self.backward()
                 loss = self._loss
             g_opt = torch.cuda.CUDAGraph()
@@ -1206,9 +1382,14 @@ class RnnNade(RnnEstimator):
             self._packed_step = -1
         self.store.step -= 1            # the captured step has not executed (host mirror of store.step_dev)
 
-        def run(x=None):
+        def run(x=None, lengths=None):
             if x is not None:
                 static_x.copy_(x)
+            if lengths is not None:
+                if not ragged:
+                    raise ValueError("this step was captured for full-length windows: capture it with lengths= to feed ragged ones")
+                static_len.copy_(lengths.to(device=dev, dtype=torch.int32))
+                set_total()
             g_fb.replay()
             if g_opt is not None:
                 allreduce_flat(self.store.grad)
@@ -1216,6 +1397,7 @@ class RnnNade(RnnEstimator):
             self.store.step += 1
             return loss
         run.graph = g_fb
+        run.ragged = ragged
         return run
 
     # -- state / sampling -----------------------------------------------------------------------
@@ -1379,6 +1561,10 @@ class RnnRBM(RnnEstimator):
 
     def build(self, x=None, y=None, lengths=None, is_train=None, mode="eval"):
         """rnn_rbm.py:71-143."""
+        return drive(self._build_co(x, y, lengths, is_train, mode))
+
+    def _build_co(self, x=None, y=None, lengths=None, is_train=None, mode="eval"):
+        """`build` as a generator function (drive / drive_group: the LSTM recurrences are yielded to the driver)."""
         Generator.build(self, x, y, lengths, is_train, mode)
         self._materialize(x.shape[-1] if x is not None else self._num_inputs)
         self._rnn.build_cell(is_train)
@@ -1393,7 +1579,7 @@ class RnnRBM(RnnEstimator):
             rw = self._row_weight(lengths, B, T, dev)
             kp = self._rnn.effective_keep_prob()
             seed = self.seed + self.store.step
-            yy, ctx, _ = self._stack.forward(x_tm, kp, self.seed, self.row0, save=(mode == "train"), step_dev=self.store.step_dev)
+            yy, ctx, _ = yield from self._stack.forward_co(x_tm, kp, self.seed, self.row0, save=(mode == "train"), step_dev=self.store.step_dev)
             out = self._biases(yy.view(N, -1))
             bh_t, bv_t = out[:, :Hn], out[:, Hn:Hn + D]
             # global flat row ids keep the Gibbs uniforms independent of the data-parallel split
@@ -1430,8 +1616,12 @@ class RnnRBM(RnnEstimator):
         self._is_built = True
 
     def _idx(self):
+        """Positions of the API-order rows (b-major, then t: sequences.py:30-31) in the arrays the kernels wrote: time-major rows, or -- for a
+        compacted ragged window -- compact rows (through the window's inverse permutation)."""
         if self._flat_idx is None:
-            self._flat_idx = flat_index(self._lengths, self._ctx["B"], self._ctx["T"], self._loss.device)
+            fi = flat_index(self._lengths, self._ctx["B"], self._ctx["T"], self._loss.device)
+            cp = self._ctx.get("compact")
+            self._flat_idx = cp["inv"].long()[fi] if cp is not None else fi
         return self._flat_idx
 
     cond_probs = property(lambda self: self._pv_tm[self._idx()])
@@ -1444,6 +1634,9 @@ class RnnRBM(RnnEstimator):
         return self._rbm.build_metrics(targets, predictions, cond_probs, log_probs)
 
     def backward(self):
+        return drive(self._backward_co())
+
+    def _backward_co(self):
         cx = self._ctx
         D, Hn, R = self.num_dims, self.num_hidden[-1], self.num_hidden_rnn[-1]
         B, T = cx["B"], cx["T"]
@@ -1497,7 +1690,8 @@ class RnnRBM(RnnEstimator):
             ops.convert2d(d_out, do_c)
         dy = torch.empty((N, R), device=dev)
         ops.gemm_tn(do_c, self._wu_p, dy)
-        self._dx = self._stack.backward(dy.view(T, B, R), cx["lstm"], cx["kp"], self.seed, self.row0, need_dx=self.need_dx, step_dev=self.store.step_dev)
+        self._dx = yield from self._stack.backward_co(dy.view(T, B, R), cx["lstm"], cx["kp"], self.seed, self.row0, need_dx=self.need_dx,
+                                                      step_dev=self.store.step_dev)
         self._unscale(ls)
 
     def zero_state(self, batch_size):

@@ -615,12 +615,49 @@ class MultINNJamming(MultIEncoderNN):
     def _generator_io(self, i):
         return self._x_encoded[i][:, :-1], self._x_encoded[i][:, 1:]                            # multinn_jamming.py:61-65
 
+    # The M generators are independent (each has its own LSTM, multinn_jamming.py:40-48) and are trained on one loss (:213-221): their build and
+    # backward passes run in LOCKSTEP (generators.drive_group), so that the same layer's recurrence of all tracks is ONE launch of the
+    # CU-resident / cluster kernels (five tracks x 256 rows fill the chip; one track alone keeps 64 CUs busy).  MULTINN_JAMMING_GROUP=0: one
+    # generator after the other, each on the two-layer persistent form.
+    group_generators = os.environ.get("MULTINN_JAMMING_GROUP", "1") != "0"
+
+    def _grouped(self, mode):
+        """True when the generators' recurrences can share launches: a train / eval build of >= 2 like generators in a 16-bit mode whose stacks
+        (two layers, 512 and 256 units) the cluster / CU-resident kernels cover at this batch size."""
+        from . import ops as _ops
+        from .generators import RnnEstimator
+        gens = self.generators
+        if not (self.group_generators and mode in ("train", "eval") and 2 <= len(gens) <= 8 and type(self) is MultINNJamming):
+            return False
+        if not all(isinstance(g, RnnEstimator) and type(g) is type(gens[0]) and g.dtype in _ops.H16 for g in gens):
+            return False
+        x0 = self._generator_io(0)[0]
+        B, T = x0.shape[0], x0.shape[1]
+        units = list(gens[0].num_hidden_rnn)
+        if not (T >= 4 and B % 256 == 0 and units == [512, 256] and all(list(g.num_hidden_rnn) == units for g in gens)):
+            return False
+        return bool(_ops.lstm_cluster_ok(B, 512) and _ops.lstm_resident_ok(B, 256) and (len(gens) * (B // 32)) % 8 == 0)
+
     def _build_generators(self, mode="eval"):
+        from .generators import drive_group
         scale = 1.0 if self.separate_losses else 1.0 / self.num_tracks
+        grouped = self._grouped(mode)
+        cos = []
         for i in range(self.num_tracks):
             gi, gt = self._generator_io(i)
-            self.generators[i].grad_scale = scale          # mean track loss, one clip over all generators (multinn_jamming.py:235-241)
-            self.generators[i].build(x=gi, y=gt, lengths=self._lengths, is_train=self._is_train, mode=mode)
+            g = self.generators[i]
+            g.grad_scale = scale                            # mean track loss, one clip over all generators (multinn_jamming.py:235-241)
+            if grouped:
+                g._materialize(gi.shape[-1])
+                g._stack.group_rowpar = True
+                cos.append(g._build_co(x=gi, y=gt, lengths=self._lengths, is_train=self._is_train, mode=mode))
+            else:
+                if getattr(g, "_stack", None) is not None:
+                    g._stack.group_rowpar = False
+                g.build(x=gi, y=gt, lengths=self._lengths, is_train=self._is_train, mode=mode)
+        if grouped:
+            drive_group(cos)
+        self._built_grouped = grouped
 
     def _build_generator_outputs(self):
         return [self.generators[i].forward() for i in range(self.num_tracks)]
@@ -661,8 +698,14 @@ class MultINNJamming(MultIEncoderNN):
         built_scale = 1.0 if self.separate_losses else 1.0 / M
         want_scale = 1.0 if separate_losses else 1.0 / M
         init_ops, update_ops, tm, tu, ts = [], [], [], [], []
+        lockstep = bool(getattr(self, "_built_grouped", False)) and not pretrain and type(self) is MultINNJamming
+        if lockstep:                                    # the M backward passes side by side: one launch per layer's backward recurrence
+            from .generators import drive_group
+            drive_group([g._backward_co() for g in self.generators])
         for i, g in enumerate(self.generators):
-            if pretrain:
+            if lockstep:
+                io, uo, m, mu, s = [], [], g.metrics, g.metrics_upd, dict(g.summaries)      # what g.train(run_optimizer=False) returns
+            elif pretrain:
                 io, uo, m, mu, s = g.pretrain(optimizer, lr, run_optimizer=separate_losses)
                 if not separate_losses:
                     g.backward()                    # the joint step below differentiates the same batch/loss

@@ -92,9 +92,43 @@ def convert2d(src, dst):
     return dst
 
 
-def pianoroll_shift_timemajor(x, lengths, inputs, targets, row_weight, n_valid_total=0, inputs_t=None, count=None):
+def ragged_index(lengths, B, T, n_total_dev=None, scale_rows=0.0):
+    """Compaction index of a ragged window, built on the device (mnn_ragged_index): returns (idx, inv, hdr) -- idx[k] = time-major row at compact
+    position k (valid rows first, time-major order kept), inv = its inverse, hdr int32 [4] = [n_valid | 1 / n_total | loss scale | 1 / loss scale]
+    (words 1..3 are f32 bits: hdr.view(torch.float32)).  n_total_dev: f32 [1] valid rows of ALL ranks (None: this rank's)."""
+    _req(lengths.dtype == torch.int32 and lengths.numel() == B and lengths.is_cuda and lengths.is_contiguous(), "ragged_index: lengths int32 [B] on the device")
+    _req(n_total_dev is None or (n_total_dev.dtype == torch.float32 and n_total_dev.numel() == 1), "ragged_index: n_total_dev f32 [1]")
+    dev = lengths.device
+    idx = torch.empty(B * T, device=dev, dtype=torch.int32)
+    inv = torch.empty(B * T, device=dev, dtype=torch.int32)
+    hdr = torch.empty(4, device=dev, dtype=torch.int32)
+    call("mnn_ragged_index", _stream(), _ptr(lengths), int(B), int(T), _ptr(n_total_dev), float(scale_rows), _ptr(idx), _ptr(inv), _ptr(hdr))
+    return idx, inv, hdr
+
+
+def rows_gather16(src, idx, hdr, dst, dst_t=None):
+    """dst[k] = src[idx[k]] for k < hdr[0], zeros behind (16-bit [N, C] rows); dst_t [C, >= N] (optional): the transposed copy."""
+    N, Cc = src.shape
+    _req(src.dtype in H16 and dst.dtype == src.dtype and dst.shape == src.shape and src.stride(1) == 1 and dst.stride(1) == 1, "rows_gather16: 16-bit [N, C]")
+    _req(dst_t is None or (dst_t.dtype == src.dtype and dst_t.shape[0] == Cc and dst_t.shape[1] >= N and dst_t.stride(1) == 1), "rows_gather16: dst_t [C, >= N]")
+    call("mnn_rows_gather16", _stream(), _ptr(src), src.stride(0), _ptr(idx), _ptr(hdr), N, Cc, _ptr(dst), dst.stride(0), _ptr(dst_t),
+         dst_t.stride(0) if dst_t is not None else 0)
+    return dst
+
+
+def rows_scatter_f32(src, inv, hdr, dst):
+    """dst[row] = src[inv[row]] where inv[row] < hdr[0], zeros elsewhere (f32 [N, C], both contiguous)."""
+    _req(src.dtype == torch.float32 and dst.dtype == torch.float32 and src.shape == dst.shape and src.is_contiguous() and dst.is_contiguous(),
+         "rows_scatter_f32: contiguous f32 [N, C]")
+    call("mnn_rows_scatter_f32", _stream(), _ptr(src), _ptr(inv), _ptr(hdr), src.shape[0], src.shape[1], _ptr(dst))
+    return dst
+
+
+def pianoroll_shift_timemajor(x, lengths, inputs, targets, row_weight, n_valid_total=0, inputs_t=None, count=None, compact=None):
     """x u8 [B,T,D] -> inputs [T,B,ld] (shifted, zero first step), targets u8 [T,B,D], row_weight f32 [T*B];
-    inputs_t (bf16 [ld, >= T*B], optional): the transposed copy of inputs, written by the same pass."""
+    inputs_t (bf16 [ld, >= T*B], optional): the transposed copy of inputs, written by the same pass.
+    compact = (inv, hdr) of ragged_index (tiled 16-bit pass only): targets and row_weight are written in COMPACT row order, the weights from the
+    device-side header (no host-side row count)."""
     _req(x.dtype == torch.uint8 and x.dim() == 3 and x.is_contiguous(), "pianoroll: x must be contiguous u8 [B,T,D]")
     B, T, D = x.shape
     _req(inputs.dim() == 3 and inputs.shape[0] == T and inputs.shape[1] == B and inputs.shape[2] >= D and inputs.is_contiguous(),
@@ -103,14 +137,16 @@ def pianoroll_shift_timemajor(x, lengths, inputs, targets, row_weight, n_valid_t
         _req(targets.dtype == torch.uint8 and targets.shape == (T, B, D) and targets.is_contiguous(), "pianoroll: targets u8 [T,B,D]")
     if row_weight is not None:
         _req(row_weight.dtype == torch.float32 and row_weight.numel() == T * B, "pianoroll: row_weight f32 [T*B]")
+    _req(compact is None or inputs_t is not None, "pianoroll: compact row order needs the tiled 16-bit pass (inputs_t)")
     if lengths is not None:
         _req(lengths.dtype == torch.int32 and lengths.numel() == B, "pianoroll: lengths int32 [B]")
-        _req(n_valid_total > 0, "pianoroll: n_valid_total required with lengths")
+        _req(n_valid_total > 0 or compact is not None, "pianoroll: n_valid_total required with lengths")
     if inputs_t is not None:
         _req(inputs.dtype in H16 and inputs_t.dtype == inputs.dtype and inputs_t.dim() == 2 and inputs_t.stride(1) == 1
              and inputs_t.shape[0] == inputs.shape[2] and inputs_t.shape[1] >= T * B, "pianoroll: inputs_t must be 16-bit [ld, >=T*B] like inputs")
         call("mnn_pianoroll_shift_timemajor_t", _stream(), _ptr(x), B, T, D, _ptr(lengths), _ptr(inputs), inputs.shape[2], _ptr(inputs_t),
-             inputs_t.stride(0), _ptr(targets), _ptr(row_weight), int(n_valid_total), dtype_code(inputs), _ptr(count))
+             inputs_t.stride(0), _ptr(targets), _ptr(row_weight), int(n_valid_total), dtype_code(inputs), _ptr(count),
+             _ptr(compact[0]) if compact is not None else None, _ptr(compact[1]) if compact is not None else None)
         return count is not None                    # True: `count` now holds the number of set target cells
     call("mnn_pianoroll_shift_timemajor", _stream(), _ptr(x), B, T, D, _ptr(lengths), _ptr(inputs), dtype_code(inputs), inputs.shape[2],
          _ptr(targets), _ptr(row_weight), int(n_valid_total))
@@ -392,6 +428,29 @@ def lstm_cluster_bwd_ok(B, units):
     return bool(_lib.load().mnn_lstm_cluster_bwd_ok(int(B), int(units)))
 
 
+def lstm_recurrence_multi(kind, T, B, descs, keep_prob, wss=None):
+    """One launch for several independent layers of one shape (the per-track generators of the jamming mode).  kind: 'resident_fwd' |
+    'resident_bwd' | 'cluster_fwd' | 'cluster_bwd'; descs: the layers' descriptors (lstm2_fwd_layer / lstm2_bwd_layer); wss: cluster forms: one
+    lstm_rowpar_workspace per job."""
+    n = len(descs)
+    _req(1 <= n <= 8, "lstm_recurrence_multi: 1..8 jobs")
+    fwd = kind.endswith("fwd")
+    arr = ((_lib.LstmFwdLayer if fwd else _lib.LstmBwdLayer) * n)(*descs)
+    if kind.startswith("resident"):
+        call("mnn_lstm_resident_%s_multi" % ("fwd" if fwd else "bwd"), _stream(), T, B, n, arr, float(keep_prob))
+    else:
+        _req(wss is not None and len(wss) == n, "lstm_recurrence_multi: one workspace per job")
+        for ws, d in zip(wss, descs):
+            _rp_ws_ok(ws, T, B, d.units)
+        ptrs = (C.c_void_p * n)(*[ws.data_ptr() for ws in wss])
+        call("mnn_lstm_cluster_%s_multi" % ("fwd" if fwd else "bwd"), _stream(), T, B, n, arr, float(keep_prob), ptrs)
+    return arr            # (keeps the by-value copies alive until the call has returned)
+
+
+def lstm_cluster_bwd_multi_ok(B, units, njobs):
+    return bool(_lib.load().mnn_lstm_cluster_bwd_multi_ok(int(B), int(units), int(njobs)))
+
+
 def lstm_cluster_fwd(T, B, L, keep_prob, ws):
     """L: descriptor of lstm2_fwd_layer, as for lstm_rowpar_fwd with a 16-bit xproj; ws: the tensor of lstm_rowpar_workspace(T, B, 512)."""
     _rp_ws_ok(ws, T, B, L.units)
@@ -445,7 +504,7 @@ def _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec):
     _req(0 < Hn <= 256, "nade: Hn must be in 1..256")
 
 
-def nade_logprob_fwd(v, bias, w_enc, w_dec, tracks, D, Hn, row_weight=None, nll=None, cond_p=None, d_bias=None, a_final=None):
+def nade_logprob_fwd(v, bias, w_enc, w_dec, tracks, D, Hn, row_weight=None, nll=None, cond_p=None, d_bias=None, a_final=None, n_rows_dev=None):
     N = bias.shape[0]
     _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)
     if nll is not None:
@@ -459,6 +518,10 @@ def nade_logprob_fwd(v, bias, w_enc, w_dec, tracks, D, Hn, row_weight=None, nll=
         _req(row_weight.dtype == torch.float32 and row_weight.numel() == N, "nade: row_weight f32 [N]")
     if a_final is not None:
         _req(a_final.dtype == torch.float32 and a_final.numel() == tracks * N * Hn and a_final.is_contiguous(), "nade: a_final f32 [tracks,N,Hn]")
+    if n_rows_dev is not None:                       # compacted ragged batch: the gated entry point carries the row count (gate NULL: always runs)
+        call("mnn_nade_logprob_fwd_gated", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
+             _ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final), None, 0, _ptr(n_rows_dev))
+        return
     call("mnn_nade_logprob_fwd", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
          _ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final))
 
@@ -500,7 +563,7 @@ def nade_f32_pack(w_dec, out):
 
 
 def nade_logprob_fwd_auto(v, bias, w_enc, w_dec, w_dec_bf, tracks, D, Hn, gate, count, dense_above=0.07, row_weight=None, nll=None,
-                          cond_p=None, d_bias=None, a_final=None, exact=False, counted=False):
+                          cond_p=None, d_bias=None, a_final=None, exact=False, counted=False, n_rows_dev=None):
     """16-bit compute modes (exact=True: the split-operand hi + lo form of fp16 mode): the matrix-core form of the scan when at most `dense_above` of the cells of v are active, the f32 vector
     form otherwise; decided on the device (mnn_density_gate), both launches issued (one returns at once).  gate int32[1], count: a zeroed
     int32[1] scratch word (left zero)."""
@@ -520,16 +583,17 @@ def nade_logprob_fwd_auto(v, bias, w_enc, w_dec, w_dec_bf, tracks, D, Hn, gate, 
     common = (tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc))
     tail = (_ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final), _ptr(gate))
     mfma = "mnn_nade_logprob_fwd_mfma_f32" if exact else "mnn_nade_logprob_fwd_mfma_gated"
+    nr = _ptr(n_rows_dev)                           # compacted ragged batch: the scans skip workgroups of padding (ragged_index)
     if gate is None:                                # gate off: always the matrix-core form
-        call(mfma, _stream(), *common, _ptr(w_dec_bf), *tail, 0)
+        call(mfma, _stream(), *common, _ptr(w_dec_bf), *tail, 0, nr)
         return
     # counted: `count` already holds the set cells of v (the piano-roll pass counted them while writing v): only the decision kernel runs
     call("mnn_density_gate", _stream(), None if counted else _ptr(v), v.numel(), int(dense_above * v.numel()), _ptr(gate), _ptr(count))
-    call(mfma, _stream(), *common, _ptr(w_dec_bf), *tail, 0)
-    call("mnn_nade_logprob_fwd_gated", _stream(), *common, _ptr(w_dec), *tail, 1)
+    call(mfma, _stream(), *common, _ptr(w_dec_bf), *tail, 0, nr)
+    call("mnn_nade_logprob_fwd_gated", _stream(), *common, _ptr(w_dec), *tail, 1, nr)
 
 
-def nade_logprob_bwd(v, bias, w_enc, w_dec, tracks, D, Hn, a_final, d_bias, d_w_enc, d_w_dec):
+def nade_logprob_bwd(v, bias, w_enc, w_dec, tracks, D, Hn, a_final, d_bias, d_w_enc, d_w_dec, n_rows_dev=None):
     N = bias.shape[0]
     _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)
     _req(d_bias.shape == bias.shape and d_bias.stride() == bias.stride() and d_bias.dtype == torch.float32, "nade bwd: d_bias")
@@ -537,7 +601,7 @@ def nade_logprob_bwd(v, bias, w_enc, w_dec, tracks, D, Hn, a_final, d_bias, d_w_
         _req(w.dtype == torch.float32 and w.is_contiguous() and w.numel() == tracks * D * Hn, "nade bwd: grad weights f32 [tracks,D,Hn]")
     _req(a_final.dtype == torch.float32 and a_final.numel() == tracks * N * Hn and a_final.is_contiguous(), "nade bwd: a_final f32 [tracks,N,Hn]")
     call("mnn_nade_logprob_bwd", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
-         _ptr(a_final), _ptr(d_bias), _ptr(d_w_enc), _ptr(d_w_dec))
+         _ptr(a_final), _ptr(d_bias), _ptr(d_w_enc), _ptr(d_w_dec), _ptr(n_rows_dev))
 
 
 def nade_sample(bias, w_enc, w_dec, tracks, D, Hn, temperature, seed, row0, sub, samples, track_minor=False, nll=None):

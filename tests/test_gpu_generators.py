@@ -92,6 +92,109 @@ def test_rnn_nade_joint_train_step(precision, ragged, units):
             assert np.abs(gen.store[name].cpu().numpy().reshape(ref.shape) - ref).max() < 2e-4, name
 
 
+def test_ragged_index_and_row_moves_vs_numpy():
+    """ops.ragged_index (the compaction of a ragged window, built on the device) against NumPy: valid rows first in time-major order, padding
+    behind them, inverse permutation, header; lengths of 0, T and beyond T, B not a multiple of the kernel's chunk.  Then the two row movers:
+    rows_gather16 (+ its transposed copy, zeros behind the valid rows) and rows_scatter_f32 (zeros on padding rows)."""
+    from multinn_amd import ops
+    rng = np.random.default_rng(3)
+    for B, T in [(5, 7), (300, 9), (1024, 4), (64, 33)]:
+        ln = rng.integers(0, T + 3, B).astype(np.int32)
+        ln[0], ln[-1] = 0, T
+        lc = np.clip(ln, 0, T)
+        idx, inv, hdr = ops.ragged_index(dev(ln), B, T, None, 256.0)
+        valid = (np.arange(T)[:, None] < lc[None, :]).reshape(-1)
+        rows = np.arange(T * B)
+        ref_idx = np.concatenate([rows[valid], rows[~valid]])
+        nv = int(valid.sum())
+        assert int(hdr[0]) == nv
+        assert np.array_equal(idx.cpu().numpy(), ref_idx)
+        assert np.array_equal(inv.cpu().numpy()[ref_idx], np.arange(T * B))
+        hf = hdr.view(torch.float32).cpu().numpy()
+        assert hf[1] == np.float32(1.0) / np.float32(max(nv, 1)) and hf[2] == 2.0 ** round(np.log2(256.0 * max(nv, 1))) and hf[3] == 1.0 / hf[2]
+        # an all-reduced total from the caller replaces the local count in the header's scale words
+        _, _, h2 = ops.ragged_index(dev(ln), B, T, torch.tensor([3.0 * max(nv, 1)], device=DEV), 0.0)
+        assert float(h2.view(torch.float32)[1]) == np.float32(1.0) / np.float32(3.0 * max(nv, 1)) and float(h2.view(torch.float32)[2]) == 1.0 and int(h2[0]) == nv
+        N, C = T * B, 72
+        for dt in (torch.float16, torch.bfloat16):
+            src = torch.randn((N, C), device=DEV).to(dt)
+            dst = torch.full((N, C), 7.0, device=DEV, dtype=dt)
+            Np = (N + 63) // 64 * 64
+            dstT = torch.full((C, Np), 7.0, device=DEV, dtype=dt)
+            ops.rows_gather16(src, idx, hdr, dst, dstT)
+            ref = torch.zeros_like(src)
+            ref[:nv] = src[torch.from_numpy(ref_idx[:nv]).to(DEV)]
+            assert torch.equal(dst, ref) and torch.equal(dstT[:, :N], ref.t())
+        g = torch.randn((N, 8), device=DEV)
+        out = torch.full((N, 8), 7.0, device=DEV)
+        ops.rows_scatter_f32(g, inv, hdr, out)
+        ref = torch.zeros_like(g)
+        ref[torch.from_numpy(ref_idx[:nv]).to(DEV)] = g[:nv]
+        assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("precision,Hn,units,B,T", [("fp16", 256, [128, 128], 96, 12), ("bf16", 20, [32, 64], 6, 5), ("fp16", 256, [512, 256], 256, 6)])
+def test_ragged_window_compacted_rows_equal_the_padded_path(precision, Hn, units, B, T):
+    """A ragged window with Dense + NADE on its valid rows only (the reference drops padded rows: utils/sequences.py:6-37) against the
+    same step with the padding rows kept at weight 0 (`ragged_compact = False`): loss, API-order NLL rows and conditionals, every gradient --
+    equal up to the summation order of the row sums.  Shapes: the split-operand matrix-core forward with its workgroups of padding skipped,
+    the f32 vector forward (Hn = 20), and the row-parallel / cluster recurrence path (B = 256)."""
+    from multinn_amd import RnnNade
+    P, M = 8, 2
+    D = P * M
+    x = dev(make_batch(B, T, P, M, 11, rho=0.1))
+    rng = np.random.default_rng(5)
+    ln = rng.integers(1, T + 1, B).astype(np.int32)
+    ln[0] = T
+    ln[B // 2:] = np.minimum(ln[B // 2:], T // 2)             # whole workgroups of padding at the late timesteps
+    res = []
+    for compact in (True, False):
+        gen = RnnNade(D, Hn, units, keep_prob=0.9, precision=precision, seed=23)
+        gen._materialize(D)
+        gen.ragged_compact = compact
+        gen._stack.rowpar_min_batch = 32
+        gen.build_pianoroll(x, dev(ln), is_train=True, mode="train")
+        assert (gen._ctx.get("compact") is not None) == compact
+        loss, nll, cp = float(gen.metrics["batch/loss"]), gen.log_probs.clone(), gen.cond_probs.clone()
+        gen.backward()
+        gen.check()
+        res.append((loss, nll, cp, gen.store.grad.clone()))
+    (la, na, ca, ga), (lb, nb_, cb, gb) = res
+    assert na.shape == nb_.shape == (int(ln.sum()),) and ca.shape == cb.shape
+    assert abs(la - lb) < 1e-6 * abs(lb)
+    assert float((na - nb_).abs().max()) <= 1e-6 * float(nb_.abs().max()) and float((ca - cb).abs().max()) <= 1e-6
+    assert bool(torch.isfinite(ga).all())
+    assert float((ga - gb).abs().max()) <= 2e-4 * float(gb.abs().max()), float((ga - gb).abs().max()) / float(gb.abs().max())
+
+
+def test_ragged_step_is_captured_once_for_any_lengths():
+    """graphed_train_step(lengths=...): ONE captured hipGraph serves every later (x, lengths) -- the compaction index, the valid-row count,
+    1 / n_valid and the f16 loss scale are computed on the device inside the graph.  Replays on three different length vectors (one of them
+    full-length, one nearly empty) against eager steps of a twin generator on the same data: same losses, same weights after the steps."""
+    from multinn_amd import RnnNade, AdamOptimizer
+    B, T, P, M, Hn, units = 64, 10, 8, 2, 256, [128, 128]
+    D = P * M
+    rng = np.random.default_rng(9)
+    xs = [dev(make_batch(B, T, P, M, 20 + i, rho=0.1)) for i in range(3)]
+    lens = [rng.integers(1, T + 1, B).astype(np.int32), np.full(B, T, np.int32), np.ones(B, np.int32)]
+    lens[2][0] = 3
+    a = RnnNade(D, Hn, units, keep_prob=0.9, precision="fp16", seed=23)
+    b = RnnNade(D, Hn, units, keep_prob=0.9, precision="fp16", seed=23)
+    a._materialize(D)
+    b._materialize(D)
+    b.store.theta.copy_(a.store.theta)
+    oa, ob = AdamOptimizer(0.01), AdamOptimizer(0.01)
+    run = a.graphed_train_step(xs[0], oa, warmup=0, lengths=dev(lens[0]))
+    assert run.ragged
+    for x, ln in zip(xs, lens):
+        la = float(run(x, dev(ln)))
+        lb = float(b.train_step(x, dev(ln), ob))
+        assert abs(la - lb) < 1e-5 * abs(lb), (la, lb)
+    a.check()
+    b.check()
+    assert float((a.store.theta - b.store.theta).abs().max()) < 2e-4
+
+
 def test_fp16_ragged_lengths_loss_scale_and_overflow_guard():
     """precision='fp16' on a RAGGED window -- one long song and many rows of length 1, N / n_valid = 8 -- against the float64 oracle: the loss
     scale of the backward pass is derived from the number of VALID rows (a scale taken from B*T would multiply every gradient seed by
@@ -114,7 +217,10 @@ def test_fp16_ragged_lengths_loss_scale_and_overflow_guard():
     load_nade_params(gen, p)
     gen._packed_step = -1
     gen.build_pianoroll(dev(x), dev(lengths), is_train=True, mode="train")
-    assert gen._n_valid == n_valid and gen._ctx["ls"] == 2.0 ** round(np.log2(256.0 * n_valid))
+    # (the compacted ragged path keeps the row count and the scale ON THE DEVICE: ops.ragged_index's header)
+    hdr = gen._ctx["compact"]["hdr"]
+    assert int(hdr[0]) == n_valid and float(hdr.view(torch.float32)[2]) == 2.0 ** round(np.log2(256.0 * n_valid))
+    assert float(hdr.view(torch.float32)[1]) == np.float32(1.0) / np.float32(n_valid) and float(gen._ctx["ls"]) == 1.0 / float(hdr.view(torch.float32)[2])
     inp, tgt = G.joint_inputs(x.astype(np.float64))
     fw = G.rnn_nade_forward(inp, tgt, lengths, p, 0.9, G.dropout_uniforms(23, B, T, units))
     g = G.rnn_nade_backward(fw, p)

@@ -929,6 +929,64 @@ def test_lstm_resident_recurrence_vs_float64(ops, B, T, keep, layout, save, dt):
     assert np.abs(db.cpu().numpy() - db_ref).max() < 1e-5 * max(1.0, np.abs(db_ref).max()) + 1e-6
 
 
+@pytest.mark.parametrize("u,njobs,B,T,keep", [(256, 5, 256, 6, 0.9), (256, 3, 64, 5, 1.0), (512, 5, 256, 6, 0.9), (512, 2, 512, 4, 1.0)])
+def test_lstm_recurrence_multi_job_launch_equals_single_launches(ops, u, njobs, B, T, keep):
+    """ONE launch for several independent layers (mnn_lstm_resident_*_multi, mnn_lstm_cluster_*_multi: the per-track generators of the jamming
+    mode share the grid of the CU-resident / cluster recurrences) against one launch per layer on the same inputs: every output of the forward
+    (h, y, c, gates, both transposed copies) and of the backward (dz row-major, K-blocked dz^T, bias gradient) bit for bit.  The 512-unit case
+    with five jobs is 40 clusters = 320 workgroups: more than the device holds at once, the last eight clusters run in a second round."""
+    tdt = torch.float16
+    kind = "resident" if u == 256 else "cluster"
+    assert (ops.lstm_resident_ok if u == 256 else ops.lstm_cluster_ok)(B, u)
+    N = T * B
+    g = torch.Generator(device=DEV).manual_seed(7)
+
+    def job():
+        j = dict(wh_t=(torch.randn((4 * u, u), device=DEV, generator=g) * 0.04).to(tdt), xproj=(torch.randn((T, B, 4 * u), device=DEV, generator=g) * 1.2).to(tdt),
+                 mask=(torch.rand((T, B, u), device=DEV, generator=g) < keep).to(torch.uint8) if keep < 1.0 else None,
+                 dh=torch.randn((T, B, u), device=DEV, generator=g) * 0.02)
+        j["wh_p"] = j["wh_t"].t().contiguous()
+        return j
+
+    def outs():
+        o = dict(gates=torch.zeros((T, B, 4 * u), device=DEV, dtype=tdt), c=torch.zeros((T, B, u), device=DEV), h=torch.zeros((T, B, u), device=DEV, dtype=tdt),
+                 y=torch.zeros((T, B, u), device=DEV, dtype=tdt) if keep < 1.0 else None, hT=torch.zeros((u, N), device=DEV, dtype=tdt),
+                 yT=torch.zeros((u, N), device=DEV, dtype=tdt), dzc=torch.zeros((T, B, 4 * u), device=DEV, dtype=tdt),
+                 dzT=torch.zeros((N // 32, 4 * u, 32), device=DEV, dtype=tdt), db=torch.zeros(4 * u, device=DEV))
+        o["ws"] = ops.lstm_rowpar_workspace(T, B, u, DEV) if kind == "cluster" else None
+        return o
+
+    def fdesc(j, o):
+        return ops.lstm2_fwd_layer(j["xproj"], j["wh_t"], None, None, o["gates"], o["c"], o["h"], o["hT"], o["y"], j["mask"], yT=o["yT"], gates_dtype=tdt, xproj_dtype=tdt)
+
+    def bdesc(j, o):
+        return ops.lstm2_bwd_layer(j["dh"], j["wh_p"], o["gates"], o["c"], None, o["dzc"], ops.lstm_seq_bwd_workspace(B, u, DEV), o["dzT"], o["db"], j["mask"], gates_dtype=tdt)
+
+    jobs = [job() for _ in range(njobs)]
+    single, multi = [outs() for _ in jobs], [outs() for _ in jobs]
+    for j, o in zip(jobs, single):
+        if kind == "resident":
+            ops.lstm_resident_fwd(T, B, fdesc(j, o), keep)
+            ops.lstm_resident_bwd(T, B, bdesc(j, o), keep)
+        else:
+            ops.lstm_cluster_fwd(T, B, fdesc(j, o), keep, o["ws"])
+            ops.lstm_cluster_bwd(T, B, bdesc(j, o), keep, o["ws"])
+    wss = [o["ws"] for o in multi] if kind == "cluster" else None
+    ops.lstm_recurrence_multi(kind + "_fwd", T, B, [fdesc(j, o) for j, o in zip(jobs, multi)], keep, wss)
+    if kind == "cluster":
+        assert ops.lstm_cluster_bwd_multi_ok(B, u, njobs)
+    ops.lstm_recurrence_multi(kind + "_bwd", T, B, [bdesc(j, o) for j, o in zip(jobs, multi)], keep, wss)
+    torch.cuda.synchronize()
+    for o in single + multi:
+        if o["ws"] is not None:
+            ops.lstm_rowpar_check(o["ws"])
+    for a, b in zip(single, multi):
+        for k in ("gates", "c", "h", "y", "hT", "yT", "dzc", "dzT", "db"):
+            if a[k] is not None:
+                assert torch.equal(a[k], b[k]), k
+    assert float(single[0]["dzc"].float().abs().max()) > 0 and not torch.equal(single[0]["h"], single[1]["h"])
+
+
 @pytest.mark.parametrize("dt", ["fp16", "bf16"])
 @pytest.mark.parametrize("B,T,keep,layout,save,nolocal", [(256, 5, 0.9, "kblock", True, False), (512, 4, 1.0, "plain", True, False), (256, 6, 0.9, None, False, False),
                                                            (256, 4, 0.9, "kblock", True, True)])

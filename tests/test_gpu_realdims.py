@@ -366,7 +366,7 @@ def test_cluster_backward_falls_back_to_rowpar_and_agrees_over_a_long_sequence(p
         took_b, loss_b, flat_b, gb = run()
     assert took_a and not took_b
     assert any("lstm_rowpar_bwd" in str(m.message) for m in w)
-    assert loss_a == loss_b                                   # the forward's hand-off policy never changes a bit
+    assert abs(loss_a - loss_b) <= 1e-6 * abs(loss_a)         # same forward (the loss is summed with f32 atomics: order-dependent in the last bit)
     assert bool(torch.isfinite(flat_a).all()) and bool(torch.isfinite(flat_b).all())
     tol = 2e-3 if precision == "fp16" else 2e-2
     print(f"\n[cluster vs row-parallel backward, {precision}, T={T}] relative difference per variable:")

@@ -68,6 +68,43 @@ def test_c3_jamming_real_widths(precision):
     assert gerr < GRAD_TOL[precision]
 
 
+def test_c3_jamming_generators_in_lockstep_equal_one_after_the_other():
+    """The jamming mode's five LSTM-RBM generators built and trained in LOCKSTEP (generators.drive_group: one launch of the cluster / CU-resident
+    recurrence per layer and direction for all tracks; B = 256 at the reference's widths) against the same model running one generator after
+    the other on the two-layer persistent form: the same Gibbs chains (they depend on the Dense outputs only through probabilities: bit-equal
+    draws are not required, equal losses to the kernels' 16-bit tolerance are), the same free energies and losses, gradients within the fp16
+    bound, and the same weights after two optimiser steps."""
+    from multinn_amd import MultINN, AdamOptimizer
+    B, T = 256, 6
+    x = TM.dev(TM.batch(B, T, P, M, 9, rho=0.05))
+    res = []
+    for grouped in (True, False):
+        m = MultINN(TM.config(P, TM.TRACKS5), TM.params("jamming", gen="RBM", Hn=HN, units=UNITS), mode="jamming", precision="fp16", seed=23)
+        m.group_generators = grouped
+        opt = AdamOptimizer(0.01)
+        m.build(x, lengths=None, is_train=True, mode="train")
+        assert bool(getattr(m, "_built_grouped", False)) == grouped
+        if grouped:
+            assert all(g._ctx["lstm"][0].get("rowpar") for g in m.generators)
+        fe = [g.free_energy.clone() for g in m.generators]
+        m.train_generators(opt, 0.01)
+        m.check()
+        grads = [g.store.grad.clone() for g in m.generators]
+        loss1 = float(m.generator_loss())
+        loss2 = float(m.train_step(x, None, opt))
+        m.check()
+        res.append((fe, grads, loss1, loss2, [g.store.theta.clone() for g in m.generators]))
+    (fa, ga, l1a, l2a, ta), (fb, gb, l1b, l2b, tb) = res
+    # (the two recurrence forms agree to 16-bit rounding, so a few Gibbs draws whose uniform sits within that of its probability differ and the
+    # chains part there: the free energy of the TARGETS is the tight check, losses and gradients -- which see the chain ends -- the loose ones)
+    print(f"\n[C3 lockstep vs sequential] loss {l1a:.5f} / {l1b:.5f}, after a step {l2a:.5f} / {l2b:.5f}")
+    for a, b in zip(fa, fb):
+        assert float((a - b).abs().max()) < 2e-3 * float(b.abs().max())
+    assert abs(l1a - l1b) < 2e-2 * max(1.0, abs(l1b)) and abs(l2a - l2b) < 2e-2 * max(1.0, abs(l2b)), (l1a, l1b, l2a, l2b)
+    for a, b in zip(ga, gb):
+        assert bool(torch.isfinite(a).all()) and float(torch.nn.functional.cosine_similarity(a, b, dim=0)) > 0.98
+
+
 @pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16"])
 def test_c4_composer_real_widths(precision):
     from multinn_amd import MultINN, AdamOptimizer
