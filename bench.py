@@ -427,6 +427,64 @@ def mode_params(w):
     return config, params
 
 
+def mode_roofline(w, precision, per, calls, N, sec):
+    """`roofline` of a mode workload (C3 jamming, C4 composer): the entry point with the largest share of the eager step (HIP events around
+    every C-ABI call) against the bound of ITS kernel, from algorithmic counts per launch:
+      LSTM recurrences (persist / cluster / resident, single or multi-job)  MFMA: 2 rows (u 4u) per layer and direction;
+      mnn_rbm_gibbs*   CD-k chain (rbm.py:148-226): 2 k 2 D Hn flop per row on the f32 matrix cores, k (D + Hn) sigmoids and as many Philox draws;
+      mnn_nade_logprob_fwd* / _bwd   HBM: the Dense-output rows the scan reads / writes (as on the joint step);
+      mnn_gemm_tn      MFMA: every plain GEMM of the step together (3 x the forward's dense contractions minus the recurrences).
+    `others` carries the next entry points the same way."""
+    M, P = w["M"], w["P"]
+    R1, R2 = UNITS
+    jam = w["mode"] == "jamming"
+    peak16, peak32 = (PEAK_MFMA_F32_TFLOPS if precision == "fp32" else PEAK_MFMA_16_TFLOPS), PEAK_MFMA_F32_TFLOPS
+    stacks = M if jam else 1                                   # jamming: one LSTM per track; composer: one shared LSTM
+    E = 84                                                     # composer: DBN code width per track (mode_params)
+    d_in = P if jam else E * M
+    Dn, tracks = (P, 1) if jam else (E, M)
+
+    def one(name, ms, n):
+        r = dict(entry_point=name, launches_per_step=n, avg_launch_us=ms * 1e3 / max(n, 1), measured_ms=ms)
+        if name.startswith(("mnn_lstm2_persist", "mnn_lstm_cluster", "mnn_lstm_resident", "mnn_lstm_rowpar")):
+            us = {"mnn_lstm_cluster": [R1], "mnn_lstm_resident": [R2]}.get(name.rsplit("_", 2)[0] if name.endswith("_multi") else name.rsplit("_", 1)[0], [R1, R2])
+            flop = 2.0 * N * stacks * sum(u * 4 * u for u in us)
+            r.update(bound="mfma", achieved=flop / (ms * 1e-3) / 1e12, peak=peak16, unit="TFLOP/s", algorithmic_flop_per_launch=flop / max(n, 1),
+                     kernel=name.replace("mnn_", "") + "_kernel", avg_timestep_us=ms * 1e3 / max(n, 1) / w["T"],
+                     note="latency-bound chain of T dependent steps (one launch per layer and direction; `_multi`: all tracks' layers in one launch)")
+        elif name.startswith("mnn_rbm_gibbs"):
+            k = 10
+            flop = 2.0 * k * 2 * P * HN * N * M
+            r.update(bound="mfma", achieved=flop / (ms * 1e-3) / 1e12, peak=peak32, unit="TFLOP/s", algorithmic_flop_per_launch=flop / max(n, 1),
+                     kernel="rbm_gibbs_mfma_kernel", sigmoids_per_launch=k * (P + HN) * N * M / max(n, 1),
+                     note="f32 products on v_mfma_f32_32x32x2_f32 (bit-exact draws need the k-ordered f32 chain); Philox + deterministic sigmoid on the VALU "
+                          "are ~60 % of an iteration")
+        elif name.startswith(("mnn_rbm_hidden", "mnn_rbm_visible", "mnn_rbm_free_energy")):
+            flop = 2.0 * 2 * (P * 168 + 168 * E) * N * M if not jam else 2.0 * 2 * P * HN * N * M
+            r.update(bound="mfma", achieved=flop / (ms * 1e-3) / 1e12, peak=peak32, unit="TFLOP/s", algorithmic_flop_per_launch=flop / max(n, 1),
+                     kernel=name.replace("mnn_", "") + "_kernel")
+        elif name.startswith("mnn_nade_logprob"):
+            byt = N * (4.0 * tracks * (HN + Dn) * (2 if name.endswith("bwd") else 1) + tracks * Dn + 4.0 * tracks * HN)
+            r.update(bound="hbm", achieved=byt / (ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", algorithmic_bytes_per_launch=byt / max(n, 1),
+                     kernel="nade_fwd_kernel" if "fwd" in name else "nade_bwd_kernel",
+                     note="dense visibles (DBN codes): the f32 vector scan; HBM is not its limiter (one sigmoid per hidden unit and active visible is)")
+        else:
+            fwd = 2.0 * N * stacks * (d_in * 4 * R1 + R1 * 4 * R2) + 2.0 * N * (M * R2 * (HN + P) if jam else R2 * M * (HN + E))
+            flop = 3.0 * fwd
+            r.update(bound="mfma", achieved=flop / (ms * 1e-3) / 1e12, peak=peak16, unit="TFLOP/s", algorithmic_flop_per_launch=flop / max(n, 1),
+                     kernel="gemm_tn_glds", note="all plain GEMMs of the step (input projections, Dense / Wuh,Wuv layers, their input and weight gradients)")
+        r["frac"] = r["achieved"] / r["peak"]
+        r["traffic"] = None
+        return r
+
+    top = sorted(per.items(), key=lambda kv: -kv[1])
+    roof = one(top[0][0], top[0][1], calls[top[0][0]])
+    roof["others"] = [one(k, ms, calls[k]) for k, ms in top[1:5] if ms > 0.04 * sum(per.values())]
+    roof["sum_device_eager_ms"] = sum(per.values())
+    roof["timing"] = "HIP events around every C-ABI call of eager steps run right after the timed replays"
+    return roof
+
+
 def main(argv=None):
     a = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -526,6 +584,7 @@ def main(argv=None):
         timing, _lib.TIMING = _lib.TIMING, None
         if rank == 0:
             per = {k: sum(e0.elapsed_time(e1) for e0, e1 in v) / nb for k, v in timing.items()}
+            calls = {k: len(v) // nb for k, v in timing.items()}
             top = sorted(per.items(), key=lambda kv: -kv[1])
             print(json.dumps({
                 "metric": "piano-roll timesteps/sec (train step), " + ("5 x LSTM-RBM CD-10 (jamming)" if w["mode"] == "jamming" else "DBNEncoder -> LSTM-MultiNADE (composer)"),
@@ -534,8 +593,7 @@ def main(argv=None):
                 "config": {"workload": w["name"], "global_batch": world * B, "per_gpu_batch": B, "seq_len": T, "pitches": P, "tracks": M, "rho": a.rho,
                            "parallelism": f"dp{world}"},
                 "launch": launch, "loss": float(loss), "dp": dp_info, "breakdown_ms": {k: round(v, 3) for k, v in top},
-                "roofline": {"note": "parity-case configuration: per-entry-point HIP-event breakdown only (the roofline line is the joint LSTM-NADE step)",
-                             "sum_device_eager_ms": sum(per.values())}}), flush=True)
+                "roofline": mode_roofline(w, a.precision, per, calls, B * T, sec)}), flush=True)
         if multi:
             dist.barrier()
             dist.destroy_process_group()
