@@ -1672,22 +1672,33 @@ class RnnRBM(RnnEstimator):
             self._dx = None
             self._unscale(ls)
             return                                   # as written: no gradient reaches the LSTM / Wuh / Wuv (R3)
-        if self.internal_bias:
-            ops.bias_grad(d_out[:, :Hn], g[f"{self._rbm.prefix}/bh"].view(-1), accumulate=True)
-            ops.bias_grad(d_out[:, Hn:Hn + D], g[f"{self._rbm.prefix}/bv"].view(-1), accumulate=True)
         Np8 = ops.round_up(N, 64)
-        yT = torch.zeros((R, Np8), device=dev, dtype=self.dtype)
-        ops.transpose(cx["y"].view(N, R), yT)
-        doT = torch.zeros((self.n_out, Np8), device=dev, dtype=self.dtype)
-        ops.transpose(d_out[:, :self.n_out], doT)
+        zalloc = torch.zeros if Np8 != N else torch.empty
+        yT = cx["lstm"][-1].get("yT") if cx["lstm"] else None      # emitted by the persistent / row-parallel recurrences
+        if yT is None:
+            yT = zalloc((R, Np8), device=dev, dtype=self.dtype)
+            ops.transpose(cx["y"].view(N, R), yT)
+        doT = zalloc((self.n_out, Np8), device=dev, dtype=self.dtype)
+        if self.dtype == torch.float32:
+            if self.internal_bias:
+                ops.bias_grad(d_out[:, :Hn], g[f"{self._rbm.prefix}/bh"].view(-1), accumulate=True)
+                ops.bias_grad(d_out[:, Hn:Hn + D], g[f"{self._rbm.prefix}/bv"].view(-1), accumulate=True)
+            ops.transpose(d_out[:, :self.n_out], doT)
+            do_c = d_out
+        else:
+            # one pass over d_out: 16-bit copy (the input-gradient operand), 16-bit transpose (the Wuh / Wuv gradient operand) and the column
+            # sums, which ARE the gradients of rbm.bh | rbm.bv (internal_bias: rnn_rbm.py:240-259 adds them to the Dense outputs) -- instead of
+            # two bias_grad passes, a transpose and a convert2d
+            do_c = torch.empty((N, self.ldo), device=dev, dtype=self.dtype)
+            colsum = torch.zeros(self.n_out, device=dev)
+            ops.grad_rows_fanout(d_out, self.n_out, do_c, doT, colsum)
+            if self.internal_bias:
+                gh, gv = g[f"{self._rbm.prefix}/bh"].view(-1), g[f"{self._rbm.prefix}/bv"].view(-1)
+                ops.axpby(1.0, colsum[:Hn], 1.0, gh, gh)
+                ops.axpby(1.0, colsum[Hn:Hn + D], 1.0, gv, gv)
         # Wuh [R,Hn] and Wuv [R,D] are separate variables: one accumulating product per block of the transposed gradient
         ops.gemm_tn(yT, doT[:Hn], g["Wuh"], accumulate=True, split_k=LstmStack._split_k(R, Hn, Np8))
         ops.gemm_tn(yT, doT[Hn:Hn + D], g["Wuv"], accumulate=True, split_k=LstmStack._split_k(R, D, Np8))
-        if self.dtype == torch.float32:
-            do_c = d_out
-        else:
-            do_c = torch.empty((N, self.ldo), device=dev, dtype=self.dtype)
-            ops.convert2d(d_out, do_c)
         dy = torch.empty((N, R), device=dev)
         ops.gemm_tn(do_c, self._wu_p, dy)
         self._dx = yield from self._stack.backward_co(dy.view(T, B, R), cx["lstm"], cx["kp"], self.seed, self.row0, need_dx=self.need_dx,
