@@ -121,28 +121,37 @@ def train_epoch(generator, X, lengths, ids, batch_size, piece_size, optimizer, l
         song_ids, j, max_len, len_batch = w
         xb = torch.from_numpy(np.ascontiguousarray(X[song_ids, j:j + max_len])).to(device or "cuda")
         full = bool((len_batch == max_len).all())
-        run = _captured_step(generator, xb, optimizer, lr) if full else None
+        lb = None if full else torch.from_numpy(len_batch).to(xb.device)
+        run = _captured_step(generator, xb, optimizer, lr, lengths=lb)
         if run is not None:
-            loss = run(xb)
+            loss = run(xb) if full else run(xb, lb)
         else:
-            loss = generator.train_step(xb, None if full else torch.from_numpy(len_batch).to(xb.device), optimizer, lr)
+            loss = generator.train_step(xb, lb, optimizer, lr)
         loss_accum.update(float(loss))
     return loss_accum.loss()
 
 
-def _captured_step(generator, xb, optimizer, lr, max_graphs=8):
-    """An eager optimiser step is host-bound (C2 shape: 7.2 ms eager, 2.85 ms as a hipGraph replay), so full-length windows of a shape
-    that keeps coming back -- batch_size x piece_size, i.e. nearly all of an epoch -- run as replays of RnnNade.graphed_train_step.
+def _captured_step(generator, xb, optimizer, lr, max_graphs=8, lengths=None):
+    """An eager optimiser step is host-bound (C2 shape: 7.2 ms eager, 2.85 ms as a hipGraph replay), so windows of a shape that keeps
+    coming back -- batch_size x piece_size, i.e. nearly all of an epoch -- run as replays of RnnNade.graphed_train_step.
     A shape is captured at its SECOND occurrence (the first one runs eagerly and creates every workspace; capturing executes nothing,
-    so the trajectory is the eager one), keyed by optimiser and learning rate (both are baked into the graph).  Only for the path the
-    captured step is tested on: the bf16 two-layer persistent recurrence.  MULTINN_TRAIN_GRAPH=0 keeps every step eager."""
+    so the trajectory is the eager one), keyed by optimiser and learning rate (both are baked into the graph).  Only for the paths the
+    captured step is tested on: the two-layer persistent recurrence and the row-parallel (CU-resident / cluster) one.
+    RAGGED windows (lengths given) are captured too where the generator runs them compacted (16-bit RnnNade: every row count lives on the
+    device, so ONE graph per window shape serves any lengths -- the reference's data is ragged, train.py:165-173); they get their own graph
+    beside the full-length one of the same shape, which skips the compaction passes.  MULTINN_TRAIN_GRAPH=0 keeps every step eager."""
     import os
     if os.environ.get("MULTINN_TRAIN_GRAPH", "1") == "0" or not xb.is_cuda or not hasattr(generator, "graphed_train_step"):
         return None
     stack = getattr(generator, "_stack", None)
-    if stack is None or getattr(stack, "packed", None) is None or not stack._persist(xb.shape[0]):
+    if stack is None or getattr(stack, "packed", None) is None or not (stack._persist(xb.shape[0], xb.shape[1]) or stack._rowpar(xb.shape[0], xb.shape[1])):
         return None
-    key = (tuple(xb.shape), id(optimizer), lr)
+    ragged = lengths is not None
+    if ragged:
+        from . import ops as _ops
+        if not (getattr(generator, "ragged_compact", False) and getattr(generator, "dtype", None) in _ops.H16 and getattr(generator, "num_tracks", 0) == 1):
+            return None
+    key = (tuple(xb.shape), id(optimizer), lr, "ragged" if ragged else "full")
     graphs = generator.__dict__.setdefault("_step_graphs", {})
     if key in graphs:
         return graphs[key]
@@ -150,7 +159,7 @@ def _captured_step(generator, xb, optimizer, lr, max_graphs=8):
     if key not in seen or len(graphs) >= max_graphs:
         seen.add(key)
         return None
-    graphs[key] = generator.graphed_train_step(xb, optimizer, lr, warmup=0)
+    graphs[key] = generator.graphed_train_step(xb, optimizer, lr, warmup=0, lengths=lengths)
     return graphs[key]
 
 

@@ -642,14 +642,15 @@ def test_driver_fit_and_checkpoints(tmp_path):
 
 
 def test_driver_epoch_replays_captured_steps(monkeypatch):
-    """train_epoch runs full-length windows of a recurring shape as hipGraph replays (captured at the shape's second occurrence,
-    nothing executed by the capture): the loss trajectory must be the eager loop's (MULTINN_TRAIN_GRAPH=0) and ragged windows stay eager."""
+    """train_epoch runs windows of a recurring shape as hipGraph replays (captured at the shape's second occurrence, nothing executed by the
+    capture): the loss trajectory must be the eager loop's (MULTINN_TRAIN_GRAPH=0).  Ragged windows are captured too (their own graph beside
+    the full-length one of the same shape: the compacted ragged step keeps its row counts on the device, so it serves any lengths)."""
     from multinn_amd import RnnNade, AdamOptimizer
     from multinn_amd.driver import train_epoch, LossAccumulator, TrainingStats
     R = np.random.default_rng(5)
     X = (R.random((24, 12, 8, 2)) < .2).astype(np.uint8)
     lengths = np.full(24, 12)
-    lengths[5] = 7                                               # one ragged song: its late windows run eagerly
+    lengths[5] = 7                                               # one ragged song: its late window is a ragged step
     ids = np.arange(24)
 
     def epoch_losses(graph):
@@ -670,6 +671,7 @@ def test_driver_epoch_replays_captured_steps(monkeypatch):
     lg, gg = epoch_losses(True)
     le, ge = epoch_losses(False)
     assert len(gg.__dict__.get("_step_graphs", {})) >= 1 and "_step_graphs" not in ge.__dict__
+    assert any(k[-1] == "ragged" for k in gg._step_graphs) and any(k[-1] == "full" for k in gg._step_graphs), list(gg._step_graphs)
     assert np.allclose(lg, le, rtol=5e-3), (lg, le)
     assert gg.store.step == ge.store.step
     assert torch.allclose(gg.store.theta, ge.store.theta, atol=5e-3)
