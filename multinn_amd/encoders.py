@@ -104,32 +104,48 @@ class DBNEncoder(Encoder):
         self._variables = dict(self.store.views)
         self._trainable_variables = [self.store[n] for n in self.store.names()]
         self._lengths = None
+        self._dec_pending = None
 
     dbn = property(lambda self: self._dbn)
 
     def build(self, x=None, y=None, lengths=None, is_train=None, mode="eval"):
         """dbn_encoder.py:52-106: forward pass through every layer (sampled codes upward), then the reconstruction
-        pass back down, every layer's probabilities and samples kept."""
+        pass back down, every layer's probabilities and samples kept.  The reference BUILDS both passes into its graph and executes the
+        reconstruction only when something fetches it (a generator's train step never does); here the downward pass runs ON DEMAND -- at the
+        first read of `decodings` / `dec_probs` / `decode()` / `metrics` -- with the RNG counters of this build, so its draws are the ones an
+        eager pass would have made (the composer's train step spent 1.4 of its 13.9 ms on reconstructions nothing read)."""
         super().build(x, y, lengths, is_train, mode)
         self._inputs, self._lengths = x, lengths
         self._enc_probs, self._encodings, self._dec_probs, self._decodings = [], [], [], []
+        self._dec_pending = None
         if x is not None and mode in ("train", "eval"):
             f, lead = self._flat(x.to(torch.uint8) if x.dtype != torch.uint8 else x)
             h = f
             for i, r in enumerate(self._dbn.rbms):                      # same counters as DBN.forward: encode(x) == encodings[-1]
                 p, h = r.forward(h, None, self.seed, self.row0, (self._sub << 4) | i, STREAM_DBN_ENC)
                 self._enc_probs.append(p.view(*lead, -1)); self._encodings.append(h.view(*lead, -1))
-            v = h
-            for i in range(len(self._dbn.rbms) - 1, -1, -1):
-                p, v = self._dbn.rbms[i].reconstruct(v, None, self.seed, self.row0, (self._sub << 4) | i, STREAM_DBN_DEC)
-                self._dec_probs.insert(0, p.view(*lead, -1)); self._decodings.insert(0, v.view(*lead, -1))
+            self._dec_pending = (h, lead, self.seed, self.row0, self._sub)
         self._metrics = self._metrics_upd = None             # dbn_encoder.py:98-104: built on demand (see `metrics`)
         self._is_built = True
 
+    def _ensure_decoded(self):
+        """The reconstruction pass of the last build (see `build`), run once, with that build's seed / row / sub-stream counters."""
+        if self._dec_pending is not None:
+            v, lead, seed, row0, sub = self._dec_pending
+            self._dec_pending = None
+            for i in range(len(self._dbn.rbms) - 1, -1, -1):
+                p, v = self._dbn.rbms[i].reconstruct(v, None, seed, row0, (sub << 4) | i, STREAM_DBN_DEC)
+                self._dec_probs.insert(0, p.view(*lead, -1)); self._decodings.insert(0, v.view(*lead, -1))
+
+    decodings = property(lambda self: (self._ensure_decoded(), self._decodings)[1])
+    dec_probs = property(lambda self: (self._ensure_decoded(), self._dec_probs)[1])
+
     def _ensure_metrics(self):
-        if self._metrics is None and self._inputs is not None and self._decodings:
-            self._metrics, self._metrics_upd, self._summaries["metrics"] = self.build_metrics(
-                targets=self._inputs, predictions=self._decodings[0], cond_probs=self._dec_probs[0])
+        if self._metrics is None and self._inputs is not None:
+            self._ensure_decoded()
+            if self._decodings:
+                self._metrics, self._metrics_upd, self._summaries["metrics"] = self.build_metrics(
+                    targets=self._inputs, predictions=self._decodings[0], cond_probs=self._dec_probs[0])
         return self._metrics
 
     metrics = property(lambda self: self._ensure_metrics())
@@ -149,6 +165,7 @@ class DBNEncoder(Encoder):
     def decode(self, h=None):
         """dbn_encoder.py:164-190."""
         if h is None:
+            self._ensure_decoded()
             return self._dec_probs[0], self._decodings[0]
         f, lead = self._flat(h.to(torch.uint8) if h.dtype != torch.uint8 else h)
         p, v = self._dbn.reconstruct(f, self.seed, self.row0, self._sub)
