@@ -103,6 +103,20 @@ def test_c3_jamming_generators_in_lockstep_equal_one_after_the_other():
     assert abs(l1a - l1b) < 2e-2 * max(1.0, abs(l1b)) and abs(l2a - l2b) < 2e-2 * max(1.0, abs(l2b)), (l1a, l1b, l2a, l2b)
     for a, b in zip(ga, gb):
         assert bool(torch.isfinite(a).all()) and float(torch.nn.functional.cosine_similarity(a, b, dim=0)) > 0.98
+    # ragged windows go through the same lockstep path (the recurrences step every row; the row weights carry the lengths)
+    ln = torch.from_numpy(np.random.default_rng(3).integers(1, T + 1, B).astype(np.int32)).to(x.device)
+    fr = []
+    for grouped in (True, False):
+        m = MultINN(TM.config(P, TM.TRACKS5), TM.params("jamming", gen="RBM", Hn=HN, units=UNITS), mode="jamming", precision="fp16", seed=23)
+        m.group_generators = grouped
+        m.build(x, lengths=ln, is_train=True, mode="train")
+        assert bool(getattr(m, "_built_grouped", False)) == grouped
+        fr.append([g.free_energy.clone() for g in m.generators])
+        m.train_generators(AdamOptimizer(0.01), 0.01)
+        m.check()
+        assert all(bool(torch.isfinite(g.store.grad).all()) for g in m.generators)
+    for a, b in zip(*fr):
+        assert a.shape == (int(ln.sum()),) and float((a - b).abs().max()) < 2e-3 * float(b.abs().max())
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16"])
