@@ -308,7 +308,11 @@ int mnn_nade_logprob_fwd_mfma(mnn_stream_t s, int tracks, int N, int D, int Hn, 
  * a zeroed scratch array of MNN_DENSITY_SLOTS u32 partial counts (spread so that the adds do not serialise on one address), left zero.
  * v == NULL: the partial counts are already there (mnn_pianoroll_shift_timemajor_t counted while it wrote v) and only the decision runs.
  * The two *_gated entries are then both launched and each returns at once unless gate[0] == run_if
- * (gate NULL: always runs).  A captured step so takes the cheaper form at every replay, whatever batch it is fed. */
+ * (gate NULL: always runs).  A captured step so takes the cheaper form at every replay, whatever batch it is fed.
+ * mnn_nade_logprob_fwd_gated with a gate and run_if = 1 (the DENSE launch of the pair) and Hn > 128 advances the hidden states multiplicatively
+ * (u = exp(-a), one multiply by exp(-w_enc[i]) per flip, h = 1 / (1 + u); `a` -- and a_final -- is still the exact sum and re-derives u whenever
+ * |a| passes 40): conditionals and NLL within 2e-5 of the direct-sigmoid form, which every other call of this entry point (and
+ * mnn_nade_logprob_fwd, the f32 parity path) keeps. */
 #define MNN_DENSITY_SLOTS 256
 int mnn_density_gate(mnn_stream_t s, const uint8_t* v, long n, long threshold, int* gate, unsigned* count);
 int mnn_nade_logprob_fwd_gated(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,

@@ -109,7 +109,15 @@ struct WStage {
     }
 };
 
-template <int HQ>
+// UT (the density-gated launch of the 16-bit modes: DENSE batches): the hidden states are advanced MULTIPLICATIVELY.  With u = exp(-a),
+// h = sigmoid(a) = 1 / (1 + u) and a flip a += w is u *= exp(-w): exp(-w[i]) is one exponential per (visible, hidden unit) for ALL the rows of the
+// wave that flip there (at rho = 0.5 four of eight), and a flip itself is mul + add + rcp instead of add + mul + exp + add + rcp -- the scan of a
+// dense batch is bound by exactly these transcendentals.  `a` is still summed exactly (it is handed to the backward pass), and it is what keeps u
+// honest: a running max of |a| per lane is tested once per visible with flips, and above 40 every row's u is re-derived from its a before the
+// next visible.  Below that bound a product of an u in [e^-40, e^40] and an exp(-w) in f32 range is exact to rounding whatever w is; past the
+// f32 range it saturates to 0 / inf, where h is 1 / 0 to 1e-38 -- so the form is exact-safe for any weights.  The multiplies' rounding compounds
+// to ~2e-6 relative over 220 flips (1e-4 is the mode's bound); the f32 parity entry point (mnn_nade_logprob_fwd) keeps the direct form.
+template <int HQ, bool UT>
 __global__ void __launch_bounds__(512)
 nade_fwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias,
                 int ld_bias, const float* __restrict__ w_enc, const float* __restrict__ w_dec, const float* __restrict__ row_weight,
@@ -146,6 +154,17 @@ nade_fwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
             if (!(row < N && j < Hn)) a[r][q] = 0.f;
             h[r][q] = fast_sigmoid(a[r][q]);
         }
+    float u[UT ? FWD_R : 1][UT ? HQ : 1];                // exp(-a), advanced by one multiply per flip (UT)
+    float amax = 0.f;                                    // running max of |a| over this lane's states since the last re-derivation
+    if constexpr (UT) {
+#pragma unroll
+        for (int r = 0; r < FWD_R; ++r)
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) {
+                u[r][q] = fast_exp2(-MNN_LOG2E * a[r][q]);
+                amax = fmaxf(amax, fabsf(a[r][q]));
+            }
+    }
     // lane L owns (row L>>3, visible L&7) of every chunk: it prefetches that v / b_dec and finalises that logit
     const int frow = rbase + (lane >> 3), fi = lane & 7;
     const bool fvalid = frow < N;
@@ -178,17 +197,55 @@ nade_fwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
             float wdv[HQ], pr[8];
 #pragma unroll
             for (int q = 0; q < HQ; ++q) wdv[q] = sd[ii * W + lane + 64 * q];
-#pragma unroll
-            for (int r = 0; r < FWD_R; ++r) {
-                float acc = h[r][0] * wdv[0];
-#pragma unroll
-                for (int q = 1; q < HQ; ++q) acc = fmaf(h[r][q], wdv[q], acc);
-                pr[r] = acc;
-                if ((mask >> (r * 8 + ii)) & 1ull) {                             // wave-uniform: encode v_i = 1 (nade.py:219)
+            if constexpr (UT) {
+                const bool any = (mask & (0x0101010101010101ull << ii)) != 0ull;   // a row of the wave flips at this visible (wave-uniform)
+                float wev[HQ], ewv[HQ];
+                if (any) {
 #pragma unroll
                     for (int q = 0; q < HQ; ++q) {
-                        a[r][q] += se[ii * W + lane + 64 * q];
-                        h[r][q] = fast_sigmoid(a[r][q]);
+                        wev[q] = se[ii * W + lane + 64 * q];
+                        ewv[q] = fast_exp2(-MNN_LOG2E * wev[q]);                   // ONE exponential per (visible, hidden unit) for all flipping rows
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < FWD_R; ++r) {
+                    float acc = h[r][0] * wdv[0];
+#pragma unroll
+                    for (int q = 1; q < HQ; ++q) acc = fmaf(h[r][q], wdv[q], acc);
+                    pr[r] = acc;
+                    if ((mask >> (r * 8 + ii)) & 1ull) {                           // wave-uniform: encode v_i = 1 (nade.py:219)
+#pragma unroll
+                        for (int q = 0; q < HQ; ++q) {
+                            a[r][q] += wev[q];                                     // the exact sum (handed to the backward pass; the guard below)
+                            u[r][q] *= ewv[q];
+                            h[r][q] = fast_rcp(1.0f + u[r][q]);
+                            amax = fmaxf(amax, fabsf(a[r][q]));
+                        }
+                    }
+                }
+                if (any && __any(amax > 40.0f)) {                                  // rare: re-derive every u from its exact a (see the header)
+                    amax = 0.f;
+#pragma unroll
+                    for (int r = 0; r < FWD_R; ++r)
+#pragma unroll
+                        for (int q = 0; q < HQ; ++q) {
+                            u[r][q] = fast_exp2(-MNN_LOG2E * a[r][q]);
+                            h[r][q] = fast_rcp(1.0f + u[r][q]);
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < FWD_R; ++r) {
+                    float acc = h[r][0] * wdv[0];
+#pragma unroll
+                    for (int q = 1; q < HQ; ++q) acc = fmaf(h[r][q], wdv[q], acc);
+                    pr[r] = acc;
+                    if ((mask >> (r * 8 + ii)) & 1ull) {                             // wave-uniform: encode v_i = 1 (nade.py:219)
+#pragma unroll
+                        for (int q = 0; q < HQ; ++q) {
+                            a[r][q] += se[ii * W + lane + 64 * q];
+                            h[r][q] = fast_sigmoid(a[r][q]);
+                        }
                     }
                 }
             }
@@ -246,11 +303,15 @@ extern "C" int mnn_nade_logprob_fwd_gated(mnn_stream_t s, int tracks, int N, int
     MNN_REQUIRE(d_bias == nullptr || row_weight != nullptr, "mnn_nade_logprob_fwd: d_bias needs row_weight");
     dim3 grid(cdiv(N, 64), tracks);
     hipStream_t st = (hipStream_t)s;
-#define FWD(HQ) hipLaunchKernelGGL(nade_fwd_kernel<HQ>, grid, dim3(512), 0, st, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, \
-                                   w_dec, row_weight, nll, cond_p, d_bias, a_final, gate, run_if, n_rows_dev)
-    if (Hn <= 64) FWD(1);
-    else if (Hn <= 128) FWD(2);
-    else FWD(4);
+    // the density-gated DENSE launch of the 16-bit modes (gate given, run_if = 1) advances the hidden states multiplicatively (UT); every other
+    // caller -- the f32 parity mode, conditionals on demand, Hn <= 128 -- keeps the direct sigmoid
+#define FWD(HQ, UT) hipLaunchKernelGGL((nade_fwd_kernel<HQ, UT>), grid, dim3(512), 0, st, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, \
+                                       w_dec, row_weight, nll, cond_p, d_bias, a_final, gate, run_if, n_rows_dev)
+    static const bool no_ut = getenv("MNN_NADE_FWD_NO_UT") != nullptr;          // (tests: the direct form as the comparison partner)
+    if (Hn <= 64) FWD(1, false);
+    else if (Hn <= 128) FWD(2, false);
+    else if (gate != nullptr && run_if == 1 && !no_ut) FWD(4, true);
+    else FWD(4, false);
 #undef FWD
     MNN_LAUNCH_CHECK();
     return MNN_OK;

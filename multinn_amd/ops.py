@@ -504,7 +504,8 @@ def _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec):
     _req(0 < Hn <= 256, "nade: Hn must be in 1..256")
 
 
-def nade_logprob_fwd(v, bias, w_enc, w_dec, tracks, D, Hn, row_weight=None, nll=None, cond_p=None, d_bias=None, a_final=None, n_rows_dev=None):
+def nade_logprob_fwd(v, bias, w_enc, w_dec, tracks, D, Hn, row_weight=None, nll=None, cond_p=None, d_bias=None, a_final=None, n_rows_dev=None,
+                     gate=None, run_if=0):
     N = bias.shape[0]
     _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)
     if nll is not None:
@@ -518,9 +519,9 @@ def nade_logprob_fwd(v, bias, w_enc, w_dec, tracks, D, Hn, row_weight=None, nll=
         _req(row_weight.dtype == torch.float32 and row_weight.numel() == N, "nade: row_weight f32 [N]")
     if a_final is not None:
         _req(a_final.dtype == torch.float32 and a_final.numel() == tracks * N * Hn and a_final.is_contiguous(), "nade: a_final f32 [tracks,N,Hn]")
-    if n_rows_dev is not None:                       # compacted ragged batch: the gated entry point carries the row count (gate NULL: always runs)
+    if n_rows_dev is not None or gate is not None:   # compacted ragged batch / a density-gated launch: the gated entry point (gate NULL: always runs)
         call("mnn_nade_logprob_fwd_gated", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
-             _ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final), None, 0, _ptr(n_rows_dev))
+             _ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final), _ptr(gate), int(run_if), _ptr(n_rows_dev))
         return
     call("mnn_nade_logprob_fwd", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
          _ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final))

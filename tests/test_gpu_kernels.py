@@ -502,7 +502,9 @@ def test_nade_mfma_exact_forward_vs_oracle(ops, N, D, tracks, rho):
 @pytest.mark.parametrize("rho,expect", [(0.03, 0), (0.3, 1)])
 def test_nade_forward_density_gate(ops, rho, expect):
     """mnn_density_gate + the two gated launches: a sparse batch runs the matrix-core form (bit-identical to calling it directly), a dense
-    one the f32 form (bit-identical to it); the scratch count word is left zero and the decision is taken on the device at every call."""
+    one the f32 vector form (the same exact pre-activations; its hidden states advanced multiplicatively since round 6, so conditionals and NLL
+    agree with the direct-sigmoid entry point to 2e-5: test_nade_dense_forward_multiplicative_states_vs_direct_form); the scratch count word is
+    left zero and the decision is taken on the device at every call."""
     N, D, Hn, tracks = 96, 120, 256, 1
     g = torch.Generator(device="cuda").manual_seed(int(rho * 100))
     v = (torch.rand((tracks, N, D), device="cuda", generator=g) < rho).to(torch.uint8)
@@ -520,9 +522,11 @@ def test_nade_forward_density_gate(ops, rho, expect):
     nll2, cp2, db2, af2 = z(tracks, N), z(tracks, N, D), torch.zeros_like(bias), z(tracks, N, Hn)
     if expect:
         ops.nade_logprob_fwd(v, bias, we, wd, tracks, D, Hn, rw, nll2, cp2, db2, af2)
+        assert torch.equal(af, af2) and float((cp - cp2).abs().max()) < 2e-5 and float((nll - nll2).abs().max()) < 2e-5 * float(nll2.abs().max())
+        assert float((db - db2).abs().max()) < 1e-4 * float(db2.abs().max())
     else:
         ops.nade_logprob_fwd_mfma(v, bias, we, wdb, tracks, D, Hn, rw, nll2, cp2, db2, af2)
-    assert torch.equal(nll, nll2) and torch.equal(cp, cp2) and torch.equal(db, db2) and torch.equal(af, af2)
+        assert torch.equal(nll, nll2) and torch.equal(cp, cp2) and torch.equal(db, db2) and torch.equal(af, af2)
     # the same buffers, the other kind of batch: the decision follows the data
     v2 = (torch.rand((tracks, N, D), device="cuda", generator=g) < (0.3 if not expect else 0.02)).to(torch.uint8)
     ops.nade_logprob_fwd_auto(v2, bias, we, wd, wdb, tracks, D, Hn, gate[:1], gate[1:], 0.07, rw, nll, cp, db, af)
@@ -927,6 +931,42 @@ def test_lstm_resident_recurrence_vs_float64(ops, B, T, keep, layout, save, dt):
         assert torch.equal(dzT[:, :N].t(), flat)
     db_ref = flat.double().sum(0).cpu().numpy()
     assert np.abs(db.cpu().numpy() - db_ref).max() < 1e-5 * max(1.0, np.abs(db_ref).max()) + 1e-6
+
+
+@pytest.mark.parametrize("N,D,tracks,rho,scale", [(512, 440, 1, 0.5, 1.0), (300, 84, 5, 0.5, 1.0), (256, 440, 1, 0.9, 1.0), (256, 440, 1, 0.5, 12.0), (130, 60, 1, 0.5, 60.0)])
+def test_nade_dense_forward_multiplicative_states_vs_direct_form(ops, N, D, tracks, rho, scale):
+    """The density-gated DENSE launch of the vector forward (`mnn_nade_logprob_fwd_gated`, gate word 1, Hn = 256) advances the hidden states
+    multiplicatively -- u = exp(-a), one multiply by exp(-w_enc[i]) per flip, h = 1 / (1 + u), the exact `a` summed beside it -- against the
+    direct sigmoid form of the same kernel: NLL, conditionals, d nll / d b_dec and the final pre-activation handed to the backward pass.
+    scale > 1 multiplies the encoder weights and biases so that |a| runs past the guard's bound of 40 and back (scale 12) and past the f32
+    range of exp (scale 60: u saturates, h is 0 / 1, every u is re-derived from its exact a): the guarded form stays with the direct one."""
+    Hn = 256
+    g = torch.Generator(device=DEV).manual_seed(11)
+    v = (torch.rand((tracks, N, D), device=DEV, generator=g) < rho).to(torch.uint8)
+    ld = (tracks * (Hn + D) + 63) // 64 * 64
+    bias = (torch.randn((N, ld), device=DEV, generator=g) * 0.5)[:, :tracks * (Hn + D)]
+    bias[:, :tracks * Hn] *= scale
+    we = torch.randn((tracks, D, Hn), device=DEV, generator=g) * 0.1 * scale
+    wd = torch.randn((tracks, D, Hn), device=DEV, generator=g) * 0.1
+    rw = torch.rand(N, device=DEV, generator=g)
+
+    def run(gate):
+        nll = torch.zeros((tracks, N), device=DEV)
+        cp = torch.zeros((tracks, N, D), device=DEV)
+        db = torch.zeros((N, ld), device=DEV)[:, :tracks * (Hn + D)]
+        af = torch.zeros((tracks, N, Hn), device=DEV)
+        ops.nade_logprob_fwd(v, bias, we, wd, tracks, D, Hn, rw, nll, cp, db, af, gate=gate, run_if=1)
+        return nll, cp, db[:, tracks * Hn:].clone(), af
+
+    n0, c0, d0, a0 = run(None)                                                 # the direct form (ungated entry)
+    n1, c1, d1, a1 = run(torch.tensor([1], device=DEV, dtype=torch.int32))     # gate word 1 = dense: the multiplicative form
+    assert torch.equal(a1, a0)                                                 # `a` is the same exact sum in both
+    ec, en = float((c1 - c0).abs().max()), float(((n1 - n0).abs() / n0.abs().clamp_min(1.0)).max())
+    ed = float((d1 - d0).abs().max()) / max(float(d0.abs().max()), 1e-30)
+    print(f"\n[dense forward, multiplicative vs direct, N={N} D={D} tracks={tracks} rho={rho} scale={scale}] conditionals {ec:.2e}  NLL {en:.2e}  d b_dec {ed:.2e}")
+    assert ec < 2e-5 and en < 2e-5 and ed < 1e-4, (ec, en, ed)
+    n2, c2, _, _ = run(torch.tensor([0], device=DEV, dtype=torch.int32))       # gate word 0: this launch leaves at once, nothing is written
+    assert float(n2.abs().max()) == 0.0 and float(c2.abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("u,njobs,B,T,keep", [(256, 5, 256, 6, 0.9), (256, 3, 64, 5, 1.0), (512, 5, 256, 6, 0.9), (512, 2, 512, 4, 1.0)])
