@@ -1101,8 +1101,27 @@ class RnnNade(RnnEstimator):
             # rnn_multinade.py:97-101: reshape(flat,[-1,D,M]) unstacked on the last axis (track-minor)
             v = y.to(torch.uint8).transpose(0, 1).reshape(T, B, D, M).permute(3, 0, 1, 2).contiguous() if M > 1 \
                 else y.to(torch.uint8).transpose(0, 1).contiguous().view(1, T, B, D)
-            rw = self._row_weight(lengths, B, T, x.device)
-            yield from self._forward_tm_co(x_tm, v, rw, lengths, B, T, train=(mode == "train"))
+            compact = None
+            if lengths is not None and mode == "train" and self.dtype in ops.H16 and self.ragged_compact and x.is_cuda:
+                # ragged window of a generator that trains on encoder outputs (composer: RnnMultiNADE; jamming / feedback with NADE generators):
+                # Dense + NADE on the valid rows only, as build_pianoroll does for the joint mode (see there); the targets and row weights are
+                # brought into compact order here (the piano-roll pass does it for the joint path)
+                dev = x.device
+                len_dev = lengths.to(device=dev, dtype=torch.int32).contiguous()
+                n_total_dev = None
+                if dp_active():
+                    n_total_dev = len_dev.clamp(0, T).sum().float().reshape(1)
+                    torch.distributed.all_reduce(n_total_dev)
+                idx, inv, hdr = ops.ragged_index(len_dev, B, T, n_total_dev, self._stack.loss_scale_rows if self.dtype == torch.float16 else 0.0)
+                compact = dict(idx=idx, inv=inv, hdr=hdr, hdr_f=hdr.view(torch.float32))
+                v = v.view(M, T * B, D).index_select(1, idx.long()).view(M, T, B, D)          # every row of the permutation: padding rows behind the valid ones
+                k = torch.arange(T * B, device=dev, dtype=torch.int32)
+                rw = torch.where(k < hdr[0], compact["hdr_f"][1], torch.zeros((), device=dev))
+                lengths = len_dev
+                self._n_valid = None
+            else:
+                rw = self._row_weight(lengths, B, T, x.device)
+            yield from self._forward_tm_co(x_tm, v, rw, lengths, B, T, train=(mode == "train"), compact=compact)
         self._is_built = True
 
     # MULTINN_RAGGED_COMPACT=0: ragged windows keep their padding rows in the Dense + NADE part (weight 0), as before round 6

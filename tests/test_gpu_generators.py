@@ -167,6 +167,40 @@ def test_ragged_window_compacted_rows_equal_the_padded_path(precision, Hn, units
     assert float((ga - gb).abs().max()) <= 2e-4 * float(gb.abs().max()), float((ga - gb).abs().max()) / float(gb.abs().max())
 
 
+def test_ragged_window_through_build_compacts_multinade_rows():
+    """`build(x, y, lengths)` of a generator that trains on encoder outputs (composer mode: RnnMultiNADE, one NADE per track on one Dense
+    output) runs Dense + NADE on the valid rows only, like `build_pianoroll` does for the joint mode: against the padded path
+    (`ragged_compact = False`) -- loss, API-order per-track NLL rows and conditionals, every gradient."""
+    from multinn_amd import RnnMultiNADE
+    B, T, E, Mt, Hn = 96, 10, 12, 3, 256
+    rng = np.random.default_rng(8)
+    codes = torch.from_numpy((rng.random((B, T + 1, E * Mt)) < 0.4).astype(np.uint8)).to(DEV)
+    x, y = codes[:, :-1].contiguous(), codes[:, 1:].contiguous()
+    ln = rng.integers(1, T + 1, B).astype(np.int32)
+    ln[0] = T
+    ln[B // 2:] = np.minimum(ln[B // 2:], T // 2)
+    res = []
+    for compact in (True, False):
+        gen = RnnMultiNADE(E, Hn, [128, 128], tracks=["a", "b", "c"], keep_prob=0.9, precision="fp16", seed=23)
+        gen._materialize(E * Mt)
+        gen.ragged_compact = compact
+        gen.build(x, y, dev(ln), True, "train")
+        assert (gen._ctx.get("compact") is not None) == compact
+        loss = float(gen.metrics["batch/loss"])
+        nll = [t.clone() for t in gen.log_probs]
+        cp = [t.clone() for t in gen.cond_probs]
+        gen.backward()
+        gen.check()
+        res.append((loss, nll, cp, gen.store.grad.clone()))
+    (la, na, ca, ga), (lb, nb_, cb, gb) = res
+    assert abs(la - lb) < 1e-6 * abs(lb)
+    for a, b in zip(na, nb_):
+        assert a.shape == (int(ln.sum()),) and float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+    for a, b in zip(ca, cb):
+        assert float((a - b).abs().max()) <= 1e-6
+    assert bool(torch.isfinite(ga).all()) and float((ga - gb).abs().max()) <= 2e-4 * float(gb.abs().max())
+
+
 def test_ragged_step_is_captured_once_for_any_lengths():
     """graphed_train_step(lengths=...): ONE captured hipGraph serves every later (x, lengths) -- the compaction index, the valid-row count,
     1 / n_valid and the f16 loss scale are computed on the device inside the graph.  Replays on three different length vectors (one of them
