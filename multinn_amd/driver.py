@@ -143,14 +143,21 @@ def _captured_step(generator, xb, optimizer, lr, max_graphs=8, lengths=None):
     import os
     if os.environ.get("MULTINN_TRAIN_GRAPH", "1") == "0" or not xb.is_cuda or not hasattr(generator, "graphed_train_step"):
         return None
-    stack = getattr(generator, "_stack", None)
-    if stack is None or getattr(stack, "packed", None) is None or not (stack._persist(xb.shape[0], xb.shape[1]) or stack._rowpar(xb.shape[0], xb.shape[1])):
-        return None
     ragged = lengths is not None
-    if ragged:
-        from . import ops as _ops
-        if not (getattr(generator, "ragged_compact", False) and getattr(generator, "dtype", None) in _ops.H16 and getattr(generator, "num_tracks", 0) == 1):
+    if getattr(generator, "_mode", None) in ("joint", "jamming", "composer") and hasattr(generator, "generators"):
+        # a mode class (multinn_amd.modes): its own captured step -- encoders, every generator, the joint clipped step -- full-length or ragged
+        # (MultINNCore.graphed_train_step keeps every row count of a ragged window on the device)
+        from .training import dp_active
+        if dp_active() or any(getattr(g, "store", None) is None or g.store.theta is None for g in generator.generators):
             return None
+    else:
+        stack = getattr(generator, "_stack", None)
+        if stack is None or getattr(stack, "packed", None) is None or not (stack._persist(xb.shape[0], xb.shape[1]) or stack._rowpar(xb.shape[0], xb.shape[1])):
+            return None
+        if ragged:
+            from . import ops as _ops
+            if not (getattr(generator, "ragged_compact", False) and getattr(generator, "dtype", None) in _ops.H16 and getattr(generator, "num_tracks", 0) == 1):
+                return None
     key = (tuple(xb.shape), id(optimizer), lr, "ragged" if ragged else "full")
     graphs = generator.__dict__.setdefault("_step_graphs", {})
     if key in graphs:

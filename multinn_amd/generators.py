@@ -139,6 +139,8 @@ class LstmStack:
         """n_valid: number of VALID rows the mean-over-rows loss divides by (summed over all ranks)."""
         if self.dtype != torch.float16:
             return 1.0
+        if n_valid is None:
+            raise RuntimeError("loss_scale: the valid-row count lives on the device (ragged_on_device): use the generator's device-side scale")
         return float(2.0 ** round(math.log2(self.loss_scale_rows * max(int(n_valid), 1))))
 
     def pack(self):
@@ -819,6 +821,11 @@ class RnnEstimator(Generator):
         out[:, :, :Din] = x.transpose(0, 1).to(self.dtype)
         return out
 
+    # set by a caller that captures ragged steps (the mode classes' graphed_train_step): row weights, valid-row count and f16 loss scale of a
+    # ragged window are then derived on the device, without a host read
+    ragged_on_device = False
+    _ls_dev = None
+
     def _row_weight(self, lengths, B, T, device):
         """1/N_valid on valid rows (N_valid summed over ALL ranks), 0 on padding.  Leaves the host copy of N_valid in self._n_valid (the
         f16 loss scale is derived from it)."""
@@ -830,8 +837,15 @@ class RnnEstimator(Generator):
             return torch.full((T * B,), 1.0 / float(B * T * n_ranks), device=device)
         mask = (torch.arange(T, device=device)[:, None] < lengths.to(device)[None, :]).float()
         n_tot = mask.sum()
-        if dp_active():
+        if dp_active() and not torch.cuda.is_current_stream_capturing():
             torch.distributed.all_reduce(n_tot)
+        if self.ragged_on_device:
+            # nothing is read on the host (a captured ragged step of a mode class: MultINNCore.graphed_train_step(lengths=...)): the valid-row
+            # count stays a device scalar, and so does the f16 loss scale derived from it (LstmStack.loss_scale's rule, on the device)
+            n_tot = n_tot.clamp_min(1.0)
+            self._n_valid = None
+            self._ls_dev = torch.exp2(torch.round(torch.log2(self._stack.loss_scale_rows * n_tot))).reshape(1) if self.dtype == torch.float16 else None
+            return (mask / n_tot).reshape(-1).contiguous()
         self._n_valid = max(int(n_tot), 1)              # ragged windows run eagerly: a host read is allowed here
         return (mask / n_tot).reshape(-1).contiguous()
 
@@ -1227,8 +1241,11 @@ class RnnNade(RnnEstimator):
             rw_g = rw_m if (self.grad_scale == 1.0 and not torch.is_tensor(ls)) else rw_m * ls * self.grad_scale
             if torch.is_tensor(ls):
                 ls = compact["hdr_f"][3:4]               # what _unscale multiplies by
+        elif train and self._n_valid is None and self.dtype == torch.float16:     # ragged_on_device without compaction: the device-side scale
+            rw_g = rw_m * (self._ls_dev * self.grad_scale)
+            ls = 1.0 / self._ls_dev
         else:
-            ls = self._stack.loss_scale(self._n_valid) if train else 1.0
+            ls = self._stack.loss_scale(self._n_valid) if (train and self._n_valid is not None) else 1.0
             gs = self.grad_scale * ls
             rw_g = rw_m if gs == 1.0 else rw_m * gs
         if self._nade_mfma():
@@ -1622,7 +1639,7 @@ class RnnRBM(RnnEstimator):
             loss = torch.zeros(1, device=dev)
             ops.weighted_sum(cost, rw, loss)
             self._ctx = dict(y=yy, lstm=ctx, out=out, tgt=tgt, v_s=v_s, rw=rw, kp=kp, seed=seed, B=B, T=T, bh_u=bh_u, bv_u=bv_u,
-                             n_valid=self._n_valid, sv=sv, ss=ss)
+                             n_valid=self._n_valid, ls_dev=self._ls_dev if self._n_valid is None else None, sv=sv, ss=ss)
             self._cost_tm, self._F_tm, self._pv_tm, self._vs_tm, self._loss = cost, Fv, p_v, v_s, loss
             self._lengths, self._flat_idx = lengths, None
             self._recon_tm = torch.empty(N, device=dev)
@@ -1669,8 +1686,13 @@ class RnnRBM(RnnEstimator):
         # Dense-output-shaped gradient block and the two scaled hidden blocks of d cost / d W = v_s^T (w ss) - v^T (w sv)
         d_out = torch.empty((N, self.ldo), device=dev)
         pos = torch.empty((N, Hn), device=dev); neg = torch.empty((N, Hn), device=dev)
-        ls = self._stack.loss_scale(cx["n_valid"])
-        ops.rbm_cd_rows(cx["tgt"], cx["v_s"], sv, ss, cx["rw"], self.grad_scale * ls, d_out, pos, neg)
+        if cx["n_valid"] is None:                    # ragged_on_device: the scale is a device scalar (folded into the row weights); _unscale gets its inverse
+            lsd = cx.get("ls_dev")
+            ops.rbm_cd_rows(cx["tgt"], cx["v_s"], sv, ss, cx["rw"] if lsd is None else cx["rw"] * lsd, self.grad_scale, d_out, pos, neg)
+            ls = 1.0 if lsd is None else 1.0 / lsd
+        else:
+            ls = self._stack.loss_scale(cx["n_valid"])
+            ops.rbm_cd_rows(cx["tgt"], cx["v_s"], sv, ss, cx["rw"], self.grad_scale * ls, d_out, pos, neg)
         # d cost / d W = v_s^T pos + v^T neg, [D, N] . [N, Hn] with K = N rows.  16-bit modes: the operands in the compute type (v, v_s are 0 / 1:
         # exact; pos / neg are loss-scaled products of a weight and a sigmoid) on the LDS-DMA GEMM -- as f32 products on v_mfma_f32_32x32x2_f32
         # (1/16 of the 16-bit rate) the two GEMMs were 0.53 ms per track of the 3.6 ms jamming step (round 4 profile); fp32 mode keeps f32.

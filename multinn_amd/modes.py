@@ -407,38 +407,52 @@ class MultINNCore(Model):
         fl = getattr(self, "_feedback_layer", None)
         return out + ([fl.store] if fl is not None else [])
 
-    def graphed_train_step(self, x, optimizer, lr=None, warmup=2):
-        """`train_step` on full-length batches as ONE hipGraph replay (single rank): encoders, every generator's build and backward, the
-        feedback module and the joint clipped step -- eagerly a mode's step is host-bound (five generators: ~200 launches and the Python
-        between them).  Step-dependent values (dropout / Gibbs seeds, Adam's step) are read from each store's device-side counter, so every
-        replay is the next step.  Returns run(x=None) -> loss."""
+    def graphed_train_step(self, x, optimizer, lr=None, warmup=2, lengths=None):
+        """`train_step` as ONE hipGraph replay (single rank): encoders, every generator's build and backward, the feedback module and the joint
+        clipped step -- eagerly a mode's step is host-bound (five generators: ~200 launches and the Python between them).  Step-dependent
+        values (dropout / Gibbs seeds, Adam's step) are read from each store's device-side counter, so every replay is the next step.
+        lengths (int32 [B], optional): capture the RAGGED step; the graph holds a static copy of the lengths and everything derived from them
+        (row weights, valid-row counts, f16 loss scales, the compaction of the NADE generators' rows) is computed on the device inside the graph
+        (`RnnEstimator.ragged_on_device`), so one capture serves every later `run(x, lengths)`.  Returns run(x=None, lengths=None) -> loss."""
         from .training import dp_active
         if dp_active():
             raise NotImplementedError("graphed_train_step of a mode is single-rank (the generators' own captured steps handle data parallelism)")
         sx = x.clone()
+        ragged = lengths is not None
+        sl = lengths.to(device=x.device, dtype=torch.int32).clone() if ragged else None
+        if ragged:
+            for g in self._generators:
+                g.ragged_on_device = True
         cur, side = torch.cuda.current_stream(), torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            for _ in range(max(int(warmup), 1)):        # >= 1: variables, persistent-kernel attributes and workspaces exist before the capture
-                self.train_step(sx, None, optimizer, lr)
+            # warm-up steps are REAL optimiser steps: variables, persistent-kernel attributes and workspaces must exist before the capture.
+            # warmup = 0 is for a caller that has just run this very step eagerly (driver._captured_step: the capture then executes nothing)
+            for _ in range(int(warmup)):
+                self.train_step(sx, sl, optimizer, lr)
         cur.wait_stream(side)
         for g in self._generators:
             g._packed_step = -1
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            loss = self.train_step(sx, None, optimizer, lr)
+            loss = self.train_step(sx, sl, optimizer, lr)
         stores = self._all_stores()
         for st in stores:
             st.step -= 1                                # the captured step has not executed (host mirror of step_dev)
 
-        def run(x=None):
+        def run(x=None, lengths=None):
             if x is not None:
                 sx.copy_(x)
+            if lengths is not None:
+                if not ragged:
+                    raise ValueError("this step was captured for full-length windows: capture it with lengths= to feed ragged ones")
+                sl.copy_(lengths.to(device=sx.device, dtype=torch.int32))
             graph.replay()
             for st in stores:
                 st.step += 1
             return loss
         run.graph = graph
+        run.ragged = ragged
         return run
 
     def build_pianoroll(self, x, lengths=None, is_train=False, mode="eval"):

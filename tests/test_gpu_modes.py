@@ -576,3 +576,83 @@ def test_load_encoders_finds_another_mode_class_checkpoint_and_restores_weights_
     assert b.name != a.name and b.load_encoders(None, str(tmp_path)) is True
     for ea, eb in zip(a.encoders, b.encoders):
         assert torch.equal(ea.store.theta, eb.store.theta) and float(eb.store.m.abs().max()) == 0.0 and int(eb.store.step_dev) == 0
+
+
+@pytest.mark.parametrize("mode,gen,enc,enc_hidden", [("jamming", "RBM", "Pass", None), ("composer", "NADE", "DBN", [12, 8]), ("jamming", "NADE", "Pass", None)])
+def test_mode_ragged_step_is_captured_once_for_any_lengths(mode, gen, enc, enc_hidden):
+    """MultINNCore.graphed_train_step(lengths=...): ONE captured hipGraph of a mode's train step -- encoders, every generator's build and
+    backward, the joint clipped step -- serves every later (x, lengths): row weights, valid-row counts, the f16 loss scale and (NADE generators)
+    the compaction of the rows are derived on the device inside the graph (`RnnEstimator.ragged_on_device`).  Three replays on different
+    length vectors (one full-length, one nearly empty) against eager steps of a twin model on the same data: the same losses and weights."""
+    from multinn_amd import MultINN, AdamOptimizer
+    B, T, P = 32, 8, 8
+    tracks = TRACKS5[:3]
+    rng = np.random.default_rng(4)
+    xs = [dev(batch(B, T, P, len(tracks), 30 + i, rho=0.15)) for i in range(3)]
+    lens = [rng.integers(1, T + 2, B).astype(np.int32), np.full(B, T + 1, np.int32), np.ones(B, np.int32)]
+    lens[2][0] = 4
+
+    def model():
+        m = MultINN(config(P, tracks), params(mode, enc=enc, enc_hidden=enc_hidden, gen=gen, Hn=256, units=(128, 128)), mode=mode, precision="fp16", seed=23)
+        return m, AdamOptimizer(0.01)
+
+    (a, oa), (b, ob) = model(), model()
+    b.train_step(xs[0], dev(lens[0]), ob)                       # materialises the twin (its weights are copied from a below)
+    a.train_step(xs[0], dev(lens[0]), oa)
+    for ga, gb in zip(a.generators, b.generators):
+        gb.store.theta.copy_(ga.store.theta); gb.store.m.copy_(ga.store.m); gb.store.v.copy_(ga.store.v)
+        gb.store.step = ga.store.step
+        gb.store.step_dev.copy_(ga.store.step_dev)
+        gb._packed_step = -1
+    for ea, eb in zip(a.encoders, b.encoders):
+        if getattr(ea, "store", None) is not None and ea.store.theta is not None:
+            eb.store.theta.copy_(ea.store.theta)
+    run = a.graphed_train_step(xs[0], oa, warmup=1, lengths=dev(lens[0]))
+    assert run.ragged
+    for ga, gb in zip(a.generators, b.generators):             # the capture's warm-up step ran on a: replay it on the twin
+        pass
+    b.train_step(xs[0], dev(lens[0]), ob)
+    for x, ln in zip(xs, lens):
+        la = float(run(x, dev(ln)))
+        lb = float(b.train_step(x, dev(ln), ob))
+        assert abs(la - lb) < 2e-3 * max(1.0, abs(lb)), (la, lb)
+    a.check()
+    b.check()
+    for ga, gb in zip(a.generators, b.generators):
+        assert float((ga.store.theta - gb.store.theta).abs().max()) < 5e-3
+
+
+def test_driver_epoch_replays_captured_mode_steps(monkeypatch):
+    """driver.train_epoch on a MODE class (jamming: three LSTM-RBM generators): windows of a recurring shape -- full-length and ragged -- run as
+    replays of the mode's captured step (captured at the shape's second occurrence with warmup = 0, so nothing extra executes): the loss
+    trajectory of two epochs is the eager loop's (MULTINN_TRAIN_GRAPH=0)."""
+    from multinn_amd import MultINN, AdamOptimizer
+    from multinn_amd.driver import train_epoch, LossAccumulator, TrainingStats
+    R = np.random.default_rng(6)
+    P, tracks = 8, TRACKS5[:3]
+    X = (R.random((16, 12, P, len(tracks))) < .2).astype(np.uint8)
+    lengths = np.full(16, 12)
+    lengths[3] = 7
+    ids = np.arange(16)
+
+    def epoch_losses(graph):
+        if not graph:
+            monkeypatch.setenv("MULTINN_TRAIN_GRAPH", "0")
+        m = MultINN(config(P, tracks), params("jamming", gen="RBM", Hn=32, units=(128, 128)), mode="jamming", precision="fp16", seed=23)
+        opt = AdamOptimizer(0.01)
+        out = []
+        for _ in range(3):
+            acc = LossAccumulator()
+            train_epoch(m, X, lengths, ids, 8, 4, opt, acc, TrainingStats(), lr=0.01, device=DEV)
+            out.append(acc.loss())
+        if not graph:
+            monkeypatch.delenv("MULTINN_TRAIN_GRAPH")
+        m.check()
+        return out, m
+
+    lg, mg = epoch_losses(True)
+    le, me = epoch_losses(False)
+    keys = list(mg.__dict__.get("_step_graphs", {}))
+    assert any(k[-1] == "ragged" for k in keys) and any(k[-1] == "full" for k in keys), keys
+    assert "_step_graphs" not in me.__dict__
+    assert np.allclose(lg, le, rtol=2e-2), (lg, le)
