@@ -43,7 +43,7 @@ enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_ST
 
 /* ABI version of THIS header: bumped whenever a signature or a descriptor struct changes.  mnn_version() returns the value the library
  * was built with; a loader must compare the two before its first call (multinn_amd/_lib.py load() does) -- a library built for another
- * version reads garbage arguments without any diagnosis otherwise.  117 (round 6): + mnn_lstm_cluster_bwd_ok, + mnn_ragged_index / mnn_rows_gather16 / mnn_rows_scatter_f32, `n_rows_dev` on the gated NADE forwards and mnn_nade_logprob_bwd, `inv` / `hdr` on mnn_pianoroll_shift_timemajor_t, + mnn_lstm_resident_{fwd,bwd}_multi / mnn_lstm_cluster_{fwd,bwd}_multi / _bwd_multi_ok.  116: + mnn_lstm_cluster_ok / _fwd / _bwd.  115: mnn_step_increment gained `sumsq`, `clip_norm`.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
+ * version reads garbage arguments without any diagnosis otherwise.  117 (round 6): + mnn_lstm_cluster_bwd_ok, + mnn_ragged_index / mnn_rows_gather16 / mnn_rows_scatter_f32, `n_rows_dev` on the gated NADE forwards and mnn_nade_logprob_bwd, `inv` / `hdr` on mnn_pianoroll_shift_timemajor_t, + mnn_lstm_resident_{fwd,bwd}_multi / mnn_lstm_cluster_{fwd,bwd}_multi / _bwd_multi_ok, `unsafe` on mnn_nade_logprob_fwd_gated, `unsafe` on mnn_nade_logprob_bwd.  116: + mnn_lstm_cluster_ok / _fwd / _bwd.  115: mnn_step_increment gained `sumsq`, `clip_norm`.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
  * mnn_pianoroll_shift_timemajor_t / mnn_grad_rows_fanout and the `f16` descriptor fields of round 3 are part of it. */
 #define MNN_ABI_VERSION 117
 int mnn_version(void);
@@ -318,7 +318,10 @@ int mnn_density_gate(mnn_stream_t s, const uint8_t* v, long n, long threshold, i
 int mnn_nade_logprob_fwd_gated(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* row_weight,
                                float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if,
-                               const int* n_rows_dev /* optional: see mnn_ragged_index */);
+                               const int* n_rows_dev /* optional: see mnn_ragged_index */,
+                               int* unsafe /* optional int32[1]: cleared by this entry point, then counted up by every wave of the multiplicative
+                                              form (below) a row of which passed |a| = 40 (and once by any other form or a gated-out launch) -- 0 is
+                                              mnn_nade_logprob_bwd's licence to carry exp(-a) */);
 int mnn_nade_logprob_fwd_mfma_gated(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride, const float* bias,
                                     int ld_bias, const float* w_enc, const void* w_dec_bf16, const float* row_weight, float* nll, float* cond_p,
                                     float* d_bias, float* a_final, const int* gate, int run_if, const int* n_rows_dev);
@@ -353,7 +356,11 @@ int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const
                          float* nll, float* cond_p, float* d_bias, float* a_final);
 int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                          const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* a_final,
-                         float* d_bias, float* d_w_enc, float* d_w_dec, const int* n_rows_dev /* optional: see mnn_ragged_index */);
+                         float* d_bias, float* d_w_enc, float* d_w_dec, const int* n_rows_dev /* optional: see mnn_ragged_index */,
+                         const int* unsafe /* optional: the counter the forward's density-gated dense launch left (mnn_nade_logprob_fwd_gated).
+                                              0 = a dense batch every row of which the forward's multiplicative form vouched for: the reverse scan
+                                              then advances exp(-a) multiplicatively like the dense forward (no exponential per flip); both
+                                              instantiations are launched, one leaves at once.  NULL: the direct form */);
 int mnn_nade_sample(mnn_stream_t s, int tracks, int N, int D, int Hn, const float* bias, int ld_bias, const float* w_enc,
                     const float* w_dec, float temperature, uint64_t seed, uint32_t row0, uint32_t sub, uint8_t* samples,
                     long s_track_stride, int s_row_stride, int s_elem_stride, float* nll);

@@ -39,7 +39,7 @@ SIGNATURES = {
     "mnn_dropout_fwd": (_i, [_p, _i, _p, _p, _i, _i, _i, _f, _u64, _p, _u32, _i, _i]),
     "mnn_dropout_bwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _u64, _p, _u32, _i, _i, _i]),
     "mnn_nade_logprob_fwd": (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
-    "mnn_nade_logprob_bwd": (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "mnn_nade_logprob_bwd": (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "mnn_nade_sample": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _f, _u64, _u32, _u32, _p, _l, _i, _i, _p]),
     "mnn_rbm_workspace_bytes": (_sz, [_i, _i]),
     "mnn_rbm_gibbs": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _u64, _u32, _p, _u32, _p, _p, _p]),
@@ -124,7 +124,7 @@ SIGNATURES["mnn_lstm_cluster_bwd"] = (_i, [_p, _i, _i, C.POINTER(LstmBwdLayer), 
 SIGNATURES["mnn_nade_mfma_ok"] = (_i, [_i])
 SIGNATURES["mnn_nade_logprob_fwd_mfma"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p])
 SIGNATURES["mnn_density_gate"] = (_i, [_p, _p, _l, _l, _p, _p])
-SIGNATURES["mnn_nade_logprob_fwd_gated"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p])
+SIGNATURES["mnn_nade_logprob_fwd_gated"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p])
 SIGNATURES["mnn_nade_logprob_fwd_mfma_gated"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p])
 SIGNATURES["mnn_nade_logprob_fwd_mfma_f32"] = (_i, [_p, _i, _i, _i, _i, _p, _l, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p])
 SIGNATURES["mnn_nade_f32_pack"] = (_i, [_p, _p, _l, _i, _p])

@@ -122,10 +122,13 @@ __global__ void __launch_bounds__(512)
 nade_fwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias,
                 int ld_bias, const float* __restrict__ w_enc, const float* __restrict__ w_dec, const float* __restrict__ row_weight,
                 float* __restrict__ nll, float* __restrict__ cond_p, float* __restrict__ d_bias, float* __restrict__ a_final,
-                const int* __restrict__ gate, int run_if, const int* __restrict__ n_rows_dev) {
+                const int* __restrict__ gate, int run_if, const int* __restrict__ n_rows_dev, int* __restrict__ unsafe) {
     constexpr int W = HQ * 64;
     __shared__ float wl[2][2][8 * W];            // [buffer][w_dec | w_enc][visible-in-chunk][hidden]
-    if (gate != nullptr && *gate != run_if) return;     // density-gated pair of launches (mnn_nade_logprob_fwd_gated): uniform exit
+    if (gate != nullptr && *gate != run_if) {           // density-gated pair of launches (mnn_nade_logprob_fwd_gated): uniform exit
+        if (unsafe != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(unsafe, 1);      // not run = not vouched for
+        return;
+    }
     const int m = blockIdx.y;
     if (nade_rows_beyond(n_rows_dev, blockIdx.x * 64)) {                  // compacted ragged batch: all 64 rows are padding
         nade_zero_rows(d_bias, ld_bias, tracks * Hn + m * D, D, blockIdx.x * 64, 64, N, 512);
@@ -156,6 +159,7 @@ nade_fwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
         }
     float u[UT ? FWD_R : 1][UT ? HQ : 1];                // exp(-a), advanced by one multiply per flip (UT)
     float amax = 0.f;                                    // running max of |a| over this lane's states since the last re-derivation
+    bool passed40 = false;                               // ... and whether it ever passed the bound (the backward's licence to drop `a`: *unsafe)
     if constexpr (UT) {
 #pragma unroll
         for (int r = 0; r < FWD_R; ++r)
@@ -225,6 +229,7 @@ nade_fwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
                 }
                 if (any && __any(amax > 40.0f)) {                                  // rare: re-derive every u from its exact a (see the header)
                     amax = 0.f;
+                    passed40 = true;
 #pragma unroll
                     for (int r = 0; r < FWD_R; ++r)
 #pragma unroll
@@ -285,18 +290,26 @@ nade_fwd_kernel(int tracks, int N, int D, int Hn, const uint8_t* __restrict__ v,
                 if (row < N && j < Hn) a_final[((size_t)m * N + row) * Hn + j] = a[r][q];
             }
     }
+    // *unsafe counts the waves a pre-activation of which (any row, any hidden unit, any point of the scan) passed |a| = 40; zero (the entry point
+    // clears it before the launch) licenses the backward scan, which walks the same values in reverse, to carry exp(-a) instead of a
+    // (nade_bwd_kernel<.., USEU>).  Only the multiplicative form tracks the bound: the direct form, and a gated-out launch, count themselves once.
+    if (unsafe != nullptr) {
+        const bool ok = UT ? !__any(passed40 || amax > 40.0f) : !(blockIdx.x == 0 && blockIdx.y == 0 && w == 0);
+        if (!ok && lane == 0) atomicAdd(unsafe, 1);
+    }
 }
 
 extern "C" int mnn_nade_logprob_fwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                     const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* row_weight,
                                     float* nll, float* cond_p, float* d_bias, float* a_final) {
     return mnn_nade_logprob_fwd_gated(s, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, w_dec, row_weight, nll, cond_p, d_bias, a_final,
-                                      nullptr, 0, nullptr);
+                                      nullptr, 0, nullptr, nullptr);
 }
 
 extern "C" int mnn_nade_logprob_fwd_gated(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                           const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* row_weight,
-                                          float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if, const int* n_rows_dev) {
+                                          float* nll, float* cond_p, float* d_bias, float* a_final, const int* gate, int run_if, const int* n_rows_dev,
+                                          int* unsafe) {
     MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn > 0 && Hn <= 256, "mnn_nade_logprob_fwd: need tracks,N,D>0 and 0<Hn<=256 (Hn=%d)", Hn);
     MNN_REQUIRE(v && bias && w_enc && w_dec, "mnn_nade_logprob_fwd: null pointer");
     MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_logprob_fwd: ld_bias %d < tracks*(Hn+D)", ld_bias);
@@ -306,7 +319,8 @@ extern "C" int mnn_nade_logprob_fwd_gated(mnn_stream_t s, int tracks, int N, int
     // the density-gated DENSE launch of the 16-bit modes (gate given, run_if = 1) advances the hidden states multiplicatively (UT); every other
     // caller -- the f32 parity mode, conditionals on demand, Hn <= 128 -- keeps the direct sigmoid
 #define FWD(HQ, UT) hipLaunchKernelGGL((nade_fwd_kernel<HQ, UT>), grid, dim3(512), 0, st, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, \
-                                       w_dec, row_weight, nll, cond_p, d_bias, a_final, gate, run_if, n_rows_dev)
+                                       w_dec, row_weight, nll, cond_p, d_bias, a_final, gate, run_if, n_rows_dev, unsafe)
+    if (unsafe != nullptr) MNN_HIP(hipMemsetAsync(unsafe, 0, sizeof(int), st));      // counted by the launch below
     static const bool no_ut = getenv("MNN_NADE_FWD_NO_UT") != nullptr;          // (tests: the direct form as the comparison partner)
     if (Hn <= 64) FWD(1, false);
     else if (Hn <= 128) FWD(2, false);
@@ -369,13 +383,17 @@ __device__ __forceinline__ void bwd_lstore(const WStage<HQ>& st, float* __restri
 
 // RG = groups of 8 rows per wave (rows per workgroup: 64 RG).  RG = 2 halves the f32 atomics per row (one add per visible and hidden unit
 // per 128 rows) and the LDS reads / exchanges per FMA, at twice the state registers (HQ = 2: 4 x 16 x 2 = 128): two waves per SIMD.
-template <int HQ, int RG>
+// USEU: the multiplicative form of the state updates for DENSE batches (see `useu` below); chosen per LAUNCH by a device word (both instantiations
+// are launched, one leaves): as a per-wave choice inside one kernel the two flip paths cost 175 registers (one workgroup per CU: 3.1 -> 5.6 ms).
+template <int HQ, int RG, bool USEU>
 __global__ void __launch_bounds__(512)
 nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __restrict__ v, long v_track_stride, const float* __restrict__ bias,
                 int ld_bias, const float* __restrict__ w_enc, const float* __restrict__ w_dec, const float* __restrict__ a_final,
-                float* __restrict__ d_bias, float* __restrict__ d_w_enc, float* __restrict__ d_w_dec, const int* __restrict__ n_rows_dev) {
+                float* __restrict__ d_bias, float* __restrict__ d_w_enc, float* __restrict__ d_w_dec, const int* __restrict__ n_rows_dev,
+                const int* __restrict__ unsafe) {
     constexpr int W = HQ * 64;
     __shared__ __attribute__((aligned(16))) float wl[2][2][8 * W];
+    if (unsafe != nullptr && (*unsafe == 0) != USEU) return;                // the pair of launches of mnn_nade_logprob_bwd: uniform exit
     // [buffer][wave][visible-in-half-chunk][d w_dec | d w_enc][hidden]: one exchange per 4 visibles.  Two buffers where they fit beside a second
     // workgroup of the CU (HQ <= 2: 2 x 32 KB + 16 KB of weights = 80 KB): an exchange then needs ONE barrier (stores -> barrier -> sums; the next
     // exchange stores into the other buffer, and a wave gets there only through the barrier every wave reaches after its previous sums), and
@@ -405,6 +423,11 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
     // Sparsity (exact): `a` only changes at visibles with v = 1 (nade.py:219), so h = sigmoid(a) is cached
     // and recomputed only there, and sum_i dl_i * w_dec[i] is accumulated per constant-h segment (c) and
     // folded into G with ONE h(1-h) factor when the segment ends.  a_D comes from the forward kernel.
+    // USEU (dense batches whose every row the forward's multiplicative form vouched for -- |a| <= 40 throughout: *unsafe == 0): the state
+    // register of a (row, unit) carries u = exp(-a) instead of a -- a flip is u *= exp(+w_enc[i]) (one exponential per (visible, unit) for all the
+    // rows that flip there), h = 1 / (1 + u): mul + add + rcp instead of sub + mul + exp + add + rcp.  The scan revisits the forward's
+    // pre-activations in reverse, so u stays in f32 range and nothing needs `a` itself.
+    constexpr bool useu = USEU;
     float a[BWD_R][HQ], h[BWD_R][HQ], c[BWD_R][HQ], G[BWD_R][HQ];
     // all a_D loads in flight together (unconditional, clamped row / hidden unit), masked afterwards: behind `valid ? load : 0` each load
     // waited for its own round trip (s_waitcnt vmcnt(0) per element at the start of every workgroup)
@@ -420,6 +443,7 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
             const int j = lane + 64 * q, row = rbase + r;
             if (!(row < Nv && j < Hn)) a[r][q] = 0.f;           // (rows behind a compacted batch's valid ones: a_final was never written for them)
             h[r][q] = fast_sigmoid(a[r][q]);
+            if constexpr (useu) a[r][q] = fast_exp2(-MNN_LOG2E * a[r][q]);   // the register now carries u = exp(-a)
             G[r][q] = 0.f;
             c[r][q] = 0.f;
         }
@@ -489,16 +513,35 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
                 // the rows are independent: first the (rare) state changes of the rows with v_i = 1 -- skipped with ONE scalar test when
                 // none of the wave's 8 rows has one (4 visibles in 5 at rho = 0.03) --, then the FMAs of all 8 rows, straight-line
                 if ((many & (0x0101010101010101ull << ii)) != 0ull) {
+                    if constexpr (useu) {
+                        float ewv[HQ];
 #pragma unroll
-                    for (int r = 0; r < BWD_R; ++r) {
-                        if ((mask[r >> 3] >> ((r & 7) * 8 + ii)) & 1ull) {
+                        for (int q = 0; q < HQ; ++q) ewv[q] = fast_exp2(MNN_LOG2E * wev[q]);          // exp(+w_enc[i]): once for every row that flips here
 #pragma unroll
-                            for (int q = 0; q < HQ; ++q) {
-                                G[r][q] = fmaf(c[r][q], fmaf(-h[r][q], h[r][q], h[r][q]), G[r][q]);   // close the segment that used a_{i+1}
-                                c[r][q] = 0.f;
-                                acce[k][q] += G[r][q];       // d w_enc[i] += v_i * G_{i+1}
-                                a[r][q] -= wev[q];           // a_i = a_{i+1} - v_i * w_enc[i]
-                                h[r][q] = fast_sigmoid(a[r][q]);
+                        for (int r = 0; r < BWD_R; ++r) {
+                            if ((mask[r >> 3] >> ((r & 7) * 8 + ii)) & 1ull) {
+#pragma unroll
+                                for (int q = 0; q < HQ; ++q) {
+                                    G[r][q] = fmaf(c[r][q], fmaf(-h[r][q], h[r][q], h[r][q]), G[r][q]);
+                                    c[r][q] = 0.f;
+                                    acce[k][q] += G[r][q];
+                                    a[r][q] *= ewv[q];           // u_i = u_{i+1} exp(+w_enc[i])
+                                    h[r][q] = fast_rcp(1.0f + a[r][q]);
+                                }
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < BWD_R; ++r) {
+                            if ((mask[r >> 3] >> ((r & 7) * 8 + ii)) & 1ull) {
+#pragma unroll
+                                for (int q = 0; q < HQ; ++q) {
+                                    G[r][q] = fmaf(c[r][q], fmaf(-h[r][q], h[r][q], h[r][q]), G[r][q]);   // close the segment that used a_{i+1}
+                                    c[r][q] = 0.f;
+                                    acce[k][q] += G[r][q];       // d w_enc[i] += v_i * G_{i+1}
+                                    a[r][q] -= wev[q];           // a_i = a_{i+1} - v_i * w_enc[i]
+                                    h[r][q] = fast_sigmoid(a[r][q]);
+                                }
                             }
                         }
                     }
@@ -601,7 +644,7 @@ nade_bwd_kernel(int tracks, int N, int D, int HnT, int nslice, const uint8_t* __
 
 extern "C" int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, int Hn, const uint8_t* v, long v_track_stride,
                                     const float* bias, int ld_bias, const float* w_enc, const float* w_dec, const float* a_final,
-                                    float* d_bias, float* d_w_enc, float* d_w_dec, const int* n_rows_dev) {
+                                    float* d_bias, float* d_w_enc, float* d_w_dec, const int* n_rows_dev, const int* unsafe) {
     MNN_REQUIRE(tracks > 0 && N > 0 && D > 0 && Hn > 0 && Hn <= 256, "mnn_nade_logprob_bwd: need tracks,N,D>0 and 0<Hn<=256 (Hn=%d)", Hn);
     MNN_REQUIRE(v && bias && w_enc && w_dec && a_final && d_bias && d_w_enc && d_w_dec, "mnn_nade_logprob_bwd: null pointer");
     MNN_REQUIRE(ld_bias >= tracks * (Hn + D), "mnn_nade_logprob_bwd: ld_bias too small");
@@ -609,10 +652,15 @@ extern "C" int mnn_nade_logprob_bwd(mnn_stream_t s, int tracks, int N, int D, in
     // The backward scan is separable over hidden units, so a wide layer runs as 128-wide slices (HQ = 2: 116 VGPRs, 80 KB of LDS -> two
     // workgroups per CU).  Measured and removed in round 4 (never the default): one 256-wide workgroup (HQ = 4), 64-wide slices, and 128 rows
     // per workgroup (two row groups per wave: 4.98 vs 3.94 ms at [1024,256,88,5] -- 187 registers leave two waves per SIMD instead of four).
-#define BWD(HQ, NS) hipLaunchKernelGGL((nade_bwd_kernel<HQ, 1>), dim3(cdiv(N, 64), tracks * (NS)), dim3(512), 0, st, tracks, N, D, Hn, NS, v, \
-                                       v_track_stride, bias, ld_bias, w_enc, w_dec, a_final, d_bias, d_w_enc, d_w_dec, n_rows_dev)
-    if (Hn <= 64) BWD(1, 1);
-    else BWD(2, cdiv(Hn, 128));
+    // unsafe (the counter the forward's density-gated dense launch left: mnn_nade_logprob_fwd_gated): 0 -> the multiplicative instantiation;
+    // both are launched and the one the word does not pick leaves at its first instruction (NULL: the direct form only)
+#define BWD(HQ, NS, U, S) hipLaunchKernelGGL((nade_bwd_kernel<HQ, 1, U>), dim3(cdiv(N, 64), tracks * (NS)), dim3(512), 0, st, tracks, N, D, Hn, NS, v, \
+                                             v_track_stride, bias, ld_bias, w_enc, w_dec, a_final, d_bias, d_w_enc, d_w_dec, n_rows_dev, S)
+    if (Hn <= 64) BWD(1, 1, false, nullptr);
+    else {
+        if (unsafe != nullptr) BWD(2, cdiv(Hn, 128), true, unsafe);
+        BWD(2, cdiv(Hn, 128), false, unsafe);
+    }
 #undef BWD
     MNN_LAUNCH_CHECK();
     return MNN_OK;

@@ -1070,7 +1070,7 @@ class RnnNade(RnnEstimator):
 
     nade_dense_above = float(os.environ.get("MULTINN_NADE_DENSE_ABOVE", "0.07"))   # density above which the f32 scan replaces the matrix-core form
 
-    def _nade_fwd(self, v, out, rw, nll, cond_p, d_out, a_fin, n_rows_dev=None):
+    def _nade_fwd(self, v, out, rw, nll, cond_p, d_out, a_fin, n_rows_dev=None, unsafe=None):
         M, D, Hn = self.num_tracks, self.num_dims, self.num_hidden[-1]
         exact = self._nade_exact()
         if self.nade_dense_above >= 1.0:                 # gate off: always the matrix-core form
@@ -1081,7 +1081,7 @@ class RnnNade(RnnEstimator):
         counted = bool(getattr(self, "_v_counted", False)) and rw is not None      # (the on-demand conditionals pass of a train build runs later: not counted)
         return ops.nade_logprob_fwd_auto(v, out, self.store["nade/w_enc"], self.store["nade/w_dec"], self._wdec_bf, M, D, Hn, self._gate[:1],
                                          self._gate[1:], self.nade_dense_above, rw, nll, cond_p, d_out, a_fin, exact=exact, counted=counted,
-                                         n_rows_dev=n_rows_dev)
+                                         n_rows_dev=n_rows_dev, unsafe=unsafe)
 
     # fp16 mode: the split-operand matrix-core scan (nade_mfma.hip, SPLIT: f16 hi + lo pairs, three 16-bit MFMA products) or the f32 vector scan
     nade_exact = os.environ.get("MULTINN_NADE_EXACT_MFMA", "1") != "0"
@@ -1251,7 +1251,9 @@ class RnnNade(RnnEstimator):
         if self._nade_mfma():
             # bf16 compute mode: the decoder dot products run as a block-sparse bf16 GEMM over each row's hidden states while the batch is
             # piano-roll-sparse; a dense batch takes the f32 vector form (decided on the device, per launch: ops.nade_logprob_fwd_auto)
-            self._nade_fwd(v.view(M, N, D), out, rw_g if train else None, nll, cond_p, d_out, a_fin, n_rows_dev=nrows)
+            # (train, density gate in use: the dense forward also counts the waves that left |a| <= 40 -- none = the dense backward's licence, see ops.nade_logprob_bwd)
+            unsafe = torch.empty(1, device=dev, dtype=torch.int32) if (train and self.nade_dense_above < 1.0) else None
+            self._nade_fwd(v.view(M, N, D), out, rw_g if train else None, nll, cond_p, d_out, a_fin, n_rows_dev=nrows, unsafe=unsafe)
         else:
             assert compact is None or Hn <= 256, "compacted rows: the f32 scan covers Hn <= 256"
             ops.nade_logprob_fwd(v.view(M, N, D), out, self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn,
@@ -1259,7 +1261,7 @@ class RnnNade(RnnEstimator):
         loss = torch.zeros(1, device=dev)
         ops.weighted_sum(nll.view(-1), rw_m.repeat(M) if M > 1 else rw_m, loss)      # statistical.py:34 / rnn_multinade.py:202-203
         self._ctx = dict(x_tm=x_tm, v=v, rw=rw_m, y=y, lstm=ctx, out=out, d_out=d_out, a_fin=a_fin, kp=kp, seed=self.seed, B=B, T=T, ls=ls,
-                         compact=compact)
+                         compact=compact, unsafe=unsafe if self._nade_mfma() else None)
         self._nll_tm, self._cond_tm, self._loss = nll, cond_p, loss
         self._flat_idx = None
         self._lengths = lengths
@@ -1324,7 +1326,8 @@ class RnnNade(RnnEstimator):
         d_out = cx["d_out"]
         compact = cx.get("compact")
         ops.nade_logprob_bwd(cx["v"].view(M, N, D), cx["out"], self.store["nade/w_enc"], self.store["nade/w_dec"], M, D, Hn, cx["a_fin"],
-                             d_out, g["nade/w_enc"], g["nade/w_dec"], n_rows_dev=compact["hdr"] if compact else None)
+                             d_out, g["nade/w_enc"], g["nade/w_dec"], n_rows_dev=compact["hdr"] if compact else None,
+                             unsafe=cx.get("unsafe"))
         # dense: dK[R,n_out] = y^T d_out ; db = sum d_out ; dy = d_out K^T
         Np = ops.round_up(N, 64)
         zalloc = torch.zeros if Np != N else torch.empty

@@ -505,7 +505,7 @@ def _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec):
 
 
 def nade_logprob_fwd(v, bias, w_enc, w_dec, tracks, D, Hn, row_weight=None, nll=None, cond_p=None, d_bias=None, a_final=None, n_rows_dev=None,
-                     gate=None, run_if=0):
+                     gate=None, run_if=0, unsafe=None):
     N = bias.shape[0]
     _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)
     if nll is not None:
@@ -519,9 +519,10 @@ def nade_logprob_fwd(v, bias, w_enc, w_dec, tracks, D, Hn, row_weight=None, nll=
         _req(row_weight.dtype == torch.float32 and row_weight.numel() == N, "nade: row_weight f32 [N]")
     if a_final is not None:
         _req(a_final.dtype == torch.float32 and a_final.numel() == tracks * N * Hn and a_final.is_contiguous(), "nade: a_final f32 [tracks,N,Hn]")
-    if n_rows_dev is not None or gate is not None:   # compacted ragged batch / a density-gated launch: the gated entry point (gate NULL: always runs)
+    _req(unsafe is None or (unsafe.dtype == torch.int32 and unsafe.numel() == 1), "nade: unsafe int32[1]")
+    if n_rows_dev is not None or gate is not None or unsafe is not None:   # compacted ragged batch / a density-gated launch: the gated entry point (gate NULL: always runs)
         call("mnn_nade_logprob_fwd_gated", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
-             _ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final), _ptr(gate), int(run_if), _ptr(n_rows_dev))
+             _ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final), _ptr(gate), int(run_if), _ptr(n_rows_dev), _ptr(unsafe))
         return
     call("mnn_nade_logprob_fwd", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
          _ptr(row_weight), _ptr(nll), _ptr(cond_p), _ptr(d_bias), _ptr(a_final))
@@ -564,7 +565,7 @@ def nade_f32_pack(w_dec, out):
 
 
 def nade_logprob_fwd_auto(v, bias, w_enc, w_dec, w_dec_bf, tracks, D, Hn, gate, count, dense_above=0.07, row_weight=None, nll=None,
-                          cond_p=None, d_bias=None, a_final=None, exact=False, counted=False, n_rows_dev=None):
+                          cond_p=None, d_bias=None, a_final=None, exact=False, counted=False, n_rows_dev=None, unsafe=None):
     """16-bit compute modes (exact=True: the split-operand hi + lo form of fp16 mode): the matrix-core form of the scan when at most `dense_above` of the cells of v are active, the f32 vector
     form otherwise; decided on the device (mnn_density_gate), both launches issued (one returns at once).  gate int32[1], count: a zeroed
     int32[1] scratch word (left zero)."""
@@ -591,10 +592,15 @@ def nade_logprob_fwd_auto(v, bias, w_enc, w_dec, w_dec_bf, tracks, D, Hn, gate, 
     # counted: `count` already holds the set cells of v (the piano-roll pass counted them while writing v): only the decision kernel runs
     call("mnn_density_gate", _stream(), None if counted else _ptr(v), v.numel(), int(dense_above * v.numel()), _ptr(gate), _ptr(count))
     call(mfma, _stream(), *common, _ptr(w_dec_bf), *tail, 0, nr)
-    call("mnn_nade_logprob_fwd_gated", _stream(), *common, _ptr(w_dec), *tail, 1, nr)
+    _req(unsafe is None or (unsafe.dtype == torch.int32 and unsafe.numel() == 1), "nade auto: unsafe int32[1]")
+    call("mnn_nade_logprob_fwd_gated", _stream(), *common, _ptr(w_dec), *tail, 1, nr, _ptr(unsafe))
 
 
-def nade_logprob_bwd(v, bias, w_enc, w_dec, tracks, D, Hn, a_final, d_bias, d_w_enc, d_w_dec, n_rows_dev=None):
+def nade_logprob_bwd(v, bias, w_enc, w_dec, tracks, D, Hn, a_final, d_bias, d_w_enc, d_w_dec, n_rows_dev=None, unsafe=None):
+    """unsafe (int32[1]): the counter the forward's density-gated dense launch left (nade_logprob_fwd_auto / nade_logprob_fwd) -- 0 (the dense
+    form ran and no wave passed |a| = 40): the scan advances exp(-a) multiplicatively (no exponential per flip; decided on the device, both
+    instantiations launched); None: the direct form."""
+    _req(unsafe is None or (unsafe.dtype == torch.int32 and unsafe.numel() == 1), "nade bwd: unsafe int32[1]")
     N = bias.shape[0]
     _nade_check(tracks, N, D, Hn, v, bias, w_enc, w_dec)
     _req(d_bias.shape == bias.shape and d_bias.stride() == bias.stride() and d_bias.dtype == torch.float32, "nade bwd: d_bias")
@@ -602,7 +608,7 @@ def nade_logprob_bwd(v, bias, w_enc, w_dec, tracks, D, Hn, a_final, d_bias, d_w_
         _req(w.dtype == torch.float32 and w.is_contiguous() and w.numel() == tracks * D * Hn, "nade bwd: grad weights f32 [tracks,D,Hn]")
     _req(a_final.dtype == torch.float32 and a_final.numel() == tracks * N * Hn and a_final.is_contiguous(), "nade bwd: a_final f32 [tracks,N,Hn]")
     call("mnn_nade_logprob_bwd", _stream(), tracks, N, D, Hn, _ptr(v), N * D, _ptr(bias), bias.stride(0), _ptr(w_enc), _ptr(w_dec),
-         _ptr(a_final), _ptr(d_bias), _ptr(d_w_enc), _ptr(d_w_dec), _ptr(n_rows_dev))
+         _ptr(a_final), _ptr(d_bias), _ptr(d_w_enc), _ptr(d_w_dec), _ptr(n_rows_dev), _ptr(unsafe))
 
 
 def nade_sample(bias, w_enc, w_dec, tracks, D, Hn, temperature, seed, row0, sub, samples, track_minor=False, nll=None):

@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
         long long z[16] = {0};
         CK(hipMemcpyToSymbol(HIP_SYMBOL(nb_trace), z, sizeof(z)));
         CK(hipEventRecord(e0));
-        if (mnn_nade_logprob_bwd(nullptr, 1, N, D, Hn, v, (long)N * D, bias, ld, we, wd, af, db, dwe, dwd, nullptr)) return 1;
+        if (mnn_nade_logprob_bwd(nullptr, 1, N, D, Hn, v, (long)N * D, bias, ld, we, wd, af, db, dwe, dwd, nullptr, nullptr)) return 1;
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(nb_trace), sizeof(z)));

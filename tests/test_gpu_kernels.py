@@ -969,6 +969,55 @@ def test_nade_dense_forward_multiplicative_states_vs_direct_form(ops, N, D, trac
     assert float(n2.abs().max()) == 0.0 and float(c2.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("N,D,tracks,rho,scale", [(512, 440, 1, 0.5, 1.0), (320, 84, 5, 0.5, 1.0), (256, 200, 1, 0.9, 1.0), (256, 440, 1, 0.5, 12.0), (300, 60, 1, 0.5, 1.0)])
+def test_nade_dense_backward_multiplicative_states_vs_direct_form(ops, N, D, tracks, rho, scale):
+    """The reverse scan on a DENSE batch: when the forward's density-gated dense launch ran and none of its waves passed |a| = 40 (it leaves a
+    zero in the `unsafe` counter), `mnn_nade_logprob_bwd(..., unsafe)` runs the instantiation that carries exp(-a) instead of a -- a flip is one
+    multiply by exp(+w_enc[i]) and a reciprocal -- against the direct form (no counter) on the same inputs: d w_enc, d w_dec, d b_enc.  scale 12:
+    the forward's guard trips, waves count themselves unsafe, the backward keeps its exact path (bit-identical to the direct form, summation
+    order of the atomics aside); N = 300: a ragged last wave; a gated-out forward launch (gate word 0, sparse) counts itself: direct path."""
+    Hn = 256
+    g = torch.Generator(device=DEV).manual_seed(13)
+    v = (torch.rand((tracks, N, D), device=DEV, generator=g) < rho).to(torch.uint8)
+    ld = (tracks * (Hn + D) + 63) // 64 * 64
+    bias = (torch.randn((N, ld), device=DEV, generator=g) * 0.5)[:, :tracks * (Hn + D)]
+    bias[:, :tracks * Hn] *= scale
+    we = torch.randn((tracks, D, Hn), device=DEV, generator=g) * 0.1 * scale
+    wd = torch.randn((tracks, D, Hn), device=DEV, generator=g) * 0.1
+    rw = torch.rand(N, device=DEV, generator=g)
+    one = torch.tensor([1], device=DEV, dtype=torch.int32)
+    d0 = torch.zeros((N, ld), device=DEV)[:, :tracks * (Hn + D)]
+    af = torch.zeros((tracks, N, Hn), device=DEV)
+    unsafe = torch.full((1,), 7, device=DEV, dtype=torch.int32)
+    ops.nade_logprob_fwd(v, bias, we, wd, tracks, D, Hn, rw, torch.zeros((tracks, N), device=DEV), None, d0, af, gate=one, run_if=1, unsafe=unsafe)
+    assert (int(unsafe) == 0) == (scale == 1.0), int(unsafe)
+
+    def run(word):
+        dwe, dwd = torch.zeros_like(we), torch.zeros_like(wd)
+        d1 = torch.zeros((N, ld), device=DEV)[:, :tracks * (Hn + D)]
+        d1.copy_(d0)
+        ops.nade_logprob_bwd(v, bias, we, wd, tracks, D, Hn, af, d1, dwe, dwd, unsafe=word)
+        return dwe, dwd, d1[:, :tracks * Hn].clone()
+
+    def rel(x, y):
+        return float((x.double() - y.double()).abs().max() / y.double().abs().max().clamp_min(1e-30))
+
+    e0, w0, b0 = run(None)
+    e1, w1, b1 = run(unsafe)
+    errs = (rel(e1, e0), rel(w1, w0), rel(b1, b0))
+    print(f"\n[dense backward, multiplicative vs direct, N={N} D={D} tracks={tracks} rho={rho} scale={scale}] d w_enc {errs[0]:.2e}  d w_dec {errs[1]:.2e}  d b_enc {errs[2]:.2e}")
+    assert errs[0] < 2e-5 and errs[1] < 2e-5 and errs[2] < 2e-5, errs
+    if scale != 1.0:
+        assert torch.equal(b1, b0)                       # unsafe rows: the exact path, bit for bit
+    gated_out = torch.full((1,), 7, device=DEV, dtype=torch.int32)
+    zero = torch.tensor([0], device=DEV, dtype=torch.int32)
+    ops.nade_logprob_fwd(v, bias, we, wd, tracks, D, Hn, None, torch.zeros((tracks, N), device=DEV), None, None, None, gate=zero, run_if=1,
+                         unsafe=gated_out)
+    assert int(gated_out) == 1                           # the dense launch did not run: nothing vouched for
+    e2, w2, b2 = run(gated_out)
+    assert torch.equal(b2, b0) and rel(w2, w0) < 1e-6
+
+
 @pytest.mark.parametrize("u,njobs,B,T,keep", [(256, 5, 256, 6, 0.9), (256, 3, 64, 5, 1.0), (512, 5, 256, 6, 0.9), (512, 2, 512, 4, 1.0)])
 def test_lstm_recurrence_multi_job_launch_equals_single_launches(ops, u, njobs, B, T, keep):
     """ONE launch for several independent layers (mnn_lstm_resident_*_multi, mnn_lstm_cluster_*_multi: the per-track generators of the jamming
