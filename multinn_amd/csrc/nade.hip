@@ -43,6 +43,13 @@ __device__ __forceinline__ void nade_zero_rows(float* __restrict__ d_bias, int l
 // ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dpp_xor8(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false)); }
 __device__ __forceinline__ float swz_xor4(float x) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x101F)); }
+// x[l ^ 4] without the LDS crossbar (a ds_swizzle is ~100 cycles on a dependent chain): two row shifts by four lanes, each written to the
+// banks (groups of four lanes) it is right for -- row_shl:4 (lane l reads l + 4) into banks 0 and 2, row_shr:4 (l - 4) into banks 1 and 3
+__device__ __forceinline__ float dpp_xor4(float x) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x104, 0xf, 0x5, false);
+    t = __builtin_amdgcn_update_dpp(t, __float_as_int(x), 0x114, 0xf, 0xa, false);
+    return __int_as_float(t);
+}
 __device__ __forceinline__ float dpp_xor2(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false)); }
 __device__ __forceinline__ float dpp_xor1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false)); }
 
@@ -691,7 +698,7 @@ __device__ __forceinline__ float wave_xor_sum(float x) {
         x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
     x = x + dpp_xor8(x);
-    x = x + swz_xor4(x);
+    x = x + dpp_xor4(x);
     x = x + dpp_xor2(x);
     x = x + dpp_xor1(x);
     return x;
@@ -849,11 +856,291 @@ nade_sample_kernel(SampleJobs J, int N, int D, int Hn, float temperature, uint32
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// The same scan G = 8 or 16 visibles at a time.  Between two draws of 1 the hidden state does not move, so the logits of the next visibles are
+// all dot products with the SAME h: a pass evaluates the G logits of an aligned chunk at once -- 4 G FMAs (packed in pairs), one reduce-scatter
+// of the xor butterfly (every level adds the same two numbers as wave_xor_sum: same bits; lane l ends with the sum of visible l >> 3, or l >> 2),
+// G sigmoids and comparisons in G lane groups -- and the ballot names the first draw of 1 (everything before it is a settled 0).  That one
+// flips the state and the chunk is re-evaluated from the visible behind it.  Passes per row: D / G + (number of ones) instead of D dependent
+// conditionals (piano-roll rows: ~13 ones in 440).  One wave per workgroup; the weight rows of a chunk arrive by LDS DMA (one
+// 16-byte-per-lane copy per row: a ring of chunks in flight, counted waits) -- a register ring that deep would need more than vmcnt's 63 loads
+// in flight.  A lone wave spends ~10 cycles per instruction of this dependent chain, so the wider pass costs little more than the narrow one:
+// G = 16 while every row has a CU to itself (96 KB of ring), G = 8 (64 KB: two workgroups per CU) for larger batches.
+// Needs Hn % 4 == 0 and 16-byte aligned weight matrices (mnn_nade_sample falls back to nade_sample_kernel otherwise).
+// profiles/tools/sample_chunk_trace.py: the stage clocks.  [72 rows, D = 440, Hn = 256, piano-roll-like draws: 112 -> see profiles/round6_e_sampling_chunks.md]
+// ----------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* nade_gas_ptr_t;
+typedef __attribute__((address_space(3))) void* nade_lds_ptr_t;
+typedef float nade_f32x2 __attribute__((ext_vector_type(2)));
+constexpr int sch_nb(int g) { return g == 16 ? 3 : 4; }      // ring depth: 3 x 32 KB (G = 16) or 4 x 16 KB (G = 8)
+#ifdef SCH_TRACE        // development only (profiles/tools/sample_chunk_trace.py): per chunk of row 0 / job 0, [wall clock at the wait | after it | after the passes | shader clock there]
+__device__ long long sch_trace[8][256];
+extern "C" int mnn_sch_trace_read(long long* host) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(sch_trace), sizeof(sch_trace)) == hipSuccess ? 0 : 1; }
+#define SCH_TR(k, c) do { if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (c) < 256) sch_trace[k][c] = (k) == 3 ? clock64() : wall_clock64(); } while (0)
+#else
+#define SCH_TR(k, c) do { } while (0)
+#endif
+template <int TMODE, bool FULL, int G>
+__global__ void __launch_bounds__(64)
+nade_sample_chunk_kernel(SampleJobs J, int N, int D, int Hn, float temperature, uint32_t row0, uint32_t sub, long s_row_stride, int s_elem_stride) {
+    constexpr int NB = sch_nb(G);
+    constexpr int KSH = G == 16 ? 2 : 3;                      // lane l decides visible l >> KSH of the chunk
+    constexpr int WAITN = (NB - 1) * 2 * G < 63 ? (NB - 1) * 2 * G : 63;        // (vmcnt counts to 63: G = 16 waits for one copy more than it needs)
+    // ring [NB][w_dec | w_enc][G][256] f32 (64 KB) | logit / log term [Dp] f32 | b_dec [Dp] f32 | 256 uniforms | draws [Dp] u8
+    extern __shared__ __attribute__((aligned(16))) unsigned char nade_sample_smem[];
+    float* ring = reinterpret_cast<float*>(nade_sample_smem);
+    const int Dp = (D + 3) & ~3;
+    float* sp = ring + NB * 2 * G * 256;
+    float* sbd = sp + Dp;
+    float* su = sbd + Dp;
+    unsigned char* son = reinterpret_cast<unsigned char*>(su + 256);
+    const SampleJob& jb = J.job[blockIdx.y];
+    const float* __restrict__ bias = jb.bias;
+    const int ld_bias = jb.ld_bias;
+    const uint64_t seed = jb.seed;
+    uint8_t* __restrict__ samples = jb.samples;
+    float* __restrict__ nll = jb.nll;
+    const int lane = threadIdx.x;
+    const int row = blockIdx.x;                              // < N by the grid
+    const float* __restrict__ we = jb.w_enc;
+    const float* __restrict__ wd = jb.w_dec;
+    const float* __restrict__ bd = bias + (size_t)row * ld_bias + jb.dec_off;
+    // LDS DMA of chunk c into ring slot b: lane l copies floats 4l .. 4l + 3 of a row (inside the row for narrow layers: what lands past Hn is never read)
+    const int src_off = min(4 * lane, Hn - 4);
+    auto stage = [&](int b, int c) {
+        if (FULL && D >= G) {
+            // Hn == 256: the rows of a chunk are 1 KB apart in memory AND in the ring, so the instruction offset (added to both addresses) walks
+            // them -- four copies per address / M0 set-up instead of one (a set-up is ~10 scalar + vector instructions: 320 -> ~100 ns per chunk).
+            // Chunks past the end (issued to keep the wait count constant, never read) and the ragged last one start at row D - G: every copy
+            // stays inside the matrix; the last chunk's rows are then read from where they landed (`rsh` below).
+            const int r0 = min(c * G, D - G);
+#pragma unroll
+            for (int k4 = 0; k4 < G; k4 += 4) {
+                const float* gd = wd + (size_t)(r0 + k4) * 256 + 4 * lane;
+                const float* ge = we + (size_t)(r0 + k4) * 256 + 4 * lane;
+                float* ld_ = ring + ((b * 2 + 0) * G + k4) * 256;
+                float* le_ = ring + ((b * 2 + 1) * G + k4) * 256;
+#define SCH_COPY4(G_, L_) __builtin_amdgcn_global_load_lds((nade_gas_ptr_t)(G_), (nade_lds_ptr_t)(L_), 16, 0, 0);    __builtin_amdgcn_global_load_lds((nade_gas_ptr_t)(G_), (nade_lds_ptr_t)(L_), 16, 1024, 0); \
+                          __builtin_amdgcn_global_load_lds((nade_gas_ptr_t)(G_), (nade_lds_ptr_t)(L_), 16, 2048, 0); __builtin_amdgcn_global_load_lds((nade_gas_ptr_t)(G_), (nade_lds_ptr_t)(L_), 16, 3072, 0)
+                SCH_COPY4(gd, ld_);
+                SCH_COPY4(ge, le_);
+#undef SCH_COPY4
+            }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const int ii = min(c * G + k, D - 1);
+            __builtin_amdgcn_global_load_lds((nade_gas_ptr_t)(wd + (size_t)ii * Hn + src_off), (nade_lds_ptr_t)(ring + ((b * 2 + 0) * G + k) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((nade_gas_ptr_t)(we + (size_t)ii * Hn + src_off), (nade_lds_ptr_t)(ring + ((b * 2 + 1) * G + k) * 256), 16, 0, 0);
+        }
+    };
+    float a[4], h[4];
+    bool in[4];
+    int off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        in[q] = FULL || lane + 64 * q < Hn;
+        off[q] = in[q] ? lane + 64 * q : 0;
+        const float av = bias[(size_t)row * ld_bias + jb.enc_off + off[q]];
+        a[q] = in[q] ? av : 0.f;
+        h[q] = det_sigmoid(a[q]);
+    }
+    for (int i = lane; i < D; i += 64) sbd[i] = bd[i];
+    const uint32_t e0 = jb.elem0;
+    uint32_t b0 = e0 >> 2;
+    auto refill = [&]() {                                    // (an LDS write waits for every copy in flight -- the compiler cannot tell them apart: once per ~31 chunks)
+        float u4[4];
+        philox_uniform4(seed, MNN_STREAM_NADE, row0 + (uint32_t)row, sub, b0 + (uint32_t)lane, u4);
+        *reinterpret_cast<float4*>(su + 4 * lane) = make_float4(u4[0], u4[1], u4[2], u4[3]);
+    };
+    if (TMODE != 0) refill();
+    asm volatile("" ::"v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));     // the initial states are evaluated HERE: behind the copies they would wait for all 64 of them
+    __builtin_amdgcn_sched_barrier(0);                       // the loads above are older than every DMA: the counted waits below cover them
+#pragma unroll
+    for (int b = 0; b < NB; ++b) stage(b, b);
+    const int kq = lane >> KSH;                              // the visible of the chunk this lane decides
+    const int nchunks = (D + G - 1) / G;
+    // what a chunk's passes read besides h: its eight w_dec rows -- visibles (2 p, 2 p + 1) side by side, one packed FMA serves both --, the lane's
+    // b_dec and uniform.  (Measured and dropped: fetching them one chunk AHEAD, under the previous chunk's passes -- 47.0 vs 46.5 us per call: a lone
+    // wave spends ~10 cycles per instruction of this chain whatever flies beside it.)
+    struct ChunkIn { nade_f32x2 w[G / 2][4]; float bdv, u; };
+    auto fetch_in = [&](int slot, int c, ChunkIn& ci) {
+        const int i0 = c * G;
+        // (Hn == 256, D % 8 != 0: the last chunk was copied from row D - 8 on -- visible i0 + k sits rsh rows further down; rows past D are never decided)
+        const int rsh = (FULL && D >= G) ? i0 - min(i0, D - G) : 0;
+        const float* rd = ring + (slot * 2 + 0) * G * 256 + rsh * 256;
+#pragma unroll
+        for (int p2 = 0; p2 < G / 2; ++p2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float x0 = rd[(2 * p2) * 256 + off[q]], x1 = rd[(2 * p2 + 1) * 256 + off[q]];
+                ci.w[p2][q] = nade_f32x2{in[q] ? x0 : 0.f, in[q] ? x1 : 0.f};
+            }
+        const int ivc = min(i0 + kq, D - 1);
+        ci.bdv = sbd[ivc];
+        ci.u = 0.f;
+        if (TMODE != 0) {
+            const uint32_t e_last = e0 + (uint32_t)min(i0 + G - 1, D - 1);
+            if ((e_last >> 2) >= b0 + 64u) {                 // uniform: the window of 64 Philox blocks restarts at this chunk's first element
+                b0 = (e0 + (uint32_t)i0) >> 2;
+                refill();
+            }
+            ci.u = su[e0 + (uint32_t)ivc - 4u * b0];
+        }
+    };
+    for (int c0 = 0; c0 < nchunks; c0 += NB) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int c = c0 + b;
+            if (c < nchunks) {                               // uniform
+                // chunk c's sixteen copies are the oldest in flight; (NB - 1) chunks behind them may still be on their way
+                SCH_TR(0, c);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+                SCH_TR(1, c);
+                ChunkIn ci;
+                fetch_in(b, c, ci);
+                const int i0 = c * G;
+                const int rsh = (FULL && D >= G) ? i0 - min(i0, D - G) : 0;
+                const float* re = ring + (b * 2 + 1) * G * 256 + rsh * 256;
+                const int iv = i0 + kq;
+                const bool mine = iv < D;
+                const float bdv = ci.bdv, u = ci.u;
+                int sfrom = 0;                               // first undecided visible of the chunk
+                SCH_TR(4, c);
+                while (true) {
+                    nade_f32x2 acc[G / 2];
+#pragma unroll
+                    for (int p2 = 0; p2 < G / 2; ++p2) {     // sum_j h_j w_dec[i0 + k][j], the contract's order (an IEEE fma per element, packed or not)
+                        acc[p2] = nade_f32x2{0.f, 0.f};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[p2] = __builtin_elementwise_fma(nade_f32x2{h[q], h[q]}, ci.w[p2][q], acc[p2]);
+                    }
+                    // reduce-scatter over the xor butterfly: at 32 the lower / upper half of the lanes keeps the lower / upper half of the visibles, at 16
+                    // a quarter each, ... until a lane holds ONE visible (G = 8: after the xor-8 level, G = 16: after xor-4); the remaining levels add
+                    // as in wave_xor_sum.  Every level adds the two numbers wave_xor_sum adds there.
+                    nade_f32x2 v4[G / 4], v2[G / 8];
+#pragma unroll
+                    for (int j = 0; j < G / 4; ++j) {        // pair j (visibles 2 j, 2 j + 1) against pair j + G / 4 (G / 2 visibles further)
+                        auto r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j].x), __float_as_uint(acc[j + G / 4].x), false, false);
+                        auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j].y), __float_as_uint(acc[j + G / 4].y), false, false);
+                        v4[j] = nade_f32x2{__uint_as_float(r0[0]), __uint_as_float(r1[0])} + nade_f32x2{__uint_as_float(r0[1]), __uint_as_float(r1[1])};
+                    }
+#pragma unroll
+                    for (int j = 0; j < G / 8; ++j) {
+                        auto r0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v4[j].x), __float_as_uint(v4[j + G / 8].x), false, false);
+                        auto r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v4[j].y), __float_as_uint(v4[j + G / 8].y), false, false);
+                        v2[j] = nade_f32x2{__uint_as_float(r0[0]), __uint_as_float(r1[0])} + nade_f32x2{__uint_as_float(r0[1]), __uint_as_float(r1[1])};
+                    }
+                    const bool up8 = (lane & 8) != 0;
+                    float x;
+                    if constexpr (G == 16) {                 // xor 8: pair 0 against pair 1; xor 4: the pair's two
+                        const nade_f32x2 keep = up8 ? v2[1] : v2[0], give = up8 ? v2[0] : v2[1];
+                        const nade_f32x2 v1 = keep + nade_f32x2{dpp_xor8(give.x), dpp_xor8(give.y)};
+                        const bool up4 = (lane & 4) != 0;
+                        const float k1 = up4 ? v1.y : v1.x, g1 = up4 ? v1.x : v1.y;
+                        x = k1 + dpp_xor4(g1);
+                    } else {
+                        const float keep = up8 ? v2[0].y : v2[0].x, give = up8 ? v2[0].x : v2[0].y;
+                        x = keep + dpp_xor8(give);
+                        x = x + dpp_xor4(x);
+                    }
+                    x = x + dpp_xor2(x);
+                    x = x + dpp_xor1(x);
+                    const float l = bdv + x;
+#ifdef SCH_TRACE
+                    if (sfrom == 0) { asm volatile("" ::"v"(l)); SCH_TR(5, c); }
+#endif
+                    const bool open = mine && kq >= sfrom;   // lanes whose visible is still undecided
+                    bool on;
+                    if (TMODE != 0) {                        // u < det_sigmoid(l / T), settled by the hardware sigmoid unless within 1e-4 of a tie (draw_below)
+                        const float xa = TMODE == 1 ? l : l / temperature;
+                        const float r = sig_approx(xa);
+                        const float d = u - r;
+                        const bool tie = !(fabsf(d) > 1e-4f * r + 1e-30f);
+                        if (__builtin_amdgcn_ballot_w64(tie && open) == 0ull) on = d < 0.f;
+                        else on = u < det_sigmoid(xa);
+                    } else {                                 // nade.py:278-279
+                        const float d = sig_approx(l) - 0.5f;
+                        const bool tie = !(fabsf(d) > 1e-4f);
+                        if (__builtin_amdgcn_ballot_w64(tie && open) == 0ull) on = d > 0.f;
+                        else on = det_sigmoid(l) >= 0.5f;
+                    }
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(on && open) & (G == 16 ? 0x1111111111111111ull : 0x0101010101010101ull);
+                    const int f = m != 0ull ? (int)(__builtin_ctzll(m) >> KSH) : G;     // the first draw of 1 (uniform)
+#ifdef SCH_TRACE
+                    if (sfrom == 0) { asm volatile("" ::"s"(f)); SCH_TR(6, c); }
+#endif
+                    if ((lane & ((1 << KSH) - 1)) == 0 && open && kq <= f) {
+                        sp[iv] = l;
+                        son[iv] = kq == f ? 1 : 0;
+                    }
+                    if (f >= G) break;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float x2 = re[f * 256 + off[q]];
+                        a[q] = a[q] + (in[q] ? x2 : 0.f);
+                        h[q] = det_sigmoid(a[q]);
+                    }
+                    sfrom = f + 1;
+                    if (sfrom >= G || i0 + sfrom >= D) break;
+                }
+                SCH_TR(2, c);
+                SCH_TR(3, c);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            stage(b, c + NB);                                // always issued (rows clamped): the wait count above stays a constant
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // after the scan: as nade_sample_kernel
+    for (int i = lane; i < D; i += 64) {
+        const float p = det_sigmoid(sp[i]);
+        const bool on = son[i] != 0;
+        samples[(size_t)row * s_row_stride + (size_t)i * s_elem_stride] = on ? 1 : 0;
+        sp[i] = on ? logf(NADE_EPS + p) : logf(NADE_EPS + (1.0f - p));
+    }
+    if (nll != nullptr) {
+        float logp = 0.f;
+        for (int i = 0; i < D; ++i) logp += sp[i];
+        if (lane == 0) nll[row] = -logp;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the last (clamped) copies land before the LDS is given back
+}
+
+static hipError_t sample_chunk_raise_lds() {                 // the ring + a row's scratch pass the 64 KB default of dynamic LDS
+    static bool raised_[64];
+    bool& raised = mnn_dev_flag(raised_);
+    if (raised) return hipSuccess;
+    hipError_t e = hipSuccess;
+#define RAISE(TM, FU) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nade_sample_chunk_kernel<TM, FU, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
+                      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nade_sample_chunk_kernel<TM, FU, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)
+    RAISE(0, true); RAISE(1, true); RAISE(2, true); RAISE(0, false); RAISE(1, false); RAISE(2, false);
+#undef RAISE
+    raised = e == hipSuccess;
+    return e;
+}
+
 static int launch_sample(hipStream_t st, const SampleJobs& J, int njobs, int N, int D, int Hn, float temperature, uint32_t row0, uint32_t sub,
                          long s_row_stride, int s_elem_stride) {
+    const int tmode = temperature > 0.f ? (temperature == 1.0f ? 1 : 2) : 0;
+    bool chunked = Hn % 4 == 0 && Hn >= 4 && getenv("MNN_SAMPLE_NO_CHUNK") == nullptr;      // (read per call: tests compare the two forms)
+    for (int j = 0; j < njobs && chunked; ++j) chunked = (((uintptr_t)J.job[j].w_enc | (uintptr_t)J.job[j].w_dec) & 15) == 0;
+    if (chunked) {                                           // eight visibles per pass, one wave per row
+        // sixteen visibles per pass while every row has a CU of its own (96 KB of ring: one workgroup per CU); eight with more rows than that
+        const int g = (long)N * njobs <= 256 && !getenv("MNN_SAMPLE_G8") ? 16 : 8;
+        const size_t ldc = (size_t)sch_nb(g) * 2 * g * 1024 + (size_t)9 * ((D + 3) & ~3) + 1024;       // <= 96 KB + 13.5 KB + 1 KB (D <= 1536)
+        MNN_HIP(sample_chunk_raise_lds());
+#define SMC(TM, FU) do { if (g == 16) hipLaunchKernelGGL((nade_sample_chunk_kernel<TM, FU, 16>), dim3(N, njobs), dim3(64), ldc, st, J, N, D, Hn, temperature, row0, sub, s_row_stride, s_elem_stride); \
+                         else hipLaunchKernelGGL((nade_sample_chunk_kernel<TM, FU, 8>), dim3(N, njobs), dim3(64), ldc, st, J, N, D, Hn, temperature, row0, sub, s_row_stride, s_elem_stride); } while (0)
+        if (Hn == 256) { if (tmode == 0) SMC(0, true); else if (tmode == 1) SMC(1, true); else SMC(2, true); }
+        else { if (tmode == 0) SMC(0, false); else if (tmode == 1) SMC(1, false); else SMC(2, false); }
+#undef SMC
+        MNN_LAUNCH_CHECK();
+        return MNN_OK;
+    }
     dim3 grid(cdiv(N, 4), njobs);
     const size_t lds = (size_t)36 * ((D + 3) & ~3) + 4096;   // 4 waves x ((2 f32 + u8) per visible + 256 uniforms)
-    const int tmode = temperature > 0.f ? (temperature == 1.0f ? 1 : 2) : 0;
 #define SMP(TM, FU, SP) hipLaunchKernelGGL((nade_sample_kernel<TM, FU, SP>), grid, dim3(256), lds, st, J, N, D, Hn, temperature, row0, sub, s_row_stride, s_elem_stride)
     if (Hn == 256 && tmode == 1) { if (getenv("MNN_SAMPLE_NO_SPEC")) SMP(1, true, false); else SMP(1, true, true); }
     else if (Hn == 256) { if (tmode == 0) SMP(0, true, false); else SMP(2, true, false); }

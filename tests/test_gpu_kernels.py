@@ -551,8 +551,11 @@ def test_nade_edge_cases(ops):
         ops.nade_logprob_fwd(v, z(N, Hn + D), z(1, D, 300), z(1, D, 300), 1, D, 300)   # Hn > 256
 
 
-@pytest.mark.parametrize("N,D,Hn,tracks,temp", [(9, 40, 64, 1, 1.0), (6, 88, 256, 2, 1.0), (5, 30, 100, 1, 0.7), (4, 25, 20, 1, None)])
+@pytest.mark.parametrize("N,D,Hn,tracks,temp", [(9, 40, 64, 1, 1.0), (6, 88, 256, 2, 1.0), (5, 30, 100, 1, 0.7), (4, 25, 20, 1, None),
+                                                (7, 440, 256, 1, 1.0), (5, 333, 256, 3, 1.0), (4, 88, 256, 5, 0.5), (3, 130, 252, 1, None), (3, 61, 30, 2, 1.0)])
 def test_nade_sample_bit_exact(ops, N, D, Hn, tracks, temp):
+    """Hn % 4 == 0: the eight-visibles-per-pass kernel (nade_sample_chunk_kernel; D = 333 x 3 tracks: chunks, track offsets and Philox windows
+    that do not line up; 440 x 256: the joint generator's shape); other widths: the visible-at-a-time kernel."""
     R = np.random.default_rng(Hn)
     ld = tracks * (Hn + D)
     bias = (R.standard_normal((N, ld)) * .5).astype(np.float32)
@@ -574,6 +577,40 @@ def test_nade_sample_bit_exact(ops, N, D, Hn, tracks, temp):
     out2 = torch.zeros((N, tracks * D), device=DEV, dtype=torch.uint8)
     ops.nade_sample(dev(bias), dev(we), dev(wd), tracks, D, Hn, temp, 77, 1000, 5, out2, track_minor=True)
     assert np.array_equal(out2.cpu().numpy().reshape(N, D, tracks).transpose(0, 2, 1).reshape(N, tracks * D), got)
+
+
+@pytest.mark.parametrize("scale", [0.3, 3.0])
+def test_nade_sample_chunked_passes_equal_the_visible_at_a_time_scan(ops, monkeypatch, scale):
+    """The three forms of the sampling scan on the same inputs (MNN_SAMPLE_G8 / MNN_SAMPLE_NO_CHUNK select the narrower pass / the
+    visible-at-a-time kernel, read per call): draws and
+    NLL bit for bit, at the joint generator's shape with piano-roll-like (b_dec ~ -3.5) and coin-flip conditionals, all three temperature modes.
+    scale 3: half the visibles flip the state -- most passes restart inside their chunk."""
+    N, D, Hn, tracks = 40, 440, 256, 2
+    g = torch.Generator(device=DEV).manual_seed(5)
+    ld = tracks * (Hn + D)
+    bias = torch.randn((N, ld), device=DEV, generator=g) * 0.5
+    if scale < 1:
+        bias[:, tracks * Hn:] -= 3.5
+    we = torch.randn((tracks, D, Hn), device=DEV, generator=g) * 0.1 * scale
+    wd = torch.randn((tracks, D, Hn), device=DEV, generator=g) * 0.1 * scale
+    for temp in (1.0, 0.8, None):
+        res = []
+        for form in ("chunks of 16", "chunks of 8", "visible at a time"):
+            monkeypatch.delenv("MNN_SAMPLE_NO_CHUNK", raising=False)
+            monkeypatch.delenv("MNN_SAMPLE_G8", raising=False)
+            if form == "chunks of 8":
+                monkeypatch.setenv("MNN_SAMPLE_G8", "1")
+            elif form == "visible at a time":
+                monkeypatch.setenv("MNN_SAMPLE_NO_CHUNK", "1")
+            out = torch.zeros((N, tracks * D), device=DEV, dtype=torch.uint8)
+            nll = torch.zeros((tracks, N), device=DEV)
+            ops.nade_sample(bias, we, wd, tracks, D, Hn, temp, seed=9, row0=77, sub=3, samples=out, nll=nll)
+            torch.cuda.synchronize()
+            res.append((out, nll))
+        assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1]), temp
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), temp
+        m = float(res[0][0].float().mean())
+        assert (0.005 < m < 0.2) if scale < 1 and temp is not None else True, m
 
 
 def test_nade_sample_near_ties_take_the_exact_comparison(ops):
