@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MULTINN_HIP_LIB", os.path.join(HERE, "libmultinn_hip.so"))   # override: A/B builds of the same ABI
 
-ABI_VERSION = 117          # == MNN_ABI_VERSION of include/multinn_hip.h; load() refuses a library built for another one
+ABI_VERSION = 118          # == MNN_ABI_VERSION of include/multinn_hip.h; load() refuses a library built for another one
 F32, BF16, U8, F16 = 0, 1, 2, 3
 GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_A_KBLOCK32 = 1, 2, 8
 
@@ -57,7 +57,9 @@ SIGNATURES = {
     "mnn_lstm_step_det": (_i, [_p, _i, _i, _p]),
     "mnn_dense_det": (_i, [_p, _i, _i, _p]),
     "mnn_nade_sample_multi": (_i, [_p, _i, _p, _i, _i, _i, _f, _u32, _u32, _l, _i]),
-    "mnn_generate_scan_workspace_bytes": (_sz, [_i, _i, _p, _i]),
+    "mnn_generate_scan_workspace_bytes": (_sz, [_i, _i, _i, _p, _i]),
+    "mnn_det_lstm_pack_bytes": (_sz, [_i, _i]),
+    "mnn_det_lstm_pack": (_i, [_p, _p, _i, _i, _p]),
     "mnn_generate_scan": (_i, [_p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _u64, _u32, _p, _p, _sz]),
     "mnn_comm_unique_id": (_i, [_p]),
     "mnn_comm_init": (_i, [C.POINTER(_p), _i, _i, _p]),
@@ -68,7 +70,7 @@ SIGNATURES = {
 class DetLstmJob(C.Structure):
     """mnn_det_lstm_job (include/multinn_hip.h)."""
     _fields_ = [("x", _p), ("x_dtype", _i), ("n_x", _i), ("ld_x", _i), ("es_x", _i), ("x2", _p), ("n_x2", _i), ("ld_x2", _i), ("h_prev", _p), ("c_prev", _p),
-                ("W", _p), ("bias", _p), ("c_out", _p), ("h_out", _p), ("units", _i)]
+                ("W", _p), ("bias", _p), ("c_out", _p), ("h_out", _p), ("units", _i), ("Wp", _p)]
 
 
 class NadeSampleJob(C.Structure):

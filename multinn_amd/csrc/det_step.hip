@@ -60,7 +60,10 @@ __device__ __forceinline__ void ds_chain_chunk(WF&& w_k, int k0, int kc, int K, 
 #pragma unroll
             for (int j = 0; j < DS_PF; ++j) xb[j] = xs_row[2 * min(sb + j, np - 1) + hh];
             __builtin_amdgcn_sched_barrier(0);                // the refill loads and the LDS reads first, then this set's MFMAs
-            if (sb < np) {
+            if (sb + DS_PF <= np) {                           // a full set: 28 MFMAs in a straight line (a test per MFMA put each one behind two jumps)
+#pragma unroll
+                for (int j = 0; j < DS_PF; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[half][j], xb[j], acc, 0, 0, 0);
+            } else if (sb < np) {                             // the chain's last, partial set
 #pragma unroll
                 for (int j = 0; j < DS_PF; ++j)
                     if (sb + j < np) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[half][j], xb[j], acc, 0, 0, 0);
@@ -124,15 +127,89 @@ __device__ __forceinline__ void ds_stage_zero(int c_lo, int c_hi, int pitch, flo
 #define DS_SPLIT 4
 __device__ __forceinline__ int ds_quarter(int kc) { return ((kc / 2) + DS_SPLIT - 1) / DS_SPLIT; }      // pairs per quarter of a chunk of kc (even) columns
 
+// ---- packed weights (mnn_det_lstm_pack): the SAME numbers, laid out so that a wave's whole quarter chain is a handful of 16-byte loads ----
+// The TF layout costs a wave one 4-byte load per MFMA (two 128-byte pieces 8 KB apart), at most 56 of them in flight: a K = 952 chain of 119
+// MFMAs (64 cycles each: 3.2 us) took 9.6 us, every set of 28 waiting ~2.3 us for loads issued one set earlier
+// (profiles/tools/det_step_trace.py).  Packed: Wp[((blk nchunks + chunk) 4 + quarter)][j4][lane = hh 32 + r][4] holds, for the lane that owns A row r
+// (gate r >> 3 of unit 8 blk + (r & 7)) and k parity hh, the weights of k-pairs 4 j4 .. 4 j4 + 3 of that quarter (zero past its end).  A load
+// instruction is then 1 KB contiguous, a K = 952 quarter is 30 of them, ALL issued before the inputs are even staged.
+__host__ __device__ inline int ds_pack_q4max(int K) { const int kc = (min(DS_KC, K) + 1) & ~1; return (((kc / 2) + DS_SPLIT - 1) / DS_SPLIT + 3) / 4; }
+__host__ __device__ inline int ds_pack_nchunks(int K) { return (K + DS_KC - 1) / DS_KC; }
+#define DS_P4MAX 32                  // float4 per lane and quarter of a full chunk: ceil(ceil(512 / 4) / 4)
+
+__global__ void __launch_bounds__(256) ds_pack_kernel(const float* __restrict__ W, int K, int u, float4* __restrict__ Wp) {
+    const int q4max = ds_pack_q4max(K), nch = ds_pack_nchunks(K);
+    const long total = (long)(u / 8) * nch * DS_SPLIT * q4max * 64;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    long rest = t >> 6;
+    const int j4 = (int)(rest % q4max); rest /= q4max;
+    const int sq = (int)(rest % DS_SPLIT); rest /= DS_SPLIT;
+    const int c = (int)(rest % nch);
+    const int blk = (int)(rest / nch);
+    const int r = lane & 31, hh = lane >> 5;
+    const int k0 = c * DS_KC, kc = (min(DS_KC, K - k0) + 1) & ~1;
+    const int q = ds_quarter(kc), p0 = min(sq * q, kc / 2), p1 = min(p0 + q, kc / 2);
+    const size_t col = (size_t)(r >> 3) * u + blk * 8 + (r & 7);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int pp = p0 + 4 * j4 + e, k = k0 + 2 * pp + hh;
+        v[e] = (pp < p1 && k < K) ? W[(size_t)k * 4 * u + col] : 0.f;
+    }
+    Wp[t] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// the chain of one quarter from packed weights already in registers: wv[j4] = the lane's weights of k-pairs 4 j4 .. 4 j4 + 3; np pairs
+__device__ __forceinline__ void ds_chain_packed(const float4 (&wv)[DS_P4MAX], int np, const float* __restrict__ xs_row, int hh, ds_f32x16& acc) {
+#pragma unroll
+    for (int s7 = 0; s7 < DS_P4MAX; s7 += 7) {               // sets of 28 k-pairs, as ds_chain_chunk: the set's inputs out of LDS first, then its MFMAs
+        const int sb = 4 * s7;
+        if (sb < np) {                                       // uniform
+            float xb[28];
+#pragma unroll
+            for (int j = 0; j < 28; ++j) xb[j] = xs_row[2 * min(sb + j, np - 1) + hh];
+            __builtin_amdgcn_sched_barrier(0);
+            if (sb + 28 <= np) {
+#pragma unroll
+                for (int j = 0; j < 28; ++j) {
+                    if (s7 + j / 4 < DS_P4MAX) {
+                        const float4& w4 = wv[(s7 + j / 4) < DS_P4MAX ? (s7 + j / 4) : 0];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(j % 4 == 0 ? w4.x : j % 4 == 1 ? w4.y : j % 4 == 2 ? w4.z : w4.w, xb[j], acc, 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 28; ++j) {
+                    if (s7 + j / 4 < DS_P4MAX && sb + j < np) {
+                        const float4& w4 = wv[(s7 + j / 4) < DS_P4MAX ? (s7 + j / 4) : 0];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(j % 4 == 0 ? w4.x : j % 4 == 1 ? w4.y : j % 4 == 2 ? w4.z : w4.w, xb[j], acc, 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+#ifdef DS_TRACE         // development only (profiles/tools/det_step_trace.py): wall-clock stamps (100 MHz) of every wave of workgroup (0, 0, 0), [stage][wave]
+__device__ long long ds_trace[8][4];
+extern "C" int mnn_ds_trace_read(long long* host) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(ds_trace), sizeof(ds_trace)) == hipSuccess ? 0 : 1; }
+#define DS_TR(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0) ds_trace[k][threadIdx.x >> 6] = wall_clock64(); } while (0)
+#else
+#define DS_TR(k) do { } while (0)
+#endif
 __global__ void __launch_bounds__(256) lstm_step_det_kernel(DetLstmJobs J, int B) {
     extern __shared__ __attribute__((aligned(16))) float ds_smem[];
+    DS_TR(0);
     const mnn_det_lstm_job& jb = J.job[blockIdx.z];
     const int u = jb.units, ub = blockIdx.x * 8;
     if (ub >= u) return;                             // the grid covers the widest job
     const int r0 = blockIdx.y * 32;
     const int n1 = jb.n_x, n2 = jb.n_x2;
     const int K = n1 + n2 + u;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;    // (w in a scalar register: the chain's bounds tests are then scalar branches, not an exec-mask dance around every MFMA)
     // every wave of the workgroup: the same 32 A rows = the four gates of units ub .. ub + 7 (row g * 8 + uu <-> TF column g * u + ub + uu);
     // wave w walks quarter w of K
     const int col = (r >> 3) * u + ub + (r & 7);
@@ -144,8 +221,16 @@ __global__ void __launch_bounds__(256) lstm_step_det_kernel(DetLstmJobs J, int B
     ds_f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const float4* __restrict__ wpk = reinterpret_cast<const float4*>(jb.Wp);
+    const int q4max = ds_pack_q4max(K), nch = ds_pack_nchunks(K);
     for (int k0 = 0; k0 < K; k0 += DS_KC) {
         const int kc = (min(DS_KC, K - k0) + 1) & ~1, pitch = kc | 1;
+        float4 wv[DS_P4MAX];
+        if (wpk != nullptr) {                            // this quarter's weights: every load in flight while the inputs are staged
+            const float4* __restrict__ pq = wpk + ((size_t)((blockIdx.x * nch + k0 / DS_KC) * DS_SPLIT + w) * q4max) * 64 + lane;
+#pragma unroll
+            for (int j4 = 0; j4 < DS_P4MAX; ++j4) wv[j4] = pq[(size_t)min(j4, q4max - 1) * 64];
+        }
         if (k0 > 0) __syncthreads();
         if (n1 > 0) {
             if (jb.x_dtype == MNN_U8) ds_stage_seg(reinterpret_cast<const uint8_t*>(jb.x), (size_t)jb.ld_x, (size_t)jb.es_x, n1, 0, B, r0, k0, kc, pitch, xs);
@@ -155,13 +240,20 @@ __global__ void __launch_bounds__(256) lstm_step_det_kernel(DetLstmJobs J, int B
         if (jb.h_prev != nullptr) ds_stage_seg(jb.h_prev, (size_t)u, (size_t)1, u, n1 + n2, B, r0, k0, kc, pitch, xs);
         else ds_stage_zero(max(0, n1 + n2 - k0), min(kc, K - k0), pitch, xs);
         if (K - k0 < kc) ds_stage_zero(K - k0, kc, pitch, xs);               // the pad column of an odd K
+        DS_TR(1);
         __syncthreads();
+        DS_TR(2);
         const int q = ds_quarter(kc), p0 = min(w * q, kc / 2), p1 = min(p0 + q, kc / 2);
-        if (p1 > p0) ds_chain_chunk(w_k, k0 + 2 * p0, 2 * (p1 - p0), K, xs + r * pitch + 2 * p0, hh, acc);
+        if (p1 > p0) {
+            if (wpk != nullptr) ds_chain_packed(wv, p1 - p0, xs + r * pitch + 2 * p0, hh, acc);
+            else ds_chain_chunk(w_k, k0 + 2 * p0, 2 * (p1 - p0), K, xs + r * pitch + 2 * p0, hh, acc);
+        }
+        DS_TR(3);
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) part[(w * 16 + e) * 64 + lane] = acc[e];
     __syncthreads();
+    DS_TR(4);
     // pointwise: thread -> (unit ub + (t & 7), row r0 + (t >> 3)); accumulator register of A row i = g * 8 + uu: e = 4 g + (uu & 3), lane half uu >> 2
     const int uu = threadIdx.x & 7, rr = threadIdx.x >> 3, row = r0 + rr, un = ub + uu;
     if (row >= B) return;
@@ -177,6 +269,7 @@ __global__ void __launch_bounds__(256) lstm_step_det_kernel(DetLstmJobs J, int B
     const float c = __fadd_rn(__fmul_rn(gc, gi), __fmul_rn(cp, gf));
     jb.c_out[(size_t)row * u + un] = c;
     jb.h_out[(size_t)row * u + un] = __fmul_rn(det_tanh(c), go);
+    DS_TR(5);
 }
 
 __global__ void __launch_bounds__(256) dense_det_kernel(DetDenseJobs J, int B) {
@@ -186,7 +279,7 @@ __global__ void __launch_bounds__(256) dense_det_kernel(DetDenseJobs J, int B) {
     if (nb >= jb.N) return;
     const int r0 = blockIdx.y * 32;
     const int K = jb.K;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;    // (w in a scalar register: the chain's bounds tests are then scalar branches, not an exec-mask dance around every MFMA)
     const int n = min(nb + r, jb.N - 1);             // this lane's A row = output column n (the same for the four waves: wave w walks quarter w of K)
     const float* __restrict__ wp = jb.W + n;
     const size_t ldw = (size_t)jb.ld_w;
@@ -231,6 +324,19 @@ static hipError_t ds_raise_lds() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_det_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     raised = e == hipSuccess;
     return e;
+}
+
+extern "C" size_t mnn_det_lstm_pack_bytes(int K, int units) {
+    if (K <= 0 || units <= 0 || units % 32 != 0) return 0;
+    return (size_t)(units / 8) * ds_pack_nchunks(K) * DS_SPLIT * ds_pack_q4max(K) * 64 * sizeof(float4);
+}
+extern "C" int mnn_det_lstm_pack(mnn_stream_t s, const float* W, int K, int units, float* Wp) {
+    MNN_REQUIRE(W && Wp && K > units && units > 0 && units % 32 == 0 && ((uintptr_t)Wp & 15) == 0,
+                "mnn_det_lstm_pack: W [K, 4 units] with K = inputs + units, units %% 32 == 0, Wp 16-byte aligned (K=%d units=%d)", K, units);
+    const long total = (long)(mnn_det_lstm_pack_bytes(K, units) / sizeof(float4));
+    hipLaunchKernelGGL(ds_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, W, K, units, reinterpret_cast<float4*>(Wp));
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
 }
 
 extern "C" int mnn_lstm_step_det(mnn_stream_t s, int B, int njobs, const mnn_det_lstm_job* jobs) {
@@ -285,10 +391,13 @@ extern "C" int mnn_dense_det(mnn_stream_t s, int B, int njobs, const mnn_det_den
 // ------------------------------------------------------------------------------------------------------------------------------------
 static size_t scan_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
-extern "C" size_t mnn_generate_scan_workspace_bytes(int B, int n_layers, const mnn_scan_lstm_layer* layers, int n_out) {
-    if (B <= 0 || n_layers <= 0 || n_layers > MNN_SCAN_MAX_LAYERS || layers == nullptr || n_out <= 0) return 0;
+extern "C" size_t mnn_generate_scan_workspace_bytes(int B, int n_in, int n_layers, const mnn_scan_lstm_layer* layers, int n_out) {
+    if (B <= 0 || n_in <= 0 || n_layers <= 0 || n_layers > MNN_SCAN_MAX_LAYERS || layers == nullptr || n_out <= 0) return 0;
     size_t bytes = scan_align((size_t)B * (size_t)((n_out + 63) & ~63) * sizeof(float));
-    for (int l = 0; l < n_layers; ++l) bytes += 4 * scan_align((size_t)B * (size_t)layers[l].units * sizeof(float));      // c, h x two generations
+    for (int l = 0; l < n_layers; ++l) {
+        bytes += 4 * scan_align((size_t)B * (size_t)layers[l].units * sizeof(float));      // c, h x two generations
+        bytes += scan_align(mnn_det_lstm_pack_bytes((l == 0 ? n_in : layers[l - 1].units) + layers[l].units, layers[l].units));      // the layer's packed weights
+    }
     return bytes;
 }
 
@@ -300,7 +409,7 @@ extern "C" int mnn_generate_scan(mnn_stream_t s, int B, int n_intro, int num_ste
                 "mnn_generate_scan: B, n_intro > 0, 1..%d layers", MNN_SCAN_MAX_LAYERS);
     MNN_REQUIRE(dense_W && tracks > 0 && D > 0 && Hn > 0 && n_out == tracks * (Hn + D) && n_in == tracks * D && w_enc && w_dec && samples,
                 "mnn_generate_scan: the Dense layer feeds `tracks` NADEs (n_out == tracks * (Hn + D)) and a sample is the next input (n_in == tracks * D)");
-    const size_t need = mnn_generate_scan_workspace_bytes(B, n_layers, layers, n_out);
+    const size_t need = mnn_generate_scan_workspace_bytes(B, n_in, n_layers, layers, n_out);
     MNN_REQUIRE(workspace && need > 0 && workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0,
                 "mnn_generate_scan: workspace of mnn_generate_scan_workspace_bytes() bytes, 256-byte aligned");
     char* wp = static_cast<char*>(workspace);
@@ -316,6 +425,15 @@ extern "C" int mnn_generate_scan(mnn_stream_t s, int B, int n_intro, int num_ste
             hbuf[l][g] = reinterpret_cast<float*>(wp); wp += scan_align((size_t)B * layers[l].units * sizeof(float));
         }
     }
+    // the master weights repacked once per scan for the step kernel's 16-byte loads (mnn_det_lstm_pack: same numbers, same chains)
+    float* wpack[MNN_SCAN_MAX_LAYERS];
+    for (int l = 0; l < n_layers; ++l) {
+        const int K = (l == 0 ? n_in : layers[l - 1].units) + layers[l].units;
+        wpack[l] = reinterpret_cast<float*>(wp);
+        wp += scan_align(mnn_det_lstm_pack_bytes(K, layers[l].units));
+        const int rc = mnn_det_lstm_pack(s, layers[l].W, K, layers[l].units, wpack[l]);
+        if (rc != MNN_OK) return rc;
+    }
     int cur = 0;                                               // generation holding the current state; -1 before the first step (zero state)
     bool have_state = false;
     auto stack_step = [&](const uint8_t* x, int ld_x) -> int {      // one step of the whole stack on a u8 input block
@@ -328,7 +446,7 @@ extern "C" int mnn_generate_scan(mnn_stream_t s, int B, int n_intro, int num_ste
             else { jb.x = hbuf[l - 1][nxt]; jb.x_dtype = MNN_F32; jb.n_x = layers[l - 1].units; jb.ld_x = layers[l - 1].units; jb.es_x = 1; }
             jb.h_prev = have_state ? hbuf[l][cur] : nullptr;
             jb.c_prev = have_state ? cbuf[l][cur] : nullptr;
-            jb.W = layers[l].W; jb.bias = layers[l].bias; jb.c_out = cbuf[l][nxt]; jb.h_out = hbuf[l][nxt]; jb.units = u;
+            jb.W = layers[l].W; jb.Wp = wpack[l]; jb.bias = layers[l].bias; jb.c_out = cbuf[l][nxt]; jb.h_out = hbuf[l][nxt]; jb.units = u;
             const int rc = mnn_lstm_step_det(s, B, 1, &jb);
             if (rc != MNN_OK) return rc;
         }

@@ -883,7 +883,26 @@ def lstm_step_det(jobs):
         a.x2, a.n_x2, a.ld_x2 = (_ptr(x2) if x2 is not None else None), n_x2, (x2.stride(0) if x2 is not None else 0)
         a.h_prev, a.c_prev = _ptr(j.get("h_prev")), _ptr(j.get("c_prev"))
         a.W, a.bias, a.c_out, a.h_out, a.units = _ptr(W), _ptr(b), _ptr(j["c_out"]), _ptr(j["h_out"]), u
+        Wp = j.get("Wp")                                     # det_lstm_pack(W, u): the same numbers in the kernel's load order (optional)
+        _req(Wp is None or (Wp.dtype == torch.float32 and Wp.is_contiguous() and Wp.numel() * 4 == det_lstm_pack_bytes(n_x + n_x2 + u, u) and Wp.data_ptr() % 16 == 0),
+             "lstm_step_det: Wp is det_lstm_pack(W, units)")
+        a.Wp = _ptr(Wp)
     call("mnn_lstm_step_det", _stream(), B, len(jobs), arr)
+
+
+def det_lstm_pack_bytes(K, units):
+    return int(_lib.load().mnn_det_lstm_pack_bytes(int(K), int(units)))
+
+
+def det_lstm_pack(W, units, out=None):
+    """W f32 [K, 4 units] (TF layout) repacked for lstm_step_det's job["Wp"]; to be redone whenever W changes."""
+    _req(W.dtype == torch.float32 and W.is_contiguous() and W.dim() == 2 and W.shape[1] == 4 * units and W.shape[0] > units, "det_lstm_pack: W f32 [K, 4 units]")
+    n = det_lstm_pack_bytes(W.shape[0], units) // 4
+    if out is None:
+        out = torch.empty(n, device=W.device, dtype=torch.float32)
+    _req(out.dtype == torch.float32 and out.numel() == n and out.is_contiguous() and out.data_ptr() % 16 == 0, "det_lstm_pack: out")
+    call("mnn_det_lstm_pack", _stream(), _ptr(W), W.shape[0], int(units), _ptr(out))
+    return out
 
 
 def dense_det(jobs):
@@ -920,7 +939,7 @@ def generate_scan(intro, num_steps, layers, dense_W, dense_bias, tracks, D, Hn, 
     _req(dense_bias is None or (dense_bias.dtype == torch.float32 and dense_bias.is_contiguous() and dense_bias.numel() == n_out), "generate_scan: Dense bias")
     for w in (w_enc, w_dec):
         _req(w.dtype == torch.float32 and w.is_contiguous() and w.numel() == tracks * D * Hn, "generate_scan: NADE weights f32 [tracks, D, Hn]")
-    need = int(_lib.load().mnn_generate_scan_workspace_bytes(B, len(layers), arr, n_out))
+    need = int(_lib.load().mnn_generate_scan_workspace_bytes(B, n_in, len(layers), arr, n_out))
     ws = torch.empty(need + 256, dtype=torch.uint8, device=intro.device)
     off = (-ws.data_ptr()) % 256
     samples = torch.empty((B, int(num_steps), n_in), dtype=torch.uint8, device=intro.device)

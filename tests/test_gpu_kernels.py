@@ -822,6 +822,17 @@ def test_det_lstm_step_and_dense_bit_exact():
     ops.lstm_step_det(jobs)                                            # six jobs of different widths: ONE launch
     for j, (c_ref, h_ref) in zip(jobs, refs):
         assert np.array_equal(j["c_out"].cpu().numpy(), c_ref) and np.array_equal(j["h_out"].cpu().numpy(), h_ref)
+    # the same six steps from PACKED weights (mnn_det_lstm_pack: the numbers of W in the kernel's load order -- what mnn_generate_scan runs on):
+    # the same bits, also with packed and in-place jobs mixed in one launch
+    for mixed in (False, True):
+        for i, j in enumerate(jobs):
+            j["c_out"].fill_(-3.0); j["h_out"].fill_(-3.0)
+            j.pop("Wp", None)
+            if not (mixed and i % 2):
+                j["Wp"] = ops.det_lstm_pack(j["W"], j["c_out"].shape[1])
+        ops.lstm_step_det(jobs)
+        for j, (c_ref, h_ref) in zip(jobs, refs):
+            assert np.array_equal(j["c_out"].cpu().numpy(), c_ref) and np.array_equal(j["h_out"].cpu().numpy(), h_ref), (mixed, j["W"].shape)
     djobs, drefs = [], []
     for (K, N, with_bias) in [(256, 696, True), (32, 5, False), (512, 344, True), (1101, 40, True), (7, 33, False)]:
         x = rng.standard_normal((B, K)).astype(np.float32)
