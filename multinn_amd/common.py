@@ -174,6 +174,18 @@ def zeros_init(shape):
 class Model(abc.ABC):
     """models/common/model.py:9-234."""
 
+    # store.step the 16-bit packed copies were made at; -1 = stale.  Every "stale" mark also starts a new pack epoch: the f32 repacks of the
+    # deterministic sampling steps (LstmStack.det_job) are redone once per epoch -- i.e. once per scan, inside its captured graph
+    @property
+    def _packed_step(self):
+        return self.__dict__.get("_packed_step_v", -1)
+
+    @_packed_step.setter
+    def _packed_step(self, v):
+        self.__dict__["_packed_step_v"] = v
+        if v == -1:
+            self.__dict__["_pack_epoch"] = self.__dict__.get("_pack_epoch", 0) + 1
+
     def __init__(self, name="model"):
         self._name = name
         self._is_built = False

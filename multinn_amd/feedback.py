@@ -19,6 +19,7 @@ class FeedbackRnn(Model):
         self._rnn.declare(self.store, num_inputs, torch.Generator().manual_seed(seed), prefix="feedback/rnn")
         self.store.materialize()
         self._stack = LstmStack(self._rnn, self.store, self.dtype)
+        self._stack.owner = self                         # (its pack epoch dates the stack's repacked sampling weights: LstmStack.det_job)
         self._rnn.build_cell(False)
         self.num_inputs, self.num_units = num_inputs, list(self._rnn.num_units)
         self.seed, self.row0, self._ctx = seed, 0, None

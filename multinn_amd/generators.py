@@ -671,15 +671,24 @@ class LstmStack:
         return y[0], [(c, h) for c, h in final]
 
     # -- deterministic f32 single steps (csrc/det_step.hip): the arithmetic of every sampling scan -----------------------------------
+    owner = None          # the estimator this stack belongs to (its pack epoch dates the repacked weights below)
+    _det_pack, _det_pack_key = None, None
+
     def det_job(self, l, x, n_x, x2, st):
-        """Descriptor of layer l's deterministic step (ops.lstm_step_det) with fresh f32 outputs.  The master weights are read in place."""
+        """Descriptor of layer l's deterministic step (ops.lstm_step_det) with fresh f32 outputs.  The master weights are read through their
+        repacked copy (ops.det_lstm_pack: the same numbers in the kernel's load order), remade when the weights may have changed: a new
+        store.step or a new pack epoch of the owner -- once per sampling scan, inside its graph."""
         u = self.rnn.num_units[l]
         ref = x if x is not None else x2
         c = torch.empty((ref.shape[0], u), device=ref.device)
         h = torch.empty_like(c)
         pre = self.rnn.prefix
+        key = (self.store.step, getattr(self.owner, "_pack_epoch", 0))
+        if self._det_pack is None or self._det_pack_key != key:
+            self._det_pack = [ops.det_lstm_pack(self.store[f"{pre}/cell_{k}/kernel"], self.rnn.num_units[k]) for k in range(len(self.rnn.num_units))]
+            self._det_pack_key = key
         return dict(x=x, n_x=n_x, x2=x2, h_prev=None if st is None else st[1], c_prev=None if st is None else st[0],
-                    W=self.store[f"{pre}/cell_{l}/kernel"], bias=self.store[f"{pre}/cell_{l}/bias"], c_out=c, h_out=h)
+                    W=self.store[f"{pre}/cell_{l}/kernel"], Wp=self._det_pack[l], bias=self.store[f"{pre}/cell_{l}/bias"], c_out=c, h_out=h)
 
     def det_step(self, x, state, x2=None):
         """One deterministic f32 step of the stack: x u8 | f32 [B, n_x] (unit inner stride), optional x2 f32 [B, n_x2] concatenated behind
@@ -801,6 +810,7 @@ class RnnEstimator(Generator):
         self._declare(self._num_inputs)
         self.store.materialize()
         self._stack = LstmStack(self._rnn, self.store, self.dtype)
+        self._stack.owner = self
         self._trainable_variables = [self.store[n] for n in self.store.names()]
         self._variables = dict(self.store.views)
 
