@@ -26,16 +26,19 @@ template <> struct Elem<float>  { static constexpr int PER16 = 4; static constex
 // 16-bit C outputs: the mnn_dtype code of C (MNN_F32 = plain f32) travels as `c16`; a 16-bit value is converted by its own flavour
 __device__ __forceinline__ h16_t cvt_c16(float v, int c16) { return c16 == MNN_F16 ? f32_to_f16(v) : f32_to_bf16(v); }
 
-template <typename T, int BM, int BN, int WM, int WN>
+// KH = 2 (f32 only): the workgroup has a second set of WM x WN waves that takes the other half of every K chunk (the step kernels of the f32
+// recurrence: one wave per 32 x 128 tile put 512 waves on 1024 SIMDs -- half of the f32 matrix-core rate at best); reduce_kh() adds the halves.
+template <typename T, int BM, int BN, int WM, int WN, int KH = 1>
 struct GemmCore {
-    static constexpr int NT = WM * WN * 64;
+    static constexpr int NT = WM * WN * KH * 64;
     static constexpr int TM = BM / WM / 32;
     static constexpr int TN = BN / WN / 32;
-    static constexpr int A_CHUNKS = BM * 4 / NT;   // 16-byte pieces per thread per stage
-    static constexpr int B_CHUNKS = BN * 4 / NT;
+    static constexpr int A_CHUNKS = (BM * 4 + NT - 1) / NT;   // 16-byte pieces per thread per stage
+    static constexpr int B_CHUNKS = (BN * 4 + NT - 1) / NT;
     static constexpr int LDS_BYTES = 2 * (BM + BN) * LDS_ROW;
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile/wave mismatch");
-    static_assert((BM * 4) % NT == 0 && (BN * 4) % NT == 0, "staging mismatch");
+    static_assert(KH == 1 || (KH == 2 && sizeof(T) == 4), "the in-workgroup K split is built for f32 operands");
+    static_assert(KH == 1 || WM * WN * 16 * 64 * 4 <= LDS_BYTES, "reduce_kh stages one tile per wave in the stage buffers");
 
     uint4 ra[A_CHUNKS], rb[B_CHUNKS];
 
@@ -43,13 +46,13 @@ struct GemmCore {
                                           int N, int n0, int K, int k0, int tid) {
 #pragma unroll
         for (int s = 0; s < A_CHUNKS; ++s) {
-            const int idx = tid + s * NT, row = idx >> 2, c = idx & 3;
+            const int idx = tid + s * NT, row = min(idx >> 2, BM - 1), c = idx & 3;     // (BM * 4 < NT: the surplus threads repeat the last row)
             const int gr = m0 + row, gk = k0 + c * Elem<T>::PER16;
             ra[s] = (gr < M && gk < K) ? *reinterpret_cast<const uint4*>(A + (size_t)gr * lda + gk) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int s = 0; s < B_CHUNKS; ++s) {
-            const int idx = tid + s * NT, row = idx >> 2, c = idx & 3;
+            const int idx = tid + s * NT, row = min(idx >> 2, BN - 1), c = idx & 3;
             const int gr = n0 + row, gk = k0 + c * Elem<T>::PER16;
             rb[s] = (gr < N && gk < K) ? *reinterpret_cast<const uint4*>(B + (size_t)gr * ldb + gk) : make_uint4(0, 0, 0, 0);
         }
@@ -57,17 +60,17 @@ struct GemmCore {
     __device__ __forceinline__ void lstore(char* sA, char* sB, int tid) {
 #pragma unroll
         for (int s = 0; s < A_CHUNKS; ++s) {
-            const int idx = tid + s * NT, row = idx >> 2, c = idx & 3;
+            const int idx = tid + s * NT, row = min(idx >> 2, BM - 1), c = idx & 3;     // (surplus threads store the same bytes again)
             *reinterpret_cast<uint4*>(sA + row * LDS_ROW + c * 16) = ra[s];
         }
 #pragma unroll
         for (int s = 0; s < B_CHUNKS; ++s) {
-            const int idx = tid + s * NT, row = idx >> 2, c = idx & 3;
+            const int idx = tid + s * NT, row = min(idx >> 2, BN - 1), c = idx & 3;
             *reinterpret_cast<uint4*>(sB + row * LDS_ROW + c * 16) = rb[s];
         }
     }
     // one 64-byte K-chunk of MFMAs for this wave
-    __device__ __forceinline__ void compute(const char* sA, const char* sB, int wm, int wn, int lane, f32x16_t (&acc)[TM][TN]) {
+    __device__ __forceinline__ void compute(const char* sA, const char* sB, int wm, int wn, int lane, f32x16_t (&acc)[TM][TN], int kh = 0) {
         const int r = lane & 31, h = lane >> 5;
         const char* pa = sA + (wm * (BM / WM) + r) * LDS_ROW;
         const char* pb = sB + (wn * (BN / WN) + r) * LDS_ROW;
@@ -89,6 +92,20 @@ struct GemmCore {
         } else {
             // K order inside the chunk is permuted (lane half h owns k = 8h..8h+7) so each lane reads
             // 32 contiguous bytes; A and B use the same permutation, so the product is unchanged.
+            if constexpr (KH == 2) {                     // this wave's half of the chunk: k = 8 h + 4 kh .. + 3 (16 bytes per lane and tile row)
+                f32x4_t a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4_t*>(pa + i * 32 * LDS_ROW + h * 32 + kh * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4_t*>(pb + j * 32 * LDS_ROW + h * 32 + kh * 16);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
+                return;
+            }
             f32x4_t a[TM][2], b[TN][2];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -113,8 +130,9 @@ struct GemmCore {
     // full K loop [kc0, kc1) in chunk units; acc must be initialised by the caller
     __device__ __forceinline__ void run(const T* __restrict__ A, int lda, int M, int m0, const T* __restrict__ B, int ldb, int N,
                                         int n0, int K, int kc0, int kc1, char* smem, f32x16_t (&acc)[TM][TN]) {
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-        const int wm = wave / WN, wn = wave % WN;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int kh = wave / (WM * WN), wq = wave % (WM * WN);
+        const int wm = wq / WN, wn = wq % WN;
         char* sA[2] = {smem, smem + (BM + BN) * LDS_ROW};
         char* sB[2] = {smem + BM * LDS_ROW, smem + (BM + BN) * LDS_ROW + BM * LDS_ROW};
         if (kc0 >= kc1) return;
@@ -125,11 +143,35 @@ struct GemmCore {
         for (int kc = kc0; kc < kc1; ++kc) {
             const bool more = kc + 1 < kc1;
             if (more) gload(A, lda, M, m0, B, ldb, N, n0, K, (kc + 1) * Elem<T>::PER_CHUNK, tid);
-            compute(sA[cur], sB[cur], wm, wn, lane, acc);
+            compute(sA[cur], sB[cur], wm, wn, lane, acc, kh);
             if (more) lstore(sA[cur ^ 1], sB[cur ^ 1], tid);
             __syncthreads();
             cur ^= 1;
         }
+    }
+    // KH == 2, after run() (its last barrier has freed the stage buffers): the second wave set's partial tiles are added into the first set's,
+    // tile by tile through `smem`.  Returns true for the waves that now hold the sums (the epilogue is theirs; wave % (WM WN) is their tile slot).
+    __device__ __forceinline__ bool reduce_kh(char* smem, f32x16_t (&acc)[TM][TN]) {
+        if constexpr (KH == 1) return true;
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int kh = wave / (WM * WN), wq = wave % (WM * WN);
+        float* red = reinterpret_cast<float*>(smem) + wq * 16 * 64;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (i + j > 0) __syncthreads();
+                if (kh == 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[i][j][r];
+                }
+                __syncthreads();
+                if (kh == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += red[r * 64 + lane];
+                }
+            }
+        return kh == 0;
     }
 };
 
@@ -674,12 +716,13 @@ extern "C" int mnn_gemm_tn(mnn_stream_t s, int dtype, int M, int N, int K, const
 // block = 64 rows x 128 pre-activation columns = 32 units x 4 gates (gate-interleaved layout),
 // 2 waves, each 32 rows x 128 cols -> every lane owns all four gates of its (row, unit) elements.
 // ----------------------------------------------------------------------------------------------
+template <typename T> struct StepKH { static constexpr int value = sizeof(T) == 4 ? 2 : 1; };      // f32: two K halves per tile (256 threads)
 template <typename T>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128 * StepKH<T>::value)
 lstm_fwd_step_kernel(const T* __restrict__ h_prev, const T* __restrict__ wh_t, const float* __restrict__ xproj,
                      const float* __restrict__ c_prev, float* __restrict__ gates, float* __restrict__ c_out, T* __restrict__ h_out,
                      int B, int U) {
-    using Core = GemmCore<T, 64, 128, 2, 1>;
+    using Core = GemmCore<T, 64, 128, 2, 1, StepKH<T>::value>;
     __shared__ __attribute__((aligned(16))) char smem[Core::LDS_BYTES];
     const int nt = blockIdx.x, m0 = blockIdx.y * 64, n0 = nt * 128;
     const int N4 = 4 * U;
@@ -692,8 +735,9 @@ lstm_fwd_step_kernel(const T* __restrict__ h_prev, const T* __restrict__ wh_t, c
         Core core;
         const int nchunks = (U + Elem<T>::PER_CHUNK - 1) / Elem<T>::PER_CHUNK;
         core.run(h_prev, U, B, m0, wh_t, U, N4, n0, U, 0, nchunks, smem, acc);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (!core.reduce_kh(smem, acc)) return;
+    } else if (threadIdx.x >= 128) return;               // (no recurrent term: the first wave set alone runs the pointwise part)
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 1;
     const int col = lane & 31, unit = nt * 32 + col;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1253,7 +1297,7 @@ extern "C" int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int uni
             hipLaunchKernelGGL(lstm_fwd_step_kernel<f16_t>, grid, dim3(128), 0, st, (const f16_t*)hp, (const f16_t*)wh_t, xp, cp, gt, ct,
                                (f16_t*)ht, B, units);
         else
-            hipLaunchKernelGGL(lstm_fwd_step_kernel<float>, grid, dim3(128), 0, st, (const float*)hp, (const float*)wh_t, xp, cp, gt, ct,
+            hipLaunchKernelGGL(lstm_fwd_step_kernel<float>, grid, dim3(256), 0, st, (const float*)hp, (const float*)wh_t, xp, cp, gt, ct,
                                (float*)ht, B, units);
     }
     MNN_LAUNCH_CHECK();
@@ -1268,31 +1312,35 @@ extern "C" int mnn_lstm_seq_fwd(mnn_stream_t s, int dtype, int T, int B, int uni
 
 // ----------------------------------------------------------------------------------------------
 // LSTM backward step: dh = dh_ext[t] + dz[t+1] . Wh^T ; pointwise -> dz[t], dc (in place)
-// block = 64 rows x 64 units, 2 waves, each 32 rows x 64 units.
+// block = 64 rows x BU units (64; f32: 32), 2 waves, each 32 rows x BU units (f32: a second wave pair takes the other half of every K chunk --
+// 64 x 64 tiles on two waves put 256 waves on 1024 SIMDs: 109 us per step at B = 1024, U = 512).
 // ----------------------------------------------------------------------------------------------
+template <typename T> struct StepBU { static constexpr int value = sizeof(T) == 4 ? 32 : 64; };
 template <typename T>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128 * StepKH<T>::value)
 lstm_bwd_step_kernel(const T* __restrict__ dz_next, const T* __restrict__ wh_p, const float* __restrict__ dh_ext,
                      const float* __restrict__ gates, const float* __restrict__ c_t, const float* __restrict__ c_prev,
                      float* __restrict__ dc, float* __restrict__ dz, T* __restrict__ dzT, float* __restrict__ dh_out, int B, int U,
                      int first) {
-    using Core = GemmCore<T, 64, 64, 2, 1>;
+    constexpr int BU = StepBU<T>::value, TNU = BU / 32;
+    using Core = GemmCore<T, 64, BU, 2, 1, StepKH<T>::value>;
     __shared__ __attribute__((aligned(16))) char smem[Core::LDS_BYTES];
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BU;
     const int N4 = 4 * U;
-    f32x16_t acc[1][2];
+    f32x16_t acc[1][TNU];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TNU; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
     if (dz_next != nullptr) {
         Core core;
         const int nchunks = (N4 + Elem<T>::PER_CHUNK - 1) / Elem<T>::PER_CHUNK;
         core.run(dz_next, N4, B, m0, wh_p, N4, U, n0, N4, 0, nchunks, smem, acc);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (!core.reduce_kh(smem, acc)) return;
+    } else if (threadIdx.x >= 128) return;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 1;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TNU; ++j) {
         const int unit = n0 + j * 32 + (lane & 31);
         if (unit >= U) continue;
         const int pc = gate_perm_col(0, unit);
@@ -1373,7 +1421,7 @@ extern "C" int mnn_lstm_seq_bwd(mnn_stream_t s, int dtype, int T, int B, int uni
                                dh_ext + (size_t)tt * us, gates + (size_t)tt * zs, c + (size_t)tt * us, cp, dc, dzt, (f16_t*)dzTt, dho, B,
                                units, t == T - 1 ? 1 : 0);
         else
-            hipLaunchKernelGGL(lstm_bwd_step_kernel<float>, grid, dim3(128), 0, st, (const float*)dzn, (const float*)wh_p,
+            hipLaunchKernelGGL(lstm_bwd_step_kernel<float>, dim3(cdiv(units, 32), cdiv(B, 64)), dim3(256), 0, st, (const float*)dzn, (const float*)wh_p,
                                dh_ext + (size_t)tt * us, gates + (size_t)tt * zs, c + (size_t)tt * us, cp, dc, dzt, (float*)dzTt, dho, B,
                                units, t == T - 1 ? 1 : 0);
     }
