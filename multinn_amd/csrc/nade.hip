@@ -885,7 +885,7 @@ __global__ void __launch_bounds__(64)
 nade_sample_chunk_kernel(SampleJobs J, int N, int D, int Hn, float temperature, uint32_t row0, uint32_t sub, long s_row_stride, int s_elem_stride) {
     constexpr int NB = sch_nb(G);
     constexpr int KSH = G == 16 ? 2 : 3;                      // lane l decides visible l >> KSH of the chunk
-    constexpr int WAITN = (NB - 1) * 2 * G < 63 ? (NB - 1) * 2 * G : 63;        // (vmcnt counts to 63: G = 16 waits for one copy more than it needs)
+    constexpr int WAITN = (NB - 2) * 2 * G;                   // copies that may still be in flight when a chunk is needed: the NB - 2 chunks behind it
     // ring [NB][w_dec | w_enc][G][256] f32 (64 KB) | logit / log term [Dp] f32 | b_dec [Dp] f32 | 256 uniforms | draws [Dp] u8
     extern __shared__ __attribute__((aligned(16))) unsigned char nade_sample_smem[];
     float* ring = reinterpret_cast<float*>(nade_sample_smem);
@@ -958,7 +958,7 @@ nade_sample_chunk_kernel(SampleJobs J, int N, int D, int Hn, float temperature, 
     asm volatile("" ::"v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));     // the initial states are evaluated HERE: behind the copies they would wait for all 64 of them
     __builtin_amdgcn_sched_barrier(0);                       // the loads above are older than every DMA: the counted waits below cover them
 #pragma unroll
-    for (int b = 0; b < NB; ++b) stage(b, b);
+    for (int b = 0; b < NB - 1; ++b) stage(b, b);            // NB - 1 chunks ahead: the last slot is refilled while its successor is evaluated (below)
     const int kq = lane >> KSH;                              // the visible of the chunk this lane decides
     const int nchunks = (D + G - 1) / G;
     // what a chunk's passes read besides h: its eight w_dec rows -- visibles (2 p, 2 p + 1) side by side, one packed FMA serves both --, the lane's
@@ -994,12 +994,15 @@ nade_sample_chunk_kernel(SampleJobs J, int N, int D, int Hn, float temperature, 
         for (int b = 0; b < NB; ++b) {
             const int c = c0 + b;
             if (c < nchunks) {                               // uniform
-                // chunk c's sixteen copies are the oldest in flight; (NB - 1) chunks behind them may still be on their way
+                // chunk c's 2 G copies are the oldest in flight; (NB - 2) chunks behind them may still be on their way
                 SCH_TR(0, c);
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
                 SCH_TR(1, c);
                 ChunkIn ci;
                 fetch_in(b, c, ci);
+                // the slot chunk c - 1 has just left takes chunk c + NB - 1: its 2 G copy instructions issue while the LDS reads above are on their way
+                // (behind the passes, on their own, they were 200-280 ns of every chunk).  Always issued (rows clamped): the wait count stays a constant.
+                stage((b + NB - 1) % NB, c + NB - 1);
                 const int i0 = c * G;
                 const int rsh = (FULL && D >= G) ? i0 - min(i0, D - G) : 0;
                 const float* re = ring + (b * 2 + 1) * G * 256 + rsh * 256;
@@ -1088,9 +1091,6 @@ nade_sample_chunk_kernel(SampleJobs J, int N, int D, int Hn, float temperature, 
                 SCH_TR(2, c);
                 SCH_TR(3, c);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            stage(b, c + NB);                                // always issued (rows clamped): the wait count above stays a constant
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // after the scan: as nade_sample_kernel
