@@ -210,8 +210,9 @@ def sampling_scan(gen, P, M, n=72, intro=32, steps=128, reps=3):
     t, dens = timed()
     res["pianoroll_like"] = {"value": n * steps / t, "us_per_step": 1e6 * t / steps, "density": round(dens, 4)}
     bias.copy_(saved)
-    # the scan is a serial chain of D conditionals per generated step: its bound is the VALU issue rate of one wave per (row, track), not
-    # HBM or MFMA; the algorithmic work per generated row is D*Hn MACs + (1 + draws of 1) * Hn sigmoids, reported against the f32 vector peak
+    # the scan is a serial chain per generated step (D / 16 + draws-of-1 passes of one wave per (row, track): nade_sample_chunk_kernel; then two
+    # LSTM steps and a Dense step of ~10 us each): its bound is the latency of dependent instructions, not HBM or MFMA; the algorithmic work per
+    # generated row is D*Hn MACs + (1 + draws of 1) * Hn sigmoids, reported against the f32 vector peak
     fma = n * steps * (D * Hn + dens * D * Hn)
     res["roofline"] = {"bound": "valu-latency", "achieved_tflops": 2 * fma / t / 1e12, "peak_tflops": PEAK_VALU_F32_TFLOPS,
                        "frac": 2 * fma / t / 1e12 / PEAK_VALU_F32_TFLOPS,
