@@ -330,11 +330,15 @@ def attach_counters(rf, workload, precision):
     if not kern:
         return
     rec = {}
+    # gated pairs of launches (both instantiations of a kernel are launched, a device word lets one leave at its first instruction -- the NADE
+    # forwards, nade_bwd_kernel<.., USEU>): the one that left moved no data and must not be averaged in as a launch
+    tdata = _recorded(workload, precision, "pmc_traffic")[0]
+    idle = {k for k, v in (tdata or {}).get("kernels", {}).items() if k.startswith(kern) and v.get("hbm_side_bytes_per_launch", 0.0) < 1e6}
     for kind in ("sq_counters", "pmc_traffic"):
         data, fn, same, here = _recorded(workload, precision, kind)
         if data is None:
             continue
-        hit = [v for k, v in data.get("kernels", {}).items() if k.startswith(kern)]
+        hit = [v for k, v in data.get("kernels", {}).items() if k.startswith(kern) and k not in idle]
         if not hit:
             continue
         calls = sum(h["calls"] for h in hit)
