@@ -43,9 +43,9 @@ enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_ST
 
 /* ABI version of THIS header: bumped whenever a signature or a descriptor struct changes.  mnn_version() returns the value the library
  * was built with; a loader must compare the two before its first call (multinn_amd/_lib.py load() does) -- a library built for another
- * version reads garbage arguments without any diagnosis otherwise.  118 (round 6): mnn_det_lstm_job gained `Wp`, + mnn_det_lstm_pack / _pack_bytes, mnn_generate_scan_workspace_bytes gained `n_in`.  117 (round 6): + mnn_lstm_cluster_bwd_ok, + mnn_ragged_index / mnn_rows_gather16 / mnn_rows_scatter_f32, `n_rows_dev` on the gated NADE forwards and mnn_nade_logprob_bwd, `inv` / `hdr` on mnn_pianoroll_shift_timemajor_t, + mnn_lstm_resident_{fwd,bwd}_multi / mnn_lstm_cluster_{fwd,bwd}_multi / _bwd_multi_ok, `unsafe` on mnn_nade_logprob_fwd_gated, `unsafe` on mnn_nade_logprob_bwd.  116: + mnn_lstm_cluster_ok / _fwd / _bwd.  115: mnn_step_increment gained `sumsq`, `clip_norm`.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
+ * version reads garbage arguments without any diagnosis otherwise.  119 (round 6): mnn_det_dense_job gained `Wp`, + mnn_det_dense_pack / _pack_bytes.  118 (round 6): mnn_det_lstm_job gained `Wp`, + mnn_det_lstm_pack / _pack_bytes, mnn_generate_scan_workspace_bytes gained `n_in`.  117 (round 6): + mnn_lstm_cluster_bwd_ok, + mnn_ragged_index / mnn_rows_gather16 / mnn_rows_scatter_f32, `n_rows_dev` on the gated NADE forwards and mnn_nade_logprob_bwd, `inv` / `hdr` on mnn_pianoroll_shift_timemajor_t, + mnn_lstm_resident_{fwd,bwd}_multi / mnn_lstm_cluster_{fwd,bwd}_multi / _bwd_multi_ok, `unsafe` on mnn_nade_logprob_fwd_gated, `unsafe` on mnn_nade_logprob_bwd.  116: + mnn_lstm_cluster_ok / _fwd / _bwd.  115: mnn_step_increment gained `sumsq`, `clip_norm`.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
  * mnn_pianoroll_shift_timemajor_t / mnn_grad_rows_fanout and the `f16` descriptor fields of round 3 are part of it. */
-#define MNN_ABI_VERSION 118
+#define MNN_ABI_VERSION 119
 int mnn_version(void);
 const char* mnn_last_error(void);
 
@@ -500,12 +500,15 @@ typedef struct {
     const float* W; int ld_w; int N;                        /* [K, ld_w >= N] */
     const float* bias;                                      /* [N] or NULL */
     float* out; int ld_out;                                 /* [B, ld_out >= N] */
+    const float* Wp;                                        /* optional: W repacked by mnn_det_dense_pack (see mnn_det_lstm_job.Wp) */
 } mnn_det_dense_job;
 int mnn_lstm_step_det(mnn_stream_t s, int B, int njobs, const mnn_det_lstm_job* jobs);
 /* W f32 [K = inputs + units, 4 units] (TF layout) -> Wp (mnn_det_lstm_pack_bytes(K, units) bytes, 16-byte aligned) for mnn_det_lstm_job.Wp; to be
  * redone whenever W changes (mnn_generate_scan does it once per scan, into its workspace) */
 size_t mnn_det_lstm_pack_bytes(int K, int units);
 int mnn_det_lstm_pack(mnn_stream_t s, const float* W, int K, int units, float* Wp);
+size_t mnn_det_dense_pack_bytes(int K, int N);
+int mnn_det_dense_pack(mnn_stream_t s, const float* W, int K, int N, int ld_w, float* Wp);
 int mnn_dense_det(mnn_stream_t s, int B, int njobs, const mnn_det_dense_job* jobs);
 
 /* mnn_generate_scan (rnn_estimator.py:271-323 `generate`): the WHOLE sampling scan of an LSTM-NADE / LSTM-MultiNADE generator in

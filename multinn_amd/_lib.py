@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MULTINN_HIP_LIB", os.path.join(HERE, "libmultinn_hip.so"))   # override: A/B builds of the same ABI
 
-ABI_VERSION = 118          # == MNN_ABI_VERSION of include/multinn_hip.h; load() refuses a library built for another one
+ABI_VERSION = 119          # == MNN_ABI_VERSION of include/multinn_hip.h; load() refuses a library built for another one
 F32, BF16, U8, F16 = 0, 1, 2, 3
 GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_A_KBLOCK32 = 1, 2, 8
 
@@ -60,6 +60,8 @@ SIGNATURES = {
     "mnn_generate_scan_workspace_bytes": (_sz, [_i, _i, _i, _p, _i]),
     "mnn_det_lstm_pack_bytes": (_sz, [_i, _i]),
     "mnn_det_lstm_pack": (_i, [_p, _p, _i, _i, _p]),
+    "mnn_det_dense_pack_bytes": (_sz, [_i, _i]),
+    "mnn_det_dense_pack": (_i, [_p, _p, _i, _i, _i, _p]),
     "mnn_generate_scan": (_i, [_p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _u64, _u32, _p, _p, _sz]),
     "mnn_comm_unique_id": (_i, [_p]),
     "mnn_comm_init": (_i, [C.POINTER(_p), _i, _i, _p]),
@@ -85,7 +87,7 @@ class ScanLstmLayer(C.Structure):
 
 class DetDenseJob(C.Structure):
     """mnn_det_dense_job (include/multinn_hip.h)."""
-    _fields_ = [("x", _p), ("ld_x", _i), ("K", _i), ("W", _p), ("ld_w", _i), ("N", _i), ("bias", _p), ("out", _p), ("ld_out", _i)]
+    _fields_ = [("x", _p), ("ld_x", _i), ("K", _i), ("W", _p), ("ld_w", _i), ("N", _i), ("bias", _p), ("out", _p), ("ld_out", _i), ("Wp", _p)]
 
 
 class LstmFwdLayer(C.Structure):

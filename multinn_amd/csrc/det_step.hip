@@ -137,9 +137,10 @@ __host__ __device__ inline int ds_pack_q4max(int K) { const int kc = (min(DS_KC,
 __host__ __device__ inline int ds_pack_nchunks(int K) { return (K + DS_KC - 1) / DS_KC; }
 #define DS_P4MAX 32                  // float4 per lane and quarter of a full chunk: ceil(ceil(512 / 4) / 4)
 
-__global__ void __launch_bounds__(256) ds_pack_kernel(const float* __restrict__ W, int K, int u, float4* __restrict__ Wp) {
+// dense_n == 0: LSTM kernel [K, 4 u] (block = 8 units x 4 gates); dense_n = N > 0: Dense kernel [K, ld_w >= N] (block = 32 columns, clamped at N - 1)
+__global__ void __launch_bounds__(256) ds_pack_kernel(const float* __restrict__ W, int K, int u, float4* __restrict__ Wp, int dense_n, int ld_w) {
     const int q4max = ds_pack_q4max(K), nch = ds_pack_nchunks(K);
-    const long total = (long)(u / 8) * nch * DS_SPLIT * q4max * 64;
+    const long total = (long)(dense_n > 0 ? (dense_n + 31) / 32 : u / 8) * nch * DS_SPLIT * q4max * 64;
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const int lane = (int)(t & 63);
@@ -151,12 +152,13 @@ __global__ void __launch_bounds__(256) ds_pack_kernel(const float* __restrict__ 
     const int r = lane & 31, hh = lane >> 5;
     const int k0 = c * DS_KC, kc = (min(DS_KC, K - k0) + 1) & ~1;
     const int q = ds_quarter(kc), p0 = min(sq * q, kc / 2), p1 = min(p0 + q, kc / 2);
-    const size_t col = (size_t)(r >> 3) * u + blk * 8 + (r & 7);
+    const size_t col = dense_n > 0 ? (size_t)min(blk * 32 + r, dense_n - 1) : (size_t)(r >> 3) * u + blk * 8 + (r & 7);
+    const size_t ldw = dense_n > 0 ? (size_t)ld_w : (size_t)4 * u;
     float v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int pp = p0 + 4 * j4 + e, k = k0 + 2 * pp + hh;
-        v[e] = (pp < p1 && k < K) ? W[(size_t)k * 4 * u + col] : 0.f;
+        v[e] = (pp < p1 && k < K) ? W[(size_t)k * ldw + col] : 0.f;
     }
     Wp[t] = make_float4(v[0], v[1], v[2], v[3]);
 }
@@ -289,14 +291,25 @@ __global__ void __launch_bounds__(256) dense_det_kernel(DetDenseJobs J, int B) {
     ds_f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const float4* __restrict__ wpk = reinterpret_cast<const float4*>(jb.Wp);
+    const int q4max = ds_pack_q4max(K), nch = ds_pack_nchunks(K);
     for (int k0 = 0; k0 < K; k0 += DS_KC) {
         const int kc = (min(DS_KC, K - k0) + 1) & ~1, pitch = kc | 1;
+        float4 wv[DS_P4MAX];
+        if (wpk != nullptr) {                            // packed weights (mnn_det_dense_pack): the quarter's loads all in flight, as in the LSTM step
+            const float4* __restrict__ pq = wpk + ((size_t)((blockIdx.x * nch + k0 / DS_KC) * DS_SPLIT + w) * q4max) * 64 + lane;
+#pragma unroll
+            for (int j4 = 0; j4 < DS_P4MAX; ++j4) wv[j4] = pq[(size_t)min(j4, q4max - 1) * 64];
+        }
         if (k0 > 0) __syncthreads();
         ds_stage_seg(jb.x, (size_t)jb.ld_x, (size_t)1, K, 0, B, r0, k0, kc, pitch, xs);
         if (K - k0 < kc) ds_stage_zero(K - k0, kc, pitch, xs);
         __syncthreads();
         const int q = ds_quarter(kc), p0 = min(w * q, kc / 2), p1 = min(p0 + q, kc / 2);
-        if (p1 > p0) ds_chain_chunk(w_k, k0 + 2 * p0, 2 * (p1 - p0), K, xs + r * pitch + 2 * p0, hh, acc);
+        if (p1 > p0) {
+            if (wpk != nullptr) ds_chain_packed(wv, p1 - p0, xs + r * pitch + 2 * p0, hh, acc);
+            else ds_chain_chunk(w_k, k0 + 2 * p0, 2 * (p1 - p0), K, xs + r * pitch + 2 * p0, hh, acc);
+        }
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) part[(w * 16 + e) * 64 + lane] = acc[e];
@@ -334,7 +347,18 @@ extern "C" int mnn_det_lstm_pack(mnn_stream_t s, const float* W, int K, int unit
     MNN_REQUIRE(W && Wp && K > units && units > 0 && units % 32 == 0 && ((uintptr_t)Wp & 15) == 0,
                 "mnn_det_lstm_pack: W [K, 4 units] with K = inputs + units, units %% 32 == 0, Wp 16-byte aligned (K=%d units=%d)", K, units);
     const long total = (long)(mnn_det_lstm_pack_bytes(K, units) / sizeof(float4));
-    hipLaunchKernelGGL(ds_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, W, K, units, reinterpret_cast<float4*>(Wp));
+    hipLaunchKernelGGL(ds_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, W, K, units, reinterpret_cast<float4*>(Wp), 0, 0);
+    MNN_LAUNCH_CHECK();
+    return MNN_OK;
+}
+extern "C" size_t mnn_det_dense_pack_bytes(int K, int N) {
+    if (K <= 0 || N <= 0) return 0;
+    return (size_t)((N + 31) / 32) * ds_pack_nchunks(K) * DS_SPLIT * ds_pack_q4max(K) * 64 * sizeof(float4);
+}
+extern "C" int mnn_det_dense_pack(mnn_stream_t s, const float* W, int K, int N, int ld_w, float* Wp) {
+    MNN_REQUIRE(W && Wp && K > 0 && N > 0 && ld_w >= N && ((uintptr_t)Wp & 15) == 0, "mnn_det_dense_pack: W [K, ld_w >= N], Wp 16-byte aligned (K=%d N=%d)", K, N);
+    const long total = (long)(mnn_det_dense_pack_bytes(K, N) / sizeof(float4));
+    hipLaunchKernelGGL(ds_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, W, K, 0, reinterpret_cast<float4*>(Wp), N, ld_w);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }
@@ -398,6 +422,7 @@ extern "C" size_t mnn_generate_scan_workspace_bytes(int B, int n_in, int n_layer
         bytes += 4 * scan_align((size_t)B * (size_t)layers[l].units * sizeof(float));      // c, h x two generations
         bytes += scan_align(mnn_det_lstm_pack_bytes((l == 0 ? n_in : layers[l - 1].units) + layers[l].units, layers[l].units));      // the layer's packed weights
     }
+    bytes += scan_align(mnn_det_dense_pack_bytes(layers[n_layers - 1].units, n_out));      // the Dense kernel's
     return bytes;
 }
 
@@ -434,6 +459,12 @@ extern "C" int mnn_generate_scan(mnn_stream_t s, int B, int n_intro, int num_ste
         const int rc = mnn_det_lstm_pack(s, layers[l].W, K, layers[l].units, wpack[l]);
         if (rc != MNN_OK) return rc;
     }
+    float* dpack = reinterpret_cast<float*>(wp);
+    wp += scan_align(mnn_det_dense_pack_bytes(layers[n_layers - 1].units, n_out));
+    {
+        const int rc = mnn_det_dense_pack(s, dense_W, layers[n_layers - 1].units, n_out, n_out, dpack);
+        if (rc != MNN_OK) return rc;
+    }
     int cur = 0;                                               // generation holding the current state; -1 before the first step (zero state)
     bool have_state = false;
     auto stack_step = [&](const uint8_t* x, int ld_x) -> int {      // one step of the whole stack on a u8 input block
@@ -458,7 +489,7 @@ extern "C" int mnn_generate_scan(mnn_stream_t s, int B, int n_intro, int num_ste
         mnn_det_dense_job dj;
         memset(&dj, 0, sizeof(dj));
         const int ul = layers[n_layers - 1].units;
-        dj.x = hbuf[n_layers - 1][cur]; dj.ld_x = ul; dj.K = ul; dj.W = dense_W; dj.ld_w = n_out; dj.N = n_out; dj.bias = dense_bias;
+        dj.x = hbuf[n_layers - 1][cur]; dj.ld_x = ul; dj.K = ul; dj.W = dense_W; dj.Wp = dpack; dj.ld_w = n_out; dj.N = n_out; dj.bias = dense_bias;
         dj.out = out; dj.ld_out = ld_out;
         return mnn_dense_det(s, B, 1, &dj);
     };

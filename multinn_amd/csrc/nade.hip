@@ -327,7 +327,7 @@ extern "C" int mnn_nade_logprob_fwd_gated(mnn_stream_t s, int tracks, int N, int
     // caller -- the f32 parity mode, conditionals on demand, Hn <= 128 -- keeps the direct sigmoid
 #define FWD(HQ, UT) hipLaunchKernelGGL((nade_fwd_kernel<HQ, UT>), grid, dim3(512), 0, st, tracks, N, D, Hn, v, v_track_stride, bias, ld_bias, w_enc, \
                                        w_dec, row_weight, nll, cond_p, d_bias, a_final, gate, run_if, n_rows_dev, unsafe)
-    if (unsafe != nullptr) MNN_HIP(hipMemsetAsync(unsafe, 0, sizeof(int), st));      // counted by the launch below
+    if (unsafe != nullptr) MNN_HIP(mnn_zero_async(unsafe, sizeof(int), sizeof(int), 1, st));      // counted by the launch below (a fill KERNEL: common.h on memset nodes)
     static const bool no_ut = getenv("MNN_NADE_FWD_NO_UT") != nullptr;          // (tests: the direct form as the comparison partner)
     if (Hn <= 64) FWD(1, false);
     else if (Hn <= 128) FWD(2, false);

@@ -918,7 +918,24 @@ def dense_det(jobs):
         _req(x.dtype == W.dtype == out.dtype == torch.float32 and x.shape == (B, K) and out.shape[0] == B and out.shape[1] == N, "dense_det: f32 x [B,K], W [K,N], out [B,N]")
         _req(b is None or (b.dtype == torch.float32 and b.is_contiguous() and b.numel() == N), "dense_det: bias f32 [N]")
         a.x, a.ld_x, a.K, a.W, a.ld_w, a.N, a.bias, a.out, a.ld_out = _ptr(x), x.stride(0), K, _ptr(W), W.stride(0), N, _ptr(b), _ptr(out), out.stride(0)
+        Wp = j.get("Wp")                                     # det_dense_pack(W): the same numbers in the kernel's load order (optional)
+        _req(Wp is None or (Wp.dtype == torch.float32 and Wp.is_contiguous() and Wp.numel() * 4 == int(_lib.load().mnn_det_dense_pack_bytes(K, N)) and Wp.data_ptr() % 16 == 0),
+             "dense_det: Wp is det_dense_pack(W)")
+        a.Wp = _ptr(Wp)
     call("mnn_dense_det", _stream(), B, len(jobs), arr)
+
+
+def det_dense_pack(W, out=None):
+    """W f32 [K, N] (row pitch >= N) repacked for dense_det's job["Wp"]; to be redone whenever W changes."""
+    _rowmajor(W, "det_dense_pack W")
+    _req(W.dtype == torch.float32 and W.dim() == 2, "det_dense_pack: W f32 [K, N]")
+    K, N = W.shape
+    n = int(_lib.load().mnn_det_dense_pack_bytes(K, N)) // 4
+    if out is None:
+        out = torch.empty(n, device=W.device, dtype=torch.float32)
+    _req(out.dtype == torch.float32 and out.numel() == n and out.is_contiguous() and out.data_ptr() % 16 == 0, "det_dense_pack: out")
+    call("mnn_det_dense_pack", _stream(), _ptr(W), K, N, W.stride(0), _ptr(out))
+    return out
 
 
 def generate_scan(intro, num_steps, layers, dense_W, dense_bias, tracks, D, Hn, w_enc, w_dec, temperature, seed, row0):

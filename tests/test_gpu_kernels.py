@@ -845,6 +845,14 @@ def test_det_lstm_step_and_dense_bit_exact():
     for j, (ref, full) in zip(djobs, drefs):
         assert np.array_equal(j["out"].cpu().numpy(), ref)
         assert bool((full[:, ref.shape[1]:] == -7.0).all())            # nothing written past N
+    for i, j in enumerate(djobs):                                      # ... and from packed weights (mnn_det_dense_pack), packed and in-place jobs mixed
+        j["out"].fill_(-5.0)
+        if i != 2:
+            j["Wp"] = ops.det_dense_pack(j["W"])
+    ops.dense_det(djobs)
+    for j, (ref, full) in zip(djobs, drefs):
+        assert np.array_equal(j["out"].cpu().numpy(), ref)
+        assert bool((full[:, ref.shape[1]:] == -7.0).all())
 
 
 def test_nade_sample_multi_equals_per_generator_launches():
