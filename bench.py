@@ -750,9 +750,9 @@ def main(argv=None):
     # the contract's `roofline` is for the dominant KERNEL: mnn_gemm_tn launches four different GEMM kernels in a step (gemm_tn_glds256<true|false>,
     # gemm_bres<7|8>, eight launches) whose sum is within box noise of the one nade_bwd_kernel launch -- entries are ranked by their time per
     # distinct kernel so the line does not flip between boxes; the GEMM family follows under `others` with its whole time
-    def rank(kv):
+    def per_kernel(kv):
         return -kv[1][0] / (4.0 if kv[0] == "mnn_gemm_tn" and kv[1][1] >= 4 else 1.0)
-    top = sorted(per_call.items(), key=rank)
+    top = sorted(per_call.items(), key=per_kernel)
     dom, (dom_ms, dom_calls) = top[0]
     roof = entry_roofline(dom, dom_ms, dom_calls)
     roof["others"] = [entry_roofline(k, ms, n) for k, (ms, n) in sorted(top[1:], key=lambda kv: -kv[1][0])[:5] if ms > 0.04 * total_ms]
