@@ -552,10 +552,12 @@ def test_nade_edge_cases(ops):
 
 
 @pytest.mark.parametrize("N,D,Hn,tracks,temp", [(9, 40, 64, 1, 1.0), (6, 88, 256, 2, 1.0), (5, 30, 100, 1, 0.7), (4, 25, 20, 1, None),
-                                                (7, 440, 256, 1, 1.0), (5, 333, 256, 3, 1.0), (4, 88, 256, 5, 0.5), (3, 130, 252, 1, None), (3, 61, 30, 2, 1.0)])
+                                                (7, 440, 256, 1, 1.0), (5, 333, 256, 3, 1.0), (4, 88, 256, 5, 0.5), (3, 130, 252, 1, None), (3, 61, 30, 2, 1.0),
+                                                (4, 12, 64, 1, 1.0), (4, 7, 256, 2, 1.0), (300, 24, 256, 1, 1.0)])
 def test_nade_sample_bit_exact(ops, N, D, Hn, tracks, temp):
     """Hn % 4 == 0: the eight-visibles-per-pass kernel (nade_sample_chunk_kernel; D = 333 x 3 tracks: chunks, track offsets and Philox windows
-    that do not line up; 440 x 256: the joint generator's shape); other widths: the visible-at-a-time kernel."""
+    that do not line up; 440 x 256: the joint generator's shape; D = 12 / 7: less than one chunk; 300 rows: more rows than CUs, the chunks of 8);
+    other widths: the visible-at-a-time kernel."""
     R = np.random.default_rng(Hn)
     ld = tracks * (Hn + D)
     bias = (R.standard_normal((N, ld)) * .5).astype(np.float32)
