@@ -181,11 +181,11 @@ __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * 
 // ----------------------------------------------------------------------------------------------
 // plain GEMM
 // ----------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(WM * WN * 64)
+template <typename T, int BM, int BN, int WM, int WN, int KH = 1>
+__global__ void __launch_bounds__(WM * WN * KH * 64)
 gemm_tn_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c_bf16,
                const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
-    using Core = GemmCore<T, BM, BN, WM, WN>;
+    using Core = GemmCore<T, BM, BN, WM, WN, KH>;
     __shared__ __attribute__((aligned(16))) char smem[Core::LDS_BYTES];
     // XCD-aware tile order: blocks b and b+8 share an XCD (speed only); give each XCD one m-panel
     // for all n-tiles so the A panel stays in that XCD's L2.
@@ -207,7 +207,8 @@ gemm_tn_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ld
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     Core core;
     core.run(A, lda, M, m0, B, ldb, N, n0, K, kc0, kc1, smem, acc);
-    if (kc0 >= kc1 && z > 0) return;
+    if (kc0 >= kc1 && z > 0) return;                     // (uniform over the workgroup)
+    if (!core.reduce_kh(smem, acc)) return;              // KH == 2: the second wave set's halves are added in; the first set owns the epilogue
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -665,6 +666,16 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
         if (K % 64 == 0) {
             hipLaunchKernelGGL((gemm_tn_glds_kernel<64, typename FlavorOf<T>::type>), grid, dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, c_bf16, bias, M,
                                N, K, flags, split_k, ntm, ntn);
+            MNN_LAUNCH_CHECK();
+            return MNN_OK;
+        }
+    }
+    if constexpr (sizeof(T) == 4) {
+        // f32 operands: eight waves per 128 x 128 tile, two per 64 x 64 quadrant, each taking half of every staged K chunk (MNN_GEMM_F32_KH=0: four)
+        static const bool kh2 = getenv("MNN_GEMM_F32_KH") == nullptr || atoi(getenv("MNN_GEMM_F32_KH")) != 0;
+        if (kh2) {
+            hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, 2, 2, 2>), grid, dim3(512), 0, st, (const T*)A, lda, (const T*)B, ldb, C, ldc,
+                               c_bf16, bias, M, N, K, flags, split_k, ntm, ntn);
             MNN_LAUNCH_CHECK();
             return MNN_OK;
         }
