@@ -16,13 +16,13 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-#define LDS_ROW 80   // bytes per LDS tile row: 64 B of K + 16 B pad
+// (LDS tile rows: GemmCore::ROW = bytes of K per stage + 16 B pad)
 #define CHUNK_B 64   // bytes of K per row per stage
 
 template <typename T> struct Elem;
 template <> struct Elem<bf16_t> { static constexpr int PER16 = 8; static constexpr int PER_CHUNK = 32; };
 template <> struct Elem<f16_t>  { static constexpr int PER16 = 8; static constexpr int PER_CHUNK = 32; };
-template <> struct Elem<float>  { static constexpr int PER16 = 4; static constexpr int PER_CHUNK = 16; };
+template <> struct Elem<float>  { static constexpr int PER16 = 4; static constexpr int PER_CHUNK = 32; };      // f32 stages 128 B of K per row (below)
 // 16-bit C outputs: the mnn_dtype code of C (MNN_F32 = plain f32) travels as `c16`; a 16-bit value is converted by its own flavour
 __device__ __forceinline__ h16_t cvt_c16(float v, int c16) { return c16 == MNN_F16 ? f32_to_f16(v) : f32_to_bf16(v); }
 
@@ -33,9 +33,12 @@ struct GemmCore {
     static constexpr int NT = WM * WN * KH * 64;
     static constexpr int TM = BM / WM / 32;
     static constexpr int TN = BN / WN / 32;
-    static constexpr int A_CHUNKS = (BM * 4 + NT - 1) / NT;   // 16-byte pieces per thread per stage
-    static constexpr int B_CHUNKS = (BN * 4 + NT - 1) / NT;
-    static constexpr int LDS_BYTES = 2 * (BM + BN) * LDS_ROW;
+    // bytes of K per tile row and stage: 64 for the 16-bit types (32 k), 128 for f32 (32 k: with 16 k a wave had 4 .. 32 MFMAs between two
+    // workgroup barriers and the step kernels of the f32 recurrence were barrier-bound); ROW = its LDS pitch (+ 16 B pad), P = 16-byte pieces
+    static constexpr int RB = sizeof(T) == 4 ? 128 : 64, ROW = RB + 16, P = RB / 16;
+    static constexpr int A_CHUNKS = (BM * P + NT - 1) / NT;   // 16-byte pieces per thread per stage
+    static constexpr int B_CHUNKS = (BN * P + NT - 1) / NT;
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * ROW;
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile/wave mismatch");
     static_assert(KH == 1 || (KH == 2 && sizeof(T) == 4), "the in-workgroup K split is built for f32 operands");
     static_assert(KH == 1 || WM * WN * 16 * 64 * 4 <= LDS_BYTES, "reduce_kh stages one tile per wave in the stage buffers");
@@ -46,13 +49,13 @@ struct GemmCore {
                                           int N, int n0, int K, int k0, int tid) {
 #pragma unroll
         for (int s = 0; s < A_CHUNKS; ++s) {
-            const int idx = tid + s * NT, row = min(idx >> 2, BM - 1), c = idx & 3;     // (BM * 4 < NT: the surplus threads repeat the last row)
+            const int idx = tid + s * NT, row = min(idx / P, BM - 1), c = idx % P;     // (BM * P < NT: the surplus threads repeat the last row)
             const int gr = m0 + row, gk = k0 + c * Elem<T>::PER16;
             ra[s] = (gr < M && gk < K) ? *reinterpret_cast<const uint4*>(A + (size_t)gr * lda + gk) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int s = 0; s < B_CHUNKS; ++s) {
-            const int idx = tid + s * NT, row = min(idx >> 2, BN - 1), c = idx & 3;
+            const int idx = tid + s * NT, row = min(idx / P, BN - 1), c = idx % P;
             const int gr = n0 + row, gk = k0 + c * Elem<T>::PER16;
             rb[s] = (gr < N && gk < K) ? *reinterpret_cast<const uint4*>(B + (size_t)gr * ldb + gk) : make_uint4(0, 0, 0, 0);
         }
@@ -60,20 +63,20 @@ struct GemmCore {
     __device__ __forceinline__ void lstore(char* sA, char* sB, int tid) {
 #pragma unroll
         for (int s = 0; s < A_CHUNKS; ++s) {
-            const int idx = tid + s * NT, row = min(idx >> 2, BM - 1), c = idx & 3;     // (surplus threads store the same bytes again)
-            *reinterpret_cast<uint4*>(sA + row * LDS_ROW + c * 16) = ra[s];
+            const int idx = tid + s * NT, row = min(idx / P, BM - 1), c = idx % P;     // (surplus threads store the same bytes again)
+            *reinterpret_cast<uint4*>(sA + row * ROW + c * 16) = ra[s];
         }
 #pragma unroll
         for (int s = 0; s < B_CHUNKS; ++s) {
-            const int idx = tid + s * NT, row = min(idx >> 2, BN - 1), c = idx & 3;
-            *reinterpret_cast<uint4*>(sB + row * LDS_ROW + c * 16) = rb[s];
+            const int idx = tid + s * NT, row = min(idx / P, BN - 1), c = idx % P;
+            *reinterpret_cast<uint4*>(sB + row * ROW + c * 16) = rb[s];
         }
     }
     // one 64-byte K-chunk of MFMAs for this wave
     __device__ __forceinline__ void compute(const char* sA, const char* sB, int wm, int wn, int lane, f32x16_t (&acc)[TM][TN], int kh = 0) {
         const int r = lane & 31, h = lane >> 5;
-        const char* pa = sA + (wm * (BM / WM) + r) * LDS_ROW;
-        const char* pb = sB + (wn * (BN / WN) + r) * LDS_ROW;
+        const char* pa = sA + (wm * (BM / WM) + r) * ROW;
+        const char* pb = sB + (wn * (BN / WN) + r) * ROW;
         if constexpr (sizeof(T) == 2) {
             using F = typename FlavorOf<T>::type;
             using V8 = typename F::x8;
@@ -81,44 +84,29 @@ struct GemmCore {
             for (int ks = 0; ks < 2; ++ks) {
                 V8 a[TM], b[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const V8*>(pa + i * 32 * LDS_ROW + ks * 32 + h * 16);
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const V8*>(pa + i * 32 * ROW + ks * 32 + h * 16);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const V8*>(pb + j * 32 * LDS_ROW + ks * 32 + h * 16);
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const V8*>(pb + j * 32 * ROW + ks * 32 + h * 16);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = F::mfma32(a[i], b[j], acc[i][j]);
             }
         } else {
-            // K order inside the chunk is permuted (lane half h owns k = 8h..8h+7) so each lane reads
-            // 32 contiguous bytes; A and B use the same permutation, so the product is unchanged.
-            if constexpr (KH == 2) {                     // this wave's half of the chunk: k = 8 h + 4 kh .. + 3 (16 bytes per lane and tile row)
-                f32x4_t a[TM], b[TN];
+            // K order inside the 32-k chunk is permuted (lane half h owns k = 16 h .. 16 h + 15) so each lane reads contiguous bytes; A and B use
+            // the same permutation, so the product is unchanged.  KH == 2: this wave multiplies half of that, k = 16 h + 8 kh .. + 7.
+            constexpr int NV = 4 / KH;                   // 16-byte pieces per lane, tile row and chunk
+            f32x4_t a[TM][NV], b[TN][NV];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4_t*>(pa + i * 32 * LDS_ROW + h * 32 + kh * 16);
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4_t*>(pb + j * 32 * LDS_ROW + h * 32 + kh * 16);
+                for (int v = 0; v < NV; ++v) a[i][v] = *reinterpret_cast<const f32x4_t*>(pa + i * 32 * ROW + h * 64 + kh * (NV * 16) + v * 16);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
+                for (int v = 0; v < NV; ++v) b[j][v] = *reinterpret_cast<const f32x4_t*>(pb + j * 32 * ROW + h * 64 + kh * (NV * 16) + v * 16);
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
-                return;
-            }
-            f32x4_t a[TM][2], b[TN][2];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                a[i][0] = *reinterpret_cast<const f32x4_t*>(pa + i * 32 * LDS_ROW + h * 32);
-                a[i][1] = *reinterpret_cast<const f32x4_t*>(pa + i * 32 * LDS_ROW + h * 32 + 16);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                b[j][0] = *reinterpret_cast<const f32x4_t*>(pb + j * 32 * LDS_ROW + h * 32);
-                b[j][1] = *reinterpret_cast<const f32x4_t*>(pb + j * 32 * LDS_ROW + h * 32 + 16);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
+            for (int ks = 0; ks < 4 * NV; ++ks)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -133,8 +121,8 @@ struct GemmCore {
         const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int kh = wave / (WM * WN), wq = wave % (WM * WN);
         const int wm = wq / WN, wn = wq % WN;
-        char* sA[2] = {smem, smem + (BM + BN) * LDS_ROW};
-        char* sB[2] = {smem + BM * LDS_ROW, smem + (BM + BN) * LDS_ROW + BM * LDS_ROW};
+        char* sA[2] = {smem, smem + (BM + BN) * ROW};
+        char* sB[2] = {smem + BM * ROW, smem + (BM + BN) * ROW + BM * ROW};
         if (kc0 >= kc1) return;
         gload(A, lda, M, m0, B, ldb, N, n0, K, kc0 * Elem<T>::PER_CHUNK, tid);
         lstore(sA[0], sB[0], tid);
@@ -186,7 +174,8 @@ __global__ void __launch_bounds__(WM * WN * KH * 64)
 gemm_tn_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c_bf16,
                const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
     using Core = GemmCore<T, BM, BN, WM, WN, KH>;
-    __shared__ __attribute__((aligned(16))) char smem[Core::LDS_BYTES];
+    extern __shared__ __attribute__((aligned(16))) char gemm_tn_smem[];      // Core::LDS_BYTES (f32: 72 KB, past the static limit)
+    char* smem = gemm_tn_smem;
     // XCD-aware tile order: blocks b and b+8 share an XCD (speed only); give each XCD one m-panel
     // for all n-tiles so the A panel stays in that XCD's L2.
     const int bid = blockIdx.x;
@@ -673,14 +662,26 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
     if constexpr (sizeof(T) == 4) {
         // f32 operands: eight waves per 128 x 128 tile, two per 64 x 64 quadrant, each taking half of every staged K chunk (MNN_GEMM_F32_KH=0: four)
         static const bool kh2 = getenv("MNN_GEMM_F32_KH") == nullptr || atoi(getenv("MNN_GEMM_F32_KH")) != 0;
+        static bool raised_[64];
+        bool& raised = mnn_dev_flag(raised_);
+        if (!raised) {
+            constexpr int need2 = GemmCore<T, BM, BN, 2, 2, 2>::LDS_BYTES, need1 = GemmCore<T, BM, BN, 2, 2>::LDS_BYTES;
+            const void* f2 = (const void*)gemm_tn_kernel<T, BM, BN, 2, 2, 2>;
+            const void* f1 = (const void*)gemm_tn_kernel<T, BM, BN, 2, 2>;
+            MNN_HIP(hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, need2));
+            MNN_HIP(hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, need1));
+            raised = true;
+        }
         if (kh2) {
-            hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, 2, 2, 2>), grid, dim3(512), 0, st, (const T*)A, lda, (const T*)B, ldb, C, ldc,
+            constexpr size_t lds2 = GemmCore<T, BM, BN, 2, 2, 2>::LDS_BYTES;
+            hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, 2, 2, 2>), grid, dim3(512), lds2, st, (const T*)A, lda, (const T*)B, ldb, C, ldc,
                                c_bf16, bias, M, N, K, flags, split_k, ntm, ntn);
             MNN_LAUNCH_CHECK();
             return MNN_OK;
         }
     }
-    hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, 2, 2>), grid, dim3(256), 0, st, (const T*)A, lda, (const T*)B, ldb, C, ldc,
+    constexpr size_t lds1 = GemmCore<T, BM, BN, 2, 2>::LDS_BYTES;
+    hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, 2, 2>), grid, dim3(256), lds1, st, (const T*)A, lda, (const T*)B, ldb, C, ldc,
                        c_bf16, bias, M, N, K, flags, split_k, ntm, ntn);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
