@@ -82,3 +82,24 @@ def test_bench_cli_contract():
     for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"', '"higher_is_better"', '"scaling"',
                 '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"'):
         assert key in src, key
+
+
+def test_pack_epoch_dates_the_repacked_sampling_weights():
+    """common.Model._packed_step: every "stale" mark (-1) starts a new pack epoch -- what LstmStack.det_job keys its repacked f32 sampling
+    weights on (one repack per sampling scan, inside its captured graph); recording the store step the 16-bit packs were made at does not."""
+    from multinn_amd.common import Model
+
+    class M(Model):
+        def build(self, *a, **k):
+            pass
+
+        def build_metrics(self, *a, **k):
+            return [], [], None
+
+    m = M()
+    assert m._packed_step == -1 and getattr(m, "_pack_epoch", 0) == 0
+    m._packed_step = 7
+    assert m._packed_step == 7 and getattr(m, "_pack_epoch", 0) == 0
+    m._packed_step = -1
+    m._packed_step = -1
+    assert m._packed_step == -1 and m._pack_epoch == 2
