@@ -779,7 +779,7 @@ def main(argv=None):
         "config": {"workload": w["name"], "global_batch": world * B, "per_gpu_batch": B, "seq_len": T, "pitches": P, "tracks": M, "rho": a.rho,
                    "nade_hidden": HN, "lstm_units": UNITS, "keep_prob": 0.9, "optimizer": "TF-Adam lr 0.01 eps 1e-4 clip 5.0",
                    "parallelism": f"dp{world}"},
-        "launch": launch, "loss": loss, "dp": dp_info,
+        "launch": launch, "loss": loss, "optimizer_steps_skipped": int(gen.store.skipped), "loss_scale_multiplier": float(gen.store.ls_dyn[0]), "dp": dp_info,
         "parity": {"mode": a.precision,
                    "gate": ("tests/test_gpu_realdims.py: loss, per-row NLL <= 1e-4 relative, conditionals <= 1e-4 absolute vs the float64 oracle at D=440, "
                             "Hn=256, [512,256], rho in {0.03, 0.5}, persistent kernels asserted ON") if a.precision in ("fp16", "fp32") else

@@ -43,9 +43,9 @@ enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_ST
 
 /* ABI version of THIS header: bumped whenever a signature or a descriptor struct changes.  mnn_version() returns the value the library
  * was built with; a loader must compare the two before its first call (multinn_amd/_lib.py load() does) -- a library built for another
- * version reads garbage arguments without any diagnosis otherwise.  119 (round 6): mnn_det_dense_job gained `Wp`, + mnn_det_dense_pack / _pack_bytes.  118 (round 6): mnn_det_lstm_job gained `Wp`, + mnn_det_lstm_pack / _pack_bytes, mnn_generate_scan_workspace_bytes gained `n_in`.  117 (round 6): + mnn_lstm_cluster_bwd_ok, + mnn_ragged_index / mnn_rows_gather16 / mnn_rows_scatter_f32, `n_rows_dev` on the gated NADE forwards and mnn_nade_logprob_bwd, `inv` / `hdr` on mnn_pianoroll_shift_timemajor_t, + mnn_lstm_resident_{fwd,bwd}_multi / mnn_lstm_cluster_{fwd,bwd}_multi / _bwd_multi_ok, `unsafe` on mnn_nade_logprob_fwd_gated, `unsafe` on mnn_nade_logprob_bwd.  116: + mnn_lstm_cluster_ok / _fwd / _bwd.  115: mnn_step_increment gained `sumsq`, `clip_norm`.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
+ * version reads garbage arguments without any diagnosis otherwise.  120 (round 6): mnn_step_increment gained `ls_dyn`, `ls_good`, `grow_after` (dynamic f16 loss scale).  119 (round 6): mnn_det_dense_job gained `Wp`, + mnn_det_dense_pack / _pack_bytes.  118 (round 6): mnn_det_lstm_job gained `Wp`, + mnn_det_lstm_pack / _pack_bytes, mnn_generate_scan_workspace_bytes gained `n_in`.  117 (round 6): + mnn_lstm_cluster_bwd_ok, + mnn_ragged_index / mnn_rows_gather16 / mnn_rows_scatter_f32, `n_rows_dev` on the gated NADE forwards and mnn_nade_logprob_bwd, `inv` / `hdr` on mnn_pianoroll_shift_timemajor_t, + mnn_lstm_resident_{fwd,bwd}_multi / mnn_lstm_cluster_{fwd,bwd}_multi / _bwd_multi_ok, `unsafe` on mnn_nade_logprob_fwd_gated, `unsafe` on mnn_nade_logprob_bwd.  116: + mnn_lstm_cluster_ok / _fwd / _bwd.  115: mnn_step_increment gained `sumsq`, `clip_norm`.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
  * mnn_pianoroll_shift_timemajor_t / mnn_grad_rows_fanout and the `f16` descriptor fields of round 3 are part of it. */
-#define MNN_ABI_VERSION 119
+#define MNN_ABI_VERSION 120
 int mnn_version(void);
 const char* mnn_last_error(void);
 
@@ -439,7 +439,11 @@ int mnn_weighted_sum(mnn_stream_t s, const float* x, const float* w, long n, flo
 int mnn_clip_adam_step(mnn_stream_t s, float* theta, const float* grad, float* m, float* v, long n, const float* sumsq,
                        float clip_norm, float lr, float beta1, float beta2, float eps, int step, const int32_t* step_dev, int sgd,
                        int32_t* skipped);
-int mnn_step_increment(mnn_stream_t s, int32_t* step_dev, const float* sumsq, float clip_norm);
+int mnn_step_increment(mnn_stream_t s, int32_t* step_dev, const float* sumsq, float clip_norm,
+                       float* ls_dyn /* optional [m, 1 / m]: the dynamic part of the f16 loss scale -- halved by a skipped step, doubled (up to 1) after
+                                        `grow_after` applied steps in a row; the owner of the backward pass multiplies its gradient seed by m and the
+                                        finished gradient by 1 / m (both read on the device: a captured step follows it) */,
+                       int32_t* ls_good /* [1]: applied steps since the last change */, int grow_after);
 int mnn_bias_grad(mnn_stream_t s, const float* dY, int rows, int cols, int ld, float* db, int accumulate);
 int mnn_fill_f32(mnn_stream_t s, float* x, long n, float value);
 /* One pass over the f32 gradient block dY[rows, cols_c] of the dense layer (rnn_estimator.py:205-215's tf.gradients through the

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MULTINN_HIP_LIB", os.path.join(HERE, "libmultinn_hip.so"))   # override: A/B builds of the same ABI
 
-ABI_VERSION = 119          # == MNN_ABI_VERSION of include/multinn_hip.h; load() refuses a library built for another one
+ABI_VERSION = 120          # == MNN_ABI_VERSION of include/multinn_hip.h; load() refuses a library built for another one
 F32, BF16, U8, F16 = 0, 1, 2, 3
 GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_A_KBLOCK32 = 1, 2, 8
 
@@ -50,7 +50,7 @@ SIGNATURES = {
     "mnn_sumsq": (_i, [_p, _p, _l, _p]),
     "mnn_weighted_sum": (_i, [_p, _p, _p, _l, _p]),
     "mnn_clip_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _f, _i, _p, _i, _p]),
-    "mnn_step_increment": (_i, [_p, _p, _p, _f]),
+    "mnn_step_increment": (_i, [_p, _p, _p, _f, _p, _p, _i]),
     "mnn_bias_grad": (_i, [_p, _p, _i, _i, _i, _p, _i]),
     "mnn_grad_rows_fanout": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i]),
     "mnn_fill_f32": (_i, [_p, _p, _l, _f]),

@@ -100,6 +100,11 @@ class ParamStore:
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)     # device copy of `step` (read by kernels under hipGraph replay)
         # optimiser steps the device skipped because the gradient norm was not finite (mnn_clip_adam_step; f16 loss-scale overflow)
         self.skipped = torch.zeros(1, device=dev, dtype=torch.int32)
+        # the dynamic part of the f16 loss scale, [m, 1 / m] (+ applied steps since its last change): a skipped step halves m, LS_GROW_AFTER
+        # applied steps in a row double it back up to 1 (mnn_step_increment); the backward passes of precision "fp16" multiply their gradient
+        # seed by m and the finished gradient by 1 / m, both read on the device
+        self.ls_dyn = torch.ones(2, device=dev)
+        self.ls_good = torch.zeros(1, device=dev, dtype=torch.int32)
         off = 0
         for name, shape, init in self._specs:
             k = math.prod(shape)
@@ -124,17 +129,26 @@ class ParamStore:
     def names(self):
         return [n for n, _, _ in self._specs]
 
-    def check(self):
+    LS_GROW_AFTER = 200
+
+    def check(self, tolerate_overflow=False):
         """Raise FloatingPointError if an optimiser step has been skipped on the device since the last check (non-finite gradient norm:
-        the f16 backward pass overflowed, or a NaN reached the gradient).  Synchronises; clears the counter."""
+        the f16 backward pass overflowed, or a NaN reached the gradient).  Synchronises; clears the counter.
+        tolerate_overflow (a training loop in precision "fp16"): skipped steps are what the dynamic loss scale feeds on -- warn, and raise only
+        when the scale has been halved down to its floor without finding a finite gradient (that is a NaN, not an overflow)."""
         if self.theta is None:
             return
         n = int(self.skipped.item())
         if n:
             self.skipped.zero_()
             self.step = int(self.step_dev.item())       # the host mirror counts attempts; the device counter only APPLIED steps
+            m = float(self.ls_dyn[0]) if getattr(self, "ls_dyn", None) is not None else 1.0
+            if tolerate_overflow and m > 2.0 ** -19:
+                import warnings
+                warnings.warn(f"{n} optimiser step(s) skipped (non-finite gradient norm: f16 overflow); the loss scale multiplier is now {m:g}")
+                return
             raise FloatingPointError(f"{n} optimiser step(s) skipped: the gradient norm was not finite (f16 loss-scale overflow or NaN "
-                                     "gradient); lower LstmStack.loss_scale_rows or use precision='bf16'")
+                                     f"gradient; dynamic loss-scale multiplier {m:g}); lower LstmStack.loss_scale_rows or use precision='bf16'")
 
     def state_dict(self):
         return dict(theta=self.theta.cpu(), m=self.m.cpu(), v=self.v.cpu(), step=int(self.step_dev.item()), names=self.names(),

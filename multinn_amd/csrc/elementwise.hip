@@ -940,13 +940,33 @@ extern "C" int mnn_grad_rows_fanout(mnn_stream_t s, const float* dY, int rows, i
 
 // the same test as clip_adam_kernel: a step whose gradient norm is not finite was NOT applied, so it does not count (the Adam bias
 // correction of the next applied step uses the number of APPLIED steps)
-__global__ void step_increment_kernel(int32_t* step_dev, const float* __restrict__ sumsq, float clip) {
-    if (clip > 0.f && sumsq != nullptr && !isfinite(sumsq[0])) return;
+// ... and the f16 loss scale follows the outcome (ls_dyn = [m, 1 / m], the power-of-two multiplier the owner of a backward pass applies on top of
+// its static scale): a skipped step halves m (the backward overflowed -- with a static scale every later step would overflow too and training
+// stands still for good: seen at the bench shape after ~270 steps at lr 0.01), `grow_after` applied steps in a row double it back, up to 1.
+__global__ void step_increment_kernel(int32_t* step_dev, const float* __restrict__ sumsq, float clip, float* ls_dyn, int32_t* ls_good,
+                                      int grow_after, float m_min) {
+    const bool skippedstep = clip > 0.f && sumsq != nullptr && !isfinite(sumsq[0]);
+    if (ls_dyn != nullptr) {
+        float m = ls_dyn[0];
+        if (skippedstep) {
+            m = fmaxf(m * 0.5f, m_min);
+            ls_good[0] = 0;
+        } else if (++ls_good[0] >= grow_after && m < 1.0f) {
+            m = fminf(m * 2.0f, 1.0f);
+            ls_good[0] = 0;
+        }
+        ls_dyn[0] = m;
+        ls_dyn[1] = 1.0f / m;
+    }
+    if (skippedstep) return;
     step_dev[0] += 1;
 }
-extern "C" int mnn_step_increment(mnn_stream_t s, int32_t* step_dev, const float* sumsq, float clip_norm) {
+extern "C" int mnn_step_increment(mnn_stream_t s, int32_t* step_dev, const float* sumsq, float clip_norm, float* ls_dyn, int32_t* ls_good,
+                                  int grow_after) {
     MNN_REQUIRE(step_dev, "mnn_step_increment: null pointer");
-    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, step_dev, sumsq, clip_norm);
+    MNN_REQUIRE((ls_dyn == nullptr) == (ls_good == nullptr) && (ls_dyn == nullptr || grow_after > 0), "mnn_step_increment: ls_dyn [2] and ls_good [1] come together, grow_after > 0");
+    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, step_dev, sumsq, clip_norm, ls_dyn, ls_good, grow_after,
+                       1.0f / 1048576.0f);
     MNN_LAUNCH_CHECK();
     return MNN_OK;
 }

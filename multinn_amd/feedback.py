@@ -64,12 +64,13 @@ class FeedbackRnn(Model):
         self.store.grad.zero_()
         dy = d_out.transpose(0, 1).contiguous()
         # f16 operands: the pass runs on loss-scaled values (LstmStack.loss_scale); d_out comes from mean-over-rows losses, ~1/(B T) per element
+        # (times the dynamic multiplier of this store's f16 loss scale, a device word: ParamStore.ls_dyn)
         ls = self._stack.loss_scale(n_valid if n_valid else dy.shape[0] * dy.shape[1])
         if ls != 1.0:
-            dy = dy * ls
+            dy = dy * (self.store.ls_dyn[0:1] * ls)
         self._stack.backward(dy, self._ctx["lstm"], self._ctx["kp"], self.seed, self.row0, step_dev=self.store.step_dev)
         if ls != 1.0:
-            ops.axpby(1.0 / ls, self.store.grad, 0.0, None, self.store.grad)
+            self.store.grad.mul_(self.store.ls_dyn[1:2] * (1.0 / ls))
 
     def single(self, x, state):
         """_apply_feedback(single_step=True): x [B,Din] -> (output [B,F] f32, new_state)."""

@@ -889,11 +889,13 @@ class RnnEstimator(Generator):
         h, new = self._stack.det_step(inputs, [(c, hh) for c, hh in initial_state.rnn_state], x2=x2)
         return self._det_state(h, new)
 
-    def check(self):
+    def check(self, tolerate_overflow=False):
         """Raise if a persistent recurrence launch of this generator ever gave up on a bounded spin (LstmStack.check)."""
         if getattr(self, "_stack", None) is not None:
             self._stack.check()
-        self.store.check()                  # an optimiser step the device skipped (non-finite gradient norm) raises here
+        # an optimiser step the device skipped (non-finite gradient norm) raises here -- unless the caller is a training loop in precision "fp16",
+        # whose dynamic loss scale has already answered the overflow (ParamStore.check)
+        self.store.check(tolerate_overflow and self.dtype == torch.float16)
 
     def _unscale(self, ls):
         """End of a loss-scaled backward pass (LstmStack.loss_scale): gradients and d loss / d inputs back to their true scale."""
@@ -1246,18 +1248,26 @@ class RnnNade(RnnEstimator):
                 d_out[:, self.n_out:].zero_()       # fp32: d_out itself is the dgrad operand; bf16: grad_rows_fanout writes the zero padding
         a_fin = torch.empty((M, N, Hn), device=dev) if train else None
         # gradient seed only (the reported loss stays unscaled): the mode's weight of this generator's loss, and the f16 loss scale
+        # (f16: times the DYNAMIC multiplier m of the store, a device word a skipped step halves -- ParamStore.ls_dyn; _unscale gets 1 / (scale m))
+        dyn = self.store.ls_dyn if (train and self.dtype == torch.float16) else None
         if compact is not None:                         # the scale is a device word (hdr[2]); its inverse is applied by _unscale
             ls = compact["hdr_f"][2:3] if (train and self.dtype == torch.float16) else 1.0
-            rw_g = rw_m if (self.grad_scale == 1.0 and not torch.is_tensor(ls)) else rw_m * ls * self.grad_scale
             if torch.is_tensor(ls):
-                ls = compact["hdr_f"][3:4]               # what _unscale multiplies by
+                rw_g = rw_m * (ls * dyn[0:1] * self.grad_scale)
+                ls = compact["hdr_f"][3:4] * dyn[1:2]    # what _unscale multiplies by
+            else:
+                rw_g = rw_m if self.grad_scale == 1.0 else rw_m * self.grad_scale
         elif train and self._n_valid is None and self.dtype == torch.float16:     # ragged_on_device without compaction: the device-side scale
-            rw_g = rw_m * (self._ls_dev * self.grad_scale)
-            ls = 1.0 / self._ls_dev
+            rw_g = rw_m * (self._ls_dev * dyn[0:1] * self.grad_scale)
+            ls = dyn[1:2] / self._ls_dev
         else:
             ls = self._stack.loss_scale(self._n_valid) if (train and self._n_valid is not None) else 1.0
             gs = self.grad_scale * ls
-            rw_g = rw_m if gs == 1.0 else rw_m * gs
+            if dyn is not None:
+                rw_g = rw_m * (dyn[0:1] * gs)
+                ls = dyn[1:2] * (1.0 / ls)               # a tensor: _unscale multiplies by it
+            else:
+                rw_g = rw_m if gs == 1.0 else rw_m * gs
         if self._nade_mfma():
             # bf16 compute mode: the decoder dot products run as a block-sparse bf16 GEMM over each row's hidden states while the batch is
             # piano-roll-sparse; a dense batch takes the f32 vector form (decided on the device, per launch: ops.nade_logprob_fwd_auto)
@@ -1699,13 +1709,20 @@ class RnnRBM(RnnEstimator):
         # Dense-output-shaped gradient block and the two scaled hidden blocks of d cost / d W = v_s^T (w ss) - v^T (w sv)
         d_out = torch.empty((N, self.ldo), device=dev)
         pos = torch.empty((N, Hn), device=dev); neg = torch.empty((N, Hn), device=dev)
+        dyn = self.store.ls_dyn if self.dtype == torch.float16 else None          # the dynamic multiplier of the f16 loss scale (ParamStore.ls_dyn)
         if cx["n_valid"] is None:                    # ragged_on_device: the scale is a device scalar (folded into the row weights); _unscale gets its inverse
             lsd = cx.get("ls_dev")
+            if lsd is not None and dyn is not None:
+                lsd = lsd * dyn[0:1]
             ops.rbm_cd_rows(cx["tgt"], cx["v_s"], sv, ss, cx["rw"] if lsd is None else cx["rw"] * lsd, self.grad_scale, d_out, pos, neg)
             ls = 1.0 if lsd is None else 1.0 / lsd
         else:
             ls = self._stack.loss_scale(cx["n_valid"])
-            ops.rbm_cd_rows(cx["tgt"], cx["v_s"], sv, ss, cx["rw"], self.grad_scale * ls, d_out, pos, neg)
+            if dyn is not None:
+                ops.rbm_cd_rows(cx["tgt"], cx["v_s"], sv, ss, cx["rw"] * dyn[0:1], self.grad_scale * ls, d_out, pos, neg)
+                ls = dyn[1:2] * (1.0 / ls)
+            else:
+                ops.rbm_cd_rows(cx["tgt"], cx["v_s"], sv, ss, cx["rw"], self.grad_scale * ls, d_out, pos, neg)
         # d cost / d W = v_s^T pos + v^T neg, [D, N] . [N, Hn] with K = N rows.  16-bit modes: the operands in the compute type (v, v_s are 0 / 1:
         # exact; pos / neg are loss-scaled products of a weight and a sigmoid) on the LDS-DMA GEMM -- as f32 products on v_mfma_f32_32x32x2_f32
         # (1/16 of the 16-bit rate) the two GEMMs were 0.53 ms per track of the 3.6 ms jamming step (round 4 profile); fp32 mode keeps f32.

@@ -373,19 +373,20 @@ class MultINNCore(Model):
                 self._feedback_layer._packed_step = -1
         return True
 
-    def check(self):
+    def check(self, tolerate_overflow=False):
         """Raise if a persistent recurrence launch of any generator (or of the feedback module) ever gave up on a bounded spin: its outputs
-        were garbage (LstmStack.check; synchronises the device).  The driver calls it before every validation pass and checkpoint."""
+        were garbage (LstmStack.check; synchronises the device).  The driver calls it before every validation pass and checkpoint.
+        tolerate_overflow (the training loop): optimiser steps skipped in precision "fp16" are the dynamic loss scale at work -- a warning."""
         for g in self._generators:
             if getattr(g, "_stack", None) is not None:
                 g._stack.check()
             if getattr(g, "store", None) is not None:
-                g.store.check()             # optimiser steps skipped on the device (non-finite gradient norm)
+                g.store.check(tolerate_overflow and getattr(g, "dtype", None) == torch.float16)      # optimiser steps skipped on the device (non-finite gradient norm)
         fl = getattr(self, "_feedback_layer", None)
         if fl is not None and getattr(fl, "_stack", None) is not None:
             fl._stack.check()
         if fl is not None and getattr(fl, "store", None) is not None:
-            fl.store.check()
+            fl.store.check(tolerate_overflow and getattr(fl, "dtype", None) == torch.float16)
         for e in getattr(self, "_encoders", None) or []:      # the encoders' stores take optimiser steps too (pretrain_encoders, compute_gradients)
             if getattr(e, "store", None) is not None:
                 e.store.check()

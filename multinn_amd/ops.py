@@ -785,10 +785,16 @@ def clip_adam_step(theta, grad, m, v, sumsq_buf, clip_norm, lr, beta1, beta2, ep
          float(beta1), float(beta2), float(eps), int(step), _ptr(step_dev), int(sgd), _ptr(skipped))
 
 
-def step_increment(step_dev, sumsq_buf=None, clip_norm=0.0):
-    """Advance the device step counter -- unless (sumsq_buf, clip_norm) say that clip_adam_step skipped this step (non-finite norm)."""
+def step_increment(step_dev, sumsq_buf=None, clip_norm=0.0, ls_dyn=None, ls_good=None, grow_after=200):
+    """Advance the device step counter -- unless (sumsq_buf, clip_norm) say that clip_adam_step skipped this step (non-finite norm).
+    ls_dyn f32 [m, 1/m] + ls_good int32[1]: the dynamic part of the f16 loss scale follows the outcome (halved by a skipped step, doubled
+    back up to 1 after `grow_after` applied steps in a row)."""
     _step_ok(step_dev)
-    call("mnn_step_increment", _stream(), _ptr(step_dev), _ptr(sumsq_buf), float(clip_norm))
+    _req((ls_dyn is None) == (ls_good is None), "step_increment: ls_dyn and ls_good come together")
+    if ls_dyn is not None:
+        _req(ls_dyn.dtype == torch.float32 and ls_dyn.numel() == 2 and ls_dyn.is_contiguous() and ls_good.dtype == torch.int32 and ls_good.numel() == 1,
+             "step_increment: ls_dyn f32[2], ls_good int32[1]")
+    call("mnn_step_increment", _stream(), _ptr(step_dev), _ptr(sumsq_buf), float(clip_norm), _ptr(ls_dyn), _ptr(ls_good), int(grow_after))
 
 
 def bias_grad(dY, db, accumulate=False):

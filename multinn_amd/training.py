@@ -119,7 +119,7 @@ def compute_gradients(optimizer, store, clip_norm=5.0, lr=None, reduce=True):
     # the step count is read from store.step_dev ON DEVICE (= store.step - 1 here), so a captured graph stays valid
     ops.clip_adam_step(store.theta, store.grad, store.m, store.v, sumsq, clip_norm, optimizer.lr if lr is None else lr,
                        optimizer.beta1, optimizer.beta2, optimizer.epsilon, store.step, optimizer.sgd, store.step_dev, store.skipped)
-    ops.step_increment(store.step_dev, sumsq, clip_norm)       # a skipped (non-finite) step does not count
+    ops.step_increment(store.step_dev, sumsq, clip_norm, store.ls_dyn, store.ls_good, store.LS_GROW_AFTER)       # a skipped (non-finite) step does not count; the f16 loss scale follows
     return sumsq
 
 
@@ -138,5 +138,5 @@ def compute_gradients_multi(optimizer, stores, clip_norm=5.0, lr=None, reduce=Tr
         st.step += 1
         ops.clip_adam_step(st.theta, st.grad, st.m, st.v, sumsq, clip_norm, optimizer.lr if lr is None else lr,
                            optimizer.beta1, optimizer.beta2, optimizer.epsilon, st.step, optimizer.sgd, st.step_dev, st.skipped)
-        ops.step_increment(st.step_dev, sumsq, clip_norm)
+        ops.step_increment(st.step_dev, sumsq, clip_norm, st.ls_dyn, st.ls_good, st.LS_GROW_AFTER)
     return sumsq

@@ -278,6 +278,39 @@ def test_fp16_ragged_lengths_loss_scale_and_overflow_guard():
     gen.check()                                         # the counter was cleared by the raise
 
 
+@pytest.mark.parametrize("graphed", [False, True])
+def test_fp16_overflow_lowers_the_dynamic_loss_scale_and_training_goes_on(graphed):
+    """precision "fp16" with a loss scale that is far too large (loss_scale_rows x 2^14: the backward pass overflows f16): the device skips
+    those steps AND halves the store's dynamic multiplier each time (ParamStore.ls_dyn, mnn_step_increment) until the gradient is finite; from
+    then on steps are applied and the loss falls.  With a static scale every step would be skipped for good (seen at the bench shape after
+    ~270 steps at lr 0.01).  Eager and as replays of ONE captured graph (the multiplier is read on the device).  check(): a training loop
+    passes tolerate_overflow and gets a warning; the strict form still raises."""
+    from multinn_amd import RnnNade, AdamOptimizer
+    B, T, P, M = 64, 16, 8, 2
+    x = dev(make_batch(B, T, P, M, 5, rho=0.1))
+    gen = RnnNade(P * M, 256, [128, 128], keep_prob=0.9, precision="fp16", seed=23)
+    gen._materialize(P * M)
+    gen._stack.loss_scale_rows = 256.0 * 2.0 ** 14
+    opt = AdamOptimizer(0.01)
+    step = gen.graphed_train_step(x, opt, warmup=0) if graphed else (lambda: gen.train_step(x, None, opt))
+    th0 = gen.store.theta.clone()
+    losses = []
+    for _ in range(40):
+        step()
+        losses.append(float(gen.metrics["batch/loss"]))
+    m, inv = gen.store.ls_dyn.tolist()
+    skipped, applied = int(gen.store.skipped), int(gen.store.step_dev)
+    print(f"\n[dynamic loss scale, graphed={graphed}] multiplier {m:g}, skipped {skipped}, applied {applied}, loss {losses[0]:.3f} -> {losses[-1]:.3f}")
+    assert 0.0 < m < 1.0 and m * inv == 1.0 and 2 <= skipped <= 20 and applied == 40 - skipped
+    assert not torch.equal(gen.store.theta, th0) and bool(torch.isfinite(gen.store.theta).all())
+    assert losses[-1] < 0.8 * losses[0]
+    with pytest.warns(UserWarning, match="loss scale multiplier"):
+        gen.check(tolerate_overflow=True)
+    gen.store.skipped.fill_(1)
+    with pytest.raises(FloatingPointError):
+        gen.check()
+
+
 @pytest.mark.parametrize("tracks", [1, 3])
 def test_rnn_nade_internal_bias(tracks):
     """internal_bias=True (nade.py:69-87, rnn_nade.py:245-251): b_enc / b_dec of the NADE(s) are added to the Dense outputs.  The oracle gets

@@ -1335,6 +1335,22 @@ def test_clip_adam_skips_a_non_finite_step_and_the_step_counter_with_it(ops):
     assert int(sd) == 8 and int(skipped) == 2 and not torch.equal(th, th0)
     ops.step_increment(sd)                      # without the norm: always advances
     assert int(sd) == 9
+    # the dynamic part of the f16 loss scale rides on the same outcome: a skipped step halves m, `grow_after` applied steps in a row double it
+    # back, never past 1; [m, 1 / m] stay exact powers of two
+    dyn, good = torch.ones(2, device=DEV), torch.zeros(1, device=DEV, dtype=torch.int32)
+    inf, fin = torch.full((1,), float("inf"), device=DEV), torch.ones(1, device=DEV)
+    for _ in range(3):
+        ops.step_increment(sd, inf, 5.0, dyn, good, 2)
+    assert int(sd) == 9 and dyn.tolist() == [0.125, 8.0] and int(good) == 0
+    ops.step_increment(sd, fin, 5.0, dyn, good, 2)
+    assert int(sd) == 10 and dyn.tolist() == [0.125, 8.0] and int(good) == 1
+    ops.step_increment(sd, fin, 5.0, dyn, good, 2)
+    assert dyn.tolist() == [0.25, 4.0] and int(good) == 0
+    ops.step_increment(sd, inf, 5.0, dyn, good, 2)
+    assert dyn.tolist() == [0.125, 8.0]
+    for _ in range(12):
+        ops.step_increment(sd, fin, 5.0, dyn, good, 2)
+    assert dyn.tolist() == [1.0, 1.0] and int(sd) == 23
 
 
 @pytest.mark.parametrize("M,N,K,cdt,hb", [(1000, 696, 256, torch.float32, True), (512, 200, 64, torch.float16, True), (768, 2048, 448, torch.float16, True),
