@@ -321,7 +321,7 @@ def _recorded(workload, precision, kind):
 
 
 def attach_counters(rf, workload, precision):
-    """rocprofv3 counters cannot be collected from inside this process: the line carries the counters RECORDED by profiles/tools/record_round5.sh (record_round4.sh in round 4)
+    """rocprofv3 counters cannot be collected from inside this process: the line carries the counters RECORDED by profiles/tools/record_round6.sh (record_round<N>.sh of the round that made them)
     (separate --pmc passes over this command in eager mode) under roofline.recorded_counters, with the file, the source hash of the recorded
     build and `same_build`.  Only when the recording was taken on this very build are its HBM bytes also reported as roofline.traffic (the
     contract's field); otherwise traffic stays null -- stale counters never stand beside live timings unmarked."""
@@ -580,7 +580,8 @@ def main(argv=None):
                 print(f"# hipGraph capture of the mode's step failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 torch.cuda.synchronize()
         sec, loss = time_region(step_fn, a.steps)
-        model.check()
+        skipped = sum(int(g.store.skipped) for g in model._generators if getattr(g, "store", None) is not None and g.store.theta is not None)
+        model.check(tolerate_overflow=True)          # (f16: a skipped step is the dynamic loss scale at work; it is reported below)
         _lib.TIMING = {}
         nb = min(a.steps, 3)
         for _ in range(nb):
@@ -597,7 +598,7 @@ def main(argv=None):
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[a.precision], "data": "synthetic",
                 "config": {"workload": w["name"], "global_batch": world * B, "per_gpu_batch": B, "seq_len": T, "pitches": P, "tracks": M, "rho": a.rho,
                            "parallelism": f"dp{world}"},
-                "launch": launch, "loss": float(loss), "dp": dp_info, "breakdown_ms": {k: round(v, 3) for k, v in top},
+                "launch": launch, "loss": float(loss), "optimizer_steps_skipped": skipped, "dp": dp_info, "breakdown_ms": {k: round(v, 3) for k, v in top},
                 "roofline": mode_roofline(w, a.precision, per, calls, B * T, sec)}), flush=True)
         if multi:
             dist.barrier()

@@ -103,3 +103,31 @@ def test_pack_epoch_dates_the_repacked_sampling_weights():
     m._packed_step = -1
     m._packed_step = -1
     assert m._packed_step == -1 and m._pack_epoch == 2
+
+
+def test_store_check_tolerates_fp16_overflow_until_the_scale_is_at_its_floor():
+    """ParamStore.check: strict by default (any skipped optimiser step raises); a training loop in precision "fp16" passes tolerate_overflow --
+    skipped steps are then what the dynamic loss scale feeds on (a warning), until the multiplier has been halved down to its floor (a NaN)."""
+    import warnings
+    import pytest
+    import torch
+    from multinn_amd.common import ParamStore
+    st = ParamStore(torch.device("cpu"))
+    st.declare("w", (3, 4), None)
+    st.materialize()
+    st.check()                                               # nothing skipped
+    st.skipped.fill_(2)
+    with pytest.raises(FloatingPointError):
+        st.check()
+    assert int(st.skipped) == 0
+    st.skipped.fill_(1)
+    st.ls_dyn.copy_(torch.tensor([0.25, 4.0]))
+    with pytest.warns(UserWarning, match="0.25"):
+        st.check(tolerate_overflow=True)
+    st.skipped.fill_(1)
+    st.ls_dyn.copy_(torch.tensor([2.0 ** -20, 2.0 ** 20]))
+    with pytest.raises(FloatingPointError):
+        st.check(tolerate_overflow=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        st.check(tolerate_overflow=True)                     # counter cleared: silent
