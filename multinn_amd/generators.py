@@ -1728,8 +1728,8 @@ class RnnRBM(RnnEstimator):
         # (1/16 of the 16-bit rate) the two GEMMs were 0.53 ms per track of the 3.6 ms jamming step (round 4 profile); fp32 mode keeps f32.
         h16 = self._stack.h16
         Np = ops.round_up(N, 64 if h16 else 4)
-        def tr(xm, rows):
-            o = torch.zeros((rows, Np), device=dev, dtype=self.dtype if h16 else torch.float32)
+        def tr(xm, rows):                                # (the zero fill is for the padding columns only: four fills per track and step at C3 otherwise)
+            o = (torch.zeros if Np != N else torch.empty)((rows, Np), device=dev, dtype=self.dtype if h16 else torch.float32)
             return ops.transpose(xm, o)
         # two output tiles and K = N rows -- without split-K two workgroups walk the whole batch (6.7 ms of a 19.6 ms step at N = 32 768);
         # slices of >= 256 rows, up to one workgroup per CU
