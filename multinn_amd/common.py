@@ -152,7 +152,7 @@ class ParamStore:
 
     def state_dict(self):
         return dict(theta=self.theta.cpu(), m=self.m.cpu(), v=self.v.cpu(), step=int(self.step_dev.item()), names=self.names(),
-                    shapes=[s for _, s, _ in self._specs])
+                    shapes=[s for _, s, _ in self._specs], ls_dyn=self.ls_dyn.cpu(), ls_good=int(self.ls_good.item()))
 
     def load_state_dict(self, sd):
         if list(sd["names"]) != self.names() or [tuple(s) for s in sd["shapes"]] != [s for _, s, _ in self._specs]:
@@ -160,6 +160,9 @@ class ParamStore:
         self.theta.copy_(sd["theta"]); self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
         self.step = int(sd["step"])
         self.step_dev.fill_(self.step)
+        if "ls_dyn" in sd:                               # (checkpoints of earlier builds: the dynamic loss scale restarts at 1)
+            self.ls_dyn.copy_(sd["ls_dyn"])
+            self.ls_good.fill_(int(sd.get("ls_good", 0)))
 
 
 def glorot_uniform(gen, fan_in, fan_out):

@@ -131,3 +131,25 @@ def test_store_check_tolerates_fp16_overflow_until_the_scale_is_at_its_floor():
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         st.check(tolerate_overflow=True)                     # counter cleared: silent
+
+
+def test_store_checkpoint_carries_the_dynamic_loss_scale():
+    import torch
+    from multinn_amd.common import ParamStore
+
+    def store():
+        st = ParamStore(torch.device("cpu"))
+        st.declare("w", (2, 3), None)
+        st.materialize()
+        return st
+
+    a = store()
+    a.ls_dyn.copy_(torch.tensor([0.125, 8.0])); a.ls_good.fill_(17); a.step_dev.fill_(5)
+    sd = a.state_dict()
+    b = store()
+    b.load_state_dict(sd)
+    assert b.ls_dyn.tolist() == [0.125, 8.0] and int(b.ls_good) == 17 and int(b.step_dev) == 5
+    sd.pop("ls_dyn"); sd.pop("ls_good")                      # a checkpoint written before the dynamic scale existed
+    c = store()
+    c.load_state_dict(sd)
+    assert c.ls_dyn.tolist() == [1.0, 1.0]
