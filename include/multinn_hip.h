@@ -43,9 +43,9 @@ enum { MNN_STREAM_DROPOUT = 0, MNN_STREAM_NADE = 1, MNN_STREAM_RBM_H = 2, MNN_ST
 
 /* ABI version of THIS header: bumped whenever a signature or a descriptor struct changes.  mnn_version() returns the value the library
  * was built with; a loader must compare the two before its first call (multinn_amd/_lib.py load() does) -- a library built for another
- * version reads garbage arguments without any diagnosis otherwise.  120 (round 6): mnn_step_increment gained `ls_dyn`, `ls_good`, `grow_after` (dynamic f16 loss scale).  119 (round 6): mnn_det_dense_job gained `Wp`, + mnn_det_dense_pack / _pack_bytes.  118 (round 6): mnn_det_lstm_job gained `Wp`, + mnn_det_lstm_pack / _pack_bytes, mnn_generate_scan_workspace_bytes gained `n_in`.  117 (round 6): + mnn_lstm_cluster_bwd_ok, + mnn_ragged_index / mnn_rows_gather16 / mnn_rows_scatter_f32, `n_rows_dev` on the gated NADE forwards and mnn_nade_logprob_bwd, `inv` / `hdr` on mnn_pianoroll_shift_timemajor_t, + mnn_lstm_resident_{fwd,bwd}_multi / mnn_lstm_cluster_{fwd,bwd}_multi / _bwd_multi_ok, `unsafe` on mnn_nade_logprob_fwd_gated, `unsafe` on mnn_nade_logprob_bwd.  116: + mnn_lstm_cluster_ok / _fwd / _bwd.  115: mnn_step_increment gained `sumsq`, `clip_norm`.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
+ * version reads garbage arguments without any diagnosis otherwise.  121 (round 6): + mnn_gemm_tn_rows.  120 (round 6): mnn_step_increment gained `ls_dyn`, `ls_good`, `grow_after` (dynamic f16 loss scale).  119 (round 6): mnn_det_dense_job gained `Wp`, + mnn_det_dense_pack / _pack_bytes.  118 (round 6): mnn_det_lstm_job gained `Wp`, + mnn_det_lstm_pack / _pack_bytes, mnn_generate_scan_workspace_bytes gained `n_in`.  117 (round 6): + mnn_lstm_cluster_bwd_ok, + mnn_ragged_index / mnn_rows_gather16 / mnn_rows_scatter_f32, `n_rows_dev` on the gated NADE forwards and mnn_nade_logprob_bwd, `inv` / `hdr` on mnn_pianoroll_shift_timemajor_t, + mnn_lstm_resident_{fwd,bwd}_multi / mnn_lstm_cluster_{fwd,bwd}_multi / _bwd_multi_ok, `unsafe` on mnn_nade_logprob_fwd_gated, `unsafe` on mnn_nade_logprob_bwd.  116: + mnn_lstm_cluster_ok / _fwd / _bwd.  115: mnn_step_increment gained `sumsq`, `clip_norm`.  114: + mnn_lstm_resident_ok / _fwd / _bwd.  113: mnn_pianoroll_shift_timemajor_t gained `count`.  112: + mnn_generate_scan.  111: mnn_rbm_free_energy gained `p_h`.  110: mnn_clip_adam_step gained `skipped`; the dtype arguments of
  * mnn_pianoroll_shift_timemajor_t / mnn_grad_rows_fanout and the `f16` descriptor fields of round 3 are part of it. */
-#define MNN_ABI_VERSION 120
+#define MNN_ABI_VERSION 121
 int mnn_version(void);
 const char* mnn_last_error(void);
 
@@ -66,6 +66,12 @@ const char* mnn_last_error(void);
 /* (flag value 4, a K-major A read through transposing LDS loads, was measured net-neutral in round 3 and removed in round 4.) */
 int mnn_gemm_tn(mnn_stream_t s, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                 void* C, int ldc, int c_dtype, const float* bias, int flags, int split_k);
+/* The same product on a COMPACTED ragged batch (mnn_ragged_index: valid rows first): m_rows_dev / k_rows_dev (device words, either may be NULL)
+ * say how many rows of A (= of C) / how much of the K dimension carry data.  A hint the large-tile 16-bit kernels act on -- row tiles past
+ * the count leave without writing (their C rows are never read), the K loop stops at the count (zeros lie behind it) -- and every other kernel
+ * ignores: the result on the valid rows is the same either way. */
+int mnn_gemm_tn_rows(mnn_stream_t s, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                     void* C, int ldc, int c_dtype, const float* bias, int flags, int split_k, const int* m_rows_dev, const int* k_rows_dev);
 
 /* out[C,R] = in[R,C]^T with dtype conversion (in_dtype in {f32,bf16,f16,u8} -> out_dtype in {f32,bf16,f16});
  * used to build K-contiguous operands for weight-gradient GEMMs and transposed weight copies. */

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MULTINN_HIP_LIB", os.path.join(HERE, "libmultinn_hip.so"))   # override: A/B builds of the same ABI
 
-ABI_VERSION = 120          # == MNN_ABI_VERSION of include/multinn_hip.h; load() refuses a library built for another one
+ABI_VERSION = 121          # == MNN_ABI_VERSION of include/multinn_hip.h; load() refuses a library built for another one
 F32, BF16, U8, F16 = 0, 1, 2, 3
 GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_A_KBLOCK32 = 1, 2, 8
 
@@ -20,6 +20,7 @@ SIGNATURES = {
     "mnn_version": (_i, []),
     "mnn_last_error": (C.c_char_p, []),
     "mnn_gemm_tn": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _i]),
+    "mnn_gemm_tn_rows": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _i, _p, _p]),
     "mnn_transpose": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _i]),
     "mnn_convert2d": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i]),
     "mnn_pianoroll_shift_timemajor": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _l]),

@@ -507,7 +507,8 @@ __device__ long long gm_trace[16];
 template <typename F, bool AKB = false>
 __global__ void __launch_bounds__(512)
 gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc, int c_bf16,
-                       const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn) {
+                       const float* __restrict__ bias, int M, int N, int K, int flags, int split_k, int ntm, int ntn,
+                       const int* __restrict__ m_rows_dev, const int* __restrict__ k_rows_dev) {
     constexpr int BK = 64, CPR = 8, ROWB = 128, TILE = 256 * ROWB;
     extern __shared__ __attribute__((aligned(16))) char smem256[];        // [stage][A | B][256 rows x 128 B]
     int z, bid;
@@ -516,7 +517,10 @@ gemm_tn_glds256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __re
     const int mt = grp * 8 + (within & 7), nt = within >> 3;
     if (mt >= ntm) return;
     const int m0 = mt * 256, n0 = nt * 256;
-    const int nkt = K / BK;
+    // compacted ragged batches (mnn_gemm_tn_rows): only the first *m_rows_dev rows of A (of C) / the first *k_rows_dev of the K dimension carry
+    // data -- row tiles past the count leave (their C rows are never read), the K loop stops at the count (what lies behind it is zero)
+    if (m_rows_dev != nullptr && m0 >= *m_rows_dev) return;
+    const int nkt = k_rows_dev != nullptr ? min(K / BK, (*k_rows_dev + BK - 1) / BK) : K / BK;
     const int per = (nkt + split_k - 1) / split_k;
     const int kt0 = z * per, kt1 = min(nkt, kt0 + per);
     if (kt0 >= kt1) return;
@@ -601,7 +605,7 @@ int mnn_gemm_bres_launch(hipStream_t st, int f16, int M, int N, int K, const voi
 
 template <typename T>
 static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                       int c_bf16, const float* bias, int flags, int split_k) {
+                       int c_bf16, const float* bias, int flags, int split_k, const int* m_rows_dev = nullptr, const int* k_rows_dev = nullptr) {
     constexpr int BM = 128, BN = 128;
     const int ntm = cdiv(M, BM), ntn = cdiv(N, BN);
     const int ngrp = cdiv(ntm, 8);
@@ -625,7 +629,7 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
             }
             dim3 grid2(cdiv(ntm2, 8) * 8 * ntn2, split_k);
             hipLaunchKernelGGL((gemm_tn_glds256_kernel<F, true>), grid2, dim3(512), 4 * 256 * 128, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C,
-                               ldc, c_bf16, bias, M, N, K, flags, split_k, ntm2, ntn2);
+                               ldc, c_bf16, bias, M, N, K, flags, split_k, ntm2, ntn2, m_rows_dev, k_rows_dev);
             MNN_LAUNCH_CHECK();
             return MNN_OK;
         }
@@ -647,7 +651,7 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
             }
             dim3 grid2(cdiv(ntm2, 8) * 8 * ntn2, split_k);
             hipLaunchKernelGGL(gemm_tn_glds256_kernel<F>, grid2, dim3(512), 4 * 256 * 128, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, c_bf16,
-                               bias, M, N, K, flags, split_k, ntm2, ntn2);
+                               bias, M, N, K, flags, split_k, ntm2, ntn2, m_rows_dev, k_rows_dev);
             MNN_LAUNCH_CHECK();
             return MNN_OK;
         }
@@ -689,6 +693,11 @@ static int launch_gemm(hipStream_t st, int M, int N, int K, const void* A, int l
 
 extern "C" int mnn_gemm_tn(mnn_stream_t s, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                            int ldc, int c_dtype, const float* bias, int flags, int split_k) {
+    return mnn_gemm_tn_rows(s, dtype, M, N, K, A, lda, B, ldb, C, ldc, c_dtype, bias, flags, split_k, nullptr, nullptr);
+}
+
+extern "C" int mnn_gemm_tn_rows(mnn_stream_t s, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                                int ldc, int c_dtype, const float* bias, int flags, int split_k, const int* m_rows_dev, const int* k_rows_dev) {
     hipStream_t st = (hipStream_t)s;
     MNN_REQUIRE(dtype == MNN_BF16 || dtype == MNN_F16 || dtype == MNN_F32, "mnn_gemm_tn: dtype must be bf16, f16 or f32 (got %d)", dtype);
     MNN_REQUIRE(c_dtype == MNN_F32 || c_dtype == MNN_BF16 || c_dtype == MNN_F16, "mnn_gemm_tn: c_dtype must be f32, bf16 or f16");
@@ -718,9 +727,9 @@ extern "C" int mnn_gemm_tn(mnn_stream_t s, int dtype, int M, int N, int K, const
     }
     MNN_REQUIRE(!(c_dtype != MNN_F32 && (flags & (MNN_GEMM_ACCUMULATE | MNN_GEMM_ATOMIC))), "mnn_gemm_tn: a 16-bit C cannot accumulate");
     const int c16 = c_dtype == MNN_F32 ? 0 : c_dtype;      // 0: f32 C; else the mnn_dtype code of the 16-bit C
-    if (dtype == MNN_BF16) return launch_gemm<bf16_t>(st, M, N, K, A, lda, B, ldb, C, ldc, c16, bias, flags, split_k);
-    if (dtype == MNN_F16) return launch_gemm<f16_t>(st, M, N, K, A, lda, B, ldb, C, ldc, c16, bias, flags, split_k);
-    return launch_gemm<float>(st, M, N, K, A, lda, B, ldb, C, ldc, c16, bias, flags, split_k);
+    if (dtype == MNN_BF16) return launch_gemm<bf16_t>(st, M, N, K, A, lda, B, ldb, C, ldc, c16, bias, flags, split_k, m_rows_dev, k_rows_dev);
+    if (dtype == MNN_F16) return launch_gemm<f16_t>(st, M, N, K, A, lda, B, ldb, C, ldc, c16, bias, flags, split_k, m_rows_dev, k_rows_dev);
+    return launch_gemm<float>(st, M, N, K, A, lda, B, ldb, C, ldc, c16, bias, flags, split_k);      // (the f32 kernels do not look at the row counts: a hint only)
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -1152,6 +1152,7 @@ class RnnNade(RnnEstimator):
 
     # MULTINN_RAGGED_COMPACT=0: ragged windows keep their padding rows in the Dense + NADE part (weight 0), as before round 6
     ragged_compact = os.environ.get("MULTINN_RAGGED_COMPACT", "1") != "0"
+    ragged_gemm_rows = os.environ.get("MULTINN_RAGGED_GEMM_ROWS", "1") != "0"     # the Dense GEMMs of a compacted window skip their padding too (ops.gemm_tn m_rows / k_rows)
 
     def build_pianoroll(self, x_u8, lengths=None, is_train=True, mode="train", n_total_dev=None):
         """Fast joint path: x_u8 [B,T,P,M] piano-roll batch; fuses multinn_joint.py:83-89,132-139
@@ -1237,7 +1238,7 @@ class RnnNade(RnnEstimator):
         else:
             y_dense = y.view(N, -1)
         out = torch.empty((N, self.ldo), device=dev)      # columns >= n_out are padding of the row pitch: never read
-        ops.gemm_tn(y_dense, self._fc_t, out[:, :self.n_out], bias=self._fc_bias)
+        ops.gemm_tn(y_dense, self._fc_t, out[:, :self.n_out], bias=self._fc_bias, m_rows=nrows if self.ragged_gemm_rows else None)      # (compact: row tiles of padding are skipped)
         nll = torch.empty((M, N), device=dev)
         cond_p = None if train else torch.empty((M, N, D), device=dev)     # the train step needs the loss only: 4 N D bytes less to write per
         rw_m = rw / M if M > 1 else rw                                       # step; `cond_probs` fills it on demand (see the property)
@@ -1368,10 +1369,11 @@ class RnnNade(RnnEstimator):
         if self.internal_bias:              # d b_enc / d b_dec = the Dense bias gradient (same column sums of d_out)
             gi = self._internal_flat(self.store.grad)
             ops.axpby(1.0, gi, 1.0, g["dense/bias"], gi)
-        ops.gemm_tn(yT, doT, g["dense/kernel"], accumulate=True, split_k=LstmStack._split_k(R, self.n_out, Np))
+        nrows = compact["hdr"] if (compact is not None and self.ragged_gemm_rows) else None      # compact: the row sums stop at the valid rows, padding row tiles are skipped
+        ops.gemm_tn(yT, doT, g["dense/kernel"], accumulate=True, split_k=LstmStack._split_k(R, self.n_out, Np), k_rows=nrows)
         del yT, doT
         dy = torch.empty((N, R), device=dev)
-        ops.gemm_tn(do_c, self._fc_p, dy)
+        ops.gemm_tn(do_c, self._fc_p, dy, m_rows=nrows)
         if compact is not None:                                     # back into time-major order for the LSTM backward (padding rows: 0)
             dy_c, dy = dy, torch.empty((N, R), device=dev)
             ops.rows_scatter_f32(dy_c, compact["inv"], compact["hdr"], dy)

@@ -52,9 +52,11 @@ def round_up(x, m):
 
 
 # ------------------------------------------------------------------------------------------------
-def gemm_tn(A, B, C_out, bias=None, accumulate=False, split_k=1, a_kblock=False):
+def gemm_tn(A, B, C_out, bias=None, accumulate=False, split_k=1, a_kblock=False, m_rows=None, k_rows=None):
     """C[M,N] (+)= A[M,K] . B[N,K]^T (+bias).  A,B same dtype (f32/bf16/f16), K-contiguous views.  a_kblock: A is
-    given K-blocked, a contiguous [K/32, rows >= M, 32] tensor (element (m, k) at [k // 32, m, k % 32]), 16-bit, K % 64 == 0."""
+    given K-blocked, a contiguous [K/32, rows >= M, 32] tensor (element (m, k) at [k // 32, m, k % 32]), 16-bit, K % 64 == 0.
+    m_rows / k_rows (int32 device words, compacted ragged batches): how many rows of A / how much of K carry data -- a hint the large-tile
+    kernels use to skip the padding (mnn_gemm_tn_rows); rows of C past m_rows are then left unwritten."""
     _rowmajor(B, "gemm B"); _rowmajor(C_out, "gemm C")
     _req(A.dtype == B.dtype and A.dtype in (torch.float32,) + H16, "gemm: A/B must both be f32, bf16 or f16")
     if a_kblock:
@@ -71,6 +73,12 @@ def gemm_tn(A, B, C_out, bias=None, accumulate=False, split_k=1, a_kblock=False)
     if bias is not None:
         _req(bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous(), "gemm: bias must be f32[N]")
     flags = (GEMM_ACCUMULATE if accumulate else 0) | (GEMM_A_KBLOCK32 if a_kblock else 0)
+    if m_rows is not None or k_rows is not None:
+        for t in (m_rows, k_rows):
+            _req(t is None or (t.dtype == torch.int32 and t.numel() >= 1 and t.is_cuda), "gemm: m_rows / k_rows are int32 device words")
+        call("mnn_gemm_tn_rows", _stream(), dtype_code(A), M, N, K, _ptr(A), lda, _ptr(B), B.stride(0), _ptr(C_out), C_out.stride(0),
+             dtype_code(C_out), _ptr(bias), flags, split_k, _ptr(m_rows), _ptr(k_rows))
+        return C_out
     call("mnn_gemm_tn", _stream(), dtype_code(A), M, N, K, _ptr(A), lda, _ptr(B), B.stride(0), _ptr(C_out), C_out.stride(0),
          dtype_code(C_out), _ptr(bias), flags, split_k)
     return C_out
