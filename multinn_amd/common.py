@@ -9,6 +9,8 @@ its gradient and Adam slots; that flat gradient buffer is also the data-parallel
 buffer.
 """
 import abc
+import contextlib
+import gc
 import math
 import os
 
@@ -27,6 +29,22 @@ def default_device():
 
 
 # --------------------------------------------------------------------------------------------
+@contextlib.contextmanager
+def graph_capture(g, **kw):
+    """`with torch.cuda.graph(g, **kw)` with the cyclic garbage collector switched off for the duration of the capture.  torch collects once
+    when the capture begins; a collection that starts DURING it runs finalisers of whatever cyclic garbage the captured Python code has left
+    behind (dead generators with their own graphs, streams, pools) in the middle of the capture -- one full GPU test run of round 6 died that
+    way ("Fatal Python error: Aborted", "Garbage-collecting", inside a captured sampling scan).  Reference-counted frees are unaffected."""
+    with torch.cuda.graph(g, **kw):
+        was = gc.isenabled()
+        gc.disable()
+        try:
+            yield
+        finally:
+            if was:
+                gc.enable()
+
+
 class ScanGraphs:
     """hipGraph cache for whole sampling scans (rnn_estimator.py:271-323, multinn_feedback.py:120-218).
 
@@ -58,7 +76,7 @@ class ScanGraphs:
                 warm(static_x)
             cur.wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with graph_capture(g, capture_error_mode="thread_local"):
                 out = scan(static_x)
             after_capture()
             ent = (g, static_x, out)

@@ -1,6 +1,8 @@
 """Feedback-RNN sampling scan: multinn_feedback.py:120-218 with the recurrent feedback
 module of multinn_feedback_rnn.py:41-79.  Composition of the per-track RnnNade generators and one more
 LSTM stack, all running through the same C-ABI kernels."""
+import weakref
+
 import torch
 
 from . import ops
@@ -19,7 +21,7 @@ class FeedbackRnn(Model):
         self._rnn.declare(self.store, num_inputs, torch.Generator().manual_seed(seed), prefix="feedback/rnn")
         self.store.materialize()
         self._stack = LstmStack(self._rnn, self.store, self.dtype)
-        self._stack.owner = self                         # (its pack epoch dates the stack's repacked sampling weights: LstmStack.det_job)
+        self._stack.owner = weakref.ref(self)            # (its pack epoch dates the stack's repacked sampling weights: LstmStack.det_job; weak: no cycle)
         self._rnn.build_cell(False)
         self.num_inputs, self.num_units = num_inputs, list(self._rnn.num_units)
         self.seed, self.row0, self._ctx = seed, 0, None

@@ -14,10 +14,12 @@ import collections
 import math
 import os
 
+import weakref
+
 import torch
 
 from . import ops
-from .common import Model, RNN, NADE, RBM, ParamStore, ScanGraphs, glorot_uniform, zeros_init, default_device
+from .common import Model, RNN, NADE, RBM, ParamStore, ScanGraphs, glorot_uniform, zeros_init, default_device, graph_capture
 from .training import compute_gradients, world, dp_active, AdamOptimizer
 
 _RnnEstimatorStateTuple = collections.namedtuple("RnnEstimatorStateTuple", ("b_enc", "b_dec", "rnn_state"))
@@ -671,7 +673,7 @@ class LstmStack:
         return y[0], [(c, h) for c, h in final]
 
     # -- deterministic f32 single steps (csrc/det_step.hip): the arithmetic of every sampling scan -----------------------------------
-    owner = None          # the estimator this stack belongs to (its pack epoch dates the repacked weights below)
+    owner = None          # weakref to the estimator this stack belongs to (its pack epoch dates the repacked weights below)
     _det_pack, _det_pack_key = None, None
 
     def det_job(self, l, x, n_x, x2, st):
@@ -683,7 +685,7 @@ class LstmStack:
         c = torch.empty((ref.shape[0], u), device=ref.device)
         h = torch.empty_like(c)
         pre = self.rnn.prefix
-        key = (self.store.step, getattr(self.owner, "_pack_epoch", 0))
+        key = (self.store.step, getattr(self.owner() if self.owner is not None else None, "_pack_epoch", 0))
         if self._det_pack is None or self._det_pack_key != key:
             self._det_pack = [ops.det_lstm_pack(self.store[f"{pre}/cell_{k}/kernel"], self.rnn.num_units[k]) for k in range(len(self.rnn.num_units))]
             self._det_pack_key = key
@@ -810,7 +812,8 @@ class RnnEstimator(Generator):
         self._declare(self._num_inputs)
         self.store.materialize()
         self._stack = LstmStack(self._rnn, self.store, self.dtype)
-        self._stack.owner = self
+        self._stack.owner = weakref.ref(self)            # (weak: a cycle would leave dead generators -- and their captured graphs -- to the garbage
+                                                         #  collector, which may then run in the middle of another capture and abort the process)
         self._trainable_variables = [self.store[n] for n in self.store.names()]
         self._variables = dict(self.store.views)
 
@@ -928,7 +931,7 @@ class RnnEstimator(Generator):
         cur.wait_stream(side)
         multi = dp_active()
         g_fb, g_opt = torch.cuda.CUDAGraph(), None
-        with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
+        with graph_capture(g_fb, capture_error_mode="thread_local"):
             self.build(sx, sy, None, True, "train")
             if multi:
                 self.backward()
@@ -937,7 +940,7 @@ class RnnEstimator(Generator):
             loss = self._loss
         if multi:
             g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_opt, pool=g_fb.pool(), capture_error_mode="thread_local"):
+            with graph_capture(g_opt, pool=g_fb.pool(), capture_error_mode="thread_local"):
                 self._grad_sumsq = compute_gradients(optimizer, self.store, self.clip_norm, lr, reduce=False)
         self._packed_step = -1
         self.store.step -= 1            # the captured step has not executed (host mirror of store.step_dev)
@@ -1427,18 +1430,18 @@ class RnnNade(RnnEstimator):
         self._packed_step = -1          # the captured step packs the weights itself, whatever ran before (warmup = 0: a caller's own steps)
         g_fb, g_opt = torch.cuda.CUDAGraph(), None
         if not multi:
-            with torch.cuda.graph(g_fb):
+            with graph_capture(g_fb):
                 self.build_pianoroll(static_x, static_len, is_train=True, mode="train")
                 self.train(optimizer, lr)
                 loss = self._loss
         else:
             # thread_local: the process group's watchdog thread may touch the runtime while this thread captures
-            with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
+            with graph_capture(g_fb, capture_error_mode="thread_local"):
                 self.build_pianoroll(static_x, static_len, is_train=True, mode="train", n_total_dev=static_ntot)
                 self.backward()
                 loss = self._loss
             g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_opt, pool=g_fb.pool(), capture_error_mode="thread_local"):
+            with graph_capture(g_opt, pool=g_fb.pool(), capture_error_mode="thread_local"):
                 self._grad_sumsq = compute_gradients(optimizer, self.store, self.clip_norm, lr, reduce=False)
             self._packed_step = -1
         self.store.step -= 1            # the captured step has not executed (host mirror of store.step_dev)

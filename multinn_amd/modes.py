@@ -23,7 +23,7 @@ import os
 
 import torch
 
-from .common import Model
+from .common import Model, graph_capture
 from .encoders import PassEncoder, DBNEncoder
 from .generators import RnnNade, RnnRBM, RnnMultiNADE
 from . import ops
@@ -435,7 +435,7 @@ class MultINNCore(Model):
         for g in self._generators:
             g._packed_step = -1
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with graph_capture(graph):
             loss = self.train_step(sx, sl, optimizer, lr)
         stores = self._all_stores()
         for st in stores:
